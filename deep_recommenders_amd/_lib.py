@@ -1,0 +1,81 @@
+"""ctypes binding of the C-ABI hot-path library (include/dr_hotpath.h).
+
+There is NO fallback: if libdr_hotpath.so is missing or a tensor is not on a HIP device the call
+raises.  PyTorch is used only for device memory and streams; every computation on the product path
+happens inside the hand-written gfx950 kernels behind this boundary.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "lib", "libdr_hotpath.so")
+
+_i64, _i32, _u64, _f32, _p = ctypes.c_int64, ctypes.c_int32, ctypes.c_uint64, ctypes.c_float, ctypes.c_void_p
+
+# name -> argtypes (all return int unless listed in _RESTYPE)
+SIGNATURES = {
+    "dr_hash_bucket_i64": [_p, _i64, _i32, _p, _p, _p],
+    "dr_hash_bucket_bytes": [_p, _p, _i64, _u64, _p, _p],
+    "dr_vocab_lookup_i64": [_p, _i64, _p, _i32, _p, _p],
+    "dr_vocab_lookup_bytes": [_p, _p, _i64, _p, _p, _i32, _p, _p],
+    "dr_emb_pool_fwd": [_p, _i64, _i32, _i32, _p, _p, _p, _i32, _p, _f32, _p, _i64, _p, _p, _p],
+    "dr_emb_pool_bwd": [_p, _i64, _i32, _i32, _p, _p, _i32, _p, _i64, _p, _i64, _p, _p, _f32, _p, _p, _p],
+    "dr_fm2_fwd": [_p, _i64, _i32, _i32, _p, _p],
+    "dr_fm2_bwd": [_p, _p, _i64, _i32, _i32, _p, _p],
+    "dr_linear_fwd": [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p],
+    "dr_linear_bwd_dx": [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _i64, _i32, _p, _i64, _p],
+    "dr_linear_bwd_dw": [_p, _i64, _p, _i64, _i64, _i32, _i32, _f32, _p, _i64, _p, _p],
+    "dr_cross_fwd": [_p, _p, _i64, _p, _i64, _p, _f32, _i64, _i32, _p, _p, _p],
+    "dr_cross_combine_bwd": [_p, _p, _p, _i64, _i32, _i64, _f32, _p, _p, _p, _p],
+    "dr_bce_fwd_bwd": [_p, _p, _i64, _i32, _p, _p, _p, _p, _p],
+    "dr_version": [],
+}
+_RESTYPE = {"dr_version": ctypes.c_char_p}
+
+DR_OK, DR_EINVAL, DR_ELAUNCH, DR_ESHAPE = 0, -1, -2, -3
+_ERR = {DR_EINVAL: "DR_EINVAL (bad argument)", DR_ELAUNCH: "DR_ELAUNCH (HIP launch error)",
+        DR_ESHAPE: "DR_ESHAPE (shape contract violated)"}
+
+_LIB = None
+
+
+class HotPathLibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """Returns the loaded library; raises (never falls back) when it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(SO_PATH):
+            raise HotPathLibraryMissing(
+                "HIP hot-path library not built: %s is missing. Build it with "
+                "`python -m deep_recommenders_amd.build` (or __graft_entry__.build()). "
+                "There is no CPU/PyTorch fallback." % SO_PATH)
+        L = ctypes.CDLL(SO_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(L, name)   # AttributeError if the .so does not export a declared symbol
+            fn.argtypes = args
+            fn.restype = _RESTYPE.get(name, ctypes.c_int)
+        _LIB = L
+    return _LIB
+
+
+def check(status, what):
+    if status != DR_OK:
+        raise RuntimeError("%s failed: %s" % (what, _ERR.get(status, status)))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("hot-path kernels need tensors in HBM (got a %s tensor); there is no CPU fallback"
+                           % t.device)
+    return t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

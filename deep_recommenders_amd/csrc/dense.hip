@@ -1,0 +1,361 @@
+// K7 / K8 — fp32 GEMMs on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact-f32 products, the
+// reference's parity bar is 1e-5 relative on the loss so no reduced-precision path) with the layer's
+// elementwise tail fused into the epilogue:
+//   fwd     y   = act(x @ W + b)                       (Dense: keras deepfm.py:30-34, estimator dnn.py:17-29)
+//   cross   out = x0 * (x @ W + b + diag*x) + x        (Cross.call: keras dcn.py:81-88)
+//   bwd_dx  dx  = (dy @ W^T) * (relu_src > 0) [+ dx]   (autodiff of the above)
+//   bwd_dw  dst += scale * x^T @ dy, dstb += scale*colsum(dy)   (split over the batch, fp32 atomics)
+//
+// One kernel template.  C[i][j] = sum_r A(i,r) * B(r,j), block tile 128 x 128 x 32, 4 waves in a
+// 2 x 2 arrangement, each wave owns 64 x 64 = 2 x 2 MFMA tiles of 32 x 32 (64 accumulator registers).
+// Operands are staged HBM -> registers -> LDS with the next tile's global loads issued before the
+// current tile's MFMAs (register double buffering).  The LDS image is always [r][i] (reduction-major):
+//   - an operand whose memory layout is reduction-contiguous (a[i*ld + r], "RC": x in fwd, dy and W
+//     in bwd_dx) is transposed on the way in: float4 global loads along r, four ds_write_b32 with row
+//     pitch 129 floats (129 % 32 == 1 makes the 4 x 8 (i, r4) lanes of a write group hit 32 banks);
+//   - an operand already reduction-major (a[r*ld + i]: W in fwd, x and dy in bwd_dw) goes in with
+//     ds_write_b128 at pitch 132 floats.
+// Fragment reads are ds_read_b32 of 32 consecutive floats per half-wave: conflict-free in both cases.
+// Consecutive workgroup ids are remapped so that the tiles sharing an A row-panel run on the same XCD
+// (same L2): dispatch places block b on XCD b % 8.
+#include "dr_common.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LD_T = 129;   // pitch of a transposed-in operand tile
+constexpr int LD_D = 132;   // pitch of a direct operand tile
+
+enum Epi { EPI_BIAS_ACT = 0, EPI_CROSS = 1, EPI_MASK = 2, EPI_ATOMIC = 3 };
+
+struct GemmArgs {
+    const float* A; int64_t lda;
+    const float* B; int64_t ldb;
+    int64_t M;      // rows of C (i)
+    int32_t N;      // cols of C (j)
+    int64_t R;      // reduction length
+    float* C; int64_t ldc;
+    // epilogue operands
+    const float* bias;        // [N]            (BIAS_ACT, CROSS)
+    int32_t act;              // 0 / 1          (BIAS_ACT)
+    const float* e0; int64_t lde0;   // CROSS: x0 ; MASK: relu_src
+    const float* e1; int64_t lde1;   // CROSS: x
+    float* aux; int64_t ldaux;       // CROSS: prod_out (may be null)
+    float alpha;              // CROSS: diag_scale ; ATOMIC: scale
+    int32_t accumulate;       // MASK: add to existing C
+    float* colsum_dst;        // ATOMIC: dstb (may be null)
+    int32_t split;            // ATOMIC: number of reduction splits (gridDim.y)
+};
+
+// bijective XCD-aware remap (cdna guide T1): consecutive logical tile ids -> same XCD
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg / 8, r = nwg % 8;
+    const int xcd = bid % 8, idx = bid / 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// load a float4 of an operand tile with edge guards.  RC layout: element (i, r) at p[i*ld + r], vector
+// runs along r; non-RC: element (r, i) at p[r*ld + i], vector runs along i.
+__device__ __forceinline__ float4 guarded_ld4(const float* __restrict__ p, int64_t ld, int64_t row, int64_t nrows,
+                                              int64_t col, int64_t ncols) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < nrows) {
+        const float* q = p + row * ld + col;
+        if (col + 3 < ncols) {
+            v = *reinterpret_cast<const float4*>(q);
+        } else {
+            if (col < ncols) v.x = q[0];
+            if (col + 1 < ncols) v.y = q[1];
+            if (col + 2 < ncols) v.z = q[2];
+        }
+    }
+    return v;
+}
+
+template <bool A_RC, bool B_RC, int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
+    constexpr int LDA = A_RC ? LD_T : LD_D;
+    constexpr int LDB = B_RC ? LD_T : LD_D;
+    __shared__ __attribute__((aligned(16))) float smem[BK * LDA + BK * LDB];
+    float* As = smem;
+    float* Bs = smem + BK * LDA;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int tiles_m = (int)((g.M + BM - 1) / BM);
+    const int nwg = tiles_m * tiles_n;
+    const int lid = xcd_remap(blockIdx.x, nwg);
+    const int64_t m0 = (int64_t)(lid / tiles_n) * BM;
+    const int n0 = (lid % tiles_n) * BN;
+
+    // reduction range of this block (split-K only for EPI_ATOMIC)
+    int64_t r_begin = 0, r_end = g.R;
+    if (EPI == EPI_ATOMIC) {
+        const int64_t per = ((g.R + g.split - 1) / g.split + BK - 1) / BK * BK;
+        r_begin = (int64_t)blockIdx.y * per;
+        r_end = r_begin + per < g.R ? r_begin + per : g.R;
+        if (r_begin >= r_end) return;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[a][b][k] = 0.f;
+
+    float4 ra[4], rb[4];
+    auto load_tiles = [&](int64_t r0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + 256 * q;
+            if (A_RC) {   // 128 rows(i) x 8 float4 along r
+                const int i = idx >> 3, r4 = idx & 7;
+                ra[q] = guarded_ld4(g.A, g.lda, m0 + i, g.M, r0 + r4 * 4, r_end);
+            } else {      // 32 rows(r) x 32 float4 along i
+                const int r = idx >> 5, c4 = idx & 31;
+                ra[q] = guarded_ld4(g.A, g.lda, r0 + r, r_end, m0 + c4 * 4, g.M);
+            }
+            if (B_RC) {
+                const int j = idx >> 3, r4 = idx & 7;
+                rb[q] = guarded_ld4(g.B, g.ldb, (int64_t)n0 + j, g.N, r0 + r4 * 4, r_end);
+            } else {
+                const int r = idx >> 5, c4 = idx & 31;
+                rb[q] = guarded_ld4(g.B, g.ldb, r0 + r, r_end, (int64_t)n0 + c4 * 4, g.N);
+            }
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + 256 * q;
+            if (A_RC) {
+                const int i = idx >> 3, r4 = idx & 7;
+                As[(r4 * 4 + 0) * LDA + i] = ra[q].x;
+                As[(r4 * 4 + 1) * LDA + i] = ra[q].y;
+                As[(r4 * 4 + 2) * LDA + i] = ra[q].z;
+                As[(r4 * 4 + 3) * LDA + i] = ra[q].w;
+            } else {
+                const int r = idx >> 5, c4 = idx & 31;
+                *reinterpret_cast<float4*>(&As[r * LDA + c4 * 4]) = ra[q];
+            }
+            if (B_RC) {
+                const int j = idx >> 3, r4 = idx & 7;
+                Bs[(r4 * 4 + 0) * LDB + j] = rb[q].x;
+                Bs[(r4 * 4 + 1) * LDB + j] = rb[q].y;
+                Bs[(r4 * 4 + 2) * LDB + j] = rb[q].z;
+                Bs[(r4 * 4 + 3) * LDB + j] = rb[q].w;
+            } else {
+                const int r = idx >> 5, c4 = idx & 31;
+                *reinterpret_cast<float4*>(&Bs[r * LDB + c4 * 4]) = rb[q];
+            }
+        }
+    };
+
+    float colsum = 0.f;   // EPI_ATOMIC: column sums of B (dy) accumulated by the m-tile-0 blocks
+    const bool do_colsum = (EPI == EPI_ATOMIC) && g.colsum_dst != nullptr && m0 == 0 && tid < BN;
+
+    load_tiles(r_begin);
+    const int a_off = wm * 64 + (lane & 31);
+    const int b_off = wn * 64 + (lane & 31);
+    const int khalf = lane >> 5;
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += BK) {
+        store_tiles();
+        __syncthreads();
+        if (r0 + BK < r_end) load_tiles(r0 + BK);
+        if (do_colsum) {
+#pragma unroll 8
+            for (int r = 0; r < BK; ++r) colsum += Bs[r * LDB + tid];
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a0 = As[(kk + khalf) * LDA + a_off];
+            const float a1 = As[(kk + khalf) * LDA + a_off + 32];
+            const float b0 = Bs[(kk + khalf) * LDB + b_off];
+            const float b1 = Bs[(kk + khalf) * LDB + b_off + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int col = n0 + wn * 64 + ni * 32 + (lane & 31);
+            if (col >= g.N) continue;
+            float bj = 0.f;
+            if ((EPI == EPI_BIAS_ACT || EPI == EPI_CROSS) && g.bias != nullptr) bj = g.bias[col];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int64_t row = m0 + wm * 64 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                if (row >= g.M) continue;
+                float v = acc[mi][ni][reg];
+                if (EPI == EPI_BIAS_ACT) {
+                    v += bj;
+                    if (g.act == 1) v = fmaxf(v, 0.f);
+                    g.C[row * g.ldc + col] = v;
+                } else if (EPI == EPI_CROSS) {
+                    const float xv = g.e1[row * g.lde1 + col];
+                    const float prod = v + bj + g.alpha * xv;
+                    if (g.aux != nullptr) g.aux[row * g.ldaux + col] = prod;
+                    g.C[row * g.ldc + col] = g.e0[row * g.lde0 + col] * prod + xv;
+                } else if (EPI == EPI_MASK) {
+                    if (g.e0 != nullptr && !(g.e0[row * g.lde0 + col] > 0.f)) v = 0.f;
+                    if (g.accumulate) v += g.C[row * g.ldc + col];
+                    g.C[row * g.ldc + col] = v;
+                } else {
+                    unsafeAtomicAdd(g.C + row * g.ldc + col, g.alpha * v);
+                }
+            }
+        }
+    }
+    if (do_colsum && n0 + tid < g.N) unsafeAtomicAdd(g.colsum_dst + n0 + tid, g.alpha * colsum);
+}
+
+template <bool A_RC, bool B_RC, int EPI>
+int launch(const GemmArgs& g, hipStream_t s) {
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int64_t tiles_m = (g.M + BM - 1) / BM;
+    if (tiles_m * tiles_n > 0x7fffffff) return DR_EINVAL;
+    dim3 grid((unsigned)(tiles_m * tiles_n), EPI == EPI_ATOMIC ? g.split : 1);
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_RC, B_RC, EPI>), grid, dim3(256), 0, s, g);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+__global__ __launch_bounds__(256) void cross_combine_fwd_kernel(const float* __restrict__ x0,
+                                                                const float* __restrict__ x,
+                                                                float* __restrict__ prod, const float* __restrict__ b,
+                                                                int64_t M, int32_t Dm, int64_t ld, float diag,
+                                                                float* __restrict__ out) {
+    const int64_t n = M * Dm;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t r = i / Dm;
+        const int c = (int)(i - r * Dm);
+        const int64_t o = r * ld + c;
+        const float xv = x[o];
+        const float p = prod[o] + (b != nullptr ? b[c] : 0.f) + diag * xv;
+        prod[o] = p;
+        out[o] = x0[o] * p + xv;
+    }
+}
+
+__global__ __launch_bounds__(256) void cross_combine_bwd_kernel(const float* __restrict__ x0,
+                                                                const float* __restrict__ prod,
+                                                                const float* __restrict__ d_out, int64_t M, int32_t Dm,
+                                                                int64_t ld, float diag, float* __restrict__ d_prod,
+                                                                float* __restrict__ d_x0, float* __restrict__ d_x) {
+    const int64_t n = M * Dm;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t r = i / Dm;
+        const int c = (int)(i - r * Dm);
+        const int64_t o = r * ld + c;
+        const float go = d_out[o];
+        const float dp = go * x0[o];
+        d_prod[o] = dp;
+        if (d_x0 != nullptr) d_x0[o] += go * prod[o];
+        if (d_x != nullptr) d_x[o] += go + diag * dp;
+    }
+}
+
+bool bad_ld(int64_t ld, int64_t min) { return ld < min || (ld & 3); }
+bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
+
+}  // namespace
+
+extern "C" int dr_linear_fwd(const float* x, int64_t ld_x, const float* W, int64_t ld_w, const float* b, int64_t M,
+                             int32_t K, int32_t N, int32_t act, float* y, int64_t ld_y, dr_stream_t stream) {
+    if (M < 0 || K <= 0 || N <= 0 || act < 0 || act > 1) return DR_EINVAL;
+    if (M == 0) return DR_OK;
+    if (!x || !W || !y || bad_ld(ld_x, K) || bad_ld(ld_w, N) || ld_y < N || misaligned(x) || misaligned(W))
+        return DR_EINVAL;
+    GemmArgs g{};
+    g.A = x; g.lda = ld_x; g.B = W; g.ldb = ld_w; g.M = M; g.N = N; g.R = K; g.C = y; g.ldc = ld_y;
+    g.bias = b; g.act = act; g.split = 1;
+    return launch<true, false, EPI_BIAS_ACT>(g, dr_s(stream));
+}
+
+extern "C" int dr_linear_bwd_dx(const float* dy, int64_t ld_dy, const float* W, int64_t ld_w, int64_t M, int32_t K,
+                                int32_t N, const float* relu_src, int64_t ld_relu_src, int32_t accumulate, float* dx,
+                                int64_t ld_dx, dr_stream_t stream) {
+    if (M < 0 || K <= 0 || N <= 0) return DR_EINVAL;
+    if (M == 0) return DR_OK;
+    if (!dy || !W || !dx || bad_ld(ld_dy, N) || bad_ld(ld_w, N) || ld_dx < K || misaligned(dy) || misaligned(W))
+        return DR_EINVAL;
+    if (relu_src != nullptr && ld_relu_src < K) return DR_EINVAL;
+    // dx[i=m][j=k] = sum_{r=n} dy[m][n] * W[k][n]  -> A = dy (RC), B(r=n, j=k) = W[k*ld_w + n] (RC)
+    GemmArgs g{};
+    g.A = dy; g.lda = ld_dy; g.B = W; g.ldb = ld_w; g.M = M; g.N = K; g.R = N; g.C = dx; g.ldc = ld_dx;
+    g.e0 = relu_src; g.lde0 = ld_relu_src; g.accumulate = accumulate; g.split = 1;
+    return launch<true, true, EPI_MASK>(g, dr_s(stream));
+}
+
+extern "C" int dr_linear_bwd_dw(const float* x, int64_t ld_x, const float* dy, int64_t ld_dy, int64_t M, int32_t K,
+                                int32_t N, float scale, float* dstW, int64_t ld_w, float* dstb, dr_stream_t stream) {
+    if (M < 0 || K <= 0 || N <= 0) return DR_EINVAL;
+    if (M == 0) return DR_OK;
+    if (!x || !dy || !dstW || bad_ld(ld_x, K) || bad_ld(ld_dy, N) || ld_w < N || misaligned(x) || misaligned(dy))
+        return DR_EINVAL;
+    // dW[i=k][j=n] = sum_{r=m} x[m][k] * dy[m][n] -> A(i=k, r=m) = x[m*ld_x + k] (not RC), B = dy (not RC)
+    GemmArgs g{};
+    g.A = x; g.lda = ld_x; g.B = dy; g.ldb = ld_dy; g.M = K; g.N = N; g.R = M; g.C = dstW; g.ldc = ld_w;
+    g.alpha = scale; g.colsum_dst = dstb;
+    const int64_t tiles = ((int64_t)(K + BM - 1) / BM) * ((N + BN - 1) / BN);
+    int64_t split = (1024 + tiles - 1) / tiles;            // aim at ~4 blocks per CU
+    const int64_t max_split = (M + 4 * BK - 1) / (4 * BK);   // at least 4 k-tiles per block
+    if (split > max_split) split = max_split;
+    if (split < 1) split = 1;
+    if (split > 65535) split = 65535;
+    g.split = (int32_t)split;
+    return launch<false, false, EPI_ATOMIC>(g, dr_s(stream));
+}
+
+extern "C" int dr_cross_fwd(const float* x0, const float* x, int64_t ld, const float* W, int64_t ld_w, const float* b,
+                            float diag_scale, int64_t M, int32_t Dm, float* out, float* prod_out,
+                            dr_stream_t stream) {
+    if (M < 0 || Dm <= 0 || diag_scale < 0.f) return DR_EINVAL;
+    if (M == 0) return DR_OK;
+    if (!x0 || !x || !out || bad_ld(ld, Dm)) return DR_EINVAL;
+    if (W == nullptr) {
+        if (prod_out == nullptr) return DR_EINVAL;
+        hipLaunchKernelGGL(cross_combine_fwd_kernel, dim3(dr_grid_for(M * Dm, 256)), dim3(256), 0, dr_s(stream), x0, x,
+                           prod_out, b, M, Dm, ld, diag_scale, out);
+        DR_CHECK_LAUNCH();
+        return DR_OK;
+    }
+    if (bad_ld(ld_w, Dm) || misaligned(x) || misaligned(W)) return DR_EINVAL;
+    GemmArgs g{};
+    g.A = x; g.lda = ld; g.B = W; g.ldb = ld_w; g.M = M; g.N = Dm; g.R = Dm; g.C = out; g.ldc = ld;
+    g.bias = b; g.e0 = x0; g.lde0 = ld; g.e1 = x; g.lde1 = ld; g.aux = prod_out; g.ldaux = ld;
+    g.alpha = diag_scale; g.split = 1;
+    return launch<true, false, EPI_CROSS>(g, dr_s(stream));
+}
+
+extern "C" int dr_cross_combine_bwd(const float* x0, const float* prod, const float* d_out, int64_t M, int32_t Dm,
+                                    int64_t ld, float diag_scale, float* d_prod, float* d_x0_accum, float* d_x_accum,
+                                    dr_stream_t stream) {
+    if (M < 0 || Dm <= 0) return DR_EINVAL;
+    if (M == 0) return DR_OK;
+    if (!x0 || !prod || !d_out || !d_prod || ld < Dm) return DR_EINVAL;
+    hipLaunchKernelGGL(cross_combine_bwd_kernel, dim3(dr_grid_for(M * Dm, 256)), dim3(256), 0, dr_s(stream), x0, prod,
+                       d_out, M, Dm, ld, diag_scale, d_prod, d_x0_accum, d_x_accum);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+extern "C" const char* dr_version(void) { return "deep_recommenders_amd hot path / gfx950 / f32"; }

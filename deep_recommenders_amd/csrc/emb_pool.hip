@@ -1,0 +1,315 @@
+// K3 / K4 — fused embedding gather + segment-mean pool (+ first-order + FM second-order) forward and
+// its transposed scatter-add backward, for gfx950.  Both are HBM-bound (random 4*D-byte row reads /
+// read-modify-writes against a table slab far larger than L2+MALL) — no MFMA here.
+//
+// Replaces the per-column [TF] safe_embedding_lookup_sparse + tf.stack + tf.concat + indicator/Dense(1)
+// + FM reduce_sum/pow/subtract op chain of keras/models/ranking/fm.py:23-37,54-64 and deepfm.py:36-47
+// (reference root), and its autodiff.
+//
+// Work decomposition (wave64): one wavefront owns one example at a time (grid-stride).  A table row of
+// D floats is read as D/4 float4's by LPR = D/4 adjacent lanes (one global_load_dwordx4 per lane, a
+// row is one contiguous 4*D-byte segment), so a wave serves NS = 64/LPR fields per load instruction and
+// keeps U such instructions in flight before consuming any of them (memory-level parallelism for the
+// ~2 us HBM miss latency).  Ids of the example are loaded once, coalesced, one per lane, and broadcast
+// with wave shuffles.  FM partial sums live in registers; the cross-field reduction is a butterfly of
+// __shfl_xor over the slot bits; the D-reduction for the second-order scalar is a butterfly over the
+// sub-lane bits.  The pooled rows are written once, directly in the [B, F*D] "concat" layout (which
+// is byte-identical to the [B, F, D] "stack" layout), so tf.stack / tf.concat cost nothing.
+#include "dr_common.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+namespace {
+
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4fma2(float4 a, float4 acc) {
+    return make_float4(fmaf(a.x, a.x, acc.x), fmaf(a.y, a.y, acc.y), fmaf(a.z, a.z, acc.z), fmaf(a.w, a.w, acc.w));
+}
+__device__ __forceinline__ float4 f4shfl_xor(float4 v, int m) {
+    return make_float4(__shfl_xor(v.x, m, 64), __shfl_xor(v.y, m, 64), __shfl_xor(v.z, m, 64), __shfl_xor(v.w, m, 64));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forward, fast path: every field single-valued (C == F), F <= 64.
+// ------------------------------------------------------------------------------------------------
+template <int LPR, int U>
+__global__ __launch_bounds__(256) void emb_pool_fwd_sv_kernel(
+    const int64_t* __restrict__ ids, int64_t B, int32_t F, const int64_t* __restrict__ row_base,
+    const float* __restrict__ table, int32_t D, const float* __restrict__ lin_w, float lin_bias,
+    float* __restrict__ concat, int64_t ld, float* __restrict__ sum_x, float* __restrict__ fm_logit) {
+    constexpr int NS = DR_WAVE / LPR;
+    const int lane = threadIdx.x & 63;
+    const int slot = lane / LPR;
+    const int sub = lane % LPR;
+    const bool dvalid = sub * 4 < D;
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    // per-lane table base row of "my" field (lane l <-> field l); constant across examples
+    const int64_t my_base = lane < F ? row_base[lane] : 0;
+
+    for (int64_t b = wave0; b < B; b += nwaves) {
+        // one coalesced 8*F-byte load; absolute row index per field, -1 if missing
+        int64_t my_row = -1;
+        if (lane < F) {
+            const int64_t id = ids[b * F + lane];
+            my_row = id >= 0 ? my_base + id : -1;
+        }
+        float4 S = f4zero(), SS = f4zero();
+        float lin = 0.f;
+        float* out_row = concat + b * ld;
+        for (int f0 = 0; f0 < F; f0 += NS * U) {
+            float4 v[U];
+            int64_t row[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int f = f0 + u * NS + slot;
+                row[u] = __shfl(my_row, f < F ? f : 0, 64);
+                if (f >= F) row[u] = -1;
+                v[u] = f4zero();
+                if (row[u] >= 0 && dvalid)
+                    v[u] = *reinterpret_cast<const float4*>(table + row[u] * D + sub * 4);
+            }
+            if (lin_w != nullptr && sub == 0) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (row[u] >= 0) lin += lin_w[row[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int f = f0 + u * NS + slot;
+                if (f < F && dvalid) *reinterpret_cast<float4*>(out_row + f * D + sub * 4) = v[u];
+                S = f4add(S, v[u]);
+                SS = f4fma2(v[u], SS);
+            }
+        }
+        if (sum_x == nullptr && fm_logit == nullptr) continue;
+        // reduce across slots (lane bits >= log2(LPR))
+#pragma unroll
+        for (int m = LPR; m < DR_WAVE; m <<= 1) {
+            S = f4add(S, f4shfl_xor(S, m));
+            SS = f4add(SS, f4shfl_xor(SS, m));
+            lin += __shfl_xor(lin, m, 64);
+        }
+        if (sum_x != nullptr && slot == 0 && dvalid) *reinterpret_cast<float4*>(sum_x + b * D + sub * 4) = S;
+        if (fm_logit != nullptr) {
+            float t = (S.x * S.x - SS.x) + (S.y * S.y - SS.y) + (S.z * S.z - SS.z) + (S.w * S.w - SS.w);
+#pragma unroll
+            for (int m = 1; m < LPR; m <<= 1) t += __shfl_xor(t, m, 64);
+            if (lane == 0) fm_logit[b] = lin_bias + lin + 0.5f * t;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forward, general path: ragged bags (field f owns columns [col_start[f], col_start[f+1])).
+// [TF] B5: drop ids < 0, sum rows in id order, one divide by the count, empty bag -> zeros.
+// ------------------------------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(256) void emb_pool_fwd_bag_kernel(
+    const int64_t* __restrict__ ids, int64_t B, int32_t F, int32_t C, const int32_t* __restrict__ col_start,
+    const int64_t* __restrict__ row_base, const float* __restrict__ table, int32_t D,
+    const float* __restrict__ lin_w, float lin_bias, float* __restrict__ concat, int64_t ld,
+    float* __restrict__ sum_x, float* __restrict__ fm_logit) {
+    constexpr int NS = DR_WAVE / LPR;
+    const int lane = threadIdx.x & 63;
+    const int slot = lane / LPR;
+    const int sub = lane % LPR;
+    const bool dvalid = sub * 4 < D;
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+
+    for (int64_t b = wave0; b < B; b += nwaves) {
+        float4 S = f4zero(), SS = f4zero();
+        float lin = 0.f;
+        float* out_row = concat + b * ld;
+        const int64_t* id_row = ids + b * C;
+        for (int f = slot; f < F; f += NS) {
+            const int c0 = col_start[f], c1 = col_start[f + 1];
+            const int64_t base = row_base[f];
+            float4 acc = f4zero();
+            int cnt = 0;
+            for (int c = c0; c < c1; ++c) {
+                const int64_t id = id_row[c];
+                if (id >= 0) {
+                    const int64_t row = base + id;
+                    if (dvalid) acc = f4add(acc, *reinterpret_cast<const float4*>(table + row * D + sub * 4));
+                    if (lin_w != nullptr && sub == 0) lin += lin_w[row];   // count vector: duplicates add
+                    ++cnt;
+                }
+            }
+            if (cnt > 1) {
+                const float n = (float)cnt;
+                acc = make_float4(acc.x / n, acc.y / n, acc.z / n, acc.w / n);
+            }
+            if (dvalid) *reinterpret_cast<float4*>(out_row + f * D + sub * 4) = acc;
+            S = f4add(S, acc);
+            SS = f4fma2(acc, SS);
+        }
+        if (sum_x == nullptr && fm_logit == nullptr) continue;
+#pragma unroll
+        for (int m = LPR; m < DR_WAVE; m <<= 1) {
+            S = f4add(S, f4shfl_xor(S, m));
+            SS = f4add(SS, f4shfl_xor(SS, m));
+            lin += __shfl_xor(lin, m, 64);
+        }
+        if (sum_x != nullptr && slot == 0 && dvalid) *reinterpret_cast<float4*>(sum_x + b * D + sub * 4) = S;
+        if (fm_logit != nullptr) {
+            float t = (S.x * S.x - SS.x) + (S.y * S.y - SS.y) + (S.z * S.z - SS.z) + (S.w * S.w - SS.w);
+#pragma unroll
+            for (int m = 1; m < LPR; m <<= 1) t += __shfl_xor(t, m, 64);
+            if (lane == 0) fm_logit[b] = lin_bias + lin + 0.5f * t;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward: g = d_concat + d_fm_logit * (sum_x - x); dst[row] += scale * g / count (hardware fp32
+// atomics at L2, fire-and-forget).  Lane -> d mapping is STRIDED (d = j*LPR*... see below) so that each
+// atomic instruction of a slot covers one contiguous 4*LPR-byte span of the row (fewer, fuller L2
+// atomic requests than a float4-per-lane mapping, where each instruction touches every 4th dword).
+// ------------------------------------------------------------------------------------------------
+template <int LPR, bool STRIDED>
+__global__ __launch_bounds__(256) void emb_pool_bwd_kernel(
+    const int64_t* __restrict__ ids, int64_t B, int32_t F, int32_t C, const int32_t* __restrict__ col_start,
+    const int64_t* __restrict__ row_base, int32_t D, const float* __restrict__ d_concat, int64_t ld_dc,
+    const float* __restrict__ concat, int64_t ld_c, const float* __restrict__ sum_x,
+    const float* __restrict__ d_fm_logit, float scale, float* __restrict__ dst_table,
+    float* __restrict__ dst_lin) {
+    constexpr int NS = DR_WAVE / LPR;
+    const int lane = threadIdx.x & 63;
+    const int slot = lane / LPR;
+    const int sub = lane % LPR;
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    // element offsets handled by this lane within a row
+    int doff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) doff[j] = STRIDED ? (j * LPR + sub) : (sub * 4 + j);
+
+    for (int64_t b = wave0; b < B; b += nwaves) {
+        const float dl = d_fm_logit != nullptr ? d_fm_logit[b] : 0.f;
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        if (d_fm_logit != nullptr && sum_x != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (doff[j] < D) s[j] = sum_x[b * D + doff[j]];
+        }
+        const int64_t* id_row = ids + b * C;
+        for (int f = slot; f < F; f += NS) {
+            const int c0 = col_start[f], c1 = col_start[f + 1];
+            int cnt = 0;
+            for (int c = c0; c < c1; ++c) cnt += id_row[c] >= 0 ? 1 : 0;
+            if (cnt == 0) continue;
+            float g[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                g[j] = 0.f;
+                if (doff[j] < D) {
+                    if (d_concat != nullptr) g[j] = d_concat[b * ld_dc + f * D + doff[j]];
+                    if (d_fm_logit != nullptr) g[j] += dl * (s[j] - concat[b * ld_c + f * D + doff[j]]);
+                    g[j] *= scale;
+                    if (cnt > 1) g[j] /= (float)cnt;
+                }
+            }
+            const int64_t base = row_base[f];
+            for (int c = c0; c < c1; ++c) {
+                const int64_t id = id_row[c];
+                if (id < 0) continue;
+                float* dst = dst_table + (base + id) * D;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (doff[j] < D) unsafeAtomicAdd(dst + doff[j], g[j]);
+                if (dst_lin != nullptr && d_fm_logit != nullptr && sub == 0) unsafeAtomicAdd(dst_lin + base + id, scale * dl);
+            }
+        }
+    }
+}
+
+int lpr_for(int D) {
+    int l = 1;
+    while (l * 4 < D) l <<= 1;
+    return l;
+}
+
+}  // namespace
+
+#define DR_DISPATCH_LPR(lpr, CALL)            \
+    switch (lpr) {                            \
+        case 1: { CALL(1) } break;            \
+        case 2: { CALL(2) } break;            \
+        case 4: { CALL(4) } break;            \
+        case 8: { CALL(8) } break;            \
+        case 16: { CALL(16) } break;          \
+        case 32: { CALL(32) } break;          \
+        case 64: { CALL(64) } break;          \
+        default: return DR_EINVAL;            \
+    }
+
+extern "C" int dr_emb_pool_fwd(const int64_t* ids, int64_t B, int32_t F, int32_t C, const int32_t* col_start,
+                               const int64_t* row_base, const float* table, int32_t D, const float* lin_w,
+                               float lin_bias, float* concat, int64_t ld_concat, float* sum_x, float* fm_logit,
+                               dr_stream_t stream) {
+    if (B < 0 || F <= 0 || C < F || D < 4 || D > 256 || (D & 3) || ld_concat < (int64_t)F * D || (ld_concat & 3))
+        return DR_EINVAL;
+    if (col_start == nullptr && C != F) return DR_EINVAL;
+    if (B == 0) return DR_OK;
+    if (!ids || !row_base || !table || !concat) return DR_EINVAL;
+    const int lpr = lpr_for(D);
+    const int grid = dr_grid_for(B, 4);
+    if (col_start == nullptr && F <= 64) {
+#define CALL(L)                                                                                                    \
+    {                                                                                                              \
+        constexpr int NS_ = 64 / L;                                                                                \
+        constexpr int U_ = NS_ >= 16 ? 2 : (NS_ >= 4 ? 8 : 4);                                                     \
+        hipLaunchKernelGGL((emb_pool_fwd_sv_kernel<L, U_>), dim3(grid), dim3(256), 0, dr_s(stream), ids, B, F,     \
+                           row_base, table, D, lin_w, lin_bias, concat, ld_concat, sum_x, fm_logit);               \
+    }
+        DR_DISPATCH_LPR(lpr, CALL)
+#undef CALL
+    } else {
+        if (col_start == nullptr) return DR_EINVAL;   // F > 64 single-valued: pass an explicit col_start
+#define CALL(L)                                                                                                    \
+    hipLaunchKernelGGL((emb_pool_fwd_bag_kernel<L>), dim3(grid), dim3(256), 0, dr_s(stream), ids, B, F, C,         \
+                       col_start, row_base, table, D, lin_w, lin_bias, concat, ld_concat, sum_x, fm_logit);
+        DR_DISPATCH_LPR(lpr, CALL)
+#undef CALL
+    }
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+// variant selector for A/B measurement of the atomic lane mapping (0 = float4-per-lane, 1 = strided)
+static int g_bwd_strided = 1;
+extern "C" void dr_debug_set_bwd_strided(int v) { g_bwd_strided = v; }
+
+extern "C" int dr_emb_pool_bwd(const int64_t* ids, int64_t B, int32_t F, int32_t C, const int32_t* col_start,
+                               const int64_t* row_base, int32_t D, const float* d_concat, int64_t ld_dconcat,
+                               const float* concat, int64_t ld_concat, const float* sum_x,
+                               const float* d_fm_logit, float scale, float* dst_table, float* dst_lin,
+                               dr_stream_t stream) {
+    if (B < 0 || F <= 0 || C < F || D < 4 || D > 256 || (D & 3)) return DR_EINVAL;
+    if (B == 0) return DR_OK;
+    if (!ids || !row_base || !dst_table || !col_start) return DR_EINVAL;
+    if (d_concat == nullptr && d_fm_logit == nullptr) return DR_EINVAL;
+    if (d_concat != nullptr && ld_dconcat < (int64_t)F * D) return DR_EINVAL;
+    if (d_fm_logit != nullptr && (concat == nullptr || sum_x == nullptr || ld_concat < (int64_t)F * D)) return DR_EINVAL;
+    const int lpr = lpr_for(D);
+    const int grid = dr_grid_for(B, 4);
+    if (g_bwd_strided) {
+#define CALL(L)                                                                                                    \
+    hipLaunchKernelGGL((emb_pool_bwd_kernel<L, true>), dim3(grid), dim3(256), 0, dr_s(stream), ids, B, F, C,       \
+                       col_start, row_base, D, d_concat, ld_dconcat, concat, ld_concat, sum_x, d_fm_logit, scale,   \
+                       dst_table, dst_lin);
+        DR_DISPATCH_LPR(lpr, CALL)
+#undef CALL
+    } else {
+#define CALL(L)                                                                                                    \
+    hipLaunchKernelGGL((emb_pool_bwd_kernel<L, false>), dim3(grid), dim3(256), 0, dr_s(stream), ids, B, F, C,      \
+                       col_start, row_base, D, d_concat, ld_dconcat, concat, ld_concat, sum_x, d_fm_logit, scale,   \
+                       dst_table, dst_lin);
+        DR_DISPATCH_LPR(lpr, CALL)
+#undef CALL
+    }
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}

@@ -1,0 +1,236 @@
+"""Thin, shape-checked Python wrappers over the C-ABI kernels (one function per entry point), plus the
+torch.autograd.Function glue that lets the reference-shaped model classes train with loss.backward().
+
+Every function launches hand-written HIP kernels on torch's current stream; nothing here computes in
+PyTorch.  Reference citations (relative to the reference root) are on the C-ABI declarations in
+include/dr_hotpath.h.
+"""
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, stream_ptr
+
+
+def _c(t: torch.Tensor, dtype) -> torch.Tensor:
+    if t.dtype != dtype:
+        raise TypeError("expected %s, got %s" % (dtype, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ----------------------------------------------------------------------------------------------
+# K1 / K2   integer id path
+# ----------------------------------------------------------------------------------------------
+def hash_bucket_i64(keys: torch.Tensor, col_buckets: torch.Tensor, out: Optional[torch.Tensor] = None):
+    """keys [B, C] int64 -> ids [B, C]; col_buckets [C] uint64-as-int64 (0 = pass-through column)."""
+    keys = _c(keys, torch.int64)
+    B, C = keys.shape
+    col_buckets = _c(col_buckets, torch.int64)
+    assert col_buckets.numel() == C
+    if out is None:
+        out = torch.empty_like(keys)
+    check(lib().dr_hash_bucket_i64(ptr(keys), B, C, ptr(col_buckets), ptr(out), stream_ptr()), "dr_hash_bucket_i64")
+    return out
+
+
+def _csr_bytes(values: Sequence, device):
+    import numpy as np
+    flat = [v if isinstance(v, (bytes, bytearray)) else str(v).encode("utf-8") for v in values]
+    offs = np.zeros(len(flat) + 1, dtype=np.int64)
+    if flat:
+        offs[1:] = np.cumsum([len(b) for b in flat])
+    blob = np.frombuffer(b"".join(flat) + b"\0", dtype=np.uint8).copy()
+    return torch.from_numpy(blob).to(device), torch.from_numpy(offs).to(device), len(flat)
+
+
+def hash_bucket_strings(values: Sequence, num_buckets: int, device="cuda"):
+    """list of str/bytes -> ids [n]; "" -> -1.  (host strings are packed to CSR bytes, hashed on device)"""
+    blob, offs, n = _csr_bytes(values, device)
+    out = torch.empty(n, dtype=torch.int64, device=device)
+    check(lib().dr_hash_bucket_bytes(ptr(blob), ptr(offs), n, int(num_buckets), ptr(out), stream_ptr()),
+          "dr_hash_bucket_bytes")
+    return out
+
+
+def vocab_lookup_i64(keys: torch.Tensor, vocab: torch.Tensor):
+    keys = _c(keys, torch.int64)
+    vocab = _c(vocab, torch.int64)
+    out = torch.empty_like(keys)
+    check(lib().dr_vocab_lookup_i64(ptr(keys), keys.numel(), ptr(vocab), vocab.numel(), ptr(out), stream_ptr()),
+          "dr_vocab_lookup_i64")
+    return out
+
+
+def vocab_lookup_strings(values: Sequence, vocab: Sequence, device="cuda"):
+    blob, offs, n = _csr_bytes(values, device)
+    vblob, voffs, m = _csr_bytes(vocab, device)
+    out = torch.empty(n, dtype=torch.int64, device=device)
+    check(lib().dr_vocab_lookup_bytes(ptr(blob), ptr(offs), n, ptr(vblob), ptr(voffs), m, ptr(out), stream_ptr()),
+          "dr_vocab_lookup_bytes")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# K3 / K4   fused embedding gather + pool (+ first-order + FM)
+# ----------------------------------------------------------------------------------------------
+def emb_pool_fwd(ids, F, col_start, row_base, table, lin_w=None, lin_bias=0.0, ld_concat=None,
+                 want_sum_x=True, want_fm=True, concat=None, sum_x=None, fm_logit=None):
+    ids = _c(ids, torch.int64)
+    B, C = ids.shape
+    D = table.shape[1]
+    ld = F * D if ld_concat is None else ld_concat
+    dev = ids.device
+    if concat is None:
+        concat = torch.empty((B, ld), dtype=torch.float32, device=dev)
+        if ld > F * D:
+            concat[:, F * D:].zero_()
+    if want_sum_x and sum_x is None:
+        sum_x = torch.empty((B, D), dtype=torch.float32, device=dev)
+    if want_fm and fm_logit is None:
+        fm_logit = torch.empty((B,), dtype=torch.float32, device=dev)
+    check(lib().dr_emb_pool_fwd(ptr(ids), B, F, C, ptr(col_start), ptr(row_base), ptr(table), D, ptr(lin_w),
+                                float(lin_bias), ptr(concat), ld, ptr(sum_x) if want_sum_x else None,
+                                ptr(fm_logit) if want_fm else None, stream_ptr()), "dr_emb_pool_fwd")
+    return concat, sum_x, fm_logit
+
+
+def emb_pool_bwd(ids, F, col_start, row_base, D, d_concat, concat, sum_x, d_fm_logit, scale, dst_table, dst_lin):
+    ids = _c(ids, torch.int64)
+    B, C = ids.shape
+    check(lib().dr_emb_pool_bwd(ptr(ids), B, F, C, ptr(col_start), ptr(row_base), D,
+                                ptr(d_concat), d_concat.stride(0) if d_concat is not None else 0,
+                                ptr(concat), concat.stride(0) if concat is not None else 0,
+                                ptr(sum_x), ptr(d_fm_logit), float(scale), ptr(dst_table), ptr(dst_lin),
+                                stream_ptr()), "dr_emb_pool_bwd")
+
+
+# ----------------------------------------------------------------------------------------------
+# K6   stand-alone FM second order
+# ----------------------------------------------------------------------------------------------
+def fm2_fwd(x):
+    x = _c(x, torch.float32)
+    B, F, D = x.shape
+    out = torch.empty((B, 1), dtype=torch.float32, device=x.device)
+    check(lib().dr_fm2_fwd(ptr(x), B, F, D, ptr(out), stream_ptr()), "dr_fm2_fwd")
+    return out
+
+
+def fm2_bwd(x, d_out):
+    x = _c(x, torch.float32)
+    d_out = _c(d_out, torch.float32)
+    B, F, D = x.shape
+    dx = torch.empty_like(x)
+    check(lib().dr_fm2_bwd(ptr(x), ptr(d_out), B, F, D, ptr(dx), stream_ptr()), "dr_fm2_bwd")
+    return dx
+
+
+# ----------------------------------------------------------------------------------------------
+# K7 / K8   dense layers on fp32 MFMA
+# ----------------------------------------------------------------------------------------------
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+def _rowmajor_ld4(t):
+    """Returns a [M, K] fp32 view whose row stride is a multiple of 4 floats and base 16-B aligned."""
+    assert t.dim() == 2 and t.dtype == torch.float32
+    if t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.stride(0) >= t.shape[1] and t.data_ptr() % 16 == 0:
+        return t
+    M, K = t.shape
+    buf = torch.zeros((M, _pad4(K)), dtype=torch.float32, device=t.device)
+    buf[:, :K].copy_(t)
+    return buf[:, :K]
+
+
+def linear_fwd(x, W, b=None, act=0, out=None):
+    """y = act(x @ W + b); x [M,K] (row stride % 4 == 0), W [K,N] row-major."""
+    x = _rowmajor_ld4(x)
+    W = _rowmajor_ld4(W)
+    M, K = x.shape
+    N = W.shape[1]
+    if out is None:
+        out = torch.empty((M, _pad4(N)), dtype=torch.float32, device=x.device)[:, :N]
+    check(lib().dr_linear_fwd(ptr(x), x.stride(0), ptr(W), W.stride(0), ptr(b), M, K, N, int(act), ptr(out),
+                              out.stride(0), stream_ptr()), "dr_linear_fwd")
+    return out
+
+
+def linear_bwd_dx(dy, W, relu_src=None, accumulate=False, out=None):
+    dy = _rowmajor_ld4(dy)
+    W = _rowmajor_ld4(W)
+    M, N = dy.shape
+    K = W.shape[0]
+    if out is None:
+        assert not accumulate
+        out = torch.empty((M, _pad4(K)), dtype=torch.float32, device=dy.device)[:, :K]
+    check(lib().dr_linear_bwd_dx(ptr(dy), dy.stride(0), ptr(W), W.stride(0), M, K, N, ptr(relu_src),
+                                 relu_src.stride(0) if relu_src is not None else 0, int(bool(accumulate)), ptr(out),
+                                 out.stride(0), stream_ptr()), "dr_linear_bwd_dx")
+    return out
+
+
+def linear_bwd_dw(x, dy, scale, dstW, dstb=None):
+    """dstW += scale * x^T @ dy ; dstb += scale * colsum(dy)   (atomic accumulation into dst)."""
+    x = _rowmajor_ld4(x)
+    dy = _rowmajor_ld4(dy)
+    M, K = x.shape
+    N = dy.shape[1]
+    assert dstW.shape == (K, N) and dstW.stride(1) == 1
+    check(lib().dr_linear_bwd_dw(ptr(x), x.stride(0), ptr(dy), dy.stride(0), M, K, N, float(scale), ptr(dstW),
+                                 dstW.stride(0), ptr(dstb), stream_ptr()), "dr_linear_bwd_dw")
+
+
+def cross_fwd(x0, x, W, b, diag_scale=0.0, want_prod=False, prod=None):
+    """out = x0 * (x @ W + b + diag*x) + x.  W None: `prod` holds x @ W (low-rank path) and is finished in place."""
+    x0 = _rowmajor_ld4(x0)
+    x = _rowmajor_ld4(x)
+    if x0.stride(0) != x.stride(0):
+        x = _rowmajor_ld4(x.contiguous())
+        x0 = _rowmajor_ld4(x0.contiguous())
+    M, Dm = x.shape
+    ld = x.stride(0)
+    out = torch.empty((M, ld), dtype=torch.float32, device=x.device)[:, :Dm]
+    if W is not None:
+        W = _rowmajor_ld4(W)
+        if want_prod:
+            prod = torch.empty((M, ld), dtype=torch.float32, device=x.device)[:, :Dm]
+        ldw = W.stride(0)
+    else:
+        assert prod is not None and prod.stride(0) == ld
+        ldw = 0
+    check(lib().dr_cross_fwd(ptr(x0), ptr(x), ld, ptr(W), ldw, ptr(b), float(diag_scale), M, Dm, ptr(out),
+                             ptr(prod) if (want_prod or W is None) else None, stream_ptr()), "dr_cross_fwd")
+    return out, prod
+
+
+def cross_combine_bwd(x0, prod, d_out, diag_scale, d_x0_accum, d_x_accum):
+    M, Dm = d_out.shape
+    ld = d_out.stride(0)
+    for t in (x0, prod, d_x0_accum, d_x_accum):
+        assert t is None or t.stride(0) == ld, "cross tensors must share one leading dimension"
+    d_prod = torch.empty((M, ld), dtype=torch.float32, device=d_out.device)[:, :Dm]
+    check(lib().dr_cross_combine_bwd(ptr(x0), ptr(prod), ptr(d_out), M, Dm, ld, float(diag_scale), ptr(d_prod),
+                                     ptr(d_x0_accum), ptr(d_x_accum), stream_ptr()), "dr_cross_combine_bwd")
+    return d_prod
+
+
+# ----------------------------------------------------------------------------------------------
+# K11   fused sigmoid + BCE
+# ----------------------------------------------------------------------------------------------
+LOSS_SIGMOID_CE, LOSS_LOG_LOSS, LOSS_KERAS_BCE = 0, 1, 2
+
+
+def bce_fwd_bwd(logits, labels, mode=LOSS_SIGMOID_CE, want_prob=True, want_grad=True, workspace=None):
+    logits = _c(logits.reshape(-1), torch.float32)
+    labels = _c(labels.reshape(-1), torch.float32)
+    n = logits.numel()
+    dev = logits.device
+    prob = torch.empty(n, dtype=torch.float32, device=dev) if want_prob else None
+    d_logit = torch.empty(n, dtype=torch.float32, device=dev) if want_grad else None
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    if workspace is None:
+        workspace = torch.empty(1024, dtype=torch.float32, device=dev)
+    check(lib().dr_bce_fwd_bwd(ptr(logits), ptr(labels), n, int(mode), ptr(prob), ptr(d_logit), ptr(loss),
+                               ptr(workspace), stream_ptr()), "dr_bce_fwd_bwd")
+    return loss, prob, d_logit

@@ -1,0 +1,180 @@
+/*
+ * dr_hotpath.h — C-ABI of the MI355X-native embedding-lookup + feature-interaction hot path.
+ *
+ * The reference (LongmaoTeamTf/deep_recommenders) is pure Python over TensorFlow and has no
+ * FFI of its own; the drop-in boundary is therefore the set of TF-op clusters
+ * its Python classes invoke.  Each entry point below replaces one such cluster and cites the
+ * reference call site it stands behind (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless marked [host]; the caller allocates all
+ *     inputs and outputs; the library holds no state between calls;
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous and stream-ordered,
+ *     no hidden synchronisation, re-entrant across streams;
+ *   - return value: DR_OK (0) or a negative DR_E* code; nothing throws across the boundary;
+ *   - ids are int64, -1 = "missing" (TF drops -1 / "" before lookup);
+ *   - all floating point is IEEE fp32 ("f32" in bench.py's dtype field).
+ *
+ * Layout of categorical inputs ("columns"): a batch is an int64 matrix ids[B, C]; field f owns the
+ * contiguous columns [col_start[f], col_start[f+1]) (its bag, padded with -1), C = col_start[F].
+ * All F embedding tables live in ONE fp32 slab table[R, D]; field f's rows start at row_base[f].
+ * The first-order ("linear"/"indicator") weights use the same row numbering: lin_w[R].
+ */
+#ifndef DR_HOTPATH_H
+#define DR_HOTPATH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DR_OK 0
+#define DR_EINVAL (-1)   /* bad argument (null pointer, negative size, unsupported D)     */
+#define DR_ELAUNCH (-2)  /* hipLaunch / runtime error (hipGetLastError() != hipSuccess)  */
+#define DR_ESHAPE (-3)   /* shape contract violated (e.g. x0 / x dim mismatch, k > n)    */
+
+typedef void* dr_stream_t; /* hipStream_t */
+
+/* Library self-description: returns the gfx arch string the kernels were compiled for. */
+const char* dr_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * K1  hash-bucket column:  id = int64( FarmHash::Fingerprint64(as_string(key)) mod N )
+ * replaces [TF] categorical_column_with_hash_bucket ->
+ *   string_to_hash_bucket_fast(as_string(x), N)
+ * reference call sites: examples/train_fm_on_movielens_estimator.py:12-13,20-21;
+ *   examples/train_deepfm_on_movielens_keras.py:13-14,21-22; tests/keras/test_fm.py:70-73
+ * keys[B, C] int64; col_buckets[C] uint64: N for a hashed column, 0 = pass the value through
+ * unchanged (column already holds ids, e.g. from dr_vocab_lookup_*).  key == -1 -> id -1.
+ * Bit-exact integer path.
+ * ---------------------------------------------------------------------------------------- */
+int dr_hash_bucket_i64(const int64_t* keys, int64_t B, int32_t C, const uint64_t* col_buckets,
+                       int64_t* ids_out, dr_stream_t stream);
+
+/* Same for byte strings in CSR form (bytes + offsets[n+1]); "" -> id -1. One bucket count. */
+int dr_hash_bucket_bytes(const uint8_t* bytes, const int64_t* offsets, int64_t n,
+                         uint64_t num_buckets, int64_t* ids_out, dr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K2  vocabulary-list column: id = position of key in vocab, OOV -> -1 (default_value=-1,
+ * num_oov_buckets=0).  replaces [TF] categorical_column_with_vocabulary_list
+ * reference call sites: examples/train_fm_on_movielens_estimator.py:14-19,22-23
+ * ---------------------------------------------------------------------------------------- */
+int dr_vocab_lookup_i64(const int64_t* keys, int64_t n, const int64_t* vocab, int32_t vocab_len,
+                        int64_t* ids_out, dr_stream_t stream);
+int dr_vocab_lookup_bytes(const uint8_t* bytes, const int64_t* offsets, int64_t n,
+                          const uint8_t* vocab_bytes, const int64_t* vocab_offsets,
+                          int32_t vocab_len, int64_t* ids_out, dr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K3 (+K5, K6 fused)  embedding gather + mean-pool forward.
+ * replaces, in ONE pass: [TF] safe_embedding_lookup_sparse(combiner='mean') x F
+ *   (keras/models/ranking/fm.py:48-51,57-61; deepfm.py:25-28,39-43; estimator/.../fm.py:48-52),
+ *   tf.stack / tf.concat (fm.py:62; deepfm.py:44-45), the first-order term
+ *   DenseFeatures(indicator)->Dense(1) / linear_model (fm.py:16-20,47,55; estimator fm.py:43-44)
+ *   and the FM second-order term (fm.py:28-35; estimator fm.py:22-26).
+ *
+ *   concat[b, f*D + d] = mean over valid ids of field f of table[row_base[f]+id, d]  (0 if empty)
+ *   sum_x[b, d]        = sum_f concat[b, f*D+d]                                   (optional)
+ *   fm_logit[b]        = lin_bias + sum over valid ids lin_w[row] + 0.5*sum_d(sum_x^2 - sum_f x^2)
+ *
+ * col_start[F+1] (device, int32) may be NULL when every field is single-valued (then C == F).
+ * concat has leading dimension ld_concat (>= F*D) so the caller can append dense features.
+ * lin_w may be NULL (no first-order term); sum_x / fm_logit may be NULL (pure lookup).
+ * D must be a multiple of 4, 4 <= D <= 256.
+ * ---------------------------------------------------------------------------------------- */
+int dr_emb_pool_fwd(const int64_t* ids, int64_t B, int32_t F, int32_t C, const int32_t* col_start,
+                    const int64_t* row_base, const float* table, int32_t D,
+                    const float* lin_w, float lin_bias,
+                    float* concat, int64_t ld_concat, float* sum_x, float* fm_logit,
+                    dr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K4  transposed scatter-add backward of K3 (autodiff of the lookup: IndexedSlices ->
+ * unsorted_segment_sum into the variable; implicit in optimizer.minimize / model.fit:
+ * examples/train_fm_on_movielens_estimator.py:51-52, examples/train_deepfm_on_movielens_keras.py:49).
+ *
+ *   g[b,f,:]   = d_concat[b, f*D:(f+1)*D] + d_fm_logit[b] * (sum_x[b,:] - concat[b, f*D:(f+1)*D])
+ *   for every valid id of (b,f):  dst_table[row,:] += scale * g[b,f,:] / bag_count(b,f)
+ *                                  dst_lin[row]    += scale * d_fm_logit[b]
+ *
+ * dst_table / dst_lin are either gradient buffers (scale = 1) or the parameters themselves
+ * (scale = -learning_rate: fused SGD step, no gradient materialised).  d_concat may be NULL
+ * (FM only), d_fm_logit may be NULL (pure lookup backward), dst_lin may be NULL.
+ * Accumulation uses hardware fp32 atomics; rows touched once are bit-exact.
+ * ---------------------------------------------------------------------------------------- */
+int dr_emb_pool_bwd(const int64_t* ids, int64_t B, int32_t F, int32_t C, const int32_t* col_start,
+                    const int64_t* row_base, int32_t D,
+                    const float* d_concat, int64_t ld_dconcat,
+                    const float* concat, int64_t ld_concat, const float* sum_x,
+                    const float* d_fm_logit, float scale,
+                    float* dst_table, float* dst_lin, dr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K6  stand-alone FM second-order term on a caller-provided [B, F, D] tensor
+ * replaces keras FM.call (keras/models/ranking/fm.py:28-35) and estimator fm(x)
+ * (estimator/models/feature_interaction/fm.py:10-26).
+ *   out[b] = 0.5 * sum_d( (sum_f x)^2 - sum_f x^2 )      dx = d_out[b] * (sum_f x - x)
+ * ---------------------------------------------------------------------------------------- */
+int dr_fm2_fwd(const float* x, int64_t B, int32_t F, int32_t D, float* out, dr_stream_t stream);
+int dr_fm2_bwd(const float* x, const float* d_out, int64_t B, int32_t F, int32_t D, float* dx,
+               dr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K7  Dense layer on fp32 MFMA (v_mfma_f32_32x32x2_f32: exact f32 products, k-ordered accumulation).
+ * replaces tf.keras.layers.Dense / tf.layers.dense (keras/models/ranking/deepfm.py:30-34;
+ * estimator/models/feature_interaction/dnn.py:17-29) and, with N = 1, the FM layer's first-order
+ * Dense(1) on an explicit multi-hot matrix (keras/models/ranking/fm.py:16-20,26,37)  [K5].
+ *
+ *   fwd     y[M,N]  = act(x[M,K] @ W[K,N] + b[N])           act: 0 linear, 1 relu; b may be NULL
+ *   bwd_dx  dx[M,K] = (dy[M,N] @ W^T) * (relu_src > 0)  (+ dx if accumulate)
+ *           dy is the PRE-activation gradient of this layer; relu_src[M,K] (may be NULL) is this
+ *           layer's input when that input is itself a relu output — so the product is directly the
+ *           pre-activation gradient of the layer below (relu' folded into the producer's epilogue).
+ *   bwd_dw  dstW[K,N] += scale * x^T @ dy ;  dstb[N] += scale * colsum(dy)
+ *           split over the batch dimension with fp32 atomics: dst is a zeroed gradient buffer
+ *           (scale = 1) or the parameter itself (scale = -lr, fused SGD).  dstb may be NULL.
+ * All matrices row-major with explicit leading dimensions (multiples of 4 floats, 16-byte aligned).
+ * ---------------------------------------------------------------------------------------- */
+int dr_linear_fwd(const float* x, int64_t ld_x, const float* W, int64_t ld_w, const float* b,
+                  int64_t M, int32_t K, int32_t N, int32_t act, float* y, int64_t ld_y,
+                  dr_stream_t stream);
+int dr_linear_bwd_dx(const float* dy, int64_t ld_dy, const float* W, int64_t ld_w, int64_t M,
+                     int32_t K, int32_t N, const float* relu_src, int64_t ld_relu_src,
+                     int32_t accumulate, float* dx, int64_t ld_dx, dr_stream_t stream);
+int dr_linear_bwd_dw(const float* x, int64_t ld_x, const float* dy, int64_t ld_dy, int64_t M,
+                     int32_t K, int32_t N, float scale, float* dstW, int64_t ld_w, float* dstb,
+                     dr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K8  DCN cross layer (keras/models/ranking/dcn.py:70-88):
+ *   prod = x @ W + b + diag_scale * x (:81,:85-86) ;  out = x0 * prod + x (:88)
+ * One GEMM with the whole combine fused in the epilogue; `prod_out` (may be NULL) saves prod for
+ * the backward.  W == NULL: "prod given" in prod_out (low-rank form :83 = two dr_linear_fwd calls,
+ * then this with W NULL adds bias-free combine).  x0, x, out, prod share leading dimension ld.
+ * bwd (elementwise part): d_prod = d_out * x0 ; d_x0 += d_out * prod ; d_x += d_out + diag_scale*d_prod;
+ * the GEMM parts are dr_linear_bwd_dx(d_prod, W, accumulate=1 -> d_x) and dr_linear_bwd_dw(x, d_prod).
+ * ---------------------------------------------------------------------------------------- */
+int dr_cross_fwd(const float* x0, const float* x, int64_t ld, const float* W, int64_t ld_w,
+                 const float* b, float diag_scale, int64_t M, int32_t Dm, float* out,
+                 float* prod_out, dr_stream_t stream);
+int dr_cross_combine_bwd(const float* x0, const float* prod, const float* d_out, int64_t M,
+                         int32_t Dm, int64_t ld, float diag_scale, float* d_prod, float* d_x0_accum,
+                         float* d_x_accum, dr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K11  fused sigmoid + binary cross-entropy (+ gradient wrt the logit).
+ * mode 0: tf.losses.sigmoid_cross_entropy(labels, logits)  (examples/train_fm_on_movielens_estimator.py:46)
+ * mode 1: tf.losses.log_loss(labels, sigmoid(logits))      (examples/train_deepfm_on_movielens_estimator.py:47)
+ * mode 2: tf.keras.losses.binary_crossentropy(labels, sigmoid(logits)) (examples/train_deepfm_on_movielens_keras.py:43)
+ * prob[n] = sigmoid(logit) (may be NULL); d_logit[n] = d(mean loss)/d logit (may be NULL);
+ * loss_out[1] = mean loss (deterministic two-stage reduction; workspace >= 1024 floats).
+ * ---------------------------------------------------------------------------------------- */
+int dr_bce_fwd_bwd(const float* logits, const float* labels, int64_t n, int32_t mode, float* prob,
+                   float* d_logit, float* loss_out, float* workspace, dr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DR_HOTPATH_H */

@@ -1,0 +1,137 @@
+"""ORACLE — test infrastructure only (see oracle/README.md).
+
+torch-CPU restatement of the same math as oracle/tf_semantics.py, used for two things only:
+  1. gradients: the reference has no backward code (TF autodiff) so the gradient oracle is
+     torch autograd over this restatement (its forward is checked against tf_semantics in tests/);
+  2. bench.py's `cpu_baseline` leg ("port"): one DeepFM training step on the host cores.
+Never imported by deep_recommenders_amd/.
+"""
+import torch
+
+
+def pool_fields(table, ids, col_start, row_base):
+    """[TF] B5 mean-combiner per field.  ids [B, C] (-1 = missing) -> list of F tensors [B, D]."""
+    out = []
+    F = len(row_base)
+    for f in range(F):
+        cols = ids[:, col_start[f]:col_start[f + 1]]
+        mask = cols >= 0
+        rows = (cols.clamp(min=0) + row_base[f])
+        e = table[rows] * mask.unsqueeze(-1).to(table.dtype)
+        acc = e[:, 0]
+        for l in range(1, e.shape[1]):          # left-to-right, id order
+            acc = acc + e[:, l]
+        cnt = mask.sum(1).clamp(min=1).to(table.dtype).unsqueeze(-1)
+        out.append(acc / cnt)
+    return out
+
+
+def first_order(lin_w, ids, col_start, row_base, bias):
+    B = ids.shape[0]
+    lin = torch.zeros(B, dtype=lin_w.dtype)
+    for f in range(len(row_base)):
+        cols = ids[:, col_start[f]:col_start[f + 1]]
+        mask = cols >= 0
+        rows = cols.clamp(min=0) + row_base[f]
+        lin = lin + (lin_w[rows] * mask.to(lin_w.dtype)).sum(1)
+    return lin + bias
+
+
+def fm_second_order(stack):
+    """keras/models/ranking/fm.py:28-35"""
+    s = stack.sum(1)
+    return 0.5 * (s * s - (stack * stack).sum(1)).sum(1)
+
+
+def emb_fm_forward(table, lin_w, bias, ids, col_start, row_base):
+    embs = pool_fields(table, ids, col_start, row_base)
+    stack = torch.stack(embs, 1)
+    concat = torch.cat(embs, 1)
+    logit = fm_second_order(stack)
+    if lin_w is not None:
+        logit = logit + first_order(lin_w, ids, col_start, row_base, bias)
+    return concat, stack.sum(1), logit
+
+
+def dnn(x, kernels, biases):
+    """keras deepfm.py:30-34 / estimator dnn.py:17-29: relu hidden layers, linear last layer."""
+    for W, b in zip(kernels[:-1], biases[:-1]):
+        x = torch.relu(x @ W + b)
+    return x @ kernels[-1] + biases[-1]
+
+
+def deepfm_logit(table, lin_w, bias, ids, col_start, row_base, kernels, biases, dense=None):
+    concat, _, fm_logit = emb_fm_forward(table, lin_w, bias, ids, col_start, row_base)
+    x = concat if dense is None else torch.cat([concat, dense], 1)
+    return fm_logit + dnn(x, kernels, biases).squeeze(1)
+
+
+def cross(x0, x, W, b, diag_scale=0.0):
+    """keras/models/ranking/dcn.py:81-88"""
+    prod = x @ W
+    if b is not None:
+        prod = prod + b
+    if diag_scale:
+        prod = prod + diag_scale * x
+    return x0 * prod + x
+
+
+def sigmoid_cross_entropy(labels, logits):
+    """[TF] B9"""
+    return (torch.clamp(logits, min=0) - logits * labels + torch.log1p(torch.exp(-logits.abs()))).mean()
+
+
+def log_loss(labels, p, eps=1e-7):
+    """[TF] B10"""
+    return (-labels * torch.log(p + eps) - (1 - labels) * torch.log(1 - p + eps)).mean()
+
+
+def keras_bce(labels, p, eps=1e-7):
+    """[TF] B11"""
+    p = p.clamp(eps, 1 - eps)
+    return (-(labels * torch.log(p + eps) + (1 - labels) * torch.log(1 - p + eps))).mean()
+
+
+def inbatch_softmax_loss(q, c, sample_weight=None, cand_prob=None, cand_ids=None, temperature=None):
+    """Retrieval.call all-optional-branches restatement (sbcnm.py:120-151)."""
+    import numpy as np
+    scores = q @ c.t()
+    B = q.shape[0]
+    labels = torch.eye(B, dtype=q.dtype)
+    if cand_prob is not None:
+        scores = scores - torch.log(cand_prob)
+    if cand_ids is not None:
+        ident = cand_ids.reshape(-1, 1)
+        dup = (ident == ident.t()).to(q.dtype) - labels
+        scores = scores + dup * float(np.finfo(np.float32).min / 100.0)
+    if temperature is not None:
+        scores = scores / temperature
+    per = torch.logsumexp(scores, 1) - (scores * labels).sum(1)
+    if sample_weight is not None:
+        per = per * sample_weight
+    return per.sum()
+
+
+def deepfm_train_step_sgd(params, ids, dense, labels, col_start, row_base, lr):
+    """One SGD step of DeepFM (forward, log-loss, backward, update) on the host — the cpu_baseline port.
+    Embedding gradients are sparse (rows touched), like TF's IndexedSlices path."""
+    table, lin_w, bias, kernels, biases = params
+    F = len(row_base)
+    rows = ids + torch.as_tensor(row_base)[None, :]              # single-valued fields
+    emb = torch.nn.functional.embedding(rows, table)            # [B, F, D]
+    emb.requires_grad_(True)
+    lw = lin_w[rows]
+    lw.requires_grad_(True)
+    ks = [k.requires_grad_(True) for k in kernels]
+    bs = [b.requires_grad_(True) for b in biases]
+    concat = emb.reshape(emb.shape[0], -1)
+    x = concat if dense is None else torch.cat([concat, dense], 1)
+    logit = fm_second_order(emb) + lw.sum(1) + bias + dnn(x, ks, bs).squeeze(1)
+    loss = sigmoid_cross_entropy(labels, logit)
+    grads = torch.autograd.grad(loss, [emb, lw] + ks + bs)
+    with torch.no_grad():
+        table.index_add_(0, rows.reshape(-1), grads[0].reshape(-1, table.shape[1]), alpha=-lr)
+        lin_w.index_add_(0, rows.reshape(-1), grads[1].reshape(-1), alpha=-lr)
+        for p, g in zip(ks + bs, grads[2:]):
+            p.sub_(lr * g)
+    return float(loss)

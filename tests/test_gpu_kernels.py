@@ -1,0 +1,267 @@
+"""GPU parity tests: every C-ABI kernel against the CPU oracle on the same seeded inputs.
+Bit-exact for the integer path and for pure-copy floating point; fp32 tolerances are written per test."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import tf_semantics as O
+from oracle import torch_ref as T
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from deep_recommenders_amd import ops as _ops
+    return _ops
+
+
+def _dev(a, dtype=None):
+    t = torch.as_tensor(a)
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+# ---------------------------------------------------------------- K1
+def test_hash_bucket_i64_bit_exact(ops):
+    rng = np.random.default_rng(42)
+    B, C = 4099, 5
+    keys = np.empty((B, C), dtype=np.int64)
+    keys[:, 0] = rng.integers(0, 10, size=B)                     # 1 digit  (1-3 byte branch)
+    keys[:, 1] = rng.integers(1000, 9999999, size=B)             # 4-7 bytes
+    keys[:, 2] = rng.integers(10**8, 10**16, size=B)             # 8-16 bytes
+    keys[:, 3] = rng.integers(10**16, 2**63 - 1, size=B)         # 17-19 bytes (17-32 branch)
+    keys[:, 4] = rng.integers(-2**63, 2**63 - 1, size=B)         # signed, up to 20 bytes
+    keys[::7, 1] = -1                                           # dropped entries
+    keys[0, 4] = -2**63
+    keys[1, 4] = 2**63 - 1
+    keys[2, 4] = 0
+    buckets = np.array([10, 6040, 10_000_000, 2**40 + 7, 3952], dtype=np.int64)
+    got = ops.hash_bucket_i64(_dev(keys), _dev(buckets)).cpu().numpy()
+    for c in range(C):
+        want = O.hash_bucket_i64(keys[:, c], int(buckets[c]))
+        np.testing.assert_array_equal(got[:, c], want)
+    # pass-through column (0 buckets): ids unchanged, -1 stays -1
+    got = ops.hash_bucket_i64(_dev(keys[:, :1]), _dev(np.array([0]))).cpu().numpy()
+    np.testing.assert_array_equal(got, keys[:, :1])
+
+
+def test_hash_bucket_upstream_vectors_on_device(ops):
+    got = ops.hash_bucket_strings(["Hello", "TensorFlow", "2.x"], 3).cpu().tolist()
+    assert got == [0, 2, 2]
+    assert ops.hash_bucket_strings(["1"], 6040).item() == 1529
+    assert ops.hash_bucket_i64(_dev(np.array([[1], [2]])), _dev(np.array([100]))).cpu().reshape(-1).tolist() == [49, 59]
+
+
+def test_hash_bucket_bytes_all_branches(ops):
+    rng = np.random.default_rng(7)
+    strs = [b""] + [bytes(rng.integers(1, 256, size=n, dtype=np.uint8)) for n in
+                    list(range(1, 70)) + [64, 65, 127, 128, 129, 200, 255, 256, 1000]]
+    got = ops.hash_bucket_strings(strs, 1_000_003).cpu().numpy()
+    want = np.array([-1 if len(s) == 0 else O.fingerprint64(s) % 1_000_003 for s in strs])
+    np.testing.assert_array_equal(got, want)
+
+
+# ---------------------------------------------------------------- K2
+def test_vocab_lookup(ops):
+    keys = np.array([1, 18, 99, -1, 56, 25, 0], dtype=np.int64)
+    vocab = np.array([1, 18, 25, 35, 45, 50, 56], dtype=np.int64)
+    got = ops.vocab_lookup_i64(_dev(keys), _dev(vocab)).cpu().numpy()
+    want = O.vocab_lookup([int(k) for k in keys], [int(v) for v in vocab])
+    want[3] = -1
+    np.testing.assert_array_equal(got, want)
+    got = ops.vocab_lookup_strings(["F", "M", "Action", "", "FM"], ["F", "M"]).cpu().tolist()
+    assert got == [0, 1, -1, -1, -1]
+
+
+# ---------------------------------------------------------------- K3 / K4
+def _rand_problem(rng, B, Ls, Vs, D, p_missing=0.15):
+    F = len(Ls)
+    col_start = np.concatenate([[0], np.cumsum(Ls)]).astype(np.int32)
+    row_base = np.concatenate([[0], np.cumsum(Vs)[:-1]]).astype(np.int64)
+    ids = np.full((B, int(col_start[-1])), -1, dtype=np.int64)
+    for f in range(F):
+        for c in range(col_start[f], col_start[f + 1]):
+            col = rng.integers(0, Vs[f], size=B)
+            col[rng.random(B) < p_missing] = -1
+            ids[:, c] = col
+    R = int(np.sum(Vs))
+    table = (rng.standard_normal((R, D)) / np.sqrt(D)).astype(np.float32)
+    lin_w = rng.standard_normal(R).astype(np.float32)
+    return F, col_start, row_base, ids, table, lin_w
+
+
+@pytest.mark.parametrize("D,Ls", [(16, [1, 1, 1, 1, 1, 3, 1]), (64, [1] * 26), (128, [2, 1, 4]), (12, [1, 2]),
+                                  (64, [1] * 70), (4, [1, 1]), (256, [1, 2])])
+def test_emb_pool_fwd_matches_oracle(ops, D, Ls):
+    rng = np.random.default_rng(42)
+    B = 515
+    Vs = [int(v) for v in rng.integers(3, 400, size=len(Ls))]
+    F, col_start, row_base, ids, table, lin_w = _rand_problem(rng, B, Ls, Vs, D)
+    single = all(l == 1 for l in Ls) and F <= 64
+    cs = None if single else _dev(col_start)
+    concat, sum_x, fm = ops.emb_pool_fwd(_dev(ids), F, cs, _dev(row_base), _dev(table), _dev(lin_w), 0.125)
+    torch.cuda.synchronize()
+    ids_f = [ids[:, col_start[f]:col_start[f + 1]] for f in range(F)]
+    tabs = [table[row_base[f]:row_base[f] + Vs[f]] for f in range(F)]
+    embs = [O.embedding_mean_pool_fast(t, i) for t, i in zip(tabs, ids_f)]
+    want_concat = np.concatenate(embs, 1)
+    # pooled rows: pure copy / in-order sum + one divide -> bit-exact
+    np.testing.assert_array_equal(concat.cpu().numpy(), want_concat)
+    stack = np.stack(embs, 1)
+    want_logit = (O.first_order_gather(ids_f, [lin_w[row_base[f]:row_base[f] + Vs[f]] for f in range(F)], 0.125)
+                  + O.fm_second_order(stack)).reshape(-1)
+    # fp32 reduction order differs (butterfly vs sequential): 1e-5 relative to the magnitude of the terms
+    scale = np.abs(want_logit).max() + 1.0
+    np.testing.assert_allclose(fm.cpu().numpy(), want_logit, rtol=0, atol=2e-5 * scale)
+    np.testing.assert_allclose(sum_x.cpu().numpy(), stack.sum(1), rtol=0, atol=1e-5)
+
+
+def test_emb_pool_fwd_padded_concat_and_no_fm(ops):
+    rng = np.random.default_rng(1)
+    F, col_start, row_base, ids, table, lin_w = _rand_problem(rng, 100, [1] * 5, [50] * 5, 16)
+    ld = 5 * 16 + 16
+    concat, sum_x, fm = ops.emb_pool_fwd(_dev(ids), F, None, _dev(row_base), _dev(table), None, 0.0, ld_concat=ld,
+                                         want_sum_x=False, want_fm=False)
+    assert sum_x is None and fm is None
+    want = np.concatenate([O.embedding_mean_pool_fast(table[row_base[f]:row_base[f] + 50], ids[:, f]) for f in range(5)], 1)
+    np.testing.assert_array_equal(concat[:, :80].cpu().numpy(), want)
+    assert float(concat[:, 80:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("D,Ls,strided", [(16, [1, 1, 3, 1], 1), (64, [1] * 26, 1), (64, [1] * 26, 0), (128, [2, 1], 1),
+                                          (12, [1, 2], 1)])
+def test_emb_pool_bwd_matches_autograd_oracle(ops, D, Ls, strided):
+    from deep_recommenders_amd import _lib
+    _lib.lib().dr_debug_set_bwd_strided(strided)
+    rng = np.random.default_rng(3)
+    B = 300
+    Vs = [int(v) for v in rng.integers(20, 400, size=len(Ls))]
+    F, col_start, row_base, ids, table, lin_w = _rand_problem(rng, B, Ls, Vs, D)
+    d_concat = rng.standard_normal((B, F * D)).astype(np.float32)
+    d_fm = rng.standard_normal(B).astype(np.float32)
+    # oracle: autograd through the torch restatement (fp64 to make it the reference)
+    tt = torch.tensor(table, dtype=torch.float64, requires_grad=True)
+    tl = torch.tensor(lin_w, dtype=torch.float64, requires_grad=True)
+    concat_o, _, logit_o = T.emb_fm_forward(tt, tl, 0.0, torch.tensor(ids), col_start.tolist(), row_base.tolist())
+    obj = (concat_o * torch.tensor(d_concat, dtype=torch.float64)).sum() + (logit_o * torch.tensor(d_fm, dtype=torch.float64)).sum()
+    obj.backward()
+    # device
+    d_ids = _dev(ids)
+    cs, rb = _dev(col_start), _dev(row_base)
+    concat, sum_x, _ = ops.emb_pool_fwd(d_ids, F, cs, rb, _dev(table), _dev(lin_w), 0.0)
+    g_table = torch.zeros_like(_dev(table))
+    g_lin = torch.zeros_like(_dev(lin_w))
+    ops.emb_pool_bwd(d_ids, F, cs, rb, D, _dev(d_concat), concat, sum_x, _dev(d_fm), 1.0, g_table, g_lin)
+    torch.cuda.synchronize()
+    _lib.lib().dr_debug_set_bwd_strided(1)
+    gt = tt.grad.numpy()
+    np.testing.assert_allclose(g_table.cpu().numpy(), gt, rtol=1e-4, atol=1e-5 * (np.abs(gt).max() + 1))
+    np.testing.assert_allclose(g_lin.cpu().numpy(), tl.grad.numpy(), rtol=1e-4, atol=1e-5)
+    # fused-SGD form: dst = parameter, scale = -lr
+    lr = 0.05
+    p_table = _dev(table).clone()
+    p_lin = _dev(lin_w).clone()
+    ops.emb_pool_bwd(d_ids, F, cs, rb, D, _dev(d_concat), concat, sum_x, _dev(d_fm), -lr, p_table, p_lin)
+    np.testing.assert_allclose(p_table.cpu().numpy(), table - lr * gt, rtol=1e-4, atol=1e-5 * (np.abs(gt).max() + 1))
+
+
+# ---------------------------------------------------------------- K6
+def test_fm2_fwd_bwd(ops):
+    rng = np.random.RandomState(0)
+    x = rng.normal(size=(10, 5, 5)).astype(np.float32)      # tests/keras/test_fm.py:17-26 shape
+    out = ops.fm2_fwd(_dev(x)).cpu().numpy()
+    np.testing.assert_allclose(out, O.fm_second_order(x), rtol=1e-6, atol=1e-6)
+    x = rng.normal(size=(333, 26, 64)).astype(np.float32)
+    out = ops.fm2_fwd(_dev(x)).cpu().numpy()
+    want = O.fm_second_order(x)
+    np.testing.assert_allclose(out, want, rtol=0, atol=1e-5 * np.abs(want).max())
+    g = rng.normal(size=(333,)).astype(np.float32)
+    dx = ops.fm2_bwd(_dev(x), _dev(g)).cpu().numpy()
+    want_dx = g[:, None, None] * (x.sum(1, keepdims=True) - x)
+    np.testing.assert_allclose(dx, want_dx, rtol=1e-5, atol=1e-5)
+
+
+# ---------------------------------------------------------------- K7
+@pytest.mark.parametrize("M,K,N,act", [(1, 3, 1, 0), (130, 70, 33, 1), (257, 1677, 256, 1), (512, 256, 32, 1), (100, 32, 1, 0),
+                                       (300, 129, 131, 0)])
+def test_linear_fwd_bwd(ops, M, K, N, act):
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    y = ops.linear_fwd(_dev(x), _dev(W), _dev(b), act)
+    want = O.dense(x, W, b, "relu" if act else None)
+    ref64 = x.astype(np.float64) @ W.astype(np.float64) + b
+    if act:
+        ref64 = np.maximum(ref64, 0)
+    tol = 2e-6 * np.sqrt(K) * (np.abs(ref64).max() + 1)      # fp32 round-off of a K-long fmaf chain
+    np.testing.assert_allclose(y.cpu().numpy(), ref64, rtol=0, atol=tol)
+    np.testing.assert_allclose(y.cpu().numpy(), want, rtol=0, atol=2 * tol)
+    # backward
+    dy = rng.standard_normal((M, N)).astype(np.float32)
+    relu_src = rng.standard_normal((M, K)).astype(np.float32)
+    dx = ops.linear_bwd_dx(_dev(dy), _dev(W), _dev(relu_src)).cpu().numpy()
+    want_dx = (dy.astype(np.float64) @ W.T.astype(np.float64)) * (relu_src > 0)
+    np.testing.assert_allclose(dx, want_dx, rtol=0, atol=2e-6 * np.sqrt(N) * (np.abs(want_dx).max() + 1))
+    dW = torch.zeros((K, N), device="cuda")
+    db = torch.zeros(N, device="cuda")
+    ops.linear_bwd_dw(_dev(x), _dev(dy), 1.0, dW, db)
+    want_dW = x.T.astype(np.float64) @ dy.astype(np.float64)
+    np.testing.assert_allclose(dW.cpu().numpy(), want_dW, rtol=0, atol=4e-6 * np.sqrt(M) * (np.abs(want_dW).max() + 1))
+    np.testing.assert_allclose(db.cpu().numpy(), dy.astype(np.float64).sum(0), rtol=0, atol=1e-5 * np.sqrt(M) * 4)
+
+
+def test_linear_transpose_detecting(ops):
+    # A = I with an ASYMMETRIC B catches a swapped C/D fragment layout
+    K = N = 64
+    x = np.eye(K, dtype=np.float32)
+    W = np.arange(K * N, dtype=np.float32).reshape(K, N)
+    y = ops.linear_fwd(_dev(x), _dev(W), None, 0).cpu().numpy()
+    np.testing.assert_array_equal(y, W)
+
+
+# ---------------------------------------------------------------- K8
+def test_cross_known_answer_and_random(ops):
+    x0 = np.array([[0.1, 0.2, 0.3]], np.float32)
+    x = np.array([[0.4, 0.5, 0.6]], np.float32)
+    out, _ = ops.cross_fwd(_dev(x0), _dev(x), _dev(np.ones((3, 3), np.float32)), _dev(np.zeros(3, np.float32)))
+    np.testing.assert_allclose(out.cpu().numpy(), [[0.55, 0.8, 1.05]], rtol=1e-6, atol=1e-6)   # tests/keras/test_dcn.py:16-23
+    rng = np.random.default_rng(9)
+    M, Dm = 200, 77
+    x0 = rng.standard_normal((M, Dm)).astype(np.float32)
+    x = rng.standard_normal((M, Dm)).astype(np.float32)
+    W = (rng.standard_normal((Dm, Dm)) * 0.05).astype(np.float32)
+    b = rng.standard_normal(Dm).astype(np.float32)
+    out, prod = ops.cross_fwd(_dev(x0), _dev(x), _dev(W), _dev(b), 0.3, want_prod=True)
+    want = O.cross(x0, x, W, b, 0.3)
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(prod.cpu().numpy(), x @ W + b + 0.3 * x, rtol=1e-5, atol=1e-5)
+
+
+# ---------------------------------------------------------------- K11
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_bce_modes(ops, mode):
+    rng = np.random.default_rng(11)
+    n = 70001
+    x = (rng.standard_normal(n) * 3).astype(np.float32)
+    x[:4] = [30.0, -30.0, 90.0, -90.0]
+    z = (rng.random(n) < 0.25).astype(np.float32)
+    loss, prob, g = ops.bce_fwd_bwd(_dev(x), _dev(z), mode)
+    tx = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    tz = torch.tensor(z, dtype=torch.float64)
+    if mode == 0:
+        want = O.sigmoid_cross_entropy(z, x)
+        lo = T.sigmoid_cross_entropy(tz, tx)
+    elif mode == 1:
+        want = O.log_loss(z, O.sigmoid(x))
+        lo = T.log_loss(tz, torch.sigmoid(tx.float()).double())
+    else:
+        want = O.keras_binary_crossentropy(z, O.sigmoid(x))
+        lo = T.keras_bce(tz, torch.sigmoid(tx.float()).double())
+    assert abs(loss.item() - float(want)) <= 1e-5 * abs(float(want))        # north_star: 1e-5 relative on the loss
+    np.testing.assert_allclose(prob.cpu().numpy(), O.sigmoid(x), rtol=1e-6, atol=1e-7)
+    if mode == 0:
+        lo.backward()
+        np.testing.assert_allclose(g.cpu().numpy(), tx.grad.numpy(), rtol=1e-4, atol=1e-9)
