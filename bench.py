@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""Headline benchmark: examples/sec of one DeepFM training step (Criteo-shaped synthetic, BASELINE.json
+configs[2]: 26 sparse + 13 dense, 10 M vocab per field, dim 64, batch 65 536 per GPU) on N MI355X GPUs.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched under
+torch.distributed.run, one rank per GPU.  Rank 0 prints ONE JSON line.
+
+A "step" = hash -> fused gather+pool+FM forward -> DNN forward -> sigmoid-CE -> DNN backward ->
+scatter-add backward, with the SGD update fused into the wgrad / scatter kernels (no work skipped).
+Inputs (raw keys, dense features, labels) are resident in HBM before the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.3 TB/s achievable copy)
+MFMA_F32_PEAK_TF = 157.3  # dense fp32 MFMA peak (same guide)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=65536, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--fields", type=int, default=26)
+    ap.add_argument("--vocab", type=int, default=10_000_000)
+    ap.add_argument("--dim", type=int, default=64)
+    ap.add_argument("--dense", type=int, default=13)
+    ap.add_argument("--dnn", type=str, default="256,32")
+    ap.add_argument("--lr", type=float, default=0.01)
+    ap.add_argument("--ids", choices=["uniform", "zipf"], default="uniform")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pool", type=int, default=8, help="number of distinct synthetic batches cycled through")
+    return ap.parse_args()
+
+
+def synth_batches(a, device, rank):
+    """Criteo-shaped synthetic batches: raw int64 keys < 1e16 (<= 16 decimal chars),
+    13 dense fp32 ~ log1p(|N(0,1)|), labels ~ Bernoulli(0.25); seed 42 (+rank)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(42 + rank)
+    out = []
+    for _ in range(a.pool):
+        if a.ids == "uniform":
+            keys = torch.randint(0, 10**16, (a.batch, a.fields), device=device, generator=g)
+        else:   # Zipf(1.05)-like raw keys: few hot keys, long tail (hashing spreads them over rows)
+            u = torch.rand((a.batch, a.fields), device=device, generator=g, dtype=torch.float64)
+            al, n = 1.05, float(10**12)
+            keys = (((n ** (1 - al) - 1) * u + 1) ** (1 / (1 - al))).long().clamp(1, 10**12)
+        dense = torch.log1p(torch.randn((a.batch, a.dense), device=device, generator=g).abs()) if a.dense else None
+        labels = (torch.rand(a.batch, device=device, generator=g) < 0.25).float()
+        out.append((keys, dense, labels))
+    return out
+
+
+def cpu_baseline(a, dnn_units):
+    """The oracle port (oracle/torch_ref.py) of the same training step on the host cores, bounded sample."""
+    from oracle import torch_ref as T
+    import math
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    V = min(a.vocab, 1_000_000)         # 26 x 1 M x 64 fp32 = 6.7 GB: the full 66.6 GB does not fit typical host RAM
+    try:
+        import psutil
+        if psutil.virtual_memory().available < 24e9:
+            V = min(V, 100_000)
+    except Exception:
+        pass
+    F, D, B = a.fields, a.dim, a.batch
+    g = torch.Generator().manual_seed(42)
+    table = torch.empty((F * V, D)).normal_(0, 1 / math.sqrt(D), generator=g)
+    lin_w = torch.zeros(F * V)
+    d = F * D + a.dense
+    kernels, biases = [], []
+    for u in dnn_units + [1]:
+        lim = math.sqrt(6.0 / (d + u))
+        kernels.append((torch.rand((d, u), generator=g) * 2 - 1) * lim)
+        biases.append(torch.zeros(u))
+        d = u
+    row_base = [f * V for f in range(F)]
+    ids = torch.randint(0, V, (B, F), generator=g)
+    dense = torch.log1p(torch.randn((B, a.dense), generator=g).abs()) if a.dense else None
+    labels = (torch.rand(B, generator=g) < 0.25).float()
+    params = (table, lin_w, torch.zeros(()), kernels, biases)
+    T.deepfm_train_step_sgd(params, ids, dense, labels, None, row_base, a.lr)       # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while n < 20 and (n < 2 or time.perf_counter() - t0 < 10.0):
+        ids = torch.randint(0, V, (B, F), generator=g)
+        T.deepfm_train_step_sgd(params, ids, dense, labels, None, row_base, a.lr)
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"value": B / dt, "unit": "examples/sec", "cores": ncores, "kind": "port",
+            "sample": "%d DeepFM SGD steps of batch %d on torch-CPU (oracle/torch_ref.py), tables scaled to "
+                      "V=%d rows/field (%.1f GB); ids pre-hashed" % (n, B, V, F * V * D * 4 / 1e9)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus %d needs a torch.distributed.run launch with %d ranks" % (a.gpus, a.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dnn_units = [int(x) for x in a.dnn.split(",") if x]
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    if world == 1:
+        from deep_recommenders_amd.engine import DeepFMEngine
+        eng = DeepFMEngine(a.fields, a.vocab, a.dim, dnn_units, a.batch, num_dense=a.dense, lr=a.lr, device=device)
+    else:
+        from deep_recommenders_amd.sharded import ShardedDeepFMEngine
+        eng = ShardedDeepFMEngine(a.fields, a.vocab, a.dim, dnn_units, a.batch, num_dense=a.dense, lr=a.lr,
+                                  device=device, world=world, rank=rank)
+    batches = synth_batches(a, device, rank)
+
+    for i in range(a.warmup):
+        eng.train_step(*batches[i % len(batches)])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    # ---- timed region: exactly K steps; per-kernel HIP events ride along on the launch stream -------
+    prof = getattr(eng, "enable_kernel_events", None)
+    if prof is not None:
+        eng.enable_kernel_events(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        eng.train_step(*batches[(a.warmup + i) % len(batches)])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    loss = float(eng.loss.item())
+    ms = dt / a.steps * 1e3
+    value = a.batch * world * a.steps / dt
+
+    kernels = eng.kernel_event_summary() if prof is not None else {}
+    roof_all = []
+    for name, k in kernels.items():
+        sec = k["ms"] * 1e-3
+        if k["bound"] == "hbm":
+            ach, peak, unit = k["alg_bytes"] / sec / 1e9, HBM_PEAK_GBS, "GB/s"
+        else:
+            ach, peak, unit = k["alg_flops"] / sec / 1e12, MFMA_F32_PEAK_TF, "TFLOP/s"
+        roof_all.append({"kernel": name, "bound": k["bound"], "achieved": round(ach, 2), "peak": peak, "unit": unit,
+                         "frac": round(ach / peak, 4), "traffic": None, "avg_us": round(k["ms"] * 1e3, 2),
+                         "launches": k["n"]})
+    roof_all.sort(key=lambda r: -r["avg_us"])
+    roofline = dict(roof_all[0]) if roof_all else None
+
+    if rank == 0:
+        out = {
+            "metric": "examples/sec/node DeepFM (26 sparse feats, 10M vocab, dim 64)",
+            "value": round(value, 1), "unit": "examples/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "DeepFM Criteo-shape synthetic training step (BASELINE.json configs[2]): %d sparse + %d "
+                                   "dense, %d vocab/field hashed on device, dim %d, DNN %s+[1] relu, sigmoid-CE, fused SGD; "
+                                   "batch %d per GPU, ids %s; tables %s"
+                                   % (a.fields, a.dense, a.vocab, a.dim, dnn_units, a.batch, a.ids,
+                                      "on one GPU (%.1f GB)" % (a.fields * a.vocab * a.dim * 4 / 1e9) if world == 1
+                                      else "row-sharded over %d GPUs (id %% N), RCCL all-to-all" % world),
+                       "global_batch": a.batch * world, "parallelism": "single" if world == 1 else "dp%d+row-sharded-tables" % world,
+                       "final_loss": round(loss, 6)},
+            "roofline": roofline,
+            "roofline_all": roof_all,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(a, dnn_units)
+            except Exception as e:     # the baseline is reported, never the thing measured
+                out["cpu_baseline"] = {"value": None, "unit": "examples/sec", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

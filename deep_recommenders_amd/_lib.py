@@ -18,8 +18,8 @@ SIGNATURES = {
     "dr_hash_bucket_bytes": [_p, _p, _i64, _u64, _p, _p],
     "dr_vocab_lookup_i64": [_p, _i64, _p, _i32, _p, _p],
     "dr_vocab_lookup_bytes": [_p, _p, _i64, _p, _p, _i32, _p, _p],
-    "dr_emb_pool_fwd": [_p, _i64, _i32, _i32, _p, _p, _p, _i32, _p, _f32, _p, _i64, _p, _p, _p],
-    "dr_emb_pool_bwd": [_p, _i64, _i32, _i32, _p, _p, _i32, _p, _i64, _p, _i64, _p, _p, _f32, _p, _p, _p],
+    "dr_emb_pool_fwd": [_p, _i64, _i32, _i32, _p, _p, _p, _i32, _p, _p, _p, _i64, _p, _p, _p],
+    "dr_emb_pool_bwd": [_p, _i64, _i32, _i32, _p, _p, _i32, _p, _i64, _p, _i64, _p, _p, _f32, _p, _p, _p, _p],
     "dr_fm2_fwd": [_p, _i64, _i32, _i32, _p, _p],
     "dr_fm2_bwd": [_p, _p, _i64, _i32, _i32, _p, _p],
     "dr_linear_fwd": [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p],
@@ -27,7 +27,10 @@ SIGNATURES = {
     "dr_linear_bwd_dw": [_p, _i64, _p, _i64, _i64, _i32, _i32, _f32, _p, _i64, _p, _p],
     "dr_cross_fwd": [_p, _p, _i64, _p, _i64, _p, _f32, _i64, _i32, _p, _p, _p],
     "dr_cross_combine_bwd": [_p, _p, _p, _i64, _i32, _i64, _f32, _p, _p, _p, _p],
-    "dr_bce_fwd_bwd": [_p, _p, _i64, _i32, _p, _p, _p, _p, _p],
+    "dr_bce_fwd_bwd": [_p, _p, _i64, _p, _i64, _i32, _p, _p, _p, _p, _p],
+    "dr_sigmoid_fwd": [_p, _i64, _p, _p],
+    "dr_sigmoid_bwd": [_p, _p, _i64, _p, _p],
+    "dr_bce_prob_fwd_bwd": [_p, _p, _i64, _i32, _p, _p, _p, _p],
     "dr_version": [],
 }
 _RESTYPE = {"dr_version": ctypes.c_char_p}

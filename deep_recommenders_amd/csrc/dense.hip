@@ -48,6 +48,7 @@ struct GemmArgs {
     int32_t accumulate;       // MASK: add to existing C
     float* colsum_dst;        // ATOMIC: dstb (may be null)
     int32_t split;            // ATOMIC: number of reduction splits (gridDim.y)
+    int32_t a_vec, b_vec;     // operand base 16-B aligned and ld % 4 == 0 -> float4 loads allowed
 };
 
 // bijective XCD-aware remap (cdna guide T1): consecutive logical tile ids -> same XCD
@@ -60,16 +61,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // load a float4 of an operand tile with edge guards.  RC layout: element (i, r) at p[i*ld + r], vector
 // runs along r; non-RC: element (r, i) at p[r*ld + i], vector runs along i.
 __device__ __forceinline__ float4 guarded_ld4(const float* __restrict__ p, int64_t ld, int64_t row, int64_t nrows,
-                                              int64_t col, int64_t ncols) {
+                                              int64_t col, int64_t ncols, bool vec_ok) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row < nrows) {
         const float* q = p + row * ld + col;
-        if (col + 3 < ncols) {
+        if (vec_ok && col + 3 < ncols) {
             v = *reinterpret_cast<const float4*>(q);
         } else {
             if (col < ncols) v.x = q[0];
             if (col + 1 < ncols) v.y = q[1];
             if (col + 2 < ncols) v.z = q[2];
+            if (col + 3 < ncols) v.w = q[3];
         }
     }
     return v;
@@ -119,17 +121,17 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
             const int idx = tid + 256 * q;
             if (A_RC) {   // 128 rows(i) x 8 float4 along r
                 const int i = idx >> 3, r4 = idx & 7;
-                ra[q] = guarded_ld4(g.A, g.lda, m0 + i, g.M, r0 + r4 * 4, r_end);
+                ra[q] = guarded_ld4(g.A, g.lda, m0 + i, g.M, r0 + r4 * 4, r_end, g.a_vec);
             } else {      // 32 rows(r) x 32 float4 along i
                 const int r = idx >> 5, c4 = idx & 31;
-                ra[q] = guarded_ld4(g.A, g.lda, r0 + r, r_end, m0 + c4 * 4, g.M);
+                ra[q] = guarded_ld4(g.A, g.lda, r0 + r, r_end, m0 + c4 * 4, g.M, g.a_vec);
             }
             if (B_RC) {
                 const int j = idx >> 3, r4 = idx & 7;
-                rb[q] = guarded_ld4(g.B, g.ldb, (int64_t)n0 + j, g.N, r0 + r4 * 4, r_end);
+                rb[q] = guarded_ld4(g.B, g.ldb, (int64_t)n0 + j, g.N, r0 + r4 * 4, r_end, g.b_vec);
             } else {
                 const int r = idx >> 5, c4 = idx & 31;
-                rb[q] = guarded_ld4(g.B, g.ldb, r0 + r, r_end, (int64_t)n0 + c4 * 4, g.N);
+                rb[q] = guarded_ld4(g.B, g.ldb, r0 + r, r_end, (int64_t)n0 + c4 * 4, g.N, g.b_vec);
             }
         }
     };
@@ -226,7 +228,9 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
 }
 
 template <bool A_RC, bool B_RC, int EPI>
-int launch(const GemmArgs& g, hipStream_t s) {
+int launch(GemmArgs& g, hipStream_t s) {
+    g.a_vec = ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0 && (g.lda & 3) == 0) ? 1 : 0;
+    g.b_vec = ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0 && (g.ldb & 3) == 0) ? 1 : 0;
     const int tiles_n = (g.N + BN - 1) / BN;
     const int64_t tiles_m = (g.M + BM - 1) / BM;
     if (tiles_m * tiles_n > 0x7fffffff) return DR_EINVAL;
@@ -273,8 +277,8 @@ __global__ __launch_bounds__(256) void cross_combine_bwd_kernel(const float* __r
     }
 }
 
-bool bad_ld(int64_t ld, int64_t min) { return ld < min || (ld & 3); }
-bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
+bool bad_ld(int64_t ld, int64_t min) { return ld < min; }
+bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3) != 0; }
 
 }  // namespace
 

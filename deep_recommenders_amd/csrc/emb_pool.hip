@@ -35,7 +35,7 @@ __device__ __forceinline__ float4 f4shfl_xor(float4 v, int m) {
 template <int LPR, int U>
 __global__ __launch_bounds__(256) void emb_pool_fwd_sv_kernel(
     const int64_t* __restrict__ ids, int64_t B, int32_t F, const int64_t* __restrict__ row_base,
-    const float* __restrict__ table, int32_t D, const float* __restrict__ lin_w, float lin_bias,
+    const float* __restrict__ table, int32_t D, const float* __restrict__ lin_w, const float* __restrict__ lin_bias,
     float* __restrict__ concat, int64_t ld, float* __restrict__ sum_x, float* __restrict__ fm_logit) {
     constexpr int NS = DR_WAVE / LPR;
     const int lane = threadIdx.x & 63;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void emb_pool_fwd_sv_kernel(
             float t = (S.x * S.x - SS.x) + (S.y * S.y - SS.y) + (S.z * S.z - SS.z) + (S.w * S.w - SS.w);
 #pragma unroll
             for (int m = 1; m < LPR; m <<= 1) t += __shfl_xor(t, m, 64);
-            if (lane == 0) fm_logit[b] = lin_bias + lin + 0.5f * t;
+            if (lane == 0) fm_logit[b] = (lin_bias != nullptr ? lin_bias[0] : 0.f) + lin + 0.5f * t;
         }
     }
 }
@@ -108,7 +108,7 @@ template <int LPR>
 __global__ __launch_bounds__(256) void emb_pool_fwd_bag_kernel(
     const int64_t* __restrict__ ids, int64_t B, int32_t F, int32_t C, const int32_t* __restrict__ col_start,
     const int64_t* __restrict__ row_base, const float* __restrict__ table, int32_t D,
-    const float* __restrict__ lin_w, float lin_bias, float* __restrict__ concat, int64_t ld,
+    const float* __restrict__ lin_w, const float* __restrict__ lin_bias, float* __restrict__ concat, int64_t ld,
     float* __restrict__ sum_x, float* __restrict__ fm_logit) {
     constexpr int NS = DR_WAVE / LPR;
     const int lane = threadIdx.x & 63;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void emb_pool_fwd_bag_kernel(
             float t = (S.x * S.x - SS.x) + (S.y * S.y - SS.y) + (S.z * S.z - SS.z) + (S.w * S.w - SS.w);
 #pragma unroll
             for (int m = 1; m < LPR; m <<= 1) t += __shfl_xor(t, m, 64);
-            if (lane == 0) fm_logit[b] = lin_bias + lin + 0.5f * t;
+            if (lane == 0) fm_logit[b] = (lin_bias != nullptr ? lin_bias[0] : 0.f) + lin + 0.5f * t;
         }
     }
 }
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void emb_pool_bwd_kernel(
     const int64_t* __restrict__ row_base, int32_t D, const float* __restrict__ d_concat, int64_t ld_dc,
     const float* __restrict__ concat, int64_t ld_c, const float* __restrict__ sum_x,
     const float* __restrict__ d_fm_logit, float scale, float* __restrict__ dst_table,
-    float* __restrict__ dst_lin) {
+    float* __restrict__ dst_lin, float* __restrict__ dst_bias) {
     constexpr int NS = DR_WAVE / LPR;
     const int lane = threadIdx.x & 63;
     const int slot = lane / LPR;
@@ -186,8 +186,10 @@ __global__ __launch_bounds__(256) void emb_pool_bwd_kernel(
 #pragma unroll
     for (int j = 0; j < 4; ++j) doff[j] = STRIDED ? (j * LPR + sub) : (sub * 4 + j);
 
+    float dl_sum = 0.f;
     for (int64_t b = wave0; b < B; b += nwaves) {
         const float dl = d_fm_logit != nullptr ? d_fm_logit[b] : 0.f;
+        dl_sum += dl;
         float s[4] = {0.f, 0.f, 0.f, 0.f};
         if (d_fm_logit != nullptr && sum_x != nullptr) {
 #pragma unroll
@@ -223,6 +225,7 @@ __global__ __launch_bounds__(256) void emb_pool_bwd_kernel(
             }
         }
     }
+    if (dst_bias != nullptr && d_fm_logit != nullptr && lane == 0 && dl_sum != 0.f) unsafeAtomicAdd(dst_bias, scale * dl_sum);
 }
 
 int lpr_for(int D) {
@@ -247,7 +250,7 @@ int lpr_for(int D) {
 
 extern "C" int dr_emb_pool_fwd(const int64_t* ids, int64_t B, int32_t F, int32_t C, const int32_t* col_start,
                                const int64_t* row_base, const float* table, int32_t D, const float* lin_w,
-                               float lin_bias, float* concat, int64_t ld_concat, float* sum_x, float* fm_logit,
+                               const float* lin_bias, float* concat, int64_t ld_concat, float* sum_x, float* fm_logit,
                                dr_stream_t stream) {
     if (B < 0 || F <= 0 || C < F || D < 4 || D > 256 || (D & 3) || ld_concat < (int64_t)F * D || (ld_concat & 3))
         return DR_EINVAL;
@@ -286,7 +289,7 @@ extern "C" int dr_emb_pool_bwd(const int64_t* ids, int64_t B, int32_t F, int32_t
                                const int64_t* row_base, int32_t D, const float* d_concat, int64_t ld_dconcat,
                                const float* concat, int64_t ld_concat, const float* sum_x,
                                const float* d_fm_logit, float scale, float* dst_table, float* dst_lin,
-                               dr_stream_t stream) {
+                               float* dst_bias, dr_stream_t stream) {
     if (B < 0 || F <= 0 || C < F || D < 4 || D > 256 || (D & 3)) return DR_EINVAL;
     if (B == 0) return DR_OK;
     if (!ids || !row_base || !dst_table || !col_start) return DR_EINVAL;
@@ -299,14 +302,14 @@ extern "C" int dr_emb_pool_bwd(const int64_t* ids, int64_t B, int32_t F, int32_t
 #define CALL(L)                                                                                                    \
     hipLaunchKernelGGL((emb_pool_bwd_kernel<L, true>), dim3(grid), dim3(256), 0, dr_s(stream), ids, B, F, C,       \
                        col_start, row_base, D, d_concat, ld_dconcat, concat, ld_concat, sum_x, d_fm_logit, scale,   \
-                       dst_table, dst_lin);
+                       dst_table, dst_lin, dst_bias);
         DR_DISPATCH_LPR(lpr, CALL)
 #undef CALL
     } else {
 #define CALL(L)                                                                                                    \
     hipLaunchKernelGGL((emb_pool_bwd_kernel<L, false>), dim3(grid), dim3(256), 0, dr_s(stream), ids, B, F, C,      \
                        col_start, row_base, D, d_concat, ld_dconcat, concat, ld_concat, sum_x, d_fm_logit, scale,   \
-                       dst_table, dst_lin);
+                       dst_table, dst_lin, dst_bias);
         DR_DISPATCH_LPR(lpr, CALL)
 #undef CALL
     }

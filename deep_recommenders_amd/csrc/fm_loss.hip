@@ -54,7 +54,8 @@ constexpr int BCE_BLOCKS = 512;   // partial sums; stage 2 is one block
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
-__global__ __launch_bounds__(256) void bce_stage1(const float* __restrict__ logits, const float* __restrict__ labels,
+__global__ __launch_bounds__(256) void bce_stage1(const float* __restrict__ logits, const float* __restrict__ logits_b,
+                                                  int64_t ldb, const float* __restrict__ labels,
                                                   int64_t n, int mode, float* __restrict__ prob,
                                                   float* __restrict__ d_logit, float* __restrict__ partial) {
     __shared__ float red[4];
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256) void bce_stage1(const float* __restrict__ logi
     float acc = 0.f;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float x = logits[i], z = labels[i];
+        const float x = logits[i] + (logits_b != nullptr ? logits_b[i * ldb] : 0.f), z = labels[i];
         const float p = sigmoidf_(x);
         float l, g;
         if (mode == 0) {
@@ -104,6 +105,46 @@ __global__ __launch_bounds__(256) void bce_stage2(const float* __restrict__ part
     if (threadIdx.x == 0) loss_out[0] = (float)(((red[0] + red[1]) + (red[2] + red[3])) / (double)n);
 }
 
+
+__global__ __launch_bounds__(256) void sigmoid_fwd_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ y) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = sigmoidf_(x[i]);
+}
+__global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                          int64_t n, float* __restrict__ dx) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float p = y[i];
+        dx[i] = dy[i] * p * (1.f - p);
+    }
+}
+
+// losses on PROBABILITIES (the reference applies them to the model's sigmoid output):
+// mode 1 = tf.losses.log_loss ([TF] B10), mode 2 = keras binary_crossentropy ([TF] B11)
+__global__ __launch_bounds__(256) void bce_prob_stage1(const float* __restrict__ prob, const float* __restrict__ labels,
+                                                       int64_t n, int mode, float* __restrict__ d_prob,
+                                                       float* __restrict__ partial) {
+    __shared__ float red[4];
+    const float inv_n = 1.f / (float)n;
+    const float eps = 1e-7f;
+    float acc = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float p = prob[i], z = labels[i];
+        float pc = p, dclip = 1.f;
+        if (mode == 2) {
+            if (p < eps) { pc = eps; dclip = 0.f; }
+            else if (p > 1.f - eps) { pc = 1.f - eps; dclip = 0.f; }
+        }
+        acc += -z * logf(pc + eps) - (1.f - z) * logf(1.f - pc + eps);
+        if (d_prob != nullptr) d_prob[i] = (-z / (pc + eps) + (1.f - z) / (1.f - pc + eps)) * dclip * inv_n;
+    }
+    acc = dr_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 }  // namespace
 
 extern "C" int dr_fm2_fwd(const float* x, int64_t B, int32_t F, int32_t D, float* out, dr_stream_t stream) {
@@ -125,13 +166,43 @@ extern "C" int dr_fm2_bwd(const float* x, const float* d_out, int64_t B, int32_t
     return DR_OK;
 }
 
-extern "C" int dr_bce_fwd_bwd(const float* logits, const float* labels, int64_t n, int32_t mode, float* prob,
-                              float* d_logit, float* loss_out, float* workspace, dr_stream_t stream) {
+extern "C" int dr_bce_fwd_bwd(const float* logits, const float* logits_b, int64_t ld_b, const float* labels, int64_t n,
+                              int32_t mode, float* prob, float* d_logit, float* loss_out, float* workspace,
+                              dr_stream_t stream) {
     if (n <= 0 || mode < 0 || mode > 2) return DR_EINVAL;
     if (!logits || !labels || !loss_out || !workspace) return DR_EINVAL;
     const int grid = dr_grid_for(n, 256, BCE_BLOCKS);
-    hipLaunchKernelGGL(bce_stage1, dim3(grid), dim3(256), 0, dr_s(stream), logits, labels, n, mode, prob, d_logit,
-                       workspace);
+    hipLaunchKernelGGL(bce_stage1, dim3(grid), dim3(256), 0, dr_s(stream), logits, logits_b, ld_b, labels, n, mode,
+                       prob, d_logit, workspace);
+    hipLaunchKernelGGL(bce_stage2, dim3(1), dim3(256), 0, dr_s(stream), workspace, grid, n, loss_out);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+extern "C" int dr_sigmoid_fwd(const float* x, int64_t n, float* y, dr_stream_t stream) {
+    if (n < 0) return DR_EINVAL;
+    if (n == 0) return DR_OK;
+    if (!x || !y) return DR_EINVAL;
+    hipLaunchKernelGGL(sigmoid_fwd_kernel, dim3(dr_grid_for(n, 256)), dim3(256), 0, dr_s(stream), x, n, y);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+extern "C" int dr_sigmoid_bwd(const float* y, const float* dy, int64_t n, float* dx, dr_stream_t stream) {
+    if (n < 0) return DR_EINVAL;
+    if (n == 0) return DR_OK;
+    if (!y || !dy || !dx) return DR_EINVAL;
+    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(dr_grid_for(n, 256)), dim3(256), 0, dr_s(stream), y, dy, n, dx);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+extern "C" int dr_bce_prob_fwd_bwd(const float* prob, const float* labels, int64_t n, int32_t mode, float* d_prob,
+                                   float* loss_out, float* workspace, dr_stream_t stream) {
+    if (n <= 0 || (mode != 1 && mode != 2)) return DR_EINVAL;
+    if (!prob || !labels || !loss_out || !workspace) return DR_EINVAL;
+    const int grid = dr_grid_for(n, 256, BCE_BLOCKS);
+    hipLaunchKernelGGL(bce_prob_stage1, dim3(grid), dim3(256), 0, dr_s(stream), prob, labels, n, mode, d_prob, workspace);
     hipLaunchKernelGGL(bce_stage2, dim3(1), dim3(256), 0, dr_s(stream), workspace, grid, n, loss_out);
     DR_CHECK_LAUNCH();
     return DR_OK;

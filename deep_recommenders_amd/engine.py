@@ -1,0 +1,163 @@
+"""Lean DeepFM training engine: one fused training step (hash -> gather+pool+FM -> MLP tower -> loss ->
+tower backward -> scatter-add backward) over preallocated HBM buffers, every optimizer update fused into
+the producing kernel (SGD: dst += -lr * grad inside the scatter / wgrad epilogues).
+
+This is the path bench.py and __graft_entry__.smoke() time; the reference-shaped classes in
+deep_recommenders_amd.keras / .estimator run the same kernels through autograd.  Model = the reference's
+DeepFM (keras/models/ranking/deepfm.py:36-47 of the reference): sigmoid(FM(first-order, stacked embeddings)
++ Sequential(Dense(u, relu)..., Dense(1))(concat embeddings [+ dense features])); loss =
+tf.losses.sigmoid_cross_entropy on the logits (examples/train_fm_on_movielens_estimator.py:46).
+"""
+import math
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import ops
+
+
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+class DeepFMEngine:
+    def __init__(self, num_fields: int, vocab_per_field: int, dim: int, dnn_units: Sequence[int], batch: int,
+                 num_dense: int = 0, lr: float = 0.01, device="cuda", seed: int = 42, hashed: bool = True,
+                 table_init_std: Optional[float] = None, lin_init_std: float = 0.0):
+        self.F, self.V, self.D, self.B = num_fields, vocab_per_field, dim, batch
+        self.Nd, self.lr, self.dev, self.hashed = num_dense, lr, device, hashed
+        F, V, D, B = self.F, self.V, self.D, self.B
+        g = torch.Generator(device=device)
+        g.manual_seed(seed)
+        self.R = F * V
+        # ---- parameters (HBM resident; 26 x 10 M x 64 fp32 = 66.6 GB at config 3) -------------------
+        self.table = torch.empty((self.R, D), dtype=torch.float32, device=device)
+        std = table_init_std if table_init_std is not None else 1.0 / math.sqrt(D)     # [TF] B4
+        chunk = 1 << 24
+        for r0 in range(0, self.R, chunk):     # in place, chunked: no second 66 GB temporary
+            self.table[r0:r0 + chunk].normal_(0.0, std, generator=g).clamp_(-2 * std, 2 * std)
+        self.lin_w = torch.zeros(self.R, dtype=torch.float32, device=device)           # zeros init (fm.py:16-20)
+        if lin_init_std > 0:
+            self.lin_w.normal_(0.0, lin_init_std, generator=g)
+        self.lin_bias = torch.zeros(1, dtype=torch.float32, device=device)
+        self.in_dim = F * D + num_dense
+        self.ld = _pad4(self.in_dim)
+        units = list(dnn_units) + [1]
+        self.Ws: List[torch.Tensor] = []
+        self.bs: List[torch.Tensor] = []
+        d = self.in_dim
+        for u in units:                                                               # [TF] B8 glorot uniform
+            limit = math.sqrt(6.0 / (d + u))
+            W = (torch.rand((d, _pad4(u)), device=device, generator=g) * 2 - 1) * limit
+            self.Ws.append(W[:, :u])
+            self.bs.append(torch.zeros(u, dtype=torch.float32, device=device))
+            d = u
+        self.acts = [1] * len(dnn_units) + [0]
+        # ---- constant metadata ---------------------------------------------------------------------
+        self.row_base = torch.arange(F, device=device, dtype=torch.int64) * V
+        self.col_start = torch.arange(F + 1, device=device, dtype=torch.int32)
+        self.col_buckets = torch.full((F,), V if hashed else 0, dtype=torch.int64, device=device)
+        # ---- activations / gradients (preallocated once) ---------------------------------------------
+        f32 = dict(dtype=torch.float32, device=device)
+        self.ids = torch.empty((B, F), dtype=torch.int64, device=device)
+        self.concat = torch.zeros((B, self.ld), **f32)
+        self.sum_x = torch.empty((B, D), **f32)
+        self.fm_logit = torch.empty((B,), **f32)
+        self.hs = [torch.empty((B, _pad4(u)), **f32)[:, :u] for u in units]
+        self.dhs = [torch.empty((B, _pad4(u)), **f32)[:, :u] for u in units[:-1]]
+        self.d_concat = torch.empty((B, self.ld), **f32)
+        self.prob = torch.empty((B,), **f32)
+        self.d_logit = torch.empty((B,), **f32)
+        self.loss = torch.zeros(1, **f32)
+        self.ws = torch.empty(1024, **f32)
+        self._events = None      # name -> [bound, work, [(start, end), ...]]
+
+    # ---- per-kernel HIP events on the launch stream (bench.py's roofline numbers) ----------------------
+    def enable_kernel_events(self, on: bool):
+        self._events = {} if on else None
+
+    def _k(self, name, bound, work, fn):
+        if self._events is None:
+            return fn()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = fn()
+        e.record()
+        self._events.setdefault(name, [bound, work, []])[2].append((s, e))
+        return r
+
+    def kernel_event_summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, (bound, work, evs) in (self._events or {}).items():
+            ms = sum(s.elapsed_time(e) for s, e in evs) / len(evs)
+            out[name] = {"bound": bound, "ms": ms, "n": len(evs),
+                         "alg_bytes" if bound == "hbm" else "alg_flops": work}
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, keys: torch.Tensor, dense: Optional[torch.Tensor], labels: Optional[torch.Tensor],
+                loss_mode: int = ops.LOSS_SIGMOID_CE):
+        F, D = self.F, self.D
+        B = self.B
+        self._k("hash_bucket_i64", "hbm", B * F * 16,
+                lambda: ops.hash_bucket_i64(keys, self.col_buckets, out=self.ids))                    # K1
+        self._k("emb_pool_fwd", "hbm", self.alg_bytes_fwd(),                                          # K3+K5+K6
+                lambda: ops.emb_pool_fwd(self.ids, F, None, self.row_base, self.table, self.lin_w, self.lin_bias,
+                                         ld_concat=self.ld, concat=self.concat, sum_x=self.sum_x,
+                                         fm_logit=self.fm_logit))
+        if self.Nd:
+            self.concat[:, F * D:F * D + self.Nd].copy_(dense)                         # layout: append dense feats
+        x = self.concat[:, :self.in_dim]
+        for i, (W, b) in enumerate(zip(self.Ws, self.bs)):                             # K7
+            self._k("linear_fwd_L%d" % i, "mfma", 2.0 * B * W.shape[0] * W.shape[1],
+                    lambda x=x, W=W, b=b, i=i: ops.linear_fwd(x, W, b, self.acts[i], out=self.hs[i]))
+            x = self.hs[i]
+        if labels is None:
+            labels = self.prob   # dummy, loss ignored
+        ops.bce_fwd_bwd(self.fm_logit, labels, loss_mode, workspace=self.ws, logits_b=self.hs[-1],    # K11
+                        out=(self.prob, self.d_logit, self.loss))
+        return self.prob
+
+    def backward_and_update(self):
+        F, D, lr = self.F, self.D, self.lr
+        n = len(self.Ws)
+        dy = self.d_logit.reshape(-1, 1)                  # d(mean loss)/d logit == pre-activation grad of Dense(1)
+        for i in range(n - 1, -1, -1):
+            x = self.concat[:, :self.in_dim] if i == 0 else self.hs[i - 1]
+            W = self.Ws[i]
+            # dx first (uses the pre-update W), then the fused SGD wgrad
+            fl = 2.0 * self.B * W.shape[0] * W.shape[1]
+            if i > 0:
+                dx = self.dhs[i - 1]
+                rs = self.hs[i - 1] if self.acts[i - 1] else None
+            else:
+                dx = self.d_concat[:, :self.in_dim]
+                rs = None
+            self._k("linear_bwd_dx_L%d" % i, "mfma", fl,
+                    lambda dy=dy, W=W, rs=rs, dx=dx: ops.linear_bwd_dx(dy, W, relu_src=rs, out=dx))
+            self._k("linear_bwd_dw_L%d" % i, "mfma", fl,
+                    lambda x=x, dy=dy, W=W, i=i: ops.linear_bwd_dw(x, dy, -lr, W, self.bs[i]))
+            dy = dx
+        self._k("emb_pool_bwd", "hbm", self.alg_bytes_bwd(),                                          # K4
+                lambda: ops.emb_pool_bwd(self.ids, F, self.col_start, self.row_base, D, self.d_concat, self.concat,
+                                         self.sum_x, self.d_logit, -lr, self.table, self.lin_w, self.lin_bias))
+
+    def train_step(self, keys, dense, labels):
+        self.forward(keys, dense, labels)
+        self.backward_and_update()
+        return self.loss
+
+    # algorithmic bytes of the two embedding kernels per step
+    def alg_bytes_fwd(self):
+        return self.B * (8 * self.F * self.D + 12 * self.F + 8)
+
+    def alg_bytes_bwd(self):
+        return self.B * (12 * self.F * self.D + 16 * self.F)
+
+    def flops_step(self):
+        fl = 0
+        d = self.in_dim
+        for W in self.Ws:
+            fl += 2 * self.B * W.shape[0] * W.shape[1]
+        return 3 * fl

@@ -74,7 +74,7 @@ def vocab_lookup_strings(values: Sequence, vocab: Sequence, device="cuda"):
 # ----------------------------------------------------------------------------------------------
 # K3 / K4   fused embedding gather + pool (+ first-order + FM)
 # ----------------------------------------------------------------------------------------------
-def emb_pool_fwd(ids, F, col_start, row_base, table, lin_w=None, lin_bias=0.0, ld_concat=None,
+def emb_pool_fwd(ids, F, col_start, row_base, table, lin_w=None, lin_bias=None, ld_concat=None,
                  want_sum_x=True, want_fm=True, concat=None, sum_x=None, fm_logit=None):
     ids = _c(ids, torch.int64)
     B, C = ids.shape
@@ -90,19 +90,20 @@ def emb_pool_fwd(ids, F, col_start, row_base, table, lin_w=None, lin_bias=0.0, l
     if want_fm and fm_logit is None:
         fm_logit = torch.empty((B,), dtype=torch.float32, device=dev)
     check(lib().dr_emb_pool_fwd(ptr(ids), B, F, C, ptr(col_start), ptr(row_base), ptr(table), D, ptr(lin_w),
-                                float(lin_bias), ptr(concat), ld, ptr(sum_x) if want_sum_x else None,
+                                ptr(lin_bias), ptr(concat), ld, ptr(sum_x) if want_sum_x else None,
                                 ptr(fm_logit) if want_fm else None, stream_ptr()), "dr_emb_pool_fwd")
     return concat, sum_x, fm_logit
 
 
-def emb_pool_bwd(ids, F, col_start, row_base, D, d_concat, concat, sum_x, d_fm_logit, scale, dst_table, dst_lin):
+def emb_pool_bwd(ids, F, col_start, row_base, D, d_concat, concat, sum_x, d_fm_logit, scale, dst_table, dst_lin,
+                 dst_bias=None):
     ids = _c(ids, torch.int64)
     B, C = ids.shape
     check(lib().dr_emb_pool_bwd(ptr(ids), B, F, C, ptr(col_start), ptr(row_base), D,
                                 ptr(d_concat), d_concat.stride(0) if d_concat is not None else 0,
                                 ptr(concat), concat.stride(0) if concat is not None else 0,
                                 ptr(sum_x), ptr(d_fm_logit), float(scale), ptr(dst_table), ptr(dst_lin),
-                                stream_ptr()), "dr_emb_pool_bwd")
+                                ptr(dst_bias), stream_ptr()), "dr_emb_pool_bwd")
 
 
 # ----------------------------------------------------------------------------------------------
@@ -135,7 +136,9 @@ def _pad4(n):
 def _rowmajor_ld4(t):
     """Returns a [M, K] fp32 view whose row stride is a multiple of 4 floats and base 16-B aligned."""
     assert t.dim() == 2 and t.dtype == torch.float32
-    if t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.stride(0) >= t.shape[1] and t.data_ptr() % 16 == 0:
+    if t.stride(1) == 1 and t.stride(0) >= t.shape[1]:
+        return t      # the kernel takes float4 loads only when base and pitch are 16-B aligned
+    if t.shape[1] == 1 and t.stride(0) >= 1:
         return t
     M, K = t.shape
     buf = torch.zeros((M, _pad4(K)), dtype=torch.float32, device=t.device)
@@ -221,16 +224,52 @@ def cross_combine_bwd(x0, prod, d_out, diag_scale, d_x0_accum, d_x_accum):
 LOSS_SIGMOID_CE, LOSS_LOG_LOSS, LOSS_KERAS_BCE = 0, 1, 2
 
 
-def bce_fwd_bwd(logits, labels, mode=LOSS_SIGMOID_CE, want_prob=True, want_grad=True, workspace=None):
+def bce_fwd_bwd(logits, labels, mode=LOSS_SIGMOID_CE, want_prob=True, want_grad=True, workspace=None, logits_b=None,
+                out=None):
     logits = _c(logits.reshape(-1), torch.float32)
     labels = _c(labels.reshape(-1), torch.float32)
     n = logits.numel()
     dev = logits.device
-    prob = torch.empty(n, dtype=torch.float32, device=dev) if want_prob else None
-    d_logit = torch.empty(n, dtype=torch.float32, device=dev) if want_grad else None
-    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    if out is not None:
+        prob, d_logit, loss = out
+    else:
+        prob = torch.empty(n, dtype=torch.float32, device=dev) if want_prob else None
+        d_logit = torch.empty(n, dtype=torch.float32, device=dev) if want_grad else None
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
     if workspace is None:
         workspace = torch.empty(1024, dtype=torch.float32, device=dev)
-    check(lib().dr_bce_fwd_bwd(ptr(logits), ptr(labels), n, int(mode), ptr(prob), ptr(d_logit), ptr(loss),
-                               ptr(workspace), stream_ptr()), "dr_bce_fwd_bwd")
+    ldb = 0
+    if logits_b is not None:
+        assert logits_b.dim() == 2 and logits_b.shape[0] == n and logits_b.dtype == torch.float32
+        ldb = logits_b.stride(0)
+    check(lib().dr_bce_fwd_bwd(ptr(logits), ptr(logits_b), ldb, ptr(labels), n, int(mode), ptr(prob), ptr(d_logit),
+                               ptr(loss), ptr(workspace), stream_ptr()), "dr_bce_fwd_bwd")
     return loss, prob, d_logit
+
+
+def sigmoid_fwd(x):
+    x = _c(x, torch.float32)
+    y = torch.empty_like(x)
+    check(lib().dr_sigmoid_fwd(ptr(x), x.numel(), ptr(y), stream_ptr()), "dr_sigmoid_fwd")
+    return y
+
+
+def sigmoid_bwd(y, dy):
+    y = _c(y, torch.float32)
+    dy = _c(dy, torch.float32)
+    dx = torch.empty_like(y)
+    check(lib().dr_sigmoid_bwd(ptr(y), ptr(dy), y.numel(), ptr(dx), stream_ptr()), "dr_sigmoid_bwd")
+    return dx
+
+
+def bce_prob_fwd_bwd(prob, labels, mode, want_grad=True, workspace=None):
+    prob = _c(prob.reshape(-1), torch.float32)
+    labels = _c(labels.reshape(-1), torch.float32)
+    n = prob.numel()
+    d_prob = torch.empty_like(prob) if want_grad else None
+    loss = torch.empty(1, dtype=torch.float32, device=prob.device)
+    if workspace is None:
+        workspace = torch.empty(1024, dtype=torch.float32, device=prob.device)
+    check(lib().dr_bce_prob_fwd_bwd(ptr(prob), ptr(labels), n, int(mode), ptr(d_prob), ptr(loss), ptr(workspace),
+                                    stream_ptr()), "dr_bce_prob_fwd_bwd")
+    return loss, d_prob

@@ -77,16 +77,17 @@ int dr_vocab_lookup_bytes(const uint8_t* bytes, const int64_t* offsets, int64_t 
  *
  *   concat[b, f*D + d] = mean over valid ids of field f of table[row_base[f]+id, d]  (0 if empty)
  *   sum_x[b, d]        = sum_f concat[b, f*D+d]                                   (optional)
- *   fm_logit[b]        = lin_bias + sum over valid ids lin_w[row] + 0.5*sum_d(sum_x^2 - sum_f x^2)
+ *   fm_logit[b]        = lin_bias[0] + sum over valid ids lin_w[row] + 0.5*sum_d(sum_x^2 - sum_f x^2)
  *
  * col_start[F+1] (device, int32) may be NULL when every field is single-valued (then C == F).
  * concat has leading dimension ld_concat (>= F*D) so the caller can append dense features.
- * lin_w may be NULL (no first-order term); sum_x / fm_logit may be NULL (pure lookup).
+ * lin_w may be NULL (no first-order term); lin_bias is a 1-element device array (the trained bias) or
+ * NULL; sum_x / fm_logit may be NULL (pure lookup).
  * D must be a multiple of 4, 4 <= D <= 256.
  * ---------------------------------------------------------------------------------------- */
 int dr_emb_pool_fwd(const int64_t* ids, int64_t B, int32_t F, int32_t C, const int32_t* col_start,
                     const int64_t* row_base, const float* table, int32_t D,
-                    const float* lin_w, float lin_bias,
+                    const float* lin_w, const float* lin_bias,
                     float* concat, int64_t ld_concat, float* sum_x, float* fm_logit,
                     dr_stream_t stream);
 
@@ -98,6 +99,7 @@ int dr_emb_pool_fwd(const int64_t* ids, int64_t B, int32_t F, int32_t C, const i
  *   g[b,f,:]   = d_concat[b, f*D:(f+1)*D] + d_fm_logit[b] * (sum_x[b,:] - concat[b, f*D:(f+1)*D])
  *   for every valid id of (b,f):  dst_table[row,:] += scale * g[b,f,:] / bag_count(b,f)
  *                                  dst_lin[row]    += scale * d_fm_logit[b]
+ *   dst_bias[0] += scale * sum_b d_fm_logit[b]                       (dst_bias may be NULL)
  *
  * dst_table / dst_lin are either gradient buffers (scale = 1) or the parameters themselves
  * (scale = -learning_rate: fused SGD step, no gradient materialised).  d_concat may be NULL
@@ -109,7 +111,7 @@ int dr_emb_pool_bwd(const int64_t* ids, int64_t B, int32_t F, int32_t C, const i
                     const float* d_concat, int64_t ld_dconcat,
                     const float* concat, int64_t ld_concat, const float* sum_x,
                     const float* d_fm_logit, float scale,
-                    float* dst_table, float* dst_lin, dr_stream_t stream);
+                    float* dst_table, float* dst_lin, float* dst_bias, dr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K6  stand-alone FM second-order term on a caller-provided [B, F, D] tensor
@@ -135,7 +137,8 @@ int dr_fm2_bwd(const float* x, const float* d_out, int64_t B, int32_t F, int32_t
  *   bwd_dw  dstW[K,N] += scale * x^T @ dy ;  dstb[N] += scale * colsum(dy)
  *           split over the batch dimension with fp32 atomics: dst is a zeroed gradient buffer
  *           (scale = 1) or the parameter itself (scale = -lr, fused SGD).  dstb may be NULL.
- * All matrices row-major with explicit leading dimensions (multiples of 4 floats, 16-byte aligned).
+ * All matrices row-major with explicit leading dimensions; 16-byte aligned bases with pitches that are
+ * multiples of 4 floats take the float4 load path, anything else a scalar-load path.
  * ---------------------------------------------------------------------------------------- */
 int dr_linear_fwd(const float* x, int64_t ld_x, const float* W, int64_t ld_w, const float* b,
                   int64_t M, int32_t K, int32_t N, int32_t act, float* y, int64_t ld_y,
@@ -168,11 +171,21 @@ int dr_cross_combine_bwd(const float* x0, const float* prod, const float* d_out,
  * mode 0: tf.losses.sigmoid_cross_entropy(labels, logits)  (examples/train_fm_on_movielens_estimator.py:46)
  * mode 1: tf.losses.log_loss(labels, sigmoid(logits))      (examples/train_deepfm_on_movielens_estimator.py:47)
  * mode 2: tf.keras.losses.binary_crossentropy(labels, sigmoid(logits)) (examples/train_deepfm_on_movielens_keras.py:43)
+ * logit[i] = logits[i] + logits_b[i*ld_b] (logits_b may be NULL): DeepFM's fm_outputs + dnn_outputs
+ * (keras/models/ranking/deepfm.py:46) is summed here instead of in a separate pass.
  * prob[n] = sigmoid(logit) (may be NULL); d_logit[n] = d(mean loss)/d logit (may be NULL);
  * loss_out[1] = mean loss (deterministic two-stage reduction; workspace >= 1024 floats).
  * ---------------------------------------------------------------------------------------- */
-int dr_bce_fwd_bwd(const float* logits, const float* labels, int64_t n, int32_t mode, float* prob,
-                   float* d_logit, float* loss_out, float* workspace, dr_stream_t stream);
+int dr_bce_fwd_bwd(const float* logits, const float* logits_b, int64_t ld_b, const float* labels,
+                   int64_t n, int32_t mode, float* prob, float* d_logit, float* loss_out,
+                   float* workspace, dr_stream_t stream);
+/* unfused forms for callers that hold probabilities (the reference models return sigmoid outputs:
+ * keras/models/ranking/fm.py:64, deepfm.py:47; estimator/models/ranking/deepfm.py:43) */
+int dr_sigmoid_fwd(const float* x, int64_t n, float* y, dr_stream_t stream);
+int dr_sigmoid_bwd(const float* y, const float* dy, int64_t n, float* dx, dr_stream_t stream);
+/* mode 1 = log_loss, mode 2 = keras binary_crossentropy, on probabilities; d_prob = d(mean loss)/dp */
+int dr_bce_prob_fwd_bwd(const float* prob, const float* labels, int64_t n, int32_t mode, float* d_prob,
+                        float* loss_out, float* workspace, dr_stream_t stream);
 
 #ifdef __cplusplus
 }

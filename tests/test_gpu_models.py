@@ -1,0 +1,348 @@
+"""GPU tests of the reference-shaped classes.  Each test names the reference test it mirrors
+(paths relative to the reference root) and checks results against the CPU oracle."""
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import tf_semantics as O
+from oracle import torch_ref as T
+
+
+def _movielens_columns(fc, dim=16):
+    # examples/train_fm_on_movielens_estimator.py:10-34 (incl. the movie_genres/gender_vocab quirk, App. A2)
+    user_id = fc.categorical_column_with_hash_bucket("user_id", 6040)
+    user_gender = fc.categorical_column_with_vocabulary_list("user_gender", ["F", "M"])
+    user_age = fc.categorical_column_with_vocabulary_list("user_age", [1, 18, 25, 35, 45, 50, 56])
+    user_occupation = fc.categorical_column_with_vocabulary_list("user_occupation", list(range(21)))
+    movie_id = fc.categorical_column_with_hash_bucket("movie_id", 3952)
+    movie_genres = fc.categorical_column_with_vocabulary_list("movie_genres", ["F", "M"])
+    base = [user_id, user_gender, user_age, user_occupation, movie_id, movie_genres]
+    return [fc.indicator_column(c) for c in base], [fc.embedding_column(c, dimension=dim) for c in base]
+
+
+def _movielens_batch(rng, B):
+    genres = ["Action", "Adventure", "Animation", "Children's", "Comedy", "Crime", "Documentary", "Drama"]
+    feats = {
+        "user_id": np.array([str(v) for v in rng.integers(1, 6041, size=B)], dtype=object),
+        "user_gender": np.array([["F", "M"][v] for v in rng.integers(0, 2, size=B)], dtype=object),
+        "user_age": np.array([1, 18, 25, 35, 45, 50, 56])[rng.integers(0, 7, size=B)],
+        "user_occupation": rng.integers(0, 21, size=B),
+        "movie_id": np.array([str(v) for v in rng.integers(1, 3953, size=B)], dtype=object),
+        "movie_genres": [list(rng.choice(genres, size=rng.integers(1, 4), replace=False)) for _ in range(B)],
+    }
+    labels = (rng.random(B) < 0.575).astype(np.float32)
+    return feats, labels
+
+
+def _oracle_ids(feats):
+    B = len(feats["user_age"])
+    L = max(len(g) for g in feats["movie_genres"])
+    genres = np.full((B, L), "", dtype=object)
+    for i, g in enumerate(feats["movie_genres"]):
+        genres[i, :len(g)] = g
+    g_ids = O.vocab_lookup(genres, ["F", "M"])
+    g_ids[genres == ""] = -1
+    return [
+        O.hash_bucket_strings(feats["user_id"], 6040).reshape(B, 1),
+        O.vocab_lookup(feats["user_gender"], ["F", "M"]).reshape(B, 1),
+        O.vocab_lookup([int(v) for v in feats["user_age"]], [1, 18, 25, 35, 45, 50, 56]).reshape(B, 1),
+        O.vocab_lookup([int(v) for v in feats["user_occupation"]], list(range(21))).reshape(B, 1),
+        O.hash_bucket_strings(feats["movie_id"], 3952).reshape(B, 1),
+        g_ids,
+    ]
+
+
+KEYS = ["user_id", "user_gender", "user_age", "user_occupation", "movie_id", "movie_genres"]
+
+
+def test_fm_layer():
+    # tests/keras/test_fm.py:17-26
+    from deep_recommenders_amd.keras.models.ranking import FM
+    rng = np.random.RandomState(1)
+    sparse_inputs = rng.randint(0, 2, size=(10, 10)).astype(np.float32)
+    embedding_inputs = rng.normal(size=(10, 5, 5)).astype(np.float32)
+    x_sum = np.sum(embedding_inputs, axis=1)
+    x_square_sum = np.sum(np.power(embedding_inputs, 2), axis=1)
+    expected = 0.5 * np.sum(np.power(x_sum, 2) - x_square_sum, axis=1, keepdims=True)
+    layer = FM()
+    out = layer(sparse_inputs, embedding_inputs)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), expected, rtol=1e-6, atol=1e-6)
+    lin_only = layer(sparse_inputs)
+    assert lin_only.shape == (10, 1) and float(lin_only.abs().max()) == 0.0        # zero-init linear (fm.py:16-20)
+    assert layer.get_config() == {}
+
+
+def test_fm_layer_train():
+    # tests/keras/test_fm.py:28-42 — FM -> Dense(1), mse, one fit pass must run and reduce the loss
+    from deep_recommenders_amd.keras.models.ranking import FM
+    from deep_recommenders_amd import layers as L
+    rng = np.random.RandomState(2)
+    sp = rng.randint(0, 2, size=(10, 10)).astype(np.float32)
+    emb = torch.tensor(rng.uniform(size=(10, 5, 5)).astype(np.float32), device="cuda", requires_grad=True)
+    y = torch.tensor(rng.uniform(size=(10, 1)).astype(np.float32), device="cuda")
+    layer = FM()
+    head_w = torch.nn.Parameter(torch.full((1, 1), 0.5, device="cuda"))
+    head_b = torch.nn.Parameter(torch.zeros(1, device="cuda"))
+    layer(sp, emb)
+    opt = torch.optim.SGD(list(layer.parameters()) + [head_w, head_b], lr=1e-3)
+    losses = []
+    for _ in range(5):
+        opt.zero_grad()
+        out = L.mlp(layer(sp, emb), [head_w], [head_b], [0])
+        loss = ((out - y) ** 2).mean()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0]
+    assert emb.grad is not None and torch.isfinite(emb.grad).all()
+
+
+@pytest.mark.parametrize("model_name", ["FactorizationMachine", "DeepFM"])
+def test_model_train_and_state_roundtrip(model_name):
+    # tests/keras/test_fm.py:67-107 and tests/keras/test_deepfm.py:16-56:
+    # hash_bucket(100) columns on keys "1"/"2", dim 16, 100 Adam steps with binary_crossentropy, then
+    # save -> load -> identical predictions and identical get_config()
+    from deep_recommenders_amd import feature_column as fc
+    from deep_recommenders_amd import losses
+    from deep_recommenders_amd.keras.models.ranking import FactorizationMachine, DeepFM
+
+    def build():
+        base = [fc.categorical_column_with_hash_bucket("user_id", 100),
+                fc.categorical_column_with_hash_bucket("movie_id", 100)]
+        ind = [fc.indicator_column(c) for c in base]
+        emb = [fc.embedding_column(c, dimension=16) for c in base]
+        if model_name == "DeepFM":
+            return DeepFM(ind, emb, dnn_units_size=[10, 5])
+        return FactorizationMachine(ind, emb)
+
+    torch.manual_seed(0)
+    model = build()
+    train = {"user_id": [["1"]] * 1000, "movie_id": [["2"]] * 1000}
+    labels = torch.zeros((1000, 1), device="cuda")            # np.random.randint(0, 1) == all zeros in the reference
+    model(train)                                               # build lazily created weights
+    opt = torch.optim.Adam(model.parameters())
+    first = None
+    for _ in range(100):
+        opt.zero_grad()
+        loss = losses.binary_crossentropy(labels, model(train))
+        loss.backward()
+        opt.step()
+        first = loss.item() if first is None else first
+    assert loss.item() < first
+    test_data = {"user_id": np.asarray([["1"], ["2"]]), "movie_id": np.asarray([["1"], ["2"]])}
+    pred = model.predict(test_data)
+    assert pred.shape == (2, 1) and np.isfinite(pred).all()
+    # the row trained on ("1","2") labels 0 must have moved below 0.5 for user "1"
+    buf = io.BytesIO()
+    torch.save(model.state_dict(), buf)
+    buf.seek(0)
+    loaded = build()
+    loaded(test_data)
+    loaded.load_state_dict(torch.load(buf))
+    np.testing.assert_array_equal(pred, loaded.predict(test_data))
+    assert {k: v for k, v in model.get_config().items() if "columns" not in k} == \
+           {k: v for k, v in loaded.get_config().items() if "columns" not in k}
+
+
+def test_keras_deepfm_matches_oracle_on_movielens_shaped_batch():
+    """End-to-end parity (north_star): ids bit-identical, loss within 1e-5 relative fp32."""
+    from deep_recommenders_amd import feature_column as fc
+    from deep_recommenders_amd import losses
+    from deep_recommenders_amd.keras.models.ranking import DeepFM, FactorizationMachine
+    rng = np.random.default_rng(42)
+    B = 256
+    feats, labels = _movielens_batch(rng, B)
+    ind, emb = _movielens_columns(fc)
+    torch.manual_seed(42)
+    model = DeepFM(ind, emb, dnn_units_size=[256, 32])          # examples/train_deepfm_on_movielens_keras.py:42
+    prob = model(feats)
+    slab = model.slab
+    slab.lin_w.data.normal_(0, 0.1)
+    slab.lin_bias.data.fill_(0.05)
+    prob = model(feats)
+    # integer path bit-identical
+    ids_dev, col_start, row_base = slab.transform(feats, KEYS)
+    want_ids = np.concatenate(_oracle_ids(feats), axis=1)
+    np.testing.assert_array_equal(ids_dev.cpu().numpy(), want_ids)
+    # oracle forward with the same weights
+    tabs = [slab.embedding_weights(k).cpu().numpy() for k in KEYS]
+    lws = [slab.linear_weights(k).cpu().numpy() for k in KEYS]
+    Ws = [w.detach().cpu().numpy() for w in model.dnn_kernels]
+    bs = [b.detach().cpu().numpy() for b in model.dnn_biases]
+    want_prob, want_logit, _ = O.deepfm_forward(_oracle_ids(feats), tabs, lws, 0.05, Ws, bs, return_parts=True)
+    got_logit = model.logits(feats).detach().cpu().numpy()
+    np.testing.assert_allclose(got_logit, want_logit, rtol=0, atol=1e-5 * (np.abs(want_logit).max() + 1))
+    np.testing.assert_allclose(prob.detach().cpu().numpy(), want_prob, rtol=1e-5, atol=1e-6)
+    lab = torch.tensor(labels, device="cuda").reshape(-1, 1)
+    for ours, theirs in [(losses.binary_crossentropy(lab, prob), O.keras_binary_crossentropy(labels, want_prob)),
+                         (losses.log_loss(lab, prob), O.log_loss(labels, want_prob)),
+                         (losses.sigmoid_cross_entropy(lab, model.logits(feats)), O.sigmoid_cross_entropy(labels, want_logit))]:
+        assert abs(ours.item() - float(theirs)) <= 1e-5 * abs(float(theirs))
+    # FactorizationMachine = same minus the DNN (fm.py:54-64)
+    fm_model = FactorizationMachine(ind, emb)
+    fm_model.slab.load_state_dict(slab.state_dict())
+    want_fm = O.deepfm_forward(_oracle_ids(feats), tabs, lws, 0.05, None, None)
+    np.testing.assert_allclose(fm_model(feats).detach().cpu().numpy(), want_fm, rtol=1e-5, atol=1e-6)
+
+
+def test_deepfm_gradients_match_autograd_oracle():
+    from deep_recommenders_amd import feature_column as fc
+    from deep_recommenders_amd import losses
+    from deep_recommenders_amd.keras.models.ranking import DeepFM
+    rng = np.random.default_rng(7)
+    B = 200
+    feats, labels = _movielens_batch(rng, B)
+    ind, emb = _movielens_columns(fc)
+    torch.manual_seed(1)
+    model = DeepFM(ind, emb, dnn_units_size=[64, 32])           # examples/train_deepfm_on_movielens_estimator.py:40
+    model(feats)
+    model.slab.lin_w.data.normal_(0, 0.1)
+    lab = torch.tensor(labels, device="cuda").reshape(-1, 1)
+    loss = losses.sigmoid_cross_entropy(lab, model.logits(feats))
+    loss.backward()
+    # oracle: fp64 autograd over the torch restatement with the same weights
+    slab = model.slab
+    ids = torch.tensor(np.concatenate(_oracle_ids(feats), axis=1))
+    widths = [a.shape[1] for a in _oracle_ids(feats)]
+    cs = [0]
+    for w in widths:
+        cs.append(cs[-1] + w)
+    rb = [slab.base[k] for k in KEYS]
+    tt = slab.table.detach().cpu().double().requires_grad_(True)
+    tl = slab.lin_w.detach().cpu().double().requires_grad_(True)
+    tb = slab.lin_bias.detach().cpu().double().requires_grad_(True)
+    Ws = [w.detach().cpu().double().requires_grad_(True) for w in model.dnn_kernels]
+    bs = [b.detach().cpu().double().requires_grad_(True) for b in model.dnn_biases]
+    logit = T.deepfm_logit(tt, tl, tb, ids, cs, rb, Ws, bs)
+    lo = T.sigmoid_cross_entropy(torch.tensor(labels, dtype=torch.float64), logit)
+    lo.backward()
+    assert abs(loss.item() - lo.item()) <= 1e-5 * abs(lo.item())
+
+    def close(a, b, name):
+        a, b = a.cpu().numpy(), b.numpy()
+        np.testing.assert_allclose(a, b, rtol=1e-3, atol=2e-6 * (np.abs(b).max() + 1e-3) + 1e-9, err_msg=name)
+
+    close(slab.table.grad, tt.grad, "table")
+    close(slab.lin_w.grad, tl.grad, "lin_w")
+    close(slab.lin_bias.grad, tb.grad, "lin_bias")
+    for i, (w, b) in enumerate(zip(model.dnn_kernels, model.dnn_biases)):
+        close(w.grad, Ws[i].grad, "W%d" % i)
+        close(b.grad, bs[i].grad, "b%d" % i)
+
+
+def test_cross_layer_api():
+    # tests/keras/test_dcn.py:16-45
+    from deep_recommenders_amd.keras.models.ranking.dcn import Cross
+    x0 = np.asarray([[0.1, 0.2, 0.3]]).astype(np.float32)
+    x = np.asarray([[0.4, 0.5, 0.6]]).astype(np.float32)
+    cross = Cross(projection_dim=None, kernel_init="ones")
+    np.testing.assert_allclose(cross(x0, x).detach().cpu().numpy(), np.asarray([[0.55, 0.8, 1.05]]), rtol=1e-6)
+    # stacking pattern + gradient flows to both layers (test_dcn.py:27-32)
+    torch.manual_seed(0)
+    c1, c2 = Cross(), Cross(diag_scale=0.1)
+    inp = torch.tensor(np.random.default_rng(0).uniform(size=(10, 13)).astype(np.float32), device="cuda")
+    x1 = c1(inp, inp)
+    x2 = c2(inp, x1)
+    want1 = O.cross(inp.cpu().numpy(), inp.cpu().numpy(), c1.kernel.detach().cpu().numpy(), c1.bias.detach().cpu().numpy())
+    want2 = O.cross(inp.cpu().numpy(), want1, c2.kernel.detach().cpu().numpy(), c2.bias.detach().cpu().numpy(), 0.1)
+    np.testing.assert_allclose(x2.detach().cpu().numpy(), want2, rtol=1e-5, atol=1e-6)
+    x2.sum().backward()
+    # gradient oracle
+    tk1 = c1.kernel.detach().cpu().double().requires_grad_(True)
+    tk2 = c2.kernel.detach().cpu().double().requires_grad_(True)
+    tb1 = c1.bias.detach().cpu().double().requires_grad_(True)
+    ti = inp.cpu().double()
+    o = T.cross(ti, T.cross(ti, ti, tk1, tb1), tk2, c2.bias.detach().cpu().double(), 0.1)
+    o.sum().backward()
+    np.testing.assert_allclose(c1.kernel.grad.cpu().numpy(), tk1.grad.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(c2.kernel.grad.cpu().numpy(), tk2.grad.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(c1.bias.grad.cpu().numpy(), tb1.grad.numpy(), rtol=1e-4, atol=1e-5)
+    # error conventions (dcn.py:32-33,48-53,75-78)
+    with pytest.raises(ValueError):
+        Cross()(np.zeros((1, 3), np.float32), np.zeros((1, 4), np.float32))
+    with pytest.raises(ValueError):
+        Cross(projection_dim=5)(np.zeros((1, 6), np.float32))
+    with pytest.raises(AssertionError):
+        Cross(diag_scale=-1.0)
+    cfg = Cross(projection_dim=2, diag_scale=0.5).get_config()
+    assert set(cfg) == {"projection_dim", "diag_scale", "use_bias", "kernel_init", "kernel_regu", "bias_init", "bias_regu"}
+    # low-rank form (dcn.py:83)
+    lr_layer = Cross(projection_dim=3)
+    xx = np.random.default_rng(1).standard_normal((4, 8)).astype(np.float32)
+    out = lr_layer(xx)
+    want = O.cross(xx, None, lr_layer.kernel.detach().cpu().numpy(), lr_layer.bias.detach().cpu().numpy(), 0.0,
+                   kernel_u=lr_layer.kernel_u.detach().cpu().numpy())
+    np.testing.assert_allclose(out.detach().cpu().numpy(), want, rtol=1e-5, atol=1e-6)
+
+
+def test_estimator_fm_and_deepfm():
+    # tests/estimator/test_fm.py:18-26 (shape) + estimator FM/DeepFM surface (estimator/.../fm.py:29-56, ranking/deepfm.py)
+    from deep_recommenders_amd import feature_column as fc
+    from deep_recommenders_amd.estimator.models.feature_interaction import fm, FM, dnn
+    from deep_recommenders_amd.estimator.models.ranking import DeepFM
+    y = fm(torch.randn(10, 2, 3))
+    assert tuple(y.shape) == (10, 1)
+    with pytest.raises(ValueError):
+        fm(torch.randn(10, 6))
+    rng = np.random.default_rng(3)
+    feats, labels = _movielens_batch(rng, 64)
+    ind, emb = _movielens_columns(fc)
+    torch.manual_seed(3)
+    model = FM(ind, emb)
+    logits = model(feats)
+    assert tuple(logits.shape) == (64, 1) and len(model.embeddings) == 6 and tuple(model.embeddings[0].shape) == (64, 16)
+    slab = model.slab
+    tabs = [slab.embedding_weights(k).cpu().numpy() for k in KEYS]
+    lws = [slab.linear_weights(k).cpu().numpy() for k in KEYS]
+    _, want_logit, _ = O.deepfm_forward(_oracle_ids(feats), tabs, lws, 0.0, None, None, return_parts=True)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), want_logit, rtol=1e-5, atol=1e-5)   # logits, no sigmoid (fm.py:56)
+    dm = DeepFM(ind, emb, dnn_units=[64, 32])
+    p = dm(feats)
+    assert tuple(p.shape) == (64, 1) and float(p.min()) > 0 and float(p.max()) < 1
+    with pytest.raises(TypeError):
+        dnn(torch.randn(4, 8), [4, 1], batch_normalization=True)      # reference quirk, dnn.py:23-24
+
+
+def test_engine_train_step_matches_oracle():
+    """The fused engine step (what bench.py times) against the host restatement: loss and updated weights."""
+    from deep_recommenders_amd.engine import DeepFMEngine
+    F, V, D, B, Nd = 5, 1000, 16, 512, 3
+    lr = 0.05
+    eng = DeepFMEngine(F, V, D, [32, 16], B, num_dense=Nd, lr=lr, seed=1, lin_init_std=0.1)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    keys = torch.randint(0, 10**12, (B, F), device="cuda", generator=g)
+    dense = torch.rand((B, Nd), device="cuda", generator=g)
+    labels = (torch.rand(B, device="cuda", generator=g) < 0.25).float()
+    # host copies of the parameters before the step
+    table0, lin0 = eng.table.cpu().clone(), eng.lin_w.cpu().clone()
+    Ws0 = [w.cpu().clone().contiguous() for w in eng.Ws]
+    bs0 = [b.cpu().clone() for b in eng.bs]
+    loss = eng.train_step(keys, dense, labels).item()
+    # oracle step
+    ids = np.stack([O.hash_bucket_i64(keys[:, f].cpu().numpy(), V) for f in range(F)], axis=1)
+    np.testing.assert_array_equal(eng.ids.cpu().numpy(), ids)
+    params = (table0.clone(), lin0.clone(), torch.zeros(()), [w.clone() for w in Ws0], [b.clone() for b in bs0])
+    # the oracle applies SGD to bias too; mirror by hand
+    tb = torch.zeros(1, requires_grad=True)
+    tt = table0.clone().requires_grad_(True)
+    tl = lin0.clone().requires_grad_(True)
+    Ws = [w.clone().requires_grad_(True) for w in Ws0]
+    bs = [b.clone().requires_grad_(True) for b in bs0]
+    rb = [f * V for f in range(F)]
+    logit = T.deepfm_logit(tt, tl, tb, torch.tensor(ids), list(range(F + 1)), rb, Ws, bs, dense.cpu())
+    lo = T.sigmoid_cross_entropy(labels.cpu(), logit)
+    lo.backward()
+    assert abs(loss - lo.item()) <= 1e-5 * abs(lo.item())
+    np.testing.assert_allclose(eng.table.cpu().numpy(), (table0 - lr * tt.grad).numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(eng.lin_w.cpu().numpy(), (lin0 - lr * tl.grad).numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(eng.lin_bias.cpu().numpy(), (-lr * tb.grad).numpy(), rtol=1e-4, atol=1e-7)
+    for i in range(len(Ws)):
+        np.testing.assert_allclose(eng.Ws[i].cpu().numpy(), (Ws0[i] - lr * Ws[i].grad).numpy(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(eng.bs[i].cpu().numpy(), (bs0[i] - lr * bs[i].grad).numpy(), rtol=1e-4, atol=1e-6)
