@@ -101,7 +101,8 @@ def test_emb_pool_fwd_matches_oracle(ops, D, Ls):
     F, col_start, row_base, ids, table, lin_w = _rand_problem(rng, B, Ls, Vs, D)
     single = all(l == 1 for l in Ls) and F <= 64
     cs = None if single else _dev(col_start)
-    concat, sum_x, fm = ops.emb_pool_fwd(_dev(ids), F, cs, _dev(row_base), _dev(table), _dev(lin_w), 0.125)
+    concat, sum_x, fm = ops.emb_pool_fwd(_dev(ids), F, cs, _dev(row_base), _dev(table), _dev(lin_w),
+                                         _dev(np.array([0.125], np.float32)))
     torch.cuda.synchronize()
     ids_f = [ids[:, col_start[f]:col_start[f + 1]] for f in range(F)]
     tabs = [table[row_base[f]:row_base[f] + Vs[f]] for f in range(F)]
@@ -122,7 +123,7 @@ def test_emb_pool_fwd_padded_concat_and_no_fm(ops):
     rng = np.random.default_rng(1)
     F, col_start, row_base, ids, table, lin_w = _rand_problem(rng, 100, [1] * 5, [50] * 5, 16)
     ld = 5 * 16 + 16
-    concat, sum_x, fm = ops.emb_pool_fwd(_dev(ids), F, None, _dev(row_base), _dev(table), None, 0.0, ld_concat=ld,
+    concat, sum_x, fm = ops.emb_pool_fwd(_dev(ids), F, None, _dev(row_base), _dev(table), None, None, ld_concat=ld,
                                          want_sum_x=False, want_fm=False)
     assert sum_x is None and fm is None
     want = np.concatenate([O.embedding_mean_pool_fast(table[row_base[f]:row_base[f] + 50], ids[:, f]) for f in range(5)], 1)
@@ -150,7 +151,7 @@ def test_emb_pool_bwd_matches_autograd_oracle(ops, D, Ls, strided):
     # device
     d_ids = _dev(ids)
     cs, rb = _dev(col_start), _dev(row_base)
-    concat, sum_x, _ = ops.emb_pool_fwd(d_ids, F, cs, rb, _dev(table), _dev(lin_w), 0.0)
+    concat, sum_x, _ = ops.emb_pool_fwd(d_ids, F, cs, rb, _dev(table), _dev(lin_w), None)
     g_table = torch.zeros_like(_dev(table))
     g_lin = torch.zeros_like(_dev(lin_w))
     ops.emb_pool_bwd(d_ids, F, cs, rb, D, _dev(d_concat), concat, sum_x, _dev(d_fm), 1.0, g_table, g_lin)

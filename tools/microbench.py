@@ -61,7 +61,7 @@ def main():
             concat = torch.zeros((B, ld), dtype=torch.float32, device=dev)
             sum_x = torch.empty((B, D), dtype=torch.float32, device=dev)
             fm = torch.empty((B,), dtype=torch.float32, device=dev)
-            t = timeit(lambda: ops.emb_pool_fwd(ids, F, None, row_base, table, lin_w, 0.0, ld_concat=ld, concat=concat,
+            t = timeit(lambda: ops.emb_pool_fwd(ids, F, None, row_base, table, lin_w, None, ld_concat=ld, concat=concat,
                                                 sum_x=sum_x, fm_logit=fm))
             alg = B * (8 * F * D + 12 * F + 8)
             res["emb_pool_fwd_" + dist] = {"us": t * 1e6, "alg_GB/s": alg / t / 1e9, "frac_of_8TB/s": alg / t / 8e12}
