@@ -1,0 +1,285 @@
+// Row-sharded tables over N ranks (new design; the reference is single-process).
+//   owner(id) = id % world ; local row on the owner = field * rows_per_shard + id / world
+// dr_shard_bucket_ids : stable counting sort of the B*F (example, field) slots by owner rank, producing the
+//                       all-to-all send layout + the inverse map.  Pure integer work, deterministic.
+// dr_rows_gather      : owner side of the forward exchange: requested local rows -> packed [n, D] (+ first-order w)
+// dr_rows_scatter_add : owner side of the backward exchange: packed row gradients -> table (fp32 atomics;
+//                       the same row can arrive from several ranks)
+// dr_axpy             : y += alpha * x (applies the all-reduced dense-tower gradient)
+#include "dr_common.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+namespace {
+
+constexpr int MAXW = 16;           // max world size for the bucketing kernels
+constexpr int SLOTS_PER_THREAD = 8;
+constexpr int CHUNK = 256 * SLOTS_PER_THREAD;
+
+__device__ __forceinline__ void slot_route(int64_t id, int64_t p, int32_t C, int64_t rows_per_shard, int32_t world,
+                                           int& owner, int64_t& local_row) {
+    if (id >= 0) {
+        owner = (int)(id % world);
+        local_row = (int64_t)(p % C) * rows_per_shard + id / world;
+    } else {                        // missing id: still occupies a slot (returns a zero row); spread evenly
+        owner = (int)(p % world);
+        local_row = -1;
+    }
+}
+
+__global__ __launch_bounds__(256) void bucket_hist_kernel(const int64_t* __restrict__ ids, int64_t n, int32_t C,
+                                                          int64_t rps, int32_t world, int64_t* __restrict__ block_hist) {
+    __shared__ int hist[MAXW];
+    if (threadIdx.x < MAXW) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * CHUNK + (int64_t)threadIdx.x * SLOTS_PER_THREAD;
+    for (int j = 0; j < SLOTS_PER_THREAD; ++j) {
+        const int64_t p = base + j;
+        if (p < n) {
+            int o; int64_t lr;
+            slot_route(ids[p], p, C, rps, world, o, lr);
+            atomicAdd(&hist[o], 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < world) block_hist[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = hist[threadIdx.x];
+}
+
+// exclusive scan over the (owner-major, block-minor) histogram; single block
+__global__ __launch_bounds__(256) void bucket_scan_kernel(int64_t* __restrict__ block_hist, int64_t nblk, int32_t world,
+                                                          int64_t* __restrict__ counts) {
+    __shared__ int64_t part[256];
+    __shared__ int64_t carry;
+    const int64_t total = nblk * world;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < total; base += 256) {
+        const int64_t i = base + threadIdx.x;
+        const int64_t v = i < total ? block_hist[i] : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            int64_t t = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+            __syncthreads();
+            part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < total) block_hist[i] = carry + part[threadIdx.x] - v;   // exclusive
+        __syncthreads();
+        if (threadIdx.x == 255) carry += part[255];
+        __syncthreads();
+    }
+    // counts[w] = start[w+1] - start[w]
+    if (threadIdx.x < world) {
+        const int64_t s0 = block_hist[(int64_t)threadIdx.x * nblk];
+        const int64_t s1 = threadIdx.x + 1 < world ? block_hist[(int64_t)(threadIdx.x + 1) * nblk] : carry;
+        counts[threadIdx.x] = s1 - s0;
+    }
+}
+
+__global__ __launch_bounds__(256) void bucket_scatter_kernel(const int64_t* __restrict__ ids, int64_t n, int32_t C,
+                                                             int64_t rps, int32_t world,
+                                                             const int64_t* __restrict__ block_off,
+                                                             int64_t* __restrict__ send_rows,
+                                                             int64_t* __restrict__ pos) {
+    __shared__ int cnt[MAXW][257];
+    const int t = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * CHUNK + (int64_t)t * SLOTS_PER_THREAD;
+    int owner[SLOTS_PER_THREAD];
+    int64_t lrow[SLOTS_PER_THREAD];
+    int local[MAXW];
+#pragma unroll
+    for (int w = 0; w < MAXW; ++w) local[w] = 0;
+#pragma unroll
+    for (int j = 0; j < SLOTS_PER_THREAD; ++j) {
+        const int64_t p = base + j;
+        owner[j] = -1;
+        if (p < n) {
+            slot_route(ids[p], p, C, rps, world, owner[j], lrow[j]);
+#pragma unroll
+            for (int w = 0; w < MAXW; ++w) local[w] += (owner[j] == w) ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < MAXW; ++w) cnt[w][t] = local[w];
+    __syncthreads();
+    // exclusive scan over threads for each owner (one wave-group per owner would be faster; this is tiny work)
+    for (int w = t >> 6; w < world; w += 4) {
+        // wave (t>>6) scans cnt[w][0..255] in 4 segments of 64 with shuffles
+        const int lane = t & 63;
+        int run = 0;
+        for (int seg = 0; seg < 4; ++seg) {
+            const int v = cnt[w][seg * 64 + lane];
+            int incl = v;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int u = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += u;
+            }
+            cnt[w][seg * 64 + lane] = run + incl - v;
+            run += __shfl(incl, 63, 64);
+        }
+    }
+    __syncthreads();
+    int seen[MAXW];
+#pragma unroll
+    for (int w = 0; w < MAXW; ++w) seen[w] = 0;
+#pragma unroll
+    for (int j = 0; j < SLOTS_PER_THREAD; ++j) {
+        const int64_t p = base + j;
+        if (p < n) {
+            const int o = owner[j];
+            int before = 0;
+#pragma unroll
+            for (int w = 0; w < MAXW; ++w)
+                if (w == o) { before = seen[w]; seen[w]++; }
+            const int64_t dst = block_off[(int64_t)o * gridDim.x + blockIdx.x] + cnt[o][t] + before;
+            send_rows[dst] = lrow[j];
+            pos[p] = dst;
+        }
+    }
+}
+
+// ---- owner-side gather / scatter of packed rows ------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(256) void rows_gather_kernel(const int64_t* __restrict__ rows, int64_t n,
+                                                          const float* __restrict__ table, int32_t D,
+                                                          const float* __restrict__ lin_w, float* __restrict__ out,
+                                                          float* __restrict__ out_lin) {
+    constexpr int RPW = DR_WAVE / LPR;    // rows per wave-instruction
+    constexpr int U = 4;
+    const int lane = threadIdx.x & 63, slot = lane / LPR, sub = lane % LPR;
+    const bool dvalid = sub * 4 < D;
+    const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t w0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    for (int64_t g = w0 * (RPW * U); g < n; g += nw * (RPW * U)) {
+        int64_t r[U];
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = g + u * RPW + slot;
+            r[u] = i < n ? rows[i] : -1;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r[u] >= 0 && dvalid) v[u] = *reinterpret_cast<const float4*>(table + r[u] * D + sub * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = g + u * RPW + slot;
+            if (i < n) {
+                if (dvalid) *reinterpret_cast<float4*>(out + i * D + sub * 4) = v[u];
+                if (out_lin != nullptr && sub == 0) out_lin[i] = (r[u] >= 0 && lin_w != nullptr) ? lin_w[r[u]] : 0.f;
+            }
+        }
+    }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void rows_scatter_add_kernel(const int64_t* __restrict__ rows, int64_t n,
+                                                               const float* __restrict__ grads, int32_t D,
+                                                               const float* __restrict__ lin_grads, float scale,
+                                                               float* __restrict__ table, float* __restrict__ lin_w) {
+    constexpr int RPW = DR_WAVE / LPR;
+    const int lane = threadIdx.x & 63, slot = lane / LPR, sub = lane % LPR;
+    const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t w0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    for (int64_t g = w0 * RPW; g < n; g += nw * RPW) {
+        const int64_t i = g + slot;
+        if (i >= n) continue;
+        const int64_t r = rows[i];
+        if (r < 0) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int d = j * LPR + sub;          // strided lane->d map: each atomic instruction covers a contiguous span
+            if (d < D) unsafeAtomicAdd(table + r * D + d, scale * grads[i * D + d]);
+        }
+        if (lin_w != nullptr && lin_grads != nullptr && sub == 0) unsafeAtomicAdd(lin_w + r, scale * lin_grads[i]);
+    }
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(int64_t n, float alpha, const float* __restrict__ x,
+                                                   float* __restrict__ y) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = fmaf(alpha, x[i], y[i]);
+}
+
+int lpr_for_d(int D) {
+    int l = 1;
+    while (l * 4 < D) l <<= 1;
+    return l;
+}
+
+}  // namespace
+
+extern "C" int64_t dr_shard_bucket_workspace_bytes(int64_t n, int32_t world) {
+    const int64_t nblk = (n + CHUNK - 1) / CHUNK;
+    return (nblk * world + 16) * (int64_t)sizeof(int64_t);
+}
+
+extern "C" int dr_shard_bucket_ids(const int64_t* ids, int64_t n, int32_t C, int64_t rows_per_shard, int32_t world,
+                                   int64_t* counts, int64_t* send_rows, int64_t* pos, int64_t* workspace,
+                                   dr_stream_t stream) {
+    if (n < 0 || C <= 0 || world <= 0 || world > MAXW || rows_per_shard <= 0) return DR_EINVAL;
+    if (!counts) return DR_EINVAL;
+    if (n == 0) {
+        hipMemsetAsync(counts, 0, sizeof(int64_t) * world, dr_s(stream));
+        return DR_OK;
+    }
+    if (!ids || !send_rows || !pos || !workspace) return DR_EINVAL;
+    const int nblk = (int)((n + CHUNK - 1) / CHUNK);
+    hipLaunchKernelGGL(bucket_hist_kernel, dim3(nblk), dim3(256), 0, dr_s(stream), ids, n, C, rows_per_shard, world,
+                       workspace);
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(256), 0, dr_s(stream), workspace, (int64_t)nblk, world, counts);
+    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nblk), dim3(256), 0, dr_s(stream), ids, n, C, rows_per_shard, world,
+                       workspace, send_rows, pos);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+#define DR_LPR_SWITCH(lpr, CALL) \
+    switch (lpr) {               \
+        case 1: CALL(1); break;  \
+        case 2: CALL(2); break;  \
+        case 4: CALL(4); break;  \
+        case 8: CALL(8); break;  \
+        case 16: CALL(16); break;\
+        case 32: CALL(32); break;\
+        case 64: CALL(64); break;\
+        default: return DR_EINVAL;\
+    }
+
+extern "C" int dr_rows_gather(const int64_t* rows, int64_t n, const float* table, int32_t D, const float* lin_w,
+                              float* out_rows, float* out_lin, dr_stream_t stream) {
+    if (n < 0 || D < 4 || D > 256 || (D & 3)) return DR_EINVAL;
+    if (n == 0) return DR_OK;
+    if (!rows || !table || !out_rows) return DR_EINVAL;
+    const int lpr = lpr_for_d(D);
+    const int grid = dr_grid_for(n, 4 * (64 / lpr) * 4);
+#define CALL(L) hipLaunchKernelGGL((rows_gather_kernel<L>), dim3(grid), dim3(256), 0, dr_s(stream), rows, n, table, D, lin_w, out_rows, out_lin)
+    DR_LPR_SWITCH(lpr, CALL)
+#undef CALL
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+extern "C" int dr_rows_scatter_add(const int64_t* rows, int64_t n, const float* grads, int32_t D,
+                                   const float* lin_grads, float scale, float* table, float* lin_w,
+                                   dr_stream_t stream) {
+    if (n < 0 || D < 4 || D > 256 || (D & 3)) return DR_EINVAL;
+    if (n == 0) return DR_OK;
+    if (!rows || !grads || !table) return DR_EINVAL;
+    const int lpr = lpr_for_d(D);
+    const int grid = dr_grid_for(n, 4 * (64 / lpr));
+#define CALL(L) hipLaunchKernelGGL((rows_scatter_add_kernel<L>), dim3(grid), dim3(256), 0, dr_s(stream), rows, n, grads, D, lin_grads, scale, table, lin_w)
+    DR_LPR_SWITCH(lpr, CALL)
+#undef CALL
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+extern "C" int dr_axpy(int64_t n, float alpha, const float* x, float* y, dr_stream_t stream) {
+    if (n < 0) return DR_EINVAL;
+    if (n == 0) return DR_OK;
+    if (!x || !y) return DR_EINVAL;
+    hipLaunchKernelGGL(axpy_kernel, dim3(dr_grid_for(n, 256)), dim3(256), 0, dr_s(stream), n, alpha, x, y);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}

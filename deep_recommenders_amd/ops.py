@@ -273,3 +273,51 @@ def bce_prob_fwd_bwd(prob, labels, mode, want_grad=True, workspace=None):
     check(lib().dr_bce_prob_fwd_bwd(ptr(prob), ptr(labels), n, int(mode), ptr(d_prob), ptr(loss), ptr(workspace),
                                     stream_ptr()), "dr_bce_prob_fwd_bwd")
     return loss, d_prob
+
+
+# ----------------------------------------------------------------------------------------------
+# row-sharded tables: bucketing + owner-side gather / scatter, dense axpy
+# ----------------------------------------------------------------------------------------------
+def shard_bucket_ids(ids, rows_per_shard, world, counts=None, send_rows=None, pos=None, workspace=None):
+    ids = _c(ids, torch.int64)
+    B, C = ids.shape
+    n = B * C
+    dev = ids.device
+    if counts is None:
+        counts = torch.empty(world, dtype=torch.int64, device=dev)
+    if send_rows is None:
+        send_rows = torch.empty(n, dtype=torch.int64, device=dev)
+    if pos is None:
+        pos = torch.empty((B, C), dtype=torch.int64, device=dev)
+    if workspace is None:
+        nbytes = lib().dr_shard_bucket_workspace_bytes(n, world)
+        workspace = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
+    check(lib().dr_shard_bucket_ids(ptr(ids), n, C, int(rows_per_shard), int(world), ptr(counts), ptr(send_rows),
+                                    ptr(pos), ptr(workspace), stream_ptr()), "dr_shard_bucket_ids")
+    return counts, send_rows, pos
+
+
+def rows_gather(rows, table, lin_w=None, out_rows=None, out_lin=None):
+    rows = _c(rows, torch.int64)
+    n = rows.numel()
+    D = table.shape[1]
+    if out_rows is None:
+        out_rows = torch.empty((n, D), dtype=torch.float32, device=rows.device)
+    if out_lin is None and lin_w is not None:
+        out_lin = torch.empty(n, dtype=torch.float32, device=rows.device)
+    check(lib().dr_rows_gather(ptr(rows), n, ptr(table), D, ptr(lin_w), ptr(out_rows), ptr(out_lin), stream_ptr()),
+          "dr_rows_gather")
+    return out_rows, out_lin
+
+
+def rows_scatter_add(rows, grads, lin_grads, scale, table, lin_w):
+    rows = _c(rows, torch.int64)
+    n = rows.numel()
+    D = table.shape[1]
+    check(lib().dr_rows_scatter_add(ptr(rows), n, ptr(grads), D, ptr(lin_grads), float(scale), ptr(table), ptr(lin_w),
+                                    stream_ptr()), "dr_rows_scatter_add")
+
+
+def axpy(alpha, x, y):
+    assert x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
+    check(lib().dr_axpy(x.numel(), float(alpha), ptr(x), ptr(y), stream_ptr()), "dr_axpy")

@@ -187,6 +187,32 @@ int dr_sigmoid_bwd(const float* y, const float* dy, int64_t n, float* dx, dr_str
 int dr_bce_prob_fwd_bwd(const float* prob, const float* labels, int64_t n, int32_t mode, float* d_prob,
                         float* loss_out, float* workspace, dr_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Row-sharded tables over N ranks (new design — the reference is single-process; the
+ * exchange mirrors no reference code).  owner(id) = id % world; on the owner, field f's shard holds
+ * rows_per_shard rows and id lives at local row f*rows_per_shard + id / world.
+ *
+ * dr_shard_bucket_ids: stable counting sort of the n = B*C (example, column) slots by owner:
+ *   counts[world]   slots routed to each rank (device int64; the all-to-all split sizes)
+ *   send_rows[n]    owner-local row of every slot, grouped by owner (missing ids travel as -1)
+ *   pos[n]          position of slot p = b*C + c inside send_rows (the inverse map: rows come back from
+ *                   the all-to-all in send order, so K3 over `pos` as ids re-assembles example order)
+ *   workspace       dr_shard_bucket_workspace_bytes(n, world) bytes.  world <= 16.  Integer, bit-exact.
+ * dr_rows_gather / dr_rows_scatter_add: owner side of the forward / backward exchange (packed [n, D]
+ *   rows + first-order weights); scatter accumulates with fp32 atomics (dst += scale * grad).
+ * dr_axpy: y += alpha * x, applies an all-reduced dense gradient.
+ * ---------------------------------------------------------------------------------------- */
+int64_t dr_shard_bucket_workspace_bytes(int64_t n, int32_t world);
+int dr_shard_bucket_ids(const int64_t* ids, int64_t n, int32_t C, int64_t rows_per_shard, int32_t world,
+                        int64_t* counts, int64_t* send_rows, int64_t* pos, int64_t* workspace,
+                        dr_stream_t stream);
+int dr_rows_gather(const int64_t* rows, int64_t n, const float* table, int32_t D, const float* lin_w,
+                   float* out_rows, float* out_lin, dr_stream_t stream);
+int dr_rows_scatter_add(const int64_t* rows, int64_t n, const float* grads, int32_t D,
+                        const float* lin_grads, float scale, float* table, float* lin_w,
+                        dr_stream_t stream);
+int dr_axpy(int64_t n, float alpha, const float* x, float* y, dr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

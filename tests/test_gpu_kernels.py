@@ -266,3 +266,53 @@ def test_bce_modes(ops, mode):
     if mode == 0:
         lo.backward()
         np.testing.assert_allclose(g.cpu().numpy(), tx.grad.numpy(), rtol=1e-4, atol=1e-9)
+
+
+# ---------------------------------------------------------------- sharding prims
+@pytest.mark.parametrize("world", [1, 2, 8])
+def test_shard_bucket_ids_bit_exact(ops, world):
+    rng = np.random.default_rng(13)
+    B, C, V = 4099, 26, 10_000_000
+    ids = rng.integers(0, V, size=(B, C))
+    ids[rng.random((B, C)) < 0.01] = -1
+    rps = (V + world - 1) // world
+    counts, send_rows, pos = ops.shard_bucket_ids(_dev(ids), rps, world)
+    flat = ids.reshape(-1)
+    p = np.arange(flat.size)
+    owner = np.where(flat >= 0, flat % world, p % world)
+    local = np.where(flat >= 0, (p % C) * rps + flat // world, -1)
+    order = np.argsort(owner, kind="stable")
+    want_pos = np.empty_like(order)
+    want_pos[order] = np.arange(order.size)
+    np.testing.assert_array_equal(counts.cpu().numpy(), np.bincount(owner, minlength=world))
+    np.testing.assert_array_equal(send_rows.cpu().numpy(), local[order])       # stable: identical layout
+    np.testing.assert_array_equal(pos.cpu().numpy().reshape(-1), want_pos)
+
+
+def test_rows_gather_scatter_axpy(ops):
+    rng = np.random.default_rng(14)
+    R, D, n = 1000, 64, 5003
+    table = rng.standard_normal((R, D)).astype(np.float32)
+    lin = rng.standard_normal(R).astype(np.float32)
+    rows = rng.integers(0, R, size=n)
+    rows[::11] = -1
+    out, out_lin = ops.rows_gather(_dev(rows), _dev(table), _dev(lin))
+    want = np.where(rows[:, None] >= 0, table[np.maximum(rows, 0)], 0)
+    np.testing.assert_array_equal(out.cpu().numpy(), want)
+    np.testing.assert_array_equal(out_lin.cpu().numpy(), np.where(rows >= 0, lin[np.maximum(rows, 0)], 0))
+    grads = rng.standard_normal((n, D)).astype(np.float32)
+    lg = rng.standard_normal(n).astype(np.float32)
+    t_dev, l_dev = _dev(table).clone(), _dev(lin).clone()
+    ops.rows_scatter_add(_dev(rows), _dev(grads), _dev(lg), -0.5, t_dev, l_dev)
+    want_t = table.astype(np.float64).copy()
+    want_l = lin.astype(np.float64).copy()
+    m = rows >= 0
+    np.add.at(want_t, rows[m], -0.5 * grads[m])
+    np.add.at(want_l, rows[m], -0.5 * lg[m])
+    np.testing.assert_allclose(t_dev.cpu().numpy(), want_t, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(l_dev.cpu().numpy(), want_l, rtol=1e-5, atol=1e-5)
+    x = _dev(rng.standard_normal(10001).astype(np.float32))
+    y = _dev(rng.standard_normal(10001).astype(np.float32))
+    want = y.cpu().numpy() + np.float32(-0.25) * x.cpu().numpy()
+    ops.axpy(-0.25, x, y)
+    np.testing.assert_allclose(y.cpu().numpy(), want, rtol=1e-6, atol=1e-7)

@@ -346,3 +346,35 @@ def test_engine_train_step_matches_oracle():
     for i in range(len(Ws)):
         np.testing.assert_allclose(eng.Ws[i].cpu().numpy(), (Ws0[i] - lr * Ws[i].grad).numpy(), rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(eng.bs[i].cpu().numpy(), (bs0[i] - lr * bs[i].grad).numpy(), rtol=1e-4, atol=1e-6)
+
+
+def test_sharded_engine_world1_matches_unsharded_engine():
+    """HIP prims through the exchange plan (RCCL process group of size 1): one step must equal the plain engine's."""
+    import torch.distributed as dist
+    from deep_recommenders_amd.engine import DeepFMEngine
+    from deep_recommenders_amd.sharded import ShardedDeepFMEngine
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        F, V, D, B, Nd = 6, 3000, 16, 777, 3
+        ref = DeepFMEngine(F, V, D, [32, 16], B, num_dense=Nd, lr=0.05, seed=9, lin_init_std=0.1)
+        sh = ShardedDeepFMEngine(F, V, D, [32, 16], B, num_dense=Nd, lr=0.05, device="cuda", world=1, rank=0, seed=9,
+                                 init_tables=(ref.table.clone(), ref.lin_w.clone()))
+        for a, b in zip(sh.Ws, ref.Ws):
+            a.copy_(b)
+        g = torch.Generator(device="cuda")
+        g.manual_seed(2)
+        keys = torch.randint(0, 10**14, (B, F), device="cuda", generator=g)
+        keys[5, 2] = -1
+        dense = torch.rand((B, Nd), device="cuda", generator=g)
+        labels = (torch.rand(B, device="cuda", generator=g) < 0.25).float()
+        l_ref = ref.train_step(keys, dense, labels).item()
+        l_sh = sh.train_step(keys, dense, labels).item()
+        assert abs(l_ref - l_sh) <= 1e-6 * abs(l_ref)
+        np.testing.assert_allclose(sh.table.cpu().numpy(), ref.table.cpu().numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(sh.lin_w.cpu().numpy(), ref.lin_w.cpu().numpy(), rtol=1e-5, atol=1e-6)
+        for a, b in zip(sh.Ws, ref.Ws):
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    finally:
+        dist.destroy_process_group()

@@ -1,0 +1,223 @@
+"""world_size-2 `gloo` tests (CPU) of the N>1 exchange logic in deep_recommenders_amd/sharded.py.
+
+The HIP kernels cannot run here, so the engine is driven with an oracle-backed `prims` object (NumPy /
+torch-CPU restatements of each primitive, tests-only): what is under test is the bucketing / all-to-all /
+inverse-permutation / gradient-return / all-reduce plan.  The result of one sharded training step on two
+ranks must equal one single-process oracle step on the concatenated global batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import tf_semantics as O
+from oracle import torch_ref as T
+
+
+class OraclePrims:
+    @staticmethod
+    def hash_bucket_i64(keys, col_buckets, out=None):
+        k = keys.numpy()
+        res = np.stack([O.hash_bucket_i64(k[:, c], int(col_buckets[c])) for c in range(k.shape[1])], axis=1)
+        res = torch.from_numpy(res)
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
+
+    @staticmethod
+    def shard_bucket_ids(ids, rows_per_shard, world):
+        B, C = ids.shape
+        flat = ids.reshape(-1).numpy()
+        p = np.arange(flat.size)
+        owner = np.where(flat >= 0, flat % world, p % world)
+        local = np.where(flat >= 0, (p % C) * rows_per_shard + flat // world, -1)
+        order = np.argsort(owner, kind="stable")
+        pos = np.empty_like(order)
+        pos[order] = np.arange(order.size)
+        counts = np.bincount(owner, minlength=world).astype(np.int64)
+        return torch.from_numpy(counts), torch.from_numpy(local[order].astype(np.int64)), \
+            torch.from_numpy(pos.astype(np.int64)).reshape(B, C)
+
+    @staticmethod
+    def rows_gather(rows, table, lin_w=None):
+        m = rows >= 0
+        out = torch.zeros((rows.numel(), table.shape[1]))
+        out[m] = table[rows[m]]
+        lin = None
+        if lin_w is not None:
+            lin = torch.zeros(rows.numel())
+            lin[m] = lin_w[rows[m]]
+        return out, lin
+
+    @staticmethod
+    def rows_scatter_add(rows, grads, lin_grads, scale, table, lin_w):
+        m = rows >= 0
+        table.index_add_(0, rows[m], grads[m], alpha=scale)
+        if lin_w is not None and lin_grads is not None:
+            lin_w.index_add_(0, rows[m], lin_grads[m], alpha=scale)
+
+    @staticmethod
+    def emb_pool_fwd(ids, F, col_start, row_base, table, lin_w, lin_bias, ld_concat=None, concat=None, sum_x=None,
+                     fm_logit=None, **kw):
+        cs = list(range(F + 1)) if col_start is None else col_start.tolist()
+        c, s, l = T.emb_fm_forward(table, lin_w, lin_bias[0] if lin_bias is not None else 0.0, ids, cs, row_base.tolist())
+        concat[:, :c.shape[1]].copy_(c)
+        sum_x.copy_(s)
+        fm_logit.copy_(l)
+        return concat, sum_x, fm_logit
+
+    @staticmethod
+    def emb_pool_bwd(ids, F, col_start, row_base, D, d_concat, concat, sum_x, d_fm, scale, dst_table, dst_lin,
+                     dst_bias=None):
+        for f in range(F):        # single-valued fields in these tests
+            rows = ids[:, f] + row_base[f]
+            g = d_concat[:, f * D:(f + 1) * D] + d_fm[:, None] * (sum_x - concat[:, f * D:(f + 1) * D])
+            dst_table.index_add_(0, rows, g, alpha=scale)
+            if dst_lin is not None:
+                dst_lin.index_add_(0, rows, d_fm, alpha=scale)
+        if dst_bias is not None:
+            dst_bias += scale * d_fm.sum()
+
+    @staticmethod
+    def linear_fwd(x, W, b, act, out=None):
+        y = x @ W + b
+        if act:
+            y = torch.relu(y)
+        out.copy_(y)
+        return out
+
+    @staticmethod
+    def linear_bwd_dx(dy, W, relu_src=None, accumulate=False, out=None):
+        dx = dy @ W.t()
+        if relu_src is not None:
+            dx = dx * (relu_src > 0)
+        out.copy_(dx)
+        return out
+
+    @staticmethod
+    def linear_bwd_dw(x, dy, scale, dstW, dstb=None):
+        dstW += scale * (x.t() @ dy)
+        if dstb is not None:
+            dstb += scale * dy.sum(0)
+
+    @staticmethod
+    def bce_fwd_bwd(logits, labels, mode, workspace=None, logits_b=None, out=None, **kw):
+        x = logits + logits_b[:, 0]
+        prob, d_logit, loss = out
+        prob.copy_(torch.sigmoid(x))
+        d_logit.copy_((torch.sigmoid(x) - labels) / x.numel())
+        loss.copy_(T.sigmoid_cross_entropy(labels, x).reshape(1))
+        return loss, prob, d_logit
+
+    @staticmethod
+    def axpy(alpha, x, y):
+        y.add_(x, alpha=alpha)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+CFG = dict(F=4, V=37, D=8, B=24, Nd=3, units=[16, 8], lr=0.1)
+
+
+def _global_problem():
+    g = torch.Generator().manual_seed(123)
+    c = CFG
+    table = torch.randn((c["F"] * c["V"], c["D"]), generator=g) * 0.3
+    lin = torch.randn(c["F"] * c["V"], generator=g) * 0.1
+    keys = torch.randint(0, 10**9, (2 * c["B"], c["F"]), generator=g)
+    keys[3, 1] = -1                                # a missing id travels through the exchange as a zero row
+    dense = torch.rand((2 * c["B"], c["Nd"]), generator=g)
+    labels = (torch.rand(2 * c["B"], generator=g) < 0.3).float()
+    return table, lin, keys, dense, labels
+
+
+def _worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from deep_recommenders_amd.sharded import ShardedDeepFMEngine
+        c = CFG
+        table, lin, keys, dense, labels = _global_problem()
+        eng = ShardedDeepFMEngine(c["F"], c["V"], c["D"], c["units"], c["B"], num_dense=c["Nd"], lr=c["lr"], device="cpu",
+                                  world=world, rank=rank, seed=5, prims=OraclePrims, init_tables=(table, lin))
+        sl = slice(rank * c["B"], (rank + 1) * c["B"])
+        Ws0 = [w.clone() for w in eng.Ws]
+        bs0 = [b.clone() for b in eng.bs]
+        loss = eng.train_step(keys[sl], dense[sl], labels[sl]).item()
+        torch.save((rank, loss, eng.table.clone(), eng.lin_w.clone(), [w.clone() for w in eng.Ws],
+                    [b.clone() for b in eng.bs], eng.lin_bias.clone(), Ws0, bs0), os.path.join(outdir, "rank%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharded_step_equals_single_process_oracle(tmp_path):
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    res = {}
+    for r in range(world):
+        item = torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r))
+        res[item[0]] = item[1:]
+    c = CFG
+    table, lin, keys, dense, labels = _global_problem()
+    F, V, D, lr = c["F"], c["V"], c["D"], c["lr"]
+    ids = np.stack([O.hash_bucket_i64(keys[:, f].numpy(), V) for f in range(F)], axis=1)
+    Ws0, bs0 = res[0][6], res[0][7]
+    for a, b in zip(Ws0, res[1][6]):
+        assert torch.equal(a, b)                    # replicas start identical
+    tt = table.clone().requires_grad_(True)
+    tl = lin.clone().requires_grad_(True)
+    tb = torch.zeros(1, requires_grad=True)
+    Ws = [w.clone().requires_grad_(True) for w in Ws0]
+    bs = [b.clone().requires_grad_(True) for b in bs0]
+    logit = T.deepfm_logit(tt, tl, tb, torch.tensor(ids), list(range(F + 1)), [f * V for f in range(F)], Ws, bs, dense)
+    lo = T.sigmoid_cross_entropy(labels, logit)
+    lo.backward()
+    # global loss = mean of the per-rank means (equal batch sizes)
+    assert abs(0.5 * (res[0][0] + res[1][0]) - lo.item()) < 1e-6
+    want_table = (table - lr * tt.grad).detach()
+    want_lin = (lin - lr * tl.grad).detach()
+    rps = (V + world - 1) // world
+    for r in range(world):
+        _, tab_r, lin_r, Ws_r, bs_r, bias_r, _, _ = res[r]
+        for f in range(F):
+            gid = torch.arange(r, V, world)
+            np.testing.assert_allclose(tab_r[f * rps:f * rps + len(gid)].numpy(), want_table[f * V + gid].numpy(),
+                                       rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(lin_r[f * rps:f * rps + len(gid)].numpy(), want_lin[f * V + gid].numpy(),
+                                       rtol=1e-5, atol=1e-6)
+        for i in range(len(Ws)):
+            np.testing.assert_allclose(Ws_r[i].numpy(), (Ws0[i] - lr * Ws[i].grad).numpy(), rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(bs_r[i].numpy(), (bs0[i] - lr * bs[i].grad).numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(bias_r.numpy(), (-lr * tb.grad).numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_bucketing_oracle_matches_owner_rule():
+    ids = torch.tensor([[5, -1, 2], [0, 7, 9]])
+    counts, send_rows, pos = OraclePrims.shard_bucket_ids(ids, 10, 2)
+    assert counts.tolist() == [2, 4]
+    flat_owner = [1, 1, 0, 0, 1, 1]       # 5%2, missing p=1 -> 1%2, 2%2, 0%2, 7%2, 9%2
+    for p, o in enumerate(flat_owner):
+        start, size = (0, 2) if o == 0 else (2, 4)
+        assert start <= pos.reshape(-1)[p] < start + size
+    assert send_rows[pos[0, 0]].item() == 0 * 10 + 5 // 2
+    assert send_rows[pos[0, 1]].item() == -1
+    assert send_rows[pos[1, 2]].item() == 2 * 10 + 9 // 2
