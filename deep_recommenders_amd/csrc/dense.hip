@@ -29,7 +29,7 @@ constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int LD_T = 129;   // pitch of a transposed-in operand tile
 constexpr int LD_D = 132;   // pitch of a direct operand tile
 
-enum Epi { EPI_BIAS_ACT = 0, EPI_CROSS = 1, EPI_MASK = 2, EPI_ATOMIC = 3 };
+enum Epi { EPI_BIAS_ACT = 0, EPI_CROSS = 1, EPI_MASK = 2, EPI_ATOMIC = 3, EPI_FMGRAD = 4 };
 
 struct GemmArgs {
     const float* A; int64_t lda;
@@ -49,6 +49,8 @@ struct GemmArgs {
     float* colsum_dst;        // ATOMIC: dstb (may be null)
     int32_t split;            // ATOMIC: number of reduction splits (gridDim.y)
     int32_t a_vec, b_vec;     // operand base 16-B aligned and ld % 4 == 0 -> float4 loads allowed
+    // FMGRAD: C = acc + dl[i] * (S[i][j % fm_D] - x[i][j]) for j < fm_FD   (e0 = x, e1 = S [M, fm_D])
+    const float* vec; int32_t fm_D, fm_FD;
 };
 
 // bijective XCD-aware remap (cdna guide T1): consecutive logical tile ids -> same XCD
@@ -214,6 +216,10 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
                     const float prod = v + bj + g.alpha * xv;
                     if (g.aux != nullptr) g.aux[row * g.ldaux + col] = prod;
                     g.C[row * g.ldc + col] = g.e0[row * g.lde0 + col] * prod + xv;
+                } else if (EPI == EPI_FMGRAD) {
+                    if (col < g.fm_FD)
+                        v += g.vec[row] * (g.e1[row * g.lde1 + (col % g.fm_D)] - g.e0[row * g.lde0 + col]);
+                    g.C[row * g.ldc + col] = v;
                 } else if (EPI == EPI_MASK) {
                     if (g.e0 != nullptr && !(g.e0[row * g.lde0 + col] > 0.f)) v = 0.f;
                     if (g.accumulate) v += g.C[row * g.ldc + col];
@@ -307,6 +313,25 @@ extern "C" int dr_linear_bwd_dx(const float* dy, int64_t ld_dy, const float* W, 
     g.A = dy; g.lda = ld_dy; g.B = W; g.ldb = ld_w; g.M = M; g.N = K; g.R = N; g.C = dx; g.ldc = ld_dx;
     g.e0 = relu_src; g.lde0 = ld_relu_src; g.accumulate = accumulate; g.split = 1;
     return launch<true, true, EPI_MASK>(g, dr_s(stream));
+}
+
+// dgrad of the FIRST tower layer with the FM second-order gradient folded in:
+//   d_concat[m, j] = (dy @ W^T)[m, j] + d_fm_logit[m] * (sum_x[m, j % D] - concat[m, j])   for j < F*D
+// so the embedding backward needs ONE gradient stream and never re-reads concat (HBM-bound there, free here).
+extern "C" int dr_linear_bwd_dx_fm(const float* dy, int64_t ld_dy, const float* W, int64_t ld_w, int64_t M, int32_t K,
+                                   int32_t N, const float* d_fm_logit, const float* sum_x, const float* concat,
+                                   int64_t ld_concat, int32_t D, int32_t FD, float* dx, int64_t ld_dx,
+                                   dr_stream_t stream) {
+    if (M < 0 || K <= 0 || N <= 0 || D <= 0 || FD < 0 || FD > K) return DR_EINVAL;
+    if (M == 0) return DR_OK;
+    if (!dy || !W || !dx || !d_fm_logit || !sum_x || !concat || bad_ld(ld_dy, N) || bad_ld(ld_w, N) || ld_dx < K ||
+        ld_concat < FD || misaligned(dy) || misaligned(W))
+        return DR_EINVAL;
+    GemmArgs g{};
+    g.A = dy; g.lda = ld_dy; g.B = W; g.ldb = ld_w; g.M = M; g.N = K; g.R = N; g.C = dx; g.ldc = ld_dx;
+    g.e0 = concat; g.lde0 = ld_concat; g.e1 = sum_x; g.lde1 = D; g.vec = d_fm_logit; g.fm_D = D; g.fm_FD = FD;
+    g.split = 1;
+    return launch<true, true, EPI_FMGRAD>(g, dr_s(stream));
 }
 
 extern "C" int dr_linear_bwd_dw(const float* x, int64_t ld_x, const float* dy, int64_t ld_dy, int64_t M, int32_t K,

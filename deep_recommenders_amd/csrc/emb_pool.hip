@@ -25,6 +25,13 @@ __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4
 __device__ __forceinline__ float4 f4fma2(float4 a, float4 acc) {
     return make_float4(fmaf(a.x, a.x, acc.x), fmaf(a.y, a.y, acc.y), fmaf(a.z, a.z, acc.z), fmaf(a.w, a.w, acc.w));
 }
+// streaming (non-temporal) 16-byte store: the pooled rows are consumed much later by the GEMM, from HBM
+__device__ __forceinline__ void f4store_nt(float* p, float4 v) {
+    __builtin_nontemporal_store(v.x, p);
+    __builtin_nontemporal_store(v.y, p + 1);
+    __builtin_nontemporal_store(v.z, p + 2);
+    __builtin_nontemporal_store(v.w, p + 3);
+}
 __device__ __forceinline__ float4 f4shfl_xor(float4 v, int m) {
     return make_float4(__shfl_xor(v.x, m, 64), __shfl_xor(v.y, m, 64), __shfl_xor(v.z, m, 64), __shfl_xor(v.w, m, 64));
 }
@@ -77,7 +84,7 @@ __global__ __launch_bounds__(256) void emb_pool_fwd_sv_kernel(
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int f = f0 + u * NS + slot;
-                if (f < F && dvalid) *reinterpret_cast<float4*>(out_row + f * D + sub * 4) = v[u];
+                if (f < F && dvalid) f4store_nt(out_row + f * D + sub * 4, v[u]);
                 S = f4add(S, v[u]);
                 SS = f4fma2(v[u], SS);
             }

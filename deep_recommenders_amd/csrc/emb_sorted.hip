@@ -1,0 +1,170 @@
+// K4, deterministic form — row-sorted, de-duplicated scatter of the embedding gradients with the SGD step
+// fused (dst_row += scale * sum of the gradients of every (example, field) slot that looked the row up).
+//
+// Why (measured on MI355X, profiles/r01_exp_emb_variants.log): fp32 atomics on 66 GB of random rows run at
+// 2.7 TB/s algorithmic; a plain 16-byte load / add / store of each touched row runs at 5.2 TB/s — but is only
+// legal when exactly one lane group owns the row.  Sorting the B*F slots by table row makes ownership explicit,
+// turns hot (Zipf) rows into a segmented sum instead of an atomic pile-up, and makes the update bit-reproducible
+// run to run.  The sort depends only on the ids, so the engine runs it on a side stream under the MFMA-bound
+// tower; it is plumbing (rocPRIM radix sort, header-only, compiled into this library) — the gather / segment-sum /
+// read-modify-write kernel is ours.
+//
+// Replaces the autodiff of [TF] safe_embedding_lookup_sparse (IndexedSlices -> unsorted_segment_sum into the
+// variable) reached from optimizer.minimize (examples/train_fm_on_movielens_estimator.py:51-52, reference root).
+#include "dr_common.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace {
+
+constexpr int CH = 32;   // a lane group sums at most CH consecutive sorted slots (bounds hot-row serialisation)
+
+__global__ __launch_bounds__(256) void make_sort_keys_kernel(const int64_t* __restrict__ ids, int64_t n, int32_t F,
+                                                             const int64_t* __restrict__ row_base, uint64_t sentinel,
+                                                             uint64_t* __restrict__ keys, int32_t* __restrict__ vals) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+        const int64_t id = ids[p];
+        keys[p] = id >= 0 ? (uint64_t)(row_base[p % F] + id) : sentinel;   // missing ids sort to the end
+        vals[p] = (int32_t)p;
+    }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void emb_bwd_sorted_kernel(const uint64_t* __restrict__ rows,
+                                                             const int32_t* __restrict__ slots, int64_t n, int32_t F,
+                                                             int32_t D, uint64_t num_rows,
+                                                             const float* __restrict__ grad, int64_t ld,
+                                                             const float* __restrict__ d_fm_logit, float scale,
+                                                             float* __restrict__ table, float* __restrict__ lin_w,
+                                                             float* __restrict__ lin_bias) {
+    constexpr int NS = DR_WAVE / LPR;
+    const int lane = threadIdx.x & 63, slot = lane / LPR, sub = lane % LPR;
+    const bool dvalid = sub * 4 < D;
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    float bias_acc = 0.f;
+    for (int64_t i0 = wave0 * NS; i0 < n; i0 += nwaves * NS) {
+        const int64_t i = i0 + slot;
+        if (i >= n) continue;
+        const uint64_t k = rows[i];
+        if (k >= num_rows) continue;                                    // sentinel (missing id)
+        const bool seg_start = (i == 0) || (rows[i - 1] != k);
+        if (!seg_start && (i % CH) != 0) continue;                      // not a chunk head
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        float dls = 0.f;
+        int64_t j = i;
+        do {
+            const int32_t p = slots[j];
+            const int32_t b = p / F, f = p - b * F;
+            if (dvalid) {
+                const float4 v = *reinterpret_cast<const float4*>(grad + (int64_t)b * ld + f * D + sub * 4);
+                g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
+            }
+            if (d_fm_logit != nullptr && sub == 0) {
+                const float dl = d_fm_logit[b];
+                dls += dl;
+                if (f == 0) bias_acc += dl;                             // each example counted once
+            }
+            ++j;
+        } while (j < n && (j % CH) != 0 && rows[j] == k);
+        const bool exclusive = seg_start && (j >= n || rows[j] != k);   // this group owns the whole row
+        float* dst = table + k * (uint64_t)D + sub * 4;
+        if (exclusive) {
+            if (dvalid) {
+                float4 t = *reinterpret_cast<const float4*>(dst);
+                t.x = fmaf(scale, g.x, t.x); t.y = fmaf(scale, g.y, t.y);
+                t.z = fmaf(scale, g.z, t.z); t.w = fmaf(scale, g.w, t.w);
+                *reinterpret_cast<float4*>(dst) = t;
+            }
+            if (lin_w != nullptr && d_fm_logit != nullptr && sub == 0) lin_w[k] = fmaf(scale, dls, lin_w[k]);
+        } else {                                                        // hot row split over several chunks
+            if (dvalid) {
+                unsafeAtomicAdd(dst + 0, scale * g.x); unsafeAtomicAdd(dst + 1, scale * g.y);
+                unsafeAtomicAdd(dst + 2, scale * g.z); unsafeAtomicAdd(dst + 3, scale * g.w);
+            }
+            if (lin_w != nullptr && d_fm_logit != nullptr && sub == 0) unsafeAtomicAdd(lin_w + k, scale * dls);
+        }
+    }
+    if (lin_bias != nullptr && d_fm_logit != nullptr) {
+        bias_acc = dr_wave_sum(bias_acc);
+        if (lane == 0 && bias_acc != 0.f) unsafeAtomicAdd(lin_bias, scale * bias_acc);
+    }
+}
+
+unsigned bits_for(uint64_t v) {
+    unsigned b = 1;
+    while (b < 64 && (v >> b) != 0) ++b;
+    return b;
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+size_t rocprim_temp_bytes(int64_t n) {
+    size_t bytes = 0;
+    rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const int32_t*)nullptr,
+                              (int32_t*)nullptr, (size_t)n, 0u, 64u, (hipStream_t)0);
+    return bytes;
+}
+
+}  // namespace
+
+// workspace layout: [keys_in n*8][vals_in n*4 (padded)][rocprim temp]
+extern "C" int64_t dr_emb_sort_workspace_bytes(int64_t n) {
+    if (n <= 0) return 256;
+    return (int64_t)(align_up((size_t)n * 8, 256) + align_up((size_t)n * 4, 256) + align_up(rocprim_temp_bytes(n), 256));
+}
+
+extern "C" int dr_emb_sort_slots(const int64_t* ids, int64_t B, int32_t F, const int64_t* row_base, int64_t num_rows,
+                                 int64_t* sorted_rows, int32_t* sorted_slots, void* workspace, int64_t workspace_bytes,
+                                 dr_stream_t stream) {
+    if (B < 0 || F <= 0 || num_rows <= 0) return DR_EINVAL;
+    const int64_t n = B * F;
+    if (n == 0) return DR_OK;
+    if (n > 0x7fffffff) return DR_EINVAL;
+    if (!ids || !row_base || !sorted_rows || !sorted_slots || !workspace) return DR_EINVAL;
+    if (workspace_bytes < dr_emb_sort_workspace_bytes(n)) return DR_EINVAL;
+    char* w = static_cast<char*>(workspace);
+    uint64_t* keys_in = reinterpret_cast<uint64_t*>(w);
+    int32_t* vals_in = reinterpret_cast<int32_t*>(w + align_up((size_t)n * 8, 256));
+    void* temp = w + align_up((size_t)n * 8, 256) + align_up((size_t)n * 4, 256);
+    size_t temp_bytes = rocprim_temp_bytes(n);
+    hipLaunchKernelGGL(make_sort_keys_kernel, dim3(dr_grid_for(n, 256)), dim3(256), 0, dr_s(stream), ids, n, F, row_base,
+                       (uint64_t)num_rows, keys_in, vals_in);
+    const unsigned end_bit = bits_for((uint64_t)num_rows);      // the sentinel == num_rows needs these bits too
+    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, reinterpret_cast<uint64_t*>(sorted_rows), vals_in,
+                                             sorted_slots, (size_t)n, 0u, end_bit, dr_s(stream));
+    if (e != hipSuccess) return DR_ELAUNCH;
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+extern "C" int dr_emb_pool_bwd_sorted(const int64_t* sorted_rows, const int32_t* sorted_slots, int64_t n, int32_t F,
+                                      int32_t D, int64_t num_rows, const float* grad, int64_t ld_grad,
+                                      const float* d_fm_logit, float scale, float* dst_table, float* dst_lin,
+                                      float* dst_bias, dr_stream_t stream) {
+    if (n < 0 || F <= 0 || D < 4 || D > 256 || (D & 3) || num_rows <= 0) return DR_EINVAL;
+    if (n == 0) return DR_OK;
+    if (!sorted_rows || !sorted_slots || !grad || !dst_table || ld_grad < (int64_t)F * D || (ld_grad & 3)) return DR_EINVAL;
+    int lpr = 1;
+    while (lpr * 4 < D) lpr <<= 1;
+    const int grid = dr_grid_for(n, 4 * (64 / lpr), 4096);
+    const uint64_t* rows = reinterpret_cast<const uint64_t*>(sorted_rows);
+#define CALL(L)                                                                                                   \
+    hipLaunchKernelGGL((emb_bwd_sorted_kernel<L>), dim3(grid), dim3(256), 0, dr_s(stream), rows, sorted_slots, n, F, D, \
+                       (uint64_t)num_rows, grad, ld_grad, d_fm_logit, scale, dst_table, dst_lin, dst_bias)
+    switch (lpr) {
+        case 1: CALL(1); break;
+        case 2: CALL(2); break;
+        case 4: CALL(4); break;
+        case 8: CALL(8); break;
+        case 16: CALL(16); break;
+        case 32: CALL(32); break;
+        case 64: CALL(64); break;
+        default: return DR_EINVAL;
+    }
+#undef CALL
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}

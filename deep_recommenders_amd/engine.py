@@ -23,7 +23,7 @@ def _pad4(n):
 class DeepFMEngine:
     def __init__(self, num_fields: int, vocab_per_field: int, dim: int, dnn_units: Sequence[int], batch: int,
                  num_dense: int = 0, lr: float = 0.01, device="cuda", seed: int = 42, hashed: bool = True,
-                 table_init_std: Optional[float] = None, lin_init_std: float = 0.0):
+                 table_init_std: Optional[float] = None, lin_init_std: float = 0.0, sorted_bwd: bool = True):
         self.F, self.V, self.D, self.B = num_fields, vocab_per_field, dim, batch
         self.Nd, self.lr, self.dev, self.hashed = num_dense, lr, device, hashed
         F, V, D, B = self.F, self.V, self.D, self.B
@@ -71,6 +71,16 @@ class DeepFMEngine:
         self.loss = torch.zeros(1, **f32)
         self.ws = torch.empty(1024, **f32)
         self._events = None      # name -> [bound, work, [(start, end), ...]]
+        # ---- deterministic backward: slots sorted by table row on a side stream (depends only on ids) ----
+        self.sorted_bwd = sorted_bwd
+        if sorted_bwd:
+            n = B * F
+            self.sorted_rows = torch.empty(n, dtype=torch.int64, device=device)
+            self.sorted_slots = torch.empty(n, dtype=torch.int32, device=device)
+            self.sort_ws = ops.emb_sort_workspace(n, device)
+            self.side = torch.cuda.Stream(device=device)
+            self.ev_ids = torch.cuda.Event()
+            self.ev_sorted = torch.cuda.Event()
 
     # ---- per-kernel HIP events on the launch stream (bench.py's roofline numbers) ----------------------
     def enable_kernel_events(self, on: bool):
@@ -102,6 +112,14 @@ class DeepFMEngine:
         B = self.B
         self._k("hash_bucket_i64", "hbm", B * F * 16,
                 lambda: ops.hash_bucket_i64(keys, self.col_buckets, out=self.ids))                    # K1
+        if self.sorted_bwd:
+            self.ev_ids.record()
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(self.ev_ids)
+                self._k("emb_sort_slots", "hbm", B * F * 36,
+                        lambda: ops.emb_sort_slots(self.ids, self.row_base, self.R, self.sorted_rows, self.sorted_slots,
+                                                   self.sort_ws))
+                self.ev_sorted.record(self.side)
         self._k("emb_pool_fwd", "hbm", self.alg_bytes_fwd(),                                          # K3+K5+K6
                 lambda: ops.emb_pool_fwd(self.ids, F, None, self.row_base, self.table, self.lin_w, self.lin_bias,
                                          ld_concat=self.ld, concat=self.concat, sum_x=self.sum_x,
@@ -134,12 +152,23 @@ class DeepFMEngine:
             else:
                 dx = self.d_concat[:, :self.in_dim]
                 rs = None
-            self._k("linear_bwd_dx_L%d" % i, "mfma", fl,
-                    lambda dy=dy, W=W, rs=rs, dx=dx: ops.linear_bwd_dx(dy, W, relu_src=rs, out=dx))
+            if i == 0 and self.sorted_bwd:     # FM second-order gradient folded into the dgrad epilogue
+                self._k("linear_bwd_dx_L0", "mfma", fl,
+                        lambda dy=dy, W=W, dx=dx: ops.linear_bwd_dx_fm(dy, W, self.d_logit, self.sum_x, self.concat, D,
+                                                                       F * D, dx))
+            else:
+                self._k("linear_bwd_dx_L%d" % i, "mfma", fl,
+                        lambda dy=dy, W=W, rs=rs, dx=dx: ops.linear_bwd_dx(dy, W, relu_src=rs, out=dx))
             self._k("linear_bwd_dw_L%d" % i, "mfma", fl,
                     lambda x=x, dy=dy, W=W, i=i: ops.linear_bwd_dw(x, dy, -lr, W, self.bs[i]))
             dy = dx
-        self._k("emb_pool_bwd", "hbm", self.alg_bytes_bwd(),                                          # K4
+        if self.sorted_bwd:
+            torch.cuda.current_stream().wait_event(self.ev_sorted)
+            self._k("emb_pool_bwd", "hbm", self.alg_bytes_bwd(),                                      # K4 (sorted)
+                    lambda: ops.emb_pool_bwd_sorted(self.sorted_rows, self.sorted_slots, F, D, self.R, self.d_concat,
+                                                    self.d_logit, -lr, self.table, self.lin_w, self.lin_bias))
+            return
+        self._k("emb_pool_bwd", "hbm", self.alg_bytes_bwd(),                                          # K4 (atomics)
                 lambda: ops.emb_pool_bwd(self.ids, F, self.col_start, self.row_base, D, self.d_concat, self.concat,
                                          self.sum_x, self.d_logit, -lr, self.table, self.lin_w, self.lin_bias))
 

@@ -321,3 +321,47 @@ def rows_scatter_add(rows, grads, lin_grads, scale, table, lin_w):
 def axpy(alpha, x, y):
     assert x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
     check(lib().dr_axpy(x.numel(), float(alpha), ptr(x), ptr(y), stream_ptr()), "dr_axpy")
+
+
+# ----------------------------------------------------------------------------------------------
+# K4 deterministic form: sort slots by row, segment-sum, plain read-modify-write
+# ----------------------------------------------------------------------------------------------
+def emb_sort_workspace(n, device):
+    return torch.empty(lib().dr_emb_sort_workspace_bytes(int(n)), dtype=torch.uint8, device=device)
+
+
+def emb_sort_slots(ids, row_base, num_rows, sorted_rows=None, sorted_slots=None, workspace=None):
+    ids = _c(ids, torch.int64)
+    B, F = ids.shape
+    n = B * F
+    dev = ids.device
+    if sorted_rows is None:
+        sorted_rows = torch.empty(n, dtype=torch.int64, device=dev)
+    if sorted_slots is None:
+        sorted_slots = torch.empty(n, dtype=torch.int32, device=dev)
+    if workspace is None:
+        workspace = emb_sort_workspace(n, dev)
+    check(lib().dr_emb_sort_slots(ptr(ids), B, F, ptr(row_base), int(num_rows), ptr(sorted_rows), ptr(sorted_slots),
+                                  ptr(workspace), workspace.numel(), stream_ptr()), "dr_emb_sort_slots")
+    return sorted_rows, sorted_slots
+
+
+def emb_pool_bwd_sorted(sorted_rows, sorted_slots, F, D, num_rows, grad, d_fm_logit, scale, dst_table, dst_lin=None,
+                        dst_bias=None):
+    n = sorted_rows.numel()
+    assert grad.stride(1) == 1
+    check(lib().dr_emb_pool_bwd_sorted(ptr(sorted_rows), ptr(sorted_slots), n, F, D, int(num_rows), ptr(grad),
+                                       grad.stride(0), ptr(d_fm_logit), float(scale), ptr(dst_table), ptr(dst_lin),
+                                       ptr(dst_bias), stream_ptr()), "dr_emb_pool_bwd_sorted")
+
+
+def linear_bwd_dx_fm(dy, W, d_fm_logit, sum_x, concat, D, FD, out):
+    """First-layer dgrad with the FM second-order gradient folded into the epilogue."""
+    dy = _rowmajor_ld4(dy)
+    W = _rowmajor_ld4(W)
+    M, N = dy.shape
+    K = W.shape[0]
+    check(lib().dr_linear_bwd_dx_fm(ptr(dy), dy.stride(0), ptr(W), W.stride(0), M, K, N, ptr(d_fm_logit), ptr(sum_x),
+                                    ptr(concat), concat.stride(0), int(D), int(FD), ptr(out), out.stride(0),
+                                    stream_ptr()), "dr_linear_bwd_dx_fm")
+    return out

@@ -114,6 +114,26 @@ int dr_emb_pool_bwd(const int64_t* ids, int64_t B, int32_t F, int32_t C, const i
                     float* dst_table, float* dst_lin, float* dst_bias, dr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * K4, deterministic form (single-valued fields, C == F): sort the B*F slots by table row once per batch
+ * (dr_emb_sort_slots — depends only on ids, so it can run on a side stream), then
+ * dr_emb_pool_bwd_sorted sums the gradients of all slots of a row and applies ONE plain read-modify-write
+ *     dst_table[row,:] += scale * sum_slots grad[b, f*D:(f+1)*D]      dst_lin[row] += scale * sum_slots d_fm_logit[b]
+ *     dst_bias[0]      += scale * sum_b d_fm_logit[b]
+ * `grad` is the complete per-slot gradient (e.g. from dr_linear_bwd_dx_fm).  Rows hotter than 32 slots are
+ * split into chunks that combine with fp32 atomics; every other row is bit-reproducible.
+ * sorted_rows[n] int64 (missing ids carry num_rows and sort last), sorted_slots[n] int32 (slot = b*F + f);
+ * workspace >= dr_emb_sort_workspace_bytes(n) bytes.
+ * ---------------------------------------------------------------------------------------- */
+int64_t dr_emb_sort_workspace_bytes(int64_t n);
+int dr_emb_sort_slots(const int64_t* ids, int64_t B, int32_t F, const int64_t* row_base, int64_t num_rows,
+                      int64_t* sorted_rows, int32_t* sorted_slots, void* workspace,
+                      int64_t workspace_bytes, dr_stream_t stream);
+int dr_emb_pool_bwd_sorted(const int64_t* sorted_rows, const int32_t* sorted_slots, int64_t n, int32_t F,
+                           int32_t D, int64_t num_rows, const float* grad, int64_t ld_grad,
+                           const float* d_fm_logit, float scale, float* dst_table, float* dst_lin,
+                           float* dst_bias, dr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * K6  stand-alone FM second-order term on a caller-provided [B, F, D] tensor
  * replaces keras FM.call (keras/models/ranking/fm.py:28-35) and estimator fm(x)
  * (estimator/models/feature_interaction/fm.py:10-26).
@@ -146,6 +166,13 @@ int dr_linear_fwd(const float* x, int64_t ld_x, const float* W, int64_t ld_w, co
 int dr_linear_bwd_dx(const float* dy, int64_t ld_dy, const float* W, int64_t ld_w, int64_t M,
                      int32_t K, int32_t N, const float* relu_src, int64_t ld_relu_src,
                      int32_t accumulate, float* dx, int64_t ld_dx, dr_stream_t stream);
+/* dgrad of the first tower layer with the FM second-order gradient folded into the epilogue:
+ *   dx[m, j] = (dy @ W^T)[m, j] + d_fm_logit[m] * (sum_x[m, j % D] - concat[m, j])   for j < FD (= F*D)
+ * (autodiff of keras/models/ranking/fm.py:28-35 + deepfm.py:46 in one stream), so K4 reads one gradient. */
+int dr_linear_bwd_dx_fm(const float* dy, int64_t ld_dy, const float* W, int64_t ld_w, int64_t M,
+                        int32_t K, int32_t N, const float* d_fm_logit, const float* sum_x,
+                        const float* concat, int64_t ld_concat, int32_t D, int32_t FD, float* dx,
+                        int64_t ld_dx, dr_stream_t stream);
 int dr_linear_bwd_dw(const float* x, int64_t ld_x, const float* dy, int64_t ld_dy, int64_t M,
                      int32_t K, int32_t N, float scale, float* dstW, int64_t ld_w, float* dstb,
                      dr_stream_t stream);

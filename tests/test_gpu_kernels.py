@@ -316,3 +316,64 @@ def test_rows_gather_scatter_axpy(ops):
     want = y.cpu().numpy() + np.float32(-0.25) * x.cpu().numpy()
     ops.axpy(-0.25, x, y)
     np.testing.assert_allclose(y.cpu().numpy(), want, rtol=1e-6, atol=1e-7)
+
+
+# ---------------------------------------------------------------- K4 deterministic (sorted) form
+@pytest.mark.parametrize("D,F,V,hot", [(64, 26, 5000, False), (16, 7, 50, True), (128, 3, 7, True), (12, 5, 1000, False)])
+def test_emb_bwd_sorted_matches_oracle_and_is_deterministic(ops, D, F, V, hot):
+    rng = np.random.default_rng(21)
+    B = 1500
+    ids = rng.integers(0, V, size=(B, F))
+    if hot:
+        ids[:, 0] = 3                                   # one row hit by every example: > 32-slot chunks + atomics
+    ids[rng.random((B, F)) < 0.05] = -1
+    row_base = (np.arange(F) * V).astype(np.int64)
+    R = F * V
+    grad = rng.standard_normal((B, F * D)).astype(np.float32)
+    dl = rng.standard_normal(B).astype(np.float32)
+    table = rng.standard_normal((R, D)).astype(np.float32)
+    lin = rng.standard_normal(R).astype(np.float32)
+    srows, sslots = ops.emb_sort_slots(_dev(ids), _dev(row_base), R)
+    # the sort itself: keys ascending, payload is a permutation, missing ids last
+    sr, ss = srows.cpu().numpy(), sslots.cpu().numpy()
+    keys = np.where(ids.reshape(-1) >= 0, (ids + row_base[None, :]).reshape(-1), R)
+    assert np.all(np.diff(sr) >= 0) and sorted(ss.tolist()) == list(range(B * F))
+    np.testing.assert_array_equal(sr, keys[ss])
+    outs = []
+    for _ in range(2):
+        t_dev, l_dev, b_dev = _dev(table).clone(), _dev(lin).clone(), torch.zeros(1, device="cuda")
+        ops.emb_pool_bwd_sorted(srows, sslots, F, D, R, _dev(grad), _dev(dl), -0.1, t_dev, l_dev, b_dev)
+        outs.append((t_dev.cpu().numpy(), l_dev.cpu().numpy(), b_dev.item()))
+    want_t = table.astype(np.float64).copy()
+    want_l = lin.astype(np.float64).copy()
+    for f in range(F):
+        m = ids[:, f] >= 0
+        np.add.at(want_t, ids[m, f] + row_base[f], -0.1 * grad[m, f * D:(f + 1) * D])
+        np.add.at(want_l, ids[m, f] + row_base[f], -0.1 * dl[m])
+    tol = 1e-5 * (B if hot else 8)
+    np.testing.assert_allclose(outs[0][0], want_t, rtol=1e-5, atol=tol)
+    np.testing.assert_allclose(outs[0][1], want_l, rtol=1e-5, atol=tol)
+    has_f0 = ids[:, 0] >= 0
+    assert abs(outs[0][2] - (-0.1 * dl[has_f0].astype(np.float64).sum())) < 1e-3
+    if not hot:     # no row exceeds one chunk -> plain RMW everywhere -> bit-reproducible
+        np.testing.assert_array_equal(outs[0][0], outs[1][0])
+        np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+
+def test_linear_bwd_dx_fm_epilogue(ops):
+    rng = np.random.default_rng(22)
+    M, F, D, Nd, N = 300, 5, 16, 3, 40
+    K = F * D + Nd
+    ld = (K + 3) // 4 * 4
+    dy = rng.standard_normal((M, N)).astype(np.float32)
+    W = rng.standard_normal((K, N)).astype(np.float32)
+    dl = rng.standard_normal(M).astype(np.float32)
+    concat = np.zeros((M, ld), np.float32)
+    concat[:, :K] = rng.standard_normal((M, K)).astype(np.float32)
+    sum_x = concat[:, :F * D].reshape(M, F, D).sum(1)
+    out = torch.empty((M, ld), device="cuda")
+    ops.linear_bwd_dx_fm(_dev(dy), _dev(W), _dev(dl), _dev(sum_x), _dev(concat), D, F * D, out[:, :K])
+    want = dy.astype(np.float64) @ W.T.astype(np.float64)
+    fm = dl[:, None, None] * (sum_x[:, None, :] - concat[:, :F * D].reshape(M, F, D))
+    want[:, :F * D] += fm.reshape(M, F * D)
+    np.testing.assert_allclose(out[:, :K].cpu().numpy(), want, rtol=0, atol=2e-5 * (np.abs(want).max() + 1))
