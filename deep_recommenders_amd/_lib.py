@@ -24,7 +24,8 @@ SIGNATURES = {
     "dr_fm2_bwd": [_p, _p, _i64, _i32, _i32, _p, _p],
     "dr_linear_fwd": [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p],
     "dr_linear_bwd_dx": [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _i64, _i32, _p, _i64, _p],
-    "dr_linear_bwd_dw": [_p, _i64, _p, _i64, _i64, _i32, _i32, _f32, _p, _i64, _p, _p],
+    "dr_linear_bwd_dw": [_p, _i64, _p, _i64, _i64, _i32, _i32, _f32, _p, _i64, _p, _p, _i64, _p],
+    "dr_linear_bwd_dw_workspace_bytes": [_i64, _i32, _i32],
     "dr_cross_fwd": [_p, _p, _i64, _p, _i64, _p, _f32, _i64, _i32, _p, _p, _p],
     "dr_cross_combine_bwd": [_p, _p, _p, _i64, _i32, _i64, _f32, _p, _p, _p, _p],
     "dr_bce_fwd_bwd": [_p, _p, _i64, _p, _i64, _i32, _p, _p, _p, _p, _p],
@@ -37,13 +38,15 @@ SIGNATURES = {
     "dr_rows_scatter_add": [_p, _i64, _p, _i32, _p, _f32, _p, _p, _p],
     "dr_axpy": [_i64, _f32, _p, _p, _p],
     "dr_emb_sort_workspace_bytes": [_i64],
-    "dr_emb_sort_slots": [_p, _i64, _i32, _p, _i64, _p, _p, _p, _i64, _p],
-    "dr_emb_pool_bwd_sorted": [_p, _p, _i64, _i32, _i32, _i64, _p, _i64, _p, _f32, _p, _p, _p, _p],
+    "dr_emb_sort_slots": [_p, _i64, _i32, _p, _i64, _p, _p, _p, _p, _i64, _p],
+    "dr_emb_pool_bwd_sorted": [_p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _i64, _p, _i64, _p, _p, _f32, _p, _p,
+                               _p, _p],
     "dr_linear_bwd_dx_fm": [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _i64, _i32, _i32, _p, _i64, _p],
     "dr_version": [],
 }
 _RESTYPE = {"dr_version": ctypes.c_char_p, "dr_shard_bucket_workspace_bytes": ctypes.c_int64,
-            "dr_emb_sort_workspace_bytes": ctypes.c_int64}
+            "dr_emb_sort_workspace_bytes": ctypes.c_int64,
+            "dr_linear_bwd_dw_workspace_bytes": ctypes.c_int64}
 
 DR_OK, DR_EINVAL, DR_ELAUNCH, DR_ESHAPE = 0, -1, -2, -3
 _ERR = {DR_EINVAL: "DR_EINVAL (bad argument)", DR_ELAUNCH: "DR_ELAUNCH (HIP launch error)",

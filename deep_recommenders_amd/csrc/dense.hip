@@ -48,6 +48,7 @@ struct GemmArgs {
     int32_t accumulate;       // MASK: add to existing C
     float* colsum_dst;        // ATOMIC: dstb (may be null)
     int32_t split;            // ATOMIC: number of reduction splits (gridDim.y)
+    float* partial;           // ATOMIC: if non-null, block (tile, y) stores its tile to partial[y][M][N] instead of atomics
     int32_t a_vec, b_vec;     // operand base 16-B aligned and ld % 4 == 0 -> float4 loads allowed
     // FMGRAD: C = acc + dl[i] * (S[i][j % fm_D] - x[i][j]) for j < fm_FD   (e0 = x, e1 = S [M, fm_D])
     const float* vec; int32_t fm_D, fm_FD;
@@ -107,6 +108,8 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
         r_end = r_begin + per < g.R ? r_begin + per : g.R;
         if (r_begin >= r_end) return;
     }
+    // block-uniform: whole tile inside the matrices and float4 loads legal -> branch-free loader
+    const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N) && g.a_vec && g.b_vec;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -116,50 +119,55 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[a][b][k] = 0.f;
 
+    // per-thread tile coordinates of its 4 float4's: RC operand -> (i = idx>>3, r4 = idx&7), else (r = idx>>5, c4 = idx&31)
+    const int rc_i = tid >> 3, rc_r4 = tid & 7;       // + 32*q rows
+    const int dr_r = tid >> 5, dr_c4 = tid & 31;      // + 8*q reduction rows
+    const float* pa = A_RC ? g.A + (m0 + rc_i) * g.lda + rc_r4 * 4 + r_begin
+                           : g.A + (r_begin + dr_r) * g.lda + m0 + dr_c4 * 4;
+    const float* pb = B_RC ? g.B + ((int64_t)n0 + rc_i) * g.ldb + rc_r4 * 4 + r_begin
+                           : g.B + (r_begin + dr_r) * g.ldb + n0 + dr_c4 * 4;
+    const int64_t a_q = A_RC ? 32 * g.lda : 8 * g.lda;      // stride between a thread's 4 loads
+    const int64_t b_q = B_RC ? 32 * g.ldb : 8 * g.ldb;
+    const int64_t a_it = A_RC ? BK : BK * g.lda;            // advance per k-tile
+    const int64_t b_it = B_RC ? BK : BK * g.ldb;
+
     float4 ra[4], rb[4];
-    auto load_tiles = [&](int64_t r0) {
+    auto load_fast = [&]() {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int idx = tid + 256 * q;
-            if (A_RC) {   // 128 rows(i) x 8 float4 along r
-                const int i = idx >> 3, r4 = idx & 7;
-                ra[q] = guarded_ld4(g.A, g.lda, m0 + i, g.M, r0 + r4 * 4, r_end, g.a_vec);
-            } else {      // 32 rows(r) x 32 float4 along i
-                const int r = idx >> 5, c4 = idx & 31;
-                ra[q] = guarded_ld4(g.A, g.lda, r0 + r, r_end, m0 + c4 * 4, g.M, g.a_vec);
-            }
-            if (B_RC) {
-                const int j = idx >> 3, r4 = idx & 7;
-                rb[q] = guarded_ld4(g.B, g.ldb, (int64_t)n0 + j, g.N, r0 + r4 * 4, r_end, g.b_vec);
-            } else {
-                const int r = idx >> 5, c4 = idx & 31;
-                rb[q] = guarded_ld4(g.B, g.ldb, r0 + r, r_end, (int64_t)n0 + c4 * 4, g.N, g.b_vec);
-            }
+            ra[q] = *reinterpret_cast<const float4*>(pa + q * a_q);
+            rb[q] = *reinterpret_cast<const float4*>(pb + q * b_q);
         }
+    };
+    auto load_guarded = [&](int64_t r0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (A_RC) ra[q] = guarded_ld4(g.A, g.lda, m0 + rc_i + 32 * q, g.M, r0 + rc_r4 * 4, r_end, g.a_vec);
+            else      ra[q] = guarded_ld4(g.A, g.lda, r0 + dr_r + 8 * q, r_end, m0 + dr_c4 * 4, g.M, g.a_vec);
+            if (B_RC) rb[q] = guarded_ld4(g.B, g.ldb, (int64_t)n0 + rc_i + 32 * q, g.N, r0 + rc_r4 * 4, r_end, g.b_vec);
+            else      rb[q] = guarded_ld4(g.B, g.ldb, r0 + dr_r + 8 * q, r_end, (int64_t)n0 + dr_c4 * 4, g.N, g.b_vec);
+        }
+    };
+    auto load_tiles = [&](int64_t r0) {
+        if (interior && r0 + BK <= r_end) load_fast();
+        else load_guarded(r0);
+        pa += a_it;
+        pb += b_it;
     };
     auto store_tiles = [&]() {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int idx = tid + 256 * q;
             if (A_RC) {
-                const int i = idx >> 3, r4 = idx & 7;
-                As[(r4 * 4 + 0) * LDA + i] = ra[q].x;
-                As[(r4 * 4 + 1) * LDA + i] = ra[q].y;
-                As[(r4 * 4 + 2) * LDA + i] = ra[q].z;
-                As[(r4 * 4 + 3) * LDA + i] = ra[q].w;
+                float* d = As + (rc_r4 * 4) * LDA + rc_i + 32 * q;
+                d[0] = ra[q].x; d[LDA] = ra[q].y; d[2 * LDA] = ra[q].z; d[3 * LDA] = ra[q].w;
             } else {
-                const int r = idx >> 5, c4 = idx & 31;
-                *reinterpret_cast<float4*>(&As[r * LDA + c4 * 4]) = ra[q];
+                *reinterpret_cast<float4*>(&As[(dr_r + 8 * q) * LDA + dr_c4 * 4]) = ra[q];
             }
             if (B_RC) {
-                const int j = idx >> 3, r4 = idx & 7;
-                Bs[(r4 * 4 + 0) * LDB + j] = rb[q].x;
-                Bs[(r4 * 4 + 1) * LDB + j] = rb[q].y;
-                Bs[(r4 * 4 + 2) * LDB + j] = rb[q].z;
-                Bs[(r4 * 4 + 3) * LDB + j] = rb[q].w;
+                float* d = Bs + (rc_r4 * 4) * LDB + rc_i + 32 * q;
+                d[0] = rb[q].x; d[LDB] = rb[q].y; d[2 * LDB] = rb[q].z; d[3 * LDB] = rb[q].w;
             } else {
-                const int r = idx >> 5, c4 = idx & 31;
-                *reinterpret_cast<float4*>(&Bs[r * LDB + c4 * 4]) = rb[q];
+                *reinterpret_cast<float4*>(&Bs[(dr_r + 8 * q) * LDB + dr_c4 * 4]) = rb[q];
             }
         }
     };
@@ -168,9 +176,8 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
     const bool do_colsum = (EPI == EPI_ATOMIC) && g.colsum_dst != nullptr && m0 == 0 && tid < BN;
 
     load_tiles(r_begin);
-    const int a_off = wm * 64 + (lane & 31);
-    const int b_off = wn * 64 + (lane & 31);
-    const int khalf = lane >> 5;
+    const float* as = As + (lane >> 5) * LDA + wm * 64 + (lane & 31);
+    const float* bs = Bs + (lane >> 5) * LDB + wn * 64 + (lane & 31);
     for (int64_t r0 = r_begin; r0 < r_end; r0 += BK) {
         store_tiles();
         __syncthreads();
@@ -179,53 +186,70 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
 #pragma unroll 8
             for (int r = 0; r < BK; ++r) colsum += Bs[r * LDB + tid];
         }
+        // software-pipelined fragment reads: the k-step kk+2 fragments are in flight under the kk MFMAs
+        float a0 = as[0], a1 = as[32], b0 = bs[0], b1 = bs[32];
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            const float a0 = As[(kk + khalf) * LDA + a_off];
-            const float a1 = As[(kk + khalf) * LDA + a_off + 32];
-            const float b0 = Bs[(kk + khalf) * LDB + b_off];
-            const float b1 = Bs[(kk + khalf) * LDB + b_off + 32];
+            float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+            if (kk + 2 < BK) {
+                na0 = as[(kk + 2) * LDA]; na1 = as[(kk + 2) * LDA + 32];
+                nb0 = bs[(kk + 2) * LDB]; nb1 = bs[(kk + 2) * LDB + 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ABOVE the MFMAs (hipcc sinks it otherwise)
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
         }
         __syncthreads();
     }
 
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const bool full = (m0 + BM <= g.M) && (n0 + BN <= g.N);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             const int col = n0 + wn * 64 + ni * 32 + (lane & 31);
-            if (col >= g.N) continue;
+            if (!full && col >= g.N) continue;
             float bj = 0.f;
             if ((EPI == EPI_BIAS_ACT || EPI == EPI_CROSS) && g.bias != nullptr) bj = g.bias[col];
+            int cmod = 0;
+            if (EPI == EPI_FMGRAD) cmod = col % g.fm_D;
+            const int64_t row_b = m0 + wm * 64 + mi * 32 + 4 * (lane >> 5);
+            float* cp = g.C + row_b * g.ldc + col;
+            const float* e0p = (EPI == EPI_CROSS || EPI == EPI_MASK || EPI == EPI_FMGRAD) && g.e0 != nullptr
+                                   ? g.e0 + row_b * g.lde0 + col : nullptr;
+            const float* e1p = (EPI == EPI_CROSS) ? g.e1 + row_b * g.lde1 + col
+                               : (EPI == EPI_FMGRAD ? g.e1 + row_b * g.lde1 + cmod : nullptr);
+            float* auxp = (EPI == EPI_CROSS && g.aux != nullptr) ? g.aux + row_b * g.ldaux + col : nullptr;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const int64_t row = m0 + wm * 64 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                if (row >= g.M) continue;
+                const int ro = (reg & 3) + 8 * (reg >> 2);
+                if (!full && row_b + ro >= g.M) continue;
                 float v = acc[mi][ni][reg];
                 if (EPI == EPI_BIAS_ACT) {
                     v += bj;
                     if (g.act == 1) v = fmaxf(v, 0.f);
-                    g.C[row * g.ldc + col] = v;
+                    cp[ro * g.ldc] = v;
                 } else if (EPI == EPI_CROSS) {
-                    const float xv = g.e1[row * g.lde1 + col];
+                    const float xv = e1p[ro * g.lde1];
                     const float prod = v + bj + g.alpha * xv;
-                    if (g.aux != nullptr) g.aux[row * g.ldaux + col] = prod;
-                    g.C[row * g.ldc + col] = g.e0[row * g.lde0 + col] * prod + xv;
+                    if (auxp != nullptr) auxp[ro * g.ldaux] = prod;
+                    cp[ro * g.ldc] = e0p[ro * g.lde0] * prod + xv;
                 } else if (EPI == EPI_FMGRAD) {
-                    if (col < g.fm_FD)
-                        v += g.vec[row] * (g.e1[row * g.lde1 + (col % g.fm_D)] - g.e0[row * g.lde0 + col]);
-                    g.C[row * g.ldc + col] = v;
+                    if (col < g.fm_FD) v += g.vec[row_b + ro] * (e1p[ro * g.lde1] - e0p[ro * g.lde0]);
+                    cp[ro * g.ldc] = v;
                 } else if (EPI == EPI_MASK) {
-                    if (g.e0 != nullptr && !(g.e0[row * g.lde0 + col] > 0.f)) v = 0.f;
-                    if (g.accumulate) v += g.C[row * g.ldc + col];
-                    g.C[row * g.ldc + col] = v;
+                    if (e0p != nullptr && !(e0p[ro * g.lde0] > 0.f)) v = 0.f;
+                    if (g.accumulate) v += cp[ro * g.ldc];
+                    cp[ro * g.ldc] = v;
                 } else {
-                    unsafeAtomicAdd(g.C + row * g.ldc + col, g.alpha * v);
+                    if (g.partial != nullptr)
+                        g.partial[((int64_t)blockIdx.y * g.M + row_b + ro) * g.N + col] = v;
+                    else
+                        unsafeAtomicAdd(cp + ro * g.ldc, g.alpha * v);
                 }
             }
         }
@@ -283,6 +307,21 @@ __global__ __launch_bounds__(256) void cross_combine_bwd_kernel(const float* __r
     }
 }
 
+// dst[k][n] += scale * sum_s partial[s][k][n]   (deterministic split-K combine with the SGD step fused)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int32_t split, int64_t K,
+                                                            int32_t N, float scale, float* __restrict__ dst,
+                                                            int64_t ld) {
+    const int64_t total = K * N;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        float acc = 0.f;
+        for (int s = 0; s < split; ++s) acc += partial[(int64_t)s * total + i];
+        const int64_t k = i / N;
+        const int n = (int)(i - k * N);
+        dst[k * ld + n] = fmaf(scale, acc, dst[k * ld + n]);
+    }
+}
+
 bool bad_ld(int64_t ld, int64_t min) { return ld < min; }
 bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3) != 0; }
 
@@ -334,8 +373,24 @@ extern "C" int dr_linear_bwd_dx_fm(const float* dy, int64_t ld_dy, const float* 
     return launch<true, true, EPI_FMGRAD>(g, dr_s(stream));
 }
 
+static int dw_split(int64_t M, int32_t K, int32_t N) {
+    const int64_t tiles = ((int64_t)(K + BM - 1) / BM) * ((N + BN - 1) / BN);
+    int64_t split = (512 + tiles - 1) / tiles;               // ~2 resident blocks per CU, one wave of blocks
+    const int64_t max_split = (M + 8 * BK - 1) / (8 * BK);     // at least 8 k-tiles per block
+    if (split > max_split) split = max_split;
+    if (split < 1) split = 1;
+    if (split > 65535) split = 65535;
+    return (int)split;
+}
+
+extern "C" int64_t dr_linear_bwd_dw_workspace_bytes(int64_t M, int32_t K, int32_t N) {
+    if (M <= 0 || K <= 0 || N <= 0) return 0;
+    return (int64_t)dw_split(M, K, N) * K * N * (int64_t)sizeof(float);
+}
+
 extern "C" int dr_linear_bwd_dw(const float* x, int64_t ld_x, const float* dy, int64_t ld_dy, int64_t M, int32_t K,
-                                int32_t N, float scale, float* dstW, int64_t ld_w, float* dstb, dr_stream_t stream) {
+                                int32_t N, float scale, float* dstW, int64_t ld_w, float* dstb, float* workspace,
+                                int64_t workspace_bytes, dr_stream_t stream) {
     if (M < 0 || K <= 0 || N <= 0) return DR_EINVAL;
     if (M == 0) return DR_OK;
     if (!x || !dy || !dstW || bad_ld(ld_x, K) || bad_ld(ld_dy, N) || ld_w < N || misaligned(x) || misaligned(dy))
@@ -344,14 +399,17 @@ extern "C" int dr_linear_bwd_dw(const float* x, int64_t ld_x, const float* dy, i
     GemmArgs g{};
     g.A = x; g.lda = ld_x; g.B = dy; g.ldb = ld_dy; g.M = K; g.N = N; g.R = M; g.C = dstW; g.ldc = ld_w;
     g.alpha = scale; g.colsum_dst = dstb;
-    const int64_t tiles = ((int64_t)(K + BM - 1) / BM) * ((N + BN - 1) / BN);
-    int64_t split = (1024 + tiles - 1) / tiles;            // aim at ~4 blocks per CU
-    const int64_t max_split = (M + 4 * BK - 1) / (4 * BK);   // at least 4 k-tiles per block
-    if (split > max_split) split = max_split;
-    if (split < 1) split = 1;
-    if (split > 65535) split = 65535;
-    g.split = (int32_t)split;
-    return launch<false, false, EPI_ATOMIC>(g, dr_s(stream));
+    g.split = dw_split(M, K, N);
+    const bool use_ws = workspace != nullptr && workspace_bytes >= dr_linear_bwd_dw_workspace_bytes(M, K, N) && g.split > 1;
+    g.partial = use_ws ? workspace : nullptr;
+    int rc = launch<false, false, EPI_ATOMIC>(g, dr_s(stream));
+    if (rc != DR_OK) return rc;
+    if (use_ws) {
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(dr_grid_for((int64_t)K * N, 256)), dim3(256), 0, dr_s(stream), workspace,
+                           g.split, (int64_t)K, N, scale, dstW, ld_w);
+        DR_CHECK_LAUNCH();
+    }
+    return DR_OK;
 }
 
 extern "C" int dr_cross_fwd(const float* x0, const float* x, int64_t ld, const float* W, int64_t ld_w, const float* b,

@@ -31,27 +31,121 @@ __global__ __launch_bounds__(256) void make_sort_keys_kernel(const int64_t* __re
     }
 }
 
-template <int LPR>
-__global__ __launch_bounds__(256) void emb_bwd_sorted_kernel(const uint64_t* __restrict__ rows,
-                                                             const int32_t* __restrict__ slots, int64_t n, int32_t F,
-                                                             int32_t D, uint64_t num_rows,
+// flag[p] = 1 iff slot p is the only slot of the batch that touches its row (valid id, no duplicate)
+__global__ __launch_bounds__(256) void mark_unique_kernel(const uint64_t* __restrict__ rows,
+                                                          const int32_t* __restrict__ slots, int64_t n,
+                                                          uint64_t num_rows, uint8_t* __restrict__ flags) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t k = rows[i];
+        const bool uniq = k < num_rows && (i == 0 || rows[i - 1] != k) && (i + 1 >= n || rows[i + 1] != k);
+        flags[slots[i]] = uniq ? 1 : 0;
+    }
+}
+
+// Fast path: streams the gradient in example order (coalesced), one wave per example; every slot whose row is
+// unique in the batch gets ONE plain 16-byte-per-lane load / fma / store of its table row.  No atomics.
+template <int LPR, int U>
+__global__ __launch_bounds__(256) void emb_bwd_unique_kernel(const int64_t* __restrict__ ids,
+                                                             const uint8_t* __restrict__ flags, int64_t B, int32_t F,
+                                                             const int64_t* __restrict__ row_base, int32_t D,
                                                              const float* __restrict__ grad, int64_t ld,
+                                                             const float* __restrict__ concat, int64_t ldc,
+                                                             const float* __restrict__ sum_x,
                                                              const float* __restrict__ d_fm_logit, float scale,
                                                              float* __restrict__ table, float* __restrict__ lin_w,
                                                              float* __restrict__ lin_bias) {
     constexpr int NS = DR_WAVE / LPR;
     const int lane = threadIdx.x & 63, slot = lane / LPR, sub = lane % LPR;
     const bool dvalid = sub * 4 < D;
+    const bool fm = concat != nullptr && sum_x != nullptr && d_fm_logit != nullptr;
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t my_base = lane < F ? row_base[lane] : 0;
     float bias_acc = 0.f;
+    for (int64_t b = wave0; b < B; b += nwaves) {
+        int64_t my_row = -1;      // lane l <-> field l: absolute row if this slot is unique, else -1
+        if (lane < F) {
+            const int64_t id = ids[b * F + lane];
+            if (id >= 0 && flags[b * F + lane]) my_row = my_base + id;
+        }
+        const float dl = d_fm_logit != nullptr ? d_fm_logit[b] : 0.f;
+        if (lane == 0) bias_acc += dl;                     // bias gradient: every example once
+        const float* grow = grad + b * ld;
+        float4 sx = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (fm && dvalid) sx = *reinterpret_cast<const float4*>(sum_x + b * D + sub * 4);
+        for (int f0 = 0; f0 < F; f0 += NS * U) {
+            int64_t row[U];
+            float4 g[U], t[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int f = f0 + u * NS + slot;
+                row[u] = __shfl(my_row, f < F ? f : 0, 64);
+                if (f >= F) row[u] = -1;
+                if (row[u] >= 0 && dvalid) {
+                    g[u] = *reinterpret_cast<const float4*>(grow + f * D + sub * 4);
+                    t[u] = *reinterpret_cast<const float4*>(table + row[u] * D + sub * 4);
+                    if (fm) {
+                        const float4 x = *reinterpret_cast<const float4*>(concat + b * ldc + f * D + sub * 4);
+                        g[u].x += dl * (sx.x - x.x); g[u].y += dl * (sx.y - x.y);
+                        g[u].z += dl * (sx.z - x.z); g[u].w += dl * (sx.w - x.w);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (row[u] >= 0) {
+                    if (dvalid) {
+                        float4 r = t[u];
+                        r.x = fmaf(scale, g[u].x, r.x); r.y = fmaf(scale, g[u].y, r.y);
+                        r.z = fmaf(scale, g[u].z, r.z); r.w = fmaf(scale, g[u].w, r.w);
+                        *reinterpret_cast<float4*>(table + row[u] * D + sub * 4) = r;
+                    }
+                    if (lin_w != nullptr && d_fm_logit != nullptr && sub == 0)
+                        lin_w[row[u]] = fmaf(scale, dl, lin_w[row[u]]);
+                }
+            }
+        }
+    }
+    if (lin_bias != nullptr && d_fm_logit != nullptr) {
+        bias_acc = dr_wave_sum(bias_acc);
+        if (lane == 0 && bias_acc != 0.f) unsafeAtomicAdd(lin_bias, scale * bias_acc);
+    }
+}
+
+// Duplicate path: rows touched by >= 2 slots.  One lane group per segment head sums the slot gradients in sorted
+// order.  A segment of <= CH slots is always owned by ONE group (plain RMW, deterministic); a hotter row is cut at
+// CH-aligned positions that lie >= CH past its start, those pieces combine with fp32 atomics.
+template <int LPR>
+__global__ __launch_bounds__(256) void emb_bwd_dups_kernel(const uint64_t* __restrict__ rows,
+                                                           const int32_t* __restrict__ slots, int64_t n, int32_t F,
+                                                           int32_t D, uint64_t num_rows,
+                                                           const float* __restrict__ grad, int64_t ld,
+                                                           const float* __restrict__ concat, int64_t ldc,
+                                                           const float* __restrict__ sum_x,
+                                                           const float* __restrict__ d_fm_logit, float scale,
+                                                           float* __restrict__ table, float* __restrict__ lin_w) {
+    constexpr int NS = DR_WAVE / LPR;
+    const int lane = threadIdx.x & 63, slot = lane / LPR, sub = lane % LPR;
+    const bool dvalid = sub * 4 < D;
+    const bool fm = concat != nullptr && sum_x != nullptr && d_fm_logit != nullptr;
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     for (int64_t i0 = wave0 * NS; i0 < n; i0 += nwaves * NS) {
         const int64_t i = i0 + slot;
         if (i >= n) continue;
         const uint64_t k = rows[i];
-        if (k >= num_rows) continue;                                    // sentinel (missing id)
+        if (k >= num_rows) continue;                                      // missing id
         const bool seg_start = (i == 0) || (rows[i - 1] != k);
-        if (!seg_start && (i % CH) != 0) continue;                      // not a chunk head
+        int64_t stop;                                                     // exclusive end of this group's piece
+        if (seg_start) {
+            if (i + 1 >= n || rows[i + 1] != k) continue;                 // unique row: done by the fast path
+            stop = ((i + CH - 1) / CH + 1) * CH;                          // first aligned position >= i + CH
+            if (i % CH == 0) stop = i + CH;
+        } else {
+            if ((i % CH) != 0 || i < CH || rows[i - CH] != k) continue;   // aligned AND >= CH past the segment start
+            stop = i + CH;
+        }
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         float dls = 0.f;
         int64_t j = i;
@@ -59,17 +153,19 @@ __global__ __launch_bounds__(256) void emb_bwd_sorted_kernel(const uint64_t* __r
             const int32_t p = slots[j];
             const int32_t b = p / F, f = p - b * F;
             if (dvalid) {
-                const float4 v = *reinterpret_cast<const float4*>(grad + (int64_t)b * ld + f * D + sub * 4);
+                float4 v = *reinterpret_cast<const float4*>(grad + (int64_t)b * ld + f * D + sub * 4);
+                if (fm) {
+                    const float dl = d_fm_logit[b];
+                    const float4 x = *reinterpret_cast<const float4*>(concat + (int64_t)b * ldc + f * D + sub * 4);
+                    const float4 sx = *reinterpret_cast<const float4*>(sum_x + (int64_t)b * D + sub * 4);
+                    v.x += dl * (sx.x - x.x); v.y += dl * (sx.y - x.y); v.z += dl * (sx.z - x.z); v.w += dl * (sx.w - x.w);
+                }
                 g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
             }
-            if (d_fm_logit != nullptr && sub == 0) {
-                const float dl = d_fm_logit[b];
-                dls += dl;
-                if (f == 0) bias_acc += dl;                             // each example counted once
-            }
+            if (d_fm_logit != nullptr && sub == 0) dls += d_fm_logit[b];
             ++j;
-        } while (j < n && (j % CH) != 0 && rows[j] == k);
-        const bool exclusive = seg_start && (j >= n || rows[j] != k);   // this group owns the whole row
+        } while (j < n && j < stop && rows[j] == k);
+        const bool exclusive = seg_start && (j >= n || rows[j] != k);
         float* dst = table + k * (uint64_t)D + sub * 4;
         if (exclusive) {
             if (dvalid) {
@@ -79,17 +175,13 @@ __global__ __launch_bounds__(256) void emb_bwd_sorted_kernel(const uint64_t* __r
                 *reinterpret_cast<float4*>(dst) = t;
             }
             if (lin_w != nullptr && d_fm_logit != nullptr && sub == 0) lin_w[k] = fmaf(scale, dls, lin_w[k]);
-        } else {                                                        // hot row split over several chunks
+        } else {
             if (dvalid) {
                 unsafeAtomicAdd(dst + 0, scale * g.x); unsafeAtomicAdd(dst + 1, scale * g.y);
                 unsafeAtomicAdd(dst + 2, scale * g.z); unsafeAtomicAdd(dst + 3, scale * g.w);
             }
             if (lin_w != nullptr && d_fm_logit != nullptr && sub == 0) unsafeAtomicAdd(lin_w + k, scale * dls);
         }
-    }
-    if (lin_bias != nullptr && d_fm_logit != nullptr) {
-        bias_acc = dr_wave_sum(bias_acc);
-        if (lane == 0 && bias_acc != 0.f) unsafeAtomicAdd(lin_bias, scale * bias_acc);
     }
 }
 
@@ -117,13 +209,13 @@ extern "C" int64_t dr_emb_sort_workspace_bytes(int64_t n) {
 }
 
 extern "C" int dr_emb_sort_slots(const int64_t* ids, int64_t B, int32_t F, const int64_t* row_base, int64_t num_rows,
-                                 int64_t* sorted_rows, int32_t* sorted_slots, void* workspace, int64_t workspace_bytes,
-                                 dr_stream_t stream) {
+                                 int64_t* sorted_rows, int32_t* sorted_slots, uint8_t* unique_flags, void* workspace,
+                                 int64_t workspace_bytes, dr_stream_t stream) {
     if (B < 0 || F <= 0 || num_rows <= 0) return DR_EINVAL;
     const int64_t n = B * F;
     if (n == 0) return DR_OK;
     if (n > 0x7fffffff) return DR_EINVAL;
-    if (!ids || !row_base || !sorted_rows || !sorted_slots || !workspace) return DR_EINVAL;
+    if (!ids || !row_base || !sorted_rows || !sorted_slots || !unique_flags || !workspace) return DR_EINVAL;
     if (workspace_bytes < dr_emb_sort_workspace_bytes(n)) return DR_EINVAL;
     char* w = static_cast<char*>(workspace);
     uint64_t* keys_in = reinterpret_cast<uint64_t*>(w);
@@ -136,24 +228,41 @@ extern "C" int dr_emb_sort_slots(const int64_t* ids, int64_t B, int32_t F, const
     hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, reinterpret_cast<uint64_t*>(sorted_rows), vals_in,
                                              sorted_slots, (size_t)n, 0u, end_bit, dr_s(stream));
     if (e != hipSuccess) return DR_ELAUNCH;
+    hipLaunchKernelGGL(mark_unique_kernel, dim3(dr_grid_for(n, 256)), dim3(256), 0, dr_s(stream),
+                       reinterpret_cast<const uint64_t*>(sorted_rows), sorted_slots, n, (uint64_t)num_rows, unique_flags);
     DR_CHECK_LAUNCH();
     return DR_OK;
 }
 
-extern "C" int dr_emb_pool_bwd_sorted(const int64_t* sorted_rows, const int32_t* sorted_slots, int64_t n, int32_t F,
+extern "C" int dr_emb_pool_bwd_sorted(const int64_t* ids, const int64_t* row_base, const int64_t* sorted_rows,
+                                      const int32_t* sorted_slots, const uint8_t* unique_flags, int64_t B, int32_t F,
                                       int32_t D, int64_t num_rows, const float* grad, int64_t ld_grad,
+                                      const float* concat, int64_t ld_concat, const float* sum_x,
                                       const float* d_fm_logit, float scale, float* dst_table, float* dst_lin,
                                       float* dst_bias, dr_stream_t stream) {
-    if (n < 0 || F <= 0 || D < 4 || D > 256 || (D & 3) || num_rows <= 0) return DR_EINVAL;
+    if (B < 0 || F <= 0 || F > 64 || D < 4 || D > 256 || (D & 3) || num_rows <= 0) return DR_EINVAL;
+    const int64_t n = B * F;
     if (n == 0) return DR_OK;
-    if (!sorted_rows || !sorted_slots || !grad || !dst_table || ld_grad < (int64_t)F * D || (ld_grad & 3)) return DR_EINVAL;
+    if (!ids || !row_base || !sorted_rows || !sorted_slots || !unique_flags || !grad || !dst_table ||
+        ld_grad < (int64_t)F * D || (ld_grad & 3))
+        return DR_EINVAL;
+    if (concat != nullptr && (ld_concat < (int64_t)F * D || (ld_concat & 3) || sum_x == nullptr)) return DR_EINVAL;
     int lpr = 1;
     while (lpr * 4 < D) lpr <<= 1;
-    const int grid = dr_grid_for(n, 4 * (64 / lpr), 4096);
     const uint64_t* rows = reinterpret_cast<const uint64_t*>(sorted_rows);
-#define CALL(L)                                                                                                   \
-    hipLaunchKernelGGL((emb_bwd_sorted_kernel<L>), dim3(grid), dim3(256), 0, dr_s(stream), rows, sorted_slots, n, F, D, \
-                       (uint64_t)num_rows, grad, ld_grad, d_fm_logit, scale, dst_table, dst_lin, dst_bias)
+    const int grid_u = dr_grid_for(B, 4, 8192);
+    const int grid_d = dr_grid_for(n, 4 * (64 / lpr), 4096);
+#define CALL(L)                                                                                                       \
+    {                                                                                                                 \
+        constexpr int NS_ = 64 / L;                                                                                   \
+        constexpr int U_ = NS_ >= 16 ? 2 : 4;                                                                         \
+        hipLaunchKernelGGL((emb_bwd_unique_kernel<L, U_>), dim3(grid_u), dim3(256), 0, dr_s(stream), ids, unique_flags, \
+                           B, F, row_base, D, grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit, scale, dst_table, dst_lin,   \
+                           dst_bias);                                                                                 \
+        hipLaunchKernelGGL((emb_bwd_dups_kernel<L>), dim3(grid_d), dim3(256), 0, dr_s(stream), rows, sorted_slots, n, \
+                           F, D, (uint64_t)num_rows, grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit, scale, dst_table,   \
+                           dst_lin);                                                                                  \
+    }
     switch (lpr) {
         case 1: CALL(1); break;
         case 2: CALL(2); break;

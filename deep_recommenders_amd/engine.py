@@ -53,6 +53,7 @@ class DeepFMEngine:
             self.bs.append(torch.zeros(u, dtype=torch.float32, device=device))
             d = u
         self.acts = [1] * len(dnn_units) + [0]
+        self.dw_ws = [ops.linear_bwd_dw_workspace(B, W.shape[0], W.shape[1], device) for W in self.Ws]
         # ---- constant metadata ---------------------------------------------------------------------
         self.row_base = torch.arange(F, device=device, dtype=torch.int64) * V
         self.col_start = torch.arange(F + 1, device=device, dtype=torch.int32)
@@ -73,10 +74,14 @@ class DeepFMEngine:
         self._events = None      # name -> [bound, work, [(start, end), ...]]
         # ---- deterministic backward: slots sorted by table row on a side stream (depends only on ids) ----
         self.sorted_bwd = sorted_bwd
+        import os as _os
+        self.sort_inline = _os.environ.get("DR_SORT_INLINE", "0") == "1"
+        self.fold_fm = _os.environ.get("DR_FOLD_FM", "0") == "1"
         if sorted_bwd:
             n = B * F
             self.sorted_rows = torch.empty(n, dtype=torch.int64, device=device)
             self.sorted_slots = torch.empty(n, dtype=torch.int32, device=device)
+            self.uniq_flags = torch.empty(n, dtype=torch.uint8, device=device)
             self.sort_ws = ops.emb_sort_workspace(n, device)
             self.side = torch.cuda.Stream(device=device)
             self.ev_ids = torch.cuda.Event()
@@ -112,13 +117,18 @@ class DeepFMEngine:
         B = self.B
         self._k("hash_bucket_i64", "hbm", B * F * 16,
                 lambda: ops.hash_bucket_i64(keys, self.col_buckets, out=self.ids))                    # K1
-        if self.sorted_bwd:
+        if self.sorted_bwd and self.sort_inline:
+            self._k("emb_sort_slots", "hbm", B * F * 36,
+                    lambda: ops.emb_sort_slots(self.ids, self.row_base, self.R, self.sorted_rows, self.sorted_slots,
+                                               self.uniq_flags, self.sort_ws))
+            self.ev_sorted.record()
+        elif self.sorted_bwd:
             self.ev_ids.record()
             with torch.cuda.stream(self.side):
                 self.side.wait_event(self.ev_ids)
                 self._k("emb_sort_slots", "hbm", B * F * 36,
                         lambda: ops.emb_sort_slots(self.ids, self.row_base, self.R, self.sorted_rows, self.sorted_slots,
-                                                   self.sort_ws))
+                                                   self.uniq_flags, self.sort_ws))
                 self.ev_sorted.record(self.side)
         self._k("emb_pool_fwd", "hbm", self.alg_bytes_fwd(),                                          # K3+K5+K6
                 lambda: ops.emb_pool_fwd(self.ids, F, None, self.row_base, self.table, self.lin_w, self.lin_bias,
@@ -152,7 +162,7 @@ class DeepFMEngine:
             else:
                 dx = self.d_concat[:, :self.in_dim]
                 rs = None
-            if i == 0 and self.sorted_bwd:     # FM second-order gradient folded into the dgrad epilogue
+            if i == 0 and self.sorted_bwd and self.fold_fm:   # FM gradient folded into the dgrad epilogue (measured: slower)
                 self._k("linear_bwd_dx_L0", "mfma", fl,
                         lambda dy=dy, W=W, dx=dx: ops.linear_bwd_dx_fm(dy, W, self.d_logit, self.sum_x, self.concat, D,
                                                                        F * D, dx))
@@ -160,13 +170,16 @@ class DeepFMEngine:
                 self._k("linear_bwd_dx_L%d" % i, "mfma", fl,
                         lambda dy=dy, W=W, rs=rs, dx=dx: ops.linear_bwd_dx(dy, W, relu_src=rs, out=dx))
             self._k("linear_bwd_dw_L%d" % i, "mfma", fl,
-                    lambda x=x, dy=dy, W=W, i=i: ops.linear_bwd_dw(x, dy, -lr, W, self.bs[i]))
+                    lambda x=x, dy=dy, W=W, i=i: ops.linear_bwd_dw(x, dy, -lr, W, self.bs[i], workspace=self.dw_ws[i]))
             dy = dx
         if self.sorted_bwd:
             torch.cuda.current_stream().wait_event(self.ev_sorted)
             self._k("emb_pool_bwd", "hbm", self.alg_bytes_bwd(),                                      # K4 (sorted)
-                    lambda: ops.emb_pool_bwd_sorted(self.sorted_rows, self.sorted_slots, F, D, self.R, self.d_concat,
-                                                    self.d_logit, -lr, self.table, self.lin_w, self.lin_bias))
+                    lambda: ops.emb_pool_bwd_sorted(self.ids, self.row_base, self.sorted_rows, self.sorted_slots,
+                                                    self.uniq_flags, D, self.R, self.d_concat, self.d_logit, -lr,
+                                                    self.table, self.lin_w, self.lin_bias,
+                                                    concat=None if self.fold_fm else self.concat,
+                                                    sum_x=None if self.fold_fm else self.sum_x))
             return
         self._k("emb_pool_bwd", "hbm", self.alg_bytes_bwd(),                                          # K4 (atomics)
                 lambda: ops.emb_pool_bwd(self.ids, F, self.col_start, self.row_base, D, self.d_concat, self.concat,

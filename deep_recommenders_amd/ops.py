@@ -173,15 +173,22 @@ def linear_bwd_dx(dy, W, relu_src=None, accumulate=False, out=None):
     return out
 
 
-def linear_bwd_dw(x, dy, scale, dstW, dstb=None):
-    """dstW += scale * x^T @ dy ; dstb += scale * colsum(dy)   (atomic accumulation into dst)."""
+def linear_bwd_dw_workspace(M, K, N, device):
+    return torch.empty(max(1, lib().dr_linear_bwd_dw_workspace_bytes(int(M), int(K), int(N)) // 4), dtype=torch.float32,
+                       device=device)
+
+
+def linear_bwd_dw(x, dy, scale, dstW, dstb=None, workspace=None):
+    """dstW += scale * x^T @ dy ; dstb += scale * colsum(dy).  With a workspace the split-K partials are combined
+    deterministically by a reduce kernel; without, by fp32 atomics."""
     x = _rowmajor_ld4(x)
     dy = _rowmajor_ld4(dy)
     M, K = x.shape
     N = dy.shape[1]
     assert dstW.shape == (K, N) and dstW.stride(1) == 1
     check(lib().dr_linear_bwd_dw(ptr(x), x.stride(0), ptr(dy), dy.stride(0), M, K, N, float(scale), ptr(dstW),
-                                 dstW.stride(0), ptr(dstb), stream_ptr()), "dr_linear_bwd_dw")
+                                 dstW.stride(0), ptr(dstb), ptr(workspace),
+                                 workspace.numel() * 4 if workspace is not None else 0, stream_ptr()), "dr_linear_bwd_dw")
 
 
 def cross_fwd(x0, x, W, b, diag_scale=0.0, want_prod=False, prod=None):
@@ -330,7 +337,7 @@ def emb_sort_workspace(n, device):
     return torch.empty(lib().dr_emb_sort_workspace_bytes(int(n)), dtype=torch.uint8, device=device)
 
 
-def emb_sort_slots(ids, row_base, num_rows, sorted_rows=None, sorted_slots=None, workspace=None):
+def emb_sort_slots(ids, row_base, num_rows, sorted_rows=None, sorted_slots=None, flags=None, workspace=None):
     ids = _c(ids, torch.int64)
     B, F = ids.shape
     n = B * F
@@ -339,20 +346,26 @@ def emb_sort_slots(ids, row_base, num_rows, sorted_rows=None, sorted_slots=None,
         sorted_rows = torch.empty(n, dtype=torch.int64, device=dev)
     if sorted_slots is None:
         sorted_slots = torch.empty(n, dtype=torch.int32, device=dev)
+    if flags is None:
+        flags = torch.empty(n, dtype=torch.uint8, device=dev)
     if workspace is None:
         workspace = emb_sort_workspace(n, dev)
     check(lib().dr_emb_sort_slots(ptr(ids), B, F, ptr(row_base), int(num_rows), ptr(sorted_rows), ptr(sorted_slots),
-                                  ptr(workspace), workspace.numel(), stream_ptr()), "dr_emb_sort_slots")
-    return sorted_rows, sorted_slots
+                                  ptr(flags), ptr(workspace), workspace.numel(), stream_ptr()), "dr_emb_sort_slots")
+    return sorted_rows, sorted_slots, flags
 
 
-def emb_pool_bwd_sorted(sorted_rows, sorted_slots, F, D, num_rows, grad, d_fm_logit, scale, dst_table, dst_lin=None,
-                        dst_bias=None):
-    n = sorted_rows.numel()
+def emb_pool_bwd_sorted(ids, row_base, sorted_rows, sorted_slots, flags, D, num_rows, grad, d_fm_logit, scale,
+                        dst_table, dst_lin=None, dst_bias=None, concat=None, sum_x=None):
+    ids = _c(ids, torch.int64)
+    B, F = ids.shape
     assert grad.stride(1) == 1
-    check(lib().dr_emb_pool_bwd_sorted(ptr(sorted_rows), ptr(sorted_slots), n, F, D, int(num_rows), ptr(grad),
-                                       grad.stride(0), ptr(d_fm_logit), float(scale), ptr(dst_table), ptr(dst_lin),
-                                       ptr(dst_bias), stream_ptr()), "dr_emb_pool_bwd_sorted")
+    check(lib().dr_emb_pool_bwd_sorted(ptr(ids), ptr(row_base), ptr(sorted_rows), ptr(sorted_slots), ptr(flags), B, F, D,
+                                       int(num_rows), ptr(grad), grad.stride(0), ptr(concat),
+                                       concat.stride(0) if concat is not None else 0, ptr(sum_x),
+                                       ptr(d_fm_logit), float(scale),
+                                       ptr(dst_table), ptr(dst_lin), ptr(dst_bias), stream_ptr()),
+          "dr_emb_pool_bwd_sorted")
 
 
 def linear_bwd_dx_fm(dy, W, d_fm_logit, sum_x, concat, D, FD, out):

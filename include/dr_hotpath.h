@@ -114,22 +114,27 @@ int dr_emb_pool_bwd(const int64_t* ids, int64_t B, int32_t F, int32_t C, const i
                     float* dst_table, float* dst_lin, float* dst_bias, dr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
- * K4, deterministic form (single-valued fields, C == F): sort the B*F slots by table row once per batch
- * (dr_emb_sort_slots — depends only on ids, so it can run on a side stream), then
- * dr_emb_pool_bwd_sorted sums the gradients of all slots of a row and applies ONE plain read-modify-write
+ * K4, deterministic form (single-valued fields, C == F <= 64): sort the B*F slots by table row once per
+ * batch (dr_emb_sort_slots — depends only on ids, so it can run on a side stream) and flag the slots whose row
+ * is unique in the batch; dr_emb_pool_bwd_sorted then applies
  *     dst_table[row,:] += scale * sum_slots grad[b, f*D:(f+1)*D]      dst_lin[row] += scale * sum_slots d_fm_logit[b]
  *     dst_bias[0]      += scale * sum_b d_fm_logit[b]
- * `grad` is the complete per-slot gradient (e.g. from dr_linear_bwd_dx_fm).  Rows hotter than 32 slots are
- * split into chunks that combine with fp32 atomics; every other row is bit-reproducible.
- * sorted_rows[n] int64 (missing ids carry num_rows and sort last), sorted_slots[n] int32 (slot = b*F + f);
- * workspace >= dr_emb_sort_workspace_bytes(n) bytes.
+ * with (a) a streaming pass in example order doing ONE plain read-modify-write per unique row, and (b) a
+ * segmented pass in sorted order for rows hit by several slots.  Per-slot gradient = grad[b, f*D:(f+1)*D]
+ * (+ d_fm_logit[b] * (sum_x[b,:] - concat[b, f*D:(f+1)*D]) when concat / sum_x are given, as in
+ * dr_emb_pool_bwd; pass NULL when `grad` already holds it, e.g. from dr_linear_bwd_dx_fm).  Rows hit by <= 32 slots are bit-reproducible; hotter rows are cut into
+ * pieces that combine with fp32 atomics.
+ * sorted_rows[n] int64 (missing ids carry num_rows and sort last), sorted_slots[n] int32 (slot = b*F + f),
+ * unique_flags[n] uint8 (indexed by slot); workspace >= dr_emb_sort_workspace_bytes(n) bytes.
  * ---------------------------------------------------------------------------------------- */
 int64_t dr_emb_sort_workspace_bytes(int64_t n);
 int dr_emb_sort_slots(const int64_t* ids, int64_t B, int32_t F, const int64_t* row_base, int64_t num_rows,
-                      int64_t* sorted_rows, int32_t* sorted_slots, void* workspace,
+                      int64_t* sorted_rows, int32_t* sorted_slots, uint8_t* unique_flags, void* workspace,
                       int64_t workspace_bytes, dr_stream_t stream);
-int dr_emb_pool_bwd_sorted(const int64_t* sorted_rows, const int32_t* sorted_slots, int64_t n, int32_t F,
+int dr_emb_pool_bwd_sorted(const int64_t* ids, const int64_t* row_base, const int64_t* sorted_rows,
+                           const int32_t* sorted_slots, const uint8_t* unique_flags, int64_t B, int32_t F,
                            int32_t D, int64_t num_rows, const float* grad, int64_t ld_grad,
+                           const float* concat, int64_t ld_concat, const float* sum_x,
                            const float* d_fm_logit, float scale, float* dst_table, float* dst_lin,
                            float* dst_bias, dr_stream_t stream);
 
@@ -155,8 +160,10 @@ int dr_fm2_bwd(const float* x, const float* d_out, int64_t B, int32_t F, int32_t
  *           layer's input when that input is itself a relu output — so the product is directly the
  *           pre-activation gradient of the layer below (relu' folded into the producer's epilogue).
  *   bwd_dw  dstW[K,N] += scale * x^T @ dy ;  dstb[N] += scale * colsum(dy)
- *           split over the batch dimension with fp32 atomics: dst is a zeroed gradient buffer
- *           (scale = 1) or the parameter itself (scale = -lr, fused SGD).  dstb may be NULL.
+ *           split over the batch dimension: dst is a zeroed gradient buffer (scale = 1) or the
+ *           parameter itself (scale = -lr, fused SGD).  With a workspace of
+ *           dr_linear_bwd_dw_workspace_bytes() the split partials are combined by a deterministic
+ *           reduce kernel; with workspace == NULL they combine with fp32 atomics.  dstb may be NULL.
  * All matrices row-major with explicit leading dimensions; 16-byte aligned bases with pitches that are
  * multiples of 4 floats take the float4 load path, anything else a scalar-load path.
  * ---------------------------------------------------------------------------------------- */
@@ -173,9 +180,10 @@ int dr_linear_bwd_dx_fm(const float* dy, int64_t ld_dy, const float* W, int64_t 
                         int32_t K, int32_t N, const float* d_fm_logit, const float* sum_x,
                         const float* concat, int64_t ld_concat, int32_t D, int32_t FD, float* dx,
                         int64_t ld_dx, dr_stream_t stream);
+int64_t dr_linear_bwd_dw_workspace_bytes(int64_t M, int32_t K, int32_t N);
 int dr_linear_bwd_dw(const float* x, int64_t ld_x, const float* dy, int64_t ld_dy, int64_t M,
                      int32_t K, int32_t N, float scale, float* dstW, int64_t ld_w, float* dstb,
-                     dr_stream_t stream);
+                     float* workspace, int64_t workspace_bytes, dr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K8  DCN cross layer (keras/models/ranking/dcn.py:70-88):
