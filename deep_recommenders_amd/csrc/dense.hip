@@ -61,26 +61,41 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-// load a float4 of an operand tile with edge guards.  RC layout: element (i, r) at p[i*ld + r], vector
-// runs along r; non-RC: element (r, i) at p[r*ld + i], vector runs along i.
-__device__ __forceinline__ float4 guarded_ld4(const float* __restrict__ p, int64_t ld, int64_t row, int64_t nrows,
-                                              int64_t col, int64_t ncols, bool vec_ok) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < nrows) {
-        const float* q = p + row * ld + col;
-        if (vec_ok && col + 3 < ncols) {
-            v = *reinterpret_cast<const float4*>(q);
-        } else {
-            if (col < ncols) v.x = q[0];
-            if (col + 1 < ncols) v.y = q[1];
-            if (col + 2 < ncols) v.z = q[2];
-            if (col + 3 < ncols) v.w = q[3];
-        }
-    }
-    return v;
+// Branch-free edge-safe float4 load of an operand tile element (row, col..col+3) of a [nrows, ncols] matrix with
+// pitch ld (ncols >= 4).  Out-of-range rows are clamped to the last row, a vector that would run past the last
+// valid column is shifted left so that it ends exactly at ncols (a dword-aligned, possibly 16-byte-unaligned
+// global_load_dwordx4), and the components are rotated back / zeroed with selects.  No control flow: hipcc keeps
+// all eight loads of a k-tile in flight across the MFMA block (with exec-mask branches it drains them first).
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+struct EdgeFix { int shift; bool ok; };
+__device__ __forceinline__ EdgeFix edge_of(int64_t row, int64_t nrows, int64_t col, int64_t ncols) {
+    const int64_t over = col + 4 - ncols;
+    EdgeFix e;
+    e.shift = over <= 0 ? 0 : (over >= 4 ? 4 : (int)over);
+    e.ok = row < nrows;
+    return e;
+}
+// raw load at the clamped address (no dependence on the loaded data -> stays in flight)
+__device__ __forceinline__ f4u ld4_raw(const float* __restrict__ p, int64_t ld, int64_t row, int64_t nrows, int64_t col,
+                                       int64_t ncols) {
+    const int64_t rr = row < nrows ? row : nrows - 1;
+    const int64_t over = col + 4 - ncols;
+    const int shift = over <= 0 ? 0 : (over >= 4 ? 4 : (int)over);
+    const int64_t cc = (col < ncols ? col : ncols) - shift;
+    return *reinterpret_cast<const f4u*>(p + rr * ld + cc);
+}
+// applied when the tile is written to LDS, i.e. after the MFMA block the load was hidden under
+__device__ __forceinline__ float4 fix4(f4u v, EdgeFix e) {
+    float4 o;
+    const int s = e.shift;
+    o.x = !e.ok ? 0.f : (s == 0 ? v.x : s == 1 ? v.y : s == 2 ? v.z : s == 3 ? v.w : 0.f);
+    o.y = !e.ok ? 0.f : (s == 0 ? v.y : s == 1 ? v.z : s == 2 ? v.w : 0.f);
+    o.z = !e.ok ? 0.f : (s == 0 ? v.z : s == 1 ? v.w : 0.f);
+    o.w = !e.ok ? 0.f : (s == 0 ? v.w : 0.f);
+    return o;
 }
 
-template <bool A_RC, bool B_RC, int EPI>
+template <bool A_RC, bool B_RC, int EPI, bool PIN>
 __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
     constexpr int LDA = A_RC ? LD_T : LD_D;
     constexpr int LDB = B_RC ? LD_T : LD_D;
@@ -108,8 +123,6 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
         r_end = r_begin + per < g.R ? r_begin + per : g.R;
         if (r_begin >= r_end) return;
     }
-    // block-uniform: whole tile inside the matrices and float4 loads legal -> branch-free loader
-    const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N) && g.a_vec && g.b_vec;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -119,55 +132,37 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[a][b][k] = 0.f;
 
-    // per-thread tile coordinates of its 4 float4's: RC operand -> (i = idx>>3, r4 = idx&7), else (r = idx>>5, c4 = idx&31)
-    const int rc_i = tid >> 3, rc_r4 = tid & 7;       // + 32*q rows
-    const int dr_r = tid >> 5, dr_c4 = tid & 31;      // + 8*q reduction rows
-    const float* pa = A_RC ? g.A + (m0 + rc_i) * g.lda + rc_r4 * 4 + r_begin
-                           : g.A + (r_begin + dr_r) * g.lda + m0 + dr_c4 * 4;
-    const float* pb = B_RC ? g.B + ((int64_t)n0 + rc_i) * g.ldb + rc_r4 * 4 + r_begin
-                           : g.B + (r_begin + dr_r) * g.ldb + n0 + dr_c4 * 4;
-    const int64_t a_q = A_RC ? 32 * g.lda : 8 * g.lda;      // stride between a thread's 4 loads
-    const int64_t b_q = B_RC ? 32 * g.ldb : 8 * g.ldb;
-    const int64_t a_it = A_RC ? BK : BK * g.lda;            // advance per k-tile
-    const int64_t b_it = B_RC ? BK : BK * g.ldb;
-
-    float4 ra[4], rb[4];
-    auto load_fast = [&]() {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            ra[q] = *reinterpret_cast<const float4*>(pa + q * a_q);
-            rb[q] = *reinterpret_cast<const float4*>(pb + q * b_q);
-        }
-    };
-    auto load_guarded = [&](int64_t r0) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (A_RC) ra[q] = guarded_ld4(g.A, g.lda, m0 + rc_i + 32 * q, g.M, r0 + rc_r4 * 4, r_end, g.a_vec);
-            else      ra[q] = guarded_ld4(g.A, g.lda, r0 + dr_r + 8 * q, r_end, m0 + dr_c4 * 4, g.M, g.a_vec);
-            if (B_RC) rb[q] = guarded_ld4(g.B, g.ldb, (int64_t)n0 + rc_i + 32 * q, g.N, r0 + rc_r4 * 4, r_end, g.b_vec);
-            else      rb[q] = guarded_ld4(g.B, g.ldb, r0 + dr_r + 8 * q, r_end, (int64_t)n0 + dr_c4 * 4, g.N, g.b_vec);
-        }
-    };
+    // per-thread coordinates of its 4 float4's: RC operand -> (i = tid>>3 (+32q), r4 = tid&7), else (r = tid>>5 (+8q), c4 = tid&31)
+    const int rc_i = tid >> 3, rc_r4 = tid & 7;
+    const int dr_r = tid >> 5, dr_c4 = tid & 31;
+    f4u va[4], vb[4];
     auto load_tiles = [&](int64_t r0) {
-        if (interior && r0 + BK <= r_end) load_fast();
-        else load_guarded(r0);
-        pa += a_it;
-        pb += b_it;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (A_RC) va[q] = ld4_raw(g.A, g.lda, m0 + rc_i + 32 * q, g.M, r0 + rc_r4 * 4, r_end);
+            else      va[q] = ld4_raw(g.A, g.lda, r0 + dr_r + 8 * q, r_end, m0 + dr_c4 * 4, g.M);
+            if (B_RC) vb[q] = ld4_raw(g.B, g.ldb, (int64_t)n0 + rc_i + 32 * q, g.N, r0 + rc_r4 * 4, r_end);
+            else      vb[q] = ld4_raw(g.B, g.ldb, r0 + dr_r + 8 * q, r_end, (int64_t)n0 + dr_c4 * 4, g.N);
+        }
     };
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](int64_t r0) {     // r0 = reduction offset the registers were loaded for
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (A_RC) {
+                const float4 t = fix4(va[q], edge_of(m0 + rc_i + 32 * q, g.M, r0 + rc_r4 * 4, r_end));
                 float* d = As + (rc_r4 * 4) * LDA + rc_i + 32 * q;
-                d[0] = ra[q].x; d[LDA] = ra[q].y; d[2 * LDA] = ra[q].z; d[3 * LDA] = ra[q].w;
+                d[0] = t.x; d[LDA] = t.y; d[2 * LDA] = t.z; d[3 * LDA] = t.w;
             } else {
-                *reinterpret_cast<float4*>(&As[(dr_r + 8 * q) * LDA + dr_c4 * 4]) = ra[q];
+                const float4 t = fix4(va[q], edge_of(r0 + dr_r + 8 * q, r_end, m0 + dr_c4 * 4, g.M));
+                *reinterpret_cast<float4*>(&As[(dr_r + 8 * q) * LDA + dr_c4 * 4]) = t;
             }
             if (B_RC) {
+                const float4 t = fix4(vb[q], edge_of((int64_t)n0 + rc_i + 32 * q, g.N, r0 + rc_r4 * 4, r_end));
                 float* d = Bs + (rc_r4 * 4) * LDB + rc_i + 32 * q;
-                d[0] = rb[q].x; d[LDB] = rb[q].y; d[2 * LDB] = rb[q].z; d[3 * LDB] = rb[q].w;
+                d[0] = t.x; d[LDB] = t.y; d[2 * LDB] = t.z; d[3 * LDB] = t.w;
             } else {
-                *reinterpret_cast<float4*>(&Bs[(dr_r + 8 * q) * LDB + dr_c4 * 4]) = rb[q];
+                const float4 t = fix4(vb[q], edge_of(r0 + dr_r + 8 * q, r_end, (int64_t)n0 + dr_c4 * 4, g.N));
+                *reinterpret_cast<float4*>(&Bs[(dr_r + 8 * q) * LDB + dr_c4 * 4]) = t;
             }
         }
     };
@@ -179,7 +174,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
     const float* as = As + (lane >> 5) * LDA + wm * 64 + (lane & 31);
     const float* bs = Bs + (lane >> 5) * LDB + wn * 64 + (lane & 31);
     for (int64_t r0 = r_begin; r0 < r_end; r0 += BK) {
-        store_tiles();
+        store_tiles(r0);
         __syncthreads();
         if (r0 + BK < r_end) load_tiles(r0 + BK);
         if (do_colsum) {
@@ -195,7 +190,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
                 na0 = as[(kk + 2) * LDA]; na1 = as[(kk + 2) * LDA + 32];
                 nb0 = bs[(kk + 2) * LDB]; nb1 = bs[(kk + 2) * LDB + 32];
             }
-            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ABOVE the MFMAs (hipcc sinks it otherwise)
+            if (PIN) __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ABOVE the MFMAs (hipcc sinks it otherwise)
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
@@ -257,6 +252,8 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
     if (do_colsum && n0 + tid < g.N) unsafeAtomicAdd(g.colsum_dst + n0 + tid, g.alpha * colsum);
 }
 
+static int g_variant = 3;   // A/B switch (measured, tools/exp/ab_gemm.py): bit0 = unpinned prefetch, bit1 = dW split target 1024 (both faster)
+
 template <bool A_RC, bool B_RC, int EPI>
 int launch(GemmArgs& g, hipStream_t s) {
     g.a_vec = ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0 && (g.lda & 3) == 0) ? 1 : 0;
@@ -265,7 +262,10 @@ int launch(GemmArgs& g, hipStream_t s) {
     const int64_t tiles_m = (g.M + BM - 1) / BM;
     if (tiles_m * tiles_n > 0x7fffffff) return DR_EINVAL;
     dim3 grid((unsigned)(tiles_m * tiles_n), EPI == EPI_ATOMIC ? g.split : 1);
-    hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_RC, B_RC, EPI>), grid, dim3(256), 0, s, g);
+    if (g_variant & 1)
+        hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_RC, B_RC, EPI, false>), grid, dim3(256), 0, s, g);
+    else
+        hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_RC, B_RC, EPI, true>), grid, dim3(256), 0, s, g);
     DR_CHECK_LAUNCH();
     return DR_OK;
 }
@@ -322,6 +322,80 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+// ---- skinny shapes (min(K, N) < 4: the Dense(1) heads) : streaming kernels, no MFMA -------------------------------
+// y[m][n] = act(sum_k x[m][k] W[k][n] + b[n]) ; one lane group of 16 per row, k strided over the lanes
+__global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict__ x, int64_t ldx,
+                                                         const float* __restrict__ W, int64_t ldw,
+                                                         const float* __restrict__ b, int64_t M, int32_t K, int32_t N,
+                                                         int32_t act, float* __restrict__ y, int64_t ldy) {
+    const int lane = threadIdx.x & 15;
+    const int64_t groups = (int64_t)gridDim.x * (blockDim.x >> 4);
+    for (int64_t m = (int64_t)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4); m < M; m += groups) {
+        for (int n = 0; n < N; ++n) {
+            float acc = 0.f;
+            for (int k = lane; k < K; k += 16) acc = fmaf(x[m * ldx + k], W[(int64_t)k * ldw + n], acc);
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 16);
+            if (lane == 0) {
+                float v = acc + (b != nullptr ? b[n] : 0.f);
+                if (act == 1) v = fmaxf(v, 0.f);
+                y[m * ldy + n] = v;
+            }
+        }
+    }
+}
+// dx[m][k] = (sum_n dy[m][n] W[k][n]) * (relu_src[m][k] > 0) (+ dx)
+__global__ __launch_bounds__(256) void skinny_dx_kernel(const float* __restrict__ dy, int64_t lddy,
+                                                        const float* __restrict__ W, int64_t ldw, int64_t M, int32_t K,
+                                                        int32_t N, const float* __restrict__ rs, int64_t ldrs,
+                                                        int32_t accumulate, float* __restrict__ dx, int64_t lddx) {
+    const int64_t total = M * K;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t m = i / K;
+        const int k = (int)(i - m * K);
+        float acc = 0.f;
+        for (int n = 0; n < N; ++n) acc = fmaf(dy[m * lddy + n], W[(int64_t)k * ldw + n], acc);
+        if (rs != nullptr && !(rs[m * ldrs + k] > 0.f)) acc = 0.f;
+        if (accumulate) acc += dx[m * lddx + k];
+        dx[m * lddx + k] = acc;
+    }
+}
+// dst[k][n] += scale * sum_m x[m][k] dy[m][n] ; dstb[n] += scale * sum_m dy[m][n].  A block owns a slab of rows and
+// all (k, n) pairs (strided over its threads), accumulates in registers, then one atomic per (k, n) per block.
+constexpr int SK_ROWS = 256;
+__global__ __launch_bounds__(256) void skinny_dw_kernel(const float* __restrict__ x, int64_t ldx,
+                                                        const float* __restrict__ dy, int64_t lddy, int64_t M, int32_t K,
+                                                        int32_t N, float scale, float* __restrict__ dst, int64_t ldw,
+                                                        float* __restrict__ dstb) {
+    const int64_t m0 = (int64_t)blockIdx.x * SK_ROWS;
+    const int64_t m1 = m0 + SK_ROWS < M ? m0 + SK_ROWS : M;
+    const int KN = K * N;
+    const int lanes_e = KN < 256 ? KN : 256;     // threads along the (k, n) pairs; the rest split the rows
+    const int R = 256 / lanes_e;
+    const int e0 = threadIdx.x % lanes_e, rl = threadIdx.x / lanes_e;
+    if (rl < R) {
+        for (int e = e0; e < KN; e += lanes_e) {
+            const int k = e / N, n = e - k * N;
+            float acc = 0.f;
+            for (int64_t m = m0 + rl; m < m1; m += R) acc = fmaf(x[m * ldx + k], dy[m * lddy + n], acc);
+            unsafeAtomicAdd(dst + (int64_t)k * ldw + n, scale * acc);
+        }
+    }
+    if (dstb != nullptr) {
+        const int ln = N < 256 ? N : 256;
+        const int Rb = 256 / ln;
+        const int n0 = threadIdx.x % ln, rb = threadIdx.x / ln;
+        if (rb < Rb) {
+            for (int n = n0; n < N; n += ln) {
+                float acc = 0.f;
+                for (int64_t m = m0 + rb; m < m1; m += Rb) acc += dy[m * lddy + n];
+                unsafeAtomicAdd(dstb + n, scale * acc);
+            }
+        }
+    }
+}
+
 bool bad_ld(int64_t ld, int64_t min) { return ld < min; }
 bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3) != 0; }
 
@@ -333,6 +407,12 @@ extern "C" int dr_linear_fwd(const float* x, int64_t ld_x, const float* W, int64
     if (M == 0) return DR_OK;
     if (!x || !W || !y || bad_ld(ld_x, K) || bad_ld(ld_w, N) || ld_y < N || misaligned(x) || misaligned(W))
         return DR_EINVAL;
+    if (K < 4 || N < 4) {
+        hipLaunchKernelGGL(skinny_fwd_kernel, dim3(dr_grid_for(M, 16)), dim3(256), 0, dr_s(stream), x, ld_x, W, ld_w, b, M, K,
+                           N, act, y, ld_y);
+        DR_CHECK_LAUNCH();
+        return DR_OK;
+    }
     GemmArgs g{};
     g.A = x; g.lda = ld_x; g.B = W; g.ldb = ld_w; g.M = M; g.N = N; g.R = K; g.C = y; g.ldc = ld_y;
     g.bias = b; g.act = act; g.split = 1;
@@ -347,6 +427,12 @@ extern "C" int dr_linear_bwd_dx(const float* dy, int64_t ld_dy, const float* W, 
     if (!dy || !W || !dx || bad_ld(ld_dy, N) || bad_ld(ld_w, N) || ld_dx < K || misaligned(dy) || misaligned(W))
         return DR_EINVAL;
     if (relu_src != nullptr && ld_relu_src < K) return DR_EINVAL;
+    if (K < 4 || N < 4) {
+        hipLaunchKernelGGL(skinny_dx_kernel, dim3(dr_grid_for(M * K, 256)), dim3(256), 0, dr_s(stream), dy, ld_dy, W, ld_w, M,
+                           K, N, relu_src, ld_relu_src, accumulate, dx, ld_dx);
+        DR_CHECK_LAUNCH();
+        return DR_OK;
+    }
     // dx[i=m][j=k] = sum_{r=n} dy[m][n] * W[k][n]  -> A = dy (RC), B(r=n, j=k) = W[k*ld_w + n] (RC)
     GemmArgs g{};
     g.A = dy; g.lda = ld_dy; g.B = W; g.ldb = ld_w; g.M = M; g.N = K; g.R = N; g.C = dx; g.ldc = ld_dx;
@@ -361,7 +447,7 @@ extern "C" int dr_linear_bwd_dx_fm(const float* dy, int64_t ld_dy, const float* 
                                    int32_t N, const float* d_fm_logit, const float* sum_x, const float* concat,
                                    int64_t ld_concat, int32_t D, int32_t FD, float* dx, int64_t ld_dx,
                                    dr_stream_t stream) {
-    if (M < 0 || K <= 0 || N <= 0 || D <= 0 || FD < 0 || FD > K) return DR_EINVAL;
+    if (M < 0 || K < 4 || N < 4 || D <= 0 || FD < 0 || FD > K) return DR_EINVAL;
     if (M == 0) return DR_OK;
     if (!dy || !W || !dx || !d_fm_logit || !sum_x || !concat || bad_ld(ld_dy, N) || bad_ld(ld_w, N) || ld_dx < K ||
         ld_concat < FD || misaligned(dy) || misaligned(W))
@@ -375,7 +461,8 @@ extern "C" int dr_linear_bwd_dx_fm(const float* dy, int64_t ld_dy, const float* 
 
 static int dw_split(int64_t M, int32_t K, int32_t N) {
     const int64_t tiles = ((int64_t)(K + BM - 1) / BM) * ((N + BN - 1) / BN);
-    int64_t split = (512 + tiles - 1) / tiles;               // ~2 resident blocks per CU, one wave of blocks
+    const int64_t target = (g_variant & 2) ? 1024 : 512;
+    int64_t split = (target + tiles - 1) / tiles;
     const int64_t max_split = (M + 8 * BK - 1) / (8 * BK);     // at least 8 k-tiles per block
     if (split > max_split) split = max_split;
     if (split < 1) split = 1;
@@ -395,6 +482,12 @@ extern "C" int dr_linear_bwd_dw(const float* x, int64_t ld_x, const float* dy, i
     if (M == 0) return DR_OK;
     if (!x || !dy || !dstW || bad_ld(ld_x, K) || bad_ld(ld_dy, N) || ld_w < N || misaligned(x) || misaligned(dy))
         return DR_EINVAL;
+    if (K < 4 || N < 4 || M < 4) {
+        hipLaunchKernelGGL(skinny_dw_kernel, dim3((unsigned)((M + SK_ROWS - 1) / SK_ROWS)), dim3(256), 0, dr_s(stream), x, ld_x,
+                           dy, ld_dy, M, K, N, scale, dstW, ld_w, dstb);
+        DR_CHECK_LAUNCH();
+        return DR_OK;
+    }
     // dW[i=k][j=n] = sum_{r=m} x[m][k] * dy[m][n] -> A(i=k, r=m) = x[m*ld_x + k] (not RC), B = dy (not RC)
     GemmArgs g{};
     g.A = x; g.lda = ld_x; g.B = dy; g.ldb = ld_dy; g.M = K; g.N = N; g.R = M; g.C = dstW; g.ldc = ld_w;
@@ -426,6 +519,15 @@ extern "C" int dr_cross_fwd(const float* x0, const float* x, int64_t ld, const f
         return DR_OK;
     }
     if (bad_ld(ld_w, Dm) || misaligned(x) || misaligned(W)) return DR_EINVAL;
+    if (Dm < 4) {   // tiny feature width: streaming product into prod (or out as scratch), then the combine pass
+        float* pbuf = prod_out != nullptr ? prod_out : out;
+        hipLaunchKernelGGL(skinny_fwd_kernel, dim3(dr_grid_for(M, 16)), dim3(256), 0, dr_s(stream), x, ld, W, ld_w,
+                           (const float*)nullptr, M, Dm, Dm, 0, pbuf, ld);
+        hipLaunchKernelGGL(cross_combine_fwd_kernel, dim3(dr_grid_for(M * Dm, 256)), dim3(256), 0, dr_s(stream), x0, x, pbuf,
+                           b, M, Dm, ld, diag_scale, out);
+        DR_CHECK_LAUNCH();
+        return DR_OK;
+    }
     GemmArgs g{};
     g.A = x; g.lda = ld; g.B = W; g.ldb = ld_w; g.M = M; g.N = Dm; g.R = Dm; g.C = out; g.ldc = ld;
     g.bias = b; g.e0 = x0; g.lde0 = ld; g.e1 = x; g.lde1 = ld; g.aux = prod_out; g.ldaux = ld;
@@ -444,5 +546,7 @@ extern "C" int dr_cross_combine_bwd(const float* x0, const float* prod, const fl
     DR_CHECK_LAUNCH();
     return DR_OK;
 }
+
+extern "C" void dr_debug_set_gemm_variant(int v) { g_variant = v; }
 
 extern "C" const char* dr_version(void) { return "deep_recommenders_amd hot path / gfx950 / f32"; }

@@ -77,11 +77,15 @@ __global__ __launch_bounds__(256) void emb_bwd_unique_kernel(const int64_t* __re
         for (int f0 = 0; f0 < F; f0 += NS * U) {
             int64_t row[U];
             float4 g[U], t[U];
+            float lw[U];
+            const bool do_lin = lin_w != nullptr && d_fm_logit != nullptr && sub == 0;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int f = f0 + u * NS + slot;
                 row[u] = __shfl(my_row, f < F ? f : 0, 64);
                 if (f >= F) row[u] = -1;
+                lw[u] = 0.f;
+                if (row[u] >= 0 && do_lin) lw[u] = lin_w[row[u]];      // issued with the row loads, not after them
                 if (row[u] >= 0 && dvalid) {
                     g[u] = *reinterpret_cast<const float4*>(grow + f * D + sub * 4);
                     t[u] = *reinterpret_cast<const float4*>(table + row[u] * D + sub * 4);
@@ -101,8 +105,7 @@ __global__ __launch_bounds__(256) void emb_bwd_unique_kernel(const int64_t* __re
                         r.z = fmaf(scale, g[u].z, r.z); r.w = fmaf(scale, g[u].w, r.w);
                         *reinterpret_cast<float4*>(table + row[u] * D + sub * 4) = r;
                     }
-                    if (lin_w != nullptr && d_fm_logit != nullptr && sub == 0)
-                        lin_w[row[u]] = fmaf(scale, dl, lin_w[row[u]]);
+                    if (do_lin) lin_w[row[u]] = fmaf(scale, dl, lw[u]);
                 }
             }
         }
