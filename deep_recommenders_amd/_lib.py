@@ -42,11 +42,28 @@ SIGNATURES = {
     "dr_emb_pool_bwd_sorted": [_p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _i64, _p, _i64, _p, _p, _f32, _p, _p,
                                _p, _p],
     "dr_linear_bwd_dx_fm": [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _i64, _i32, _i32, _p, _i64, _p],
+    "dr_inbatch_softmax_workspace_bytes": [_i64],
+    "dr_inbatch_softmax_fwd": [_p, _p, _i64, _i32, _p, _p, _p, _f32, _p, _p, _p, _p, _i64, _p],
+    "dr_inbatch_softmax_grad_scores": [_p, _p, _i64, _i32, _p, _p, _p, _f32, _p, _f32, _p, _i64, _p],
+    "dr_scores_nt": [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _i64, _p],
+    "dr_topk_select": [_p, _i64, _i64, _i64, _i32, _i64, _i32, _p, _p, _p],
+    "dr_topk_workspace_bytes": [_i64, _i64, _i32],
+    "dr_topk_mips": [_p, _i64, _p, _i64, _i32, _i32, _i64, _i32, _p, _p, _p, _i64, _p],
+    "dr_topk_merge": [_p, _p, _i32, _p, _p, _i32, _i64, _i32, _p, _p, _p],
+    "dr_rowdot": [_p, _p, _i64, _i32, _p, _p],
+    "dr_gather_i64": [_p, _i64, _p, _i64, _p, _p],
+    "dr_take_along_rows_f32": [_p, _i64, _i64, _i32, _p, _i32, _p, _p],
+    "dr_take_along_rows_i64": [_p, _i64, _i64, _i32, _p, _i32, _p, _p],
+    "dr_topk_hits": [_p, _p, _i64, _i32, _p, _i32, _p, _p],
+    "dr_exclude_adjust": [_p, _p, _i64, _i32, _p, _i32, _p, _p],
+    "dr_logits_adjust": [_p, _p, _i64, _i32, _p, _p, _f32, _p, _p],
+    "dr_softmax_ce_rows": [_p, _p, _i64, _i32, _f32, _p, _p, _p, _p],
     "dr_version": [],
 }
 _RESTYPE = {"dr_version": ctypes.c_char_p, "dr_shard_bucket_workspace_bytes": ctypes.c_int64,
             "dr_emb_sort_workspace_bytes": ctypes.c_int64,
-            "dr_linear_bwd_dw_workspace_bytes": ctypes.c_int64}
+            "dr_linear_bwd_dw_workspace_bytes": ctypes.c_int64,
+            "dr_inbatch_softmax_workspace_bytes": ctypes.c_int64, "dr_topk_workspace_bytes": ctypes.c_int64}
 
 DR_OK, DR_EINVAL, DR_ELAUNCH, DR_ESHAPE = 0, -1, -2, -3
 _ERR = {DR_EINVAL: "DR_EINVAL (bad argument)", DR_ELAUNCH: "DR_ELAUNCH (HIP launch error)",

@@ -29,7 +29,7 @@ constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int LD_T = 129;   // pitch of a transposed-in operand tile
 constexpr int LD_D = 132;   // pitch of a direct operand tile
 
-enum Epi { EPI_BIAS_ACT = 0, EPI_CROSS = 1, EPI_MASK = 2, EPI_ATOMIC = 3, EPI_FMGRAD = 4 };
+enum Epi { EPI_BIAS_ACT = 0, EPI_CROSS = 1, EPI_MASK = 2, EPI_ATOMIC = 3, EPI_FMGRAD = 4, EPI_LSE = 5, EPI_SMGRAD = 6 };
 
 struct GemmArgs {
     const float* A; int64_t lda;
@@ -52,6 +52,13 @@ struct GemmArgs {
     int32_t a_vec, b_vec;     // operand base 16-B aligned and ld % 4 == 0 -> float4 loads allowed
     // FMGRAD: C = acc + dl[i] * (S[i][j % fm_D] - x[i][j]) for j < fm_FD   (e0 = x, e1 = S [M, fm_D])
     const float* vec; int32_t fm_D, fm_FD;
+    // LSE / SMGRAD (in-batch softmax, Retrieval.call): score s_ij = (acc - log p_j + dupmask_ij * MIN_FLOAT) * inv_t
+    const float* cand_prob;       // [N] or null
+    const int64_t* cand_ids;      // [N] or null (N == M)
+    float inv_t;
+    float* part_m; float* part_l; // LSE: partial row max / sum-exp, [2*tiles_n][M]
+    float* pos;                   // LSE: s_ii
+    const float* lse;             // SMGRAD: row log-sum-exp ; vec = sample_weight (or null) ; alpha = d_loss
 };
 
 // bijective XCD-aware remap (cdna guide T1): consecutive logical tile ids -> same XCD
@@ -200,6 +207,68 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
         __syncthreads();
     }
 
+    if (EPI == EPI_LSE || EPI == EPI_SMGRAD) {
+        constexpr float MIN_FLOAT = -3.4028234663852886e36f;   // np.finfo(np.float32).min / 100 (sbcnm.py:10)
+        float colcorr[2];
+        int64_t colid[2];
+        int colj[2];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            colj[ni] = n0 + wn * 64 + ni * 32 + (lane & 31);
+            const bool cv = colj[ni] < g.N;
+            colcorr[ni] = (cv && g.cand_prob != nullptr) ? -logf(g.cand_prob[colj[ni]]) : 0.f;
+            colid[ni] = (cv && g.cand_ids != nullptr) ? g.cand_ids[colj[ni]] : 0;
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int64_t row = m0 + wm * 64 + mi * 32 + 4 * (lane >> 5) + (reg & 3) + 8 * (reg >> 2);
+                const bool rv = row < g.M;
+                const int64_t rid = (rv && g.cand_ids != nullptr) ? g.cand_ids[row] : 0;
+                float sv[2];
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    float v = acc[mi][ni][reg] + colcorr[ni];
+                    if (g.cand_ids != nullptr && rid == colid[ni] && row != colj[ni]) v += MIN_FLOAT;
+                    sv[ni] = v * g.inv_t;
+                }
+                if (EPI == EPI_LSE) {
+                    float m = -INFINITY;
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        if (colj[ni] < g.N) m = fmaxf(m, sv[ni]);
+#pragma unroll
+                    for (int o = 1; o < 32; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+                    float l = 0.f;
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        if (colj[ni] < g.N) l += expf(sv[ni] - m);
+#pragma unroll
+                    for (int o = 1; o < 32; o <<= 1) l += __shfl_xor(l, o, 64);
+                    if (rv && (lane & 31) == 0) {
+                        const int64_t pc = (int64_t)((n0 / BN) * 2 + wn);
+                        g.part_m[pc * g.M + row] = m;
+                        g.part_l[pc * g.M + row] = l;
+                    }
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        if (rv && row == colj[ni]) g.pos[row] = sv[ni];
+                } else {
+                    if (!rv) continue;
+                    const float w = g.vec != nullptr ? g.vec[row] : 1.f;
+                    const float lse = g.lse[row];
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        if (colj[ni] >= g.N) continue;
+                        const float pr = expf(sv[ni] - lse) - (row == colj[ni] ? 1.f : 0.f);
+                        g.C[row * g.ldc + colj[ni]] = w * pr * g.inv_t * g.alpha;
+                    }
+                }
+            }
+        }
+        return;
+    }
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const bool full = (m0 + BM <= g.M) && (n0 + BN <= g.N);
 #pragma unroll
@@ -545,6 +614,93 @@ extern "C" int dr_cross_combine_bwd(const float* x0, const float* prod, const fl
                        d_out, M, Dm, ld, diag_scale, d_prod, d_x0_accum, d_x_accum);
     DR_CHECK_LAUNCH();
     return DR_OK;
+}
+
+// ---- K9: in-batch sampled softmax (Retrieval.call, keras/models/retrieval/sbcnm.py:120-151 of the reference) ----------
+__global__ __launch_bounds__(256) void lse_finalize_kernel(const float* __restrict__ part_m, const float* __restrict__ part_l,
+                                                           int32_t nparts, int64_t B, const float* __restrict__ pos,
+                                                           const float* __restrict__ w, float* __restrict__ row_lse,
+                                                           float* __restrict__ block_sums) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += stride) {
+        float m = -INFINITY;
+        for (int p = 0; p < nparts; ++p) m = fmaxf(m, part_m[(int64_t)p * B + i]);
+        float l = 0.f;
+        for (int p = 0; p < nparts; ++p) l += part_l[(int64_t)p * B + i] * expf(part_m[(int64_t)p * B + i] - m);
+        const float lse = m + logf(l);
+        row_lse[i] = lse;
+        acc += (w != nullptr ? w[i] : 1.f) * (lse - pos[i]);
+    }
+    acc = dr_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void sum_blocks_kernel(const float* __restrict__ block_sums, int n, float* __restrict__ out) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += (double)block_sums[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (float)((red[0] + red[1]) + (red[2] + red[3]));
+}
+
+extern "C" int64_t dr_inbatch_softmax_workspace_bytes(int64_t B) {
+    const int64_t tiles_n = (B + BN - 1) / BN;
+    return (2 * tiles_n * 2 * B + 1024) * (int64_t)sizeof(float);
+}
+
+extern "C" int dr_inbatch_softmax_fwd(const float* q, const float* c, int64_t B, int32_t D, const float* cand_prob,
+                                      const int64_t* cand_ids, const float* sample_weight, float inv_temperature,
+                                      float* row_lse, float* pos_score, float* loss_out, float* workspace,
+                                      int64_t workspace_bytes, dr_stream_t stream) {
+    if (B <= 0 || D < 4 || B > 0x7fffffff) return DR_EINVAL;
+    if (!q || !c || !row_lse || !pos_score || !loss_out || !workspace) return DR_EINVAL;
+    if (workspace_bytes < dr_inbatch_softmax_workspace_bytes(B)) return DR_EINVAL;
+    const int tiles_n = (int)((B + BN - 1) / BN);
+    GemmArgs g{};
+    g.A = q; g.lda = D; g.B = c; g.ldb = D; g.M = B; g.N = (int32_t)B; g.R = D; g.C = nullptr; g.ldc = 0;
+    g.cand_prob = cand_prob; g.cand_ids = cand_ids; g.inv_t = inv_temperature;
+    g.part_m = workspace; g.part_l = workspace + (int64_t)2 * tiles_n * B; g.pos = pos_score; g.split = 1;
+    int rc = launch<true, true, EPI_LSE>(g, dr_s(stream));
+    if (rc != DR_OK) return rc;
+    float* block_sums = workspace + (int64_t)4 * tiles_n * B;
+    const int grid = dr_grid_for(B, 256, 512);
+    hipLaunchKernelGGL(lse_finalize_kernel, dim3(grid), dim3(256), 0, dr_s(stream), g.part_m, g.part_l, 2 * tiles_n, B,
+                       pos_score, sample_weight, row_lse, block_sums);
+    hipLaunchKernelGGL(sum_blocks_kernel, dim3(1), dim3(256), 0, dr_s(stream), block_sums, grid, loss_out);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+// G[i][j] = d_loss * w_i * (softmax_ij - delta_ij) * inv_t  (the gradient of the loss wrt the raw q.c^T scores);
+// the caller finishes with two plain GEMMs: dq = G @ c (dr_linear_fwd), dc = G^T @ q (dr_linear_bwd_dw).
+extern "C" int dr_inbatch_softmax_grad_scores(const float* q, const float* c, int64_t B, int32_t D, const float* cand_prob,
+                                              const int64_t* cand_ids, const float* sample_weight, float inv_temperature,
+                                              const float* row_lse, float d_loss, float* G, int64_t ld_g,
+                                              dr_stream_t stream) {
+    if (B <= 0 || D < 4 || B > 0x7fffffff || ld_g < B) return DR_EINVAL;
+    if (!q || !c || !row_lse || !G) return DR_EINVAL;
+    GemmArgs g{};
+    g.A = q; g.lda = D; g.B = c; g.ldb = D; g.M = B; g.N = (int32_t)B; g.R = D; g.C = G; g.ldc = ld_g;
+    g.cand_prob = cand_prob; g.cand_ids = cand_ids; g.inv_t = inv_temperature; g.lse = row_lse; g.vec = sample_weight;
+    g.alpha = d_loss; g.split = 1;
+    return launch<true, true, EPI_SMGRAD>(g, dr_s(stream));
+}
+
+// plain scores = a @ b^T for two reduction-contiguous operands (queries x candidates), used by the top-K search
+extern "C" int dr_scores_nt(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t M, int32_t N, int32_t D,
+                            float* out, int64_t ld_out, dr_stream_t stream) {
+    if (M < 0 || N <= 0 || D < 4 || ld_out < N || lda < D || ldb < D) return DR_EINVAL;
+    if (M == 0) return DR_OK;
+    if (!a || !b || !out) return DR_EINVAL;
+    GemmArgs g{};
+    g.A = a; g.lda = lda; g.B = b; g.ldb = ldb; g.M = M; g.N = N; g.R = D; g.C = out; g.ldc = ld_out; g.split = 1;
+    return launch<true, true, EPI_BIAS_ACT>(g, dr_s(stream));
 }
 
 extern "C" void dr_debug_set_gemm_variant(int v) { g_variant = v; }

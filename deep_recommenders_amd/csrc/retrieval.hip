@@ -1,0 +1,387 @@
+// K10 + helpers — exact top-K maximum-inner-product search and the small retrieval-task ops.
+//
+// Replaces BruteForce.call / Streaming.call (keras/models/retrieval/factorized_top_k.py:178-260,316-334 of the
+// reference: tf.matmul + tf.math.top_k, plus Streaming's concat/re-top_k reduce), _exclude / _take_long_axis
+// (:26-67), FactorizedTopK.update_state (:489-512) and the helper layers of sbcnm.py:15-86.
+//
+// Search = chunked scores (dr_scores_nt, MFMA) into a workspace small enough to stay in the 256 MB Infinity
+// Cache, then one wavefront per query row folds the chunk into a running, sorted top-k list held in registers
+// (2 entries per lane, k <= 128).  Only elements strictly greater than the current k-th score enter the list
+// (expected k*ln(N/k) insertions per row over the whole corpus), insertion = one rank count (wave sum) + a
+// lane shift (__shfl_up).  Ties resolve to the lower candidate index, as tf.math.top_k does.
+#include "dr_common.h"
+#include <math.h>
+
+extern "C" int dr_scores_nt(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t M, int32_t N, int32_t D,
+                            float* out, int64_t ld_out, dr_stream_t stream);
+
+namespace {
+
+constexpr int KMAX = 128;
+
+__device__ __forceinline__ int64_t shfl_i64(int64_t v, int src) {
+    int lo = __shfl((int)(v & 0xffffffffll), src, 64);
+    int hi = __shfl((int)(v >> 32), src, 64);
+    return ((int64_t)hi << 32) | (uint32_t)lo;
+}
+__device__ __forceinline__ int64_t shfl_up_i64(int64_t v, int d) {
+    int lo = __shfl_up((int)(v & 0xffffffffll), d, 64);
+    int hi = __shfl_up((int)(v >> 32), d, 64);
+    return ((int64_t)hi << 32) | (uint32_t)lo;
+}
+
+// fold scores[row, 0..n) (candidate index = index_base + j) into the running sorted list of `row`
+__global__ __launch_bounds__(256) void topk_select_kernel(const float* __restrict__ scores, int64_t ld, int64_t Bq,
+                                                          int64_t n, int32_t k, int64_t index_base, int32_t init,
+                                                          float* __restrict__ out_s, int64_t* __restrict__ out_i) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= Bq) return;
+    const int p0 = lane, p1 = lane + 64;
+    float e0 = -INFINITY, e1 = -INFINITY;
+    int64_t i0 = -1, i1 = -1;
+    if (!init) {
+        if (p0 < k) { e0 = out_s[row * k + p0]; i0 = out_i[row * k + p0]; }
+        if (p1 < k) { e1 = out_s[row * k + p1]; i1 = out_i[row * k + p1]; }
+    }
+    // tau = score of the last list slot once the list is full (slot k-1), else -inf with "not full"
+    auto kth = [&]() -> float {
+        const float a = __shfl(e0, (k - 1) & 63, 64), b = __shfl(e1, (k - 1) & 63, 64);
+        return (k - 1) < 64 ? a : b;
+    };
+    auto kth_valid = [&]() -> bool {
+        const int64_t a = shfl_i64(i0, (k - 1) & 63), b = shfl_i64(i1, (k - 1) & 63);
+        return ((k - 1) < 64 ? a : b) >= 0;
+    };
+    bool full = kth_valid();
+    float tau = kth();
+    const float* srow = scores + row * ld;
+    for (int64_t j0 = 0; j0 < n; j0 += 64) {
+        const int64_t j = j0 + lane;
+        const float v = j < n ? srow[j] : -INFINITY;
+        unsigned long long mask = __ballot(j < n && (!full || v > tau));
+        while (mask) {
+            const int l = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const float cand = __shfl(v, l, 64);
+            if (full && !(cand > tau)) continue;
+            const int64_t cidx = index_base + j0 + l;
+            // rank = number of list entries that stay ahead of cand (score >= cand among valid entries; NaN-free input)
+            int c = 0;
+            if (p0 < k && i0 >= 0 && e0 >= cand) ++c;
+            if (p1 < k && i1 >= 0 && e1 >= cand) ++c;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+            const int pos = c;
+            if (pos >= k) continue;
+            const float pe0 = __shfl_up(e0, 1, 64), pe1 = __shfl_up(e1, 1, 64), w0 = __shfl(e0, 63, 64);
+            const int64_t pi0 = shfl_up_i64(i0, 1), pi1 = shfl_up_i64(i1, 1), wi0 = shfl_i64(i0, 63);
+            const float n0 = p0 < pos ? e0 : (p0 == pos ? cand : pe0);
+            const int64_t ni0 = p0 < pos ? i0 : (p0 == pos ? cidx : pi0);
+            const float n1 = p1 < pos ? e1 : (p1 == pos ? cand : (lane == 0 ? w0 : pe1));
+            const int64_t ni1 = p1 < pos ? i1 : (p1 == pos ? cidx : (lane == 0 ? wi0 : pi1));
+            e0 = n0; i0 = ni0; e1 = n1; i1 = ni1;
+            full = kth_valid();
+            tau = kth();
+        }
+    }
+    if (p0 < k) { out_s[row * k + p0] = e0; out_i[row * k + p0] = i0; }
+    if (p1 < k) { out_s[row * k + p1] = e1; out_i[row * k + p1] = i1; }
+}
+
+// two-pointer merge of two sorted lists per row, list a wins ties (Streaming's reduce; cross-rank merge)
+__global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict__ sa, const int64_t* __restrict__ ia, int32_t ka,
+                                                         const float* __restrict__ sb, const int64_t* __restrict__ ib, int32_t kb,
+                                                         int64_t Bq, int32_t k, float* __restrict__ os, int64_t* __restrict__ oi) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= Bq) return;
+    int a = 0, b = 0;
+    for (int t = 0; t < k; ++t) {
+        const bool av = a < ka && ia[row * ka + a] >= 0, bv = b < kb && ib[row * kb + b] >= 0;
+        float s = -INFINITY;
+        int64_t id = -1;
+        if (av && (!bv || sa[row * ka + a] >= sb[row * kb + b])) { s = sa[row * ka + a]; id = ia[row * ka + a]; ++a; }
+        else if (bv) { s = sb[row * kb + b]; id = ib[row * kb + b]; ++b; }
+        os[row * k + t] = s;
+        oi[row * k + t] = id;
+    }
+}
+
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t B, int32_t D,
+                                                     float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < B; r += nw) {
+        float acc = 0.f;
+        for (int d = lane; d < D; d += 64) acc = fmaf(a[r * D + d], b[r * D + d], acc);
+        acc = dr_wave_sum(acc);
+        if (lane == 0) out[r] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_i64_kernel(const int64_t* __restrict__ src, int64_t nsrc, const int64_t* __restrict__ idx,
+                                                         int64_t n, int64_t* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t j = idx[i];
+        out[i] = (j >= 0 && j < nsrc) ? src[j] : -1;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void take_along_rows_kernel(const T* __restrict__ arr, int64_t ld, int64_t B, int32_t C,
+                                                              const int64_t* __restrict__ idx, int32_t K, T* __restrict__ out) {
+    const int64_t n = B * K;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t r = i / K;
+        const int64_t j = idx[i];
+        out[i] = (j >= 0 && j < C) ? arr[r * ld + j] : (T)0;
+    }
+}
+
+// hits[t] += #rows whose positive score has fewer than ks[t] top-k scores strictly above it ([TF] in_top_k, B14)
+__global__ __launch_bounds__(256) void topk_hits_kernel(const float* __restrict__ pos, const float* __restrict__ topk, int64_t B,
+                                                        int32_t K, const int32_t* __restrict__ ks, int32_t nk,
+                                                        unsigned long long* __restrict__ hits) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < B; r += stride) {
+        const float p = pos[r];
+        int cnt = 0;
+        for (int j = 0; j < K; ++j) cnt += topk[r * K + j] > p ? 1 : 0;
+        for (int t = 0; t < nk; ++t)
+            if (cnt < ks[t]) atomicAdd(&hits[t], 1ull);
+    }
+}
+
+// adjusted = scores - isin(identifiers, exclude) * 1e5   (factorized_top_k.py:57-62)
+__global__ __launch_bounds__(256) void exclude_adjust_kernel(const float* __restrict__ scores, const int64_t* __restrict__ ids,
+                                                             int64_t B, int32_t K, const int64_t* __restrict__ excl, int32_t E,
+                                                             float* __restrict__ out) {
+    const int64_t n = B * K;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t r = i / K;
+        const int64_t id = ids[i];
+        bool isin = false;
+        for (int e = 0; e < E; ++e) isin |= excl[r * E + e] == id;
+        out[i] = scores[i] - (isin ? 1.0e5f : 0.f);
+    }
+}
+
+// sbcnm helper layers on explicit [B, C] logits
+__global__ __launch_bounds__(256) void logits_adjust_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
+                                                            int64_t B, int32_t C, const float* __restrict__ cand_prob,
+                                                            const int64_t* __restrict__ cand_ids, float add_label_scale,
+                                                            float* __restrict__ out) {
+    constexpr float MIN_FLOAT = -3.4028234663852886e36f;
+    // one wave per row: argmax(labels) (first max) then the per-element adjustment
+    const int lane = threadIdx.x & 63;
+    const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < B; r += nw) {
+        int best = C;
+        float bv = -INFINITY;
+        if (cand_ids != nullptr) {
+            for (int j = lane; j < C; j += 64) {
+                const float v = labels[r * C + j];
+                if (v > bv) { bv = v; best = j; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o, 64);
+                const int ob = __shfl_xor(best, o, 64);
+                if (ov > bv || (ov == bv && ob < best)) { bv = ov; best = ob; }
+            }
+        }
+        const int64_t pid = (cand_ids != nullptr && best < C) ? cand_ids[best] : 0;
+        for (int j = lane; j < C; j += 64) {
+            float v = logits[r * C + j];
+            if (cand_prob != nullptr) v -= logf(cand_prob[j]);                                  // sbcnm.py:86
+            if (cand_ids != nullptr) v += ((cand_ids[j] == pid ? 1.f : 0.f) - labels[r * C + j]) * MIN_FLOAT;   // :66-75
+            if (add_label_scale != 0.f) v += labels[r * C + j] * add_label_scale;                // :44 (logits + labels*MAX_FLOAT)
+            out[r * C + j] = v;
+        }
+    }
+}
+
+// CCE(from_logits) per row on an explicit [B, C] matrix: row_loss = w * (lse * sum_j y_j - sum_j y_j s_j)
+__global__ __launch_bounds__(256) void softmax_ce_rows_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
+                                                              int64_t B, int32_t C, float inv_t, const float* __restrict__ w,
+                                                              float* __restrict__ row_loss) {
+    const int lane = threadIdx.x & 63;
+    const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < B; r += nw) {
+        float m = -INFINITY;
+        for (int j = lane; j < C; j += 64) m = fmaxf(m, logits[r * C + j] * inv_t);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        float l = 0.f, ys = 0.f, y1 = 0.f;
+        for (int j = lane; j < C; j += 64) {
+            const float sv = logits[r * C + j] * inv_t, y = labels[r * C + j];
+            l += expf(sv - m);
+            ys = fmaf(y, sv, ys);
+            y1 += y;
+        }
+        l = dr_wave_sum(l); ys = dr_wave_sum(ys); y1 = dr_wave_sum(y1);
+        if (lane == 0) row_loss[r] = (w != nullptr ? w[r] : 1.f) * ((m + logf(l)) * y1 - ys);
+    }
+}
+__global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ v, int64_t n, float* __restrict__ out) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) acc += (double)v[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (float)((red[0] + red[1]) + (red[2] + red[3]));
+}
+
+__global__ __launch_bounds__(256) void fill_topk_kernel(float* __restrict__ s, int64_t* __restrict__ i, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) { s[t] = -INFINITY; i[t] = -1; }
+}
+
+}  // namespace
+
+extern "C" int dr_topk_select(const float* scores, int64_t ld, int64_t Bq, int64_t n, int32_t k, int64_t index_base,
+                              int32_t init, float* out_scores, int64_t* out_index, dr_stream_t stream) {
+    if (Bq < 0 || n < 0 || k <= 0 || k > KMAX || ld < n) return DR_EINVAL;
+    if (Bq == 0) return DR_OK;
+    if (!out_scores || !out_index || (n > 0 && !scores)) return DR_EINVAL;
+    hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)((Bq + 3) / 4)), dim3(256), 0, dr_s(stream), scores, ld, Bq, n, k,
+                       index_base, init, out_scores, out_index);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+extern "C" int64_t dr_topk_workspace_bytes(int64_t Bq, int64_t N, int32_t k) {
+    (void)k;
+    int64_t chunk = (int64_t)(128ll << 20) / (Bq > 0 ? Bq * 4 : 4);     // ~128 MB of scores: stays in the Infinity Cache
+    chunk = chunk / 128 * 128;
+    if (chunk < 128) chunk = 128;
+    if (chunk > N) chunk = (N + 3) / 4 * 4;
+    return Bq * chunk * 4;
+}
+
+extern "C" int dr_topk_mips(const float* q, int64_t Bq, const float* cand, int64_t N, int32_t D, int32_t k,
+                            int64_t index_base, int32_t init, float* out_scores, int64_t* out_index, float* workspace,
+                            int64_t workspace_bytes, dr_stream_t stream) {
+    if (Bq < 0 || N < 0 || D < 4 || k <= 0 || k > KMAX) return DR_EINVAL;
+    if (Bq == 0) return DR_OK;
+    if (!q || !out_scores || !out_index || !workspace || (N > 0 && !cand)) return DR_EINVAL;
+    if (init && k > N) return DR_ESHAPE;                 // "input must have at least k columns"
+    int64_t chunk = workspace_bytes / (Bq * 4);
+    chunk = chunk >= 128 ? chunk / 128 * 128 : chunk / 4 * 4;
+    if (chunk < 4 && N > 0) return DR_EINVAL;
+    int first = init;
+    if (N == 0 && init) {
+        hipLaunchKernelGGL(fill_topk_kernel, dim3(dr_grid_for(Bq * k, 256)), dim3(256), 0, dr_s(stream), out_scores, out_index,
+                           Bq * k);
+    }
+    for (int64_t c0 = 0; c0 < N; c0 += chunk) {
+        const int64_t nc = N - c0 < chunk ? N - c0 : chunk;
+        int rc = dr_scores_nt(q, D, cand + c0 * D, D, Bq, (int32_t)nc, D, workspace, chunk, stream);
+        if (rc != DR_OK) return rc;
+        rc = dr_topk_select(workspace, chunk, Bq, nc, k, index_base + c0, first, out_scores, out_index, stream);
+        if (rc != DR_OK) return rc;
+        first = 0;
+    }
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+extern "C" int dr_topk_merge(const float* sa, const int64_t* ia, int32_t ka, const float* sb, const int64_t* ib, int32_t kb,
+                             int64_t Bq, int32_t k, float* out_scores, int64_t* out_index, dr_stream_t stream) {
+    if (Bq < 0 || ka < 0 || kb < 0 || k <= 0) return DR_EINVAL;
+    if (Bq == 0) return DR_OK;
+    if (!out_scores || !out_index || (ka > 0 && (!sa || !ia)) || (kb > 0 && (!sb || !ib))) return DR_EINVAL;
+    hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)((Bq + 255) / 256)), dim3(256), 0, dr_s(stream), sa, ia, ka, sb, ib, kb,
+                       Bq, k, out_scores, out_index);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+extern "C" int dr_rowdot(const float* a, const float* b, int64_t B, int32_t D, float* out, dr_stream_t stream) {
+    if (B < 0 || D <= 0) return DR_EINVAL;
+    if (B == 0) return DR_OK;
+    if (!a || !b || !out) return DR_EINVAL;
+    hipLaunchKernelGGL(rowdot_kernel, dim3(dr_grid_for(B, 4)), dim3(256), 0, dr_s(stream), a, b, B, D, out);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+extern "C" int dr_gather_i64(const int64_t* src, int64_t nsrc, const int64_t* idx, int64_t n, int64_t* out, dr_stream_t stream) {
+    if (n < 0 || nsrc < 0) return DR_EINVAL;
+    if (n == 0) return DR_OK;
+    if (!src || !idx || !out) return DR_EINVAL;
+    hipLaunchKernelGGL(gather_i64_kernel, dim3(dr_grid_for(n, 256)), dim3(256), 0, dr_s(stream), src, nsrc, idx, n, out);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+extern "C" int dr_take_along_rows_f32(const float* arr, int64_t ld, int64_t B, int32_t C, const int64_t* idx, int32_t K, float* out,
+                                      dr_stream_t stream) {
+    if (B < 0 || C <= 0 || K < 0 || ld < C) return DR_EINVAL;
+    if (B == 0 || K == 0) return DR_OK;
+    if (!arr || !idx || !out) return DR_EINVAL;
+    hipLaunchKernelGGL((take_along_rows_kernel<float>), dim3(dr_grid_for(B * K, 256)), dim3(256), 0, dr_s(stream), arr, ld, B, C,
+                       idx, K, out);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+extern "C" int dr_take_along_rows_i64(const int64_t* arr, int64_t ld, int64_t B, int32_t C, const int64_t* idx, int32_t K,
+                                      int64_t* out, dr_stream_t stream) {
+    if (B < 0 || C <= 0 || K < 0 || ld < C) return DR_EINVAL;
+    if (B == 0 || K == 0) return DR_OK;
+    if (!arr || !idx || !out) return DR_EINVAL;
+    hipLaunchKernelGGL((take_along_rows_kernel<int64_t>), dim3(dr_grid_for(B * K, 256)), dim3(256), 0, dr_s(stream), arr, ld, B, C,
+                       idx, K, out);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+extern "C" int dr_topk_hits(const float* pos, const float* topk, int64_t B, int32_t K, const int32_t* ks, int32_t nk,
+                            uint64_t* hits, dr_stream_t stream) {
+    if (B < 0 || K < 0 || nk <= 0) return DR_EINVAL;
+    if (B == 0) return DR_OK;
+    if (!pos || !ks || !hits || (K > 0 && !topk)) return DR_EINVAL;
+    hipLaunchKernelGGL(topk_hits_kernel, dim3(dr_grid_for(B, 256)), dim3(256), 0, dr_s(stream), pos, topk, B, K, ks, nk,
+                       reinterpret_cast<unsigned long long*>(hits));
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+extern "C" int dr_exclude_adjust(const float* scores, const int64_t* ids, int64_t B, int32_t K, const int64_t* exclude, int32_t E,
+                                 float* adjusted, dr_stream_t stream) {
+    if (B < 0 || K <= 0 || E < 0) return DR_EINVAL;
+    if (B == 0) return DR_OK;
+    if (!scores || !ids || !adjusted || (E > 0 && !exclude)) return DR_EINVAL;
+    hipLaunchKernelGGL(exclude_adjust_kernel, dim3(dr_grid_for(B * K, 256)), dim3(256), 0, dr_s(stream), scores, ids, B, K, exclude,
+                       E, adjusted);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+extern "C" int dr_logits_adjust(const float* logits, const float* labels, int64_t B, int32_t C, const float* cand_prob,
+                                const int64_t* cand_ids, float add_label_scale, float* out, dr_stream_t stream) {
+    if (B < 0 || C <= 0) return DR_EINVAL;
+    if (B == 0) return DR_OK;
+    if (!logits || !out || ((cand_ids != nullptr || add_label_scale != 0.f) && !labels)) return DR_EINVAL;
+    hipLaunchKernelGGL(logits_adjust_kernel, dim3(dr_grid_for(B, 4)), dim3(256), 0, dr_s(stream), logits, labels, B, C, cand_prob,
+                       cand_ids, add_label_scale, out);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+extern "C" int dr_softmax_ce_rows(const float* logits, const float* labels, int64_t B, int32_t C, float inv_temperature,
+                                  const float* sample_weight, float* row_loss, float* loss_out, dr_stream_t stream) {
+    if (B <= 0 || C <= 0) return DR_EINVAL;
+    if (!logits || !labels || !row_loss || !loss_out) return DR_EINVAL;
+    hipLaunchKernelGGL(softmax_ce_rows_kernel, dim3(dr_grid_for(B, 4)), dim3(256), 0, dr_s(stream), logits, labels, B, C,
+                       inv_temperature, sample_weight, row_loss);
+    hipLaunchKernelGGL(sum_rows_kernel, dim3(1), dim3(256), 0, dr_s(stream), row_loss, B, loss_out);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}

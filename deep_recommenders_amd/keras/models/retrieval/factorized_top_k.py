@@ -1,0 +1,218 @@
+"""Top-K retrieval indices + the FactorizedTopK metric — same surface as the reference's
+keras/models/retrieval/factorized_top_k.py (`_take_long_axis` :26-41, `_exclude` :44-67, `TopK` :70-136,
+`Streaming` :139-260, `BruteForce` :263-334, `FactorizedTopK` :464-522), on the K10 kernels.
+The `Faiss` (IVF-Flat) index is §8f "next" and is not provided."""
+import abc
+from typing import Iterable, List, Optional, Sequence, Tuple, Union
+
+import torch
+from torch import nn
+
+from deep_recommenders_amd import ops
+
+
+def _dev(t, dtype=None):
+    t = torch.as_tensor(t)
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda() if not t.is_cuda else t
+
+
+def _take_long_axis(arr, indices):
+    """arr [B, C], indices [B, K] -> arr[b, indices[b, k]]  (factorized_top_k.py:26-41)"""
+    arr = _dev(arr)
+    if arr.dtype not in (torch.float32, torch.int64):
+        arr = arr.to(torch.float32 if arr.is_floating_point() else torch.int64)
+    return ops.take_along_rows(arr, _dev(indices, torch.int64))
+
+
+def _exclude(scores, identifiers, exclude, k):
+    """Remove `exclude` identifiers from a top-k result (factorized_top_k.py:44-67, penalty 1e5 at :62)."""
+    scores = _dev(scores, torch.float32)
+    identifiers = _dev(identifiers, torch.int64)
+    exclude = _dev(exclude, torch.int64)
+    adjusted = ops.exclude_adjust(scores, identifiers, exclude)
+    k = min(int(k), scores.shape[1])
+    _, indices = ops.topk_select(adjusted, k)
+    return _take_long_axis(scores, indices), _take_long_axis(identifiers, indices)
+
+
+class TopK(nn.Module, abc.ABC):
+    """TopK layer interface: `index(candidates, identifiers=None) -> self`, `call(queries, k=None) -> (scores, ids)`."""
+
+    def __init__(self, k: int, *args, **kwargs):
+        super().__init__()
+        self._k = k
+
+    @abc.abstractmethod
+    def index(self, candidates, identifiers=None) -> "TopK":
+        raise NotImplementedError("Implementers must provide `index` method.")
+
+    @abc.abstractmethod
+    def call(self, queries, k: Optional[int] = None, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
+        raise NotImplementedError()
+
+    def forward(self, queries, k: Optional[int] = None, **kwargs):
+        return self.call(queries, k=k, **kwargs)
+
+    def query_with_exclusions(self, queries, exclusions, k: Optional[int] = None):
+        """factorized_top_k.py:111-129"""
+        k = k if k is not None else self._k
+        exclusions = _dev(exclusions, torch.int64)
+        adjusted_k = k + exclusions.shape[1]
+        scores, identifiers = self(queries=queries, k=adjusted_k)
+        return _exclude(scores, identifiers, exclusions, adjusted_k)
+
+
+def _batches(x) -> List[torch.Tensor]:
+    """A 'dataset' here is any iterable of [n_i, D] batches (the reference uses tf.data.Dataset.batch)."""
+    if isinstance(x, torch.Tensor):
+        return [x]
+    if hasattr(x, "shape") and not isinstance(x, (list, tuple)):
+        return [torch.as_tensor(x)]
+    return [torch.as_tensor(b) for b in x]
+
+
+class Streaming(TopK):
+    """Retrieves top k scoring items and identifiers from a large (batched) candidate set (:139-260):
+    per candidate batch a top-k (map), merged into the running top-k (reduce) — here each batch is folded
+    straight into the running per-query list by the K10 kernels."""
+
+    def __init__(self, k: int = 10, query_model=None, handle_incomplete_batches: bool = True, num_parallel_calls=None,
+                 sorted_order: bool = True, *args, **kwargs):
+        super().__init__(k, *args, **kwargs)
+        self._query_model = query_model
+        self._handle_incomplete_batches = handle_incomplete_batches
+        self._num_parallel_calls = num_parallel_calls
+        self._sorted_order = sorted_order
+        self._candidates = None
+        self._identifiers = None
+
+    def index(self, candidates, identifiers=None, **kwargs) -> "Streaming":
+        self._candidates = candidates
+        self._identifiers = identifiers
+        return self
+
+    def call(self, queries, k: Optional[int] = None, **kwargs):
+        k = k if k is not None else self._k
+        if self._candidates is None:
+            raise ValueError("The `index` method must be called first to "
+                             "create the retrieval index.")                       # :191-193
+        if self._query_model is not None:
+            queries = self._query_model(queries)
+        queries = _dev(queries, torch.float32)
+        cand_batches = _batches(self._candidates)
+        id_batches = _batches(self._identifiers) if self._identifiers is not None else None
+        total = sum(int(b.shape[0]) for b in cand_batches)
+        if not self._handle_incomplete_batches:
+            for b in cand_batches:
+                if b.shape[0] < k:                                                 # :13-23,256
+                    raise ValueError("Tried to retrieve k={k} top items, but candidate batch too small."
+                                     "To resolve this, 1. increase batch-size, 2. set `drop_remainder`=True, "
+                                     "3. set `handle_incomplete_batches`=True in constructor.".format(k=k))
+        k_eff = min(k, total)
+        state = ops.topk_init(queries.shape[0], k_eff, queries.device)      # initial_state: empty (:239-240)
+        counter = 0                                                         # counter-based row ids (:244-254)
+        for b in cand_batches:
+            b = _dev(b, torch.float32)
+            ops.topk_mips(queries, b, k_eff, index_base=counter, init=False, state=state)
+            counter += b.shape[0]
+        scores, index = state
+        if id_batches is not None:
+            ids = torch.cat([_dev(i).reshape(-1) for i in id_batches]).to(torch.int64)
+            return scores, ops.gather_i64(ids, index)
+        return scores, index
+
+
+class BruteForce(TopK):
+    """Brute-force retrieval (:263-334): scores = queries @ candidates^T, top-k, gather identifiers."""
+
+    def __init__(self, k: int = 10, query_model=None, *args, **kwargs):
+        super().__init__(k, *args, **kwargs)
+        self._query_model = query_model
+        self._candidates = None
+        self._identifiers = None
+
+    def index(self, candidates, identifiers=None) -> "BruteForce":
+        cand = torch.cat([_dev(b, torch.float32) for b in _batches(candidates)], dim=0)
+        if cand.dim() != 2:
+            raise ValueError("`candidates` ndim should be 2. "
+                             "Got `ndim` = {}".format(cand.dim()))                  # :288-290
+        if identifiers is None:
+            ids = torch.arange(cand.shape[0], device=cand.device, dtype=torch.int64)
+        else:
+            ids = torch.cat([_dev(b).reshape(-1) for b in _batches(identifiers)]).to(torch.int64)
+        # non-trainable state so the index serialises with the module (:292-311)
+        self.register_buffer("_candidates", cand.contiguous())
+        self.register_buffer("_identifiers", ids.contiguous())
+        return self
+
+    def call(self, queries, k: Optional[int] = None, **kwargs):
+        k = k if k is not None else self._k
+        if self._candidates is None:
+            raise ValueError("The `index` method must be called first to "
+                             "create the retrieval index.")                       # :323-325
+        if self._query_model is not None:
+            queries = self._query_model(queries)
+        queries = _dev(queries, torch.float32)
+        scores, index = ops.topk_mips(queries, self._candidates, k)                # :330-332
+        return scores, ops.gather_i64(self._identifiers, index)                    # :334
+
+
+class TopKCategoricalAccuracy:
+    """[TF] tf.keras.metrics.TopKCategoricalAccuracy(k) restricted to what FactorizedTopK feeds it
+    (y_true = [1, 0, ...], y_pred = [positive, top-k...]): running mean of in_top_k (App. B14)."""
+
+    def __init__(self, k: int = 5, name: Optional[str] = None):
+        self.k = int(k)
+        self.name = name or "top_k_categorical_accuracy"
+        self.reset_states()
+
+    def reset_states(self):
+        self.hits = 0
+        self.count = 0
+
+    def result(self) -> float:
+        return self.hits / self.count if self.count else 0.0
+
+
+class FactorizedTopK(nn.Module):
+    """Metric for a retrieval model (:464-522): top-{1,5,10,50,100} categorical accuracy of the true candidate
+    against the top-k retrieved from `candidates` (a TopK layer or an iterable of candidate batches)."""
+
+    def __init__(self, candidates, metrics: Optional[Sequence[TopKCategoricalAccuracy]] = None, k: int = 100,
+                 name: str = "factorized_top_k", **kwargs):
+        super().__init__()
+        self.name = name
+        if metrics is None:
+            metrics = [TopKCategoricalAccuracy(k=n, name=f"{self.name}/top_{n}_categorical_accuracy")
+                       for n in [1, 5, 10, 50, 100]]                                # :475-480
+        if not isinstance(candidates, TopK):
+            candidates = Streaming(k=k).index(candidates)                           # :482-483
+        self._candidates = candidates
+        self._metrics = list(metrics)
+        self._k = k
+
+    @property
+    def metrics(self):
+        return self._metrics
+
+    def update_state(self, query_embeddings, true_candidate_embeddings) -> None:
+        q = _dev(query_embeddings, torch.float32)
+        c = _dev(true_candidate_embeddings, torch.float32)
+        positive_scores = ops.rowdot(q, c)                                          # :494-495
+        top_k_predictions, _ = self._candidates(q, k=self._k)                      # :497
+        ks = torch.tensor([m.k for m in self._metrics], dtype=torch.int32, device=q.device)
+        hits = torch.zeros(len(self._metrics), dtype=torch.int64, device=q.device)
+        ops.topk_hits(positive_scores, top_k_predictions, ks, hits)                # :499-512 (in_top_k counting)
+        h = hits.cpu().tolist()
+        for m, v in zip(self._metrics, h):
+            m.hits += int(v)
+            m.count += q.shape[0]
+
+    def reset_states(self) -> None:
+        for metric in self.metrics:
+            metric.reset_states()
+
+    def result(self) -> List[float]:
+        return [metric.result() for metric in self.metrics]

@@ -378,3 +378,163 @@ def linear_bwd_dx_fm(dy, W, d_fm_logit, sum_x, concat, D, FD, out):
                                     ptr(concat), concat.stride(0), int(D), int(FD), ptr(out), out.stride(0),
                                     stream_ptr()), "dr_linear_bwd_dx_fm")
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# K9 / K10   two-tower retrieval
+# ----------------------------------------------------------------------------------------------
+def inbatch_softmax_fwd(q, c, cand_prob=None, cand_ids=None, sample_weight=None, inv_temperature=1.0):
+    q = _c(q, torch.float32)
+    c = _c(c, torch.float32)
+    B, D = q.shape
+    dev = q.device
+    row_lse = torch.empty(B, dtype=torch.float32, device=dev)
+    pos = torch.empty(B, dtype=torch.float32, device=dev)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    nbytes = lib().dr_inbatch_softmax_workspace_bytes(B)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    check(lib().dr_inbatch_softmax_fwd(ptr(q), ptr(c), B, D, ptr(cand_prob), ptr(cand_ids), ptr(sample_weight),
+                                       float(inv_temperature), ptr(row_lse), ptr(pos), ptr(loss), ptr(ws), nbytes,
+                                       stream_ptr()), "dr_inbatch_softmax_fwd")
+    return loss, row_lse, pos
+
+
+def inbatch_softmax_grad_scores(q, c, row_lse, d_loss, cand_prob=None, cand_ids=None, sample_weight=None,
+                                inv_temperature=1.0):
+    B, D = q.shape
+    G = torch.empty((B, _pad4(B)), dtype=torch.float32, device=q.device)[:, :B]
+    check(lib().dr_inbatch_softmax_grad_scores(ptr(q), ptr(c), B, D, ptr(cand_prob), ptr(cand_ids), ptr(sample_weight),
+                                               float(inv_temperature), ptr(row_lse), float(d_loss), ptr(G), G.stride(0),
+                                               stream_ptr()), "dr_inbatch_softmax_grad_scores")
+    return G
+
+
+def scores_nt(a, b, out=None):
+    a = _rowmajor_ld4(a)
+    b = _rowmajor_ld4(b)
+    M, D = a.shape
+    N = b.shape[0]
+    if out is None:
+        out = torch.empty((M, _pad4(N)), dtype=torch.float32, device=a.device)[:, :N]
+    check(lib().dr_scores_nt(ptr(a), a.stride(0), ptr(b), b.stride(0), M, N, D, ptr(out), out.stride(0), stream_ptr()),
+          "dr_scores_nt")
+    return out
+
+
+def topk_state(Bq, k, device):
+    return (torch.empty((Bq, k), dtype=torch.float32, device=device), torch.empty((Bq, k), dtype=torch.int64, device=device))
+
+
+def topk_select(scores, k, index_base=0, init=True, state=None):
+    """row-wise top-k of an explicit [Bq, n] score matrix, folded into `state` (scores, index)."""
+    assert scores.stride(1) == 1
+    Bq, n = scores.shape
+    if state is None:
+        state = topk_state(Bq, k, scores.device)
+    check(lib().dr_topk_select(ptr(scores), scores.stride(0), Bq, n, int(k), int(index_base), int(bool(init)),
+                               ptr(state[0]), ptr(state[1]), stream_ptr()), "dr_topk_select")
+    return state
+
+
+def topk_mips(q, cand, k, index_base=0, init=True, state=None, workspace=None):
+    q = _c(q, torch.float32)
+    cand = _c(cand, torch.float32)
+    Bq, D = q.shape
+    N = cand.shape[0]
+    if state is None:
+        state = topk_state(Bq, k, q.device)
+    if workspace is None:
+        workspace = torch.empty(max(1, lib().dr_topk_workspace_bytes(Bq, N, int(k)) // 4), dtype=torch.float32, device=q.device)
+    rc = lib().dr_topk_mips(ptr(q), Bq, ptr(cand), N, D, int(k), int(index_base), int(bool(init)), ptr(state[0]),
+                            ptr(state[1]), ptr(workspace), workspace.numel() * 4, stream_ptr())
+    if rc == _lib.DR_ESHAPE:
+        raise ValueError("Tried to retrieve k={k} top items, but candidate batch too small."
+                         "To resolve this, 1. increase batch-size, 2. set `drop_remainder`=True, "
+                         "3. set `handle_incomplete_batches`=True in constructor.".format(k=k))
+    check(rc, "dr_topk_mips")
+    return state
+
+
+def topk_merge(sa, ia, sb, ib, k):
+    Bq = sa.shape[0]
+    out = topk_state(Bq, k, sa.device)
+    check(lib().dr_topk_merge(ptr(sa), ptr(ia), sa.shape[1], ptr(sb), ptr(ib), sb.shape[1], Bq, int(k), ptr(out[0]),
+                              ptr(out[1]), stream_ptr()), "dr_topk_merge")
+    return out
+
+
+def rowdot(a, b):
+    a = _c(a, torch.float32)
+    b = _c(b, torch.float32)
+    out = torch.empty((a.shape[0], 1), dtype=torch.float32, device=a.device)
+    check(lib().dr_rowdot(ptr(a), ptr(b), a.shape[0], a.shape[1], ptr(out), stream_ptr()), "dr_rowdot")
+    return out
+
+
+def gather_i64(src, idx):
+    src = _c(src, torch.int64)
+    idx = _c(idx, torch.int64)
+    out = torch.empty_like(idx)
+    check(lib().dr_gather_i64(ptr(src), src.numel(), ptr(idx), idx.numel(), ptr(out), stream_ptr()), "dr_gather_i64")
+    return out
+
+
+def take_along_rows(arr, idx):
+    idx = _c(idx, torch.int64)
+    arr = arr if arr.stride(1) == 1 else arr.contiguous()
+    B, C = arr.shape
+    K = idx.shape[1]
+    out = torch.empty((B, K), dtype=arr.dtype, device=arr.device)
+    if arr.dtype == torch.float32:
+        fn, nm = lib().dr_take_along_rows_f32, "dr_take_along_rows_f32"
+    elif arr.dtype == torch.int64:
+        fn, nm = lib().dr_take_along_rows_i64, "dr_take_along_rows_i64"
+    else:
+        raise TypeError("take_along_rows supports float32 / int64, got %s" % arr.dtype)
+    check(fn(ptr(arr), arr.stride(0), B, C, ptr(idx), K, ptr(out), stream_ptr()), nm)
+    return out
+
+
+def topk_hits(pos, topk, ks, hits):
+    """hits[t] += number of rows whose positive is within the top ks[t] ([TF] in_top_k semantics)."""
+    pos = _c(pos.reshape(-1), torch.float32)
+    topk = _c(topk, torch.float32)
+    check(lib().dr_topk_hits(ptr(pos), ptr(topk), pos.numel(), topk.shape[1], ptr(ks), ks.numel(), ptr(hits), stream_ptr()),
+          "dr_topk_hits")
+
+
+def exclude_adjust(scores, ids, exclude):
+    scores = _c(scores, torch.float32)
+    ids = _c(ids, torch.int64)
+    exclude = _c(exclude, torch.int64)
+    out = torch.empty_like(scores)
+    check(lib().dr_exclude_adjust(ptr(scores), ptr(ids), scores.shape[0], scores.shape[1], ptr(exclude), exclude.shape[1],
+                                  ptr(out), stream_ptr()), "dr_exclude_adjust")
+    return out
+
+
+def logits_adjust(logits, labels=None, cand_prob=None, cand_ids=None, add_label_scale=0.0):
+    logits = _c(logits, torch.float32)
+    labels = _c(labels, torch.float32) if labels is not None else None
+    out = torch.empty_like(logits)
+    check(lib().dr_logits_adjust(ptr(logits), ptr(labels), logits.shape[0], logits.shape[1], ptr(cand_prob), ptr(cand_ids),
+                                 float(add_label_scale), ptr(out), stream_ptr()), "dr_logits_adjust")
+    return out
+
+
+def topk_init(Bq, k, device):
+    """empty running top-k lists (scores -inf, index -1)"""
+    state = topk_state(Bq, k, device)
+    check(lib().dr_topk_select(None, 0, Bq, 0, int(k), 0, 1, ptr(state[0]), ptr(state[1]), stream_ptr()), "dr_topk_select")
+    return state
+
+
+def softmax_ce_rows(logits, labels, inv_temperature=1.0, sample_weight=None):
+    logits = _c(logits, torch.float32)
+    labels = _c(labels, torch.float32)
+    B, C = logits.shape
+    row = torch.empty(B, dtype=torch.float32, device=logits.device)
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    check(lib().dr_softmax_ce_rows(ptr(logits), ptr(labels), B, C, float(inv_temperature), ptr(sample_weight), ptr(row),
+                                   ptr(loss), stream_ptr()), "dr_softmax_ce_rows")
+    return loss.reshape(())

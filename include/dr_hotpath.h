@@ -223,6 +223,72 @@ int dr_bce_prob_fwd_bwd(const float* prob, const float* labels, int64_t n, int32
                         float* loss_out, float* workspace, dr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * K9  in-batch sampled-softmax retrieval loss (Retrieval.call, keras/models/retrieval/sbcnm.py:120-151)
+ *   scores = q @ c^T (:129); labels = eye (:134); optional -log(p_j) (:86), duplicate-id mask
+ *   (+MIN_FLOAT = finfo(f32).min/100, :66-75), * 1/temperature (:148-149);
+ *   loss = CCE(from_logits, reduction=SUM) = sum_i w_i * (logsumexp_j s_ij - s_ii)   (:100-102,151)
+ * The B x B score matrix is never materialised in the forward: the MFMA GEMM's epilogue reduces each
+ * 32-column group to (max, sum-exp) partials, a finalize pass combines them.
+ *   row_lse[B], pos_score[B] (= s_ii) are outputs the backward reuses; loss_out[1].
+ * Backward: dr_inbatch_softmax_grad_scores writes G = d_loss * w_i * (softmax_ij - delta_ij) / T into a
+ *   caller-provided [B, ld_g] buffer; then dq = G @ c is dr_linear_fwd(G, c) and dc = G^T @ q is
+ *   dr_linear_bwd_dw(G, q) — two plain GEMMs.  cand_prob / cand_ids / sample_weight may be NULL.
+ * ---------------------------------------------------------------------------------------- */
+int64_t dr_inbatch_softmax_workspace_bytes(int64_t B);
+int dr_inbatch_softmax_fwd(const float* q, const float* c, int64_t B, int32_t D, const float* cand_prob,
+                           const int64_t* cand_ids, const float* sample_weight, float inv_temperature,
+                           float* row_lse, float* pos_score, float* loss_out, float* workspace,
+                           int64_t workspace_bytes, dr_stream_t stream);
+int dr_inbatch_softmax_grad_scores(const float* q, const float* c, int64_t B, int32_t D,
+                                   const float* cand_prob, const int64_t* cand_ids,
+                                   const float* sample_weight, float inv_temperature, const float* row_lse,
+                                   float d_loss, float* G, int64_t ld_g, dr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K10  exact top-K maximum-inner-product search (BruteForce.call factorized_top_k.py:316-334,
+ * Streaming.call :178-260): scores = q @ cand^T, k largest per query, descending, ties -> lower candidate
+ * index first ([TF] tf.math.top_k).  The [Bq, N] score matrix is never materialised: candidates are scored
+ * in chunks (dr_scores_nt into `workspace`) and folded into a running sorted list per query
+ * (dr_topk_select).  k <= 128.  out_scores[Bq,k] fp32, out_index[Bq,k] int64 (candidate position +
+ * index_base, -1 = empty slot).  init = 1 starts a new search, init = 0 continues one (Streaming's
+ * per-batch map + reduce, :201-233).  Returns DR_ESHAPE if init && k > N (the reference's
+ * "input must have at least k columns", :13-23).
+ * dr_topk_merge: merge two sorted lists per row, list a wins ties (Streaming's reduce; cross-rank merge).
+ * ---------------------------------------------------------------------------------------- */
+int dr_scores_nt(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t M, int32_t N, int32_t D,
+                 float* out, int64_t ld_out, dr_stream_t stream);
+int dr_topk_select(const float* scores, int64_t ld, int64_t Bq, int64_t n, int32_t k, int64_t index_base,
+                   int32_t init, float* out_scores, int64_t* out_index, dr_stream_t stream);
+int64_t dr_topk_workspace_bytes(int64_t Bq, int64_t N, int32_t k);
+int dr_topk_mips(const float* q, int64_t Bq, const float* cand, int64_t N, int32_t D, int32_t k,
+                 int64_t index_base, int32_t init, float* out_scores, int64_t* out_index,
+                 float* workspace, int64_t workspace_bytes, dr_stream_t stream);
+int dr_topk_merge(const float* sa, const int64_t* ia, int32_t ka, const float* sb, const int64_t* ib,
+                  int32_t kb, int64_t Bq, int32_t k, float* out_scores, int64_t* out_index,
+                  dr_stream_t stream);
+/* small retrieval ops: positive scores sum(q*c, axis=1) (factorized_top_k.py:494-495); identifier gather
+ * (:334); _take_long_axis (:26-41) / _gather_elements_along_row (sbcnm.py:15-30); _exclude's penalty
+ * (:57-62); FactorizedTopK's in_top_k counting (:499-512, [TF] B14); and the sbcnm helper layers on explicit
+ * logits: out = logits - log(p_j) (:86) + (dup_ij - labels_ij) * MIN_FLOAT (:66-75) + labels_ij * scale (:44) */
+int dr_rowdot(const float* a, const float* b, int64_t B, int32_t D, float* out, dr_stream_t stream);
+int dr_gather_i64(const int64_t* src, int64_t nsrc, const int64_t* idx, int64_t n, int64_t* out,
+                  dr_stream_t stream);
+int dr_take_along_rows_f32(const float* arr, int64_t ld, int64_t B, int32_t C, const int64_t* idx, int32_t K,
+                           float* out, dr_stream_t stream);
+int dr_take_along_rows_i64(const int64_t* arr, int64_t ld, int64_t B, int32_t C, const int64_t* idx,
+                           int32_t K, int64_t* out, dr_stream_t stream);
+int dr_topk_hits(const float* pos, const float* topk, int64_t B, int32_t K, const int32_t* ks, int32_t nk,
+                 uint64_t* hits, dr_stream_t stream);
+int dr_exclude_adjust(const float* scores, const int64_t* ids, int64_t B, int32_t K, const int64_t* exclude,
+                      int32_t E, float* adjusted, dr_stream_t stream);
+int dr_logits_adjust(const float* logits, const float* labels, int64_t B, int32_t C, const float* cand_prob,
+                     const int64_t* cand_ids, float add_label_scale, float* out, dr_stream_t stream);
+/* CCE(from_logits=True, reduction=SUM) on an explicit [B, C] logits / labels pair (the hard-negative branch,
+ * sbcnm.py:145-151): row_loss[B] scratch, loss_out[1] = sum_i w_i * (lse_i * sum_j y_ij - sum_j y_ij s_ij / T) */
+int dr_softmax_ce_rows(const float* logits, const float* labels, int64_t B, int32_t C, float inv_temperature,
+                       const float* sample_weight, float* row_loss, float* loss_out, dr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Row-sharded tables over N ranks (new design — the reference is single-process; the
  * exchange mirrors no reference code).  owner(id) = id % world; on the owner, field f's shard holds
  * rows_per_shard rows and id lives at local row f*rows_per_shard + id / world.
