@@ -120,7 +120,13 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)
 
-    if world == 1:
+    force_sharded = os.environ.get("DR_FORCE_SHARDED", "0") == "1"      # exercise the N>1 code path on one GPU
+    if world == 1 and force_sharded:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    if world == 1 and not force_sharded:
         from deep_recommenders_amd.engine import DeepFMEngine
         eng = DeepFMEngine(a.fields, a.vocab, a.dim, dnn_units, a.batch, num_dense=a.dense, lr=a.lr, device=device)
     else:

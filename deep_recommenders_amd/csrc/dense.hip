@@ -61,6 +61,10 @@ struct GemmArgs {
     const float* lse;             // SMGRAD: row log-sum-exp ; vec = sample_weight (or null) ; alpha = d_loss
 };
 
+// exp() of a non-positive softmax argument; masked logits sit at ~-5e36 (MIN_FLOAT / temperature), far outside the
+// range the libm range reduction is exact for, so anything below -87 (exp < FLT_MIN) is taken as exactly 0
+__device__ __forceinline__ float safe_exp(float d) { return d < -87.f ? 0.f : expf(d); }
+
 // bijective XCD-aware remap (cdna guide T1): consecutive logical tile ids -> same XCD
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg / 8, r = nwg % 8;
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
                     float l = 0.f;
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni)
-                        if (colj[ni] < g.N) l += expf(sv[ni] - m);
+                        if (colj[ni] < g.N) l += safe_exp(sv[ni] - m);
 #pragma unroll
                     for (int o = 1; o < 32; o <<= 1) l += __shfl_xor(l, o, 64);
                     if (rv && (lane & 31) == 0) {
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni) {
                         if (colj[ni] >= g.N) continue;
-                        const float pr = expf(sv[ni] - lse) - (row == colj[ni] ? 1.f : 0.f);
+                        const float pr = safe_exp(sv[ni] - lse) - (row == colj[ni] ? 1.f : 0.f);
                         g.C[row * g.ldc + colj[ni]] = w * pr * g.inv_t * g.alpha;
                     }
                 }
@@ -628,7 +632,7 @@ __global__ __launch_bounds__(256) void lse_finalize_kernel(const float* __restri
         float m = -INFINITY;
         for (int p = 0; p < nparts; ++p) m = fmaxf(m, part_m[(int64_t)p * B + i]);
         float l = 0.f;
-        for (int p = 0; p < nparts; ++p) l += part_l[(int64_t)p * B + i] * expf(part_m[(int64_t)p * B + i] - m);
+        for (int p = 0; p < nparts; ++p) l += part_l[(int64_t)p * B + i] * safe_exp(part_m[(int64_t)p * B + i] - m);
         const float lse = m + logf(l);
         row_lse[i] = lse;
         acc += (w != nullptr ? w[i] : 1.f) * (lse - pos[i]);

@@ -130,8 +130,9 @@ class BruteForce(TopK):
     def __init__(self, k: int = 10, query_model=None, *args, **kwargs):
         super().__init__(k, *args, **kwargs)
         self._query_model = query_model
-        self._candidates = None
-        self._identifiers = None
+        # non-trainable state so the index serialises with the module (:292-311)
+        self.register_buffer("_candidates", None)
+        self.register_buffer("_identifiers", None)
 
     def index(self, candidates, identifiers=None) -> "BruteForce":
         cand = torch.cat([_dev(b, torch.float32) for b in _batches(candidates)], dim=0)
@@ -142,9 +143,8 @@ class BruteForce(TopK):
             ids = torch.arange(cand.shape[0], device=cand.device, dtype=torch.int64)
         else:
             ids = torch.cat([_dev(b).reshape(-1) for b in _batches(identifiers)]).to(torch.int64)
-        # non-trainable state so the index serialises with the module (:292-311)
-        self.register_buffer("_candidates", cand.contiguous())
-        self.register_buffer("_identifiers", ids.contiguous())
+        self._candidates = cand.contiguous()
+        self._identifiers = ids.contiguous()
         return self
 
     def call(self, queries, k: Optional[int] = None, **kwargs):
