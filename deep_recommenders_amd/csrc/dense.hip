@@ -25,7 +25,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int BM = 128, BN = 128, BK = 32;   // wide configuration; the narrow one is 128 x 32 (template NARROW)
 constexpr int LD_T = 129;   // pitch of a transposed-in operand tile
 constexpr int LD_D = 132;   // pitch of a direct operand tile
 
@@ -106,10 +106,14 @@ __device__ __forceinline__ float4 fix4(f4u v, EdgeFix e) {
     return o;
 }
 
-template <bool A_RC, bool B_RC, int EPI, bool PIN>
+template <bool A_RC, bool B_RC, int EPI, bool NARROW>
 __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
+    // wide: 2 x 2 waves, each 2 x 2 MFMA tiles (128 x 128);  narrow: 4 x 1 waves, each 1 x 1 tile (128 x 32)
+    constexpr int BN = NARROW ? 32 : 128;
+    constexpr int TM = NARROW ? 1 : 2, TN = NARROW ? 1 : 2;
+    constexpr int NQB = NARROW ? 1 : 4;                      // float4's of the B tile per thread
     constexpr int LDA = A_RC ? LD_T : LD_D;
-    constexpr int LDB = B_RC ? LD_T : LD_D;
+    constexpr int LDB = B_RC ? (NARROW ? 33 : LD_T) : (NARROW ? 36 : LD_D);
     __shared__ __attribute__((aligned(16))) float smem[BK * LDA + BK * LDB];
     float* As = smem;
     float* Bs = smem + BK * LDA;
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = NARROW ? wave : (wave >> 1), wn = NARROW ? 0 : (wave & 1);
 
     const int tiles_n = (g.N + BN - 1) / BN;
     const int tiles_m = (int)((g.M + BM - 1) / BM);
@@ -135,24 +139,30 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
         if (r_begin >= r_end) return;
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[a][b][k] = 0.f;
 
-    // per-thread coordinates of its 4 float4's: RC operand -> (i = tid>>3 (+32q), r4 = tid&7), else (r = tid>>5 (+8q), c4 = tid&31)
+    // per-thread coordinates of its float4's.  RC operand: (i = tid>>3 (+32q), r4 = tid&7); reduction-major operand, wide:
+    // (r = tid>>5 (+8q), c4 = tid&31), narrow B (32 columns): (r = tid>>3, c4 = tid&7), one float4 per thread.
     const int rc_i = tid >> 3, rc_r4 = tid & 7;
     const int dr_r = tid >> 5, dr_c4 = tid & 31;
-    f4u va[4], vb[4];
+    const int nb_r = tid >> 3, nb_c4 = tid & 7;
+    f4u va[4], vb[NQB];
     auto load_tiles = [&](int64_t r0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (A_RC) va[q] = ld4_raw(g.A, g.lda, m0 + rc_i + 32 * q, g.M, r0 + rc_r4 * 4, r_end);
             else      va[q] = ld4_raw(g.A, g.lda, r0 + dr_r + 8 * q, r_end, m0 + dr_c4 * 4, g.M);
+        }
+#pragma unroll
+        for (int q = 0; q < NQB; ++q) {
             if (B_RC) vb[q] = ld4_raw(g.B, g.ldb, (int64_t)n0 + rc_i + 32 * q, g.N, r0 + rc_r4 * 4, r_end);
+            else if (NARROW) vb[q] = ld4_raw(g.B, g.ldb, r0 + nb_r, r_end, (int64_t)n0 + nb_c4 * 4, g.N);
             else      vb[q] = ld4_raw(g.B, g.ldb, r0 + dr_r + 8 * q, r_end, (int64_t)n0 + dr_c4 * 4, g.N);
         }
     };
@@ -167,10 +177,16 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
                 const float4 t = fix4(va[q], edge_of(r0 + dr_r + 8 * q, r_end, m0 + dr_c4 * 4, g.M));
                 *reinterpret_cast<float4*>(&As[(dr_r + 8 * q) * LDA + dr_c4 * 4]) = t;
             }
+        }
+#pragma unroll
+        for (int q = 0; q < NQB; ++q) {
             if (B_RC) {
                 const float4 t = fix4(vb[q], edge_of((int64_t)n0 + rc_i + 32 * q, g.N, r0 + rc_r4 * 4, r_end));
                 float* d = Bs + (rc_r4 * 4) * LDB + rc_i + 32 * q;
                 d[0] = t.x; d[LDB] = t.y; d[2 * LDB] = t.z; d[3 * LDB] = t.w;
+            } else if (NARROW) {
+                const float4 t = fix4(vb[q], edge_of(r0 + nb_r, r_end, (int64_t)n0 + nb_c4 * 4, g.N));
+                *reinterpret_cast<float4*>(&Bs[nb_r * LDB + nb_c4 * 4]) = t;
             } else {
                 const float4 t = fix4(vb[q], edge_of(r0 + dr_r + 8 * q, r_end, (int64_t)n0 + dr_c4 * 4, g.N));
                 *reinterpret_cast<float4*>(&Bs[(dr_r + 8 * q) * LDB + dr_c4 * 4]) = t;
@@ -182,8 +198,8 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
     const bool do_colsum = (EPI == EPI_ATOMIC) && g.colsum_dst != nullptr && m0 == 0 && tid < BN;
 
     load_tiles(r_begin);
-    const float* as = As + (lane >> 5) * LDA + wm * 64 + (lane & 31);
-    const float* bs = Bs + (lane >> 5) * LDB + wn * 64 + (lane & 31);
+    const float* as = As + (lane >> 5) * LDA + wm * (TM * 32) + (lane & 31);
+    const float* bs = Bs + (lane >> 5) * LDB + wn * (TN * 32) + (lane & 31);
     for (int64_t r0 = r_begin; r0 < r_end; r0 += BK) {
         store_tiles(r0);
         __syncthreads();
@@ -192,27 +208,25 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
 #pragma unroll 8
             for (int r = 0; r < BK; ++r) colsum += Bs[r * LDB + tid];
         }
-        // software-pipelined fragment reads: the k-step kk+2 fragments are in flight under the kk MFMAs
-        float a0 = as[0], a1 = as[32], b0 = bs[0], b1 = bs[32];
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
-            if (kk + 2 < BK) {
-                na0 = as[(kk + 2) * LDA]; na1 = as[(kk + 2) * LDA + 32];
-                nb0 = bs[(kk + 2) * LDB]; nb1 = bs[(kk + 2) * LDB + 32];
-            }
-            if (PIN) __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ABOVE the MFMAs (hipcc sinks it otherwise)
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) af[t] = as[kk * LDA + 32 * t];
+#pragma unroll
+            for (int t = 0; t < TN; ++t) bf[t] = bs[kk * LDB + 32 * t];
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
         }
         __syncthreads();
     }
 
-    if (EPI == EPI_LSE || EPI == EPI_SMGRAD) {
+    if constexpr ((EPI == EPI_LSE || EPI == EPI_SMGRAD) && !NARROW) {
         constexpr float MIN_FLOAT = -3.4028234663852886e36f;   // np.finfo(np.float32).min / 100 (sbcnm.py:10)
+        static_assert(!((EPI == EPI_LSE || EPI == EPI_SMGRAD) && NARROW), "softmax epilogues use the wide tile");
         float colcorr[2];
         int64_t colid[2];
         int colj[2];
@@ -276,16 +290,16 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const bool full = (m0 + BM <= g.M) && (n0 + BN <= g.N);
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int col = n0 + wn * 64 + ni * 32 + (lane & 31);
+        for (int ni = 0; ni < TN; ++ni) {
+            const int col = n0 + wn * (TN * 32) + ni * 32 + (lane & 31);
             if (!full && col >= g.N) continue;
             float bj = 0.f;
             if ((EPI == EPI_BIAS_ACT || EPI == EPI_CROSS) && g.bias != nullptr) bj = g.bias[col];
             int cmod = 0;
             if (EPI == EPI_FMGRAD) cmod = col % g.fm_D;
-            const int64_t row_b = m0 + wm * 64 + mi * 32 + 4 * (lane >> 5);
+            const int64_t row_b = m0 + wm * (TM * 32) + mi * 32 + 4 * (lane >> 5);
             float* cp = g.C + row_b * g.ldc + col;
             const float* e0p = (EPI == EPI_CROSS || EPI == EPI_MASK || EPI == EPI_FMGRAD) && g.e0 != nullptr
                                    ? g.e0 + row_b * g.lde0 + col : nullptr;
@@ -331,14 +345,18 @@ template <bool A_RC, bool B_RC, int EPI>
 int launch(GemmArgs& g, hipStream_t s) {
     g.a_vec = ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0 && (g.lda & 3) == 0) ? 1 : 0;
     g.b_vec = ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0 && (g.ldb & 3) == 0) ? 1 : 0;
-    const int tiles_n = (g.N + BN - 1) / BN;
+    const bool narrow = g.N <= 32 && (EPI == EPI_BIAS_ACT || EPI == EPI_MASK || EPI == EPI_ATOMIC);
+    const int bn = narrow ? 32 : BN;
+    const int tiles_n = (g.N + bn - 1) / bn;
     const int64_t tiles_m = (g.M + BM - 1) / BM;
     if (tiles_m * tiles_n > 0x7fffffff) return DR_EINVAL;
     dim3 grid((unsigned)(tiles_m * tiles_n), EPI == EPI_ATOMIC ? g.split : 1);
-    if (g_variant & 1)
+    if (narrow) {
+        if constexpr (EPI == EPI_BIAS_ACT || EPI == EPI_MASK || EPI == EPI_ATOMIC)
+            hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_RC, B_RC, EPI, true>), grid, dim3(256), 0, s, g);
+    } else {
         hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_RC, B_RC, EPI, false>), grid, dim3(256), 0, s, g);
-    else
-        hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_RC, B_RC, EPI, true>), grid, dim3(256), 0, s, g);
+    }
     DR_CHECK_LAUNCH();
     return DR_OK;
 }
@@ -436,35 +454,54 @@ __global__ __launch_bounds__(256) void skinny_dx_kernel(const float* __restrict_
 }
 // dst[k][n] += scale * sum_m x[m][k] dy[m][n] ; dstb[n] += scale * sum_m dy[m][n].  A block owns a slab of rows and
 // all (k, n) pairs (strided over its threads), accumulates in registers, then one atomic per (k, n) per block.
-constexpr int SK_ROWS = 256;
+constexpr int SK_ROWS = 1024;
 __global__ __launch_bounds__(256) void skinny_dw_kernel(const float* __restrict__ x, int64_t ldx,
                                                         const float* __restrict__ dy, int64_t lddy, int64_t M, int32_t K,
                                                         int32_t N, float scale, float* __restrict__ dst, int64_t ldw,
                                                         float* __restrict__ dstb) {
+    __shared__ float sm[256];
     const int64_t m0 = (int64_t)blockIdx.x * SK_ROWS;
     const int64_t m1 = m0 + SK_ROWS < M ? m0 + SK_ROWS : M;
     const int KN = K * N;
     const int lanes_e = KN < 256 ? KN : 256;     // threads along the (k, n) pairs; the rest split the rows
     const int R = 256 / lanes_e;
     const int e0 = threadIdx.x % lanes_e, rl = threadIdx.x / lanes_e;
-    if (rl < R) {
-        for (int e = e0; e < KN; e += lanes_e) {
+    // the same-address atomics of different blocks serialise (~88 per us): combine the row-lanes in LDS first,
+    // then ONE atomic per (k, n) per block
+    for (int eb = 0; eb < KN; eb += lanes_e) {
+        const int e = eb + e0;
+        float acc = 0.f;
+        if (e < KN && rl < R) {
             const int k = e / N, n = e - k * N;
-            float acc = 0.f;
             for (int64_t m = m0 + rl; m < m1; m += R) acc = fmaf(x[m * ldx + k], dy[m * lddy + n], acc);
-            unsafeAtomicAdd(dst + (int64_t)k * ldw + n, scale * acc);
         }
+        sm[threadIdx.x] = acc;
+        __syncthreads();
+        if (rl == 0 && e < KN) {
+            float t = 0.f;
+            for (int r = 0; r < R; ++r) t += sm[e0 + r * lanes_e];
+            const int k = e / N, n = e - k * N;
+            unsafeAtomicAdd(dst + (int64_t)k * ldw + n, scale * t);
+        }
+        __syncthreads();
     }
     if (dstb != nullptr) {
         const int ln = N < 256 ? N : 256;
         const int Rb = 256 / ln;
         const int n0 = threadIdx.x % ln, rb = threadIdx.x / ln;
-        if (rb < Rb) {
-            for (int n = n0; n < N; n += ln) {
-                float acc = 0.f;
+        for (int nb = 0; nb < N; nb += ln) {
+            const int n = nb + n0;
+            float acc = 0.f;
+            if (n < N && rb < Rb)
                 for (int64_t m = m0 + rb; m < m1; m += Rb) acc += dy[m * lddy + n];
-                unsafeAtomicAdd(dstb + n, scale * acc);
+            sm[threadIdx.x] = acc;
+            __syncthreads();
+            if (rb == 0 && n < N) {
+                float t = 0.f;
+                for (int r = 0; r < Rb; ++r) t += sm[n0 + r * ln];
+                unsafeAtomicAdd(dstb + n, scale * t);
             }
+            __syncthreads();
         }
     }
 }
@@ -533,7 +570,8 @@ extern "C" int dr_linear_bwd_dx_fm(const float* dy, int64_t ld_dy, const float* 
 }
 
 static int dw_split(int64_t M, int32_t K, int32_t N) {
-    const int64_t tiles = ((int64_t)(K + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const int bn = N <= 32 ? 32 : BN;
+    const int64_t tiles = ((int64_t)(K + BM - 1) / BM) * ((N + bn - 1) / bn);
     const int64_t target = (g_variant & 2) ? 1024 : 512;
     int64_t split = (target + tiles - 1) / tiles;
     const int64_t max_split = (M + 8 * BK - 1) / (8 * BK);     // at least 8 k-tiles per block
