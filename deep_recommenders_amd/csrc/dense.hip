@@ -106,7 +106,7 @@ __device__ __forceinline__ float4 fix4(f4u v, EdgeFix e) {
     return o;
 }
 
-template <bool A_RC, bool B_RC, int EPI, bool NARROW>
+template <bool A_RC, bool B_RC, int EPI, bool NARROW, bool PF2>
 __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
     // wide: 2 x 2 waves, each 2 x 2 MFMA tiles (128 x 128);  narrow: 4 x 1 waves, each 1 x 1 tile (128 x 32)
     constexpr int BN = NARROW ? 32 : 128;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
     const int dr_r = tid >> 5, dr_c4 = tid & 31;
     const int nb_r = tid >> 3, nb_c4 = tid & 7;
     f4u va[4], vb[NQB];
-    auto load_tiles = [&](int64_t r0) {
+    auto load_tiles = [&](f4u (&va)[4], f4u (&vb)[NQB], int64_t r0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (A_RC) va[q] = ld4_raw(g.A, g.lda, m0 + rc_i + 32 * q, g.M, r0 + rc_r4 * 4, r_end);
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
             else      vb[q] = ld4_raw(g.B, g.ldb, r0 + dr_r + 8 * q, r_end, (int64_t)n0 + dr_c4 * 4, g.N);
         }
     };
-    auto store_tiles = [&](int64_t r0) {     // r0 = reduction offset the registers were loaded for
+    auto store_tiles = [&](const f4u (&va)[4], const f4u (&vb)[NQB], int64_t r0) {     // r0 = offset the set was loaded for
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (A_RC) {
@@ -197,13 +197,9 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
     float colsum = 0.f;   // EPI_ATOMIC: column sums of B (dy) accumulated by the m-tile-0 blocks
     const bool do_colsum = (EPI == EPI_ATOMIC) && g.colsum_dst != nullptr && m0 == 0 && tid < BN;
 
-    load_tiles(r_begin);
     const float* as = As + (lane >> 5) * LDA + wm * (TM * 32) + (lane & 31);
     const float* bs = Bs + (lane >> 5) * LDB + wn * (TN * 32) + (lane & 31);
-    for (int64_t r0 = r_begin; r0 < r_end; r0 += BK) {
-        store_tiles(r0);
-        __syncthreads();
-        if (r0 + BK < r_end) load_tiles(r0 + BK);
+    auto mfma_block = [&]() {
         if (do_colsum) {
 #pragma unroll 8
             for (int r = 0; r < BK; ++r) colsum += Bs[r * LDB + tid];
@@ -221,7 +217,82 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
                 for (int b = 0; b < TN; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
         }
+    };
+    // ---- lean path for interior blocks: raw pointer-bumped dwordx4 loads, direct LDS stores, no edge logic.
+    // (PMC, tools/exp/gemm_only.py: the clamped loader + fix-up costs ~600 SALU/VALU instructions per wave per k-tile,
+    // as long as the 64-MFMA block itself; the lean loop issues ~60.)
+    const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);
+    const int64_t nfull = (r_end - r_begin) / BK;             // whole k-tiles
+    const bool has_tail = r_begin + nfull * BK < r_end;
+    if (interior && nfull > 0) {
+        const float* pa = A_RC ? g.A + (m0 + rc_i) * g.lda + r_begin + rc_r4 * 4
+                               : g.A + (r_begin + dr_r) * g.lda + m0 + dr_c4 * 4;
+        const float* pb = B_RC ? g.B + ((int64_t)n0 + rc_i) * g.ldb + r_begin + rc_r4 * 4
+                               : (NARROW ? g.B + (r_begin + nb_r) * g.ldb + n0 + nb_c4 * 4
+                                         : g.B + (r_begin + dr_r) * g.ldb + n0 + dr_c4 * 4);
+        const int64_t a_q = A_RC ? 32 * g.lda : 8 * g.lda;
+        const int64_t b_q = B_RC ? 32 * g.ldb : 8 * g.ldb;
+        const int64_t a_it = A_RC ? (int64_t)BK : BK * g.lda;
+        const int64_t b_it = B_RC ? (int64_t)BK : BK * g.ldb;
+        auto load_fast = [&]() {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) va[q] = *reinterpret_cast<const f4u*>(pa + q * a_q);
+#pragma unroll
+            for (int q = 0; q < NQB; ++q) vb[q] = *reinterpret_cast<const f4u*>(pb + q * b_q);
+            pa += a_it;
+            pb += b_it;
+        };
+        auto store_fast = [&]() {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (A_RC) {
+                    float* d = As + (rc_r4 * 4) * LDA + rc_i + 32 * q;
+                    d[0] = va[q].x; d[LDA] = va[q].y; d[2 * LDA] = va[q].z; d[3 * LDA] = va[q].w;
+                } else {
+                    *reinterpret_cast<f4u*>(&As[(dr_r + 8 * q) * LDA + dr_c4 * 4]) = va[q];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NQB; ++q) {
+                if (B_RC) {
+                    float* d = Bs + (rc_r4 * 4) * LDB + rc_i + 32 * q;
+                    d[0] = vb[q].x; d[LDB] = vb[q].y; d[2 * LDB] = vb[q].z; d[3 * LDB] = vb[q].w;
+                } else if (NARROW) {
+                    *reinterpret_cast<f4u*>(&Bs[nb_r * LDB + nb_c4 * 4]) = vb[q];
+                } else {
+                    *reinterpret_cast<f4u*>(&Bs[(dr_r + 8 * q) * LDB + dr_c4 * 4]) = vb[q];
+                }
+            }
+        };
+        load_fast();
+        for (int64_t t = 0; t + 1 < nfull; ++t) {
+            store_fast();
+            __syncthreads();
+            load_fast();
+            mfma_block();
+            __syncthreads();
+        }
+        // last whole tile (+ the clamped tail tile, if any), straight-line
+        store_fast();
         __syncthreads();
+        if (has_tail) load_tiles(va, vb, r_begin + nfull * BK);
+        mfma_block();
+        __syncthreads();
+        if (has_tail) {
+            store_tiles(va, vb, r_begin + nfull * BK);
+            __syncthreads();
+            mfma_block();
+            __syncthreads();
+        }
+    } else {
+        load_tiles(va, vb, r_begin);
+        for (int64_t r0 = r_begin; r0 < r_end; r0 += BK) {
+            store_tiles(va, vb, r0);
+            __syncthreads();
+            if (r0 + BK < r_end) load_tiles(va, vb, r0 + BK);
+            mfma_block();
+            __syncthreads();
+        }
     }
 
     if constexpr ((EPI == EPI_LSE || EPI == EPI_SMGRAD) && !NARROW) {
@@ -339,7 +410,8 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
     if (do_colsum && n0 + tid < g.N) unsafeAtomicAdd(g.colsum_dst + n0 + tid, g.alpha * colsum);
 }
 
-static int g_variant = 3;   // A/B switch (measured, tools/exp/ab_gemm.py): bit0 = unpinned prefetch, bit1 = dW split target 1024 (both faster)
+static int g_variant = 2;   // A/B switch (tools/exp/ab_gemm.py): bit1 = dW split target 1024 (faster). A two-tile-deep
+                            // register prefetch was measured neutral (not load-latency bound) and removed.
 
 template <bool A_RC, bool B_RC, int EPI>
 int launch(GemmArgs& g, hipStream_t s) {
@@ -353,9 +425,9 @@ int launch(GemmArgs& g, hipStream_t s) {
     dim3 grid((unsigned)(tiles_m * tiles_n), EPI == EPI_ATOMIC ? g.split : 1);
     if (narrow) {
         if constexpr (EPI == EPI_BIAS_ACT || EPI == EPI_MASK || EPI == EPI_ATOMIC)
-            hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_RC, B_RC, EPI, true>), grid, dim3(256), 0, s, g);
+            hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_RC, B_RC, EPI, true, false>), grid, dim3(256), 0, s, g);
     } else {
-        hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_RC, B_RC, EPI, false>), grid, dim3(256), 0, s, g);
+        hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_RC, B_RC, EPI, false, false>), grid, dim3(256), 0, s, g);
     }
     DR_CHECK_LAUNCH();
     return DR_OK;

@@ -40,8 +40,7 @@ for (K, N) in [(1677, 256), (1677, 1677), (1677, 1024)]:
     for rnd in range(3):
         res = {}
         for name, L in (("old", old), ("new", new)):
-            if name == "new":
-                new.dr_debug_set_gemm_variant(3)
+            new.dr_debug_set_gemm_variant(2)
             tf = timeit(lambda: L.dr_linear_fwd(x.data_ptr(), ldx, W.data_ptr(), N, b.data_ptr(), M, K, N, 1, y.data_ptr(), ldn, st))
             td = timeit(lambda: L.dr_linear_bwd_dx(dy.data_ptr(), ldn, W.data_ptr(), N, M, K, N, x.data_ptr(), ldx, 0, dx.data_ptr(), ldx, st))
             if name == "old":
@@ -50,5 +49,5 @@ for (K, N) in [(1677, 256), (1677, 1677), (1677, 1024)]:
                 tw = timeit(lambda: L.dr_linear_bwd_dw(x.data_ptr(), ldx, dy.data_ptr(), ldn, M, K, N, 1e-6, dW.data_ptr(), N, b.data_ptr(), None, 0, st))
             res[name] = (fl / tf / 1e12, fl / td / 1e12, fl / tw / 1e12)
         tt = timeit(lambda: torch.relu(torch.addmm(b, x[:, :K], W)))
-        print("ABOLD %dx%d round %d  old fwd/dx/dw %.1f %.1f %.1f | new %.1f %.1f %.1f | rocblas fwd %.1f" % (
+        print("ABOLD %dx%d round %d  first-kernel fwd/dx/dw %.1f %.1f %.1f | current %.1f %.1f %.1f | rocblas fwd %.1f" % (
             K, N, rnd, *res["old"], *res["new"], fl / tt / 1e12))
