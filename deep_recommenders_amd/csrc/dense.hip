@@ -221,26 +221,55 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
     // ---- lean path for interior blocks: raw pointer-bumped dwordx4 loads, direct LDS stores, no edge logic.
     // (PMC, tools/exp/gemm_only.py: the clamped loader + fix-up costs ~600 SALU/VALU instructions per wave per k-tile,
     // as long as the 64-MFMA block itself; the lean loop issues ~60.)
-    const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);
+    // Row / column edges of the OUTPUT tile need no masking here: an operand row (RC) or column (reduction-major)
+    // that lies outside the matrix only feeds accumulator rows / columns the epilogue never stores, so its address is
+    // simply clamped into the matrix (computed once, outside the loop).  Only the reduction tail needs zero fill.
     const int64_t nfull = (r_end - r_begin) / BK;             // whole k-tiles
     const bool has_tail = r_begin + nfull * BK < r_end;
-    if (interior && nfull > 0) {
-        const float* pa = A_RC ? g.A + (m0 + rc_i) * g.lda + r_begin + rc_r4 * 4
-                               : g.A + (r_begin + dr_r) * g.lda + m0 + dr_c4 * 4;
-        const float* pb = B_RC ? g.B + ((int64_t)n0 + rc_i) * g.ldb + r_begin + rc_r4 * 4
-                               : (NARROW ? g.B + (r_begin + nb_r) * g.ldb + n0 + nb_c4 * 4
-                                         : g.B + (r_begin + dr_r) * g.ldb + n0 + dr_c4 * 4);
-        const int64_t a_q = A_RC ? 32 * g.lda : 8 * g.lda;
-        const int64_t b_q = B_RC ? 32 * g.ldb : 8 * g.ldb;
+    // a float4 that straddles the last column of a reduction-major operand is loaded unshifted, which is only legal
+    // when the row pitch covers it (padded buffers); a tight pitch sends that edge block down the clamped slow path
+    const bool a_tight = !A_RC && (m0 + BM > g.M) && (g.M & 3) && g.lda < ((g.M + 3) & ~(int64_t)3);
+    const bool b_tight = !B_RC && (n0 + BN > g.N) && (g.N & 3) && g.ldb < (((int64_t)g.N + 3) & ~(int64_t)3);
+    if (nfull > 0 && !a_tight && !b_tight) {
+        const float* pa[4];
+        const float* pb[NQB];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (A_RC) {
+                int64_t row = m0 + rc_i + 32 * q;
+                row = row < g.M ? row : g.M - 1;
+                pa[q] = g.A + row * g.lda + r_begin + rc_r4 * 4;
+            } else {
+                int64_t col = m0 + dr_c4 * 4;
+                col = col < g.M ? col : g.M - 4;             // fully outside -> anywhere legal; straddling -> unshifted
+                pa[q] = g.A + (r_begin + dr_r + 8 * q) * g.lda + col;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NQB; ++q) {
+            if (B_RC) {
+                int64_t row = (int64_t)n0 + rc_i + 32 * q;
+                row = row < g.N ? row : g.N - 1;
+                pb[q] = g.B + row * g.ldb + r_begin + rc_r4 * 4;
+            } else {
+                int64_t col = (int64_t)n0 + (NARROW ? nb_c4 : dr_c4) * 4;
+                col = col < g.N ? col : g.N - 4;
+                pb[q] = g.B + (r_begin + (NARROW ? nb_r : dr_r + 8 * q)) * g.ldb + col;
+            }
+        }
         const int64_t a_it = A_RC ? (int64_t)BK : BK * g.lda;
         const int64_t b_it = B_RC ? (int64_t)BK : BK * g.ldb;
         auto load_fast = [&]() {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) va[q] = *reinterpret_cast<const f4u*>(pa + q * a_q);
+            for (int q = 0; q < 4; ++q) {
+                va[q] = *reinterpret_cast<const f4u*>(pa[q]);
+                pa[q] += a_it;
+            }
 #pragma unroll
-            for (int q = 0; q < NQB; ++q) vb[q] = *reinterpret_cast<const f4u*>(pb + q * b_q);
-            pa += a_it;
-            pb += b_it;
+            for (int q = 0; q < NQB; ++q) {
+                vb[q] = *reinterpret_cast<const f4u*>(pb[q]);
+                pb[q] += b_it;
+            }
         };
         auto store_fast = [&]() {
 #pragma unroll
@@ -644,8 +673,8 @@ extern "C" int dr_linear_bwd_dx_fm(const float* dy, int64_t ld_dy, const float* 
 static int dw_split(int64_t M, int32_t K, int32_t N) {
     const int bn = N <= 32 ? 32 : BN;
     const int64_t tiles = ((int64_t)(K + BM - 1) / BM) * ((N + bn - 1) / bn);
-    const int64_t target = (g_variant & 2) ? 1024 : 512;
-    int64_t split = (target + tiles - 1) / tiles;
+    const int64_t target = (g_variant & 2) ? 768 : 1024;      // 768 = 256 CUs x 3 resident blocks: one wave of blocks
+    int64_t split = target / tiles;
     const int64_t max_split = (M + 8 * BK - 1) / (8 * BK);     // at least 8 k-tiles per block
     if (split > max_split) split = max_split;
     if (split < 1) split = 1;
