@@ -107,7 +107,7 @@ __device__ __forceinline__ float4 fix4(f4u v, EdgeFix e) {
 }
 
 template <bool A_RC, bool B_RC, int EPI, bool NARROW, bool PF2>
-__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, 4) void gemm_f32_mfma_kernel(GemmArgs g) {
     // wide: 2 x 2 waves, each 2 x 2 MFMA tiles (128 x 128);  narrow: 4 x 1 waves, each 1 x 1 tile (128 x 32)
     constexpr int BN = NARROW ? 32 : 128;
     constexpr int TM = NARROW ? 1 : 2, TN = NARROW ? 1 : 2;
