@@ -161,6 +161,21 @@ def main():
     value = a.batch * world * a.steps / dt
 
     kernels = eng.kernel_event_summary() if prof is not None else {}
+    # HBM traffic per launch from the PMC counters (collected in separate rocprofv3 --pmc passes of this same command,
+    # corrected as MI355X_MICROARCH.md prescribes; committed under profiles/): event name -> profiled kernel name
+    traffic = {}
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+        name_map = {"emb_pool_fwd": "emb_pool_fwd_sv_kernel<16,8>", "emb_pool_bwd": "emb_bwd_unique_kernel<16,4>",
+                    "hash_bucket_i64": "hash_bucket_i64_kernel",
+                    "linear_fwd_L0": "gemm_f32_mfma_kernel<true,false,0,false,false>",
+                    "linear_bwd_dx_L0": "gemm_f32_mfma_kernel<true,true,2,false,false>",
+                    "linear_bwd_dw_L0": "gemm_f32_mfma_kernel<false,false,3,false,false>"}
+        default_cfg = (a.batch, a.fields, a.vocab, a.dim, a.dense, a.dnn) == (65536, 26, 10_000_000, 64, 13, "256,32")
+        if default_cfg and world == 1:
+            traffic = {ev: int(pmc[k]["hbm_bytes_corrected"]) for ev, k in name_map.items() if k in pmc}
+    except Exception:
+        traffic = {}
     roof_all = []
     for name, k in kernels.items():
         sec = k["ms"] * 1e-3
@@ -169,7 +184,7 @@ def main():
         else:
             ach, peak, unit = k["alg_flops"] / sec / 1e12, MFMA_F32_PEAK_TF, "TFLOP/s"
         roof_all.append({"kernel": name, "bound": k["bound"], "achieved": round(ach, 2), "peak": peak, "unit": unit,
-                         "frac": round(ach / peak, 4), "traffic": None, "avg_us": round(k["ms"] * 1e3, 2),
+                         "frac": round(ach / peak, 4), "traffic": traffic.get(name), "avg_us": round(k["ms"] * 1e3, 2),
                          "launches": k["n"]})
     roof_all.sort(key=lambda r: -r["avg_us"])
     roofline = dict(roof_all[0]) if roof_all else None

@@ -32,14 +32,22 @@ __global__ __launch_bounds__(256) void make_sort_keys_kernel(const int64_t* __re
 }
 
 // flag[p] = 1 iff slot p is the only slot of the batch that touches its row (valid id, no duplicate)
+// Also compacts the work list of the duplicate pass: every sorted position that heads a piece of a row touched by
+// >= 2 slots (the segment start, plus each CH-aligned position >= CH past it) is appended to dup_heads.
 __global__ __launch_bounds__(256) void mark_unique_kernel(const uint64_t* __restrict__ rows,
                                                           const int32_t* __restrict__ slots, int64_t n,
-                                                          uint64_t num_rows, uint8_t* __restrict__ flags) {
+                                                          uint64_t num_rows, uint8_t* __restrict__ flags,
+                                                          int32_t* __restrict__ dup_heads, int32_t* __restrict__ dup_count) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint64_t k = rows[i];
-        const bool uniq = k < num_rows && (i == 0 || rows[i - 1] != k) && (i + 1 >= n || rows[i + 1] != k);
-        flags[slots[i]] = uniq ? 1 : 0;
+        const bool valid = k < num_rows;
+        const bool seg_start = (i == 0) || (rows[i - 1] != k);
+        const bool has_next = (i + 1 < n) && (rows[i + 1] == k);
+        flags[slots[i]] = (valid && seg_start && !has_next) ? 1 : 0;
+        const bool head = valid && ((seg_start && has_next) ||
+                                    (!seg_start && (i % CH) == 0 && i >= CH && rows[i - CH] == k));
+        if (head) dup_heads[atomicAdd(dup_count, 1)] = (int32_t)i;
     }
 }
 
@@ -121,7 +129,9 @@ __global__ __launch_bounds__(256) void emb_bwd_unique_kernel(const int64_t* __re
 // CH-aligned positions that lie >= CH past its start, those pieces combine with fp32 atomics.
 template <int LPR>
 __global__ __launch_bounds__(256) void emb_bwd_dups_kernel(const uint64_t* __restrict__ rows,
-                                                           const int32_t* __restrict__ slots, int64_t n, int32_t F,
+                                                           const int32_t* __restrict__ slots, int64_t n,
+                                                           const int32_t* __restrict__ dup_heads,
+                                                           const int32_t* __restrict__ dup_count, int32_t F,
                                                            int32_t D, uint64_t num_rows,
                                                            const float* __restrict__ grad, int64_t ld,
                                                            const float* __restrict__ concat, int64_t ldc,
@@ -134,21 +144,15 @@ __global__ __launch_bounds__(256) void emb_bwd_dups_kernel(const uint64_t* __res
     const bool fm = concat != nullptr && sum_x != nullptr && d_fm_logit != nullptr;
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    for (int64_t i0 = wave0 * NS; i0 < n; i0 += nwaves * NS) {
-        const int64_t i = i0 + slot;
-        if (i >= n) continue;
+    const int64_t nheads = dup_count[0];
+    for (int64_t h0 = wave0 * NS; h0 < nheads; h0 += nwaves * NS) {
+        const int64_t h = h0 + slot;
+        if (h >= nheads) continue;
+        const int64_t i = dup_heads[h];
         const uint64_t k = rows[i];
-        if (k >= num_rows) continue;                                      // missing id
         const bool seg_start = (i == 0) || (rows[i - 1] != k);
-        int64_t stop;                                                     // exclusive end of this group's piece
-        if (seg_start) {
-            if (i + 1 >= n || rows[i + 1] != k) continue;                 // unique row: done by the fast path
-            stop = ((i + CH - 1) / CH + 1) * CH;                          // first aligned position >= i + CH
-            if (i % CH == 0) stop = i + CH;
-        } else {
-            if ((i % CH) != 0 || i < CH || rows[i - CH] != k) continue;   // aligned AND >= CH past the segment start
-            stop = i + CH;
-        }
+        // piece owned by this head: the segment start runs to the first aligned position >= i + CH, aligned heads run CH
+        int64_t stop = seg_start ? (((i % CH) == 0) ? i + CH : ((i + CH - 1) / CH + 1) * CH) : i + CH;
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         float dls = 0.f;
         int64_t j = i;
@@ -212,13 +216,14 @@ extern "C" int64_t dr_emb_sort_workspace_bytes(int64_t n) {
 }
 
 extern "C" int dr_emb_sort_slots(const int64_t* ids, int64_t B, int32_t F, const int64_t* row_base, int64_t num_rows,
-                                 int64_t* sorted_rows, int32_t* sorted_slots, uint8_t* unique_flags, void* workspace,
-                                 int64_t workspace_bytes, dr_stream_t stream) {
+                                 int64_t* sorted_rows, int32_t* sorted_slots, uint8_t* unique_flags, int32_t* dup_heads,
+                                 int32_t* dup_count, void* workspace, int64_t workspace_bytes, dr_stream_t stream) {
     if (B < 0 || F <= 0 || num_rows <= 0) return DR_EINVAL;
     const int64_t n = B * F;
     if (n == 0) return DR_OK;
     if (n > 0x7fffffff) return DR_EINVAL;
-    if (!ids || !row_base || !sorted_rows || !sorted_slots || !unique_flags || !workspace) return DR_EINVAL;
+    if (!ids || !row_base || !sorted_rows || !sorted_slots || !unique_flags || !dup_heads || !dup_count || !workspace)
+        return DR_EINVAL;
     if (workspace_bytes < dr_emb_sort_workspace_bytes(n)) return DR_EINVAL;
     char* w = static_cast<char*>(workspace);
     uint64_t* keys_in = reinterpret_cast<uint64_t*>(w);
@@ -231,14 +236,17 @@ extern "C" int dr_emb_sort_slots(const int64_t* ids, int64_t B, int32_t F, const
     hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, reinterpret_cast<uint64_t*>(sorted_rows), vals_in,
                                              sorted_slots, (size_t)n, 0u, end_bit, dr_s(stream));
     if (e != hipSuccess) return DR_ELAUNCH;
+    if (hipMemsetAsync(dup_count, 0, sizeof(int32_t), dr_s(stream)) != hipSuccess) return DR_ELAUNCH;
     hipLaunchKernelGGL(mark_unique_kernel, dim3(dr_grid_for(n, 256)), dim3(256), 0, dr_s(stream),
-                       reinterpret_cast<const uint64_t*>(sorted_rows), sorted_slots, n, (uint64_t)num_rows, unique_flags);
+                       reinterpret_cast<const uint64_t*>(sorted_rows), sorted_slots, n, (uint64_t)num_rows, unique_flags,
+                       dup_heads, dup_count);
     DR_CHECK_LAUNCH();
     return DR_OK;
 }
 
 extern "C" int dr_emb_pool_bwd_sorted(const int64_t* ids, const int64_t* row_base, const int64_t* sorted_rows,
-                                      const int32_t* sorted_slots, const uint8_t* unique_flags, int64_t B, int32_t F,
+                                      const int32_t* sorted_slots, const uint8_t* unique_flags,
+                                      const int32_t* dup_heads, const int32_t* dup_count, int64_t B, int32_t F,
                                       int32_t D, int64_t num_rows, const float* grad, int64_t ld_grad,
                                       const float* concat, int64_t ld_concat, const float* sum_x,
                                       const float* d_fm_logit, float scale, float* dst_table, float* dst_lin,
@@ -246,7 +254,8 @@ extern "C" int dr_emb_pool_bwd_sorted(const int64_t* ids, const int64_t* row_bas
     if (B < 0 || F <= 0 || F > 64 || D < 4 || D > 256 || (D & 3) || num_rows <= 0) return DR_EINVAL;
     const int64_t n = B * F;
     if (n == 0) return DR_OK;
-    if (!ids || !row_base || !sorted_rows || !sorted_slots || !unique_flags || !grad || !dst_table ||
+    if (!ids || !row_base || !sorted_rows || !sorted_slots || !unique_flags || !dup_heads || !dup_count || !grad ||
+        !dst_table ||
         ld_grad < (int64_t)F * D || (ld_grad & 3))
         return DR_EINVAL;
     if (concat != nullptr && (ld_concat < (int64_t)F * D || (ld_concat & 3) || sum_x == nullptr)) return DR_EINVAL;
@@ -254,7 +263,7 @@ extern "C" int dr_emb_pool_bwd_sorted(const int64_t* ids, const int64_t* row_bas
     while (lpr * 4 < D) lpr <<= 1;
     const uint64_t* rows = reinterpret_cast<const uint64_t*>(sorted_rows);
     const int grid_u = dr_grid_for(B, 4, 8192);
-    const int grid_d = dr_grid_for(n, 4 * (64 / lpr), 4096);
+    const int grid_d = 256;     // the duplicate work list is short; its length lives on the device
 #define CALL(L)                                                                                                       \
     {                                                                                                                 \
         constexpr int NS_ = 64 / L;                                                                                   \
@@ -263,7 +272,7 @@ extern "C" int dr_emb_pool_bwd_sorted(const int64_t* ids, const int64_t* row_bas
                            B, F, row_base, D, grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit, scale, dst_table, dst_lin,   \
                            dst_bias);                                                                                 \
         hipLaunchKernelGGL((emb_bwd_dups_kernel<L>), dim3(grid_d), dim3(256), 0, dr_s(stream), rows, sorted_slots, n, \
-                           F, D, (uint64_t)num_rows, grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit, scale, dst_table,   \
+                           dup_heads, dup_count, F, D, (uint64_t)num_rows, grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit, scale, dst_table,   \
                            dst_lin);                                                                                  \
     }
     switch (lpr) {

@@ -79,10 +79,7 @@ class DeepFMEngine:
         self.fold_fm = _os.environ.get("DR_FOLD_FM", "0") == "1"
         if sorted_bwd:
             n = B * F
-            self.sorted_rows = torch.empty(n, dtype=torch.int64, device=device)
-            self.sorted_slots = torch.empty(n, dtype=torch.int32, device=device)
-            self.uniq_flags = torch.empty(n, dtype=torch.uint8, device=device)
-            self.sort_ws = ops.emb_sort_workspace(n, device)
+            self.plan = ops.SortPlan(n, device)
             self.side = torch.cuda.Stream(device=device)
             self.ev_ids = torch.cuda.Event()
             self.ev_sorted = torch.cuda.Event()
@@ -119,16 +116,14 @@ class DeepFMEngine:
                 lambda: ops.hash_bucket_i64(keys, self.col_buckets, out=self.ids))                    # K1
         if self.sorted_bwd and self.sort_inline:
             self._k("emb_sort_slots", "hbm", B * F * 36,
-                    lambda: ops.emb_sort_slots(self.ids, self.row_base, self.R, self.sorted_rows, self.sorted_slots,
-                                               self.uniq_flags, self.sort_ws))
+                    lambda: ops.emb_sort_slots(self.ids, self.row_base, self.R, self.plan))
             self.ev_sorted.record()
         elif self.sorted_bwd:
             self.ev_ids.record()
             with torch.cuda.stream(self.side):
                 self.side.wait_event(self.ev_ids)
                 self._k("emb_sort_slots", "hbm", B * F * 36,
-                        lambda: ops.emb_sort_slots(self.ids, self.row_base, self.R, self.sorted_rows, self.sorted_slots,
-                                                   self.uniq_flags, self.sort_ws))
+                        lambda: ops.emb_sort_slots(self.ids, self.row_base, self.R, self.plan))
                 self.ev_sorted.record(self.side)
         self._k("emb_pool_fwd", "hbm", self.alg_bytes_fwd(),                                          # K3+K5+K6
                 lambda: ops.emb_pool_fwd(self.ids, F, None, self.row_base, self.table, self.lin_w, self.lin_bias,
@@ -175,8 +170,7 @@ class DeepFMEngine:
         if self.sorted_bwd:
             torch.cuda.current_stream().wait_event(self.ev_sorted)
             self._k("emb_pool_bwd", "hbm", self.alg_bytes_bwd(),                                      # K4 (sorted)
-                    lambda: ops.emb_pool_bwd_sorted(self.ids, self.row_base, self.sorted_rows, self.sorted_slots,
-                                                    self.uniq_flags, D, self.R, self.d_concat, self.d_logit, -lr,
+                    lambda: ops.emb_pool_bwd_sorted(self.ids, self.row_base, self.plan, D, self.R, self.d_concat, self.d_logit, -lr,
                                                     self.table, self.lin_w, self.lin_bias,
                                                     concat=None if self.fold_fm else self.concat,
                                                     sum_x=None if self.fold_fm else self.sum_x))

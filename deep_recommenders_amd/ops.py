@@ -337,35 +337,39 @@ def emb_sort_workspace(n, device):
     return torch.empty(lib().dr_emb_sort_workspace_bytes(int(n)), dtype=torch.uint8, device=device)
 
 
-def emb_sort_slots(ids, row_base, num_rows, sorted_rows=None, sorted_slots=None, flags=None, workspace=None):
+class SortPlan:
+    """Per-batch outputs of dr_emb_sort_slots (all preallocated, reusable across steps)."""
+
+    def __init__(self, n, device):
+        self.rows = torch.empty(n, dtype=torch.int64, device=device)
+        self.slots = torch.empty(n, dtype=torch.int32, device=device)
+        self.flags = torch.empty(n, dtype=torch.uint8, device=device)
+        self.dup_heads = torch.empty(n, dtype=torch.int32, device=device)
+        self.dup_count = torch.zeros(1, dtype=torch.int32, device=device)
+        self.workspace = emb_sort_workspace(n, device)
+
+
+def emb_sort_slots(ids, row_base, num_rows, plan=None):
     ids = _c(ids, torch.int64)
     B, F = ids.shape
-    n = B * F
-    dev = ids.device
-    if sorted_rows is None:
-        sorted_rows = torch.empty(n, dtype=torch.int64, device=dev)
-    if sorted_slots is None:
-        sorted_slots = torch.empty(n, dtype=torch.int32, device=dev)
-    if flags is None:
-        flags = torch.empty(n, dtype=torch.uint8, device=dev)
-    if workspace is None:
-        workspace = emb_sort_workspace(n, dev)
-    check(lib().dr_emb_sort_slots(ptr(ids), B, F, ptr(row_base), int(num_rows), ptr(sorted_rows), ptr(sorted_slots),
-                                  ptr(flags), ptr(workspace), workspace.numel(), stream_ptr()), "dr_emb_sort_slots")
-    return sorted_rows, sorted_slots, flags
+    if plan is None:
+        plan = SortPlan(B * F, ids.device)
+    check(lib().dr_emb_sort_slots(ptr(ids), B, F, ptr(row_base), int(num_rows), ptr(plan.rows), ptr(plan.slots),
+                                  ptr(plan.flags), ptr(plan.dup_heads), ptr(plan.dup_count), ptr(plan.workspace),
+                                  plan.workspace.numel(), stream_ptr()), "dr_emb_sort_slots")
+    return plan
 
 
-def emb_pool_bwd_sorted(ids, row_base, sorted_rows, sorted_slots, flags, D, num_rows, grad, d_fm_logit, scale,
-                        dst_table, dst_lin=None, dst_bias=None, concat=None, sum_x=None):
+def emb_pool_bwd_sorted(ids, row_base, plan, D, num_rows, grad, d_fm_logit, scale, dst_table, dst_lin=None, dst_bias=None,
+                        concat=None, sum_x=None):
     ids = _c(ids, torch.int64)
     B, F = ids.shape
     assert grad.stride(1) == 1
-    check(lib().dr_emb_pool_bwd_sorted(ptr(ids), ptr(row_base), ptr(sorted_rows), ptr(sorted_slots), ptr(flags), B, F, D,
-                                       int(num_rows), ptr(grad), grad.stride(0), ptr(concat),
-                                       concat.stride(0) if concat is not None else 0, ptr(sum_x),
-                                       ptr(d_fm_logit), float(scale),
-                                       ptr(dst_table), ptr(dst_lin), ptr(dst_bias), stream_ptr()),
-          "dr_emb_pool_bwd_sorted")
+    check(lib().dr_emb_pool_bwd_sorted(ptr(ids), ptr(row_base), ptr(plan.rows), ptr(plan.slots), ptr(plan.flags),
+                                       ptr(plan.dup_heads), ptr(plan.dup_count), B, F, D, int(num_rows), ptr(grad),
+                                       grad.stride(0), ptr(concat), concat.stride(0) if concat is not None else 0,
+                                       ptr(sum_x), ptr(d_fm_logit), float(scale), ptr(dst_table), ptr(dst_lin), ptr(dst_bias),
+                                       stream_ptr()), "dr_emb_pool_bwd_sorted")
 
 
 def linear_bwd_dx_fm(dy, W, d_fm_logit, sum_x, concat, D, FD, out):

@@ -125,14 +125,18 @@ int dr_emb_pool_bwd(const int64_t* ids, int64_t B, int32_t F, int32_t C, const i
  * dr_emb_pool_bwd; pass NULL when `grad` already holds it, e.g. from dr_linear_bwd_dx_fm).  Rows hit by <= 32 slots are bit-reproducible; hotter rows are cut into
  * pieces that combine with fp32 atomics.
  * sorted_rows[n] int64 (missing ids carry num_rows and sort last), sorted_slots[n] int32 (slot = b*F + f),
- * unique_flags[n] uint8 (indexed by slot); workspace >= dr_emb_sort_workspace_bytes(n) bytes.
+ * unique_flags[n] uint8 (indexed by slot); dup_heads[n] int32 + dup_count[1] int32 = compact work list of the
+ * duplicate pass (sorted positions heading a piece of a multiply-hit row); workspace >=
+ * dr_emb_sort_workspace_bytes(n) bytes.
  * ---------------------------------------------------------------------------------------- */
 int64_t dr_emb_sort_workspace_bytes(int64_t n);
 int dr_emb_sort_slots(const int64_t* ids, int64_t B, int32_t F, const int64_t* row_base, int64_t num_rows,
-                      int64_t* sorted_rows, int32_t* sorted_slots, uint8_t* unique_flags, void* workspace,
-                      int64_t workspace_bytes, dr_stream_t stream);
+                      int64_t* sorted_rows, int32_t* sorted_slots, uint8_t* unique_flags,
+                      int32_t* dup_heads, int32_t* dup_count, void* workspace, int64_t workspace_bytes,
+                      dr_stream_t stream);
 int dr_emb_pool_bwd_sorted(const int64_t* ids, const int64_t* row_base, const int64_t* sorted_rows,
-                           const int32_t* sorted_slots, const uint8_t* unique_flags, int64_t B, int32_t F,
+                           const int32_t* sorted_slots, const uint8_t* unique_flags,
+                           const int32_t* dup_heads, const int32_t* dup_count, int64_t B, int32_t F,
                            int32_t D, int64_t num_rows, const float* grad, int64_t ld_grad,
                            const float* concat, int64_t ld_concat, const float* sum_x,
                            const float* d_fm_logit, float scale, float* dst_table, float* dst_lin,

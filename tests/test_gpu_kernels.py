@@ -335,7 +335,8 @@ def test_emb_bwd_sorted_matches_oracle_and_is_deterministic(ops, D, F, V, hot):
     table = rng.standard_normal((R, D)).astype(np.float32)
     lin = rng.standard_normal(R).astype(np.float32)
     d_ids, d_rb = _dev(ids), _dev(row_base)
-    srows, sslots, flags = ops.emb_sort_slots(d_ids, d_rb, R)
+    plan = ops.emb_sort_slots(d_ids, d_rb, R)
+    srows, sslots, flags = plan.rows, plan.slots, plan.flags
     # the sort itself: keys ascending, payload is a permutation, missing ids last
     sr, ss = srows.cpu().numpy(), sslots.cpu().numpy()
     keys = np.where(ids.reshape(-1) >= 0, (ids + row_base[None, :]).reshape(-1), R)
@@ -346,7 +347,7 @@ def test_emb_bwd_sorted_matches_oracle_and_is_deterministic(ops, D, F, V, hot):
     outs = []
     for _ in range(2):
         t_dev, l_dev, b_dev = _dev(table).clone(), _dev(lin).clone(), torch.zeros(1, device="cuda")
-        ops.emb_pool_bwd_sorted(d_ids, d_rb, srows, sslots, flags, D, R, _dev(grad), _dev(dl), -0.1, t_dev, l_dev, b_dev)
+        ops.emb_pool_bwd_sorted(d_ids, d_rb, plan, D, R, _dev(grad), _dev(dl), -0.1, t_dev, l_dev, b_dev)
         outs.append((t_dev.cpu().numpy(), l_dev.cpu().numpy(), b_dev.item()))
     want_t = table.astype(np.float64).copy()
     want_l = lin.astype(np.float64).copy()
@@ -398,9 +399,10 @@ def test_emb_bwd_sorted_with_fm_term_equals_atomic_kernel(ops):
     dl = _dev(rng.standard_normal(B).astype(np.float32))
     t1, l1, b1 = _dev(table).clone(), _dev(lin).clone(), torch.zeros(1, device="cuda")
     ops.emb_pool_bwd(d_ids, F, cs, d_rb, D, d_concat, concat, sum_x, dl, -0.2, t1, l1, b1)
-    srows, sslots, flags = ops.emb_sort_slots(d_ids, d_rb, R)
+    plan = ops.emb_sort_slots(d_ids, d_rb, R)
+    srows, sslots, flags = plan.rows, plan.slots, plan.flags
     t2, l2, b2 = _dev(table).clone(), _dev(lin).clone(), torch.zeros(1, device="cuda")
-    ops.emb_pool_bwd_sorted(d_ids, d_rb, srows, sslots, flags, D, R, d_concat, dl, -0.2, t2, l2, b2, concat=concat, sum_x=sum_x)
+    ops.emb_pool_bwd_sorted(d_ids, d_rb, plan, D, R, d_concat, dl, -0.2, t2, l2, b2, concat=concat, sum_x=sum_x)
     np.testing.assert_allclose(t2.cpu().numpy(), t1.cpu().numpy(), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(l2.cpu().numpy(), l1.cpu().numpy(), rtol=1e-5, atol=1e-5)
     assert abs(b1.item() - b2.item()) < 1e-3

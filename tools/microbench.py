@@ -77,16 +77,15 @@ def main():
             _lib.lib().dr_debug_set_bwd_strided(1)
             NB = 4
             idsl = [ids] + [torch.randint(0, V, (B, F), device=dev, generator=g) for _ in range(NB - 1)] if dist == "uniform" else [ids]
-            sr = torch.empty(B * F, dtype=torch.int64, device=dev); ss = torch.empty(B * F, dtype=torch.int32, device=dev)
-            fl = torch.empty(B * F, dtype=torch.uint8, device=dev); wsb = ops.emb_sort_workspace(B * F, dev)
+            plan = ops.SortPlan(B * F, dev); fl = plan.flags
             cnt = [0]
             def do_sort():
                 cnt[0] += 1
-                ops.emb_sort_slots(idsl[cnt[0] % len(idsl)], row_base, R, sr, ss, fl, wsb)
+                ops.emb_sort_slots(idsl[cnt[0] % len(idsl)], row_base, R, plan)
             t = timeit(do_sort)
             res["emb_sort_slots_" + dist] = {"us": t * 1e6}
-            ops.emb_sort_slots(ids, row_base, R, sr, ss, fl, wsb)
-            t = timeit(lambda: ops.emb_pool_bwd_sorted(ids, row_base, sr, ss, fl, D, R, d_concat, d_fm, -1e-3, table, lin_w))
+            ops.emb_sort_slots(ids, row_base, R, plan)
+            t = timeit(lambda: ops.emb_pool_bwd_sorted(ids, row_base, plan, D, R, d_concat, d_fm, -1e-3, table, lin_w))
             res["emb_pool_bwd_sorted_" + dist] = {"us": t * 1e6, "alg_GB/s": alg / t / 1e9, "frac_of_8TB/s": alg / t / 8e12,
                                                    "unique_frac": float(fl.float().mean())}
         # copy ceiling for reference: device-to-device copy of the concat-sized buffer
