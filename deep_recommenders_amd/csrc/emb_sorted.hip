@@ -97,11 +97,6 @@ __global__ __launch_bounds__(256) void emb_bwd_unique_kernel(const int64_t* __re
                 if (row[u] >= 0 && dvalid) {
                     g[u] = *reinterpret_cast<const float4*>(grow + f * D + sub * 4);
                     t[u] = *reinterpret_cast<const float4*>(table + row[u] * D + sub * 4);
-                    if (fm) {
-                        const float4 x = *reinterpret_cast<const float4*>(concat + b * ldc + f * D + sub * 4);
-                        g[u].x += dl * (sx.x - x.x); g[u].y += dl * (sx.y - x.y);
-                        g[u].z += dl * (sx.z - x.z); g[u].w += dl * (sx.w - x.w);
-                    }
                 }
             }
 #pragma unroll
@@ -109,6 +104,11 @@ __global__ __launch_bounds__(256) void emb_bwd_unique_kernel(const int64_t* __re
                 if (row[u] >= 0) {
                     if (dvalid) {
                         float4 r = t[u];
+                        if (fm) {   // the row is unique in the batch and single-valued: its current value IS the forward
+                                    // activation x[b, f, :] (bit-for-bit), so the FM term needs no concat re-read
+                            g[u].x += dl * (sx.x - r.x); g[u].y += dl * (sx.y - r.y);
+                            g[u].z += dl * (sx.z - r.z); g[u].w += dl * (sx.w - r.w);
+                        }
                         r.x = fmaf(scale, g[u].x, r.x); r.y = fmaf(scale, g[u].y, r.y);
                         r.z = fmaf(scale, g[u].z, r.z); r.w = fmaf(scale, g[u].w, r.w);
                         *reinterpret_cast<float4*>(table + row[u] * D + sub * 4) = r;

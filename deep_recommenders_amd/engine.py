@@ -77,6 +77,8 @@ class DeepFMEngine:
         import os as _os
         self.sort_inline = _os.environ.get("DR_SORT_INLINE", "0") == "1"
         self.fold_fm = _os.environ.get("DR_FOLD_FM", "0") == "1"
+        # optional: main pipeline on a high-priority stream (measured neutral-to-worse vs the side-stream sort: 2.89 vs 2.82 ms)
+        self.main = torch.cuda.Stream(device=device, priority=-1) if _os.environ.get("DR_HIPRIO", "0") == "1" else None
         if sorted_bwd:
             n = B * F
             self.plan = ops.SortPlan(n, device)
@@ -180,8 +182,16 @@ class DeepFMEngine:
                                          self.sum_x, self.d_logit, -lr, self.table, self.lin_w, self.lin_bias))
 
     def train_step(self, keys, dense, labels):
-        self.forward(keys, dense, labels)
-        self.backward_and_update()
+        if self.main is None:
+            self.forward(keys, dense, labels)
+            self.backward_and_update()
+            return self.loss
+        cur = torch.cuda.current_stream()
+        self.main.wait_stream(cur)
+        with torch.cuda.stream(self.main):
+            self.forward(keys, dense, labels)
+            self.backward_and_update()
+        cur.wait_stream(self.main)
         return self.loss
 
     # algorithmic bytes of the two embedding kernels per step
