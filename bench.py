@@ -177,8 +177,12 @@ def main():
     except Exception:
         traffic = {}
     roof_all = []
+    comm_phases = {}
     for name, k in kernels.items():
         sec = k["ms"] * 1e-3
+        if k["bound"] == "xgmi":      # exchange phases (all-to-all / all-reduce + their local halves): reported apart
+            comm_phases[name] = {"avg_us": round(k["ms"] * 1e3, 2), "bytes_per_rank": k.get("alg_bytes"), "launches": k["n"]}
+            continue
         if k["bound"] == "hbm":
             ach, peak, unit = k["alg_bytes"] / sec / 1e9, HBM_PEAK_GBS, "GB/s"
         else:
@@ -206,6 +210,8 @@ def main():
             "roofline": roofline,
             "roofline_all": roof_all,
         }
+        if comm_phases:
+            out["exchange_phases"] = comm_phases
         if world == 1 and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(a, dnn_units)

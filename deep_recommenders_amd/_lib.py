@@ -37,9 +37,10 @@ SIGNATURES = {
     "dr_rows_gather": [_p, _i64, _p, _i32, _p, _p, _p, _p],
     "dr_rows_scatter_add": [_p, _i64, _p, _i32, _p, _f32, _p, _p, _p],
     "dr_axpy": [_i64, _f32, _p, _p, _p],
+    "dr_emb_pack_grads": [_p, _i64, _i32, _i32, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p],
     "dr_emb_sort_workspace_bytes": [_i64],
     "dr_emb_sort_slots": [_p, _i64, _i32, _p, _i64, _p, _p, _p, _p, _p, _p, _i64, _p],
-    "dr_emb_pool_bwd_sorted": [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _i64, _p, _i64, _p, _p, _f32, _p, _p,
+    "dr_emb_pool_bwd_sorted": [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _i64, _p, _i64, _p, _p, _p, _f32, _p, _p,
                                _p, _p],
     "dr_linear_bwd_dx_fm": [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _i64, _i32, _i32, _p, _i64, _p],
     "dr_inbatch_softmax_workspace_bytes": [_i64],

@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void emb_bwd_unique_kernel(const int64_t* __re
                                                              const float* __restrict__ grad, int64_t ld,
                                                              const float* __restrict__ concat, int64_t ldc,
                                                              const float* __restrict__ sum_x,
-                                                             const float* __restrict__ d_fm_logit, float scale,
+                                                             const float* __restrict__ d_fm_logit,
+                                                             const float* __restrict__ slot_lin, float scale,
                                                              float* __restrict__ table, float* __restrict__ lin_w,
                                                              float* __restrict__ lin_bias) {
     constexpr int NS = DR_WAVE / LPR;
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void emb_bwd_unique_kernel(const int64_t* __re
             int64_t row[U];
             float4 g[U], t[U];
             float lw[U];
-            const bool do_lin = lin_w != nullptr && d_fm_logit != nullptr && sub == 0;
+            const bool do_lin = lin_w != nullptr && (d_fm_logit != nullptr || slot_lin != nullptr) && sub == 0;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int f = f0 + u * NS + slot;
@@ -113,7 +114,10 @@ __global__ __launch_bounds__(256) void emb_bwd_unique_kernel(const int64_t* __re
                         r.z = fmaf(scale, g[u].z, r.z); r.w = fmaf(scale, g[u].w, r.w);
                         *reinterpret_cast<float4*>(table + row[u] * D + sub * 4) = r;
                     }
-                    if (do_lin) lin_w[row[u]] = fmaf(scale, dl, lw[u]);
+                    if (do_lin) {
+                        const float gl = slot_lin != nullptr ? slot_lin[b * F + f0 + u * NS + slot] : dl;
+                        lin_w[row[u]] = fmaf(scale, gl, lw[u]);
+                    }
                 }
             }
         }
@@ -136,12 +140,14 @@ __global__ __launch_bounds__(256) void emb_bwd_dups_kernel(const uint64_t* __res
                                                            const float* __restrict__ grad, int64_t ld,
                                                            const float* __restrict__ concat, int64_t ldc,
                                                            const float* __restrict__ sum_x,
-                                                           const float* __restrict__ d_fm_logit, float scale,
+                                                           const float* __restrict__ d_fm_logit,
+                                                           const float* __restrict__ slot_lin, float scale,
                                                            float* __restrict__ table, float* __restrict__ lin_w) {
     constexpr int NS = DR_WAVE / LPR;
     const int lane = threadIdx.x & 63, slot = lane / LPR, sub = lane % LPR;
     const bool dvalid = sub * 4 < D;
     const bool fm = concat != nullptr && sum_x != nullptr && d_fm_logit != nullptr;
+    const bool any_lin = d_fm_logit != nullptr || slot_lin != nullptr;
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nheads = dup_count[0];
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(256) void emb_bwd_dups_kernel(const uint64_t* __res
                 }
                 g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
             }
-            if (d_fm_logit != nullptr && sub == 0) dls += d_fm_logit[b];
+            if (any_lin && sub == 0) dls += slot_lin != nullptr ? slot_lin[p] : d_fm_logit[b];
             ++j;
         } while (j < n && j < stop && rows[j] == k);
         const bool exclusive = seg_start && (j >= n || rows[j] != k);
@@ -181,13 +187,13 @@ __global__ __launch_bounds__(256) void emb_bwd_dups_kernel(const uint64_t* __res
                 t.z = fmaf(scale, g.z, t.z); t.w = fmaf(scale, g.w, t.w);
                 *reinterpret_cast<float4*>(dst) = t;
             }
-            if (lin_w != nullptr && d_fm_logit != nullptr && sub == 0) lin_w[k] = fmaf(scale, dls, lin_w[k]);
+            if (lin_w != nullptr && any_lin && sub == 0) lin_w[k] = fmaf(scale, dls, lin_w[k]);
         } else {
             if (dvalid) {
                 unsafeAtomicAdd(dst + 0, scale * g.x); unsafeAtomicAdd(dst + 1, scale * g.y);
                 unsafeAtomicAdd(dst + 2, scale * g.z); unsafeAtomicAdd(dst + 3, scale * g.w);
             }
-            if (lin_w != nullptr && d_fm_logit != nullptr && sub == 0) unsafeAtomicAdd(lin_w + k, scale * dls);
+            if (lin_w != nullptr && any_lin && sub == 0) unsafeAtomicAdd(lin_w + k, scale * dls);
         }
     }
 }
@@ -249,8 +255,8 @@ extern "C" int dr_emb_pool_bwd_sorted(const int64_t* ids, const int64_t* row_bas
                                       const int32_t* dup_heads, const int32_t* dup_count, int64_t B, int32_t F,
                                       int32_t D, int64_t num_rows, const float* grad, int64_t ld_grad,
                                       const float* concat, int64_t ld_concat, const float* sum_x,
-                                      const float* d_fm_logit, float scale, float* dst_table, float* dst_lin,
-                                      float* dst_bias, dr_stream_t stream) {
+                                      const float* d_fm_logit, const float* slot_lin_grad, float scale,
+                                      float* dst_table, float* dst_lin, float* dst_bias, dr_stream_t stream) {
     if (B < 0 || F <= 0 || F > 64 || D < 4 || D > 256 || (D & 3) || num_rows <= 0) return DR_EINVAL;
     const int64_t n = B * F;
     if (n == 0) return DR_OK;
@@ -269,10 +275,12 @@ extern "C" int dr_emb_pool_bwd_sorted(const int64_t* ids, const int64_t* row_bas
         constexpr int NS_ = 64 / L;                                                                                   \
         constexpr int U_ = NS_ >= 16 ? 2 : 4;                                                                         \
         hipLaunchKernelGGL((emb_bwd_unique_kernel<L, U_>), dim3(grid_u), dim3(256), 0, dr_s(stream), ids, unique_flags, \
-                           B, F, row_base, D, grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit, scale, dst_table, dst_lin,   \
+                           B, F, row_base, D, grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit, slot_lin_grad, scale,       \
+                           dst_table, dst_lin,                                                                        \
                            dst_bias);                                                                                 \
         hipLaunchKernelGGL((emb_bwd_dups_kernel<L>), dim3(grid_d), dim3(256), 0, dr_s(stream), rows, sorted_slots, n, \
-                           dup_heads, dup_count, F, D, (uint64_t)num_rows, grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit, scale, dst_table,   \
+                           dup_heads, dup_count, F, D, (uint64_t)num_rows, grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit, \
+                           slot_lin_grad, scale, dst_table,                                                           \
                            dst_lin);                                                                                  \
     }
     switch (lpr) {

@@ -195,6 +195,45 @@ __global__ __launch_bounds__(256) void rows_scatter_add_kernel(const int64_t* __
     }
 }
 
+// Backward half of the exchange on the requesting rank: per-slot gradient rows written straight into the all-to-all
+// send layout (pos is a permutation of 0..n-1: every destination written exactly once — no zero fill, no atomics).
+//   out_rows[pos[b,f], :] = d_concat[b, f*D:(f+1)*D] + d_fm_logit[b] * (sum_x[b,:] - concat[b, f*D:(f+1)*D])
+//   out_lin[pos[b,f]]     = d_fm_logit[b]
+template <int LPR>
+__global__ __launch_bounds__(256) void pack_grads_kernel(const int64_t* __restrict__ pos, int64_t B, int32_t F, int32_t D,
+                                                         const float* __restrict__ d_concat, int64_t ld,
+                                                         const float* __restrict__ concat, int64_t ldc,
+                                                         const float* __restrict__ sum_x,
+                                                         const float* __restrict__ d_fm_logit,
+                                                         float* __restrict__ out_rows, float* __restrict__ out_lin,
+                                                         float* __restrict__ bias_sum) {
+    constexpr int NS = DR_WAVE / LPR;
+    const int lane = threadIdx.x & 63, slot = lane / LPR, sub = lane % LPR;
+    const bool dvalid = sub * 4 < D;
+    const bool fm = concat != nullptr && sum_x != nullptr && d_fm_logit != nullptr;
+    const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+    float bacc = 0.f;
+    for (int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); b < B; b += nw) {
+        const float dl = d_fm_logit != nullptr ? d_fm_logit[b] : 0.f;
+        if (lane == 0) bacc += dl;
+        float4 sx = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (fm && dvalid) sx = *reinterpret_cast<const float4*>(sum_x + b * D + sub * 4);
+        for (int f = slot; f < F; f += NS) {
+            const int64_t p = pos[b * F + f];
+            if (dvalid) {
+                float4 g = *reinterpret_cast<const float4*>(d_concat + b * ld + f * D + sub * 4);
+                if (fm) {
+                    const float4 x = *reinterpret_cast<const float4*>(concat + b * ldc + f * D + sub * 4);
+                    g.x += dl * (sx.x - x.x); g.y += dl * (sx.y - x.y); g.z += dl * (sx.z - x.z); g.w += dl * (sx.w - x.w);
+                }
+                *reinterpret_cast<float4*>(out_rows + p * D + sub * 4) = g;
+            }
+            if (out_lin != nullptr && sub == 0) out_lin[p] = dl;
+        }
+    }
+    if (bias_sum != nullptr && lane == 0 && bacc != 0.f) unsafeAtomicAdd(bias_sum, bacc);
+}
+
 __global__ __launch_bounds__(256) void axpy_kernel(int64_t n, float alpha, const float* __restrict__ x,
                                                    float* __restrict__ y) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -280,6 +319,22 @@ extern "C" int dr_axpy(int64_t n, float alpha, const float* x, float* y, dr_stre
     if (n == 0) return DR_OK;
     if (!x || !y) return DR_EINVAL;
     hipLaunchKernelGGL(axpy_kernel, dim3(dr_grid_for(n, 256)), dim3(256), 0, dr_s(stream), n, alpha, x, y);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+extern "C" int dr_emb_pack_grads(const int64_t* pos, int64_t B, int32_t F, int32_t D, const float* d_concat, int64_t ld_dconcat,
+                                 const float* concat, int64_t ld_concat, const float* sum_x, const float* d_fm_logit,
+                                 float* out_rows, float* out_lin, float* bias_sum, dr_stream_t stream) {
+    if (B < 0 || F <= 0 || D < 4 || D > 256 || (D & 3)) return DR_EINVAL;
+    if (B == 0) return DR_OK;
+    if (!pos || !d_concat || !out_rows || ld_dconcat < (int64_t)F * D || (ld_dconcat & 3)) return DR_EINVAL;
+    if (concat != nullptr && (ld_concat < (int64_t)F * D || (ld_concat & 3))) return DR_EINVAL;
+    const int lpr = lpr_for_d(D);
+    const int grid = dr_grid_for(B, 4, 8192);
+#define CALL(L) hipLaunchKernelGGL((pack_grads_kernel<L>), dim3(grid), dim3(256), 0, dr_s(stream), pos, B, F, D, d_concat, ld_dconcat, concat, ld_concat, sum_x, d_fm_logit, out_rows, out_lin, bias_sum)
+    DR_LPR_SWITCH(lpr, CALL)
+#undef CALL
     DR_CHECK_LAUNCH();
     return DR_OK;
 }

@@ -361,14 +361,15 @@ def emb_sort_slots(ids, row_base, num_rows, plan=None):
 
 
 def emb_pool_bwd_sorted(ids, row_base, plan, D, num_rows, grad, d_fm_logit, scale, dst_table, dst_lin=None, dst_bias=None,
-                        concat=None, sum_x=None):
+                        concat=None, sum_x=None, slot_lin_grad=None):
     ids = _c(ids, torch.int64)
     B, F = ids.shape
     assert grad.stride(1) == 1
     check(lib().dr_emb_pool_bwd_sorted(ptr(ids), ptr(row_base), ptr(plan.rows), ptr(plan.slots), ptr(plan.flags),
                                        ptr(plan.dup_heads), ptr(plan.dup_count), B, F, D, int(num_rows), ptr(grad),
                                        grad.stride(0), ptr(concat), concat.stride(0) if concat is not None else 0,
-                                       ptr(sum_x), ptr(d_fm_logit), float(scale), ptr(dst_table), ptr(dst_lin), ptr(dst_bias),
+                                       ptr(sum_x), ptr(d_fm_logit), ptr(slot_lin_grad), float(scale), ptr(dst_table), ptr(dst_lin),
+                                       ptr(dst_bias),
                                        stream_ptr()), "dr_emb_pool_bwd_sorted")
 
 
@@ -542,3 +543,11 @@ def softmax_ce_rows(logits, labels, inv_temperature=1.0, sample_weight=None):
     check(lib().dr_softmax_ce_rows(ptr(logits), ptr(labels), B, C, float(inv_temperature), ptr(sample_weight), ptr(row),
                                    ptr(loss), stream_ptr()), "dr_softmax_ce_rows")
     return loss.reshape(())
+
+
+def emb_pack_grads(pos, D, d_concat, concat, sum_x, d_fm_logit, out_rows, out_lin=None, bias_sum=None):
+    pos = _c(pos, torch.int64)
+    B, F = pos.shape
+    check(lib().dr_emb_pack_grads(ptr(pos), B, F, D, ptr(d_concat), d_concat.stride(0), ptr(concat),
+                                  concat.stride(0) if concat is not None else 0, ptr(sum_x), ptr(d_fm_logit), ptr(out_rows),
+                                  ptr(out_lin), ptr(bias_sum), stream_ptr()), "dr_emb_pack_grads")

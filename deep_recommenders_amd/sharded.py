@@ -12,8 +12,8 @@ One step on every rank:
   5. all-to-all: rows [*, D] (+ first-order weights) back     RCCL  (C2: 4*D B per slot)
   6. fused pool + first-order + FM over the received rows (K3 with `pos` as ids) -> concat, fm_logit
   7. dense tower forward / loss / backward (K7, K11)          local MFMA
-  8. K4 into a packed per-slot gradient buffer -> all-to-all gradients to the owners (C3) ->
-     owners scatter-add with the SGD step fused (dr_rows_scatter_add)
+  8. per-slot gradients packed into the send layout (dr_emb_pack_grads) -> all-to-all to the owners (C3) ->
+     owners apply them with the sorted plain read-modify-write K4 (SGD step fused)
   9. one flat all-reduce of the dense-tower gradients (C4) -> dr_axpy into the replicated weights
 
 All compute goes through a `prims` object: `HipPrims` (the HIP kernels, the only implementation shipped
@@ -41,6 +41,9 @@ class HipPrims:
     rows_scatter_add = staticmethod(ops.rows_scatter_add)
     emb_pool_fwd = staticmethod(ops.emb_pool_fwd)
     emb_pool_bwd = staticmethod(ops.emb_pool_bwd)
+    emb_pack_grads = staticmethod(ops.emb_pack_grads)
+    emb_sort_slots = staticmethod(ops.emb_sort_slots)
+    emb_pool_bwd_sorted = staticmethod(ops.emb_pool_bwd_sorted)
     linear_fwd = staticmethod(ops.linear_fwd)
     linear_bwd_dx = staticmethod(ops.linear_bwd_dx)
     linear_bwd_dw = staticmethod(ops.linear_bwd_dw)
@@ -49,7 +52,14 @@ class HipPrims:
 
 
 class ShardedEmbeddingExchange:
-    """Steps 2-6 and 8 above for one (ids [B, F]) batch."""
+    """Steps 2-6 and 8 above for one (ids [B, F]) batch.
+
+    Owner side: the received row list is viewed as [n/32, 32] "examples x fields" (padded with -1) so that the
+    single-GPU sorted K4 (sort on a side stream during the forward, one plain read-modify-write per unique row)
+    applies the returned gradients; the requesting side packs its per-slot gradients straight into the all-to-all
+    send layout (dr_emb_pack_grads: a permutation, no atomics)."""
+
+    GROUP = 32      # pseudo-fields per pseudo-example of the owner-side slot list
 
     def __init__(self, num_fields, vocab_per_field, dim, world, rank, device, prims=None, group=None):
         self.F, self.V, self.D = num_fields, vocab_per_field, dim
@@ -59,12 +69,31 @@ class ShardedEmbeddingExchange:
         self.p = prims if prims is not None else HipPrims
         self.group = group
         self._zero_base = torch.zeros(num_fields, dtype=torch.int64, device=device)
+        self._zero_base_g = torch.zeros(self.GROUP, dtype=torch.int64, device=device)
         self._col_start = torch.arange(num_fields + 1, dtype=torch.int32, device=device)
         self._st = None
+        self._cap = 0
+        self._rows_pad = self._g_pad = self._gl_pad = self._plan = None
+        self._cuda = torch.device(device).type == "cuda"
+        self._side = torch.cuda.Stream(device=device) if self._cuda else None
+        self._ev_rows = torch.cuda.Event() if self._cuda else None
+        self._ev_sorted = torch.cuda.Event() if self._cuda else None
 
     def _a2a(self, out, inp, out_splits, in_splits):
         dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
         return out
+
+    def _ensure_capacity(self, n_recv, device):
+        G = self.GROUP
+        need = (n_recv + G - 1) // G * G
+        if need > self._cap:
+            cap = max(need, int(self._cap * 1.25) // G * G)
+            self._rows_pad = torch.full((cap,), -1, dtype=torch.int64, device=device)
+            self._g_pad = torch.zeros((cap, self.D), dtype=torch.float32, device=device)
+            self._gl_pad = torch.zeros(cap, dtype=torch.float32, device=device)
+            self._plan = None
+            self._cap = cap
+        return need
 
     def forward(self, ids, table_local, lin_local, lin_bias, ld_concat, concat=None, sum_x=None, fm_logit=None):
         B, F = ids.shape
@@ -75,8 +104,21 @@ class ShardedEmbeddingExchange:
         send_splits = [int(v) for v in counts.tolist()]                               # host sync: exact sizes
         recv_splits = [int(v) for v in recv_counts.tolist()]
         n_recv = sum(recv_splits)
-        recv_rows = torch.empty(n_recv, dtype=torch.int64, device=ids.device)
+        n_pad = self._ensure_capacity(n_recv, ids.device)
+        rows_pad = self._rows_pad[:n_pad]
+        rows_pad[n_recv:].fill_(-1)
+        recv_rows = rows_pad[:n_recv]
         self._a2a(recv_rows, send_rows, recv_splits, send_splits)                     # C1
+        # the owner-side sort only needs the received row list: side stream, hidden under the exchange + tower
+        G = self.GROUP
+        if self._cuda:
+            self._ev_rows.record()
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(self._ev_rows)
+                self._plan = self.p.emb_sort_slots(rows_pad.view(-1, G), self._zero_base_g, self.local_rows, self._plan)
+                self._ev_sorted.record(self._side)
+        else:
+            self._plan = self.p.emb_sort_slots(rows_pad.view(-1, G), self._zero_base_g, self.local_rows, self._plan)
         rows_buf, lin_buf = self.p.rows_gather(recv_rows, table_local, lin_local)     # owner-side gather
         got_rows = torch.empty((n, D), dtype=torch.float32, device=ids.device)
         self._a2a(got_rows, rows_buf, send_splits, recv_splits)                       # C2
@@ -88,23 +130,34 @@ class ShardedEmbeddingExchange:
         concat, sum_x, fm_logit = self.p.emb_pool_fwd(pos, F, None if F <= 64 else self._col_start, self._zero_base,
                                                       got_rows, got_lin, lin_bias, ld_concat=ld_concat, concat=concat,
                                                       sum_x=sum_x, fm_logit=fm_logit)
-        self._st = (pos, send_splits, recv_splits, recv_rows, n, n_recv, lin_local is not None)
+        self._st = (pos, send_splits, recv_splits, n, n_recv, n_pad, lin_local is not None)
         return concat, sum_x, fm_logit
 
-    def backward(self, d_concat, d_fm_logit, concat, sum_x, scale, table_local, lin_local, g_bias=None):
-        pos, send_splits, recv_splits, recv_rows, n, n_recv, has_lin = self._st
-        D, F = self.D, self.F
-        g_rows = torch.zeros((n, D), dtype=torch.float32, device=pos.device)          # packed per-slot gradients
-        g_lin = torch.zeros(n, dtype=torch.float32, device=pos.device) if has_lin else None
-        self.p.emb_pool_bwd(pos, F, self._col_start, self._zero_base, D, d_concat, concat, sum_x, d_fm_logit, 1.0,
-                            g_rows, g_lin, g_bias)
-        recv_g = torch.empty((n_recv, D), dtype=torch.float32, device=pos.device)
-        self._a2a(recv_g, g_rows, recv_splits, send_splits)                           # C3
-        recv_gl = None
+    def pack(self, d_concat, d_fm_logit, concat, sum_x, g_bias=None):
+        """requesting side: per-slot gradients into the send layout (local, HBM-bound)"""
+        pos, send_splits, recv_splits, n, n_recv, n_pad, has_lin = self._st
+        g_rows = torch.empty((n, self.D), dtype=torch.float32, device=pos.device)
+        g_lin = torch.empty(n, dtype=torch.float32, device=pos.device) if has_lin else None
+        self.p.emb_pack_grads(pos, self.D, d_concat, concat, sum_x, d_fm_logit, g_rows, g_lin, g_bias)
+        return g_rows, g_lin
+
+    def exchange_and_apply(self, g_rows, g_lin, scale, table_local, lin_local):
+        """C3 + owner-side update (may run on a communication stream, overlapped with the tower's wgrad)"""
+        pos, send_splits, recv_splits, n, n_recv, n_pad, has_lin = self._st
+        D, G = self.D, self.GROUP
+        g_pad, gl_pad, rows_pad = self._g_pad[:n_pad], self._gl_pad[:n_pad], self._rows_pad[:n_pad]
+        self._a2a(g_pad[:n_recv], g_rows, recv_splits, send_splits)                   # C3
         if has_lin:
-            recv_gl = torch.empty(n_recv, dtype=torch.float32, device=pos.device)
-            self._a2a(recv_gl, g_lin, recv_splits, send_splits)
-        self.p.rows_scatter_add(recv_rows, recv_g, recv_gl, scale, table_local, lin_local)
+            self._a2a(gl_pad[:n_recv], g_lin, recv_splits, send_splits)
+        if self._cuda:
+            torch.cuda.current_stream().wait_event(self._ev_sorted)
+        self.p.emb_pool_bwd_sorted(rows_pad.view(-1, G), self._zero_base_g, self._plan, D, self.local_rows,
+                                   g_pad.view(-1, G * D), None, scale, table_local, lin_local if has_lin else None, None,
+                                   slot_lin_grad=gl_pad if has_lin else None)
+
+    def backward(self, d_concat, d_fm_logit, concat, sum_x, scale, table_local, lin_local, g_bias=None):
+        g_rows, g_lin = self.pack(d_concat, d_fm_logit, concat, sum_x, g_bias)
+        self.exchange_and_apply(g_rows, g_lin, scale, table_local, lin_local)
 
 
 class ShardedDeepFMEngine:
@@ -184,38 +237,90 @@ class ShardedDeepFMEngine:
         self.d_logit = torch.empty((B,), **f32)
         self.loss = torch.zeros(1, **f32)
         self.ws = torch.empty(1024, **f32)
+        self._cuda = torch.device(device).type == "cuda"
+        self.comm = torch.cuda.Stream(device=device) if self._cuda else None   # backward exchange + owner update
+        self.ev_packed = torch.cuda.Event() if self._cuda else None
+        self.ev_applied = torch.cuda.Event() if self._cuda else None
+        self._events = None
+
+    # ---- per-phase HIP events (same contract as engine.DeepFMEngine) -------------------------------------------
+    def enable_kernel_events(self, on: bool):
+        self._events = {} if (on and self._cuda) else None
+
+    def _k(self, name, bound, work, fn):
+        if self._events is None:
+            return fn()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = fn()
+        e.record()
+        self._events.setdefault(name, [bound, work, []])[2].append((s, e))
+        return r
+
+    def kernel_event_summary(self):
+        if self._events is None:
+            return {}
+        torch.cuda.synchronize()
+        out = {}
+        for name, (bound, work, evs) in self._events.items():
+            ms = sum(s.elapsed_time(e) for s, e in evs) / len(evs)
+            key = "alg_bytes" if bound in ("hbm", "xgmi") else "alg_flops"
+            out[name] = {"bound": bound, "ms": ms, "n": len(evs), key: work}
+        return out
 
     def train_step(self, keys, dense, labels):
-        p, F, D, W = self.p, self.F, self.D, self.world
-        p.hash_bucket_i64(keys, self.col_buckets, out=self.ids)
-        self.ex.forward(self.ids, self.table, self.lin_w, self.lin_bias, self.ld, concat=self.concat, sum_x=self.sum_x,
-                        fm_logit=self.fm_logit)
+        p, F, D, W, B = self.p, self.F, self.D, self.world, self.B
+        self._k("hash_bucket_i64", "hbm", B * F * 16, lambda: p.hash_bucket_i64(keys, self.col_buckets, out=self.ids))
+        # steps 2-6: bucket, exchange ids, owner gather, exchange rows, fused pool+FM over the received rows
+        self._k("emb_exchange_fwd(bucket+a2a+gather+a2a+K3)", "xgmi", B * F * (8 + 4 * D + 4),
+                lambda: self.ex.forward(self.ids, self.table, self.lin_w, self.lin_bias, self.ld, concat=self.concat,
+                                        sum_x=self.sum_x, fm_logit=self.fm_logit))
         if self.Nd:
             self.concat[:, F * D:F * D + self.Nd].copy_(dense)
         x = self.concat[:, :self.in_dim]
         for i, (Wt, b) in enumerate(zip(self.Ws, self.bs)):
-            p.linear_fwd(x, Wt, b, self.acts[i], out=self.hs[i])
+            self._k("linear_fwd_L%d" % i, "mfma", 2.0 * B * Wt.shape[0] * Wt.shape[1],
+                    lambda x=x, Wt=Wt, b=b, i=i: p.linear_fwd(x, Wt, b, self.acts[i], out=self.hs[i]))
             x = self.hs[i]
         p.bce_fwd_bwd(self.fm_logit, labels, ops.LOSS_SIGMOID_CE, workspace=self.ws, logits_b=self.hs[-1],
                       out=(self.prob, self.d_logit, self.loss))
         # ---- backward: dense tower gradients into the flat bucket ----------------------------------------
         self.flat_grads.zero_()
+        # dgrad chain first (it produces d_concat, the input of the embedding exchange); wgrads afterwards so that they
+        # overlap the backward exchange running on the communication stream
+        n_layers = len(self.Ws)
+        dys = [None] * n_layers
         dy = self.d_logit.reshape(-1, 1)
-        for i in range(len(self.Ws) - 1, -1, -1):
-            xin = self.concat[:, :self.in_dim] if i == 0 else self.hs[i - 1]
+        for i in range(n_layers - 1, -1, -1):
+            dys[i] = dy
             if i > 0:
                 dx = self.dhs[i - 1]
                 rs = self.hs[i - 1] if self.acts[i - 1] else None
             else:
                 dx = self.d_concat[:, :self.in_dim]
                 rs = None
-            p.linear_bwd_dx(dy, self.Ws[i], relu_src=rs, out=dx)
-            p.linear_bwd_dw(xin, dy, 1.0, self.gWs[i], self.gbs[i])
+            self._k("linear_bwd_dx_L%d" % i, "mfma", 2.0 * B * self.Ws[i].shape[0] * self.Ws[i].shape[1],
+                    lambda dy=dy, i=i, rs=rs, dx=dx: p.linear_bwd_dx(dy, self.Ws[i], relu_src=rs, out=dx))
             dy = dx
-        # ---- embedding backward: packed gradients -> owners, SGD fused in the owner-side scatter ------------
-        self.ex.backward(self.d_concat, self.d_logit, self.concat, self.sum_x, -self.lr / W, self.table, self.lin_w,
-                         g_bias=self.g_lin_bias)
+        # ---- embedding backward: pack (local), then C3 + owner-side sorted update on the communication stream -------
+        g_rows, g_lin = self._k("emb_pack_grads", "hbm", B * F * (12 * D + 4),
+                                lambda: self.ex.pack(self.d_concat, self.d_logit, self.concat, self.sum_x, self.g_lin_bias))
+        if self._cuda:
+            self.ev_packed.record()
+            with torch.cuda.stream(self.comm):
+                self.comm.wait_event(self.ev_packed)
+                self.ex.exchange_and_apply(g_rows, g_lin, -self.lr / W, self.table, self.lin_w)
+                self.ev_applied.record(self.comm)
+        else:
+            self.ex.exchange_and_apply(g_rows, g_lin, -self.lr / W, self.table, self.lin_w)
+        for i in range(n_layers - 1, -1, -1):
+            xin = self.concat[:, :self.in_dim] if i == 0 else self.hs[i - 1]
+            self._k("linear_bwd_dw_L%d" % i, "mfma", 2.0 * B * self.Ws[i].shape[0] * self.Ws[i].shape[1],
+                    lambda xin=xin, i=i: p.linear_bwd_dw(xin, dys[i], 1.0, self.gWs[i], self.gbs[i]))
         # ---- dense tower: one all-reduce, then w += -(lr / W) * sum_r g_r  (mean over the global batch) ------
-        dist.all_reduce(self.flat_grads, group=self.group)
+        self._k("allreduce_dense_grads", "xgmi", self.flat_grads.numel() * 4,
+                lambda: dist.all_reduce(self.flat_grads, group=self.group))
         p.axpy(-self.lr / W, self.flat_grads, self.flat_params)
+        if self._cuda:
+            torch.cuda.current_stream().wait_event(self.ev_applied)     # next step's gather must see the update
         return self.loss

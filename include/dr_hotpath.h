@@ -122,7 +122,8 @@ int dr_emb_pool_bwd(const int64_t* ids, int64_t B, int32_t F, int32_t C, const i
  * with (a) a streaming pass in example order doing ONE plain read-modify-write per unique row, and (b) a
  * segmented pass in sorted order for rows hit by several slots.  Per-slot gradient = grad[b, f*D:(f+1)*D]
  * (+ d_fm_logit[b] * (sum_x[b,:] - concat[b, f*D:(f+1)*D]) when concat / sum_x are given, as in
- * dr_emb_pool_bwd; pass NULL when `grad` already holds it, e.g. from dr_linear_bwd_dx_fm).  Rows hit by <= 32 slots are bit-reproducible; hotter rows are cut into
+ * dr_emb_pool_bwd; pass NULL when `grad` already holds it).  slot_lin_grad[n] (may be NULL) replaces d_fm_logit[b]
+ * as the per-slot first-order gradient — the owner side of the sharded exchange receives gradients per slot.  Rows hit by <= 32 slots are bit-reproducible; hotter rows are cut into
  * pieces that combine with fp32 atomics.
  * sorted_rows[n] int64 (missing ids carry num_rows and sort last), sorted_slots[n] int32 (slot = b*F + f),
  * unique_flags[n] uint8 (indexed by slot); dup_heads[n] int32 + dup_count[1] int32 = compact work list of the
@@ -139,8 +140,8 @@ int dr_emb_pool_bwd_sorted(const int64_t* ids, const int64_t* row_base, const in
                            const int32_t* dup_heads, const int32_t* dup_count, int64_t B, int32_t F,
                            int32_t D, int64_t num_rows, const float* grad, int64_t ld_grad,
                            const float* concat, int64_t ld_concat, const float* sum_x,
-                           const float* d_fm_logit, float scale, float* dst_table, float* dst_lin,
-                           float* dst_bias, dr_stream_t stream);
+                           const float* d_fm_logit, const float* slot_lin_grad, float scale,
+                           float* dst_table, float* dst_lin, float* dst_bias, dr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K6  stand-alone FM second-order term on a caller-provided [B, F, D] tensor
@@ -317,6 +318,15 @@ int dr_rows_scatter_add(const int64_t* rows, int64_t n, const float* grads, int3
                         const float* lin_grads, float scale, float* table, float* lin_w,
                         dr_stream_t stream);
 int dr_axpy(int64_t n, float alpha, const float* x, float* y, dr_stream_t stream);
+/* requesting-rank half of the backward exchange: per-slot gradient rows written straight into the all-to-all send
+ * layout (pos is a permutation, every destination is written exactly once):
+ *   out_rows[pos[b,f],:] = d_concat[b, f*D:(f+1)*D] + d_fm_logit[b] * (sum_x[b,:] - concat[b, f*D:(f+1)*D]) ;
+ *   out_lin[pos[b,f]] = d_fm_logit[b] ;  bias_sum[0] += sum_b d_fm_logit[b].
+ *   concat / sum_x / d_fm_logit / out_lin / bias_sum may be NULL. */
+int dr_emb_pack_grads(const int64_t* pos, int64_t B, int32_t F, int32_t D, const float* d_concat,
+                      int64_t ld_dconcat, const float* concat, int64_t ld_concat, const float* sum_x,
+                      const float* d_fm_logit, float* out_rows, float* out_lin, float* bias_sum,
+                      dr_stream_t stream);
 
 #ifdef __cplusplus
 }

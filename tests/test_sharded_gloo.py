@@ -83,6 +83,31 @@ class OraclePrims:
             dst_bias += scale * d_fm.sum()
 
     @staticmethod
+    def emb_pack_grads(pos, D, d_concat, concat, sum_x, d_fm, out_rows, out_lin=None, bias_sum=None):
+        B, F = pos.shape
+        for f in range(F):
+            g = d_concat[:, f * D:(f + 1) * D] + d_fm[:, None] * (sum_x - concat[:, f * D:(f + 1) * D])
+            out_rows[pos[:, f]] = g
+            if out_lin is not None:
+                out_lin[pos[:, f]] = d_fm
+        if bias_sum is not None:
+            bias_sum += d_fm.sum()
+
+    @staticmethod
+    def emb_sort_slots(ids, row_base, num_rows, plan=None):
+        return "oracle-plan"       # the oracle applies gradients with index_add_: no plan needed
+
+    @staticmethod
+    def emb_pool_bwd_sorted(ids, row_base, plan, D, num_rows, grad, d_fm, scale, dst_table, dst_lin=None, dst_bias=None,
+                            concat=None, sum_x=None, slot_lin_grad=None):
+        flat = ids.reshape(-1)
+        m = flat >= 0
+        g = grad.reshape(-1, D)
+        dst_table.index_add_(0, flat[m], g[m], alpha=scale)
+        if dst_lin is not None and slot_lin_grad is not None:
+            dst_lin.index_add_(0, flat[m], slot_lin_grad[m], alpha=scale)
+
+    @staticmethod
     def linear_fwd(x, W, b, act, out=None):
         y = x @ W + b
         if act:
