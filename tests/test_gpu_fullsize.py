@@ -1,0 +1,140 @@
+"""Full-size (BASELINE.json config 3 / 5) GPU checks through size-independent properties — the oracle cannot
+finish these sizes in seconds, so each test checks an invariant of the domain instead, plus an oracle comparison
+on a sampled subset:
+  * hash ids: in range, idempotent (same keys -> same ids), sampled subset bit-equal to the C oracle;
+  * gather+pool: every pooled row equals the table row its id names (sampled), sum_x is the field sum, fm_logit
+    equals the closed form recomputed from the kernel's own concat output;
+  * scatter update: linearity / checksum — sum over the table of (after - before) equals scale * sum of the slot
+    gradients, only rows named by the batch change, and applying +g then -g restores every row to <= 1 ulp-level error;
+  * sort plan: keys ascending, payload a permutation, unique flags consistent with neighbour equality;
+  * top-K: scores descending, idempotent, and no sampled non-selected candidate beats the k-th score."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import tf_semantics as O
+
+B, F, D, V = 65536, 26, 64, 10_000_000
+
+
+@pytest.fixture(scope="module")
+def big():
+    from deep_recommenders_amd import ops
+    g = torch.Generator(device="cuda")
+    g.manual_seed(42)
+    R = F * V
+    table = torch.empty((R, D), dtype=torch.float32, device="cuda")
+    for r0 in range(0, R, 1 << 24):
+        table[r0:r0 + (1 << 24)].normal_(0, 0.125, generator=g)
+    lin = torch.empty(R, dtype=torch.float32, device="cuda").normal_(0, 0.1, generator=g)
+    keys = torch.randint(0, 10**16, (B, F), device="cuda", generator=g)
+    keys[::1000, 3] = -1                                     # some missing ids
+    row_base = torch.arange(F, device="cuda", dtype=torch.int64) * V
+    buckets = torch.full((F,), V, dtype=torch.int64, device="cuda")
+    ids = ops.hash_bucket_i64(keys, buckets)
+    yield dict(ops=ops, table=table, lin=lin, keys=keys, ids=ids, row_base=row_base, buckets=buckets, g=g, R=R)
+    del table, lin
+    torch.cuda.empty_cache()
+
+
+def test_hash_full_size_properties(big):
+    ops, keys, ids = big["ops"], big["keys"], big["ids"]
+    assert int(ids.max()) < V and int(ids[keys != -1].min()) >= 0
+    assert bool((ids[keys == -1] == -1).all())
+    again = ops.hash_bucket_i64(keys, big["buckets"])
+    assert torch.equal(ids, again)                                              # idempotent / deterministic
+    sample = torch.randint(0, B, (2000,), device="cuda", generator=big["g"])
+    k_cpu, i_cpu = keys[sample].cpu().numpy(), ids[sample].cpu().numpy()
+    for f in (0, 7, 25):
+        np.testing.assert_array_equal(i_cpu[:, f], O.hash_bucket_i64(k_cpu[:, f], V))   # bit-exact vs the C oracle
+
+
+def test_gather_pool_full_size_properties(big):
+    ops, table, lin, ids, rb = big["ops"], big["table"], big["lin"], big["ids"], big["row_base"]
+    bias = torch.tensor([0.25], device="cuda")
+    concat, sum_x, fm = ops.emb_pool_fwd(ids, F, None, rb, table, lin, bias)
+    # (1) sampled rows are exact copies of the table rows (single-valued bag -> x/1), zeros for missing ids
+    sample = torch.randint(0, B, (4096,), device="cuda", generator=big["g"])
+    for f in (0, 3, 13, 25):
+        idf = ids[sample, f]
+        want = torch.where((idf >= 0)[:, None], table[(idf.clamp(min=0) + rb[f])], torch.zeros((), device="cuda"))
+        assert torch.equal(concat[sample, f * D:(f + 1) * D], want)
+    # (2) sum_x is the sum over fields of the kernel's own output (fp32 order differs: tolerance)
+    ref_sum = concat.view(B, F, D).sum(1)
+    assert float((sum_x - ref_sum).abs().max()) <= 1e-5
+    # (3) fm_logit = bias + sum w[id] + 0.5 * sum_d (S^2 - sum_f x^2), recomputed in fp64 on a sample
+    x = concat[sample].view(-1, F, D).double()
+    idv = ids[sample]
+    w = torch.where(idv >= 0, lin[(idv.clamp(min=0) + rb[None, :])].double(), torch.zeros((), dtype=torch.float64, device="cuda"))
+    want = 0.25 + w.sum(1) + 0.5 * ((x.sum(1) ** 2) - (x ** 2).sum(1)).sum(1)
+    got = fm[sample].double()
+    assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max() + 1)
+
+
+def test_sorted_update_full_size_properties(big):
+    ops, table, lin, ids, rb, R = big["ops"], big["table"], big["lin"], big["ids"], big["row_base"], big["R"]
+    g = big["g"]
+    plan = ops.emb_sort_slots(ids, rb, R)
+    rows, slots, flags = plan.rows, plan.slots, plan.flags
+    # sort plan invariants
+    assert bool((rows[1:] >= rows[:-1]).all())
+    assert torch.equal(torch.sort(slots.long()).values, torch.arange(B * F, device="cuda"))
+    keys = torch.where(ids >= 0, ids + rb[None, :], torch.full((), R, device="cuda")).reshape(-1)
+    assert torch.equal(rows, keys[slots.long()])
+    same_prev = torch.cat([torch.zeros(1, dtype=torch.bool, device="cuda"), rows[1:] == rows[:-1]])
+    same_next = torch.cat([rows[1:] == rows[:-1], torch.zeros(1, dtype=torch.bool, device="cuda")])
+    uniq_sorted = (~same_prev) & (~same_next) & (rows < R)
+    assert torch.equal(flags[slots.long()].bool(), uniq_sorted)
+    # update: checksum / linearity, touched set, round trip
+    grad = torch.randn((B, F * D), device="cuda", generator=g) * 1e-2
+    dl = torch.randn(B, device="cuda", generator=g) * 1e-2
+    touched = torch.unique(keys[keys < R])
+    before = table[touched].clone()
+    lin_before = lin[touched].clone()
+    total_before = table.double().sum() if False else None           # 66 GB reduction skipped: use touched rows only
+    scale = -0.5
+    ops.emb_pool_bwd_sorted(ids, rb, plan, D, R, grad, dl, scale, table, lin, None)
+    delta = (table[touched].double() - before.double()).sum()
+    valid = (ids >= 0)
+    want = scale * (grad.view(B, F, D).double() * valid[:, :, None]).sum()
+    assert abs(float(delta) - float(want)) <= 1e-6 * float(grad.abs().double().sum()) + 1e-3
+    dlin = (lin[touched].double() - lin_before.double()).sum()
+    want_lin = scale * (dl.double()[:, None] * valid).sum()
+    assert abs(float(dlin) - float(want_lin)) <= 1e-4 * abs(float(want_lin)) + 1e-4
+    # rows not named by the batch did not move (sample of untouched rows)
+    probe = torch.randint(0, R, (200000,), device="cuda", generator=g)
+    probe = probe[~torch.isin(probe, touched)]
+    snapshot = table[probe].clone()
+    # round trip: apply the opposite update -> every touched row returns to its value up to fp32 rounding of one add
+    ops.emb_pool_bwd_sorted(ids, rb, plan, D, R, grad, dl, -scale, table, lin, None)
+    assert torch.equal(table[probe], snapshot)
+    err = (table[touched] - before).abs().max()
+    assert float(err) <= 4e-7 * float(before.abs().max() + 1)
+
+
+def test_topk_full_size_properties():
+    from deep_recommenders_amd import ops
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    Bq, N, Dq, k = 2048, 1_000_000, 128, 100
+    q = torch.randn((Bq, Dq), device="cuda", generator=g) / Dq ** 0.5
+    corpus = torch.randn((N, Dq), device="cuda", generator=g) / Dq ** 0.5
+    s, idx = ops.topk_mips(q, corpus, k)
+    assert bool((s[:, 1:] <= s[:, :-1]).all())                                   # descending
+    assert bool(((idx >= 0) & (idx < N)).all())
+    s2, idx2 = ops.topk_mips(q, corpus, k)
+    assert torch.equal(s, s2) and torch.equal(idx, idx2)                         # idempotent / deterministic
+    # reported scores are the true inner products of the reported candidates
+    rows = torch.arange(0, Bq, 37, device="cuda")
+    true = torch.einsum("bd,bkd->bk", q[rows].double(), corpus[idx[rows]].double())
+    assert float((s[rows].double() - true).abs().max()) <= 1e-5
+    # no sampled candidate outside the result beats the k-th score
+    probe = torch.randint(0, N, (20000,), device="cuda", generator=g)
+    sc = q[rows] @ corpus[probe].T                                              # checker only
+    kth = s[rows, -1:]
+    in_res = (probe[None, None, :] == idx[rows][:, :, None]).any(1)
+    assert bool(((sc <= kth + 1e-6) | in_res).all())
+    # distinct indices per row
+    assert int((torch.sort(idx, dim=1).values[:, 1:] == torch.sort(idx, dim=1).values[:, :-1]).sum()) == 0
