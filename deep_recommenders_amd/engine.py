@@ -106,7 +106,7 @@ class DeepFMEngine:
         for name, (bound, work, evs) in (self._events or {}).items():
             ms = sum(s.elapsed_time(e) for s, e in evs) / len(evs)
             out[name] = {"bound": bound, "ms": ms, "n": len(evs),
-                         "alg_bytes" if bound == "hbm" else "alg_flops": work}
+                         "alg_bytes" if bound in ("hbm", "overlap") else "alg_flops": work}
         return out
 
     # ------------------------------------------------------------------------------------------
@@ -124,7 +124,7 @@ class DeepFMEngine:
             self.ev_ids.record()
             with torch.cuda.stream(self.side):
                 self.side.wait_event(self.ev_ids)
-                self._k("emb_sort_slots", "hbm", B * F * 36,
+                self._k("emb_sort_slots(side stream, overlapped)", "overlap", B * F * 36,
                         lambda: ops.emb_sort_slots(self.ids, self.row_base, self.R, self.plan))
                 self.ev_sorted.record(self.side)
         self._k("emb_pool_fwd", "hbm", self.alg_bytes_fwd(),                                          # K3+K5+K6
