@@ -37,7 +37,16 @@ __device__ __forceinline__ float4 f4shfl_xor(float4 v, int m) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Forward, fast path: every field single-valued (C == F), F <= 64.
+// Forward, fast path: every field single-valued (C == F), F <= 64.  Branch-free: every memory instruction of the
+// loop body is UNCONDITIONAL:
+//  * a conditional load/store always gets an s_cbranch_execz around it, and across those branches the
+//    compiler's wait-count bookkeeping turns pessimistic (s_waitcnt vmcnt(0) before every access), which
+//    serialised the first-order loads and the concat stores into one HBM round trip each;
+//  * so out-of-range work is clamped instead of masked: a slot past the last field repeats field F-1 (same
+//    row, same destination, same value: a benign duplicate store), a missing id (-1) reads row 0 and its
+//    value is replaced by zeros in registers, lanes past D/4 repeat the last float4 of the row;
+//  * the next example's ids are fetched before this example's rows, so the loop-top wait is already
+//    satisfied (vmcnt retires in order) and never covers this example's stores.
 // ------------------------------------------------------------------------------------------------
 template <int LPR, int U>
 __global__ __launch_bounds__(256) void emb_pool_fwd_sv_kernel(
@@ -48,49 +57,55 @@ __global__ __launch_bounds__(256) void emb_pool_fwd_sv_kernel(
     const int lane = threadIdx.x & 63;
     const int slot = lane / LPR;
     const int sub = lane % LPR;
-    const bool dvalid = sub * 4 < D;
+    const int nq = D >> 2;
+    const bool dvalid = sub < nq;
+    const int subc = dvalid ? sub : nq - 1;
+    const float* __restrict__ lsrc = lin_w != nullptr ? lin_w : table;     // value discarded when lin_w == NULL
+    const bool use_lin = lin_w != nullptr && sub == 0;
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    // per-lane table base row of "my" field (lane l <-> field l); constant across examples
-    const int64_t my_base = lane < F ? row_base[lane] : 0;
-
+    if (wave0 >= B) return;
+    const int lanec = lane < F ? lane : F - 1;
+    const int64_t my_base = row_base[lanec];
+    int64_t my_row;
+    {
+        const int64_t id = ids[wave0 * F + lanec];
+        my_row = (lane < F && id >= 0) ? my_base + id : -1;
+    }
     for (int64_t b = wave0; b < B; b += nwaves) {
-        // one coalesced 8*F-byte load; absolute row index per field, -1 if missing
-        int64_t my_row = -1;
-        if (lane < F) {
-            const int64_t id = ids[b * F + lane];
-            my_row = id >= 0 ? my_base + id : -1;
-        }
+        const int64_t bn = b + nwaves;
+        const int64_t next_id = ids[(bn < B ? bn : b) * F + lanec];           // prefetch: consumed at the loop bottom
         float4 S = f4zero(), SS = f4zero();
         float lin = 0.f;
         float* out_row = concat + b * ld;
         for (int f0 = 0; f0 < F; f0 += NS * U) {
             float4 v[U];
-            int64_t row[U];
+            float lw[U];
+            bool present[U], counted[U];
+            int fc[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int f = f0 + u * NS + slot;
-                row[u] = __shfl(my_row, f < F ? f : 0, 64);
-                if (f >= F) row[u] = -1;
-                v[u] = f4zero();
-                if (row[u] >= 0 && dvalid)
-                    v[u] = *reinterpret_cast<const float4*>(table + row[u] * D + sub * 4);
-            }
-            if (lin_w != nullptr && sub == 0) {
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-                    if (row[u] >= 0) lin += lin_w[row[u]];
+                fc[u] = f < F ? f : F - 1;
+                const int64_t r = __shfl(my_row, fc[u], 64);
+                present[u] = r >= 0;
+                counted[u] = f < F && dvalid;
+                const int64_t rc = present[u] ? r : 0;
+                v[u] = *reinterpret_cast<const float4*>(table + rc * D + subc * 4);
+                lw[u] = lsrc[rc];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int f = f0 + u * NS + slot;
-                if (f < F && dvalid) f4store_nt(out_row + f * D + sub * 4, v[u]);
-                S = f4add(S, v[u]);
-                SS = f4fma2(v[u], SS);
+                const float4 x = present[u] ? v[u] : f4zero();
+                f4store_nt(out_row + fc[u] * D + subc * 4, x);
+                const float4 xs = counted[u] ? x : f4zero();
+                S = f4add(S, xs);
+                SS = f4fma2(xs, SS);
+                lin += (counted[u] && present[u] && use_lin) ? lw[u] : 0.f;
             }
         }
+        my_row = (bn < B && lane < F && next_id >= 0) ? my_base + next_id : -1;
         if (sum_x == nullptr && fm_logit == nullptr) continue;
-        // reduce across slots (lane bits >= log2(LPR))
 #pragma unroll
         for (int m = LPR; m < DR_WAVE; m <<= 1) {
             S = f4add(S, f4shfl_xor(S, m));
@@ -193,10 +208,9 @@ __global__ __launch_bounds__(256) void emb_pool_bwd_kernel(
 #pragma unroll
     for (int j = 0; j < 4; ++j) doff[j] = STRIDED ? (j * LPR + sub) : (sub * 4 + j);
 
-    float dl_sum = 0.f;
+    if (blockIdx.x == 0 && dst_bias != nullptr && d_fm_logit != nullptr) dr_block_sum_axpy(d_fm_logit, B, scale, dst_bias);
     for (int64_t b = wave0; b < B; b += nwaves) {
         const float dl = d_fm_logit != nullptr ? d_fm_logit[b] : 0.f;
-        dl_sum += dl;
         float s[4] = {0.f, 0.f, 0.f, 0.f};
         if (d_fm_logit != nullptr && sum_x != nullptr) {
 #pragma unroll
@@ -232,7 +246,6 @@ __global__ __launch_bounds__(256) void emb_pool_bwd_kernel(
             }
         }
     }
-    if (dst_bias != nullptr && d_fm_logit != nullptr && lane == 0 && dl_sum != 0.f) unsafeAtomicAdd(dst_bias, scale * dl_sum);
 }
 
 int lpr_for(int D) {

@@ -53,78 +53,92 @@ __global__ __launch_bounds__(256) void mark_unique_kernel(const uint64_t* __rest
 
 // Fast path: streams the gradient in example order (coalesced), one wave per example; every slot whose row is
 // unique in the batch gets ONE plain 16-byte-per-lane load / fma / store of its table row.  No atomics.
+// Branch-free load phase (see emb_pool_fwd_sv_kernel in emb_pool.hip for why): every load of the
+// loop body is unconditional with a clamped address -- a slot that is not unique / missing / past the last field
+// reads table row 0 and its own (or field F-1's) gradient and simply stores nothing -- so all U row loads, U
+// gradient loads and U first-order loads of an iteration are in flight together instead of one round trip each,
+// and the next example's ids/flags are fetched ahead of them.  Only the stores stay predicated.
 template <int LPR, int U>
 __global__ __launch_bounds__(256) void emb_bwd_unique_kernel(const int64_t* __restrict__ ids,
-                                                             const uint8_t* __restrict__ flags, int64_t B, int32_t F,
-                                                             const int64_t* __restrict__ row_base, int32_t D,
-                                                             const float* __restrict__ grad, int64_t ld,
-                                                             const float* __restrict__ concat, int64_t ldc,
-                                                             const float* __restrict__ sum_x,
-                                                             const float* __restrict__ d_fm_logit,
-                                                             const float* __restrict__ slot_lin, float scale,
-                                                             float* __restrict__ table, float* __restrict__ lin_w,
-                                                             float* __restrict__ lin_bias) {
+                                                              const uint8_t* __restrict__ flags, int64_t B, int32_t F,
+                                                              const int64_t* __restrict__ row_base, int32_t D,
+                                                              const float* __restrict__ grad, int64_t ld,
+                                                              const float* __restrict__ concat, int64_t ldc,
+                                                              const float* __restrict__ sum_x,
+                                                              const float* __restrict__ d_fm_logit,
+                                                              const float* __restrict__ slot_lin, float scale,
+                                                              float* __restrict__ table, float* __restrict__ lin_w,
+                                                              float* __restrict__ lin_bias) {
     constexpr int NS = DR_WAVE / LPR;
     const int lane = threadIdx.x & 63, slot = lane / LPR, sub = lane % LPR;
-    const bool dvalid = sub * 4 < D;
+    const int nq = D >> 2;
+    const bool dvalid = sub < nq;
+    const int subc = dvalid ? sub : nq - 1;
     const bool fm = concat != nullptr && sum_x != nullptr && d_fm_logit != nullptr;
+    const bool do_lin = lin_w != nullptr && (d_fm_logit != nullptr || slot_lin != nullptr) && sub == 0;
+    const float* lsrc = lin_w != nullptr ? lin_w : table;                 // loaded value unused when lin_w == NULL
+    const float* dlsrc = d_fm_logit != nullptr ? d_fm_logit : grad;       // idem
+    const float* sxsrc = fm ? sum_x : grad;                               // idem
+    const int64_t sx_pitch = fm ? D : 0;
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int64_t my_base = lane < F ? row_base[lane] : 0;
-    float bias_acc = 0.f;
+    // Bias gradient = scale * sum_b d_fm_logit[b].  One same-address atomic per wave (32 K of them at ~88/us on one L2
+    // channel) used to cost more than the whole scatter; block 0 now sums the B values itself, in a fixed order
+    // (deterministic), overlapped with every other block's work, and is the only writer of lin_bias.
+    if (blockIdx.x == 0 && lin_bias != nullptr && d_fm_logit != nullptr) dr_block_sum_axpy(d_fm_logit, B, scale, lin_bias);
+    if (wave0 >= B) return;
+    const int lanec = lane < F ? lane : F - 1;
+    const int64_t my_base = row_base[lanec];
+    int64_t my_row;
+    float dl;
+    {
+        const int64_t id = ids[wave0 * F + lanec];
+        const uint8_t fl = flags[wave0 * F + lanec];
+        my_row = (lane < F && id >= 0 && fl) ? my_base + id : -1;
+        dl = dlsrc[wave0];
+    }
     for (int64_t b = wave0; b < B; b += nwaves) {
-        int64_t my_row = -1;      // lane l <-> field l: absolute row if this slot is unique, else -1
-        if (lane < F) {
-            const int64_t id = ids[b * F + lane];
-            if (id >= 0 && flags[b * F + lane]) my_row = my_base + id;
-        }
-        const float dl = d_fm_logit != nullptr ? d_fm_logit[b] : 0.f;
-        if (lane == 0) bias_acc += dl;                     // bias gradient: every example once
+        const int64_t bn = b + nwaves, bnc = bn < B ? bn : b;
+        const int64_t next_id = ids[bnc * F + lanec];                    // prefetch, consumed at the loop bottom
+        const uint8_t next_fl = flags[bnc * F + lanec];
+        const float next_dl = dlsrc[bnc];
+        if (d_fm_logit == nullptr) dl = 0.f;
         const float* grow = grad + b * ld;
-        float4 sx = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (fm && dvalid) sx = *reinterpret_cast<const float4*>(sum_x + b * D + sub * 4);
+        const float4 sx = *reinterpret_cast<const float4*>(sxsrc + b * sx_pitch + subc * 4);
         for (int f0 = 0; f0 < F; f0 += NS * U) {
             int64_t row[U];
             float4 g[U], t[U];
-            float lw[U];
-            const bool do_lin = lin_w != nullptr && (d_fm_logit != nullptr || slot_lin != nullptr) && sub == 0;
+            float lw[U], gl[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int f = f0 + u * NS + slot;
-                row[u] = __shfl(my_row, f < F ? f : 0, 64);
+                const int fc = f < F ? f : F - 1;
+                row[u] = __shfl(my_row, fc, 64);
                 if (f >= F) row[u] = -1;
-                lw[u] = 0.f;
-                if (row[u] >= 0 && do_lin) lw[u] = lin_w[row[u]];      // issued with the row loads, not after them
-                if (row[u] >= 0 && dvalid) {
-                    g[u] = *reinterpret_cast<const float4*>(grow + f * D + sub * 4);
-                    t[u] = *reinterpret_cast<const float4*>(table + row[u] * D + sub * 4);
-                }
+                const int64_t rc = row[u] >= 0 ? row[u] : 0;
+                g[u] = *reinterpret_cast<const float4*>(grow + fc * D + subc * 4);
+                t[u] = *reinterpret_cast<const float4*>(table + rc * D + subc * 4);
+                lw[u] = lsrc[rc];
+                gl[u] = slot_lin != nullptr ? slot_lin[b * F + fc] : dl;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
+                float4 r = t[u];
+                if (fm) {   // unique + single-valued: the row's current value IS the forward activation x[b, f, :]
+                    g[u].x += dl * (sx.x - r.x); g[u].y += dl * (sx.y - r.y);
+                    g[u].z += dl * (sx.z - r.z); g[u].w += dl * (sx.w - r.w);
+                }
+                r.x = fmaf(scale, g[u].x, r.x); r.y = fmaf(scale, g[u].y, r.y);
+                r.z = fmaf(scale, g[u].z, r.z); r.w = fmaf(scale, g[u].w, r.w);
+                const float nl = fmaf(scale, gl[u], lw[u]);
                 if (row[u] >= 0) {
-                    if (dvalid) {
-                        float4 r = t[u];
-                        if (fm) {   // the row is unique in the batch and single-valued: its current value IS the forward
-                                    // activation x[b, f, :] (bit-for-bit), so the FM term needs no concat re-read
-                            g[u].x += dl * (sx.x - r.x); g[u].y += dl * (sx.y - r.y);
-                            g[u].z += dl * (sx.z - r.z); g[u].w += dl * (sx.w - r.w);
-                        }
-                        r.x = fmaf(scale, g[u].x, r.x); r.y = fmaf(scale, g[u].y, r.y);
-                        r.z = fmaf(scale, g[u].z, r.z); r.w = fmaf(scale, g[u].w, r.w);
-                        *reinterpret_cast<float4*>(table + row[u] * D + sub * 4) = r;
-                    }
-                    if (do_lin) {
-                        const float gl = slot_lin != nullptr ? slot_lin[b * F + f0 + u * NS + slot] : dl;
-                        lin_w[row[u]] = fmaf(scale, gl, lw[u]);
-                    }
+                    if (dvalid) *reinterpret_cast<float4*>(table + row[u] * D + sub * 4) = r;
+                    if (do_lin) lin_w[row[u]] = nl;
                 }
             }
         }
-    }
-    if (lin_bias != nullptr && d_fm_logit != nullptr) {
-        bias_acc = dr_wave_sum(bias_acc);
-        if (lane == 0 && bias_acc != 0.f) unsafeAtomicAdd(lin_bias, scale * bias_acc);
+        my_row = (bn < B && lane < F && next_id >= 0 && next_fl) ? my_base + next_id : -1;
+        dl = next_dl;
     }
 }
 

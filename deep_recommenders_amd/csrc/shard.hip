@@ -212,10 +212,9 @@ __global__ __launch_bounds__(256) void pack_grads_kernel(const int64_t* __restri
     const bool dvalid = sub * 4 < D;
     const bool fm = concat != nullptr && sum_x != nullptr && d_fm_logit != nullptr;
     const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
-    float bacc = 0.f;
+    if (blockIdx.x == 0 && bias_sum != nullptr && d_fm_logit != nullptr) dr_block_sum_axpy(d_fm_logit, B, 1.f, bias_sum);
     for (int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); b < B; b += nw) {
         const float dl = d_fm_logit != nullptr ? d_fm_logit[b] : 0.f;
-        if (lane == 0) bacc += dl;
         float4 sx = make_float4(0.f, 0.f, 0.f, 0.f);
         if (fm && dvalid) sx = *reinterpret_cast<const float4*>(sum_x + b * D + sub * 4);
         for (int f = slot; f < F; f += NS) {
@@ -231,7 +230,6 @@ __global__ __launch_bounds__(256) void pack_grads_kernel(const int64_t* __restri
             if (out_lin != nullptr && sub == 0) out_lin[p] = dl;
         }
     }
-    if (bias_sum != nullptr && lane == 0 && bacc != 0.f) unsafeAtomicAdd(bias_sum, bacc);
 }
 
 __global__ __launch_bounds__(256) void axpy_kernel(int64_t n, float alpha, const float* __restrict__ x,
