@@ -79,12 +79,17 @@ class DeepFMEngine:
         self.fold_fm = _os.environ.get("DR_FOLD_FM", "0") == "1"
         # optional: main pipeline on a high-priority stream (measured neutral-to-worse vs the side-stream sort: 2.89 vs 2.82 ms)
         self.main = torch.cuda.Stream(device=device, priority=-1) if _os.environ.get("DR_HIPRIO", "0") == "1" else None
+        # K4 (HBM-bound scatter) needs only dx_L0; dw_L0 (MFMA-bound) is independent of it: run them concurrently
+        self.overlap_k4 = sorted_bwd and _os.environ.get("DR_OVERLAP_K4", "1") == "1"
         if sorted_bwd:
             n = B * F
             self.plan = ops.SortPlan(n, device)
             self.side = torch.cuda.Stream(device=device)
             self.ev_ids = torch.cuda.Event()
             self.ev_sorted = torch.cuda.Event()
+            self.scatter = torch.cuda.Stream(device=device)
+            self.ev_dx0 = torch.cuda.Event()
+            self.ev_k4 = torch.cuda.Event()
 
     # ---- per-kernel HIP events on the launch stream (bench.py's roofline numbers) ----------------------
     def enable_kernel_events(self, on: bool):
@@ -166,20 +171,34 @@ class DeepFMEngine:
             else:
                 self._k("linear_bwd_dx_L%d" % i, "mfma", fl,
                         lambda dy=dy, W=W, rs=rs, dx=dx: ops.linear_bwd_dx(dy, W, relu_src=rs, out=dx))
+            if i == 0 and self.overlap_k4:
+                cur = torch.cuda.current_stream()
+                self.ev_dx0.record(cur)
+                with torch.cuda.stream(self.scatter):
+                    self.scatter.wait_event(self.ev_dx0)
+                    self.scatter.wait_event(self.ev_sorted)
+                    self._k("emb_pool_bwd(scatter stream, overlaps linear_bwd_dw_L0)", "overlap", self.alg_bytes_bwd(),
+                            lambda: self._k4_sorted())
+                    self.ev_k4.record(self.scatter)
             self._k("linear_bwd_dw_L%d" % i, "mfma", fl,
                     lambda x=x, dy=dy, W=W, i=i: ops.linear_bwd_dw(x, dy, -lr, W, self.bs[i], workspace=self.dw_ws[i]))
             dy = dx
+        if self.overlap_k4:
+            torch.cuda.current_stream().wait_event(self.ev_k4)
+            return
         if self.sorted_bwd:
             torch.cuda.current_stream().wait_event(self.ev_sorted)
-            self._k("emb_pool_bwd", "hbm", self.alg_bytes_bwd(),                                      # K4 (sorted)
-                    lambda: ops.emb_pool_bwd_sorted(self.ids, self.row_base, self.plan, D, self.R, self.d_concat, self.d_logit, -lr,
-                                                    self.table, self.lin_w, self.lin_bias,
-                                                    concat=None if self.fold_fm else self.concat,
-                                                    sum_x=None if self.fold_fm else self.sum_x))
+            self._k("emb_pool_bwd", "hbm", self.alg_bytes_bwd(), lambda: self._k4_sorted())            # K4 (sorted)
             return
         self._k("emb_pool_bwd", "hbm", self.alg_bytes_bwd(),                                          # K4 (atomics)
                 lambda: ops.emb_pool_bwd(self.ids, F, self.col_start, self.row_base, D, self.d_concat, self.concat,
                                          self.sum_x, self.d_logit, -lr, self.table, self.lin_w, self.lin_bias))
+
+    def _k4_sorted(self):
+        return ops.emb_pool_bwd_sorted(self.ids, self.row_base, self.plan, self.D, self.R, self.d_concat, self.d_logit,
+                                       -self.lr, self.table, self.lin_w, self.lin_bias,
+                                       concat=None if self.fold_fm else self.concat,
+                                       sum_x=None if self.fold_fm else self.sum_x)
 
     def train_step(self, keys, dense, labels):
         if self.main is None:

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Collect the round's judged profiles on the GPU box (run through gpurun):
+#   gpurun_out/prof_stats/   rocprofv3 --kernel-trace --stats of the default bench command
+#   gpurun_out/pmc_traffic.json   per-kernel HBM bytes (FETCH_SIZE / WRITE_SIZE in separate --pmc passes)
+# Copy the results into profiles/ afterwards (tools/rocpd_stats.py turns the kernel trace into a CSV summary).
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd /tmp && export TMPDIR=/tmp
+mkdir -p $R/gpurun_out
+BENCH="python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/prof_stats_bench.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$c -- $BENCH > /dev/null 2>&1
+done
+python $R/tools/pmc_traffic.py $R/gpurun_out/pmc_traffic.json $(find $R/gpurun_out/pmc_FETCH_SIZE $R/gpurun_out/pmc_WRITE_SIZE -name "*counter_collection.csv") > $R/gpurun_out/pmc_traffic.txt 2>&1
+STATS=$(find $R/gpurun_out/prof_stats -name "*kernel_stats.csv" | head -1)
+[ -n "$STATS" ] && cp "$STATS" $R/gpurun_out/kernel_stats.csv
+tail -1 $R/gpurun_out/prof_stats_bench.log | cut -c1-300

@@ -1,5 +1,9 @@
-"""Aggregate a rocprofv3 --pmc counter_collection.csv per kernel (average counter value per launch).
-Usage: python tools/pmc_traffic.py <counter_collection.csv> <out.json>"""
+"""Per-kernel HBM traffic from rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected in SEPARATE runs, as
+MI355X_MICROARCH.md's HBM section prescribes), averaged per launch and corrected for gfx950:
+FETCH_SIZE under-reports wide coalesced reads by 2x  ->  hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.
+
+Usage: python tools/pmc_traffic.py <out.json> <counter_collection.csv> [<counter_collection.csv> ...]
+"""
 import collections
 import csv
 import json
@@ -15,16 +19,30 @@ def short(name):
 
 
 def main():
+    out_path, csvs = sys.argv[1], sys.argv[2:]
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(sys.argv[1])):
-        k = r["Kernel_Name"]
-        if "at::native" in k or "rocclr" in k:
+    for path in csvs:
+        for r in csv.DictReader(open(path)):
+            k = r["Kernel_Name"]
+            if "at::native" in k or "rocclr" in k or "rocprim" in k.lower():
+                continue
+            agg[short(k)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    kernels = {}
+    for k, d in sorted(agg.items()):
+        f = d.get("FETCH_SIZE")
+        w = d.get("WRITE_SIZE")
+        if not f or not w:
             continue
-        agg[short(k)][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    out = {k: {c: {"calls": len(v), "avg": sum(v) / len(v)} for c, v in d.items()} for k, d in agg.items()}
-    json.dump(out, open(sys.argv[2], "w"), indent=1, sort_keys=True)
-    for k, d in sorted(out.items()):
-        print(k, {c: round(v["avg"], 1) for c, v in d.items()})
+        fk, wk = sum(f) / len(f), sum(w) / len(w)
+        kernels[k] = {"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "launches": len(f),
+                      "hbm_bytes_corrected": (2 * fk + wk) * 1024}
+    note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over `bench.py --steps 4 --warmup 2 "
+            "--no-cpu-baseline` (MI355X). Units KB (1024 B) per launch, averaged over launches. gfx950 correction "
+            "(MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports 1/2 of wide coalesced reads -> hbm_bytes = "
+            "(2*FETCH_SIZE + WRITE_SIZE) * 1024. Calibration: hash_bucket_i64_kernel reads 13.63 MB and writes 13.63 MB.")
+    json.dump({"_note": note, "kernels": kernels}, open(out_path, "w"), indent=1, sort_keys=True)
+    for k, v in kernels.items():
+        print("%-60s %10.1f MB" % (k, v["hbm_bytes_corrected"] / 1e6))
 
 
 if __name__ == "__main__":
