@@ -26,6 +26,11 @@ SIGNATURES = {
     "dr_linear_bwd_dx": [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _i64, _i32, _p, _i64, _p],
     "dr_linear_bwd_dw": [_p, _i64, _p, _i64, _i64, _i32, _i32, _f32, _p, _i64, _p, _p, _i64, _p],
     "dr_linear_bwd_dw_workspace_bytes": [_i64, _i32, _i32],
+    "dr_linear_bwd_narrow_workspace_bytes": [_i64, _i32, _i32],
+    "dr_tower_head_workspace_bytes": [_i64],
+    "dr_tower_head_fwd_bwd": [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _p, _i32, _f32, _p, _i64, _p, _p,
+                              _p, _i64, _p, _p, _i64, _p],
+    "dr_linear_bwd_narrow": [_p, _i64, _p, _i64, _p, _i64, _i64, _i32, _i32, _i32, _f32, _p, _i64, _p, _p, _i64, _p, _i64, _p],
     "dr_cross_fwd": [_p, _p, _i64, _p, _i64, _p, _f32, _i64, _i32, _p, _p, _p],
     "dr_cross_combine_bwd": [_p, _p, _p, _i64, _i32, _i64, _f32, _p, _p, _p, _p],
     "dr_bce_fwd_bwd": [_p, _p, _i64, _p, _i64, _i32, _p, _p, _p, _p, _p],
@@ -64,6 +69,8 @@ SIGNATURES = {
 _RESTYPE = {"dr_version": ctypes.c_char_p, "dr_shard_bucket_workspace_bytes": ctypes.c_int64,
             "dr_emb_sort_workspace_bytes": ctypes.c_int64,
             "dr_linear_bwd_dw_workspace_bytes": ctypes.c_int64,
+            "dr_linear_bwd_narrow_workspace_bytes": ctypes.c_int64,
+            "dr_tower_head_workspace_bytes": ctypes.c_int64,
             "dr_inbatch_softmax_workspace_bytes": ctypes.c_int64, "dr_topk_workspace_bytes": ctypes.c_int64}
 
 DR_OK, DR_EINVAL, DR_ELAUNCH, DR_ESHAPE = 0, -1, -2, -3

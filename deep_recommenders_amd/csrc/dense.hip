@@ -29,7 +29,8 @@ constexpr int BM = 128, BN = 128, BK = 32;   // wide configuration; the narrow o
 constexpr int LD_T = 129;   // pitch of a transposed-in operand tile
 constexpr int LD_D = 132;   // pitch of a direct operand tile
 
-enum Epi { EPI_BIAS_ACT = 0, EPI_CROSS = 1, EPI_MASK = 2, EPI_ATOMIC = 3, EPI_FMGRAD = 4, EPI_LSE = 5, EPI_SMGRAD = 6 };
+enum Epi { EPI_BIAS_ACT = 0, EPI_CROSS = 1, EPI_MASK = 2, EPI_ATOMIC = 3, EPI_FMGRAD = 4, EPI_LSE = 5, EPI_SMGRAD = 6, EPI_HEAD = 7 };
+constexpr int HEAD_PART = 34;   // per-block partials of the fused tower head: dw2[32], db2, loss
 
 struct GemmArgs {
     const float* A; int64_t lda;
@@ -59,6 +60,17 @@ struct GemmArgs {
     float* part_m; float* part_l; // LSE: partial row max / sum-exp, [2*tiles_n][M]
     float* pos;                   // LSE: s_ii
     const float* lse;             // SMGRAD: row log-sum-exp ; vec = sample_weight (or null) ; alpha = d_loss
+    // HEAD (narrow tile only): y = act(acc + bias) is the last hidden layer [M, N<=32]; logit = y . head_w + head_b + extra;
+    // loss / gradient per example (dr_bce_terms), d_h = d_logit * head_w * act'(y); C (h itself) optional
+    const float* head_w; int64_t ld_head_w;
+    const float* head_b;
+    const float* head_extra;      // [M] or null (the FM logit)
+    const float* labels;          // [M]
+    int32_t loss_mode;
+    float inv_n;
+    float* prob; float* d_logit;  // [M] (either may be null)
+    float* d_h; int64_t ld_dh;    // [M, N] or null
+    float* head_partial;          // [gridDim.x][HEAD_PART]
 };
 
 // exp() of a non-positive softmax argument; masked logits sit at ~-5e36 (MIN_FLOAT / temperature), far outside the
@@ -391,6 +403,61 @@ __global__ __launch_bounds__(256, NARROW ? 4 : 3) void gemm_f32_mfma_kernel(Gemm
         }
         return;
     }
+    if constexpr (EPI == EPI_HEAD && NARROW) {
+        // Fused tower head (the Dense(1) that follows the last hidden layer, the loss, and their backward):
+        // lane (col, half) holds 16 rows of column col of y; the Dense(1) dot product is a butterfly over the 32 columns.
+        const int col = lane & 31, hh = lane >> 5;
+        const bool cv = col < g.N;
+        const int colc = cv ? col : g.N - 1;
+        const float bj = g.bias != nullptr ? g.bias[colc] : 0.f;
+        const float wj = cv ? g.head_w[(int64_t)colc * g.ld_head_w] : 0.f;
+        const float b2 = g.head_b != nullptr ? g.head_b[0] : 0.f;
+        const int64_t row_b = m0 + wm * 32 + 4 * hh;
+        float dw_acc = 0.f, db_acc = 0.f, loss_acc = 0.f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int ro = (reg & 3) + 8 * (reg >> 2);
+            const int64_t row = row_b + ro;
+            const bool rv = row < g.M;
+            const int64_t rc = rv ? row : g.M - 1;
+            float v = acc[0][0][reg] + bj;
+            if (g.act == 1) v = fmaxf(v, 0.f);
+            if (!cv) v = 0.f;
+            float dot = v * wj;
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) dot += __shfl_xor(dot, o, 64);
+            const float x = (dot + b2) + (g.head_extra != nullptr ? g.head_extra[rc] : 0.f);
+            float p, l, gr;
+            dr_bce_terms(x, g.labels[rc], g.loss_mode, p, l, gr);
+            float gs = gr * g.inv_n;
+            if (!rv) { l = 0.f; gs = 0.f; }
+            if (rv && col == 0) {
+                if (g.prob != nullptr) g.prob[row] = p;
+                if (g.d_logit != nullptr) g.d_logit[row] = gs;
+            }
+            if (rv && cv) {
+                if (g.d_h != nullptr) g.d_h[row * g.ld_dh + col] = (g.act == 1 && !(v > 0.f)) ? 0.f : gs * wj;
+                if (g.C != nullptr) g.C[row * g.ldc + col] = v;
+            }
+            dw_acc = fmaf(v, gs, dw_acc);
+            if (col == 0) { db_acc += gs; loss_acc += l; }
+        }
+        __syncthreads();                                   // every wave is done with the operand tiles
+        float* red = smem;                                 // [8 = wave * 2 + half][HEAD_PART]
+        red[(wave * 2 + hh) * HEAD_PART + col] = dw_acc;
+        if (col == 0) {
+            red[(wave * 2 + hh) * HEAD_PART + 32] = db_acc;
+            red[(wave * 2 + hh) * HEAD_PART + 33] = loss_acc;
+        }
+        __syncthreads();
+        if (tid < HEAD_PART) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sacc += red[i * HEAD_PART + tid];
+            g.head_partial[(int64_t)blockIdx.x * HEAD_PART + tid] = sacc;
+        }
+        return;
+    }
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const bool full = (m0 + BM <= g.M) && (n0 + BN <= g.N);
 #pragma unroll
@@ -450,17 +517,18 @@ template <bool A_RC, bool B_RC, int EPI>
 int launch(GemmArgs& g, hipStream_t s) {
     g.a_vec = ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0 && (g.lda & 3) == 0) ? 1 : 0;
     g.b_vec = ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0 && (g.ldb & 3) == 0) ? 1 : 0;
-    const bool narrow = g.N <= 32 && (EPI == EPI_BIAS_ACT || EPI == EPI_MASK || EPI == EPI_ATOMIC);
+    const bool narrow = g.N <= 32 && (EPI == EPI_BIAS_ACT || EPI == EPI_MASK || EPI == EPI_ATOMIC || EPI == EPI_HEAD);
     const int bn = narrow ? 32 : BN;
     const int tiles_n = (g.N + bn - 1) / bn;
     const int64_t tiles_m = (g.M + BM - 1) / BM;
     if (tiles_m * tiles_n > 0x7fffffff) return DR_EINVAL;
     dim3 grid((unsigned)(tiles_m * tiles_n), EPI == EPI_ATOMIC ? g.split : 1);
     if (narrow) {
-        if constexpr (EPI == EPI_BIAS_ACT || EPI == EPI_MASK || EPI == EPI_ATOMIC)
+        if constexpr (EPI == EPI_BIAS_ACT || EPI == EPI_MASK || EPI == EPI_ATOMIC || EPI == EPI_HEAD)
             hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_RC, B_RC, EPI, true>), grid, dim3(256), 0, s, g);
     } else {
-        hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_RC, B_RC, EPI, false>), grid, dim3(256), 0, s, g);
+        if constexpr (EPI == EPI_HEAD) return DR_ESHAPE;
+        else hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_RC, B_RC, EPI, false>), grid, dim3(256), 0, s, g);
     }
     DR_CHECK_LAUNCH();
     return DR_OK;
@@ -615,6 +683,79 @@ bool bad_ld(int64_t ld, int64_t min) { return ld < min; }
 bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3) != 0; }
 
 }  // namespace
+
+// w2[n] += scale * sum_b partial[b][n] ; b2 += scale * sum_b partial[b][32] ; loss = inv_n * sum_b partial[b][33].
+// Fixed summation order.  7 groups of 34 threads stride over the blocks with 8 loads in flight each: a plain
+// "acc += partial[b]" loop is a chain of dependent L2 round trips (128 of them cost ~45 us for a 70 KB reduction).
+__global__ __launch_bounds__(256) void head_finish_kernel(const float* __restrict__ partial, int32_t nblocks, int32_t N,
+                                                          float scale, float inv_n, float* __restrict__ w2,
+                                                          int64_t ldw2, float* __restrict__ b2,
+                                                          float* __restrict__ loss_out) {
+    constexpr int NG = 7;
+    __shared__ float red[NG][HEAD_PART];
+    const int grp = threadIdx.x / HEAD_PART, c = threadIdx.x % HEAD_PART;
+    if (grp < NG) {
+        float acc = 0.f;
+        for (int b0 = grp; b0 < nblocks; b0 += NG * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int b = b0 + u * NG;
+                v[u] = partial[(int64_t)(b < nblocks ? b : b0) * HEAD_PART + c];
+                if (b >= nblocks) v[u] = 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        red[grp][c] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < HEAD_PART) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int g2 = 0; g2 < NG; ++g2) sacc += red[g2][c];
+        if (c < 32) {
+            if (c < N && w2 != nullptr && scale != 0.f) w2[(int64_t)c * ldw2] = fmaf(scale, sacc, w2[(int64_t)c * ldw2]);
+        } else if (c == 32) {
+            if (b2 != nullptr && scale != 0.f) b2[0] = fmaf(scale, sacc, b2[0]);
+        } else if (loss_out != nullptr) {
+            loss_out[0] = sacc * inv_n;
+        }
+    }
+}
+
+extern "C" int64_t dr_tower_head_workspace_bytes(int64_t M) {
+    const int64_t tiles = (M + BM - 1) / BM;
+    return (tiles > 0 ? tiles : 1) * HEAD_PART * (int64_t)sizeof(float);
+}
+
+extern "C" int dr_tower_head_fwd_bwd(const float* x, int64_t ld_x, const float* W1, int64_t ld_w1, const float* b1,
+                                     int64_t M, int32_t K, int32_t H, int32_t act, float* w2, int64_t ld_w2, float* b2,
+                                     const float* extra_logit, const float* labels, int32_t loss_mode, float scale,
+                                     float* h_out, int64_t ld_h, float* prob, float* d_logit, float* d_h, int64_t ld_dh,
+                                     float* loss_out, void* workspace, int64_t workspace_bytes, dr_stream_t stream) {
+    if (M <= 0 || K <= 0 || H <= 0) return DR_EINVAL;
+    if (H > 32) return DR_ESHAPE;
+    if (!x || !W1 || !w2 || !labels || !workspace || loss_mode < 0 || loss_mode > 2) return DR_EINVAL;
+    if (ld_x < K || ld_w1 < H || ld_w2 < 1 || (h_out && ld_h < H) || (d_h && ld_dh < H)) return DR_EINVAL;
+    if (workspace_bytes < dr_tower_head_workspace_bytes(M)) return DR_EINVAL;
+    GemmArgs g{};
+    g.A = x; g.lda = ld_x; g.B = W1; g.ldb = ld_w1; g.M = M; g.N = H; g.R = K;
+    g.C = h_out; g.ldc = ld_h;
+    g.bias = b1; g.act = act;
+    g.head_w = w2; g.ld_head_w = ld_w2; g.head_b = b2; g.head_extra = extra_logit; g.labels = labels;
+    g.loss_mode = loss_mode; g.inv_n = 1.f / (float)M;
+    g.prob = prob; g.d_logit = d_logit; g.d_h = d_h; g.ld_dh = ld_dh;
+    g.head_partial = static_cast<float*>(workspace);
+    g.split = 1;
+    int rc = launch<true, false, EPI_HEAD>(g, dr_s(stream));
+    if (rc != DR_OK) return rc;
+    const int nblocks = (int)((M + BM - 1) / BM);
+    hipLaunchKernelGGL(head_finish_kernel, dim3(1), dim3(256), 0, dr_s(stream), g.head_partial, nblocks, H, scale, g.inv_n, w2,
+                       ld_w2, b2, loss_out);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
 
 extern "C" int dr_linear_fwd(const float* x, int64_t ld_x, const float* W, int64_t ld_w, const float* b, int64_t M,
                              int32_t K, int32_t N, int32_t act, float* y, int64_t ld_y, dr_stream_t stream) {

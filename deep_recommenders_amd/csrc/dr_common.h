@@ -28,6 +28,29 @@ __device__ __forceinline__ float dr_wave_sum(float v) {
     return v;
 }
 
+// Binary cross-entropy terms of one example, logit x, label z (shared by the stand-alone loss kernel and the fused tower
+// head).  mode 0: [TF] sigmoid_cross_entropy_with_logits  max(x,0) - x z + log1p(exp(-|x|)) ; mode 1: tf.losses.log_loss
+// on p = sigmoid(x) (eps 1e-7) ; mode 2: keras binary_crossentropy (p clipped to [eps, 1-eps] first).  Outputs the
+// probability, the loss term and d(loss term)/dx.
+__device__ __forceinline__ void dr_bce_terms(float x, float z, int mode, float& p, float& l, float& g) {
+    p = 1.f / (1.f + expf(-x));
+    if (mode == 0) {
+        l = fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x)));
+        g = p - z;
+    } else {
+        const float eps = 1e-7f;
+        float pc = p;
+        float dclip = 1.f;
+        if (mode == 2) {
+            if (p < eps) { pc = eps; dclip = 0.f; }
+            else if (p > 1.f - eps) { pc = 1.f - eps; dclip = 0.f; }
+        }
+        l = -z * logf(pc + eps) - (1.f - z) * logf(1.f - pc + eps);
+        const float dl_dp = -z / (pc + eps) + (1.f - z) / (1.f - pc + eps);
+        g = dl_dp * dclip * p * (1.f - p);
+    }
+}
+
 // dst[0] += alpha * sum_{i<n} x[i], computed by ONE 256-thread block in a fixed order (deterministic) and written
 // with a plain read-modify-write: the caller guarantees this block is the only writer of dst during the kernel.
 // Replaces "one same-address atomic per wave": tens of thousands of those serialise on a single L2 channel

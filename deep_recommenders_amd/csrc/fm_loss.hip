@@ -64,25 +64,8 @@ __global__ __launch_bounds__(256) void bce_stage1(const float* __restrict__ logi
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const float x = logits[i] + (logits_b != nullptr ? logits_b[i * ldb] : 0.f), z = labels[i];
-        const float p = sigmoidf_(x);
-        float l, g;
-        if (mode == 0) {
-            // [TF] B9: max(x,0) - x*z + log1p(exp(-|x|));  d/dx = sigmoid(x) - z
-            l = fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x)));
-            g = p - z;
-        } else {
-            const float eps = 1e-7f;
-            // [TF] B10 log_loss on p ; B11 keras bce additionally clips p to [eps, 1-eps] first
-            float pc = p;
-            float dclip = 1.f;
-            if (mode == 2) {
-                if (p < eps) { pc = eps; dclip = 0.f; }
-                else if (p > 1.f - eps) { pc = 1.f - eps; dclip = 0.f; }
-            }
-            l = -z * logf(pc + eps) - (1.f - z) * logf(1.f - pc + eps);
-            const float dl_dp = -z / (pc + eps) + (1.f - z) / (1.f - pc + eps);
-            g = dl_dp * dclip * p * (1.f - p);
-        }
+        float p, l, g;
+        dr_bce_terms(x, z, mode, p, l, g);      // [TF] B9 / B10 / B11
         acc += l;
         if (prob != nullptr) prob[i] = p;
         if (d_logit != nullptr) d_logit[i] = g * inv_n;

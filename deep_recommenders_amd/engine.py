@@ -52,8 +52,20 @@ class DeepFMEngine:
             self.Ws.append(W[:, :u])
             self.bs.append(torch.zeros(u, dtype=torch.float32, device=device))
             d = u
+        import os as _os
         self.acts = [1] * len(dnn_units) + [0]
         self.dw_ws = [ops.linear_bwd_dw_workspace(B, W.shape[0], W.shape[1], device) for W in self.Ws]
+        # narrow layers (N <= 32, K in {128,256,512}) below the first: dx + dW + db fused in one pass over the activations
+        self.fuse_narrow = _os.environ.get("DR_FUSE_NARROW", "1") == "1"
+        # last hidden layer (<= 32 units, relu) + Dense(1) + loss + Dense(1) backward fused into one GEMM epilogue
+        nl = len(self.Ws)
+        self.fuse_head = (_os.environ.get("DR_FUSE_HEAD", "1") == "1" and nl >= 2 and self.Ws[-1].shape[1] == 1
+                          and self.Ws[-2].shape[1] <= 32 and self.acts[-2] == 1)
+        self.head_ws = ops.tower_head_workspace(B, device) if self.fuse_head else None
+        self._head_done = False
+        self.narrow_ws = [ops.linear_bwd_narrow_workspace(B, W.shape[0], W.shape[1], device)
+                          if (i > 0 and self.acts[i - 1] and ops.linear_bwd_narrow_supported(B, W.shape[0], W.shape[1])) else None
+                          for i, W in enumerate(self.Ws)]
         # ---- constant metadata ---------------------------------------------------------------------
         self.row_base = torch.arange(F, device=device, dtype=torch.int64) * V
         self.col_start = torch.arange(F + 1, device=device, dtype=torch.int32)
@@ -74,20 +86,22 @@ class DeepFMEngine:
         self._events = None      # name -> [bound, work, [(start, end), ...]]
         # ---- deterministic backward: slots sorted by table row on a side stream (depends only on ids) ----
         self.sorted_bwd = sorted_bwd
-        import os as _os
         self.sort_inline = _os.environ.get("DR_SORT_INLINE", "0") == "1"
         self.fold_fm = _os.environ.get("DR_FOLD_FM", "0") == "1"
         # optional: main pipeline on a high-priority stream (measured neutral-to-worse vs the side-stream sort: 2.89 vs 2.82 ms)
         self.main = torch.cuda.Stream(device=device, priority=-1) if _os.environ.get("DR_HIPRIO", "0") == "1" else None
-        # K4 (HBM-bound scatter) needs only dx_L0; dw_L0 (MFMA-bound) is independent of it: run them concurrently
-        self.overlap_k4 = sorted_bwd and _os.environ.get("DR_OVERLAP_K4", "1") == "1"
+        # K4 (HBM-bound scatter) needs only dx_L0; dw_L0 (MFMA-bound) is independent of it: they can run concurrently.
+        # Measured: a win (2.59 -> 2.53 ms) before K4 was fixed, neutral-to-worse after (2.35 vs 2.39 ms) -> off by default.
+        # where the side-stream sort starts: 'bwd' = before the first-layer dgrad (hidden under dx_L0 / dw_L0)
+        self.sort_at = _os.environ.get("DR_SORT_AT", "fwd")
+        self.overlap_k4 = sorted_bwd and _os.environ.get("DR_OVERLAP_K4", "0") == "1"
         if sorted_bwd:
             n = B * F
             self.plan = ops.SortPlan(n, device)
-            self.side = torch.cuda.Stream(device=device)
+            self.side = torch.cuda.Stream(device=device, priority=-1 if _os.environ.get("DR_SORT_HIPRIO", "0") == "1" else 0)
             self.ev_ids = torch.cuda.Event()
             self.ev_sorted = torch.cuda.Event()
-            self.scatter = torch.cuda.Stream(device=device)
+            self.scatter = torch.cuda.Stream(device=device, priority=-1 if _os.environ.get("DR_SCATTER_HIPRIO", "0") == "1" else 0)
             self.ev_dx0 = torch.cuda.Event()
             self.ev_k4 = torch.cuda.Event()
 
@@ -121,28 +135,38 @@ class DeepFMEngine:
         B = self.B
         self._k("hash_bucket_i64", "hbm", B * F * 16,
                 lambda: ops.hash_bucket_i64(keys, self.col_buckets, out=self.ids))                    # K1
+        if self.sorted_bwd and not self.sort_inline and self.sort_at == "hash":
+            self._launch_sort()
         if self.sorted_bwd and self.sort_inline:
             self._k("emb_sort_slots", "hbm", B * F * 36,
                     lambda: ops.emb_sort_slots(self.ids, self.row_base, self.R, self.plan))
             self.ev_sorted.record()
-        elif self.sorted_bwd:
-            self.ev_ids.record()
-            with torch.cuda.stream(self.side):
-                self.side.wait_event(self.ev_ids)
-                self._k("emb_sort_slots(side stream, overlapped)", "overlap", B * F * 36,
-                        lambda: ops.emb_sort_slots(self.ids, self.row_base, self.R, self.plan))
-                self.ev_sorted.record(self.side)
         self._k("emb_pool_fwd", "hbm", self.alg_bytes_fwd(),                                          # K3+K5+K6
                 lambda: ops.emb_pool_fwd(self.ids, F, None, self.row_base, self.table, self.lin_w, self.lin_bias,
                                          ld_concat=self.ld, concat=self.concat, sum_x=self.sum_x,
                                          fm_logit=self.fm_logit))
+        if self.sorted_bwd and not self.sort_inline and self.sort_at == "fwd":
+            self._launch_sort()
         if self.Nd:
             self.concat[:, F * D:F * D + self.Nd].copy_(dense)                         # layout: append dense feats
         x = self.concat[:, :self.in_dim]
+        head = self.fuse_head and labels is not None
+        nl = len(self.Ws)
         for i, (W, b) in enumerate(zip(self.Ws, self.bs)):                             # K7
+            if head and i == nl - 2:
+                break
             self._k("linear_fwd_L%d" % i, "mfma", 2.0 * B * W.shape[0] * W.shape[1],
                     lambda x=x, W=W, b=b, i=i: ops.linear_fwd(x, W, b, self.acts[i], out=self.hs[i]))
             x = self.hs[i]
+        self._head_done = head
+        if head:
+            # K7 tail + K11: Dense(H<=32, relu), Dense(1), + FM logit, loss, d_logit, d_h and the Dense(1) SGD step
+            W1, W2 = self.Ws[-2], self.Ws[-1]
+            self._k("tower_head_fwd_bwd", "hbm", 4.0 * B * (W1.shape[0] + W1.shape[1] + 4),
+                    lambda x=x, W1=W1, W2=W2: ops.tower_head_fwd_bwd(
+                        x, W1, self.bs[-2], W2, self.bs[-1], self.fm_logit, labels, loss_mode, -self.lr, act=1,
+                        prob=self.prob, d_logit=self.d_logit, d_h=self.dhs[-1], loss=self.loss, workspace=self.head_ws))
+            return self.prob
         if labels is None:
             labels = self.prob   # dummy, loss ignored
         ops.bce_fwd_bwd(self.fm_logit, labels, loss_mode, workspace=self.ws, logits_b=self.hs[-1],    # K11
@@ -153,7 +177,11 @@ class DeepFMEngine:
         F, D, lr = self.F, self.D, self.lr
         n = len(self.Ws)
         dy = self.d_logit.reshape(-1, 1)                  # d(mean loss)/d logit == pre-activation grad of Dense(1)
-        for i in range(n - 1, -1, -1):
+        top = n - 1
+        if self._head_done:                               # Dense(1) backward + SGD already done by the fused head
+            top = n - 2
+            dy = self.dhs[-1]
+        for i in range(top, -1, -1):
             x = self.concat[:, :self.in_dim] if i == 0 else self.hs[i - 1]
             W = self.Ws[i]
             # dx first (uses the pre-update W), then the fused SGD wgrad
@@ -164,6 +192,14 @@ class DeepFMEngine:
             else:
                 dx = self.d_concat[:, :self.in_dim]
                 rs = None
+            if i > 0 and self.fuse_narrow and self.narrow_ws[i] is not None:
+                self._k("linear_bwd_narrow_L%d" % i, "hbm", 4.0 * self.B * (2 * W.shape[0] + W.shape[1]),
+                        lambda x=x, dy=dy, W=W, dx=dx, i=i: ops.linear_bwd_narrow(x, dy, W, -lr, W, self.bs[i], dx, relu_mask=True,
+                                                                                 workspace=self.narrow_ws[i]))
+                dy = dx
+                continue
+            if i == 0 and self.sorted_bwd and not self.sort_inline and self.sort_at != "fwd":
+                self._launch_sort()
             if i == 0 and self.sorted_bwd and self.fold_fm:   # FM gradient folded into the dgrad epilogue (measured: slower)
                 self._k("linear_bwd_dx_L0", "mfma", fl,
                         lambda dy=dy, W=W, dx=dx: ops.linear_bwd_dx_fm(dy, W, self.d_logit, self.sum_x, self.concat, D,
@@ -193,6 +229,17 @@ class DeepFMEngine:
         self._k("emb_pool_bwd", "hbm", self.alg_bytes_bwd(),                                          # K4 (atomics)
                 lambda: ops.emb_pool_bwd(self.ids, F, self.col_start, self.row_base, D, self.d_concat, self.concat,
                                          self.sum_x, self.d_logit, -lr, self.table, self.lin_w, self.lin_bias))
+
+    def _launch_sort(self):
+        # The sort depends only on ids and is needed only by K4.  It is HBM-bound like K3 and, at low occupancy next to
+        # a GEMM, long (~690 us vs 167 us alone): started with the forward it stretched first K3, then (moved after K3)
+        # the small tail kernels; started here, before the first-layer dgrad, it hides under dx_L0 / dw_L0.
+        self.ev_ids.record()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.ev_ids)
+            self._k("emb_sort_slots(side stream, overlapped)", "overlap", self.B * self.F * 36,
+                    lambda: ops.emb_sort_slots(self.ids, self.row_base, self.R, self.plan))
+            self.ev_sorted.record(self.side)
 
     def _k4_sorted(self):
         return ops.emb_pool_bwd_sorted(self.ids, self.row_base, self.plan, self.D, self.R, self.d_concat, self.d_logit,

@@ -191,6 +191,58 @@ def linear_bwd_dw(x, dy, scale, dstW, dstb=None, workspace=None):
                                  workspace.numel() * 4 if workspace is not None else 0, stream_ptr()), "dr_linear_bwd_dw")
 
 
+def linear_bwd_narrow_supported(M, K, N):
+    """Shape domain of the fused narrow-layer backward (dr_linear_bwd_narrow)."""
+    return N <= 32 and K in (128, 256, 512) and M > 0 and M % 32 == 0
+
+
+def linear_bwd_narrow_workspace(M, K, N, device):
+    return torch.empty(max(64, lib().dr_linear_bwd_narrow_workspace_bytes(int(M), int(K), int(N)) // 4),
+                       dtype=torch.float32, device=device)
+
+
+def linear_bwd_narrow(x, dy, W, scale, dstW, dstb, dx, relu_mask=True, workspace=None):
+    """One pass over x: dx = (dy @ W^T) * (x > 0 if relu_mask); dstW += scale * x^T dy; dstb += scale * colsum(dy).
+    dx uses the pre-update W even when dstW is W.  Raises RuntimeError(DR_ESHAPE) outside the kernel's domain."""
+    M, K = x.shape
+    N = dy.shape[1]
+    assert x.stride(1) == 1 and dy.stride(1) == 1 and W.stride(1) == 1 and dstW.stride(1) == 1 and dx.stride(1) == 1
+    assert W.shape == (K, N) and dstW.shape == (K, N) and dx.shape == (M, K)
+    if workspace is None:
+        workspace = linear_bwd_narrow_workspace(M, K, N, x.device)
+    check(lib().dr_linear_bwd_narrow(ptr(x), x.stride(0), ptr(dy), dy.stride(0), ptr(W), W.stride(0), M, K, N,
+                                     1 if relu_mask else 0, float(scale), ptr(dstW), dstW.stride(0), ptr(dstb), ptr(dx),
+                                     dx.stride(0), ptr(workspace), workspace.numel() * 4, stream_ptr()),
+          "dr_linear_bwd_narrow")
+    return dx
+
+
+def tower_head_workspace(M, device):
+    return torch.empty(max(64, lib().dr_tower_head_workspace_bytes(int(M)) // 4), dtype=torch.float32, device=device)
+
+
+def tower_head_fwd_bwd(x, W1, b1, W2, b2, extra_logit, labels, loss_mode, scale, act=1, h_out=None, prob=None, d_logit=None,
+                       d_h=None, loss=None, workspace=None):
+    """Last hidden layer (H <= 32) + Dense(1) + extra logit + BCE loss + the Dense(1) backward with its SGD step, fused.
+    W2: [H, 1] (any row stride).  Returns (loss, prob, d_logit, d_h)."""
+    M, K = x.shape
+    H = W1.shape[1]
+    dev = x.device
+    assert x.stride(1) == 1 and W1.stride(1) == 1 and W2.shape == (H, 1)
+    prob = prob if prob is not None else torch.empty(M, dtype=torch.float32, device=dev)
+    d_logit = d_logit if d_logit is not None else torch.empty(M, dtype=torch.float32, device=dev)
+    d_h = d_h if d_h is not None else torch.empty((M, _pad4(H)), dtype=torch.float32, device=dev)[:, :H]
+    loss = loss if loss is not None else torch.empty(1, dtype=torch.float32, device=dev)
+    if workspace is None:
+        workspace = tower_head_workspace(M, dev)
+    check(lib().dr_tower_head_fwd_bwd(ptr(x), x.stride(0), ptr(W1), W1.stride(0), ptr(b1), M, K, H, int(act), ptr(W2),
+                                      W2.stride(0), ptr(b2), ptr(extra_logit), ptr(labels), int(loss_mode), float(scale),
+                                      ptr(h_out), h_out.stride(0) if h_out is not None else 0, ptr(prob), ptr(d_logit),
+                                      ptr(d_h), d_h.stride(0), ptr(loss), ptr(workspace), workspace.numel() * 4,
+                                      stream_ptr()), "dr_tower_head_fwd_bwd")
+    return loss, prob, d_logit, d_h
+
+
 def cross_fwd(x0, x, W, b, diag_scale=0.0, want_prod=False, prod=None):
     """out = x0 * (x @ W + b + diag*x) + x.  W None: `prod` holds x @ W (low-rank path) and is finished in place."""
     x0 = _rowmajor_ld4(x0)

@@ -189,6 +189,35 @@ int64_t dr_linear_bwd_dw_workspace_bytes(int64_t M, int32_t K, int32_t N);
 int dr_linear_bwd_dw(const float* x, int64_t ld_x, const float* dy, int64_t ld_dy, int64_t M,
                      int32_t K, int32_t N, float scale, float* dstW, int64_t ld_w, float* dstb,
                      float* workspace, int64_t workspace_bytes, dr_stream_t stream);
+/* Fused backward of a NARROW layer (N <= 32, e.g. the Dense(32) that precedes Dense(1) in the reference's
+ * towers, keras/models/ranking/deepfm.py:30-34, estimator/models/feature_interaction/dnn.py:17-29): one pass over x
+ * produces  dx = (dy @ W^T) * (x > 0 if relu_mask)  and the fused SGD step  dstW += scale * x^T dy,
+ * dstb += scale * colsum(dy)  (dx uses the pre-update W even when dstW == W).  Deterministic.
+ * Domain: N <= 32, K in {128, 256, 512}, M a multiple of 32, x/dx rows 4*(K/128)-byte aligned; anything else returns
+ * DR_ESHAPE and the caller uses dr_linear_bwd_dx + dr_linear_bwd_dw. */
+int64_t dr_linear_bwd_narrow_workspace_bytes(int64_t M, int32_t K, int32_t N);
+int dr_linear_bwd_narrow(const float* x, int64_t ld_x, const float* dy, int64_t ld_dy, const float* W,
+                         int64_t ld_w, int64_t M, int32_t K, int32_t N, int32_t relu_mask, float scale,
+                         float* dstW, int64_t ld_dstw, float* dstb, float* dx, int64_t ld_dx,
+                         void* workspace, int64_t workspace_bytes, dr_stream_t stream);
+
+/* Fused tower head: the last hidden layer (H <= 32 units), the Dense(1) output that follows it, the FM logit, the loss,
+ * and the backward of the Dense(1) -- i.e. keras/models/ranking/deepfm.py:30-34,41-47 `Dense(32, relu)`, `Dense(1)`,
+ * `sigmoid(fm + dnn)` plus the loss of examples/train_deepfm_on_movielens_keras.py:43 /
+ * examples/train_deepfm_on_movielens_estimator.py:47, in one GEMM launch:
+ *   h      = act(x @ W1 + b1)                       [M, H]   (written to h_out if not NULL)
+ *   logit  = h @ w2 + b2 + extra_logit              [M]      (w2[n] at w2[n * ld_w2]; extra_logit may be NULL)
+ *   prob, loss, d_logit = BCE(logit, labels, loss_mode) as dr_bce_fwd_bwd  (d_logit = d mean-loss / d logit)
+ *   d_h    = d_logit (x) w2 * act'(h)               [M, H]   (gradient for dr_linear_bwd_narrow / _bwd_dx)
+ *   w2    += scale * h^T d_logit ;  b2 += scale * sum(d_logit)   (fused SGD; scale = 0 leaves them untouched;
+ *                                                                 d_h always uses the pre-update w2)
+ * Deterministic.  H > 32 returns DR_ESHAPE (use dr_linear_fwd x2 + dr_bce_fwd_bwd + dr_linear_bwd_*). */
+int64_t dr_tower_head_workspace_bytes(int64_t M);
+int dr_tower_head_fwd_bwd(const float* x, int64_t ld_x, const float* W1, int64_t ld_w1, const float* b1,
+                          int64_t M, int32_t K, int32_t H, int32_t act, float* w2, int64_t ld_w2, float* b2,
+                          const float* extra_logit, const float* labels, int32_t loss_mode, float scale,
+                          float* h_out, int64_t ld_h, float* prob, float* d_logit, float* d_h, int64_t ld_dh,
+                          float* loss_out, void* workspace, int64_t workspace_bytes, dr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K8  DCN cross layer (keras/models/ranking/dcn.py:70-88):

@@ -215,6 +215,100 @@ def test_linear_fwd_bwd(ops, M, K, N, act):
         np.testing.assert_allclose(db.cpu().numpy(), dy.astype(np.float64).sum(0), rtol=0, atol=1e-5 * np.sqrt(M) * 4)
 
 
+@pytest.mark.parametrize("M,K,N,mask", [(32, 128, 32, True), (96, 256, 32, True), (4096, 256, 32, True),
+                                          (640, 256, 17, False), (2048, 512, 32, True), (64, 128, 1, True),
+                                          (32 * 700, 256, 32, True)])
+def test_linear_bwd_narrow_fused(ops, M, K, N, mask):
+    """Fused dx + dW + db of a narrow layer == the two-kernel path's definition (fp64 reference), in-place SGD on W."""
+    rng = np.random.default_rng(31)
+    x = np.maximum(rng.standard_normal((M, K)), 0).astype(np.float32)        # post-ReLU activations (zeros included)
+    dy = rng.standard_normal((M, N)).astype(np.float32)
+    W = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    scale = -0.01
+    ldn = (N + 3) // 4 * 4
+    Wd = torch.zeros((K, ldn), device="cuda")[:, :N]
+    Wd.copy_(_dev(W))
+    bd = _dev(b).clone()
+    dyd = torch.zeros((M, ldn), device="cuda")[:, :N]
+    dyd.copy_(_dev(dy))
+    dx = torch.full((M, K), 7.0, device="cuda")
+    ops.linear_bwd_narrow(_dev(x), dyd, Wd, scale, Wd, bd, dx, relu_mask=mask)
+    want_dx = dy.astype(np.float64) @ W.T.astype(np.float64)
+    if mask:
+        want_dx = want_dx * (x > 0)
+    np.testing.assert_allclose(dx.cpu().numpy(), want_dx, rtol=0, atol=2e-6 * np.sqrt(N) * (np.abs(want_dx).max() + 1))
+    gW = x.T.astype(np.float64) @ dy.astype(np.float64)
+    np.testing.assert_allclose(Wd.cpu().numpy(), W + scale * gW, rtol=0,
+                               atol=abs(scale) * 4e-6 * np.sqrt(M) * (np.abs(gW).max() + 1) + 1e-7)
+    gb = dy.astype(np.float64).sum(0)
+    np.testing.assert_allclose(bd.cpu().numpy(), b + scale * gb, rtol=0, atol=abs(scale) * 1e-5 * np.sqrt(M) * 4 + 1e-6)
+    # deterministic: a second run from the same inputs gives the same bits
+    Wd2 = torch.zeros((K, ldn), device="cuda")[:, :N]
+    Wd2.copy_(_dev(W))
+    bd2 = _dev(b).clone()
+    dx2 = torch.empty((M, K), device="cuda")
+    ops.linear_bwd_narrow(_dev(x), dyd, Wd2, scale, Wd2, bd2, dx2, relu_mask=mask)
+    assert torch.equal(Wd, Wd2) and torch.equal(bd, bd2) and torch.equal(dx, dx2)
+
+
+def test_linear_bwd_narrow_shape_contract(ops):
+    x = torch.zeros((40, 256), device="cuda")
+    dy = torch.zeros((40, 32), device="cuda")
+    W = torch.zeros((256, 32), device="cuda")
+    assert not ops.linear_bwd_narrow_supported(40, 256, 32) and not ops.linear_bwd_narrow_supported(64, 200, 32)
+    assert not ops.linear_bwd_narrow_supported(64, 256, 33) and ops.linear_bwd_narrow_supported(64, 256, 32)
+    with pytest.raises(RuntimeError, match="DR_ESHAPE"):
+        ops.linear_bwd_narrow(x, dy, W, -0.1, W, None, torch.empty_like(x))
+
+
+@pytest.mark.parametrize("M,K,H,mode", [(128, 256, 32, 0), (1000, 256, 32, 0), (4096 + 77, 64, 32, 1), (513, 100, 17, 2),
+                                         (65536, 256, 32, 0)])
+def test_tower_head_fused(ops, M, K, H, mode):
+    """Fused Dense(H, relu) + Dense(1) + extra logit + BCE + Dense(1) backward/SGD == the op-by-op definition."""
+    rng = np.random.default_rng(41)
+    x = np.maximum(rng.standard_normal((M, K)), 0).astype(np.float32)
+    W1 = (rng.standard_normal((K, H)) / np.sqrt(K)).astype(np.float32)
+    b1 = (rng.standard_normal(H) * 0.1).astype(np.float32)
+    w2 = (rng.standard_normal((H, 1)) / np.sqrt(H)).astype(np.float32)
+    b2 = np.array([0.05], np.float32)
+    extra = rng.standard_normal(M).astype(np.float32)
+    z = (rng.random(M) < 0.3).astype(np.float32)
+    scale = -0.05
+    W2d = torch.zeros((H, 4), device="cuda")[:, :1]
+    W2d.copy_(_dev(w2))
+    b2d = _dev(b2).clone()
+    xd = torch.zeros((M, (K + 3) // 4 * 4), device="cuda")[:, :K]
+    xd.copy_(_dev(x))
+    h_out = torch.empty((M, (H + 3) // 4 * 4), device="cuda")[:, :H]
+    loss, prob, d_logit, d_h = ops.tower_head_fwd_bwd(xd, _dev(W1), _dev(b1), W2d, b2d, _dev(extra), _dev(z), mode, scale,
+                                                       h_out=h_out)
+    # fp64 reference through torch autograd
+    tx = torch.tensor(x, dtype=torch.float64)
+    tW1 = torch.tensor(W1, dtype=torch.float64)
+    tw2 = torch.tensor(w2, dtype=torch.float64, requires_grad=True)
+    tb2 = torch.tensor(b2, dtype=torch.float64, requires_grad=True)
+    pre = (tx @ tW1 + torch.tensor(b1, dtype=torch.float64)).requires_grad_(True)
+    h = torch.relu(pre)
+    logit = (h @ tw2).reshape(-1) + tb2 + torch.tensor(extra, dtype=torch.float64)
+    logit.retain_grad()
+    tz = torch.tensor(z, dtype=torch.float64)
+    if mode == 0:
+        lo = T.sigmoid_cross_entropy(tz, logit)
+    elif mode == 1:
+        lo = T.log_loss(tz, torch.sigmoid(logit))
+    else:
+        lo = T.keras_bce(tz, torch.sigmoid(logit))
+    lo.backward()
+    np.testing.assert_allclose(h_out.cpu().numpy(), h.detach().numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(prob.cpu().numpy(), torch.sigmoid(logit).detach().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(loss.item(), lo.item(), rtol=1e-5)                       # north_star tolerance on the loss
+    np.testing.assert_allclose(d_logit.cpu().numpy() * M, logit.grad.numpy() * M, rtol=0, atol=5e-5)
+    np.testing.assert_allclose(d_h.cpu().numpy() * M, pre.grad.numpy() * M, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(W2d.cpu().numpy(), w2 + scale * tw2.grad.numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(b2d.cpu().numpy(), b2 + scale * tb2.grad.numpy(), rtol=0, atol=2e-6)
+
+
 def test_linear_transpose_detecting(ops):
     # A = I with an ASYMMETRIC B catches a swapped C/D fragment layout
     K = N = 64
