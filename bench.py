@@ -15,6 +15,11 @@ import os
 import sys
 import time
 
+# HIP multiplexes streams onto 4 hardware queues by default; the sharded engine uses 5+ (training, routing, communication,
+# RCCL's own, sort) and two that share a queue serialize (seen in the kernel trace: the routing stream ran in-line with
+# the GEMMs).  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -135,8 +140,9 @@ def main():
                                   device=device, world=world, rank=rank)
     batches = synth_batches(a, device, rank)
 
+    nb = len(batches)
     for i in range(a.warmup):
-        eng.train_step(*batches[i % len(batches)])
+        eng.train_step(*batches[i % nb], next_keys=batches[(i + 1) % nb][0])
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -148,8 +154,8 @@ def main():
         eng.enable_kernel_events(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(a.steps):
-        eng.train_step(*batches[(a.warmup + i) % len(batches)])
+    for i in range(a.steps):          # the data loader knows the next batch: its keys are handed over for route prefetch
+        eng.train_step(*batches[(a.warmup + i) % nb], next_keys=batches[(a.warmup + i + 1) % nb][0])
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -232,7 +238,12 @@ def main():
             except Exception as e:     # the baseline is reported, never the thing measured
                 out["cpu_baseline"] = {"value": None, "unit": "examples/sec", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}
-        print(json.dumps(out))
+        try:        # RCCL's version banner sits in the C stdio buffer until exit: push it out BEFORE the JSON line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

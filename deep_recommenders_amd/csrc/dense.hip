@@ -688,9 +688,8 @@ bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3) != 
 // Fixed summation order.  7 groups of 34 threads stride over the blocks with 8 loads in flight each: a plain
 // "acc += partial[b]" loop is a chain of dependent L2 round trips (128 of them cost ~45 us for a 70 KB reduction).
 __global__ __launch_bounds__(256) void head_finish_kernel(const float* __restrict__ partial, int32_t nblocks, int32_t N,
-                                                          float scale, float inv_n, float* __restrict__ w2,
-                                                          int64_t ldw2, float* __restrict__ b2,
-                                                          float* __restrict__ loss_out) {
+                                                          float scale, float inv_n, float* w2, int64_t ldw2,
+                                                          float* b2, float* __restrict__ loss_out) {
     constexpr int NG = 7;
     __shared__ float red[NG][HEAD_PART];
     const int grp = threadIdx.x / HEAD_PART, c = threadIdx.x % HEAD_PART;
@@ -730,14 +729,15 @@ extern "C" int64_t dr_tower_head_workspace_bytes(int64_t M) {
 }
 
 extern "C" int dr_tower_head_fwd_bwd(const float* x, int64_t ld_x, const float* W1, int64_t ld_w1, const float* b1,
-                                     int64_t M, int32_t K, int32_t H, int32_t act, float* w2, int64_t ld_w2, float* b2,
-                                     const float* extra_logit, const float* labels, int32_t loss_mode, float scale,
+                                     int64_t M, int32_t K, int32_t H, int32_t act, const float* w2, int64_t ld_w2,
+                                     const float* b2, const float* extra_logit, const float* labels, int32_t loss_mode,
+                                     float scale, float* dst_w2, int64_t ld_dst_w2, float* dst_b2,
                                      float* h_out, int64_t ld_h, float* prob, float* d_logit, float* d_h, int64_t ld_dh,
                                      float* loss_out, void* workspace, int64_t workspace_bytes, dr_stream_t stream) {
     if (M <= 0 || K <= 0 || H <= 0) return DR_EINVAL;
     if (H > 32) return DR_ESHAPE;
     if (!x || !W1 || !w2 || !labels || !workspace || loss_mode < 0 || loss_mode > 2) return DR_EINVAL;
-    if (ld_x < K || ld_w1 < H || ld_w2 < 1 || (h_out && ld_h < H) || (d_h && ld_dh < H)) return DR_EINVAL;
+    if (ld_x < K || ld_w1 < H || ld_w2 < 1 || (dst_w2 && ld_dst_w2 < 1) || (h_out && ld_h < H) || (d_h && ld_dh < H)) return DR_EINVAL;
     if (workspace_bytes < dr_tower_head_workspace_bytes(M)) return DR_EINVAL;
     GemmArgs g{};
     g.A = x; g.lda = ld_x; g.B = W1; g.ldb = ld_w1; g.M = M; g.N = H; g.R = K;
@@ -751,8 +751,8 @@ extern "C" int dr_tower_head_fwd_bwd(const float* x, int64_t ld_x, const float* 
     int rc = launch<true, false, EPI_HEAD>(g, dr_s(stream));
     if (rc != DR_OK) return rc;
     const int nblocks = (int)((M + BM - 1) / BM);
-    hipLaunchKernelGGL(head_finish_kernel, dim3(1), dim3(256), 0, dr_s(stream), g.head_partial, nblocks, H, scale, g.inv_n, w2,
-                       ld_w2, b2, loss_out);
+    hipLaunchKernelGGL(head_finish_kernel, dim3(1), dim3(256), 0, dr_s(stream), g.head_partial, nblocks, H, scale, g.inv_n,
+                       dst_w2, ld_dst_w2, dst_b2, loss_out);
     DR_CHECK_LAUNCH();
     return DR_OK;
 }

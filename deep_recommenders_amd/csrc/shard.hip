@@ -140,6 +140,8 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(const int64_t* __re
 }
 
 // ---- owner-side gather / scatter of packed rows ------------------------------------------------------
+// Branch-free (see emb_pool.hip): every load and store is unconditional.  An index past n is clamped to n - 1 (same
+// source row, same destination, same value: a benign duplicate); a missing row (-1) reads row 0 and stores zeros.
 template <int LPR>
 __global__ __launch_bounds__(256) void rows_gather_kernel(const int64_t* __restrict__ rows, int64_t n,
                                                           const float* __restrict__ table, int32_t D,
@@ -148,26 +150,34 @@ __global__ __launch_bounds__(256) void rows_gather_kernel(const int64_t* __restr
     constexpr int RPW = DR_WAVE / LPR;    // rows per wave-instruction
     constexpr int U = 4;
     const int lane = threadIdx.x & 63, slot = lane / LPR, sub = lane % LPR;
-    const bool dvalid = sub * 4 < D;
+    const int nq = D >> 2;
+    const int subc = sub < nq ? sub : nq - 1;
+    const float* lsrc = lin_w != nullptr ? lin_w : table;           // value unused when lin_w == NULL
+    float* ldst = out_lin != nullptr ? out_lin : out;               // idem: the row store that follows overwrites it
+    const int64_t lpitch = out_lin != nullptr ? 1 : D;
     const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int64_t w0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     for (int64_t g = w0 * (RPW * U); g < n; g += nw * (RPW * U)) {
-        int64_t r[U];
+        int64_t ic[U];
+        bool present[U];
         float4 v[U];
+        float lw[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t i = g + u * RPW + slot;
-            r[u] = i < n ? rows[i] : -1;
-            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r[u] >= 0 && dvalid) v[u] = *reinterpret_cast<const float4*>(table + r[u] * D + sub * 4);
+            ic[u] = i < n ? i : n - 1;
+            const int64_t r = rows[ic[u]];
+            present[u] = r >= 0;
+            const int64_t rc = present[u] ? r : 0;
+            v[u] = *reinterpret_cast<const float4*>(table + rc * D + subc * 4);
+            lw[u] = lsrc[rc];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int64_t i = g + u * RPW + slot;
-            if (i < n) {
-                if (dvalid) *reinterpret_cast<float4*>(out + i * D + sub * 4) = v[u];
-                if (out_lin != nullptr && sub == 0) out_lin[i] = (r[u] >= 0 && lin_w != nullptr) ? lin_w[r[u]] : 0.f;
-            }
+            const float4 x = present[u] ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (out_lin == nullptr) ldst[ic[u] * lpitch + subc * 4] = x.x;      // dummy (same value the row store writes)
+            else ldst[ic[u]] = (present[u] && lin_w != nullptr) ? lw[u] : 0.f;
+            *reinterpret_cast<float4*>(out + ic[u] * D + subc * 4) = x;
         }
     }
 }
@@ -199,7 +209,7 @@ __global__ __launch_bounds__(256) void rows_scatter_add_kernel(const int64_t* __
 // send layout (pos is a permutation of 0..n-1: every destination written exactly once — no zero fill, no atomics).
 //   out_rows[pos[b,f], :] = d_concat[b, f*D:(f+1)*D] + d_fm_logit[b] * (sum_x[b,:] - concat[b, f*D:(f+1)*D])
 //   out_lin[pos[b,f]]     = d_fm_logit[b]
-template <int LPR>
+template <int LPR, int U>
 __global__ __launch_bounds__(256) void pack_grads_kernel(const int64_t* __restrict__ pos, int64_t B, int32_t F, int32_t D,
                                                          const float* __restrict__ d_concat, int64_t ld,
                                                          const float* __restrict__ concat, int64_t ldc,
@@ -207,27 +217,60 @@ __global__ __launch_bounds__(256) void pack_grads_kernel(const int64_t* __restri
                                                          const float* __restrict__ d_fm_logit,
                                                          float* __restrict__ out_rows, float* __restrict__ out_lin,
                                                          float* __restrict__ bias_sum) {
+    // One wave per example; branch-free loop body (see emb_pool.hip): slots past the last field repeat field F-1 (same
+    // destination, same value), lanes past D/4 repeat the last float4; the example's F positions are read once,
+    // coalesced, and broadcast with shuffles; the next example's positions are prefetched.
     constexpr int NS = DR_WAVE / LPR;
     const int lane = threadIdx.x & 63, slot = lane / LPR, sub = lane % LPR;
-    const bool dvalid = sub * 4 < D;
+    const int nq = D >> 2;
+    const int subc = sub < nq ? sub : nq - 1;
     const bool fm = concat != nullptr && sum_x != nullptr && d_fm_logit != nullptr;
+    const float* xsrc = fm ? concat : d_concat;                      // values unused when !fm
+    const int64_t xld = fm ? ldc : ld;
+    const float* sxsrc = fm ? sum_x : d_concat;
+    const int64_t sxp = fm ? (int64_t)D : 0;
+    const float* dlsrc = d_fm_logit != nullptr ? d_fm_logit : d_concat;
+    float* ldst = out_lin != nullptr ? out_lin : out_rows;
     const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t w0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (blockIdx.x == 0 && bias_sum != nullptr && d_fm_logit != nullptr) dr_block_sum_axpy(d_fm_logit, B, 1.f, bias_sum);
-    for (int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); b < B; b += nw) {
-        const float dl = d_fm_logit != nullptr ? d_fm_logit[b] : 0.f;
-        float4 sx = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (fm && dvalid) sx = *reinterpret_cast<const float4*>(sum_x + b * D + sub * 4);
-        for (int f = slot; f < F; f += NS) {
-            const int64_t p = pos[b * F + f];
-            if (dvalid) {
-                float4 g = *reinterpret_cast<const float4*>(d_concat + b * ld + f * D + sub * 4);
-                if (fm) {
-                    const float4 x = *reinterpret_cast<const float4*>(concat + b * ldc + f * D + sub * 4);
-                    g.x += dl * (sx.x - x.x); g.y += dl * (sx.y - x.y); g.z += dl * (sx.z - x.z); g.w += dl * (sx.w - x.w);
+    if (w0 >= B) return;
+    for (int fg = 0; fg < F; fg += 64) {                               // one pass per group of 64 fields (F <= 64: one)
+        const int Fg = F - fg < 64 ? F - fg : 64;
+        const int lanec = fg + (lane < Fg ? lane : Fg - 1);
+        int64_t my_pos = pos[w0 * F + lanec];
+        float dl = dlsrc[w0];
+        for (int64_t b = w0; b < B; b += nw) {
+            const int64_t bn = b + nw < B ? b + nw : b;
+            const int64_t next_pos = pos[bn * F + lanec];
+            const float next_dl = dlsrc[bn];
+            if (d_fm_logit == nullptr) dl = 0.f;
+            const float4 sx = *reinterpret_cast<const float4*>(sxsrc + b * sxp + subc * 4);
+            for (int f0 = 0; f0 < Fg; f0 += NS * U) {
+                float4 g[U], x[U];
+                int64_t p[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int f = f0 + u * NS + slot;
+                    const int fl = f < Fg ? f : Fg - 1;                   // field within the group (lane that holds its pos)
+                    const int fc = fg + fl;
+                    p[u] = __shfl(my_pos, fl, 64);
+                    g[u] = *reinterpret_cast<const float4*>(d_concat + b * ld + fc * D + subc * 4);
+                    x[u] = *reinterpret_cast<const float4*>(xsrc + b * xld + fc * D + subc * 4);
                 }
-                *reinterpret_cast<float4*>(out_rows + p * D + sub * 4) = g;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    float4 v = g[u];
+                    if (fm) {
+                        v.x += dl * (sx.x - x[u].x); v.y += dl * (sx.y - x[u].y);
+                        v.z += dl * (sx.z - x[u].z); v.w += dl * (sx.w - x[u].w);
+                    }
+                    if (out_lin != nullptr) ldst[p[u]] = dl;
+                    *reinterpret_cast<float4*>(out_rows + p[u] * D + subc * 4) = v;
+                }
             }
-            if (out_lin != nullptr && sub == 0) out_lin[p] = dl;
+            my_pos = next_pos;
+            dl = next_dl;
         }
     }
 }
@@ -330,7 +373,7 @@ extern "C" int dr_emb_pack_grads(const int64_t* pos, int64_t B, int32_t F, int32
     if (concat != nullptr && (ld_concat < (int64_t)F * D || (ld_concat & 3))) return DR_EINVAL;
     const int lpr = lpr_for_d(D);
     const int grid = dr_grid_for(B, 4, 8192);
-#define CALL(L) hipLaunchKernelGGL((pack_grads_kernel<L>), dim3(grid), dim3(256), 0, dr_s(stream), pos, B, F, D, d_concat, ld_dconcat, concat, ld_concat, sum_x, d_fm_logit, out_rows, out_lin, bias_sum)
+#define CALL(L) hipLaunchKernelGGL((pack_grads_kernel<L, (64 / L >= 16 ? 2 : 4)>), dim3(grid), dim3(256), 0, dr_s(stream), pos, B, F, D, d_concat, ld_dconcat, concat, ld_concat, sum_x, d_fm_logit, out_rows, out_lin, bias_sum)
     DR_LPR_SWITCH(lpr, CALL)
 #undef CALL
     DR_CHECK_LAUNCH();

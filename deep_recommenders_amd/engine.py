@@ -247,7 +247,8 @@ class DeepFMEngine:
                                        concat=None if self.fold_fm else self.concat,
                                        sum_x=None if self.fold_fm else self.sum_x)
 
-    def train_step(self, keys, dense, labels):
+    def train_step(self, keys, dense, labels, next_keys=None):
+        # next_keys: accepted for interface parity with ShardedDeepFMEngine (which routes the next batch ahead); unused here
         if self.main is None:
             self.forward(keys, dense, labels)
             self.backward_and_update()

@@ -222,9 +222,15 @@ def tower_head_workspace(M, device):
 
 
 def tower_head_fwd_bwd(x, W1, b1, W2, b2, extra_logit, labels, loss_mode, scale, act=1, h_out=None, prob=None, d_logit=None,
-                       d_h=None, loss=None, workspace=None):
-    """Last hidden layer (H <= 32) + Dense(1) + extra logit + BCE loss + the Dense(1) backward with its SGD step, fused.
-    W2: [H, 1] (any row stride).  Returns (loss, prob, d_logit, d_h)."""
+                       d_h=None, loss=None, workspace=None, dst_W2="inplace", dst_b2="inplace"):
+    """Last hidden layer (H <= 32) + Dense(1) + extra logit + BCE loss + the Dense(1) backward, fused.
+    W2: [H, 1] (any row stride).  dst_W2 / dst_b2 += scale * gradient: by default the parameters themselves (fused SGD,
+    scale = -lr); pass gradient buffers with scale = 1 for data-parallel training, or None to skip.
+    Returns (loss, prob, d_logit, d_h)."""
+    if isinstance(dst_W2, str):
+        dst_W2 = W2
+    if isinstance(dst_b2, str):
+        dst_b2 = b2
     M, K = x.shape
     H = W1.shape[1]
     dev = x.device
@@ -237,6 +243,7 @@ def tower_head_fwd_bwd(x, W1, b1, W2, b2, extra_logit, labels, loss_mode, scale,
         workspace = tower_head_workspace(M, dev)
     check(lib().dr_tower_head_fwd_bwd(ptr(x), x.stride(0), ptr(W1), W1.stride(0), ptr(b1), M, K, H, int(act), ptr(W2),
                                       W2.stride(0), ptr(b2), ptr(extra_logit), ptr(labels), int(loss_mode), float(scale),
+                                      ptr(dst_W2), dst_W2.stride(0) if dst_W2 is not None else 0, ptr(dst_b2),
                                       ptr(h_out), h_out.stride(0) if h_out is not None else 0, ptr(prob), ptr(d_logit),
                                       ptr(d_h), d_h.stride(0), ptr(loss), ptr(workspace), workspace.numel() * 4,
                                       stream_ptr()), "dr_tower_head_fwd_bwd")

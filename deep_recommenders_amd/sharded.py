@@ -49,17 +49,34 @@ class HipPrims:
     linear_bwd_dw = staticmethod(ops.linear_bwd_dw)
     bce_fwd_bwd = staticmethod(ops.bce_fwd_bwd)
     axpy = staticmethod(ops.axpy)
+    tower_head_fwd_bwd = staticmethod(ops.tower_head_fwd_bwd)
+    linear_bwd_narrow = staticmethod(ops.linear_bwd_narrow)
+    linear_bwd_narrow_supported = staticmethod(ops.linear_bwd_narrow_supported)
+
+
+class Route:
+    """Everything about one batch that depends only on its keys: where each slot's row lives, how many rows travel to /
+    from each rank, the owner-side list of requested rows and its sort plan.  Built by ShardedEmbeddingExchange.route()
+    on a dedicated stream, possibly one step ahead of its use."""
+    __slots__ = ("pos", "send_splits", "recv_splits", "n", "n_recv", "n_pad", "slot", "ready", "sorted", "key", "has_lin")
 
 
 class ShardedEmbeddingExchange:
-    """Steps 2-6 and 8 above for one (ids [B, F]) batch.
+    """Steps 1-6 and 8 above for one (keys [B, F]) batch.
+
+    route()   steps 1-3 (hash, bucket, split sizes + row ids to the owners) and the owner-side sort plan.  This is the
+              only part that needs the host (exact all-to-all split sizes): it runs on its own stream so that its host
+              sync covers a handful of small kernels instead of draining the training stream, and it can be issued for the
+              NEXT batch while the current step computes.
+    forward() steps 4-6: owners gather, rows come back, fused pool + first-order + FM over the received rows.
+    pack() / exchange_and_apply()  step 8.
 
     Owner side: the received row list is viewed as [n/32, 32] "examples x fields" (padded with -1) so that the
-    single-GPU sorted K4 (sort on a side stream during the forward, one plain read-modify-write per unique row)
-    applies the returned gradients; the requesting side packs its per-slot gradients straight into the all-to-all
-    send layout (dr_emb_pack_grads: a permutation, no atomics)."""
+    single-GPU sorted K4 (one plain read-modify-write per unique row) applies the returned gradients; the requesting
+    side packs its per-slot gradients straight into the all-to-all send layout (dr_emb_pack_grads: a permutation)."""
 
     GROUP = 32      # pseudo-fields per pseudo-example of the owner-side slot list
+    SLOTS = 2       # routes in flight: the one being trained on and the prefetched one
 
     def __init__(self, num_fields, vocab_per_field, dim, world, rank, device, prims=None, group=None):
         self.F, self.V, self.D = num_fields, vocab_per_field, dim
@@ -71,93 +88,143 @@ class ShardedEmbeddingExchange:
         self._zero_base = torch.zeros(num_fields, dtype=torch.int64, device=device)
         self._zero_base_g = torch.zeros(self.GROUP, dtype=torch.int64, device=device)
         self._col_start = torch.arange(num_fields + 1, dtype=torch.int32, device=device)
+        self._col_buckets = torch.full((num_fields,), vocab_per_field, dtype=torch.int64, device=device)
         self._st = None
-        self._cap = 0
-        self._rows_pad = self._g_pad = self._gl_pad = self._plan = None
         self._cuda = torch.device(device).type == "cuda"
-        self._side = torch.cuda.Stream(device=device) if self._cuda else None
-        self._ev_rows = torch.cuda.Event() if self._cuda else None
-        self._ev_sorted = torch.cuda.Event() if self._cuda else None
+        self._rs = torch.cuda.Stream(device=device) if self._cuda else None      # routing stream
+        # per-slot owner-side buffers (the route of step t is still read by step t's backward while step t+1 is routed)
+        self._slots = [dict(cap=0, rows_pad=None, g_pad=None, gl_pad=None, plan=None, ids=None) for _ in range(self.SLOTS)]
+        self._next_slot = 0
 
     def _a2a(self, out, inp, out_splits, in_splits):
         dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
         return out
 
-    def _ensure_capacity(self, n_recv, device):
+    def _ensure_capacity(self, sl, n_recv, device):
         G = self.GROUP
         need = (n_recv + G - 1) // G * G
-        if need > self._cap:
-            cap = max(need, int(self._cap * 1.25) // G * G)
-            self._rows_pad = torch.full((cap,), -1, dtype=torch.int64, device=device)
-            self._g_pad = torch.zeros((cap, self.D), dtype=torch.float32, device=device)
-            self._gl_pad = torch.zeros(cap, dtype=torch.float32, device=device)
-            self._plan = None
-            self._cap = cap
+        if need > sl["cap"]:
+            cap = max(need, int(sl["cap"] * 1.25) // G * G)
+            sl["rows_pad"] = torch.full((cap,), -1, dtype=torch.int64, device=device)
+            sl["g_pad"] = torch.zeros((cap, self.D), dtype=torch.float32, device=device)
+            sl["gl_pad"] = torch.zeros(cap, dtype=torch.float32, device=device)
+            sl["plan"] = None
+            sl["cap"] = cap
         return need
 
-    def forward(self, ids, table_local, lin_local, lin_bias, ld_concat, concat=None, sum_x=None, fm_logit=None):
-        B, F = ids.shape
-        n, D, W = B * F, self.D, self.world
-        counts, send_rows, pos = self.p.shard_bucket_ids(ids, self.rows_per_shard, W)
-        recv_counts = torch.empty_like(counts)
-        dist.all_to_all_single(recv_counts, counts, group=self.group)                 # split sizes
-        send_splits = [int(v) for v in counts.tolist()]                               # host sync: exact sizes
-        recv_splits = [int(v) for v in recv_counts.tolist()]
-        n_recv = sum(recv_splits)
-        n_pad = self._ensure_capacity(n_recv, ids.device)
-        rows_pad = self._rows_pad[:n_pad]
-        rows_pad[n_recv:].fill_(-1)
-        recv_rows = rows_pad[:n_recv]
-        self._a2a(recv_rows, send_rows, recv_splits, send_splits)                     # C1
-        # the owner-side sort only needs the received row list: side stream, hidden under the exchange + tower
-        G = self.GROUP
+    # ---- steps 1-3 -------------------------------------------------------------------------------------------
+    def route(self, keys, hashed=True, wait_current=True):
+        """keys [B, F] int64 (raw keys if `hashed`, else ids).  Returns a Route; on CUDA the work is queued on the routing
+        stream and `route.ready` / `route.sorted` are events consumers wait on.  wait_current=False: the caller guarantees
+        `keys` is already complete (a prefetched batch), so routing does not queue behind the training stream."""
+        sl_i = self._next_slot
+        self._next_slot = (sl_i + 1) % self.SLOTS
+        sl = self._slots[sl_i]
+        W = self.world
+        r = Route()
+        r.key = (keys.data_ptr(), tuple(keys.shape))
+        r.slot = sl_i
+        ctx = torch.cuda.stream(self._rs) if self._cuda else _NullCtx()
+        if self._cuda and wait_current:
+            self._rs.wait_stream(torch.cuda.current_stream())        # keys may have been produced on the caller's stream
+        if self._cuda and sl.get("free_ev") is not None:
+            self._rs.wait_event(sl["free_ev"])       # the step that last used this slot's buffers has applied its gradients
+        with ctx:
+            if hashed:
+                if sl["ids"] is None or sl["ids"].shape != keys.shape:
+                    sl["ids"] = torch.empty(keys.shape, dtype=torch.int64, device=keys.device)
+                ids = self.p.hash_bucket_i64(keys, self._col_buckets, out=sl["ids"])            # K1
+            else:
+                ids = keys
+            B, F = ids.shape
+            counts, send_rows, pos = self.p.shard_bucket_ids(ids, self.rows_per_shard, W)
+            recv_counts = torch.empty_like(counts)
+            dist.all_to_all_single(recv_counts, counts, group=self.group)                 # split sizes
+            r.send_splits = [int(v) for v in counts.tolist()]              # host sync of THIS stream only
+            r.recv_splits = [int(v) for v in recv_counts.tolist()]
+            r.n, r.n_recv = B * F, sum(r.recv_splits)
+            r.n_pad = self._ensure_capacity(sl, r.n_recv, ids.device)
+            rows_pad = sl["rows_pad"][:r.n_pad]
+            rows_pad[r.n_recv:].fill_(-1)
+            self._a2a(rows_pad[:r.n_recv], send_rows, r.recv_splits, r.send_splits)      # C1
+            r.pos = pos
+            if self._cuda:
+                r.ready = torch.cuda.Event()
+                r.ready.record(self._rs)
+            # owner-side sort: needs only the received row list
+            sl["plan"] = self.p.emb_sort_slots(rows_pad.view(-1, self.GROUP), self._zero_base_g, self.local_rows, sl["plan"])
+            if self._cuda:
+                r.sorted = torch.cuda.Event()
+                r.sorted.record(self._rs)
+        return r
+
+    # ---- steps 4-6 ---------------------------------------------------------------------------------------------
+    def forward(self, route, table_local, lin_local, lin_bias, ld_concat, concat=None, sum_x=None, fm_logit=None):
+        r = route
+        sl = self._slots[r.slot]
+        n, D, F = r.n, self.D, self.F
         if self._cuda:
-            self._ev_rows.record()
-            with torch.cuda.stream(self._side):
-                self._side.wait_event(self._ev_rows)
-                self._plan = self.p.emb_sort_slots(rows_pad.view(-1, G), self._zero_base_g, self.local_rows, self._plan)
-                self._ev_sorted.record(self._side)
-        else:
-            self._plan = self.p.emb_sort_slots(rows_pad.view(-1, G), self._zero_base_g, self.local_rows, self._plan)
+            cur = torch.cuda.current_stream()
+            cur.wait_event(r.ready)
+            r.pos.record_stream(cur)
+        recv_rows = sl["rows_pad"][:r.n_recv]
         rows_buf, lin_buf = self.p.rows_gather(recv_rows, table_local, lin_local)     # owner-side gather
-        got_rows = torch.empty((n, D), dtype=torch.float32, device=ids.device)
-        self._a2a(got_rows, rows_buf, send_splits, recv_splits)                       # C2
+        got_rows = torch.empty((n, D), dtype=torch.float32, device=recv_rows.device)
+        self._a2a(got_rows, rows_buf, r.send_splits, r.recv_splits)                   # C2
         got_lin = None
         if lin_local is not None:
-            got_lin = torch.empty(n, dtype=torch.float32, device=ids.device)
-            self._a2a(got_lin, lin_buf, send_splits, recv_splits)
+            got_lin = torch.empty(n, dtype=torch.float32, device=recv_rows.device)
+            self._a2a(got_lin, lin_buf, r.send_splits, r.recv_splits)
         # K3 over the received rows: ids := position in the receive buffer, table := receive buffer
-        concat, sum_x, fm_logit = self.p.emb_pool_fwd(pos, F, None if F <= 64 else self._col_start, self._zero_base,
+        concat, sum_x, fm_logit = self.p.emb_pool_fwd(r.pos, F, None if F <= 64 else self._col_start, self._zero_base,
                                                       got_rows, got_lin, lin_bias, ld_concat=ld_concat, concat=concat,
                                                       sum_x=sum_x, fm_logit=fm_logit)
-        self._st = (pos, send_splits, recv_splits, n, n_recv, n_pad, lin_local is not None)
+        r.has_lin = lin_local is not None
+        self._st = r
         return concat, sum_x, fm_logit
 
     def pack(self, d_concat, d_fm_logit, concat, sum_x, g_bias=None):
         """requesting side: per-slot gradients into the send layout (local, HBM-bound)"""
-        pos, send_splits, recv_splits, n, n_recv, n_pad, has_lin = self._st
-        g_rows = torch.empty((n, self.D), dtype=torch.float32, device=pos.device)
-        g_lin = torch.empty(n, dtype=torch.float32, device=pos.device) if has_lin else None
-        self.p.emb_pack_grads(pos, self.D, d_concat, concat, sum_x, d_fm_logit, g_rows, g_lin, g_bias)
+        r = self._st
+        g_rows = torch.empty((r.n, self.D), dtype=torch.float32, device=r.pos.device)
+        g_lin = torch.empty(r.n, dtype=torch.float32, device=r.pos.device) if r.has_lin else None
+        self.p.emb_pack_grads(r.pos, self.D, d_concat, concat, sum_x, d_fm_logit, g_rows, g_lin, g_bias)
         return g_rows, g_lin
 
     def exchange_and_apply(self, g_rows, g_lin, scale, table_local, lin_local):
         """C3 + owner-side update (may run on a communication stream, overlapped with the tower's wgrad)"""
-        pos, send_splits, recv_splits, n, n_recv, n_pad, has_lin = self._st
+        r = self._st
+        sl = self._slots[r.slot]
         D, G = self.D, self.GROUP
-        g_pad, gl_pad, rows_pad = self._g_pad[:n_pad], self._gl_pad[:n_pad], self._rows_pad[:n_pad]
-        self._a2a(g_pad[:n_recv], g_rows, recv_splits, send_splits)                   # C3
-        if has_lin:
-            self._a2a(gl_pad[:n_recv], g_lin, recv_splits, send_splits)
+        g_pad, gl_pad, rows_pad = sl["g_pad"][:r.n_pad], sl["gl_pad"][:r.n_pad], sl["rows_pad"][:r.n_pad]
         if self._cuda:
-            torch.cuda.current_stream().wait_event(self._ev_sorted)
-        self.p.emb_pool_bwd_sorted(rows_pad.view(-1, G), self._zero_base_g, self._plan, D, self.local_rows,
-                                   g_pad.view(-1, G * D), None, scale, table_local, lin_local if has_lin else None, None,
-                                   slot_lin_grad=gl_pad if has_lin else None)
+            cur = torch.cuda.current_stream()
+            g_rows.record_stream(cur)
+            if g_lin is not None:
+                g_lin.record_stream(cur)
+        self._a2a(g_pad[:r.n_recv], g_rows, r.recv_splits, r.send_splits)             # C3
+        if r.has_lin:
+            self._a2a(gl_pad[:r.n_recv], g_lin, r.recv_splits, r.send_splits)
+        if self._cuda:
+            torch.cuda.current_stream().wait_event(r.sorted)
+        self.p.emb_pool_bwd_sorted(rows_pad.view(-1, G), self._zero_base_g, sl["plan"], D, self.local_rows,
+                                   g_pad.view(-1, G * D), None, scale, table_local, lin_local if r.has_lin else None, None,
+                                   slot_lin_grad=gl_pad if r.has_lin else None)
+        if self._cuda:
+            sl["free_ev"] = torch.cuda.Event()
+            sl["free_ev"].record()
 
     def backward(self, d_concat, d_fm_logit, concat, sum_x, scale, table_local, lin_local, g_bias=None):
         g_rows, g_lin = self.pack(d_concat, d_fm_logit, concat, sum_x, g_bias)
         self.exchange_and_apply(g_rows, g_lin, scale, table_local, lin_local)
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
 
 
 class ShardedDeepFMEngine:
@@ -238,10 +305,27 @@ class ShardedDeepFMEngine:
         self.loss = torch.zeros(1, **f32)
         self.ws = torch.empty(1024, **f32)
         self._cuda = torch.device(device).type == "cuda"
+        # fused tower tail (same kernels as engine.DeepFMEngine, writing into the gradient bucket instead of the weights)
+        nl = len(self.Ws)
+        self.fuse_head = (hasattr(self.p, "tower_head_fwd_bwd") and nl >= 2 and self.Ws[-1].shape[1] == 1
+                          and self.Ws[-2].shape[1] <= 32 and self.acts[-2] == 1)
+        self.narrow = [hasattr(self.p, "linear_bwd_narrow") and i > 0 and self.acts[i - 1] == 1
+                       and self.p.linear_bwd_narrow_supported(B, Wt.shape[0], Wt.shape[1]) for i, Wt in enumerate(self.Ws)]
+        if self._cuda:
+            self.head_ws = ops.tower_head_workspace(B, device) if self.fuse_head else None
+            self.narrow_ws = [ops.linear_bwd_narrow_workspace(B, Wt.shape[0], Wt.shape[1], device) if self.narrow[i] else None
+                              for i, Wt in enumerate(self.Ws)]
+            self.dw_ws = [ops.linear_bwd_dw_workspace(B, Wt.shape[0], Wt.shape[1], device) for Wt in self.Ws]
+        else:
+            self.head_ws = None
+            self.narrow_ws = [None] * nl
+            self.dw_ws = [None] * nl
         self.comm = torch.cuda.Stream(device=device) if self._cuda else None   # backward exchange + owner update
         self.ev_packed = torch.cuda.Event() if self._cuda else None
         self.ev_applied = torch.cuda.Event() if self._cuda else None
         self._events = None
+        self._route = None
+        self._done = []
 
     # ---- per-phase HIP events (same contract as engine.DeepFMEngine) -------------------------------------------
     def enable_kernel_events(self, on: bool):
@@ -268,30 +352,61 @@ class ShardedDeepFMEngine:
             out[name] = {"bound": bound, "ms": ms, "n": len(evs), key: work}
         return out
 
-    def train_step(self, keys, dense, labels):
+    def prefetch_route(self, next_keys):
+        """Route the NEXT batch (hash, bucket, id exchange, owner-side sort) now, on the routing stream.  `next_keys` must
+        already be complete (it is not ordered against the training stream)."""
+        self._route = self.ex.route(next_keys, hashed=True, wait_current=False)
+
+    def train_step(self, keys, dense, labels, next_keys=None):
         p, F, D, W, B = self.p, self.F, self.D, self.world, self.B
-        self._k("hash_bucket_i64", "hbm", B * F * 16, lambda: p.hash_bucket_i64(keys, self.col_buckets, out=self.ids))
-        # steps 2-6: bucket, exchange ids, owner gather, exchange rows, fused pool+FM over the received rows
-        self._k("emb_exchange_fwd(bucket+a2a+gather+a2a+K3)", "xgmi", B * F * (8 + 4 * D + 4),
-                lambda: self.ex.forward(self.ids, self.table, self.lin_w, self.lin_bias, self.ld, concat=self.concat,
+        if self._cuda:                                   # bound the host's run-ahead to two steps
+            if len(self._done) >= 2:
+                self._done.pop(0).synchronize()
+        # steps 1-3: use the prefetched route if it was built for exactly these keys, else route now
+        route = self._route
+        self._route = None
+        if route is None or route.key != (keys.data_ptr(), tuple(keys.shape)):
+            route = self._k("emb_route(hash+bucket+a2a ids+sort)", "xgmi", B * F * 24, lambda: self.ex.route(keys, hashed=True))
+        # steps 4-6: owner gather, exchange rows, fused pool+FM over the received rows
+        self._k("emb_exchange_fwd(gather+a2a+K3)", "xgmi", B * F * (8 + 4 * D + 4),
+                lambda: self.ex.forward(route, self.table, self.lin_w, self.lin_bias, self.ld, concat=self.concat,
                                         sum_x=self.sum_x, fm_logit=self.fm_logit))
+        if next_keys is not None:
+            # queued after this step's forward exchange, before its backward collectives: the route's host sync then only
+            # waits for the forward exchange, and the host stays a whole tower ahead of the GPU
+            self.prefetch_route(next_keys)
         if self.Nd:
             self.concat[:, F * D:F * D + self.Nd].copy_(dense)
         x = self.concat[:, :self.in_dim]
+        n_layers = len(self.Ws)
+        self.flat_grads.zero_()
         for i, (Wt, b) in enumerate(zip(self.Ws, self.bs)):
+            if self.fuse_head and i == n_layers - 2:
+                break
             self._k("linear_fwd_L%d" % i, "mfma", 2.0 * B * Wt.shape[0] * Wt.shape[1],
                     lambda x=x, Wt=Wt, b=b, i=i: p.linear_fwd(x, Wt, b, self.acts[i], out=self.hs[i]))
             x = self.hs[i]
-        p.bce_fwd_bwd(self.fm_logit, labels, ops.LOSS_SIGMOID_CE, workspace=self.ws, logits_b=self.hs[-1],
-                      out=(self.prob, self.d_logit, self.loss))
+        if self.fuse_head:
+            # Dense(H<=32, relu) + Dense(1) + FM logit + loss + the Dense(1) gradient (into the all-reduce bucket), fused
+            self._k("tower_head_fwd_bwd", "hbm", 4.0 * B * (self.Ws[-2].shape[0] + self.Ws[-2].shape[1] + 4),
+                    lambda x=x: p.tower_head_fwd_bwd(x, self.Ws[-2], self.bs[-2], self.Ws[-1], self.bs[-1], self.fm_logit, labels,
+                                                      ops.LOSS_SIGMOID_CE, 1.0, act=1, prob=self.prob, d_logit=self.d_logit,
+                                                      d_h=self.dhs[-1], loss=self.loss, workspace=self.head_ws,
+                                                      dst_W2=self.gWs[-1], dst_b2=self.gbs[-1]))
+        else:
+            p.bce_fwd_bwd(self.fm_logit, labels, ops.LOSS_SIGMOID_CE, workspace=self.ws, logits_b=self.hs[-1],
+                          out=(self.prob, self.d_logit, self.loss))
         # ---- backward: dense tower gradients into the flat bucket ----------------------------------------
-        self.flat_grads.zero_()
         # dgrad chain first (it produces d_concat, the input of the embedding exchange); wgrads afterwards so that they
-        # overlap the backward exchange running on the communication stream
-        n_layers = len(self.Ws)
+        # overlap the backward exchange running on the communication stream.  Narrow layers do dx + dW in one kernel.
         dys = [None] * n_layers
         dy = self.d_logit.reshape(-1, 1)
-        for i in range(n_layers - 1, -1, -1):
+        top = n_layers - 1
+        if self.fuse_head:
+            top = n_layers - 2
+            dy = self.dhs[-1]
+        dw_todo = []
+        for i in range(top, -1, -1):
             dys[i] = dy
             if i > 0:
                 dx = self.dhs[i - 1]
@@ -299,8 +414,14 @@ class ShardedDeepFMEngine:
             else:
                 dx = self.d_concat[:, :self.in_dim]
                 rs = None
-            self._k("linear_bwd_dx_L%d" % i, "mfma", 2.0 * B * self.Ws[i].shape[0] * self.Ws[i].shape[1],
-                    lambda dy=dy, i=i, rs=rs, dx=dx: p.linear_bwd_dx(dy, self.Ws[i], relu_src=rs, out=dx))
+            if self.narrow[i]:
+                self._k("linear_bwd_narrow_L%d" % i, "hbm", 4.0 * B * (2 * self.Ws[i].shape[0] + self.Ws[i].shape[1]),
+                        lambda dy=dy, i=i, dx=dx: p.linear_bwd_narrow(self.hs[i - 1], dy, self.Ws[i], 1.0, self.gWs[i], self.gbs[i],
+                                                                      dx, relu_mask=True, workspace=self.narrow_ws[i]))
+            else:
+                self._k("linear_bwd_dx_L%d" % i, "mfma", 2.0 * B * self.Ws[i].shape[0] * self.Ws[i].shape[1],
+                        lambda dy=dy, i=i, rs=rs, dx=dx: p.linear_bwd_dx(dy, self.Ws[i], relu_src=rs, out=dx))
+                dw_todo.append(i)
             dy = dx
         # ---- embedding backward: pack (local), then C3 + owner-side sorted update on the communication stream -------
         g_rows, g_lin = self._k("emb_pack_grads", "hbm", B * F * (12 * D + 4),
@@ -313,14 +434,17 @@ class ShardedDeepFMEngine:
                 self.ev_applied.record(self.comm)
         else:
             self.ex.exchange_and_apply(g_rows, g_lin, -self.lr / W, self.table, self.lin_w)
-        for i in range(n_layers - 1, -1, -1):
+        for i in dw_todo:
             xin = self.concat[:, :self.in_dim] if i == 0 else self.hs[i - 1]
             self._k("linear_bwd_dw_L%d" % i, "mfma", 2.0 * B * self.Ws[i].shape[0] * self.Ws[i].shape[1],
-                    lambda xin=xin, i=i: p.linear_bwd_dw(xin, dys[i], 1.0, self.gWs[i], self.gbs[i]))
+                    lambda xin=xin, i=i: p.linear_bwd_dw(xin, dys[i], 1.0, self.gWs[i], self.gbs[i], workspace=self.dw_ws[i]))
         # ---- dense tower: one all-reduce, then w += -(lr / W) * sum_r g_r  (mean over the global batch) ------
         self._k("allreduce_dense_grads", "xgmi", self.flat_grads.numel() * 4,
                 lambda: dist.all_reduce(self.flat_grads, group=self.group))
         p.axpy(-self.lr / W, self.flat_grads, self.flat_params)
         if self._cuda:
             torch.cuda.current_stream().wait_event(self.ev_applied)     # next step's gather must see the update
+            ev = torch.cuda.Event()
+            ev.record()
+            self._done.append(ev)
         return self.loss

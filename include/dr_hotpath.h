@@ -209,14 +209,15 @@ int dr_linear_bwd_narrow(const float* x, int64_t ld_x, const float* dy, int64_t 
  *   logit  = h @ w2 + b2 + extra_logit              [M]      (w2[n] at w2[n * ld_w2]; extra_logit may be NULL)
  *   prob, loss, d_logit = BCE(logit, labels, loss_mode) as dr_bce_fwd_bwd  (d_logit = d mean-loss / d logit)
  *   d_h    = d_logit (x) w2 * act'(h)               [M, H]   (gradient for dr_linear_bwd_narrow / _bwd_dx)
- *   w2    += scale * h^T d_logit ;  b2 += scale * sum(d_logit)   (fused SGD; scale = 0 leaves them untouched;
- *                                                                 d_h always uses the pre-update w2)
+ *   dst_w2 += scale * h^T d_logit ;  dst_b2 += scale * sum(d_logit)
+ *            dst_* = the parameters themselves with scale = -lr (fused SGD; d_h always uses the pre-update w2), or
+ *            gradient buffers with scale = 1 (data-parallel: all-reduce, then apply); NULL / scale = 0: skipped
  * Deterministic.  H > 32 returns DR_ESHAPE (use dr_linear_fwd x2 + dr_bce_fwd_bwd + dr_linear_bwd_*). */
 int64_t dr_tower_head_workspace_bytes(int64_t M);
 int dr_tower_head_fwd_bwd(const float* x, int64_t ld_x, const float* W1, int64_t ld_w1, const float* b1,
-                          int64_t M, int32_t K, int32_t H, int32_t act, float* w2, int64_t ld_w2, float* b2,
-                          const float* extra_logit, const float* labels, int32_t loss_mode, float scale,
-                          float* h_out, int64_t ld_h, float* prob, float* d_logit, float* d_h, int64_t ld_dh,
+                          int64_t M, int32_t K, int32_t H, int32_t act, const float* w2, int64_t ld_w2,
+                          const float* b2, const float* extra_logit, const float* labels, int32_t loss_mode,
+                          float scale, float* dst_w2, int64_t ld_dst_w2, float* dst_b2, float* h_out, int64_t ld_h, float* prob, float* d_logit, float* d_h, int64_t ld_dh,
                           float* loss_out, void* workspace, int64_t workspace_bytes, dr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------

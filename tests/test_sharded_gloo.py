@@ -124,10 +124,43 @@ class OraclePrims:
         return out
 
     @staticmethod
-    def linear_bwd_dw(x, dy, scale, dstW, dstb=None):
+    def linear_bwd_dw(x, dy, scale, dstW, dstb=None, workspace=None):
         dstW += scale * (x.t() @ dy)
         if dstb is not None:
             dstb += scale * dy.sum(0)
+
+    @staticmethod
+    def linear_bwd_narrow_supported(M, K, N):
+        return N <= 32 and K in (128, 256, 512) and M > 0 and M % 32 == 0        # same domain as the HIP kernel
+
+    @staticmethod
+    def linear_bwd_narrow(x, dy, W, scale, dstW, dstb, dx, relu_mask=True, workspace=None):
+        g = dy @ W.t()                                    # pre-update W (dstW may alias it)
+        dx.copy_(g * (x > 0) if relu_mask else g)
+        dstW += scale * (x.t() @ dy)
+        if dstb is not None:
+            dstb += scale * dy.sum(0)
+        return dx
+
+    @staticmethod
+    def tower_head_fwd_bwd(x, W1, b1, W2, b2, extra_logit, labels, loss_mode, scale, act=1, h_out=None, prob=None,
+                           d_logit=None, d_h=None, loss=None, workspace=None, dst_W2="inplace", dst_b2="inplace"):
+        assert loss_mode == 0
+        dst_W2 = W2 if isinstance(dst_W2, str) else dst_W2
+        dst_b2 = b2 if isinstance(dst_b2, str) else dst_b2
+        h = x @ W1 + b1
+        if act:
+            h = torch.relu(h)
+        z = (h @ W2)[:, 0] + b2[0] + (extra_logit if extra_logit is not None else 0.0)
+        prob.copy_(torch.sigmoid(z))
+        d_logit.copy_((torch.sigmoid(z) - labels) / z.numel())
+        loss.copy_(T.sigmoid_cross_entropy(labels, z).reshape(1))
+        d_h.copy_(d_logit[:, None] * W2[:, 0][None, :] * ((h > 0).float() if act else 1.0))
+        if dst_W2 is not None:
+            dst_W2 += scale * (h.t() @ d_logit[:, None])
+        if dst_b2 is not None:
+            dst_b2 += scale * d_logit.sum()
+        return loss, prob, d_logit, d_h
 
     @staticmethod
     def bce_fwd_bwd(logits, labels, mode, workspace=None, logits_b=None, out=None, **kw):
