@@ -28,7 +28,7 @@ SIGNATURES = {
     "dr_linear_bwd_dw_workspace_bytes": [_i64, _i32, _i32],
     "dr_linear_bwd_narrow_workspace_bytes": [_i64, _i32, _i32],
     "dr_tower_head_workspace_bytes": [_i64],
-    "dr_tower_head_fwd_bwd": [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _p, _i32, _f32, _p, _i64, _p,
+    "dr_tower_head_fwd_bwd": [_p, _i64, _p, _i64, _p, _i64, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _p, _i32, _f32, _p, _i64, _p,
                               _p, _i64, _p, _p, _p, _i64, _p, _p, _i64, _p],
     "dr_linear_bwd_narrow": [_p, _i64, _p, _i64, _p, _i64, _i64, _i32, _i32, _i32, _f32, _p, _i64, _p, _p, _i64, _p, _i64, _p],
     "dr_cross_fwd": [_p, _p, _i64, _p, _i64, _p, _f32, _i64, _i32, _p, _p, _p],

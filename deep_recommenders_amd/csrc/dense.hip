@@ -729,9 +729,9 @@ extern "C" int64_t dr_tower_head_workspace_bytes(int64_t M) {
 }
 
 extern "C" int dr_tower_head_fwd_bwd(const float* x, int64_t ld_x, const float* W1, int64_t ld_w1, const float* b1,
-                                     int64_t M, int32_t K, int32_t H, int32_t act, const float* w2, int64_t ld_w2,
-                                     const float* b2, const float* extra_logit, const float* labels, int32_t loss_mode,
-                                     float scale, float* dst_w2, int64_t ld_dst_w2, float* dst_b2,
+                                     int64_t M, int64_t n_total, int32_t K, int32_t H, int32_t act, const float* w2,
+                                     int64_t ld_w2, const float* b2, const float* extra_logit, const float* labels,
+                                     int32_t loss_mode, float scale, float* dst_w2, int64_t ld_dst_w2, float* dst_b2,
                                      float* h_out, int64_t ld_h, float* prob, float* d_logit, float* d_h, int64_t ld_dh,
                                      float* loss_out, void* workspace, int64_t workspace_bytes, dr_stream_t stream) {
     if (M <= 0 || K <= 0 || H <= 0) return DR_EINVAL;
@@ -744,7 +744,7 @@ extern "C" int dr_tower_head_fwd_bwd(const float* x, int64_t ld_x, const float* 
     g.C = h_out; g.ldc = ld_h;
     g.bias = b1; g.act = act;
     g.head_w = w2; g.ld_head_w = ld_w2; g.head_b = b2; g.head_extra = extra_logit; g.labels = labels;
-    g.loss_mode = loss_mode; g.inv_n = 1.f / (float)M;
+    g.loss_mode = loss_mode; g.inv_n = 1.f / (float)(n_total > 0 ? n_total : M);
     g.prob = prob; g.d_logit = d_logit; g.d_h = d_h; g.ld_dh = ld_dh;
     g.head_partial = static_cast<float*>(workspace);
     g.split = 1;

@@ -222,10 +222,11 @@ def tower_head_workspace(M, device):
 
 
 def tower_head_fwd_bwd(x, W1, b1, W2, b2, extra_logit, labels, loss_mode, scale, act=1, h_out=None, prob=None, d_logit=None,
-                       d_h=None, loss=None, workspace=None, dst_W2="inplace", dst_b2="inplace"):
+                       d_h=None, loss=None, workspace=None, dst_W2="inplace", dst_b2="inplace", n_total=0):
     """Last hidden layer (H <= 32) + Dense(1) + extra logit + BCE loss + the Dense(1) backward, fused.
     W2: [H, 1] (any row stride).  dst_W2 / dst_b2 += scale * gradient: by default the parameters themselves (fused SGD,
-    scale = -lr); pass gradient buffers with scale = 1 for data-parallel training, or None to skip.
+    scale = -lr); pass gradient buffers with scale = 1 for data-parallel training, or None to skip.  n_total: size of
+    the batch the loss is a mean over when x is one slice of it (0 = M).
     Returns (loss, prob, d_logit, d_h)."""
     if isinstance(dst_W2, str):
         dst_W2 = W2
@@ -241,7 +242,7 @@ def tower_head_fwd_bwd(x, W1, b1, W2, b2, extra_logit, labels, loss_mode, scale,
     loss = loss if loss is not None else torch.empty(1, dtype=torch.float32, device=dev)
     if workspace is None:
         workspace = tower_head_workspace(M, dev)
-    check(lib().dr_tower_head_fwd_bwd(ptr(x), x.stride(0), ptr(W1), W1.stride(0), ptr(b1), M, K, H, int(act), ptr(W2),
+    check(lib().dr_tower_head_fwd_bwd(ptr(x), x.stride(0), ptr(W1), W1.stride(0), ptr(b1), M, int(n_total), K, H, int(act), ptr(W2),
                                       W2.stride(0), ptr(b2), ptr(extra_logit), ptr(labels), int(loss_mode), float(scale),
                                       ptr(dst_W2), dst_W2.stride(0) if dst_W2 is not None else 0, ptr(dst_b2),
                                       ptr(h_out), h_out.stride(0) if h_out is not None else 0, ptr(prob), ptr(d_logit),

@@ -76,7 +76,7 @@ class ShardedEmbeddingExchange:
     side packs its per-slot gradients straight into the all-to-all send layout (dr_emb_pack_grads: a permutation)."""
 
     GROUP = 32      # pseudo-fields per pseudo-example of the owner-side slot list
-    SLOTS = 2       # routes in flight: the one being trained on and the prefetched one
+    SLOTS = 4       # routes in flight: (micro-batches per step = 2) x (the step being trained + the prefetched one)
 
     def __init__(self, num_fields, vocab_per_field, dim, world, rank, device, prims=None, group=None):
         self.F, self.V, self.D = num_fields, vocab_per_field, dim
@@ -89,7 +89,6 @@ class ShardedEmbeddingExchange:
         self._zero_base_g = torch.zeros(self.GROUP, dtype=torch.int64, device=device)
         self._col_start = torch.arange(num_fields + 1, dtype=torch.int32, device=device)
         self._col_buckets = torch.full((num_fields,), vocab_per_field, dtype=torch.int64, device=device)
-        self._st = None
         self._cuda = torch.device(device).type == "cuda"
         self._rs = torch.cuda.Stream(device=device) if self._cuda else None      # routing stream
         # per-slot owner-side buffers (the route of step t is still read by step t's backward while step t+1 is routed)
@@ -158,42 +157,50 @@ class ShardedEmbeddingExchange:
                 r.sorted.record(self._rs)
         return r
 
-    # ---- steps 4-6 ---------------------------------------------------------------------------------------------
-    def forward(self, route, table_local, lin_local, lin_bias, ld_concat, concat=None, sum_x=None, fm_logit=None):
+    # ---- steps 4-5: owner gather + rows back (communication stream) ---------------------------------------------
+    def fetch(self, route, table_local, lin_local):
         r = route
         sl = self._slots[r.slot]
-        n, D, F = r.n, self.D, self.F
         if self._cuda:
-            cur = torch.cuda.current_stream()
-            cur.wait_event(r.ready)
-            r.pos.record_stream(cur)
+            torch.cuda.current_stream().wait_event(r.ready)
         recv_rows = sl["rows_pad"][:r.n_recv]
         rows_buf, lin_buf = self.p.rows_gather(recv_rows, table_local, lin_local)     # owner-side gather
-        got_rows = torch.empty((n, D), dtype=torch.float32, device=recv_rows.device)
+        got_rows = torch.empty((r.n, self.D), dtype=torch.float32, device=recv_rows.device)
         self._a2a(got_rows, rows_buf, r.send_splits, r.recv_splits)                   # C2
         got_lin = None
         if lin_local is not None:
-            got_lin = torch.empty(n, dtype=torch.float32, device=recv_rows.device)
+            got_lin = torch.empty(r.n, dtype=torch.float32, device=recv_rows.device)
             self._a2a(got_lin, lin_buf, r.send_splits, r.recv_splits)
-        # K3 over the received rows: ids := position in the receive buffer, table := receive buffer
-        concat, sum_x, fm_logit = self.p.emb_pool_fwd(r.pos, F, None if F <= 64 else self._col_start, self._zero_base,
-                                                      got_rows, got_lin, lin_bias, ld_concat=ld_concat, concat=concat,
-                                                      sum_x=sum_x, fm_logit=fm_logit)
         r.has_lin = lin_local is not None
-        self._st = r
-        return concat, sum_x, fm_logit
+        return got_rows, got_lin
 
-    def pack(self, d_concat, d_fm_logit, concat, sum_x, g_bias=None):
+    # ---- step 6: K3 over the received rows (ids := position in the receive buffer, table := receive buffer) --------
+    def pool(self, route, got_rows, got_lin, lin_bias, ld_concat, concat=None, sum_x=None, fm_logit=None):
+        r, F = route, self.F
+        if self._cuda:
+            cur = torch.cuda.current_stream()
+            for t in (r.pos, got_rows, got_lin):
+                if t is not None:
+                    t.record_stream(cur)
+        return self.p.emb_pool_fwd(r.pos, F, None if F <= 64 else self._col_start, self._zero_base, got_rows, got_lin,
+                                   lin_bias, ld_concat=ld_concat, concat=concat, sum_x=sum_x, fm_logit=fm_logit)
+
+    def forward(self, route, table_local, lin_local, lin_bias, ld_concat, concat=None, sum_x=None, fm_logit=None):
+        got_rows, got_lin = self.fetch(route, table_local, lin_local)
+        return self.pool(route, got_rows, got_lin, lin_bias, ld_concat, concat=concat, sum_x=sum_x, fm_logit=fm_logit)
+
+    # ---- step 8 -------------------------------------------------------------------------------------------------
+    def pack(self, route, d_concat, d_fm_logit, concat, sum_x, g_bias=None):
         """requesting side: per-slot gradients into the send layout (local, HBM-bound)"""
-        r = self._st
+        r = route
         g_rows = torch.empty((r.n, self.D), dtype=torch.float32, device=r.pos.device)
         g_lin = torch.empty(r.n, dtype=torch.float32, device=r.pos.device) if r.has_lin else None
         self.p.emb_pack_grads(r.pos, self.D, d_concat, concat, sum_x, d_fm_logit, g_rows, g_lin, g_bias)
         return g_rows, g_lin
 
-    def exchange_and_apply(self, g_rows, g_lin, scale, table_local, lin_local):
-        """C3 + owner-side update (may run on a communication stream, overlapped with the tower's wgrad)"""
-        r = self._st
+    def exchange_and_apply(self, route, g_rows, g_lin, scale, table_local, lin_local):
+        """C3 + owner-side update (runs on the communication stream, overlapped with the tower)"""
+        r = route
         sl = self._slots[r.slot]
         D, G = self.D, self.GROUP
         g_pad, gl_pad, rows_pad = sl["g_pad"][:r.n_pad], sl["gl_pad"][:r.n_pad], sl["rows_pad"][:r.n_pad]
@@ -214,10 +221,6 @@ class ShardedEmbeddingExchange:
             sl["free_ev"] = torch.cuda.Event()
             sl["free_ev"].record()
 
-    def backward(self, d_concat, d_fm_logit, concat, sum_x, scale, table_local, lin_local, g_bias=None):
-        g_rows, g_lin = self.pack(d_concat, d_fm_logit, concat, sum_x, g_bias)
-        self.exchange_and_apply(g_rows, g_lin, scale, table_local, lin_local)
-
 
 class _NullCtx:
     def __enter__(self):
@@ -233,7 +236,7 @@ class ShardedDeepFMEngine:
 
     def __init__(self, num_fields, vocab_per_field, dim, dnn_units: Sequence[int], batch, num_dense=0, lr=0.01,
                  device="cuda", world=None, rank=None, seed=42, prims=None, group=None, lin_init_std=0.0,
-                 init_tables=None):
+                 init_tables=None, micro_batches=None):
         self.world = world if world is not None else dist.get_world_size(group)
         self.rank = rank if rank is not None else dist.get_rank(group)
         self.F, self.V, self.D, self.B = num_fields, vocab_per_field, dim, batch
@@ -320,9 +323,17 @@ class ShardedDeepFMEngine:
             self.head_ws = None
             self.narrow_ws = [None] * nl
             self.dw_ws = [None] * nl
-        self.comm = torch.cuda.Stream(device=device) if self._cuda else None   # backward exchange + owner update
-        self.ev_packed = torch.cuda.Event() if self._cuda else None
-        self.ev_applied = torch.cuda.Event() if self._cuda else None
+        self.comm = torch.cuda.Stream(device=device) if self._cuda else None   # every exchange + the owner-side updates
+        # micro-batches per step (see train_step); needs the fused head (per-slice loss normalisation) and slices the
+        # narrow kernel accepts
+        mb = int(micro_batches) if micro_batches else 2
+        if not self.fuse_head or B % mb:
+            mb = 1
+        self.mb = mb
+        Bm = B // mb
+        self.narrow = [hasattr(self.p, "linear_bwd_narrow") and i > 0 and self.acts[i - 1] == 1
+                       and self.p.linear_bwd_narrow_supported(Bm, Wt.shape[0], Wt.shape[1]) for i, Wt in enumerate(self.Ws)]
+        self.loss_parts = torch.zeros(mb, **f32)
         self._events = None
         self._route = None
         self._done = []
@@ -352,98 +363,144 @@ class ShardedDeepFMEngine:
             out[name] = {"bound": bound, "ms": ms, "n": len(evs), key: work}
         return out
 
+    def _mb_slices(self):
+        Bm = self.B // self.mb
+        return [slice(m * Bm, (m + 1) * Bm) for m in range(self.mb)]
+
+    def _route_batch(self, keys, wait_current):
+        return [self.ex.route(keys[sl], hashed=True, wait_current=wait_current) for sl in self._mb_slices()]
+
     def prefetch_route(self, next_keys):
         """Route the NEXT batch (hash, bucket, id exchange, owner-side sort) now, on the routing stream.  `next_keys` must
         already be complete (it is not ordered against the training stream)."""
-        self._route = self.ex.route(next_keys, hashed=True, wait_current=False)
+        self._route = (self._route_batch(next_keys, False), (next_keys.data_ptr(), tuple(next_keys.shape)))
 
     def train_step(self, keys, dense, labels, next_keys=None):
-        p, F, D, W, B = self.p, self.F, self.D, self.world, self.B
-        if self._cuda:                                   # bound the host's run-ahead to two steps
-            if len(self._done) >= 2:
-                self._done.pop(0).synchronize()
-        # steps 1-3: use the prefetched route if it was built for exactly these keys, else route now
-        route = self._route
+        """One step.  The rank's batch is processed as `self.mb` micro-batches that share one set of weights (all
+        forwards read pre-update tables; the dense gradients are summed; the loss is the mean over world * B examples):
+        micro-batch m+1's row exchange is in flight while micro-batch m runs its tower, and micro-batch m's gradient
+        exchange + owner-side update run under micro-batch m+1's tower and the first-layer wgrad."""
+        p, F, D, W, B, M = self.p, self.F, self.D, self.world, self.B, self.mb
+        Bm = B // M
+        cuda = self._cuda
+        if cuda and len(self._done) >= 2:                 # bound the host's run-ahead to two steps
+            self._done.pop(0).synchronize()
+        # steps 1-3: use the prefetched routes if they were built for exactly these keys, else route now
+        routes = None
+        if self._route is not None and self._route[1] == (keys.data_ptr(), tuple(keys.shape)):
+            routes = self._route[0]
         self._route = None
-        if route is None or route.key != (keys.data_ptr(), tuple(keys.shape)):
-            route = self._k("emb_route(hash+bucket+a2a ids+sort)", "xgmi", B * F * 24, lambda: self.ex.route(keys, hashed=True))
-        # steps 4-6: owner gather, exchange rows, fused pool+FM over the received rows
-        self._k("emb_exchange_fwd(gather+a2a+K3)", "xgmi", B * F * (8 + 4 * D + 4),
-                lambda: self.ex.forward(route, self.table, self.lin_w, self.lin_bias, self.ld, concat=self.concat,
-                                        sum_x=self.sum_x, fm_logit=self.fm_logit))
-        if next_keys is not None:
-            # queued after this step's forward exchange, before its backward collectives: the route's host sync then only
-            # waits for the forward exchange, and the host stays a whole tower ahead of the GPU
-            self.prefetch_route(next_keys)
+        if routes is None:
+            routes = self._k("emb_route(hash+bucket+a2a ids+sort)", "xgmi", B * F * 24, lambda: self._route_batch(keys, True))
+        main = torch.cuda.current_stream() if cuda else None
+        comm_ctx = (lambda: torch.cuda.stream(self.comm)) if cuda else _NullCtx
+        # ---- steps 4-5 for every micro-batch, back to back on the communication stream ---------------------------
+        got, ev_rows = [], []
+        if cuda:
+            self.comm.wait_stream(main)       # tables / weights of the previous step are final (K4 ran on comm; belt and braces)
+        with comm_ctx():
+            for m in range(M):
+                got.append(self._k("emb_fetch(gather+a2a rows)", "xgmi", Bm * F * (4 * D + 4),
+                                   lambda m=m: self.ex.fetch(routes[m], self.table, self.lin_w)))
+                if cuda:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    ev_rows.append(ev)
+        self.flat_grads.zero_()
         if self.Nd:
             self.concat[:, F * D:F * D + self.Nd].copy_(dense)
-        x = self.concat[:, :self.in_dim]
         n_layers = len(self.Ws)
-        self.flat_grads.zero_()
-        for i, (Wt, b) in enumerate(zip(self.Ws, self.bs)):
-            if self.fuse_head and i == n_layers - 2:
-                break
-            self._k("linear_fwd_L%d" % i, "mfma", 2.0 * B * Wt.shape[0] * Wt.shape[1],
-                    lambda x=x, Wt=Wt, b=b, i=i: p.linear_fwd(x, Wt, b, self.acts[i], out=self.hs[i]))
-            x = self.hs[i]
-        if self.fuse_head:
-            # Dense(H<=32, relu) + Dense(1) + FM logit + loss + the Dense(1) gradient (into the all-reduce bucket), fused
-            self._k("tower_head_fwd_bwd", "hbm", 4.0 * B * (self.Ws[-2].shape[0] + self.Ws[-2].shape[1] + 4),
-                    lambda x=x: p.tower_head_fwd_bwd(x, self.Ws[-2], self.bs[-2], self.Ws[-1], self.bs[-1], self.fm_logit, labels,
-                                                      ops.LOSS_SIGMOID_CE, 1.0, act=1, prob=self.prob, d_logit=self.d_logit,
-                                                      d_h=self.dhs[-1], loss=self.loss, workspace=self.head_ws,
-                                                      dst_W2=self.gWs[-1], dst_b2=self.gbs[-1]))
-        else:
-            p.bce_fwd_bwd(self.fm_logit, labels, ops.LOSS_SIGMOID_CE, workspace=self.ws, logits_b=self.hs[-1],
-                          out=(self.prob, self.d_logit, self.loss))
-        # ---- backward: dense tower gradients into the flat bucket ----------------------------------------
-        # dgrad chain first (it produces d_concat, the input of the embedding exchange); wgrads afterwards so that they
-        # overlap the backward exchange running on the communication stream.  Narrow layers do dx + dW in one kernel.
+        x_in = self.concat[:, :self.in_dim]
         dys = [None] * n_layers
-        dy = self.d_logit.reshape(-1, 1)
-        top = n_layers - 1
-        if self.fuse_head:
-            top = n_layers - 2
-            dy = self.dhs[-1]
         dw_todo = []
-        for i in range(top, -1, -1):
-            dys[i] = dy
-            if i > 0:
-                dx = self.dhs[i - 1]
-                rs = self.hs[i - 1] if self.acts[i - 1] else None
+        slices = self._mb_slices()
+        prefetched = next_keys is None
+        ev_last_apply = None
+        for m, sl in enumerate(slices):
+            # ---- step 6 + tower forward + loss ----------------------------------------------------------------------
+            if cuda:
+                main.wait_event(ev_rows[m])
+            self._k("emb_pool_fwd", "hbm", Bm * (8 * F * D + 12 * F + 8),
+                    lambda m=m, sl=sl: self.ex.pool(routes[m], got[m][0], got[m][1], self.lin_bias, self.ld, concat=self.concat[sl],
+                                                   sum_x=self.sum_x[sl], fm_logit=self.fm_logit[sl]))
+            x = x_in[sl]
+            for i, (Wt, b) in enumerate(zip(self.Ws, self.bs)):
+                if self.fuse_head and i == n_layers - 2:
+                    break
+                self._k("linear_fwd_L%d" % i, "mfma", 2.0 * Bm * Wt.shape[0] * Wt.shape[1],
+                        lambda x=x, Wt=Wt, b=b, i=i, sl=sl: p.linear_fwd(x, Wt, b, self.acts[i], out=self.hs[i][sl]))
+                x = self.hs[i][sl]
+            if self.fuse_head:
+                self._k("tower_head_fwd_bwd", "hbm", 4.0 * Bm * (self.Ws[-2].shape[0] + self.Ws[-2].shape[1] + 4),
+                        lambda x=x, sl=sl, m=m: p.tower_head_fwd_bwd(
+                            x, self.Ws[-2], self.bs[-2], self.Ws[-1], self.bs[-1], self.fm_logit[sl], labels[sl],
+                            ops.LOSS_SIGMOID_CE, 1.0, act=1, prob=self.prob[sl], d_logit=self.d_logit[sl], d_h=self.dhs[-1][sl],
+                            loss=self.loss_parts[m:m + 1], workspace=self.head_ws, dst_W2=self.gWs[-1], dst_b2=self.gbs[-1],
+                            n_total=B))
+            else:                                          # M == 1 here (see __init__)
+                p.bce_fwd_bwd(self.fm_logit, labels, ops.LOSS_SIGMOID_CE, workspace=self.ws, logits_b=self.hs[-1],
+                              out=(self.prob, self.d_logit, self.loss_parts[0:1]))
+            # ---- dgrad chain (produces d_concat, the input of the embedding exchange) ------------------------------
+            dy = self.d_logit[sl].reshape(-1, 1)
+            top = n_layers - 1
+            if self.fuse_head:
+                top = n_layers - 2
+                dy = self.dhs[-1][sl]
+            for i in range(top, -1, -1):
+                if i > 0:
+                    dx = self.dhs[i - 1][sl]
+                    rs = self.hs[i - 1][sl] if self.acts[i - 1] else None
+                else:
+                    dx = self.d_concat[sl, :self.in_dim]
+                    rs = None
+                if self.narrow[i]:
+                    self._k("linear_bwd_narrow_L%d" % i, "hbm", 4.0 * Bm * (2 * self.Ws[i].shape[0] + self.Ws[i].shape[1]),
+                            lambda dy=dy, i=i, dx=dx, sl=sl: p.linear_bwd_narrow(self.hs[i - 1][sl], dy, self.Ws[i], 1.0, self.gWs[i],
+                                                                                self.gbs[i], dx, relu_mask=True,
+                                                                                workspace=self.narrow_ws[i]))
+                else:
+                    self._k("linear_bwd_dx_L%d" % i, "mfma", 2.0 * Bm * self.Ws[i].shape[0] * self.Ws[i].shape[1],
+                            lambda dy=dy, i=i, rs=rs, dx=dx: p.linear_bwd_dx(dy, self.Ws[i], relu_src=rs, out=dx))
+                    if m == 0:
+                        dw_todo.append(i)
+                dy = dx
+            # ---- step 8: pack (local), then C3 + owner-side sorted update on the communication stream ------------------
+            g_rows, g_lin = self._k("emb_pack_grads", "hbm", Bm * F * (12 * D + 4),
+                                    lambda sl=sl, m=m: self.ex.pack(routes[m], self.d_concat[sl], self.d_logit[sl], self.concat[sl],
+                                                                    self.sum_x[sl], self.g_lin_bias))
+            if not prefetched and m == M - 1:
+                # Route the next batch now: the last micro-batch's whole tower is already enqueued, so the route's host sync
+                # (it waits for the collectives issued so far plus a handful of small kernels) overlaps queued GPU work, and
+                # its two small all-to-alls sit in front of the last gradient exchange instead of behind it.
+                self.prefetch_route(next_keys)
+                prefetched = True
+            if cuda:
+                ev_p = torch.cuda.Event()
+                ev_p.record()
+                with torch.cuda.stream(self.comm):
+                    self.comm.wait_event(ev_p)
+                    self._k("emb_grads(a2a+sorted K4)", "xgmi", Bm * F * (4 * D + 4),
+                            lambda m=m, g_rows=g_rows, g_lin=g_lin: self.ex.exchange_and_apply(routes[m], g_rows, g_lin, -self.lr / W,
+                                                                                               self.table, self.lin_w))
+                    if m == M - 1:
+                        ev_last_apply = torch.cuda.Event()
+                        ev_last_apply.record()
             else:
-                dx = self.d_concat[:, :self.in_dim]
-                rs = None
-            if self.narrow[i]:
-                self._k("linear_bwd_narrow_L%d" % i, "hbm", 4.0 * B * (2 * self.Ws[i].shape[0] + self.Ws[i].shape[1]),
-                        lambda dy=dy, i=i, dx=dx: p.linear_bwd_narrow(self.hs[i - 1], dy, self.Ws[i], 1.0, self.gWs[i], self.gbs[i],
-                                                                      dx, relu_mask=True, workspace=self.narrow_ws[i]))
-            else:
-                self._k("linear_bwd_dx_L%d" % i, "mfma", 2.0 * B * self.Ws[i].shape[0] * self.Ws[i].shape[1],
-                        lambda dy=dy, i=i, rs=rs, dx=dx: p.linear_bwd_dx(dy, self.Ws[i], relu_src=rs, out=dx))
-                dw_todo.append(i)
-            dy = dx
-        # ---- embedding backward: pack (local), then C3 + owner-side sorted update on the communication stream -------
-        g_rows, g_lin = self._k("emb_pack_grads", "hbm", B * F * (12 * D + 4),
-                                lambda: self.ex.pack(self.d_concat, self.d_logit, self.concat, self.sum_x, self.g_lin_bias))
-        if self._cuda:
-            self.ev_packed.record()
-            with torch.cuda.stream(self.comm):
-                self.comm.wait_event(self.ev_packed)
-                self.ex.exchange_and_apply(g_rows, g_lin, -self.lr / W, self.table, self.lin_w)
-                self.ev_applied.record(self.comm)
-        else:
-            self.ex.exchange_and_apply(g_rows, g_lin, -self.lr / W, self.table, self.lin_w)
+                self.ex.exchange_and_apply(routes[m], g_rows, g_lin, -self.lr / W, self.table, self.lin_w)
+        # ---- wgrads over the WHOLE rank batch (activations of all micro-batches are contiguous): under the last exchange --
+        dys[0] = self.dhs[0] if n_layers > 1 else self.d_logit.reshape(-1, 1)
         for i in dw_todo:
-            xin = self.concat[:, :self.in_dim] if i == 0 else self.hs[i - 1]
+            xin = x_in if i == 0 else self.hs[i - 1]
+            dyi = self.dhs[i] if i < n_layers - 1 else self.d_logit.reshape(-1, 1)
             self._k("linear_bwd_dw_L%d" % i, "mfma", 2.0 * B * self.Ws[i].shape[0] * self.Ws[i].shape[1],
-                    lambda xin=xin, i=i: p.linear_bwd_dw(xin, dys[i], 1.0, self.gWs[i], self.gbs[i], workspace=self.dw_ws[i]))
+                    lambda xin=xin, dyi=dyi, i=i: p.linear_bwd_dw(xin, dyi, 1.0, self.gWs[i], self.gbs[i], workspace=self.dw_ws[i]))
         # ---- dense tower: one all-reduce, then w += -(lr / W) * sum_r g_r  (mean over the global batch) ------
         self._k("allreduce_dense_grads", "xgmi", self.flat_grads.numel() * 4,
                 lambda: dist.all_reduce(self.flat_grads, group=self.group))
         p.axpy(-self.lr / W, self.flat_grads, self.flat_params)
-        if self._cuda:
-            torch.cuda.current_stream().wait_event(self.ev_applied)     # next step's gather must see the update
+        torch.sum(self.loss_parts, dim=0, keepdim=True, out=self.loss)
+        if cuda:
+            main.wait_event(ev_last_apply)                 # the step ends when every owner has applied its updates
             ev = torch.cuda.Event()
             ev.record()
             self._done.append(ev)

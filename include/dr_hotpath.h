@@ -212,12 +212,14 @@ int dr_linear_bwd_narrow(const float* x, int64_t ld_x, const float* dy, int64_t 
  *   dst_w2 += scale * h^T d_logit ;  dst_b2 += scale * sum(d_logit)
  *            dst_* = the parameters themselves with scale = -lr (fused SGD; d_h always uses the pre-update w2), or
  *            gradient buffers with scale = 1 (data-parallel: all-reduce, then apply); NULL / scale = 0: skipped
+ * n_total (0 = M): the number of examples the loss is a mean over, when these M rows are one slice of a larger batch
+ * (micro-batches): loss_out = sum(l) / n_total, d_logit = dl/dlogit / n_total.
  * Deterministic.  H > 32 returns DR_ESHAPE (use dr_linear_fwd x2 + dr_bce_fwd_bwd + dr_linear_bwd_*). */
 int64_t dr_tower_head_workspace_bytes(int64_t M);
 int dr_tower_head_fwd_bwd(const float* x, int64_t ld_x, const float* W1, int64_t ld_w1, const float* b1,
-                          int64_t M, int32_t K, int32_t H, int32_t act, const float* w2, int64_t ld_w2,
-                          const float* b2, const float* extra_logit, const float* labels, int32_t loss_mode,
-                          float scale, float* dst_w2, int64_t ld_dst_w2, float* dst_b2, float* h_out, int64_t ld_h, float* prob, float* d_logit, float* d_h, int64_t ld_dh,
+                          int64_t M, int64_t n_total, int32_t K, int32_t H, int32_t act, const float* w2,
+                          int64_t ld_w2, const float* b2, const float* extra_logit, const float* labels,
+                          int32_t loss_mode, float scale, float* dst_w2, int64_t ld_dst_w2, float* dst_b2, float* h_out, int64_t ld_h, float* prob, float* d_logit, float* d_h, int64_t ld_dh,
                           float* loss_out, void* workspace, int64_t workspace_bytes, dr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------

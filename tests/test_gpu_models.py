@@ -357,24 +357,31 @@ def test_sharded_engine_world1_matches_unsharded_engine():
     os.environ.setdefault("MASTER_PORT", "29533")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
-        F, V, D, B, Nd = 6, 3000, 16, 777, 3
+        F, V, D, B, Nd = 6, 3000, 16, 768, 3
         ref = DeepFMEngine(F, V, D, [32, 16], B, num_dense=Nd, lr=0.05, seed=9, lin_init_std=0.1)
         sh = ShardedDeepFMEngine(F, V, D, [32, 16], B, num_dense=Nd, lr=0.05, device="cuda", world=1, rank=0, seed=9,
                                  init_tables=(ref.table.clone(), ref.lin_w.clone()))
+        assert sh.mb == 2                                   # two micro-batches per step
         for a, b in zip(sh.Ws, ref.Ws):
             a.copy_(b)
         g = torch.Generator(device="cuda")
         g.manual_seed(2)
-        keys = torch.randint(0, 10**14, (B, F), device="cuda", generator=g)
-        keys[5, 2] = -1
-        dense = torch.rand((B, Nd), device="cuda", generator=g)
-        labels = (torch.rand(B, device="cuda", generator=g) < 0.25).float()
-        l_ref = ref.train_step(keys, dense, labels).item()
-        l_sh = sh.train_step(keys, dense, labels).item()
-        assert abs(l_ref - l_sh) <= 1e-6 * abs(l_ref)
-        np.testing.assert_allclose(sh.table.cpu().numpy(), ref.table.cpu().numpy(), rtol=1e-5, atol=1e-6)
-        np.testing.assert_allclose(sh.lin_w.cpu().numpy(), ref.lin_w.cpu().numpy(), rtol=1e-5, atol=1e-6)
+        batches = []
+        for _ in range(3):
+            keys = torch.randint(0, 10**14, (B, F), device="cuda", generator=g)
+            keys[5, 2] = -1
+            dense = torch.rand((B, Nd), device="cuda", generator=g)
+            labels = (torch.rand(B, device="cuda", generator=g) < 0.25).float()
+            batches.append((keys, dense, labels))
+        for t, (keys, dense, labels) in enumerate(batches):     # prefetched routes from the second step on
+            nk = batches[t + 1][0] if t + 1 < len(batches) else None
+            l_ref = ref.train_step(keys, dense, labels).item()
+            l_sh = sh.train_step(keys, dense, labels, next_keys=nk).item()
+            assert abs(l_ref - l_sh) <= 2e-6 * abs(l_ref)
+        np.testing.assert_allclose(sh.table.cpu().numpy(), ref.table.cpu().numpy(), rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(sh.lin_w.cpu().numpy(), ref.lin_w.cpu().numpy(), rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(sh.lin_bias.cpu().numpy(), ref.lin_bias.cpu().numpy(), rtol=2e-5, atol=2e-7)
         for a, b in zip(sh.Ws, ref.Ws):
-            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-5, atol=2e-6)
     finally:
         dist.destroy_process_group()

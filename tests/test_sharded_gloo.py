@@ -144,8 +144,9 @@ class OraclePrims:
 
     @staticmethod
     def tower_head_fwd_bwd(x, W1, b1, W2, b2, extra_logit, labels, loss_mode, scale, act=1, h_out=None, prob=None,
-                           d_logit=None, d_h=None, loss=None, workspace=None, dst_W2="inplace", dst_b2="inplace"):
+                           d_logit=None, d_h=None, loss=None, workspace=None, dst_W2="inplace", dst_b2="inplace", n_total=0):
         assert loss_mode == 0
+        nt = n_total if n_total else x.shape[0]
         dst_W2 = W2 if isinstance(dst_W2, str) else dst_W2
         dst_b2 = b2 if isinstance(dst_b2, str) else dst_b2
         h = x @ W1 + b1
@@ -153,8 +154,8 @@ class OraclePrims:
             h = torch.relu(h)
         z = (h @ W2)[:, 0] + b2[0] + (extra_logit if extra_logit is not None else 0.0)
         prob.copy_(torch.sigmoid(z))
-        d_logit.copy_((torch.sigmoid(z) - labels) / z.numel())
-        loss.copy_(T.sigmoid_cross_entropy(labels, z).reshape(1))
+        d_logit.copy_((torch.sigmoid(z) - labels) / nt)
+        loss.copy_((T.sigmoid_cross_entropy(labels, z) * z.numel() / nt).reshape(1))
         d_h.copy_(d_logit[:, None] * W2[:, 0][None, :] * ((h > 0).float() if act else 1.0))
         if dst_W2 is not None:
             dst_W2 += scale * (h.t() @ d_logit[:, None])
@@ -187,44 +188,59 @@ def _free_port():
 CFG = dict(F=4, V=37, D=8, B=24, Nd=3, units=[16, 8], lr=0.1)
 
 
+NSTEPS = 2
+
+
 def _global_problem():
+    """NSTEPS global batches of 2 * B examples (rank r trains on rows [r*B, (r+1)*B) of each)."""
     g = torch.Generator().manual_seed(123)
     c = CFG
     table = torch.randn((c["F"] * c["V"], c["D"]), generator=g) * 0.3
     lin = torch.randn(c["F"] * c["V"], generator=g) * 0.1
-    keys = torch.randint(0, 10**9, (2 * c["B"], c["F"]), generator=g)
-    keys[3, 1] = -1                                # a missing id travels through the exchange as a zero row
-    dense = torch.rand((2 * c["B"], c["Nd"]), generator=g)
-    labels = (torch.rand(2 * c["B"], generator=g) < 0.3).float()
-    return table, lin, keys, dense, labels
+    batches = []
+    for _ in range(NSTEPS):
+        keys = torch.randint(0, 10**9, (2 * c["B"], c["F"]), generator=g)
+        keys[3, 1] = -1                            # a missing id travels through the exchange as a zero row
+        dense = torch.rand((2 * c["B"], c["Nd"]), generator=g)
+        labels = (torch.rand(2 * c["B"], generator=g) < 0.3).float()
+        batches.append((keys, dense, labels))
+    return table, lin, batches
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, micro_batches):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from deep_recommenders_amd.sharded import ShardedDeepFMEngine
         c = CFG
-        table, lin, keys, dense, labels = _global_problem()
+        table, lin, batches = _global_problem()
         eng = ShardedDeepFMEngine(c["F"], c["V"], c["D"], c["units"], c["B"], num_dense=c["Nd"], lr=c["lr"], device="cpu",
-                                  world=world, rank=rank, seed=5, prims=OraclePrims, init_tables=(table, lin))
+                                  world=world, rank=rank, seed=5, prims=OraclePrims, init_tables=(table, lin),
+                                  micro_batches=micro_batches)
+        assert eng.mb == micro_batches
         sl = slice(rank * c["B"], (rank + 1) * c["B"])
         Ws0 = [w.clone() for w in eng.Ws]
         bs0 = [b.clone() for b in eng.bs]
-        loss = eng.train_step(keys[sl], dense[sl], labels[sl]).item()
-        torch.save((rank, loss, eng.table.clone(), eng.lin_w.clone(), [w.clone() for w in eng.Ws],
+        local = [(k[sl].contiguous(), d[sl].contiguous(), l[sl].contiguous()) for k, d, l in batches]
+        losses = []
+        for t, (k, d, l) in enumerate(local):       # every step but the last hands over the next batch's keys (route prefetch)
+            nk = local[t + 1][0] if t + 1 < len(local) else None
+            losses.append(eng.train_step(k, d, l, next_keys=nk).item())
+        torch.save((rank, losses, eng.table.clone(), eng.lin_w.clone(), [w.clone() for w in eng.Ws],
                     [b.clone() for b in eng.bs], eng.lin_bias.clone(), Ws0, bs0), os.path.join(outdir, "rank%d.pt" % rank))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_sharded_step_equals_single_process_oracle(tmp_path):
+@pytest.mark.parametrize("micro_batches", [1, 2])
+def test_two_rank_sharded_steps_equal_single_process_oracle(tmp_path, micro_batches):
+    """2 ranks x NSTEPS steps (prefetched routes, micro-batches) == plain SGD on the global batches in one process."""
     world = 2
     port = _free_port()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path), micro_batches)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -235,37 +251,38 @@ def test_two_rank_sharded_step_equals_single_process_oracle(tmp_path):
         item = torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r))
         res[item[0]] = item[1:]
     c = CFG
-    table, lin, keys, dense, labels = _global_problem()
+    table, lin, batches = _global_problem()
     F, V, D, lr = c["F"], c["V"], c["D"], c["lr"]
-    ids = np.stack([O.hash_bucket_i64(keys[:, f].numpy(), V) for f in range(F)], axis=1)
     Ws0, bs0 = res[0][6], res[0][7]
     for a, b in zip(Ws0, res[1][6]):
         assert torch.equal(a, b)                    # replicas start identical
-    tt = table.clone().requires_grad_(True)
-    tl = lin.clone().requires_grad_(True)
-    tb = torch.zeros(1, requires_grad=True)
-    Ws = [w.clone().requires_grad_(True) for w in Ws0]
-    bs = [b.clone().requires_grad_(True) for b in bs0]
-    logit = T.deepfm_logit(tt, tl, tb, torch.tensor(ids), list(range(F + 1)), [f * V for f in range(F)], Ws, bs, dense)
-    lo = T.sigmoid_cross_entropy(labels, logit)
-    lo.backward()
-    # global loss = mean of the per-rank means (equal batch sizes)
-    assert abs(0.5 * (res[0][0] + res[1][0]) - lo.item()) < 1e-6
-    want_table = (table - lr * tt.grad).detach()
-    want_lin = (lin - lr * tl.grad).detach()
+    # ---- single-process oracle: NSTEPS plain SGD steps on the global batches ----
+    tab, li, bias = table.clone(), lin.clone(), torch.zeros(1)
+    Wc, bc = [w.clone() for w in Ws0], [b.clone() for b in bs0]
+    for t, (keys, dense, labels) in enumerate(batches):
+        ids = np.stack([O.hash_bucket_i64(keys[:, f].numpy(), V) for f in range(F)], axis=1)
+        tt, tl, tb = tab.clone().requires_grad_(True), li.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+        Ws = [w.clone().requires_grad_(True) for w in Wc]
+        bs = [b.clone().requires_grad_(True) for b in bc]
+        logit = T.deepfm_logit(tt, tl, tb, torch.tensor(ids), list(range(F + 1)), [f * V for f in range(F)], Ws, bs, dense)
+        lo = T.sigmoid_cross_entropy(labels, logit)
+        lo.backward()
+        # global loss = mean of the per-rank means (equal batch sizes)
+        assert abs(0.5 * (res[0][0][t] + res[1][0][t]) - lo.item()) < 2e-6
+        tab, li, bias = (tab - lr * tt.grad).detach(), (li - lr * tl.grad).detach(), (bias - lr * tb.grad).detach()
+        Wc = [(w - lr * g.grad).detach() for w, g in zip(Wc, Ws)]
+        bc = [(b - lr * g.grad).detach() for b, g in zip(bc, bs)]
     rps = (V + world - 1) // world
     for r in range(world):
         _, tab_r, lin_r, Ws_r, bs_r, bias_r, _, _ = res[r]
         for f in range(F):
             gid = torch.arange(r, V, world)
-            np.testing.assert_allclose(tab_r[f * rps:f * rps + len(gid)].numpy(), want_table[f * V + gid].numpy(),
-                                       rtol=1e-5, atol=1e-6)
-            np.testing.assert_allclose(lin_r[f * rps:f * rps + len(gid)].numpy(), want_lin[f * V + gid].numpy(),
-                                       rtol=1e-5, atol=1e-6)
-        for i in range(len(Ws)):
-            np.testing.assert_allclose(Ws_r[i].numpy(), (Ws0[i] - lr * Ws[i].grad).numpy(), rtol=1e-5, atol=1e-6)
-            np.testing.assert_allclose(bs_r[i].numpy(), (bs0[i] - lr * bs[i].grad).numpy(), rtol=1e-5, atol=1e-6)
-        np.testing.assert_allclose(bias_r.numpy(), (-lr * tb.grad).numpy(), rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(tab_r[f * rps:f * rps + len(gid)].numpy(), tab[f * V + gid].numpy(), rtol=2e-5, atol=2e-6)
+            np.testing.assert_allclose(lin_r[f * rps:f * rps + len(gid)].numpy(), li[f * V + gid].numpy(), rtol=2e-5, atol=2e-6)
+        for i in range(len(Wc)):
+            np.testing.assert_allclose(Ws_r[i].numpy(), Wc[i].numpy(), rtol=2e-5, atol=2e-6)
+            np.testing.assert_allclose(bs_r[i].numpy(), bc[i].numpy(), rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(bias_r.numpy(), bias.numpy(), rtol=2e-5, atol=2e-7)
 
 
 def test_bucketing_oracle_matches_owner_rule():
