@@ -47,7 +47,17 @@ __global__ __launch_bounds__(256) void mark_unique_kernel(const uint64_t* __rest
         flags[slots[i]] = (valid && seg_start && !has_next) ? 1 : 0;
         const bool head = valid && ((seg_start && has_next) ||
                                     (!seg_start && (i % CH) == 0 && i >= CH && rows[i - CH] == k));
-        if (head) dup_heads[atomicAdd(dup_count, 1)] = (int32_t)i;
+        // append to the head list: ONE atomic per wave (ballot + prefix rank), not one per head -- a skewed batch has ~1e5
+        // heads and same-address atomics retire at ~88 per microsecond
+        const uint64_t bal = __ballot(head);
+        if (bal != 0) {
+            const int lane = threadIdx.x & 63;
+            const int leader = __ffsll((unsigned long long)bal) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(dup_count, __popcll(bal));
+            base = __shfl(base, leader, 64);
+            if (head) dup_heads[base + __popcll(bal & ((1ull << lane) - 1ull))] = (int32_t)i;
+        }
     }
 }
 
@@ -157,57 +167,101 @@ __global__ __launch_bounds__(256) void emb_bwd_dups_kernel(const uint64_t* __res
                                                            const float* __restrict__ d_fm_logit,
                                                            const float* __restrict__ slot_lin, float scale,
                                                            float* __restrict__ table, float* __restrict__ lin_w) {
+    // One lane group (LPR lanes = one table row) per head.  The piece is walked in chunks of LPR sorted entries: the
+    // chunk's row ids and slot numbers are fetched with ONE coalesced load each, the length of the matching prefix comes
+    // from a ballot, and the gradient rows of the prefix are fetched UN at a time with clamped (unconditional) addresses.
+    // (The first version chased slots[j] -> gradient row one entry at a time: a chain of dependent round trips that made
+    // this kernel 3x the cost of everything else in K4 on Zipf-distributed ids.)
     constexpr int NS = DR_WAVE / LPR;
+    constexpr int UN = LPR < 4 ? LPR : 4;
     const int lane = threadIdx.x & 63, slot = lane / LPR, sub = lane % LPR;
-    const bool dvalid = sub * 4 < D;
+    const int nq = D >> 2;
+    const bool dvalid = sub < nq;
+    const int subc = dvalid ? sub : nq - 1;
     const bool fm = concat != nullptr && sum_x != nullptr && d_fm_logit != nullptr;
     const bool any_lin = d_fm_logit != nullptr || slot_lin != nullptr;
+    const float* xsrc = fm ? concat : grad;                    // values unused when !fm
+    const int64_t xld = fm ? ldc : ld;
+    const float* sxsrc = fm ? sum_x : grad;
+    const int64_t sxp = fm ? (int64_t)D : 0;
+    const float* dlsrc = d_fm_logit != nullptr ? d_fm_logit : grad;
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nheads = dup_count[0];
+    const uint64_t gmask = LPR == 64 ? ~0ull : ((1ull << LPR) - 1ull);
     for (int64_t h0 = wave0 * NS; h0 < nheads; h0 += nwaves * NS) {
         const int64_t h = h0 + slot;
-        if (h >= nheads) continue;
-        const int64_t i = dup_heads[h];
+        const bool live = h < nheads;
+        const int64_t i = dup_heads[live ? h : nheads - 1];
         const uint64_t k = rows[i];
-        const bool seg_start = (i == 0) || (rows[i - 1] != k);
+        const bool seg_start = (i == 0) || (rows[i > 0 ? i - 1 : 0] != k);
         // piece owned by this head: the segment start runs to the first aligned position >= i + CH, aligned heads run CH
         int64_t stop = seg_start ? (((i % CH) == 0) ? i + CH : ((i + CH - 1) / CH + 1) * CH) : i + CH;
+        if (stop > n) stop = n;
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         float dls = 0.f;
         int64_t j = i;
-        do {
-            const int32_t p = slots[j];
-            const int32_t b = p / F, f = p - b * F;
-            if (dvalid) {
-                float4 v = *reinterpret_cast<const float4*>(grad + (int64_t)b * ld + f * D + sub * 4);
-                if (fm) {
-                    const float dl = d_fm_logit[b];
-                    const float4 x = *reinterpret_cast<const float4*>(concat + (int64_t)b * ldc + f * D + sub * 4);
-                    const float4 sx = *reinterpret_cast<const float4*>(sum_x + (int64_t)b * D + sub * 4);
-                    v.x += dl * (sx.x - x.x); v.y += dl * (sx.y - x.y); v.z += dl * (sx.z - x.z); v.w += dl * (sx.w - x.w);
+        bool done = !live;
+        while (__any(!done)) {
+            const int64_t jj = j + sub;
+            const bool inb = jj < stop;
+            const int64_t jc = inb ? jj : stop - 1;                       // stop - 1 >= i: always a valid index
+            const uint64_t rk = rows[jc];
+            const int32_t sp = slots[jc];
+            const bool match = !done && inb && rk == k;
+            const uint64_t gb = (__ballot(match) >> (slot * LPR)) & gmask;
+            const int cnt = gb == gmask ? LPR : (__ffsll((unsigned long long)~gb) - 1);     // matching prefix of the chunk
+            for (int t0 = 0; t0 < LPR; t0 += UN) {
+                if (!__any(t0 < cnt)) break;
+                float4 v[UN], x[UN], sxv[UN];
+                float dl[UN], gl[UN];
+                bool act[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const int t = t0 + u;
+                    act[u] = t < cnt;
+                    const int32_t p = __shfl(sp, slot * LPR + (act[u] ? t : 0), 64);
+                    const int32_t b = p / F, f = p - b * F;
+                    v[u] = *reinterpret_cast<const float4*>(grad + (int64_t)b * ld + f * D + subc * 4);
+                    x[u] = *reinterpret_cast<const float4*>(xsrc + (int64_t)b * xld + f * D + subc * 4);
+                    sxv[u] = *reinterpret_cast<const float4*>(sxsrc + (int64_t)b * sxp + subc * 4);
+                    dl[u] = dlsrc[b];
+                    gl[u] = slot_lin != nullptr ? slot_lin[p] : dl[u];
                 }
-                g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    float4 w = v[u];
+                    if (fm) {
+                        w.x += dl[u] * (sxv[u].x - x[u].x); w.y += dl[u] * (sxv[u].y - x[u].y);
+                        w.z += dl[u] * (sxv[u].z - x[u].z); w.w += dl[u] * (sxv[u].w - x[u].w);
+                    }
+                    if (act[u]) {
+                        g.x += w.x; g.y += w.y; g.z += w.z; g.w += w.w;
+                        dls += gl[u];
+                    }
+                }
             }
-            if (any_lin && sub == 0) dls += slot_lin != nullptr ? slot_lin[p] : d_fm_logit[b];
-            ++j;
-        } while (j < n && j < stop && rows[j] == k);
-        const bool exclusive = seg_start && (j >= n || rows[j] != k);
+            j += cnt;
+            if (cnt < LPR || j >= stop) done = true;
+        }
+        const bool exclusive = seg_start && (j >= n || rows[j < n ? j : n - 1] != k);
         float* dst = table + k * (uint64_t)D + sub * 4;
-        if (exclusive) {
-            if (dvalid) {
-                float4 t = *reinterpret_cast<const float4*>(dst);
-                t.x = fmaf(scale, g.x, t.x); t.y = fmaf(scale, g.y, t.y);
-                t.z = fmaf(scale, g.z, t.z); t.w = fmaf(scale, g.w, t.w);
-                *reinterpret_cast<float4*>(dst) = t;
+        if (live) {
+            if (exclusive) {
+                if (dvalid) {
+                    float4 t = *reinterpret_cast<const float4*>(dst);
+                    t.x = fmaf(scale, g.x, t.x); t.y = fmaf(scale, g.y, t.y);
+                    t.z = fmaf(scale, g.z, t.z); t.w = fmaf(scale, g.w, t.w);
+                    *reinterpret_cast<float4*>(dst) = t;
+                }
+                if (lin_w != nullptr && any_lin && sub == 0) lin_w[k] = fmaf(scale, dls, lin_w[k]);
+            } else {
+                if (dvalid) {
+                    unsafeAtomicAdd(dst + 0, scale * g.x); unsafeAtomicAdd(dst + 1, scale * g.y);
+                    unsafeAtomicAdd(dst + 2, scale * g.z); unsafeAtomicAdd(dst + 3, scale * g.w);
+                }
+                if (lin_w != nullptr && any_lin && sub == 0) unsafeAtomicAdd(lin_w + k, scale * dls);
             }
-            if (lin_w != nullptr && any_lin && sub == 0) lin_w[k] = fmaf(scale, dls, lin_w[k]);
-        } else {
-            if (dvalid) {
-                unsafeAtomicAdd(dst + 0, scale * g.x); unsafeAtomicAdd(dst + 1, scale * g.y);
-                unsafeAtomicAdd(dst + 2, scale * g.z); unsafeAtomicAdd(dst + 3, scale * g.w);
-            }
-            if (lin_w != nullptr && any_lin && sub == 0) unsafeAtomicAdd(lin_w + k, scale * dls);
         }
     }
 }
@@ -283,7 +337,8 @@ extern "C" int dr_emb_pool_bwd_sorted(const int64_t* ids, const int64_t* row_bas
     while (lpr * 4 < D) lpr <<= 1;
     const uint64_t* rows = reinterpret_cast<const uint64_t*>(sorted_rows);
     const int grid_u = dr_grid_for(B, 4, 8192);
-    const int grid_d = 256;     // the duplicate work list is short; its length lives on the device
+    const int grid_d = 2048;    // the duplicate list's length lives on the device: uniform ids leave it nearly empty (surplus
+                                // blocks exit at once), skewed ids fill it
 #define CALL(L)                                                                                                       \
     {                                                                                                                 \
         constexpr int NS_ = 64 / L;                                                                                   \
