@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--lr", type=float, default=0.01)
     ap.add_argument("--ids", choices=["uniform", "zipf"], default="uniform")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--optimizer", choices=["sgd", "adam"], default="sgd",
+                    help="sgd: fused SGD (the headline line); adam: fused row-wise Adam in K4 + dense Adam (single GPU only)")
     ap.add_argument("--pool", type=int, default=8, help="number of distinct synthetic batches cycled through")
     return ap.parse_args()
 
@@ -133,7 +135,8 @@ def main():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
     if world == 1 and not force_sharded:
         from deep_recommenders_amd.engine import DeepFMEngine
-        eng = DeepFMEngine(a.fields, a.vocab, a.dim, dnn_units, a.batch, num_dense=a.dense, lr=a.lr, device=device)
+        eng = DeepFMEngine(a.fields, a.vocab, a.dim, dnn_units, a.batch, num_dense=a.dense, lr=a.lr, device=device,
+                           optimizer=a.optimizer)
     else:
         from deep_recommenders_amd.sharded import ShardedDeepFMEngine
         eng = ShardedDeepFMEngine(a.fields, a.vocab, a.dim, dnn_units, a.batch, num_dense=a.dense, lr=a.lr,
@@ -218,9 +221,9 @@ def main():
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "DeepFM Criteo-shape synthetic training step (BASELINE.json configs[2]): %d sparse + %d "
-                                   "dense, %d vocab/field hashed on device, dim %d, DNN %s+[1] relu, sigmoid-CE, fused SGD; "
+                                   "dense, %d vocab/field hashed on device, dim %d, DNN %s+[1] relu, sigmoid-CE, fused %s; "
                                    "batch %d per GPU, ids %s; tables %s"
-                                   % (a.fields, a.dense, a.vocab, a.dim, dnn_units, a.batch, a.ids,
+                                   % (a.fields, a.dense, a.vocab, a.dim, dnn_units, "SGD" if a.optimizer == "sgd" else "Adam (row-wise on the tables)", a.batch, a.ids,
                                       "on one GPU (%.1f GB)" % (a.fields * a.vocab * a.dim * 4 / 1e9) if world == 1
                                       else "row-sharded over %d GPUs (id %% N), RCCL all-to-all" % world),
                        "global_batch": a.batch * world, "parallelism": "single" if world == 1 else "dp%d+row-sharded-tables" % world,

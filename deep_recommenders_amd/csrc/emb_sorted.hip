@@ -68,7 +68,23 @@ __global__ __launch_bounds__(256) void mark_unique_kernel(const uint64_t* __rest
 // reads table row 0 and its own (or field F-1's) gradient and simply stores nothing -- so all U row loads, U
 // gradient loads and U first-order loads of an iteration are in flight together instead of one round trip each,
 // and the next example's ids/flags are fetched ahead of them.  Only the stores stay predicated.
-template <int LPR, int U>
+// Row-wise (lazy) Adam state for the fused optimizer form of K4: first/second moments with the table's shape, the
+// [TF] B15 update  m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; w -= lr_t m / (sqrt(v) + eps),  lr_t = lr sqrt(1-b2^t)/(1-b1^t)
+// (tf.train.AdamOptimizer, examples/train_fm_on_movielens_estimator.py:51 of the reference) applied to the rows a batch
+// touches; duplicate slots of a row are summed first (one update per row and step).
+struct AdamArgs {
+    float* m; float* v;            // [R, D]
+    float* m_lin; float* v_lin;    // [R] (may be null when there is no first-order table)
+    float lr_t, b1, b2, eps;
+};
+
+__device__ __forceinline__ float adam_elem(float g, float& m, float& v, const AdamArgs& a) {
+    m = fmaf(a.b1, m, (1.f - a.b1) * g);
+    v = fmaf(a.b2, v, (1.f - a.b2) * g * g);
+    return -a.lr_t * m / (sqrtf(v) + a.eps);
+}
+
+template <int LPR, int U, bool ADAM>
 __global__ __launch_bounds__(256) void emb_bwd_unique_kernel(const int64_t* __restrict__ ids,
                                                               const uint8_t* __restrict__ flags, int64_t B, int32_t F,
                                                               const int64_t* __restrict__ row_base, int32_t D,
@@ -78,7 +94,7 @@ __global__ __launch_bounds__(256) void emb_bwd_unique_kernel(const int64_t* __re
                                                               const float* __restrict__ d_fm_logit,
                                                               const float* __restrict__ slot_lin, float scale,
                                                               float* __restrict__ table, float* __restrict__ lin_w,
-                                                              float* __restrict__ lin_bias) {
+                                                              float* __restrict__ lin_bias, AdamArgs ad) {
     constexpr int NS = DR_WAVE / LPR;
     const int lane = threadIdx.x & 63, slot = lane / LPR, sub = lane % LPR;
     const int nq = D >> 2;
@@ -95,7 +111,9 @@ __global__ __launch_bounds__(256) void emb_bwd_unique_kernel(const int64_t* __re
     // Bias gradient = scale * sum_b d_fm_logit[b].  One same-address atomic per wave (32 K of them at ~88/us on one L2
     // channel) used to cost more than the whole scatter; block 0 now sums the B values itself, in a fixed order
     // (deterministic), overlapped with every other block's work, and is the only writer of lin_bias.
-    if (blockIdx.x == 0 && lin_bias != nullptr && d_fm_logit != nullptr) dr_block_sum_axpy(d_fm_logit, B, scale, lin_bias);
+    if (!ADAM && blockIdx.x == 0 && lin_bias != nullptr && d_fm_logit != nullptr) dr_block_sum_axpy(d_fm_logit, B, scale, lin_bias);
+    const float* mlsrc = (ADAM && ad.m_lin != nullptr) ? ad.m_lin : table;        // values unused when there is no first-order state
+    const float* vlsrc = (ADAM && ad.v_lin != nullptr) ? ad.v_lin : table;
     if (wave0 >= B) return;
     const int lanec = lane < F ? lane : F - 1;
     const int64_t my_base = row_base[lanec];
@@ -118,6 +136,8 @@ __global__ __launch_bounds__(256) void emb_bwd_unique_kernel(const int64_t* __re
         for (int f0 = 0; f0 < F; f0 += NS * U) {
             int64_t row[U];
             float4 g[U], t[U];
+            float4 mt[ADAM ? U : 1], vt[ADAM ? U : 1];
+            float ml[ADAM ? U : 1], vl[ADAM ? U : 1];
             float lw[U], gl[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -130,6 +150,12 @@ __global__ __launch_bounds__(256) void emb_bwd_unique_kernel(const int64_t* __re
                 t[u] = *reinterpret_cast<const float4*>(table + rc * D + subc * 4);
                 lw[u] = lsrc[rc];
                 gl[u] = slot_lin != nullptr ? slot_lin[b * F + fc] : dl;
+                if (ADAM) {
+                    mt[u] = *reinterpret_cast<const float4*>(ad.m + rc * D + subc * 4);
+                    vt[u] = *reinterpret_cast<const float4*>(ad.v + rc * D + subc * 4);
+                    ml[u] = mlsrc[rc];
+                    vl[u] = vlsrc[rc];
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -138,12 +164,28 @@ __global__ __launch_bounds__(256) void emb_bwd_unique_kernel(const int64_t* __re
                     g[u].x += dl * (sx.x - r.x); g[u].y += dl * (sx.y - r.y);
                     g[u].z += dl * (sx.z - r.z); g[u].w += dl * (sx.w - r.w);
                 }
-                r.x = fmaf(scale, g[u].x, r.x); r.y = fmaf(scale, g[u].y, r.y);
-                r.z = fmaf(scale, g[u].z, r.z); r.w = fmaf(scale, g[u].w, r.w);
-                const float nl = fmaf(scale, gl[u], lw[u]);
+                float nl;
+                if (ADAM) {
+                    r.x += adam_elem(g[u].x, mt[u].x, vt[u].x, ad); r.y += adam_elem(g[u].y, mt[u].y, vt[u].y, ad);
+                    r.z += adam_elem(g[u].z, mt[u].z, vt[u].z, ad); r.w += adam_elem(g[u].w, mt[u].w, vt[u].w, ad);
+                    nl = lw[u] + adam_elem(gl[u], ml[u], vl[u], ad);
+                } else {
+                    r.x = fmaf(scale, g[u].x, r.x); r.y = fmaf(scale, g[u].y, r.y);
+                    r.z = fmaf(scale, g[u].z, r.z); r.w = fmaf(scale, g[u].w, r.w);
+                    nl = fmaf(scale, gl[u], lw[u]);
+                }
                 if (row[u] >= 0) {
-                    if (dvalid) *reinterpret_cast<float4*>(table + row[u] * D + sub * 4) = r;
-                    if (do_lin) lin_w[row[u]] = nl;
+                    if (dvalid) {
+                        *reinterpret_cast<float4*>(table + row[u] * D + sub * 4) = r;
+                        if (ADAM) {
+                            *reinterpret_cast<float4*>(ad.m + row[u] * D + sub * 4) = mt[u];
+                            *reinterpret_cast<float4*>(ad.v + row[u] * D + sub * 4) = vt[u];
+                        }
+                    }
+                    if (do_lin) {
+                        lin_w[row[u]] = nl;
+                        if (ADAM && ad.m_lin != nullptr) { ad.m_lin[row[u]] = ml[u]; ad.v_lin[row[u]] = vl[u]; }
+                    }
                 }
             }
         }
@@ -155,7 +197,7 @@ __global__ __launch_bounds__(256) void emb_bwd_unique_kernel(const int64_t* __re
 // Duplicate path: rows touched by >= 2 slots.  One lane group per segment head sums the slot gradients in sorted
 // order.  A segment of <= CH slots is always owned by ONE group (plain RMW, deterministic); a hotter row is cut at
 // CH-aligned positions that lie >= CH past its start, those pieces combine with fp32 atomics.
-template <int LPR>
+template <int LPR, bool ADAM>
 __global__ __launch_bounds__(256) void emb_bwd_dups_kernel(const uint64_t* __restrict__ rows,
                                                            const int32_t* __restrict__ slots, int64_t n,
                                                            const int32_t* __restrict__ dup_heads,
@@ -166,7 +208,9 @@ __global__ __launch_bounds__(256) void emb_bwd_dups_kernel(const uint64_t* __res
                                                            const float* __restrict__ sum_x,
                                                            const float* __restrict__ d_fm_logit,
                                                            const float* __restrict__ slot_lin, float scale,
-                                                           float* __restrict__ table, float* __restrict__ lin_w) {
+                                                           float* __restrict__ table, float* __restrict__ lin_w, AdamArgs ad) {
+    // ADAM: the update is not linear in the gradient, so a row's slots must be summed completely before the one update:
+    // the segment-start head walks the WHOLE segment (however long) and the aligned heads of hot rows do nothing.
     // One lane group (LPR lanes = one table row) per head.  The piece is walked in chunks of LPR sorted entries: the
     // chunk's row ids and slot numbers are fetched with ONE coalesced load each, the length of the matching prefix comes
     // from a ballot, and the gradient rows of the prefix are fetched UN at a time with clamped (unconditional) addresses.
@@ -197,11 +241,12 @@ __global__ __launch_bounds__(256) void emb_bwd_dups_kernel(const uint64_t* __res
         const bool seg_start = (i == 0) || (rows[i > 0 ? i - 1 : 0] != k);
         // piece owned by this head: the segment start runs to the first aligned position >= i + CH, aligned heads run CH
         int64_t stop = seg_start ? (((i % CH) == 0) ? i + CH : ((i + CH - 1) / CH + 1) * CH) : i + CH;
+        if (ADAM) stop = n;
         if (stop > n) stop = n;
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         float dls = 0.f;
         int64_t j = i;
-        bool done = !live;
+        bool done = !live || (ADAM && !seg_start);
         while (__any(!done)) {
             const int64_t jj = j + sub;
             const bool inb = jj < stop;
@@ -246,7 +291,25 @@ __global__ __launch_bounds__(256) void emb_bwd_dups_kernel(const uint64_t* __res
         }
         const bool exclusive = seg_start && (j >= n || rows[j < n ? j : n - 1] != k);
         float* dst = table + k * (uint64_t)D + sub * 4;
-        if (live) {
+        if (ADAM) {
+            if (live && seg_start) {
+                if (dvalid) {
+                    float4 t = *reinterpret_cast<const float4*>(dst);
+                    float4 mt = *reinterpret_cast<const float4*>(ad.m + k * (uint64_t)D + sub * 4);
+                    float4 vt = *reinterpret_cast<const float4*>(ad.v + k * (uint64_t)D + sub * 4);
+                    t.x += adam_elem(g.x, mt.x, vt.x, ad); t.y += adam_elem(g.y, mt.y, vt.y, ad);
+                    t.z += adam_elem(g.z, mt.z, vt.z, ad); t.w += adam_elem(g.w, mt.w, vt.w, ad);
+                    *reinterpret_cast<float4*>(dst) = t;
+                    *reinterpret_cast<float4*>(ad.m + k * (uint64_t)D + sub * 4) = mt;
+                    *reinterpret_cast<float4*>(ad.v + k * (uint64_t)D + sub * 4) = vt;
+                }
+                if (lin_w != nullptr && any_lin && sub == 0) {
+                    float ml = ad.m_lin != nullptr ? ad.m_lin[k] : 0.f, vl = ad.v_lin != nullptr ? ad.v_lin[k] : 0.f;
+                    lin_w[k] += adam_elem(dls, ml, vl, ad);
+                    if (ad.m_lin != nullptr) { ad.m_lin[k] = ml; ad.v_lin[k] = vl; }
+                }
+            }
+        } else if (live) {
             if (exclusive) {
                 if (dvalid) {
                     float4 t = *reinterpret_cast<const float4*>(dst);
@@ -318,13 +381,12 @@ extern "C" int dr_emb_sort_slots(const int64_t* ids, int64_t B, int32_t F, const
     return DR_OK;
 }
 
-extern "C" int dr_emb_pool_bwd_sorted(const int64_t* ids, const int64_t* row_base, const int64_t* sorted_rows,
-                                      const int32_t* sorted_slots, const uint8_t* unique_flags,
-                                      const int32_t* dup_heads, const int32_t* dup_count, int64_t B, int32_t F,
-                                      int32_t D, int64_t num_rows, const float* grad, int64_t ld_grad,
-                                      const float* concat, int64_t ld_concat, const float* sum_x,
-                                      const float* d_fm_logit, const float* slot_lin_grad, float scale,
-                                      float* dst_table, float* dst_lin, float* dst_bias, dr_stream_t stream) {
+static int bwd_sorted_impl(const int64_t* ids, const int64_t* row_base, const int64_t* sorted_rows,
+                           const int32_t* sorted_slots, const uint8_t* unique_flags, const int32_t* dup_heads,
+                           const int32_t* dup_count, int64_t B, int32_t F, int32_t D, int64_t num_rows, const float* grad,
+                           int64_t ld_grad, const float* concat, int64_t ld_concat, const float* sum_x,
+                           const float* d_fm_logit, const float* slot_lin_grad, float scale, float* dst_table,
+                           float* dst_lin, float* dst_bias, const AdamArgs* adam, dr_stream_t stream) {
     if (B < 0 || F <= 0 || F > 64 || D < 4 || D > 256 || (D & 3) || num_rows <= 0) return DR_EINVAL;
     const int64_t n = B * F;
     if (n == 0) return DR_OK;
@@ -339,19 +401,21 @@ extern "C" int dr_emb_pool_bwd_sorted(const int64_t* ids, const int64_t* row_bas
     const int grid_u = dr_grid_for(B, 4, 8192);
     const int grid_d = 2048;    // the duplicate list's length lives on the device: uniform ids leave it nearly empty (surplus
                                 // blocks exit at once), skewed ids fill it
-#define CALL(L)                                                                                                       \
+    AdamArgs ad{};
+    if (adam != nullptr) ad = *adam;
+#define LAUNCH(L, ADAM_)                                                                                              \
     {                                                                                                                 \
         constexpr int NS_ = 64 / L;                                                                                   \
         constexpr int U_ = NS_ >= 16 ? 2 : 4;                                                                         \
-        hipLaunchKernelGGL((emb_bwd_unique_kernel<L, U_>), dim3(grid_u), dim3(256), 0, dr_s(stream), ids, unique_flags, \
-                           B, F, row_base, D, grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit, slot_lin_grad, scale,       \
-                           dst_table, dst_lin,                                                                        \
-                           dst_bias);                                                                                 \
-        hipLaunchKernelGGL((emb_bwd_dups_kernel<L>), dim3(grid_d), dim3(256), 0, dr_s(stream), rows, sorted_slots, n, \
-                           dup_heads, dup_count, F, D, (uint64_t)num_rows, grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit, \
-                           slot_lin_grad, scale, dst_table,                                                           \
-                           dst_lin);                                                                                  \
+        hipLaunchKernelGGL((emb_bwd_unique_kernel<L, U_, ADAM_>), dim3(grid_u), dim3(256), 0, dr_s(stream), ids,      \
+                           unique_flags, B, F, row_base, D, grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit,      \
+                           slot_lin_grad, scale, dst_table, dst_lin, dst_bias, ad);                                   \
+        hipLaunchKernelGGL((emb_bwd_dups_kernel<L, ADAM_>), dim3(grid_d), dim3(256), 0, dr_s(stream), rows,           \
+                           sorted_slots, n, dup_heads, dup_count, F, D, (uint64_t)num_rows, grad, ld_grad, concat,    \
+                           ld_concat, sum_x, d_fm_logit, slot_lin_grad, scale, dst_table, dst_lin, ad);               \
     }
+#define CALL(L)                                                                                                       \
+    if (adam != nullptr) LAUNCH(L, true) else LAUNCH(L, false)
     switch (lpr) {
         case 1: CALL(1); break;
         case 2: CALL(2); break;
@@ -363,6 +427,67 @@ extern "C" int dr_emb_pool_bwd_sorted(const int64_t* ids, const int64_t* row_bas
         default: return DR_EINVAL;
     }
 #undef CALL
+#undef LAUNCH
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+extern "C" int dr_emb_pool_bwd_sorted(const int64_t* ids, const int64_t* row_base, const int64_t* sorted_rows,
+                                      const int32_t* sorted_slots, const uint8_t* unique_flags,
+                                      const int32_t* dup_heads, const int32_t* dup_count, int64_t B, int32_t F,
+                                      int32_t D, int64_t num_rows, const float* grad, int64_t ld_grad,
+                                      const float* concat, int64_t ld_concat, const float* sum_x,
+                                      const float* d_fm_logit, const float* slot_lin_grad, float scale,
+                                      float* dst_table, float* dst_lin, float* dst_bias, dr_stream_t stream) {
+    return bwd_sorted_impl(ids, row_base, sorted_rows, sorted_slots, unique_flags, dup_heads, dup_count, B, F, D, num_rows,
+                           grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit, slot_lin_grad, scale, dst_table, dst_lin,
+                           dst_bias, nullptr, stream);
+}
+
+// Fused row-wise Adam form of the sorted K4: same inputs, `grad` is the gradient of the mean
+// loss (no scale); rows touched by the batch get ONE [TF] B15 Adam update from the sum of their slots' gradients, with
+// first/second moments m/v stored like the table.  lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t) is computed by the
+// caller.  Untouched rows keep their moments ("lazy" Adam): identical to tf.train.AdamOptimizer on the first step,
+// and on every step for rows that are touched every step; TF itself decays m/v of the whole variable each step.
+// The bias of the first-order term is a dense parameter: update it with dr_adam_step on its own gradient.
+extern "C" int dr_emb_pool_bwd_sorted_adam(const int64_t* ids, const int64_t* row_base, const int64_t* sorted_rows,
+                                           const int32_t* sorted_slots, const uint8_t* unique_flags,
+                                           const int32_t* dup_heads, const int32_t* dup_count, int64_t B, int32_t F,
+                                           int32_t D, int64_t num_rows, const float* grad, int64_t ld_grad,
+                                           const float* concat, int64_t ld_concat, const float* sum_x,
+                                           const float* d_fm_logit, const float* slot_lin_grad, float lr_t, float beta1,
+                                           float beta2, float eps, float* table, float* m_table, float* v_table,
+                                           float* lin_w, float* m_lin, float* v_lin, dr_stream_t stream) {
+    if (!m_table || !v_table) return DR_EINVAL;
+    if (lin_w != nullptr && (!m_lin || !v_lin)) return DR_EINVAL;
+    AdamArgs ad{m_table, v_table, m_lin, v_lin, lr_t, beta1, beta2, eps};
+    return bwd_sorted_impl(ids, row_base, sorted_rows, sorted_slots, unique_flags, dup_heads, dup_count, B, F, D, num_rows,
+                           grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit, slot_lin_grad, 0.f, table, lin_w, nullptr,
+                           &ad, stream);
+}
+
+__global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                        float lr_t, float b1, float b2, float eps, float gscale) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float gi = g[i] * gscale;
+        const float mi = fmaf(b1, m[i], (1.f - b1) * gi);
+        const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+// Dense [TF] B15 Adam step over a flat parameter buffer: g is scaled by grad_scale first (e.g. 1 / world_size).
+extern "C" int dr_adam_step(float* param, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1,
+                            float beta2, float eps, float grad_scale, dr_stream_t stream) {
+    if (n < 0) return DR_EINVAL;
+    if (n == 0) return DR_OK;
+    if (!param || !grad || !m || !v) return DR_EINVAL;
+    hipLaunchKernelGGL(adam_step_kernel, dim3(dr_grid_for(n, 256 * 4)), dim3(256), 0, dr_s(stream), param, grad, m, v, n, lr_t,
+                       beta1, beta2, eps, grad_scale);
     DR_CHECK_LAUNCH();
     return DR_OK;
 }

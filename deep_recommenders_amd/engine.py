@@ -23,7 +23,8 @@ def _pad4(n):
 class DeepFMEngine:
     def __init__(self, num_fields: int, vocab_per_field: int, dim: int, dnn_units: Sequence[int], batch: int,
                  num_dense: int = 0, lr: float = 0.01, device="cuda", seed: int = 42, hashed: bool = True,
-                 table_init_std: Optional[float] = None, lin_init_std: float = 0.0, sorted_bwd: bool = True):
+                 table_init_std: Optional[float] = None, lin_init_std: float = 0.0, sorted_bwd: bool = True,
+                 optimizer: str = "sgd", beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8):
         self.F, self.V, self.D, self.B = num_fields, vocab_per_field, dim, batch
         self.Nd, self.lr, self.dev, self.hashed = num_dense, lr, device, hashed
         F, V, D, B = self.F, self.V, self.D, self.B
@@ -39,19 +40,50 @@ class DeepFMEngine:
         self.lin_w = torch.zeros(self.R, dtype=torch.float32, device=device)           # zeros init (fm.py:16-20)
         if lin_init_std > 0:
             self.lin_w.normal_(0.0, lin_init_std, generator=g)
-        self.lin_bias = torch.zeros(1, dtype=torch.float32, device=device)
         self.in_dim = F * D + num_dense
         self.ld = _pad4(self.in_dim)
         units = list(dnn_units) + [1]
+        # dense parameters live in ONE flat buffer (weights, biases, the first-order bias): the Adam mode then needs one
+        # gradient bucket and one dr_adam_step launch; the SGD mode updates the views in place from inside the wgrad kernels
+        shapes, d = [], self.in_dim
+        for u in units:
+            shapes.append((d, u))
+            d = u
+        total = sum(k * _pad4(u) + _pad4(u) for k, u in shapes) + 4
+        self.flat_params = torch.zeros(total, dtype=torch.float32, device=device)
         self.Ws: List[torch.Tensor] = []
         self.bs: List[torch.Tensor] = []
-        d = self.in_dim
-        for u in units:                                                               # [TF] B8 glorot uniform
-            limit = math.sqrt(6.0 / (d + u))
-            W = (torch.rand((d, _pad4(u)), device=device, generator=g) * 2 - 1) * limit
-            self.Ws.append(W[:, :u])
-            self.bs.append(torch.zeros(u, dtype=torch.float32, device=device))
-            d = u
+        self._views = []         # (offset, k, pu, u) of every weight, then biases, for the gradient-bucket views
+        off = 0
+        for k, u in shapes:                                                            # [TF] B8 glorot uniform
+            pu = _pad4(u)
+            limit = math.sqrt(6.0 / (k + u))
+            Wfull = self.flat_params[off:off + k * pu].view(k, pu)
+            Wfull.copy_((torch.rand((k, pu), device=device, generator=g) * 2 - 1) * limit)
+            Wfull[:, u:].zero_()
+            self.Ws.append(Wfull[:, :u])
+            w_off = off
+            off += k * pu
+            self.bs.append(self.flat_params[off:off + u])
+            self._views.append((w_off, k, pu, u, off))
+            off += pu
+        self.lin_bias = self.flat_params[off:off + 1]
+        self._bias_off = off
+        assert optimizer in ("sgd", "adam") and (optimizer == "sgd" or sorted_bwd), "adam needs the sorted K4"
+        self.optimizer, self.beta1, self.beta2, self.eps, self.t = optimizer, beta1, beta2, eps, 0
+        if optimizer == "adam":
+            # gradient bucket + moments for the dense parameters; row-wise moments for the tables (2 x 66.6 GB at config 3:
+            # table + m + v = 200 GB of the 288 GB HBM)
+            self.flat_grads = torch.zeros_like(self.flat_params)
+            self.flat_m = torch.zeros_like(self.flat_params)
+            self.flat_v = torch.zeros_like(self.flat_params)
+            self.gWs = [self.flat_grads[wo:wo + k * pu].view(k, pu)[:, :u] for wo, k, pu, u, bo in self._views]
+            self.gbs = [self.flat_grads[bo:bo + u] for wo, k, pu, u, bo in self._views]
+            self.g_lin_bias = self.flat_grads[self._bias_off:self._bias_off + 1]
+            self.m_table = torch.zeros_like(self.table)
+            self.v_table = torch.zeros_like(self.table)
+            self.m_lin = torch.zeros_like(self.lin_w)
+            self.v_lin = torch.zeros_like(self.lin_w)
         import os as _os
         self.acts = [1] * len(dnn_units) + [0]
         self.dw_ws = [ops.linear_bwd_dw_workspace(B, W.shape[0], W.shape[1], device) for W in self.Ws]
@@ -133,6 +165,8 @@ class DeepFMEngine:
                 loss_mode: int = ops.LOSS_SIGMOID_CE):
         F, D = self.F, self.D
         B = self.B
+        if self.optimizer == "adam":
+            self.flat_grads.zero_()          # the fused head already writes Dense(1) gradients during the forward
         self._k("hash_bucket_i64", "hbm", B * F * 16,
                 lambda: ops.hash_bucket_i64(keys, self.col_buckets, out=self.ids))                    # K1
         if self.sorted_bwd and not self.sort_inline and self.sort_at == "hash":
@@ -164,8 +198,11 @@ class DeepFMEngine:
             W1, W2 = self.Ws[-2], self.Ws[-1]
             self._k("tower_head_fwd_bwd", "hbm", 4.0 * B * (W1.shape[0] + W1.shape[1] + 4),
                     lambda x=x, W1=W1, W2=W2: ops.tower_head_fwd_bwd(
-                        x, W1, self.bs[-2], W2, self.bs[-1], self.fm_logit, labels, loss_mode, -self.lr, act=1,
-                        prob=self.prob, d_logit=self.d_logit, d_h=self.dhs[-1], loss=self.loss, workspace=self.head_ws))
+                        x, W1, self.bs[-2], W2, self.bs[-1], self.fm_logit, labels, loss_mode,
+                        1.0 if self.optimizer == "adam" else -self.lr, act=1,
+                        prob=self.prob, d_logit=self.d_logit, d_h=self.dhs[-1], loss=self.loss, workspace=self.head_ws,
+                        dst_W2=self.gWs[-1] if self.optimizer == "adam" else "inplace",
+                        dst_b2=self.gbs[-1] if self.optimizer == "adam" else "inplace"))
             return self.prob
         if labels is None:
             labels = self.prob   # dummy, loss ignored
@@ -175,6 +212,8 @@ class DeepFMEngine:
 
     def backward_and_update(self):
         F, D, lr = self.F, self.D, self.lr
+        adam = self.optimizer == "adam"
+        sc = 1.0 if adam else -lr                         # Adam: gradients into the bucket; SGD: the step itself
         n = len(self.Ws)
         dy = self.d_logit.reshape(-1, 1)                  # d(mean loss)/d logit == pre-activation grad of Dense(1)
         top = n - 1
@@ -194,8 +233,9 @@ class DeepFMEngine:
                 rs = None
             if i > 0 and self.fuse_narrow and self.narrow_ws[i] is not None:
                 self._k("linear_bwd_narrow_L%d" % i, "hbm", 4.0 * self.B * (2 * W.shape[0] + W.shape[1]),
-                        lambda x=x, dy=dy, W=W, dx=dx, i=i: ops.linear_bwd_narrow(x, dy, W, -lr, W, self.bs[i], dx, relu_mask=True,
-                                                                                 workspace=self.narrow_ws[i]))
+                        lambda x=x, dy=dy, W=W, dx=dx, i=i: ops.linear_bwd_narrow(x, dy, W, sc, self.gWs[i] if adam else W,
+                                                                                 self.gbs[i] if adam else self.bs[i], dx,
+                                                                                 relu_mask=True, workspace=self.narrow_ws[i]))
                 dy = dx
                 continue
             if i == 0 and self.sorted_bwd and not self.sort_inline and self.sort_at != "fwd":
@@ -207,7 +247,7 @@ class DeepFMEngine:
             else:
                 self._k("linear_bwd_dx_L%d" % i, "mfma", fl,
                         lambda dy=dy, W=W, rs=rs, dx=dx: ops.linear_bwd_dx(dy, W, relu_src=rs, out=dx))
-            if i == 0 and self.overlap_k4:
+            if i == 0 and self.overlap_k4 and not adam:
                 cur = torch.cuda.current_stream()
                 self.ev_dx0.record(cur)
                 with torch.cuda.stream(self.scatter):
@@ -217,8 +257,12 @@ class DeepFMEngine:
                             lambda: self._k4_sorted())
                     self.ev_k4.record(self.scatter)
             self._k("linear_bwd_dw_L%d" % i, "mfma", fl,
-                    lambda x=x, dy=dy, W=W, i=i: ops.linear_bwd_dw(x, dy, -lr, W, self.bs[i], workspace=self.dw_ws[i]))
+                    lambda x=x, dy=dy, W=W, i=i: ops.linear_bwd_dw(x, dy, sc, self.gWs[i] if adam else W,
+                                                                   self.gbs[i] if adam else self.bs[i], workspace=self.dw_ws[i]))
             dy = dx
+        if adam:
+            self._adam_finish()
+            return
         if self.overlap_k4:
             torch.cuda.current_stream().wait_event(self.ev_k4)
             return
@@ -240,6 +284,21 @@ class DeepFMEngine:
             self._k("emb_sort_slots(side stream, overlapped)", "overlap", self.B * self.F * 36,
                     lambda: ops.emb_sort_slots(self.ids, self.row_base, self.R, self.plan))
             self.ev_sorted.record(self.side)
+
+    def _adam_finish(self):
+        """Adam mode: fused row-wise Adam K4, first-order bias gradient, one dense Adam step over the flat parameters."""
+        self.t += 1
+        lr_t = ops.adam_lr_t(self.lr, self.beta1, self.beta2, self.t)
+        torch.cuda.current_stream().wait_event(self.ev_sorted)
+        self._k("emb_pool_bwd_adam", "hbm", self.B * (28 * self.F * self.D + 40 * self.F),                # K4 + optimizer
+                lambda: ops.emb_pool_bwd_sorted_adam(self.ids, self.row_base, self.plan, self.D, self.R, self.d_concat,
+                                                     self.d_logit, lr_t, self.beta1, self.beta2, self.eps, self.table,
+                                                     self.m_table, self.v_table, self.lin_w, self.m_lin, self.v_lin,
+                                                     concat=self.concat, sum_x=self.sum_x))
+        torch.sum(self.d_logit, dim=0, keepdim=True, out=self.g_lin_bias)       # d loss / d (first-order bias)
+        self._k("adam_step_dense", "hbm", 28.0 * self.flat_params.numel(),
+                lambda: ops.adam_step(self.flat_params, self.flat_grads, self.flat_m, self.flat_v, lr_t, self.beta1, self.beta2,
+                                      self.eps))
 
     def _k4_sorted(self):
         return ops.emb_pool_bwd_sorted(self.ids, self.row_base, self.plan, self.D, self.R, self.d_concat, self.d_logit,

@@ -433,6 +433,34 @@ def emb_pool_bwd_sorted(ids, row_base, plan, D, num_rows, grad, d_fm_logit, scal
                                        stream_ptr()), "dr_emb_pool_bwd_sorted")
 
 
+def adam_lr_t(lr, beta1, beta2, step):
+    """[TF] B15: lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t), t = step counted from 1."""
+    return lr * (1.0 - beta2 ** step) ** 0.5 / (1.0 - beta1 ** step)
+
+
+def emb_pool_bwd_sorted_adam(ids, row_base, plan, D, num_rows, grad, d_fm_logit, lr_t, beta1, beta2, eps, table, m_table,
+                             v_table, lin_w=None, m_lin=None, v_lin=None, concat=None, sum_x=None, slot_lin_grad=None):
+    """Sorted K4 with a fused row-wise Adam update (see dr_emb_pool_bwd_sorted_adam in include/dr_hotpath.h)."""
+    ids = _c(ids, torch.int64)
+    B, F = ids.shape
+    assert grad.stride(1) == 1
+    check(lib().dr_emb_pool_bwd_sorted_adam(ptr(ids), ptr(row_base), ptr(plan.rows), ptr(plan.slots), ptr(plan.flags),
+                                            ptr(plan.dup_heads), ptr(plan.dup_count), B, F, D, int(num_rows), ptr(grad),
+                                            grad.stride(0), ptr(concat), concat.stride(0) if concat is not None else 0,
+                                            ptr(sum_x), ptr(d_fm_logit), ptr(slot_lin_grad), float(lr_t), float(beta1),
+                                            float(beta2), float(eps), ptr(table), ptr(m_table), ptr(v_table), ptr(lin_w),
+                                            ptr(m_lin), ptr(v_lin), stream_ptr()), "dr_emb_pool_bwd_sorted_adam")
+
+
+def adam_step(param, grad, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    """Dense Adam step over flat fp32 buffers (in place)."""
+    assert param.is_contiguous() and grad.is_contiguous() and m.is_contiguous() and v.is_contiguous()
+    n = param.numel()
+    assert grad.numel() == n and m.numel() == n and v.numel() == n
+    check(lib().dr_adam_step(ptr(param), ptr(grad), ptr(m), ptr(v), n, float(lr_t), float(beta1), float(beta2), float(eps),
+                             float(grad_scale), stream_ptr()), "dr_adam_step")
+
+
 def linear_bwd_dx_fm(dy, W, d_fm_logit, sum_x, concat, D, FD, out):
     """First-layer dgrad with the FM second-order gradient folded into the epilogue."""
     dy = _rowmajor_ld4(dy)

@@ -143,6 +143,28 @@ int dr_emb_pool_bwd_sorted(const int64_t* ids, const int64_t* row_base, const in
                            const float* d_fm_logit, const float* slot_lin_grad, float scale,
                            float* dst_table, float* dst_lin, float* dst_bias, dr_stream_t stream);
 
+/* SURVEY.md section 8f rank 1 -- the optimizer of the reference's own examples (tf.train.AdamOptimizer(0.01),
+ * examples/train_fm_on_movielens_estimator.py:51-52; tf.keras.optimizers.Adam(), examples/train_deepfm_on_movielens_keras.py:44)
+ * fused into the sorted K4: every row the batch touches gets ONE Adam update from the SUM of its slots' gradients
+ *   m = b1 m + (1-b1) g ;  v = b2 v + (1-b2) g^2 ;  w -= lr_t m / (sqrt(v) + eps),   lr_t = lr sqrt(1-b2^t) / (1-b1^t)
+ * (lr_t computed by the caller).  `grad` is the gradient of the mean loss (no scale).  m_table / v_table [R, D] and
+ * m_lin / v_lin [R] are the moment slabs.  Rows the batch does not touch keep their moments (row-wise "lazy" Adam):
+ * equal to TF's Adam on the first step and for rows touched on every step; TF decays m/v of the whole variable each step
+ * (SURVEY App. B15), which is a full pass over the 66 GB table at config 3.  The first-order bias is a dense parameter:
+ * dr_adam_step.  Deterministic (a row's slots are summed by one lane group in sorted order). */
+int dr_emb_pool_bwd_sorted_adam(const int64_t* ids, const int64_t* row_base, const int64_t* sorted_rows,
+                                const int32_t* sorted_slots, const uint8_t* unique_flags,
+                                const int32_t* dup_heads, const int32_t* dup_count, int64_t B, int32_t F,
+                                int32_t D, int64_t num_rows, const float* grad, int64_t ld_grad,
+                                const float* concat, int64_t ld_concat, const float* sum_x,
+                                const float* d_fm_logit, const float* slot_lin_grad, float lr_t, float beta1,
+                                float beta2, float eps, float* table, float* m_table, float* v_table,
+                                float* lin_w, float* m_lin, float* v_lin, dr_stream_t stream);
+/* Dense Adam step (same formula) over a flat parameter buffer; grad is multiplied by grad_scale first. */
+int dr_adam_step(float* param, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1,
+                 float beta2, float eps, float grad_scale, dr_stream_t stream);
+
+
 /* ------------------------------------------------------------------------------------------
  * K6  stand-alone FM second-order term on a caller-provided [B, F, D] tensor
  * replaces keras FM.call (keras/models/ranking/fm.py:28-35) and estimator fm(x)

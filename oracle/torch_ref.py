@@ -135,3 +135,29 @@ def deepfm_train_step_sgd(params, ids, dense, labels, col_start, row_base, lr):
         for p, g in zip(ks + bs, grads[2:]):
             p.sub_(lr * g)
     return float(loss)
+
+
+def adam_lr_t(lr, beta1, beta2, step):
+    """[TF] B15 (tf.train.AdamOptimizer, examples/train_fm_on_movielens_estimator.py:51 of the reference):
+    lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)."""
+    return lr * (1.0 - beta2 ** step) ** 0.5 / (1.0 - beta1 ** step)
+
+
+def adam_dense_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
+    """[TF] B15 dense update, in place on torch tensors: m, v, then p -= lr_t * m / (sqrt(v) + eps)."""
+    lr_t = adam_lr_t(lr, beta1, beta2, step)
+    m.mul_(beta1).add_(g, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    p.sub_(lr_t * m / (v.sqrt() + eps))
+
+
+def adam_rows_step(p, dense_grad, touched_rows, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
+    """Row-wise ("lazy") Adam: the [TF] B15 update applied only to `touched_rows` of p / m / v, with `dense_grad` the
+    gradient already summed over duplicate ids (what autograd's index_add produces).  Equal to TF's non-lazy Adam on
+    step 1 (all moments zero) and for rows touched on every step; documented divergence otherwise."""
+    lr_t = adam_lr_t(lr, beta1, beta2, step)
+    r = torch.unique(touched_rows[touched_rows >= 0])
+    g = dense_grad[r]
+    m[r] = beta1 * m[r] + (1 - beta1) * g
+    v[r] = beta2 * v[r] + (1 - beta2) * g * g
+    p[r] = p[r] - lr_t * m[r] / (v[r].sqrt() + eps)

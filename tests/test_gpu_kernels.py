@@ -458,6 +458,72 @@ def test_emb_bwd_sorted_matches_oracle_and_is_deterministic(ops, D, F, V, hot):
         np.testing.assert_array_equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("D,F,V,hot", [(64, 26, 5000, False), (16, 7, 50, True), (12, 5, 1000, False)])
+def test_emb_bwd_sorted_adam_matches_oracle_over_steps(ops, D, F, V, hot):
+    """Fused row-wise Adam K4 over 3 steps == oracle (pre-summed duplicate gradients, [TF] B15 update on touched rows);
+    first-order table and FM term included; hot rows (one row hit by every example) summed by one owner."""
+    rng = np.random.default_rng(33)
+    B, R = 900, F * V
+    lr, b1, b2, eps = 0.01, 0.9, 0.999, 1e-8
+    row_base = (np.arange(F) * V).astype(np.int64)
+    table = (rng.standard_normal((R, D)) * 0.3).astype(np.float32)
+    lin = (rng.standard_normal(R) * 0.1).astype(np.float32)
+    t_dev, l_dev = _dev(table).clone(), _dev(lin).clone()
+    m_dev, v_dev = torch.zeros_like(t_dev), torch.zeros_like(t_dev)
+    ml_dev, vl_dev = torch.zeros_like(l_dev), torch.zeros_like(l_dev)
+    tt, tl = torch.tensor(table, dtype=torch.float64), torch.tensor(lin, dtype=torch.float64)
+    tm, tv, tml, tvl = torch.zeros_like(tt), torch.zeros_like(tt), torch.zeros_like(tl), torch.zeros_like(tl)
+    d_rb = _dev(row_base)
+    zero_bias = torch.zeros(1, device="cuda")
+    for step in range(1, 4):
+        ids = rng.integers(0, V, size=(B, F))
+        if hot:
+            ids[:, 0] = 3
+        ids[rng.random((B, F)) < 0.05] = -1
+        grad = rng.standard_normal((B, F * D)).astype(np.float32)
+        dl = rng.standard_normal(B).astype(np.float32)
+        d_ids = _dev(ids)
+        plan = ops.emb_sort_slots(d_ids, d_rb, R)
+        concat, sum_x, _ = ops.emb_pool_fwd(d_ids, F, None, d_rb, t_dev, l_dev, zero_bias)       # forward activations
+        ops.emb_pool_bwd_sorted_adam(d_ids, d_rb, plan, D, R, _dev(grad), _dev(dl), ops.adam_lr_t(lr, b1, b2, step), b1, b2, eps,
+                                     t_dev, m_dev, v_dev, l_dev, ml_dev, vl_dev, concat=concat, sum_x=sum_x)
+        # oracle (fp64): per-slot gradient incl. the FM term, summed per row, then the row-wise Adam update
+        rows = torch.tensor(np.where(ids >= 0, ids + row_base[None, :], -1))
+        x = torch.zeros((B, F, D), dtype=torch.float64)
+        mask = rows >= 0
+        x[mask] = tt[rows[mask]]
+        sx = x.sum(1)
+        g = torch.tensor(grad, dtype=torch.float64).reshape(B, F, D) + torch.tensor(dl, dtype=torch.float64)[:, None, None] * (sx[:, None, :] - x)
+        dense_g = torch.zeros_like(tt)
+        dense_g.index_add_(0, rows[mask], g[mask])
+        dense_gl = torch.zeros_like(tl)
+        dense_gl.index_add_(0, rows[mask], torch.tensor(dl, dtype=torch.float64)[:, None].expand(B, F)[mask])
+        T.adam_rows_step(tt, dense_g, rows.reshape(-1), tm, tv, lr, step, b1, b2, eps)
+        T.adam_rows_step(tl, dense_gl, rows.reshape(-1), tml, tvl, lr, step, b1, b2, eps)
+    # Adam normalises every step to ~lr whatever the gradient's size, and m / sqrt(v) of a tiny gradient is where fp32 and
+    # fp64 differ most: parameters are compared to 1 % of one step, the moments relatively
+    np.testing.assert_allclose(t_dev.cpu().numpy(), tt.numpy(), rtol=0, atol=1e-2 * lr)
+    np.testing.assert_allclose(l_dev.cpu().numpy(), tl.numpy(), rtol=0, atol=1e-2 * lr)
+    np.testing.assert_allclose(m_dev.cpu().numpy(), tm.numpy(), rtol=1e-4, atol=1e-5 * (B if hot else 8))
+    np.testing.assert_allclose(v_dev.cpu().numpy(), tv.numpy(), rtol=2e-4, atol=1e-5 * (B if hot else 8))
+    np.testing.assert_allclose(ml_dev.cpu().numpy(), tml.numpy(), rtol=1e-4, atol=1e-5 * (B if hot else 8))
+
+
+def test_adam_step_dense(ops):
+    rng = np.random.default_rng(34)
+    n = 100003
+    p = rng.standard_normal(n).astype(np.float32)
+    pd, md, vd = _dev(p).clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    tp, tm, tv = torch.tensor(p, dtype=torch.float64), torch.zeros(n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
+    for step in range(1, 5):
+        g = rng.standard_normal(n).astype(np.float32)
+        ops.adam_step(pd, _dev(g), md, vd, ops.adam_lr_t(0.01, 0.9, 0.999, step), 0.9, 0.999, 1e-8, grad_scale=0.5)
+        T.adam_dense_step(tp, torch.tensor(g, dtype=torch.float64) * 0.5, tm, tv, 0.01, step)
+    np.testing.assert_allclose(pd.cpu().numpy(), tp.numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(md.cpu().numpy(), tm.numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(vd.cpu().numpy(), tv.numpy(), rtol=1e-5, atol=1e-7)
+
+
 def test_linear_bwd_dx_fm_epilogue(ops):
     rng = np.random.default_rng(22)
     M, F, D, Nd, N = 300, 5, 16, 3, 40

@@ -348,6 +348,51 @@ def test_engine_train_step_matches_oracle():
         np.testing.assert_allclose(eng.bs[i].cpu().numpy(), (bs0[i] - lr * bs[i].grad).numpy(), rtol=1e-4, atol=1e-6)
 
 
+def test_engine_adam_steps_match_oracle():
+    """optimizer="adam": 3 engine steps (fused row-wise Adam in K4 + dense Adam over the flat parameter buffer) against the
+    host restatement ([TF] B15 formulas; tables updated on touched rows).  Parameters to 2 % of one Adam step."""
+    from deep_recommenders_amd.engine import DeepFMEngine
+    F, V, D, B, Nd = 5, 300, 16, 512, 3
+    lr = 0.01
+    eng = DeepFMEngine(F, V, D, [32, 16], B, num_dense=Nd, lr=lr, seed=1, lin_init_std=0.1, optimizer="adam")
+    g = torch.Generator(device="cuda")
+    g.manual_seed(6)
+    tt, tl, tb = eng.table.cpu().double(), eng.lin_w.cpu().double(), torch.zeros(1, dtype=torch.float64)
+    Ws = [w.cpu().double().contiguous() for w in eng.Ws]
+    bs = [b.cpu().double() for b in eng.bs]
+    zl = lambda t: torch.zeros_like(t)
+    mt, vt, ml, vl, mb, vb = zl(tt), zl(tt), zl(tl), zl(tl), zl(tb), zl(tb)
+    mW, vW, mB, vB = [zl(w) for w in Ws], [zl(w) for w in Ws], [zl(b) for b in bs], [zl(b) for b in bs]
+    rb = [f * V for f in range(F)]
+    for step in range(1, 4):
+        keys = torch.randint(0, 10**12, (B, F), device="cuda", generator=g)
+        dense = torch.rand((B, Nd), device="cuda", generator=g)
+        labels = (torch.rand(B, device="cuda", generator=g) < 0.25).float()
+        loss = eng.train_step(keys, dense, labels).item()
+        ids = np.stack([O.hash_bucket_i64(keys[:, f].cpu().numpy(), V) for f in range(F)], axis=1)
+        a = [t.clone().requires_grad_(True) for t in (tt, tl, tb)]
+        aW = [w.clone().requires_grad_(True) for w in Ws]
+        aB = [b.clone().requires_grad_(True) for b in bs]
+        logit = T.deepfm_logit(a[0], a[1], a[2], torch.tensor(ids), list(range(F + 1)), rb, aW, aB, dense.cpu().double())
+        lo = T.sigmoid_cross_entropy(labels.cpu().double(), logit)
+        lo.backward()
+        assert abs(loss - lo.item()) <= 2e-5 * abs(lo.item())
+        rows = torch.tensor(ids + np.array(rb)[None, :]).reshape(-1)
+        T.adam_rows_step(tt, a[0].grad, rows, mt, vt, lr, step)
+        T.adam_rows_step(tl, a[1].grad, rows, ml, vl, lr, step)
+        T.adam_dense_step(tb, a[2].grad, mb, vb, lr, step)
+        for i in range(len(Ws)):
+            T.adam_dense_step(Ws[i], aW[i].grad, mW[i], vW[i], lr, step)
+            T.adam_dense_step(bs[i], aB[i].grad, mB[i], vB[i], lr, step)
+    tol = 2e-2 * lr
+    np.testing.assert_allclose(eng.table.cpu().numpy(), tt.numpy(), rtol=0, atol=tol)
+    np.testing.assert_allclose(eng.lin_w.cpu().numpy(), tl.numpy(), rtol=0, atol=tol)
+    np.testing.assert_allclose(eng.lin_bias.cpu().numpy(), tb.numpy(), rtol=0, atol=tol)
+    for i in range(len(Ws)):
+        np.testing.assert_allclose(eng.Ws[i].cpu().numpy(), Ws[i].numpy(), rtol=0, atol=tol)
+        np.testing.assert_allclose(eng.bs[i].cpu().numpy(), bs[i].numpy(), rtol=0, atol=tol)
+
+
 def test_sharded_engine_world1_matches_unsharded_engine():
     """HIP prims through the exchange plan (RCCL process group of size 1): one step must equal the plain engine's."""
     import torch.distributed as dist
