@@ -12,6 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 SO = os.path.join(LIBDIR, "libdr_hotpath.so")
+HOST_SRC = os.path.join(HERE, "csrc_host")
+HOST_SO = os.path.join(LIBDIR, "libdr_input.so")          # host-side input boundary (include/dr_input.h), plain g++
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
          "-Wno-unused-function", "-Wno-unused-result"]
 
@@ -49,7 +51,22 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    build_host(force=force, verbose=verbose)
     return SO
+
+
+def build_host(force=False, verbose=False):
+    """libdr_input.so: TFRecord / tf.Example reader (host C++, no GPU code)."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs = sorted(glob.glob(os.path.join(HOST_SRC, "*.cpp")))
+    headers = glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    if force or _stale(HOST_SO, srcs + headers):
+        cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra",
+               "-I" + os.path.join(HERE, "..", "include")] + srcs + ["-o", HOST_SO]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return HOST_SO
 
 
 if __name__ == "__main__":

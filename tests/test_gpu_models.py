@@ -348,6 +348,33 @@ def test_engine_train_step_matches_oracle():
         np.testing.assert_allclose(eng.bs[i].cpu().numpy(), (bs0[i] - lr * bs[i].grad).numpy(), rtol=1e-4, atol=1e-6)
 
 
+def test_tfrecord_batch_through_feature_columns_and_fm(tmp_path):
+    """Input side -> hot path: a batch parsed by the native TFRecord / tf.Example reader (bytes features) through the
+    reference-shaped feature columns and FM model equals the oracle evaluated on the same strings."""
+    from oracle import tfrecord_py as W
+    from deep_recommenders_amd import feature_column as fc
+    from deep_recommenders_amd.datasets import MovielensRanking
+    from deep_recommenders_amd.keras.models.ranking import FM
+    rng = np.random.default_rng(12)
+    feats0, _ = _movielens_batch(rng, 96)
+    rows = [W.movielens_example(feats0["user_id"][i].encode(), feats0["movie_id"][i].encode(), int(rng.integers(1, 6)), 978300000 + i,
+                                feats0["user_gender"][i].encode(), int(feats0["user_age"][i]), int(feats0["user_occupation"][i]),
+                                b"94110", b"Title %d" % i, [g.encode() for g in feats0["movie_genres"][i]]) for i in range(96)]
+    path = str(tmp_path / "movielens.tfrecords")
+    W.write_tfrecords(path, [W.encode_example(r) for r in rows])
+    feats, labels = next(iter(MovielensRanking(epochs=1, batch_size=96, filename=path).input_fn()))
+    assert labels.shape == (96, 1) and isinstance(feats["user_id"][0], bytes)
+    ind, emb = _movielens_columns(fc)
+    torch.manual_seed(3)
+    model = FM(ind, emb)
+    logits = model(feats)                                                  # bytes in, as the reader produced them
+    slab = model.slab
+    tabs = [slab.embedding_weights(k).cpu().numpy() for k in KEYS]
+    lws = [slab.linear_weights(k).cpu().numpy() for k in KEYS]
+    _, want_logit, _ = O.deepfm_forward(_oracle_ids(feats0), tabs, lws, 0.0, None, None, return_parts=True)   # str oracle
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), want_logit, rtol=1e-5, atol=1e-5)
+
+
 def test_engine_adam_steps_match_oracle():
     """optimizer="adam": 3 engine steps (fused row-wise Adam in K4 + dense Adam over the flat parameter buffer) against the
     host restatement ([TF] B15 formulas; tables updated on touched rows).  Parameters to 2 % of one Adam step."""
