@@ -25,6 +25,9 @@ SIGNATURES = {
     "dr_linear_fwd": [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p],
     "dr_linear_bwd_dx": [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _i64, _i32, _p, _i64, _p],
     "dr_linear_bwd_dw": [_p, _i64, _p, _i64, _i64, _i32, _i32, _f32, _p, _i64, _p, _p, _i64, _p],
+    "dr_emb_pool_fwd_ex": [_p, _i64, _i32, _i32, _p, _p, _p, _i32, _p, _p, _p, _i64, _p, _p, _i32, _p],
+    "dr_lin_fields_fwd": [_p, _i64, _i32, _i32, _p, _p, _p, _p, _i64, _p],
+    "dr_lin_fields_bwd": [_p, _i64, _i32, _i32, _p, _p, _p, _i64, _f32, _p, _p],
     "dr_emb_pool_bwd_sorted_adam": [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _i64, _p, _i64, _p, _p, _p, _f32, _f32,
                                     _f32, _f32, _p, _p, _p, _p, _p, _p, _p],
     "dr_adam_step": [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _p],

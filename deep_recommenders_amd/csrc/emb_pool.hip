@@ -52,7 +52,7 @@ template <int LPR, int U>
 __global__ __launch_bounds__(256) void emb_pool_fwd_sv_kernel(
     const int64_t* __restrict__ ids, int64_t B, int32_t F, const int64_t* __restrict__ row_base,
     const float* __restrict__ table, int32_t D, const float* __restrict__ lin_w, const float* __restrict__ lin_bias,
-    float* __restrict__ concat, int64_t ld, float* __restrict__ sum_x, float* __restrict__ fm_logit) {
+    float* __restrict__ concat, int64_t ld, float* __restrict__ sum_x, float* __restrict__ fm_logit, float so) {
     constexpr int NS = DR_WAVE / LPR;
     const int lane = threadIdx.x & 63;
     const int slot = lane / LPR;
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void emb_pool_fwd_sv_kernel(
             float t = (S.x * S.x - SS.x) + (S.y * S.y - SS.y) + (S.z * S.z - SS.z) + (S.w * S.w - SS.w);
 #pragma unroll
             for (int m = 1; m < LPR; m <<= 1) t += __shfl_xor(t, m, 64);
-            if (lane == 0) fm_logit[b] = (lin_bias != nullptr ? lin_bias[0] : 0.f) + lin + 0.5f * t;
+            if (lane == 0) fm_logit[b] = (lin_bias != nullptr ? lin_bias[0] : 0.f) + lin + so * t;
         }
     }
 }
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void emb_pool_fwd_bag_kernel(
     const int64_t* __restrict__ ids, int64_t B, int32_t F, int32_t C, const int32_t* __restrict__ col_start,
     const int64_t* __restrict__ row_base, const float* __restrict__ table, int32_t D,
     const float* __restrict__ lin_w, const float* __restrict__ lin_bias, float* __restrict__ concat, int64_t ld,
-    float* __restrict__ sum_x, float* __restrict__ fm_logit) {
+    float* __restrict__ sum_x, float* __restrict__ fm_logit, float so) {
     constexpr int NS = DR_WAVE / LPR;
     const int lane = threadIdx.x & 63;
     const int slot = lane / LPR;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void emb_pool_fwd_bag_kernel(
             float t = (S.x * S.x - SS.x) + (S.y * S.y - SS.y) + (S.z * S.z - SS.z) + (S.w * S.w - SS.w);
 #pragma unroll
             for (int m = 1; m < LPR; m <<= 1) t += __shfl_xor(t, m, 64);
-            if (lane == 0) fm_logit[b] = (lin_bias != nullptr ? lin_bias[0] : 0.f) + lin + 0.5f * t;
+            if (lane == 0) fm_logit[b] = (lin_bias != nullptr ? lin_bias[0] : 0.f) + lin + so * t;
         }
     }
 }
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void emb_pool_bwd_kernel(
                 g[j] = 0.f;
                 if (doff[j] < D) {
                     if (d_concat != nullptr) g[j] = d_concat[b * ld_dc + f * D + doff[j]];
-                    if (d_fm_logit != nullptr) g[j] += dl * (s[j] - concat[b * ld_c + f * D + doff[j]]);
+                    if (d_fm_logit != nullptr && concat != nullptr) g[j] += dl * (s[j] - concat[b * ld_c + f * D + doff[j]]);
                     g[j] *= scale;
                     if (cnt > 1) g[j] /= (float)cnt;
                 }
@@ -268,10 +268,11 @@ int lpr_for(int D) {
         default: return DR_EINVAL;            \
     }
 
-extern "C" int dr_emb_pool_fwd(const int64_t* ids, int64_t B, int32_t F, int32_t C, const int32_t* col_start,
-                               const int64_t* row_base, const float* table, int32_t D, const float* lin_w,
-                               const float* lin_bias, float* concat, int64_t ld_concat, float* sum_x, float* fm_logit,
-                               dr_stream_t stream) {
+extern "C" int dr_emb_pool_fwd_ex(const int64_t* ids, int64_t B, int32_t F, int32_t C, const int32_t* col_start,
+                                  const int64_t* row_base, const float* table, int32_t D, const float* lin_w,
+                                  const float* lin_bias, float* concat, int64_t ld_concat, float* sum_x, float* fm_logit,
+                                  int32_t flags, dr_stream_t stream) {
+    const float so = (flags & 1) ? 0.f : 0.5f;          // DR_POOL_FIRST_ORDER_ONLY: fm_logit = bias + sum w (the "wide" logit)
     if (B < 0 || F <= 0 || C < F || D < 4 || D > 256 || (D & 3) || ld_concat < (int64_t)F * D || (ld_concat & 3))
         return DR_EINVAL;
     if (col_start == nullptr && C != F) return DR_EINVAL;
@@ -285,7 +286,7 @@ extern "C" int dr_emb_pool_fwd(const int64_t* ids, int64_t B, int32_t F, int32_t
         constexpr int NS_ = 64 / L;                                                                                \
         constexpr int U_ = NS_ >= 16 ? 2 : (NS_ >= 4 ? 8 : 4);                                                     \
         hipLaunchKernelGGL((emb_pool_fwd_sv_kernel<L, U_>), dim3(grid), dim3(256), 0, dr_s(stream), ids, B, F,     \
-                           row_base, table, D, lin_w, lin_bias, concat, ld_concat, sum_x, fm_logit);               \
+                           row_base, table, D, lin_w, lin_bias, concat, ld_concat, sum_x, fm_logit, so);           \
     }
         DR_DISPATCH_LPR(lpr, CALL)
 #undef CALL
@@ -293,10 +294,85 @@ extern "C" int dr_emb_pool_fwd(const int64_t* ids, int64_t B, int32_t F, int32_t
         if (col_start == nullptr) return DR_EINVAL;   // F > 64 single-valued: pass an explicit col_start
 #define CALL(L)                                                                                                    \
     hipLaunchKernelGGL((emb_pool_fwd_bag_kernel<L>), dim3(grid), dim3(256), 0, dr_s(stream), ids, B, F, C,         \
-                       col_start, row_base, table, D, lin_w, lin_bias, concat, ld_concat, sum_x, fm_logit);
+                       col_start, row_base, table, D, lin_w, lin_bias, concat, ld_concat, sum_x, fm_logit, so);
         DR_DISPATCH_LPR(lpr, CALL)
 #undef CALL
     }
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+extern "C" int dr_emb_pool_fwd(const int64_t* ids, int64_t B, int32_t F, int32_t C, const int32_t* col_start,
+                               const int64_t* row_base, const float* table, int32_t D, const float* lin_w,
+                               const float* lin_bias, float* concat, int64_t ld_concat, float* sum_x, float* fm_logit,
+                               dr_stream_t stream) {
+    return dr_emb_pool_fwd_ex(ids, B, F, C, col_start, row_base, table, D, lin_w, lin_bias, concat, ld_concat, sum_x, fm_logit,
+                              0, stream);
+}
+
+// ---- per-field first-order outputs (FNN, estimator/models/ranking/fnn.py:53-64 of the reference: one Dense(1, no bias)
+// over each indicator column's multi-hot input, then tf.concat -> [B, F]):  out[b][f] = sum_{c in bag f} w[row_base[f] + id]
+namespace {
+__global__ __launch_bounds__(256) void lin_fields_fwd_kernel(const int64_t* __restrict__ ids, int64_t B, int32_t F, int32_t C,
+                                                             const int32_t* __restrict__ col_start,
+                                                             const int64_t* __restrict__ row_base,
+                                                             const float* __restrict__ lin_w, float* __restrict__ out,
+                                                             int64_t ld) {
+    const int64_t n = B * F, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t b = i / F;
+        const int f = (int)(i - b * F);
+        const int c0 = col_start != nullptr ? col_start[f] : f, c1 = col_start != nullptr ? col_start[f + 1] : f + 1;
+        const int64_t base = row_base[f];
+        float acc = 0.f;
+        for (int c = c0; c < c1; ++c) {
+            const int64_t id = ids[b * C + c];
+            if (id >= 0) acc += lin_w[base + id];
+        }
+        out[b * ld + f] = acc;
+    }
+}
+__global__ __launch_bounds__(256) void lin_fields_bwd_kernel(const int64_t* __restrict__ ids, int64_t B, int32_t F, int32_t C,
+                                                             const int32_t* __restrict__ col_start,
+                                                             const int64_t* __restrict__ row_base,
+                                                             const float* __restrict__ d_out, int64_t ld, float scale,
+                                                             float* __restrict__ dst_lin) {
+    const int64_t n = B * F, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t b = i / F;
+        const int f = (int)(i - b * F);
+        const int c0 = col_start != nullptr ? col_start[f] : f, c1 = col_start != nullptr ? col_start[f + 1] : f + 1;
+        const int64_t base = row_base[f];
+        const float g = scale * d_out[b * ld + f];
+        for (int c = c0; c < c1; ++c) {
+            const int64_t id = ids[b * C + c];
+            if (id >= 0) unsafeAtomicAdd(dst_lin + base + id, g);
+        }
+    }
+}
+}  // namespace
+
+extern "C" int dr_lin_fields_fwd(const int64_t* ids, int64_t B, int32_t F, int32_t C, const int32_t* col_start,
+                                 const int64_t* row_base, const float* lin_w, float* out, int64_t ld_out, dr_stream_t stream) {
+    if (B < 0 || F <= 0 || C < F || ld_out < F) return DR_EINVAL;
+    if (col_start == nullptr && C != F) return DR_EINVAL;
+    if (B == 0) return DR_OK;
+    if (!ids || !row_base || !lin_w || !out) return DR_EINVAL;
+    hipLaunchKernelGGL(lin_fields_fwd_kernel, dim3(dr_grid_for(B * F, 256)), dim3(256), 0, dr_s(stream), ids, B, F, C, col_start,
+                       row_base, lin_w, out, ld_out);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+extern "C" int dr_lin_fields_bwd(const int64_t* ids, int64_t B, int32_t F, int32_t C, const int32_t* col_start,
+                                 const int64_t* row_base, const float* d_out, int64_t ld_dout, float scale, float* dst_lin,
+                                 dr_stream_t stream) {
+    if (B < 0 || F <= 0 || C < F || ld_dout < F) return DR_EINVAL;
+    if (col_start == nullptr && C != F) return DR_EINVAL;
+    if (B == 0) return DR_OK;
+    if (!ids || !row_base || !d_out || !dst_lin) return DR_EINVAL;
+    hipLaunchKernelGGL(lin_fields_bwd_kernel, dim3(dr_grid_for(B * F, 256)), dim3(256), 0, dr_s(stream), ids, B, F, C, col_start,
+                       row_base, d_out, ld_dout, scale, dst_lin);
     DR_CHECK_LAUNCH();
     return DR_OK;
 }
@@ -315,7 +391,10 @@ extern "C" int dr_emb_pool_bwd(const int64_t* ids, int64_t B, int32_t F, int32_t
     if (!ids || !row_base || !dst_table || !col_start) return DR_EINVAL;
     if (d_concat == nullptr && d_fm_logit == nullptr) return DR_EINVAL;
     if (d_concat != nullptr && ld_dconcat < (int64_t)F * D) return DR_EINVAL;
-    if (d_fm_logit != nullptr && (concat == nullptr || sum_x == nullptr || ld_concat < (int64_t)F * D)) return DR_EINVAL;
+    // d_fm_logit with concat == sum_x == NULL: the logit was first-order only (DR_POOL_FIRST_ORDER_ONLY): its gradient
+    // reaches dst_lin / dst_bias, not the rows
+    if (d_fm_logit != nullptr && (concat == nullptr) != (sum_x == nullptr)) return DR_EINVAL;
+    if (d_fm_logit != nullptr && concat != nullptr && ld_concat < (int64_t)F * D) return DR_EINVAL;
     const int lpr = lpr_for(D);
     const int grid = dr_grid_for(B, 4);
     if (g_bwd_strided) {

@@ -36,3 +36,17 @@ class FM(nn.Module):
         return fm_logit.reshape(-1, 1)                       # linear_outputs + factorized_outputs
 
     forward = call
+
+    # TF1 names of fm.py:43-52: linear/linear_model/<key>_indicator/weights, linear/linear_model/bias_weights,
+    # factorized/input_layer/<key>_embedding/embedding_weights -- the contract FNN.warm_up reads (ranking/fnn.py:32-48)
+    def export_variables(self):
+        from deep_recommenders_amd.estimator.models import variables as V
+        return V.export_slab(self.slab)
+
+    def import_variables(self, variables, strict=True):
+        from deep_recommenders_amd.estimator.models import variables as V
+        return V.import_slab(self.slab, variables, strict=strict)
+
+    def save_variables(self, path):
+        import numpy as np
+        np.savez(path, **self.export_variables())

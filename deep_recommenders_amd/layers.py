@@ -27,9 +27,10 @@ class _EmbPoolFn(torch.autograd.Function):
     slab (no gradient materialised — the only feasible mode for 10 M-row tables)."""
 
     @staticmethod
-    def forward(ctx, table, lin_w, lin_bias, ids, F, col_start, row_base, ld_concat, sparse_lr):
-        concat, sum_x, fm = ops.emb_pool_fwd(ids, F, col_start, row_base, table, lin_w, lin_bias, ld_concat=ld_concat)
-        ctx.F, ctx.sparse_lr = F, sparse_lr
+    def forward(ctx, table, lin_w, lin_bias, ids, F, col_start, row_base, ld_concat, sparse_lr, second_order=True):
+        concat, sum_x, fm = ops.emb_pool_fwd(ids, F, col_start, row_base, table, lin_w, lin_bias, ld_concat=ld_concat,
+                                             second_order=second_order)
+        ctx.F, ctx.sparse_lr, ctx.second_order = F, sparse_lr, second_order
         ctx.has_bias = lin_bias is not None
         ctx.bias_data = lin_bias.data if lin_bias is not None else None
         ctx.save_for_backward(table, lin_w, ids, col_start, row_base, concat, sum_x)
@@ -47,17 +48,37 @@ class _EmbPoolFn(torch.autograd.Function):
         if d_fm is not None:
             d_fm = d_fm.contiguous()
         if d_concat is None and d_fm is None:
-            return (None,) * 9
+            return (None,) * 10
         has_bias = ctx.has_bias and d_fm is not None
+        if not ctx.second_order:          # first-order-only logit: its gradient reaches lin_w / bias, not the rows
+            concat, sum_x = None, None
         if ctx.sparse_lr is None:
             g_table = torch.zeros_like(table)
             g_lin = torch.zeros_like(lin_w) if lin_w is not None else None
             g_bias = torch.zeros(1, dtype=torch.float32, device=table.device) if has_bias else None
             ops.emb_pool_bwd(ids, F, col_start, row_base, D, d_concat, concat, sum_x, d_fm, 1.0, g_table, g_lin, g_bias)
-            return g_table, g_lin, g_bias, None, None, None, None, None, None
+            return g_table, g_lin, g_bias, None, None, None, None, None, None, None
         ops.emb_pool_bwd(ids, F, col_start, row_base, D, d_concat, concat, sum_x, d_fm, -float(ctx.sparse_lr),
                          table.data, lin_w.data if lin_w is not None else None, ctx.bias_data if has_bias else None)
-        return None, None, None, None, None, None, None, None, None
+        return None, None, None, None, None, None, None, None, None, None
+
+
+class _LinFieldsFn(torch.autograd.Function):
+    """Per-field first-order outputs [B, F] (FNN's bias-free Dense(1) over each indicator column, fnn.py:53-64)."""
+
+    @staticmethod
+    def forward(ctx, lin_w, ids, F, col_start, row_base):
+        ctx.F = F
+        ctx.save_for_backward(lin_w, ids, col_start, row_base)
+        return ops.lin_fields_fwd(ids, F, col_start, row_base, lin_w)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        lin_w, ids, col_start, row_base = ctx.saved_tensors
+        g = torch.zeros_like(lin_w)
+        d_out = d_out if d_out.stride(1) == 1 else d_out.contiguous()
+        ops.lin_fields_bwd(ids, ctx.F, col_start, row_base, d_out, 1.0, g)
+        return g, None, None, None, None
 
 
 class _Fm2Fn(torch.autograd.Function):
@@ -261,10 +282,17 @@ class EmbeddingSlab(nn.Module):
             self._rb_cache[ck] = cached
         return ids.contiguous(), cached[0], cached[1]
 
-    def forward(self, inputs: Dict[str, object], field_keys: Sequence[str], ld_concat: Optional[int] = None):
-        """-> concat [B, ld] (first F*D columns valid), fm_logit [B] (first-order + bias + second-order), sum_x"""
+    def forward(self, inputs: Dict[str, object], field_keys: Sequence[str], ld_concat: Optional[int] = None,
+                second_order: bool = True):
+        """-> concat [B, ld] (first F*D columns valid), fm_logit [B] (first-order + bias + second-order; with
+        second_order=False the first-order + bias only: WDL's "wide" logit), sum_x"""
         ids, col_start, row_base = self.transform(inputs, field_keys)
         F = len(field_keys)
         concat, fm, sum_x = _EmbPoolFn.apply(self.table, self.lin_w, self.lin_bias, ids, F, col_start, row_base,
-                                             ld_concat, self.sparse_lr)
+                                             ld_concat, self.sparse_lr, second_order)
         return concat, fm, sum_x
+
+    def first_order_fields(self, inputs: Dict[str, object], field_keys: Sequence[str]):
+        """[B, F]: every field's own first-order output sum_bag w[id] (no bias) -- FNN's `concat_weights`."""
+        ids, col_start, row_base = self.transform(inputs, field_keys)
+        return _LinFieldsFn.apply(self.lin_w, ids, len(field_keys), col_start, row_base)

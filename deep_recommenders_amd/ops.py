@@ -75,7 +75,7 @@ def vocab_lookup_strings(values: Sequence, vocab: Sequence, device="cuda"):
 # K3 / K4   fused embedding gather + pool (+ first-order + FM)
 # ----------------------------------------------------------------------------------------------
 def emb_pool_fwd(ids, F, col_start, row_base, table, lin_w=None, lin_bias=None, ld_concat=None,
-                 want_sum_x=True, want_fm=True, concat=None, sum_x=None, fm_logit=None):
+                 want_sum_x=True, want_fm=True, concat=None, sum_x=None, fm_logit=None, second_order=True):
     ids = _c(ids, torch.int64)
     B, C = ids.shape
     D = table.shape[1]
@@ -89,10 +89,29 @@ def emb_pool_fwd(ids, F, col_start, row_base, table, lin_w=None, lin_bias=None, 
         sum_x = torch.empty((B, D), dtype=torch.float32, device=dev)
     if want_fm and fm_logit is None:
         fm_logit = torch.empty((B,), dtype=torch.float32, device=dev)
-    check(lib().dr_emb_pool_fwd(ptr(ids), B, F, C, ptr(col_start), ptr(row_base), ptr(table), D, ptr(lin_w),
-                                ptr(lin_bias), ptr(concat), ld, ptr(sum_x) if want_sum_x else None,
-                                ptr(fm_logit) if want_fm else None, stream_ptr()), "dr_emb_pool_fwd")
+    check(lib().dr_emb_pool_fwd_ex(ptr(ids), B, F, C, ptr(col_start), ptr(row_base), ptr(table), D, ptr(lin_w),
+                                   ptr(lin_bias), ptr(concat), ld, ptr(sum_x) if want_sum_x else None,
+                                   ptr(fm_logit) if want_fm else None, 0 if second_order else 1, stream_ptr()),
+          "dr_emb_pool_fwd_ex")
     return concat, sum_x, fm_logit
+
+
+def lin_fields_fwd(ids, F, col_start, row_base, lin_w):
+    """out[b, f] = sum over field f's bag of lin_w[row_base[f] + id] (FNN's per-field first-order inputs)."""
+    ids = _c(ids, torch.int64)
+    B, C = ids.shape
+    out = torch.empty((B, _pad4(F)), dtype=torch.float32, device=ids.device)[:, :F]
+    check(lib().dr_lin_fields_fwd(ptr(ids), B, F, C, ptr(col_start), ptr(row_base), ptr(lin_w), ptr(out), out.stride(0),
+                                  stream_ptr()), "dr_lin_fields_fwd")
+    return out
+
+
+def lin_fields_bwd(ids, F, col_start, row_base, d_out, scale, dst_lin):
+    ids = _c(ids, torch.int64)
+    B, C = ids.shape
+    assert d_out.stride(1) == 1
+    check(lib().dr_lin_fields_bwd(ptr(ids), B, F, C, ptr(col_start), ptr(row_base), ptr(d_out), d_out.stride(0), float(scale),
+                                  ptr(dst_lin), stream_ptr()), "dr_lin_fields_bwd")
 
 
 def emb_pool_bwd(ids, F, col_start, row_base, D, d_concat, concat, sum_x, d_fm_logit, scale, dst_table, dst_lin,

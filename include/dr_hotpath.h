@@ -91,6 +91,24 @@ int dr_emb_pool_fwd(const int64_t* ids, int64_t B, int32_t F, int32_t C, const i
                     float* concat, int64_t ld_concat, float* sum_x, float* fm_logit,
                     dr_stream_t stream);
 
+/* Same, with flags.  DR_POOL_FIRST_ORDER_ONLY: fm_logit = lin_bias + sum w (no second-order term) -- the "wide" logit of
+ * WDL (`tf.feature_column.linear_model`, estimator/models/ranking/wide_and_deep.py:30-32 of the reference). */
+#define DR_POOL_FIRST_ORDER_ONLY 1
+int dr_emb_pool_fwd_ex(const int64_t* ids, int64_t B, int32_t F, int32_t C, const int32_t* col_start,
+                       const int64_t* row_base, const float* table, int32_t D, const float* lin_w,
+                       const float* lin_bias, float* concat, int64_t ld_concat, float* sum_x,
+                       float* fm_logit, int32_t flags, dr_stream_t stream);
+/* Per-field first-order outputs (FNN, estimator/models/ranking/fnn.py:53-64: a bias-free Dense(1) over every indicator
+ * column's multi-hot input, concatenated):  out[b][f] = sum over the bag of field f of lin_w[row_base[f] + id]  (ids < 0
+ * skipped).  bwd: dst_lin[row] += scale * d_out[b][f] for every id of the bag (fp32 atomics). */
+int dr_lin_fields_fwd(const int64_t* ids, int64_t B, int32_t F, int32_t C, const int32_t* col_start,
+                      const int64_t* row_base, const float* lin_w, float* out, int64_t ld_out,
+                      dr_stream_t stream);
+int dr_lin_fields_bwd(const int64_t* ids, int64_t B, int32_t F, int32_t C, const int32_t* col_start,
+                      const int64_t* row_base, const float* d_out, int64_t ld_dout, float scale,
+                      float* dst_lin, dr_stream_t stream);
+
+
 /* ------------------------------------------------------------------------------------------
  * K4  transposed scatter-add backward of K3 (autodiff of the lookup: IndexedSlices ->
  * unsorted_segment_sum into the variable; implicit in optimizer.minimize / model.fit:
@@ -103,7 +121,8 @@ int dr_emb_pool_fwd(const int64_t* ids, int64_t B, int32_t F, int32_t C, const i
  *
  * dst_table / dst_lin are either gradient buffers (scale = 1) or the parameters themselves
  * (scale = -learning_rate: fused SGD step, no gradient materialised).  d_concat may be NULL
- * (FM only), d_fm_logit may be NULL (pure lookup backward), dst_lin may be NULL.
+ * (FM only), d_fm_logit may be NULL (pure lookup backward), dst_lin may be NULL.  concat == sum_x == NULL with d_fm_logit
+ * given: the logit was first-order only (DR_POOL_FIRST_ORDER_ONLY), its gradient reaches dst_lin / dst_bias only.
  * Accumulation uses hardware fp32 atomics; rows touched once are bit-exact.
  * ---------------------------------------------------------------------------------------- */
 int dr_emb_pool_bwd(const int64_t* ids, int64_t B, int32_t F, int32_t C, const int32_t* col_start,

@@ -278,6 +278,30 @@ def deepfm_forward(ids_per_field, tables, lin_w, lin_b, dnn_kernels, dnn_biases,
     return prob
 
 
+def wdl_forward(ids_per_field, tables, lin_w, lin_b, dnn_kernels, dnn_biases, activation="relu"):
+    """estimator/models/ranking/wide_and_deep.py:29-48 of the reference: sigmoid(linear_model(indicator columns) +
+    dnn(concat(input_layer(embedding column) ...), units + [1]))."""
+    embs = [embedding_mean_pool_fast(t, i) for t, i in zip(tables, ids_per_field)]
+    wide = first_order_gather(ids_per_field, lin_w, lin_b)                    # :30-32
+    deep = dnn(np.concatenate(embs, axis=1), dnn_kernels, dnn_biases, activation)   # :34-46
+    return sigmoid(wide + deep)                                                # :48
+
+
+def fnn_forward(ids_per_field, tables, lin_w, fm_bias, dnn_kernels, dnn_biases, activation="relu"):
+    """estimator/models/ranking/fnn.py:50-90: dnn input = [FM bias (tiled) | per-field Dense(1, no bias)(multi-hot) |
+    per-field embedding]; output sigmoid(dnn(...))."""
+    B = ids_per_field[0].shape[0]
+    weights = []
+    for ids, w in zip(ids_per_field, lin_w):                                   # :52-63
+        m = ids >= 0
+        weights.append((np.where(m, np.asarray(w, np.float32)[np.where(m, ids, 0)], 0.0)).sum(axis=1, keepdims=True))
+    concat_weights = np.concatenate(weights, axis=1).astype(np.float32)        # :64
+    embs = [embedding_mean_pool_fast(t, i) for t, i in zip(tables, ids_per_field)]   # :66-77
+    bias = np.tile(np.asarray(fm_bias, np.float32).reshape(1, -1), (B, 1))     # :80-81
+    x = np.concatenate([bias, concat_weights, np.concatenate(embs, axis=1)], axis=1)   # :83
+    return sigmoid(dnn(x, dnn_kernels, dnn_biases, activation))                # :85-90
+
+
 # --------------------------------------------------------------------------------------
 # a9  Cross layer   keras/models/ranking/dcn.py:70-88
 # --------------------------------------------------------------------------------------

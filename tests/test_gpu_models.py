@@ -348,13 +348,92 @@ def test_engine_train_step_matches_oracle():
         np.testing.assert_allclose(eng.bs[i].cpu().numpy(), (bs0[i] - lr * bs[i].grad).numpy(), rtol=1e-4, atol=1e-6)
 
 
+def _store_params(store, scope="dnn"):
+    ks, bs, i = [], [], 0
+    while True:
+        name = ("%s/dense%s" % (scope, "" if i == 0 else "_%d" % i)).replace("/", "__")
+        if name + "__kernel" not in store.vars:
+            return ks, bs
+        ks.append(store.vars[name + "__kernel"].detach().cpu().numpy())
+        bs.append(store.vars[name + "__bias"].detach().cpu().numpy())
+        i += 1
+
+
+def test_estimator_wdl_and_fnn(tmp_path):
+    """WDL (wide_and_deep.py:29-48) and FNN (fnn.py:50-90) on the MovieLens-shaped batch against their
+    oracle restatements; gradients reach the wide weights; FNN warm-starts from an FM through the reference's TF variable
+    names (object, dict and .npz file)."""
+    from deep_recommenders_amd import feature_column as fc
+    from deep_recommenders_amd.estimator.models.feature_interaction import FM
+    from deep_recommenders_amd.estimator.models.ranking import WDL, FNN
+    rng = np.random.default_rng(4)
+    feats, labels = _movielens_batch(rng, 80)
+    ind, emb = _movielens_columns(fc)
+    ids = _oracle_ids(feats)
+    # ---- WDL ----
+    torch.manual_seed(5)
+    wdl = WDL(ind, emb, dnn_units=[32, 16])
+    with torch.no_grad():                                   # non-trivial first-order weights (zero-initialised otherwise)
+        wdl.slab.lin_w.normal_(0, 0.1)
+        wdl.slab.lin_bias.fill_(0.05)
+    p = wdl(feats)
+    assert tuple(p.shape) == (80, 1)
+    tabs = [wdl.slab.embedding_weights(k).cpu().numpy() for k in KEYS]
+    lws = [wdl.slab.linear_weights(k).cpu().numpy() for k in KEYS]
+    ks, bs = _store_params(wdl.store)
+    want = O.wdl_forward(ids, tabs, lws, 0.05, ks, bs)
+    np.testing.assert_allclose(p.detach().cpu().numpy(), want, rtol=1e-5, atol=2e-6)
+    loss = torch.nn.functional.binary_cross_entropy(p, torch.tensor(labels, device="cuda").reshape(-1, 1))
+    loss.backward()
+    assert float(wdl.slab.lin_w.grad.abs().sum()) > 0 and float(wdl.slab.table.grad.abs().sum()) > 0
+    assert float(wdl.slab.lin_bias.grad.abs().sum()) > 0
+    names = wdl.export_variables()
+    assert "wide/linear_model/user_id_indicator/weights" in names and "wide/linear_model/bias_weights" in names
+    assert "deep/input_layer/movie_id_embedding/embedding_weights" in names and "deep/dense/kernel" in names and "deep/dense_2/bias" in names
+    assert names["wide/linear_model/user_id_indicator/weights"].shape == (6040, 1)
+    wdl2 = WDL(ind, emb, dnn_units=[32, 16])
+    wdl2(feats)                                             # materialise the dense variables
+    wdl2.import_variables({k + ":0": v for k, v in names.items()})          # TF's ':0' suffix accepted
+    np.testing.assert_array_equal(wdl2(feats).detach().cpu().numpy(), wdl(feats).detach().cpu().numpy())
+    # ---- FM -> FNN warm start ----
+    torch.manual_seed(6)
+    fm_model = FM(ind, emb)
+    with torch.no_grad():
+        fm_model.slab.lin_w.normal_(0, 0.1)
+        fm_model.slab.lin_bias.fill_(-0.2)
+    fm_vars = fm_model.export_variables()
+    assert set(n.split("/")[0] for n in fm_vars) == {"linear", "factorized"}
+    npz = str(tmp_path / "fm_variables.npz")
+    fm_model.save_variables(npz)
+    outs = []
+    for src in (fm_model, fm_vars, npz):
+        torch.manual_seed(7)                                # same DNN initialisation for the three sources
+        fnn = FNN(ind, emb, src, dnn_units=[24, 8])
+        lin_v, fac_v = fnn.warm_up()
+        assert set(lin_v) == set(KEYS) | {"bias"} and set(fac_v) == set(KEYS) and fac_v["user_id"].shape == (6040, 16)
+        q = fnn(feats)
+        outs.append(q.detach().cpu().numpy())
+        np.testing.assert_array_equal(fnn.slab.table.detach().cpu().numpy(), fm_model.slab.table.detach().cpu().numpy())
+        np.testing.assert_array_equal(fnn.slab.lin_w.detach().cpu().numpy(), fm_model.slab.lin_w.detach().cpu().numpy())
+    np.testing.assert_array_equal(outs[0], outs[1])
+    np.testing.assert_array_equal(outs[0], outs[2])
+    tabs = [fm_model.slab.embedding_weights(k).cpu().numpy() for k in KEYS]
+    lws = [fm_model.slab.linear_weights(k).cpu().numpy() for k in KEYS]
+    ks, bs = _store_params(fnn.store)
+    assert ks[0].shape == (1 + 6 + 6 * 16, 24)              # [bias | 6 first-order | 6 x 16 embeddings]  (fnn.py:83)
+    want = O.fnn_forward(ids, tabs, lws, [-0.2], ks, bs)
+    np.testing.assert_allclose(outs[0], want, rtol=1e-5, atol=2e-6)
+    q.sum().backward()                                      # the warm-started first-order weights keep training (fnn.py:57-60)
+    assert float(fnn.slab.lin_w.grad.abs().sum()) > 0 and float(fnn.slab.table.grad.abs().sum()) > 0
+
+
 def test_tfrecord_batch_through_feature_columns_and_fm(tmp_path):
     """Input side -> hot path: a batch parsed by the native TFRecord / tf.Example reader (bytes features) through the
     reference-shaped feature columns and FM model equals the oracle evaluated on the same strings."""
     from oracle import tfrecord_py as W
     from deep_recommenders_amd import feature_column as fc
     from deep_recommenders_amd.datasets import MovielensRanking
-    from deep_recommenders_amd.keras.models.ranking import FM
+    from deep_recommenders_amd.estimator.models.feature_interaction import FM
     rng = np.random.default_rng(12)
     feats0, _ = _movielens_batch(rng, 96)
     rows = [W.movielens_example(feats0["user_id"][i].encode(), feats0["movie_id"][i].encode(), int(rng.integers(1, 6)), 978300000 + i,
