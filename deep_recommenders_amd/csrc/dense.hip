@@ -29,7 +29,7 @@ constexpr int BM = 128, BN = 128, BK = 32;   // wide configuration; the narrow o
 constexpr int LD_T = 129;   // pitch of a transposed-in operand tile
 constexpr int LD_D = 132;   // pitch of a direct operand tile
 
-enum Epi { EPI_BIAS_ACT = 0, EPI_CROSS = 1, EPI_MASK = 2, EPI_ATOMIC = 3, EPI_FMGRAD = 4, EPI_LSE = 5, EPI_SMGRAD = 6, EPI_HEAD = 7 };
+enum Epi { EPI_BIAS_ACT = 0, EPI_CROSS = 1, EPI_MASK = 2, EPI_ATOMIC = 3, EPI_FMGRAD = 4, EPI_LSE = 5, EPI_SMGRAD = 6, EPI_HEAD = 7, EPI_FILTER = 8 };
 constexpr int HEAD_PART = 34;   // per-block partials of the fused tower head: dw2[32], db2, loss
 
 struct GemmArgs {
@@ -71,6 +71,12 @@ struct GemmArgs {
     float* prob; float* d_logit;  // [M] (either may be null)
     float* d_h; int64_t ld_dh;    // [M, N] or null
     float* head_partial;          // [gridDim.x][HEAD_PART]
+    // FILTER (top-K scan): a score is kept only if it beats its row's current k-th best `tau[row]`; kept scores are
+    // appended to the row's candidate list (one atomic per 32-column group that has any) instead of writing C
+    const float* tau;             // [M]
+    float* cand_s; int32_t* cand_c;   // [M][cand_cap] scores / column numbers
+    int32_t* cand_cnt;            // [M] append cursors (may exceed cand_cap: the consumer clamps; cap == N never overflows)
+    int64_t cand_cap;
 };
 
 // exp() of a non-positive softmax argument; masked logits sit at ~-5e36 (MIN_FLOAT / temperature), far outside the
@@ -397,6 +403,39 @@ __global__ __launch_bounds__(256, NARROW ? 4 : 3) void gemm_f32_mfma_kernel(Gemm
                         if (colj[ni] >= g.N) continue;
                         const float pr = safe_exp(sv[ni] - lse) - (row == colj[ni] ? 1.f : 0.f);
                         g.C[row * g.ldc + colj[ni]] = w * pr * g.inv_t * g.alpha;
+                    }
+                }
+            }
+        }
+        return;
+    }
+    if constexpr (EPI == EPI_FILTER && !NARROW) {
+        const int c31 = lane & 31, hh = lane >> 5;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int64_t row = m0 + wm * (TM * 32) + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                const bool rv = row < g.M;
+                const float t = rv ? g.tau[row] : INFINITY;
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) {
+                    const int col = n0 + wn * (TN * 32) + ni * 32 + c31;
+                    const float v = acc[mi][ni][reg];
+                    const bool pass = rv && col < g.N && v > t;
+                    const unsigned half = (unsigned)((__ballot(pass) >> (32 * hh)) & 0xffffffffull);
+                    if (half != 0u) {                      // rare once tau has warmed up: one atomic per (row, 32 columns)
+                        const int leader = 32 * hh + __ffs((int)half) - 1;
+                        int base = 0;
+                        if (lane == leader) base = atomicAdd(g.cand_cnt + row, __popc(half));
+                        base = __shfl(base, leader, 64);
+                        if (pass) {
+                            const int64_t pos = base + __popc(half & ((1u << c31) - 1u));
+                            if (pos < g.cand_cap) {
+                                g.cand_s[row * g.cand_cap + pos] = v;
+                                g.cand_c[row * g.cand_cap + pos] = col;
+                            }
+                        }
                     }
                 }
             }
@@ -981,6 +1020,19 @@ extern "C" int dr_inbatch_softmax_grad_scores(const float* q, const float* c, in
 }
 
 // plain scores = a @ b^T for two reduction-contiguous operands (queries x candidates), used by the top-K search
+// internal (C++ linkage, used by retrieval.hip): scores = a @ b^T, filtered against tau into per-row candidate lists
+int dr_scores_nt_filter(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t M, int32_t N, int32_t D,
+                        const float* tau, float* cand_s, int32_t* cand_c, int32_t* cand_cnt, int64_t cand_cap,
+                        dr_stream_t stream) {
+    if (M < 0 || N <= 0 || D < 4 || lda < D || ldb < D || cand_cap <= 0) return DR_EINVAL;
+    if (M == 0) return DR_OK;
+    if (!a || !b || !tau || !cand_s || !cand_c || !cand_cnt) return DR_EINVAL;
+    GemmArgs g{};
+    g.A = a; g.lda = lda; g.B = b; g.ldb = ldb; g.M = M; g.N = N; g.R = D; g.split = 1;
+    g.tau = tau; g.cand_s = cand_s; g.cand_c = cand_c; g.cand_cnt = cand_cnt; g.cand_cap = cand_cap;
+    return launch<true, true, EPI_FILTER>(g, dr_s(stream));
+}
+
 extern "C" int dr_scores_nt(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t M, int32_t N, int32_t D,
                             float* out, int64_t ld_out, dr_stream_t stream) {
     if (M < 0 || N <= 0 || D < 4 || ld_out < N || lda < D || ldb < D) return DR_EINVAL;

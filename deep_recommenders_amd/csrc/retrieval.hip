@@ -31,9 +31,15 @@ __device__ __forceinline__ int64_t shfl_up_i64(int64_t v, int d) {
 }
 
 // fold scores[row, 0..n) (candidate index = index_base + j) into the running sorted list of `row`
+// Candidate-list mode (cols != NULL): row `row` holds min(cnt[row], ld) entries (score, column) in ARBITRARY order (the
+// filtering GEMM epilogue appends them with atomics); list order is made independent of arrival order by breaking score
+// ties on the candidate index (lower index first == the order a left-to-right scan produces, and tf.math.top_k's rule).
+// On exit the kernel optionally publishes tau[row] (k-th best, -inf while the list is not full) and clears cnt[row].
 __global__ __launch_bounds__(256) void topk_select_kernel(const float* __restrict__ scores, int64_t ld, int64_t Bq,
                                                           int64_t n, int32_t k, int64_t index_base, int32_t init,
-                                                          float* __restrict__ out_s, int64_t* __restrict__ out_i) {
+                                                          float* __restrict__ out_s, int64_t* __restrict__ out_i,
+                                                          const int32_t* __restrict__ cols, int32_t* __restrict__ cnt,
+                                                          float* __restrict__ tau_out) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= Bq) return;
@@ -56,20 +62,27 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const float* __restric
     bool full = kth_valid();
     float tau = kth();
     const float* srow = scores + row * ld;
+    const int32_t* crow = cols != nullptr ? cols + row * ld : nullptr;
+    if (cnt != nullptr) {
+        const int64_t have = cnt[row];
+        n = have < ld ? have : ld;
+    }
     for (int64_t j0 = 0; j0 < n; j0 += 64) {
         const int64_t j = j0 + lane;
         const float v = j < n ? srow[j] : -INFINITY;
+        const int64_t myidx = index_base + (crow != nullptr ? (int64_t)(j < n ? crow[j] : 0) : j);
         unsigned long long mask = __ballot(j < n && (!full || v > tau));
         while (mask) {
             const int l = __ffsll((long long)mask) - 1;
             mask &= mask - 1;
             const float cand = __shfl(v, l, 64);
             if (full && !(cand > tau)) continue;
-            const int64_t cidx = index_base + j0 + l;
-            // rank = number of list entries that stay ahead of cand (score >= cand among valid entries; NaN-free input)
+            const int64_t cidx = shfl_i64(myidx, l);
+            // rank = number of list entries that stay ahead of cand: higher score, or equal score and lower index
+            // (NaN-free input)
             int c = 0;
-            if (p0 < k && i0 >= 0 && e0 >= cand) ++c;
-            if (p1 < k && i1 >= 0 && e1 >= cand) ++c;
+            if (p0 < k && i0 >= 0 && (e0 > cand || (e0 == cand && i0 < cidx))) ++c;
+            if (p1 < k && i1 >= 0 && (e1 > cand || (e1 == cand && i1 < cidx))) ++c;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
             const int pos = c;
@@ -87,6 +100,10 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const float* __restric
     }
     if (p0 < k) { out_s[row * k + p0] = e0; out_i[row * k + p0] = i0; }
     if (p1 < k) { out_s[row * k + p1] = e1; out_i[row * k + p1] = i1; }
+    if (lane == 0) {
+        if (tau_out != nullptr) tau_out[row] = full ? tau : -INFINITY;
+        if (cnt != nullptr) cnt[row] = 0;
+    }
 }
 
 // two-pointer merge of two sorted lists per row, list a wins ties (Streaming's reduce; cross-rank merge)
@@ -250,20 +267,39 @@ extern "C" int dr_topk_select(const float* scores, int64_t ld, int64_t Bq, int64
     if (Bq == 0) return DR_OK;
     if (!out_scores || !out_index || (n > 0 && !scores)) return DR_EINVAL;
     hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)((Bq + 3) / 4)), dim3(256), 0, dr_s(stream), scores, ld, Bq, n, k,
-                       index_base, init, out_scores, out_index);
+                       index_base, init, out_scores, out_index, (const int32_t*)nullptr, (int32_t*)nullptr, (float*)nullptr);
     DR_CHECK_LAUNCH();
     return DR_OK;
 }
 
+// workspace = [append cursors Bq x i32][tau Bq x f32] (256-B aligned) + Bq x chunk x 8 B, used as a dense score matrix
+// [Bq, chunk] for the first chunk and as candidate lists (scores + columns, capacity = chunk: cannot overflow) afterwards
+static int64_t topk_hdr_bytes(int64_t Bq) { return (Bq * 8 + 255) / 256 * 256; }
+
 extern "C" int64_t dr_topk_workspace_bytes(int64_t Bq, int64_t N, int32_t k) {
     (void)k;
-    int64_t chunk = (int64_t)(128ll << 20) / (Bq > 0 ? Bq * 4 : 4);     // ~128 MB of scores: stays in the Infinity Cache
+    int64_t chunk = (int64_t)(128ll << 20) / (Bq > 0 ? Bq * 4 : 4);     // ~128 MB of scores per chunk: Infinity-Cache sized
     chunk = chunk / 128 * 128;
     if (chunk < 128) chunk = 128;
     if (chunk > N) chunk = (N + 3) / 4 * 4;
-    return Bq * chunk * 4;
+    if (chunk < 4) chunk = 4;
+    return topk_hdr_bytes(Bq) + Bq * chunk * 8;
 }
 
+int dr_scores_nt_filter(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t M, int32_t N, int32_t D,
+                        const float* tau, float* cand_s, int32_t* cand_c, int32_t* cand_cnt, int64_t cand_cap,
+                        dr_stream_t stream);        // dense.hip
+
+__global__ __launch_bounds__(256) void zero_i32_kernel(int32_t* __restrict__ p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+
+// Exact top-k of q @ cand^T over N candidates, never materialising [Bq, N].  Chunk 0 is scored densely and selected
+// (nothing is known about the rows yet); every later chunk runs the GEMM with the FILTER epilogue: a score is written
+// only if it beats its row's current k-th best, into a per-row candidate list that the selection kernel then folds in.
+// After a few chunks almost nothing passes (expected k / items_seen of a chunk), so neither the [Bq, chunk] score
+// matrix nor its re-read exist any more.
 extern "C" int dr_topk_mips(const float* q, int64_t Bq, const float* cand, int64_t N, int32_t D, int32_t k,
                             int64_t index_base, int32_t init, float* out_scores, int64_t* out_index, float* workspace,
                             int64_t workspace_bytes, dr_stream_t stream) {
@@ -271,20 +307,36 @@ extern "C" int dr_topk_mips(const float* q, int64_t Bq, const float* cand, int64
     if (Bq == 0) return DR_OK;
     if (!q || !out_scores || !out_index || !workspace || (N > 0 && !cand)) return DR_EINVAL;
     if (init && k > N) return DR_ESHAPE;                 // "input must have at least k columns"
-    int64_t chunk = workspace_bytes / (Bq * 4);
+    const int64_t hdr = topk_hdr_bytes(Bq);
+    int64_t chunk = (workspace_bytes - hdr) / (Bq * 8);
     chunk = chunk >= 128 ? chunk / 128 * 128 : chunk / 4 * 4;
     if (chunk < 4 && N > 0) return DR_EINVAL;
-    int first = init;
+    char* wsb = reinterpret_cast<char*>(workspace);
+    int32_t* cnt = reinterpret_cast<int32_t*>(wsb);
+    float* tau = reinterpret_cast<float*>(wsb + Bq * 4);
+    float* dense = reinterpret_cast<float*>(wsb + hdr);                       // [Bq, chunk] scores (chunk 0)
+    float* cand_s = dense;                                                    // [Bq, chunk] candidate scores (later chunks)
+    int32_t* cand_c = reinterpret_cast<int32_t*>(wsb + hdr + Bq * chunk * 4); // [Bq, chunk] candidate columns
+    const unsigned sel_grid = (unsigned)((Bq + 3) / 4);
     if (N == 0 && init) {
         hipLaunchKernelGGL(fill_topk_kernel, dim3(dr_grid_for(Bq * k, 256)), dim3(256), 0, dr_s(stream), out_scores, out_index,
                            Bq * k);
     }
+    int first = init;
     for (int64_t c0 = 0; c0 < N; c0 += chunk) {
         const int64_t nc = N - c0 < chunk ? N - c0 : chunk;
-        int rc = dr_scores_nt(q, D, cand + c0 * D, D, Bq, (int32_t)nc, D, workspace, chunk, stream);
-        if (rc != DR_OK) return rc;
-        rc = dr_topk_select(workspace, chunk, Bq, nc, k, index_base + c0, first, out_scores, out_index, stream);
-        if (rc != DR_OK) return rc;
+        if (c0 == 0) {
+            int rc = dr_scores_nt(q, D, cand, D, Bq, (int32_t)nc, D, dense, chunk, stream);
+            if (rc != DR_OK) return rc;
+            if (N > chunk) hipLaunchKernelGGL(zero_i32_kernel, dim3(dr_grid_for(Bq, 256)), dim3(256), 0, dr_s(stream), cnt, Bq);
+            hipLaunchKernelGGL(topk_select_kernel, dim3(sel_grid), dim3(256), 0, dr_s(stream), dense, chunk, Bq, nc, k,
+                               index_base, first, out_scores, out_index, (const int32_t*)nullptr, (int32_t*)nullptr, tau);
+        } else {
+            int rc = dr_scores_nt_filter(q, D, cand + c0 * D, D, Bq, (int32_t)nc, D, tau, cand_s, cand_c, cnt, chunk, stream);
+            if (rc != DR_OK) return rc;
+            hipLaunchKernelGGL(topk_select_kernel, dim3(sel_grid), dim3(256), 0, dr_s(stream), cand_s, chunk, Bq, nc, k,
+                               index_base + c0, 0, out_scores, out_index, cand_c, cnt, tau);
+        }
         first = 0;
     }
     DR_CHECK_LAUNCH();
