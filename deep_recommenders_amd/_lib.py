@@ -61,6 +61,8 @@ SIGNATURES = {
     "dr_topk_select": [_p, _i64, _i64, _i64, _i32, _i64, _i32, _p, _p, _p],
     "dr_topk_workspace_bytes": [_i64, _i64, _i32],
     "dr_topk_mips": [_p, _i64, _p, _i64, _i32, _i32, _i64, _i32, _p, _p, _p, _i64, _p],
+    "dr_ivf_pack": [_p, _i64, _i32, _p, _p, _p, _i32, _i64, _p, _p, _p, _p],
+    "dr_ivf_scan": [_p, _i64, _i32, _p, _i32, _p, _p, _p, _i32, _p, _p, _p],
     "dr_topk_merge": [_p, _p, _i32, _p, _p, _i32, _i64, _i32, _p, _p, _p],
     "dr_rowdot": [_p, _p, _i64, _i32, _p, _p],
     "dr_gather_i64": [_p, _i64, _p, _i64, _p, _p],

@@ -10,6 +10,7 @@
 // (expected k*ln(N/k) insertions per row over the whole corpus), insertion = one rank count (wave sum) + a
 // lane shift (__shfl_up).  Ties resolve to the lower candidate index, as tf.math.top_k does.
 #include "dr_common.h"
+#include "topk_list.h"
 #include <math.h>
 
 extern "C" int dr_scores_nt(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t M, int32_t N, int32_t D,
@@ -17,24 +18,14 @@ extern "C" int dr_scores_nt(const float* a, int64_t lda, const float* b, int64_t
 
 namespace {
 
-constexpr int KMAX = 128;
+using drtk::KMAX;
+using drtk::shfl_i64;
+using drtk::shfl_up_i64;
 
-__device__ __forceinline__ int64_t shfl_i64(int64_t v, int src) {
-    int lo = __shfl((int)(v & 0xffffffffll), src, 64);
-    int hi = __shfl((int)(v >> 32), src, 64);
-    return ((int64_t)hi << 32) | (uint32_t)lo;
-}
-__device__ __forceinline__ int64_t shfl_up_i64(int64_t v, int d) {
-    int lo = __shfl_up((int)(v & 0xffffffffll), d, 64);
-    int hi = __shfl_up((int)(v >> 32), d, 64);
-    return ((int64_t)hi << 32) | (uint32_t)lo;
-}
-
-// fold scores[row, 0..n) (candidate index = index_base + j) into the running sorted list of `row`
+// fold scores[row, 0..n) (candidate index = index_base + j) into the running sorted list of `row`.
 // Candidate-list mode (cols != NULL): row `row` holds min(cnt[row], ld) entries (score, column) in ARBITRARY order (the
-// filtering GEMM epilogue appends them with atomics); list order is made independent of arrival order by breaking score
-// ties on the candidate index (lower index first == the order a left-to-right scan produces, and tf.math.top_k's rule).
-// On exit the kernel optionally publishes tau[row] (k-th best, -inf while the list is not full) and clears cnt[row].
+// filtering GEMM epilogue appends them with atomics); the list's index tie-break makes the result independent of arrival
+// order.  On exit the kernel optionally publishes tau[row] (k-th best, -inf while the list is not full) and clears cnt[row].
 __global__ __launch_bounds__(256) void topk_select_kernel(const float* __restrict__ scores, int64_t ld, int64_t Bq,
                                                           int64_t n, int32_t k, int64_t index_base, int32_t init,
                                                           float* __restrict__ out_s, int64_t* __restrict__ out_i,
@@ -43,24 +34,9 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const float* __restric
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= Bq) return;
-    const int p0 = lane, p1 = lane + 64;
-    float e0 = -INFINITY, e1 = -INFINITY;
-    int64_t i0 = -1, i1 = -1;
-    if (!init) {
-        if (p0 < k) { e0 = out_s[row * k + p0]; i0 = out_i[row * k + p0]; }
-        if (p1 < k) { e1 = out_s[row * k + p1]; i1 = out_i[row * k + p1]; }
-    }
-    // tau = score of the last list slot once the list is full (slot k-1), else -inf with "not full"
-    auto kth = [&]() -> float {
-        const float a = __shfl(e0, (k - 1) & 63, 64), b = __shfl(e1, (k - 1) & 63, 64);
-        return (k - 1) < 64 ? a : b;
-    };
-    auto kth_valid = [&]() -> bool {
-        const int64_t a = shfl_i64(i0, (k - 1) & 63), b = shfl_i64(i1, (k - 1) & 63);
-        return ((k - 1) < 64 ? a : b) >= 0;
-    };
-    bool full = kth_valid();
-    float tau = kth();
+    drtk::List L;
+    L.init(k, lane);
+    if (!init) L.load(out_s + row * k, out_i + row * k);
     const float* srow = scores + row * ld;
     const int32_t* crow = cols != nullptr ? cols + row * ld : nullptr;
     if (cnt != nullptr) {
@@ -71,37 +47,11 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const float* __restric
         const int64_t j = j0 + lane;
         const float v = j < n ? srow[j] : -INFINITY;
         const int64_t myidx = index_base + (crow != nullptr ? (int64_t)(j < n ? crow[j] : 0) : j);
-        unsigned long long mask = __ballot(j < n && (!full || v > tau));
-        while (mask) {
-            const int l = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            const float cand = __shfl(v, l, 64);
-            if (full && !(cand > tau)) continue;
-            const int64_t cidx = shfl_i64(myidx, l);
-            // rank = number of list entries that stay ahead of cand: higher score, or equal score and lower index
-            // (NaN-free input)
-            int c = 0;
-            if (p0 < k && i0 >= 0 && (e0 > cand || (e0 == cand && i0 < cidx))) ++c;
-            if (p1 < k && i1 >= 0 && (e1 > cand || (e1 == cand && i1 < cidx))) ++c;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-            const int pos = c;
-            if (pos >= k) continue;
-            const float pe0 = __shfl_up(e0, 1, 64), pe1 = __shfl_up(e1, 1, 64), w0 = __shfl(e0, 63, 64);
-            const int64_t pi0 = shfl_up_i64(i0, 1), pi1 = shfl_up_i64(i1, 1), wi0 = shfl_i64(i0, 63);
-            const float n0 = p0 < pos ? e0 : (p0 == pos ? cand : pe0);
-            const int64_t ni0 = p0 < pos ? i0 : (p0 == pos ? cidx : pi0);
-            const float n1 = p1 < pos ? e1 : (p1 == pos ? cand : (lane == 0 ? w0 : pe1));
-            const int64_t ni1 = p1 < pos ? i1 : (p1 == pos ? cidx : (lane == 0 ? wi0 : pi1));
-            e0 = n0; i0 = ni0; e1 = n1; i1 = ni1;
-            full = kth_valid();
-            tau = kth();
-        }
+        L.offer(v, myidx, j < n);
     }
-    if (p0 < k) { out_s[row * k + p0] = e0; out_i[row * k + p0] = i0; }
-    if (p1 < k) { out_s[row * k + p1] = e1; out_i[row * k + p1] = i1; }
+    L.store(out_s + row * k, out_i + row * k);
     if (lane == 0) {
-        if (tau_out != nullptr) tau_out[row] = full ? tau : -INFINITY;
+        if (tau_out != nullptr) tau_out[row] = L.full ? L.tau : -INFINITY;
         if (cnt != nullptr) cnt[row] = 0;
     }
 }

@@ -1,7 +1,6 @@
 """Top-K retrieval indices + the FactorizedTopK metric — same surface as the reference's
 keras/models/retrieval/factorized_top_k.py (`_take_long_axis` :26-41, `_exclude` :44-67, `TopK` :70-136,
-`Streaming` :139-260, `BruteForce` :263-334, `FactorizedTopK` :464-522), on the K10 kernels.
-The `Faiss` (IVF-Flat) index is §8f "next" and is not provided."""
+`Streaming` :139-260, `BruteForce` :263-334, `Faiss` :337-461, `FactorizedTopK` :464-522), on the K10 kernels."""
 import abc
 from typing import Iterable, List, Optional, Sequence, Tuple, Union
 
@@ -157,6 +156,105 @@ class BruteForce(TopK):
         queries = _dev(queries, torch.float32)
         scores, index = ops.topk_mips(queries, self._candidates, k)                # :330-332
         return scores, ops.gather_i64(self._identifiers, index)                    # :334
+
+
+class Faiss(TopK):
+    """IVF-Flat retrieval index for a factorized retrieval model (:337-461) -- same constructor (`k`, `query_model`, `nlist`,
+    `nprobe`, `normalize`), `index(candidates, identifiers=None)`, `call(queries, k=None)`.
+
+    The reference delegates to faiss-cpu 1.6.3 (`IndexIVFFlat(IndexFlatIP(d), d, nlist, METRIC_INNER_PRODUCT)`, :367-371),
+    a third-party library that is neither in the reference tree nor in this image.  This is the same index family on the
+    GPU (csrc/ivf.hip): k-means centroids trained on the candidates with inner-product assignment, every candidate stored
+    in the list of its best centroid, a query scans the `nprobe` best lists exactly.  The trained centroids are this
+    implementation's own (seeded, `niter` Lloyd iterations from a random subset), so for `nprobe < nlist` the approximate
+    results are those of THIS index, not bit-identical to faiss'; with `nlist == 1` or `nprobe == nlist` the search is exact
+    (the only behaviour the reference's tests pin: tests/keras/test_factorized_top_k.py:86-130)."""
+
+    def __init__(self, k: int = 10, query_model=None, nlist: Optional[int] = 1, nprobe: Optional[int] = 1,
+                 normalize: bool = False, niter: int = 10, seed: int = 1234, *args, **kwargs):
+        super().__init__(k, *args, **kwargs)
+        self._query_model = query_model
+        self._nlist = int(nlist)
+        self._nprobe = int(nprobe)
+        self._normalize = normalize
+        self._niter = int(niter)
+        self._seed = int(seed)
+        for name in ("_centroids", "_packed", "_packed_ids", "_blk_off", "_identifiers"):
+            self.register_buffer(name, None)
+        self._assignments = None         # list of every candidate (kept for inspection / tests)
+
+    @staticmethod
+    def _normalize_L2(x):
+        n = torch.linalg.vector_norm(x, dim=1, keepdim=True)
+        return x / torch.where(n > 0, n, torch.ones_like(n))                      # faiss.normalize_L2 leaves zero rows alone
+
+    def _assign(self, x, centroids):
+        _, best = ops.topk_mips(x, centroids, 1)                                  # coarse quantizer = exact inner product
+        return best.reshape(-1)
+
+    def _train(self, cand):
+        """k-means with inner-product assignment (what `index.train(candidates)` does for an IP index, :372)."""
+        N, D = cand.shape
+        if N < self._nlist:
+            raise ValueError("Number of training points ({}) should be at least as large as number of clusters ({})".format(
+                N, self._nlist))
+        g = torch.Generator(device=cand.device)
+        g.manual_seed(self._seed)
+        centroids = cand[torch.randperm(N, device=cand.device, generator=g)[:self._nlist]].clone()
+        if self._nlist == 1:
+            return cand.mean(0, keepdim=True)
+        for _ in range(self._niter):
+            a = self._assign(cand, centroids)
+            sums = torch.zeros((self._nlist, D), dtype=torch.float32, device=cand.device)
+            ops.rows_scatter_add(a, cand, None, 1.0, sums, None)
+            counts = torch.bincount(a, minlength=self._nlist).to(torch.float32).reshape(-1, 1)
+            centroids = torch.where(counts > 0, sums / counts.clamp(min=1.0), centroids)     # an empty cluster keeps its centroid
+        return centroids
+
+    def index(self, candidates, identifiers=None) -> "Faiss":
+        cand = torch.cat([_dev(b, torch.float32) for b in _batches(candidates)], dim=0)
+        if cand.dim() != 2:
+            raise ValueError("`candidates` ndim should be 2. "
+                             "Got `ndim` = {}".format(cand.dim()))                   # :409-411
+        N = cand.shape[0]
+        ids = None
+        self._identifiers = None
+        if identifiers is not None:
+            idt = torch.cat([_dev(b).reshape(-1) for b in _batches(identifiers)])
+            if idt.dtype in (torch.int8, torch.int16, torch.int32, torch.int64):
+                ids = idt.to(torch.int64).contiguous()                                # add_with_ids (:387)
+            else:
+                self._identifiers = idt                                               # gathered after the search (:413-427,461)
+        if self._normalize is True:
+            cand = self._normalize_L2(cand)                                           # :370-371
+        cand = cand.contiguous()
+        self._centroids = self._train(cand).contiguous()
+        assign = self._assign(cand, self._centroids)
+        self._assignments = assign
+        order = torch.argsort(assign, stable=True)
+        list_start = torch.zeros(self._nlist + 1, dtype=torch.int64, device=cand.device)
+        list_start[1:] = torch.cumsum(torch.bincount(assign, minlength=self._nlist), 0)
+        self._packed, self._packed_ids, self._blk_off = ops.ivf_pack(cand, order, list_start, ids)
+        return self
+
+    def call(self, queries, k: Optional[int] = None, **kwargs):
+        k = k if k is not None else self._k
+        if self._packed is None:
+            raise ValueError("The `index` method must be called first to "
+                             "create the retrieval index.")                       # :437-439
+        if self._query_model is not None:
+            queries = self._query_model(queries)
+        if isinstance(queries, dict) or not (isinstance(queries, torch.Tensor) or hasattr(queries, "shape")):
+            raise ValueError("Queries must be a tensor, got {}.".format(type(queries)))        # :444-445
+        queries = _dev(queries, torch.float32)
+        if self._normalize is True:
+            queries = self._normalize_L2(queries)                                  # :450-451
+        nprobe = max(1, min(self._nprobe, self._nlist))                             # searcher.nprobe (:453)
+        _, probes = ops.topk_mips(queries.contiguous(), self._centroids, nprobe)
+        distances, indices = ops.ivf_scan(queries.contiguous(), probes, self._blk_off, self._packed, self._packed_ids, int(k))
+        if self._identifiers is None:
+            return distances, indices
+        return distances, self._identifiers[indices.clamp(min=0)]                   # :461
 
 
 class TopKCategoricalAccuracy:

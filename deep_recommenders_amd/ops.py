@@ -567,6 +567,33 @@ def topk_mips(q, cand, k, index_base=0, init=True, state=None, workspace=None):
     return state
 
 
+def ivf_pack(cand, order, list_start, ids=None):
+    """IVF-Flat storage: lists padded to 64-vector blocks, each block dimension-major.  -> (packed, packed_ids, blk_off)"""
+    cand = _c(cand, torch.float32)
+    N, D = cand.shape
+    nlist = list_start.numel() - 1
+    counts = (list_start[1:] - list_start[:-1])
+    nblk = (counts + 63) // 64
+    blk_off = torch.zeros(nlist + 1, dtype=torch.int64, device=cand.device)
+    blk_off[1:] = torch.cumsum(nblk, 0)
+    total = int(blk_off[-1].item())
+    packed = torch.empty(max(total, 1) * D * 64, dtype=torch.float32, device=cand.device)
+    packed_ids = torch.empty(max(total, 1) * 64, dtype=torch.int64, device=cand.device)
+    check(lib().dr_ivf_pack(ptr(cand), N, D, ptr(_c(order, torch.int64)), ptr(_c(list_start, torch.int64)), ptr(blk_off), nlist,
+                            total, ptr(ids), ptr(packed), ptr(packed_ids), stream_ptr()), "dr_ivf_pack")
+    return packed, packed_ids, blk_off
+
+
+def ivf_scan(q, probes, blk_off, packed, packed_ids, k):
+    q = _c(q, torch.float32)
+    probes = _c(probes, torch.int64)
+    Bq, D = q.shape
+    s, i = topk_state(Bq, k, q.device)
+    check(lib().dr_ivf_scan(ptr(q), Bq, D, ptr(probes), probes.shape[1], ptr(blk_off), ptr(packed), ptr(packed_ids), int(k), ptr(s),
+                            ptr(i), stream_ptr()), "dr_ivf_scan")
+    return s, i
+
+
 def topk_merge(sa, ia, sb, ib, k):
     Bq = sa.shape[0]
     out = topk_state(Bq, k, sa.device)

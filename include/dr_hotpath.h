@@ -341,6 +341,24 @@ int64_t dr_topk_workspace_bytes(int64_t Bq, int64_t N, int32_t k);
 int dr_topk_mips(const float* q, int64_t Bq, const float* cand, int64_t N, int32_t D, int32_t k,
                  int64_t index_base, int32_t init, float* out_scores, int64_t* out_index,
                  float* workspace, int64_t workspace_bytes, dr_stream_t stream);
+/* ------------------------------------------------------------------------------------------
+ * SURVEY.md section 8f rank 4 -- IVF-Flat approximate top-K, the GPU counterpart of the reference's `Faiss` index
+ * (keras/models/retrieval/factorized_top_k.py:337-461: faiss.IndexIVFFlat(faiss.IndexFlatIP(d), d, nlist,
+ * faiss.METRIC_INNER_PRODUCT), `searcher.nprobe = nprobe`, `searcher.search(queries, k)`).
+ *   dr_ivf_pack: builds the index storage.  `order` = candidate numbers grouped by list (list l = order[list_start[l] ..
+ *                list_start[l+1])), `blk_off[l]` = first 64-vector block of list l (lists padded to whole blocks),
+ *                packed[(blk*D + d)*64 + lane] = component d of the vector in slot (blk, lane), packed_ids its identifier
+ *                (ids[src] or src; -1 in padding slots).
+ *   dr_ivf_scan: probes[q, 0..nprobe) = lists to scan for query q (any negative entry is skipped); exact inner products
+ *                over those lists, top k (score descending, ties by identifier ascending); slots that find fewer than k
+ *                vectors keep score -inf / index -1 (faiss returns -1 labels there too).
+ * ---------------------------------------------------------------------------------------- */
+int dr_ivf_pack(const float* cand, int64_t N, int32_t D, const int64_t* order, const int64_t* list_start,
+                const int64_t* blk_off, int32_t nlist, int64_t total_blocks, const int64_t* ids, float* packed,
+                int64_t* packed_ids, dr_stream_t stream);
+int dr_ivf_scan(const float* q, int64_t Bq, int32_t D, const int64_t* probes, int32_t nprobe,
+                const int64_t* blk_off, const float* packed, const int64_t* packed_ids, int32_t k,
+                float* out_scores, int64_t* out_index, dr_stream_t stream);
 int dr_topk_merge(const float* sa, const int64_t* ia, int32_t ka, const float* sb, const int64_t* ib,
                   int32_t kb, int64_t Bq, int32_t k, float* out_scores, int64_t* out_index,
                   dr_stream_t stream);

@@ -472,6 +472,30 @@ def streaming_top_k(queries, candidate_batches, identifier_batches=None, k=10, h
     return state_s, state_i
 
 
+def ivf_flat_search(queries, candidates, identifiers, centroids, assignments, nprobe, k):
+    """IVF-Flat with inner product (the reference's `Faiss` index, factorized_top_k.py:337-461 -> faiss.IndexIVFFlat with
+    METRIC_INNER_PRODUCT and `nprobe`), restated from faiss' published algorithm: probe the `nprobe` lists whose centroids
+    have the largest inner product with the query, score their members exactly, keep the top k (score descending, ties by
+    identifier ascending); missing results are (-inf, -1).  `centroids` / `assignments` are inputs: training is not part
+    of the search semantics."""
+    q = np.asarray(queries, np.float32)
+    c = np.asarray(candidates, np.float32)
+    ids = np.arange(c.shape[0], dtype=np.int64) if identifiers is None else np.asarray(identifiers, np.int64)
+    cs = q.astype(np.float64) @ np.asarray(centroids, np.float64).T
+    out_s = np.full((q.shape[0], k), -np.inf, np.float32)
+    out_i = np.full((q.shape[0], k), -1, np.int64)
+    for r in range(q.shape[0]):
+        order = np.lexsort((np.arange(cs.shape[1]), -cs[r]))[:nprobe]
+        members = np.nonzero(np.isin(assignments, order))[0]
+        if members.size == 0:
+            continue
+        sc = (c[members].astype(np.float64) @ q[r].astype(np.float64)).astype(np.float32)
+        best = np.lexsort((ids[members], -sc))[:k]
+        out_s[r, :best.size] = sc[best]
+        out_i[r, :best.size] = ids[members][best]
+    return out_s, out_i
+
+
 def in_top_k(targets, predictions, k):
     """[TF] B14: target in top-k iff fewer than k entries are strictly greater than its score."""
     predictions = np.asarray(predictions)

@@ -81,6 +81,69 @@ def test_topk_mips_matches_oracle_large_and_ties():
         ops.topk_mips(torch.tensor(q).cuda(), torch.tensor(cand[:5]).cuda(), 10)
 
 
+def test_faiss_ivf_flat_index():
+    """the `Faiss` (IVF-Flat, inner product) index.  Pinned like the reference pins it
+    (tests/keras/test_factorized_top_k.py:36-130): exact top-k with nlist=1 on 100 items, save/load self-consistency; plus
+    the IVF semantics against the oracle given the index's own centroids / assignments, exactness at nprobe == nlist,
+    L2-normalisation, identifiers, and the error messages."""
+    from deep_recommenders_amd.keras.models.retrieval import factorized_top_k as ftk
+    rng = np.random.default_rng(42)
+    # --- exact with one list (reference test shape: 100 candidates, D=4, k=10) ---
+    cand = rng.standard_normal((100, 4)).astype(np.float32)
+    q = rng.standard_normal((16, 4)).astype(np.float32)
+    idx = ftk.Faiss(k=10, nlist=1).index(torch.tensor(cand))
+    s, i = idx(torch.tensor(q))
+    want_s, want_i = O.brute_force_top_k(q, cand, None, 10)
+    np.testing.assert_allclose(s.cpu().numpy(), want_s, rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(i.cpu().numpy(), want_i)
+    # --- IVF semantics: nlist=16, nprobe=4 ---
+    N, D, Bq, k = 5000, 32, 64, 20
+    cand = rng.standard_normal((N, D)).astype(np.float32)
+    ids = rng.permutation(10 * N)[:N].astype(np.int64)
+    q = rng.standard_normal((Bq, D)).astype(np.float32)
+    ivf = ftk.Faiss(k=k, nlist=16, nprobe=4).index(torch.tensor(cand), torch.tensor(ids))
+    s, i = ivf(torch.tensor(q))
+    cen = ivf._centroids.cpu().numpy()
+    asg = ivf._assignments.cpu().numpy()
+    assert cen.shape == (16, D) and np.bincount(asg, minlength=16).min() > 0
+    np.testing.assert_array_equal(asg, np.argmax(cand.astype(np.float64) @ cen.astype(np.float64).T, axis=1))
+    want_s, want_i = O.ivf_flat_search(q, cand, ids, cen, asg, 4, k)
+    np.testing.assert_allclose(s.cpu().numpy(), want_s, rtol=1e-5, atol=1e-5)
+    assert (i.cpu().numpy() == want_i).mean() > 0.999                      # fp32 near-ties may swap neighbours
+    exact_s, _ = O.brute_force_top_k(q, cand, ids, k)
+    recall = np.mean([len(set(i.cpu().numpy()[r]) & set(O.brute_force_top_k(q[r:r + 1], cand, ids, k)[1][0])) / k for r in range(Bq)])
+    assert 0.3 < recall <= 1.0                                               # 4 of 16 lists of isotropic data: approximate
+    # --- probing every list is exact ---
+    s_all, i_all = ftk.Faiss(k=k, nlist=16, nprobe=16).index(torch.tensor(cand), torch.tensor(ids))(torch.tensor(q))
+    np.testing.assert_allclose(s_all.cpu().numpy(), exact_s, rtol=1e-5, atol=1e-5)
+    # --- save / load self-consistency (state travels with the module) ---
+    clone = ftk.Faiss(k=k, nlist=16, nprobe=4)
+    state = ivf.state_dict()
+    for name in ("_centroids", "_packed", "_packed_ids", "_blk_off"):
+        setattr(clone, name, state[name].clone())
+    s2, i2 = clone(torch.tensor(q))
+    assert torch.equal(s, s2) and torch.equal(i, i2)
+    # --- cosine (normalize=True) and k override ---
+    cos = ftk.Faiss(k=5, nlist=1, normalize=True).index(torch.tensor(cand))
+    sc, ic = cos(torch.tensor(q), k=3)
+    cn = cand / np.linalg.norm(cand, axis=1, keepdims=True)
+    qn = q / np.linalg.norm(q, axis=1, keepdims=True)
+    w_s, w_i = O.brute_force_top_k(qn, cn, None, 3)
+    np.testing.assert_allclose(sc.cpu().numpy(), w_s, rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(ic.cpu().numpy(), w_i)
+    # --- fewer members than k in the probed lists -> (-inf, -1) tail, like faiss' -1 labels ---
+    tiny = ftk.Faiss(k=8, nlist=4, nprobe=1).index(torch.tensor(cand[:12]))
+    st, it = tiny(torch.tensor(q[:4]))
+    assert (it.cpu().numpy() == -1).any() and np.isneginf(st.cpu().numpy()[it.cpu().numpy() == -1]).all()
+    # --- error surface ---
+    with pytest.raises(ValueError, match="must be called first"):
+        ftk.Faiss()(torch.tensor(q))
+    with pytest.raises(ValueError, match="ndim should be 2"):
+        ftk.Faiss().index(torch.zeros(5))
+    with pytest.raises(ValueError, match="Queries must be a tensor"):
+        idx({"a": torch.tensor(q)})
+
+
 def test_streaming_and_bruteforce_api():
     from deep_recommenders_amd.keras.models.retrieval import factorized_top_k as ftk
     rng = np.random.default_rng(6)

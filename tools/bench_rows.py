@@ -84,5 +84,21 @@ t2 = timeit(lambda: ops.scores_nt(q, corpus[:chunk], out=wsb[:Bq * chunk].view(B
 res["  of which one chunk of scores (%d candidates)" % chunk] = {"ms": t2 * 1e3, "TF/s": 2.0 * Bq * chunk * D / t2 / 1e12}
 t3 = timeit(lambda: ops.topk_select(wsb[:Bq * chunk].view(Bq, chunk), k, 0, False, state), iters=3, warm=1)
 res["  of which one chunk of selection (steady state)"] = {"ms": t3 * 1e3, "GB/s": Bq * chunk * 4 / t3 / 1e9}
+# IVF-Flat approximate search on the same corpus: build once, then time the search and measure recall
+import time
+from deep_recommenders_amd.keras.models.retrieval import factorized_top_k as ftk
+for nlist, nprobe in ((1024, 8), (1024, 32)):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ivf = ftk.Faiss(k=k, nlist=nlist, nprobe=nprobe).index(corpus)
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    t = timeit(lambda: ivf(q), iters=3, warm=1)
+    _, got = ivf(q)
+    exact = state[1]
+    hit = (got[:256, :, None] == exact[:256, None, :]).any(-1).float().mean().item()
+    scanned = Bq * nprobe * (N / nlist)
+    res["ivf_flat_8192q_x_1M_x128_k100 nlist=%d nprobe=%d" % (nlist, nprobe)] = {
+        "ms": t * 1e3, "recall@100_vs_exact": hit, "build_s": build_s, "scan_GB/s": scanned * D * 4 / t / 1e9}
 for kname, v in res.items():
     print("ROWS", kname, json.dumps({a: round(b, 4) for a, b in v.items()}))
