@@ -177,7 +177,7 @@ def main():
     traffic = {}
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-        name_map = {"emb_pool_fwd": "emb_pool_fwd_sv_kernel<16,8>", "emb_pool_bwd": "emb_bwd_unique_kernel<16,4>",
+        name_map = {"emb_pool_fwd": "emb_pool_fwd_sv_kernel<16,8>", "emb_pool_bwd": "emb_bwd_unique_kernel<16,4,false>",
                     "hash_bucket_i64": "hash_bucket_i64_kernel",
                     "linear_fwd_L0": "gemm_f32_mfma_kernel<true,false,0,false>",
                     "linear_bwd_dx_L0": "gemm_f32_mfma_kernel<true,true,2,false>",
