@@ -337,6 +337,7 @@ class ShardedDeepFMEngine:
         self._events = None
         self._route = None
         self._done = []
+        self._comm_synced = False
 
     # ---- per-phase HIP events (same contract as engine.DeepFMEngine) -------------------------------------------
     def enable_kernel_events(self, on: bool):
@@ -396,8 +397,12 @@ class ShardedDeepFMEngine:
         comm_ctx = (lambda: torch.cuda.stream(self.comm)) if cuda else _NullCtx
         # ---- steps 4-5 for every micro-batch, back to back on the communication stream ---------------------------
         got, ev_rows = [], []
-        if cuda:
-            self.comm.wait_stream(main)       # tables / weights of the previous step are final (K4 ran on comm; belt and braces)
+        if cuda and not self._comm_synced:
+            # once: the tables were initialised on the construction stream.  Afterwards the gathers depend only on the
+            # owner-side updates, which run on the communication stream itself (in order) -- NOT on the training stream, so
+            # the next step's first row fetch may start while this step's wgrad / all-reduce are still running.
+            self.comm.wait_stream(main)
+            self._comm_synced = True
         with comm_ctx():
             for m in range(M):
                 got.append(self._k("emb_fetch(gather+a2a rows)", "xgmi", Bm * F * (4 * D + 4),
