@@ -117,25 +117,16 @@ class DeepFMEngine:
         self.ws = torch.empty(1024, **f32)
         self._events = None      # name -> [bound, work, [(start, end), ...]]
         # ---- deterministic backward: slots sorted by table row on a side stream (depends only on ids) ----
+        # Schedule experiments and their outcomes are recorded in DESIGN.md section 3 (sort started with K3 / in the backward /
+        # on a high-priority stream, K4 overlapped with the first-layer wgrad, FM gradient folded into the dgrad epilogue):
+        # what remains here is the best measured schedule plus DR_SORT_INLINE=1 (sort on the training stream, for profiling).
         self.sorted_bwd = sorted_bwd
         self.sort_inline = _os.environ.get("DR_SORT_INLINE", "0") == "1"
-        self.fold_fm = _os.environ.get("DR_FOLD_FM", "0") == "1"
-        # optional: main pipeline on a high-priority stream (measured neutral-to-worse vs the side-stream sort: 2.89 vs 2.82 ms)
-        self.main = torch.cuda.Stream(device=device, priority=-1) if _os.environ.get("DR_HIPRIO", "0") == "1" else None
-        # K4 (HBM-bound scatter) needs only dx_L0; dw_L0 (MFMA-bound) is independent of it: they can run concurrently.
-        # Measured: a win (2.59 -> 2.53 ms) before K4 was fixed, neutral-to-worse after (2.35 vs 2.39 ms) -> off by default.
-        # where the side-stream sort starts: 'bwd' = before the first-layer dgrad (hidden under dx_L0 / dw_L0)
-        self.sort_at = _os.environ.get("DR_SORT_AT", "fwd")
-        self.overlap_k4 = sorted_bwd and _os.environ.get("DR_OVERLAP_K4", "0") == "1"
         if sorted_bwd:
-            n = B * F
-            self.plan = ops.SortPlan(n, device)
-            self.side = torch.cuda.Stream(device=device, priority=-1 if _os.environ.get("DR_SORT_HIPRIO", "0") == "1" else 0)
+            self.plan = ops.SortPlan(B * F, device)
+            self.side = torch.cuda.Stream(device=device)
             self.ev_ids = torch.cuda.Event()
             self.ev_sorted = torch.cuda.Event()
-            self.scatter = torch.cuda.Stream(device=device, priority=-1 if _os.environ.get("DR_SCATTER_HIPRIO", "0") == "1" else 0)
-            self.ev_dx0 = torch.cuda.Event()
-            self.ev_k4 = torch.cuda.Event()
 
     # ---- per-kernel HIP events on the launch stream (bench.py's roofline numbers) ----------------------
     def enable_kernel_events(self, on: bool):
@@ -169,8 +160,6 @@ class DeepFMEngine:
             self.flat_grads.zero_()          # the fused head already writes Dense(1) gradients during the forward
         self._k("hash_bucket_i64", "hbm", B * F * 16,
                 lambda: ops.hash_bucket_i64(keys, self.col_buckets, out=self.ids))                    # K1
-        if self.sorted_bwd and not self.sort_inline and self.sort_at == "hash":
-            self._launch_sort()
         if self.sorted_bwd and self.sort_inline:
             self._k("emb_sort_slots", "hbm", B * F * 36,
                     lambda: ops.emb_sort_slots(self.ids, self.row_base, self.R, self.plan))
@@ -179,8 +168,8 @@ class DeepFMEngine:
                 lambda: ops.emb_pool_fwd(self.ids, F, None, self.row_base, self.table, self.lin_w, self.lin_bias,
                                          ld_concat=self.ld, concat=self.concat, sum_x=self.sum_x,
                                          fm_logit=self.fm_logit))
-        if self.sorted_bwd and not self.sort_inline and self.sort_at == "fwd":
-            self._launch_sort()
+        if self.sorted_bwd and not self.sort_inline:
+            self._launch_sort()              # after K3: shares the machine with the MFMA-bound first GEMM, not with the gather
         if self.Nd:
             self.concat[:, F * D:F * D + self.Nd].copy_(dense)                         # layout: append dense feats
         x = self.concat[:, :self.in_dim]
@@ -217,13 +206,13 @@ class DeepFMEngine:
         n = len(self.Ws)
         dy = self.d_logit.reshape(-1, 1)                  # d(mean loss)/d logit == pre-activation grad of Dense(1)
         top = n - 1
-        if self._head_done:                               # Dense(1) backward + SGD already done by the fused head
+        if self._head_done:                               # Dense(1) backward + its update already done by the fused head
             top = n - 2
             dy = self.dhs[-1]
         for i in range(top, -1, -1):
             x = self.concat[:, :self.in_dim] if i == 0 else self.hs[i - 1]
             W = self.Ws[i]
-            # dx first (uses the pre-update W), then the fused SGD wgrad
+            dstW, dstb = (self.gWs[i], self.gbs[i]) if adam else (W, self.bs[i])
             fl = 2.0 * self.B * W.shape[0] * W.shape[1]
             if i > 0:
                 dx = self.dhs[i - 1]
@@ -233,51 +222,33 @@ class DeepFMEngine:
                 rs = None
             if i > 0 and self.fuse_narrow and self.narrow_ws[i] is not None:
                 self._k("linear_bwd_narrow_L%d" % i, "hbm", 4.0 * self.B * (2 * W.shape[0] + W.shape[1]),
-                        lambda x=x, dy=dy, W=W, dx=dx, i=i: ops.linear_bwd_narrow(x, dy, W, sc, self.gWs[i] if adam else W,
-                                                                                 self.gbs[i] if adam else self.bs[i], dx,
-                                                                                 relu_mask=True, workspace=self.narrow_ws[i]))
+                        lambda x=x, dy=dy, W=W, dx=dx, i=i, dstW=dstW, dstb=dstb: ops.linear_bwd_narrow(
+                            x, dy, W, sc, dstW, dstb, dx, relu_mask=True, workspace=self.narrow_ws[i]))
                 dy = dx
                 continue
-            if i == 0 and self.sorted_bwd and not self.sort_inline and self.sort_at != "fwd":
-                self._launch_sort()
-            if i == 0 and self.sorted_bwd and self.fold_fm:   # FM gradient folded into the dgrad epilogue (measured: slower)
-                self._k("linear_bwd_dx_L0", "mfma", fl,
-                        lambda dy=dy, W=W, dx=dx: ops.linear_bwd_dx_fm(dy, W, self.d_logit, self.sum_x, self.concat, D,
-                                                                       F * D, dx))
-            else:
-                self._k("linear_bwd_dx_L%d" % i, "mfma", fl,
-                        lambda dy=dy, W=W, rs=rs, dx=dx: ops.linear_bwd_dx(dy, W, relu_src=rs, out=dx))
-            if i == 0 and self.overlap_k4 and not adam:
-                cur = torch.cuda.current_stream()
-                self.ev_dx0.record(cur)
-                with torch.cuda.stream(self.scatter):
-                    self.scatter.wait_event(self.ev_dx0)
-                    self.scatter.wait_event(self.ev_sorted)
-                    self._k("emb_pool_bwd(scatter stream, overlaps linear_bwd_dw_L0)", "overlap", self.alg_bytes_bwd(),
-                            lambda: self._k4_sorted())
-                    self.ev_k4.record(self.scatter)
+            # dx first (uses the pre-update W), then the wgrad (with the fused SGD step unless Adam)
+            self._k("linear_bwd_dx_L%d" % i, "mfma", fl,
+                    lambda dy=dy, W=W, rs=rs, dx=dx: ops.linear_bwd_dx(dy, W, relu_src=rs, out=dx))
             self._k("linear_bwd_dw_L%d" % i, "mfma", fl,
-                    lambda x=x, dy=dy, W=W, i=i: ops.linear_bwd_dw(x, dy, sc, self.gWs[i] if adam else W,
-                                                                   self.gbs[i] if adam else self.bs[i], workspace=self.dw_ws[i]))
+                    lambda x=x, dy=dy, i=i, dstW=dstW, dstb=dstb: ops.linear_bwd_dw(x, dy, sc, dstW, dstb, workspace=self.dw_ws[i]))
             dy = dx
         if adam:
             self._adam_finish()
-            return
-        if self.overlap_k4:
-            torch.cuda.current_stream().wait_event(self.ev_k4)
-            return
-        if self.sorted_bwd:
+        elif self.sorted_bwd:
             torch.cuda.current_stream().wait_event(self.ev_sorted)
-            self._k("emb_pool_bwd", "hbm", self.alg_bytes_bwd(), lambda: self._k4_sorted())            # K4 (sorted)
-            return
-        self._k("emb_pool_bwd", "hbm", self.alg_bytes_bwd(),                                          # K4 (atomics)
-                lambda: ops.emb_pool_bwd(self.ids, F, self.col_start, self.row_base, D, self.d_concat, self.concat,
-                                         self.sum_x, self.d_logit, -lr, self.table, self.lin_w, self.lin_bias))
+            self._k("emb_pool_bwd", "hbm", self.alg_bytes_bwd(),                                      # K4 (sorted)
+                    lambda: ops.emb_pool_bwd_sorted(self.ids, self.row_base, self.plan, D, self.R, self.d_concat, self.d_logit,
+                                                    -lr, self.table, self.lin_w, self.lin_bias, concat=self.concat,
+                                                    sum_x=self.sum_x))
+        else:
+            self._k("emb_pool_bwd", "hbm", self.alg_bytes_bwd(),                                      # K4 (atomics)
+                    lambda: ops.emb_pool_bwd(self.ids, F, self.col_start, self.row_base, D, self.d_concat, self.concat,
+                                             self.sum_x, self.d_logit, -lr, self.table, self.lin_w, self.lin_bias))
 
     def _launch_sort(self):
-        # The sort depends only on ids and is needed only by K4.  It is HBM-bound like K3 and, at low occupancy next to
-        # a GEMM, long (~690 us vs 167 us alone): started with the forward it stretched first K3, then (moved after K3)
-        # the small tail kernels; started here, before the first-layer dgrad, it hides under dx_L0 / dw_L0.
+        """The slot sort depends only on ids and is needed only by K4: it runs on a side stream.  It is HBM-bound like K3 and,
+        squeezed next to a GEMM, long (~660 us vs 167 us alone): started with K3 it stretched K3; started before the first-layer
+        dgrad it crawled to 1.17 ms and K4 waited for it; started after K3 it hides under the first GEMM and the tower tail."""
         self.ev_ids.record()
         with torch.cuda.stream(self.side):
             self.side.wait_event(self.ev_ids)
@@ -300,24 +271,10 @@ class DeepFMEngine:
                 lambda: ops.adam_step(self.flat_params, self.flat_grads, self.flat_m, self.flat_v, lr_t, self.beta1, self.beta2,
                                       self.eps))
 
-    def _k4_sorted(self):
-        return ops.emb_pool_bwd_sorted(self.ids, self.row_base, self.plan, self.D, self.R, self.d_concat, self.d_logit,
-                                       -self.lr, self.table, self.lin_w, self.lin_bias,
-                                       concat=None if self.fold_fm else self.concat,
-                                       sum_x=None if self.fold_fm else self.sum_x)
-
     def train_step(self, keys, dense, labels, next_keys=None):
         # next_keys: accepted for interface parity with ShardedDeepFMEngine (which routes the next batch ahead); unused here
-        if self.main is None:
-            self.forward(keys, dense, labels)
-            self.backward_and_update()
-            return self.loss
-        cur = torch.cuda.current_stream()
-        self.main.wait_stream(cur)
-        with torch.cuda.stream(self.main):
-            self.forward(keys, dense, labels)
-            self.backward_and_update()
-        cur.wait_stream(self.main)
+        self.forward(keys, dense, labels)
+        self.backward_and_update()
         return self.loss
 
     # algorithmic bytes of the two embedding kernels per step
