@@ -138,3 +138,59 @@ def test_topk_full_size_properties():
     assert bool(((sc <= kth + 1e-6) | in_res).all())
     # distinct indices per row
     assert int((torch.sort(idx, dim=1).values[:, 1:] == torch.sort(idx, dim=1).values[:, :-1]).sum()) == 0
+
+
+def test_tower_tail_full_size_consistency():
+    """The fused tower tail at the bench shape (M = 65 536, 256 -> 32 -> 1): dr_tower_head_fwd_bwd and dr_linear_bwd_narrow
+    against the op-by-op path they replace (linear_fwd x2, bce, skinny dx / dw, GEMM dx / dw), both on the GPU, plus
+    invariants that need no reference: probabilities in (0, 1), loss == mean of its own per-example terms, d_logit sums
+    to the bias gradient, masked dx is zero exactly where the ReLU input is zero."""
+    from deep_recommenders_amd import ops
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    M, K, H = 65536, 256, 32
+    lr = 0.01
+    h0 = torch.randn((M, K), device="cuda", generator=g).relu_()
+    W1 = torch.randn((K, H), device="cuda", generator=g) / 16
+    b1 = torch.randn(H, device="cuda", generator=g) * 0.1
+    W2 = (torch.randn((H, 4), device="cuda", generator=g) / 6)[:, :1]
+    b2 = torch.full((1,), 0.03, device="cuda")
+    fm = torch.randn(M, device="cuda", generator=g)
+    z = (torch.rand(M, device="cuda", generator=g) < 0.25).float()
+    # ---- op-by-op path ----
+    W2a, b2a = W2.clone(), b2.clone()
+    W2a_buf = torch.zeros((H, 4), device="cuda")[:, :1]
+    W2a_buf.copy_(W2a)
+    h1 = ops.linear_fwd(h0, W1, b1, 1)
+    h2 = ops.linear_fwd(h1, W2a_buf, b2a, 0)
+    loss_a, prob_a, dlog_a = ops.bce_fwd_bwd(fm, z, 0, logits_b=h2)
+    dh1_a = ops.linear_bwd_dx(dlog_a.reshape(-1, 1), W2a_buf, relu_src=h1)
+    ops.linear_bwd_dw(h1, dlog_a.reshape(-1, 1), -lr, W2a_buf, b2a, workspace=ops.linear_bwd_dw_workspace(M, H, 1, "cuda"))
+    W1a, b1a = W1.clone(), b1.clone()
+    dh0_a = ops.linear_bwd_dx(dh1_a, W1a, relu_src=h0)
+    ops.linear_bwd_dw(h0, dh1_a, -lr, W1a, b1a, workspace=ops.linear_bwd_dw_workspace(M, K, H, "cuda"))
+    # ---- fused path ----
+    W2b_buf = torch.zeros((H, 4), device="cuda")[:, :1]
+    W2b_buf.copy_(W2)
+    b2b = b2.clone()
+    loss_b, prob_b, dlog_b, dh1_b = ops.tower_head_fwd_bwd(h0, W1, b1, W2b_buf, b2b, fm, z, 0, -lr)
+    W1b, b1b = W1.clone(), b1.clone()
+    dh0_b = torch.empty((M, K), device="cuda")
+    ops.linear_bwd_narrow(h0, dh1_b, W1b, -lr, W1b, b1b, dh0_b, relu_mask=True)
+    torch.cuda.synchronize()
+    assert abs(loss_a.item() - loss_b.item()) <= 1e-5 * abs(loss_a.item())
+    torch.testing.assert_close(prob_b, prob_a, rtol=0, atol=2e-6)
+    torch.testing.assert_close(dlog_b * M, dlog_a * M, rtol=0, atol=5e-6)
+    torch.testing.assert_close(dh1_b * M, dh1_a * M, rtol=0, atol=2e-5)
+    torch.testing.assert_close(dh0_b * M, dh0_a * M, rtol=0, atol=1e-4)
+    torch.testing.assert_close(W2b_buf, W2a_buf, rtol=0, atol=1e-6)
+    torch.testing.assert_close(b2b, b2a, rtol=0, atol=1e-6)
+    torch.testing.assert_close(W1b, W1a, rtol=0, atol=1e-6)
+    torch.testing.assert_close(b1b, b1a, rtol=0, atol=1e-6)
+    # ---- invariants ----
+    assert float(prob_b.min()) > 0 and float(prob_b.max()) < 1
+    x = fm.double() + (h1.double() @ W2.double()).reshape(-1) + 0.03
+    terms = torch.clamp(x, min=0) - x * z.double() + torch.log1p(torch.exp(-x.abs()))
+    assert abs(terms.mean().item() - loss_b.item()) <= 1e-5 * abs(loss_b.item())
+    assert abs((b2b - b2).item() - (-lr) * dlog_b.double().sum().item()) < 1e-6
+    assert float(dh0_b[h0 == 0].abs().max()) == 0.0
