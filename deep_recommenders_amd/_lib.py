@@ -72,6 +72,7 @@ SIGNATURES = {
     "dr_exclude_adjust": [_p, _p, _i64, _i32, _p, _i32, _p, _p],
     "dr_logits_adjust": [_p, _p, _i64, _i32, _p, _p, _f32, _p, _p],
     "dr_softmax_ce_rows": [_p, _p, _i64, _i32, _f32, _p, _p, _p, _p],
+    "dr_softmax_ce_rows_bwd": [_p, _p, _i64, _i32, _f32, _p, _f32, _p, _p, _i64, _p],
     "dr_version": [],
 }
 _RESTYPE = {"dr_version": ctypes.c_char_p, "dr_shard_bucket_workspace_bytes": ctypes.c_int64,

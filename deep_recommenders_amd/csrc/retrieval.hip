@@ -377,6 +377,47 @@ extern "C" int dr_logits_adjust(const float* logits, const float* labels, int64_
     return DR_OK;
 }
 
+// d(row loss)/d logits of softmax_ce_rows_kernel, scaled by d_loss:  g[r][j] = w_r * inv_t * d_loss * (y1_r * softmax_j - y_j).
+// cols == NULL: written densely to out[r * ld_out + j]; cols given ([B, C] column numbers, the hard-negative selection):
+// scattered to out[r * ld_out + cols[r][j]] (out pre-zeroed by the caller).
+__global__ __launch_bounds__(256) void softmax_ce_rows_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
+                                                                  int64_t B, int32_t C, float inv_t, const float* __restrict__ w,
+                                                                  float d_loss, const int64_t* __restrict__ cols,
+                                                                  float* __restrict__ out, int64_t ld_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < B; r += nw) {
+        float m = -INFINITY;
+        for (int j = lane; j < C; j += 64) m = fmaxf(m, logits[r * C + j] * inv_t);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        float l = 0.f, y1 = 0.f;
+        for (int j = lane; j < C; j += 64) {
+            l += expf(logits[r * C + j] * inv_t - m);
+            y1 += labels[r * C + j];
+        }
+        l = dr_wave_sum(l); y1 = dr_wave_sum(y1);
+        const float k = (w != nullptr ? w[r] : 1.f) * inv_t * d_loss, inv_l = 1.f / l;
+        for (int j = lane; j < C; j += 64) {
+            const float g = k * (y1 * expf(logits[r * C + j] * inv_t - m) * inv_l - labels[r * C + j]);
+            const int64_t col = cols != nullptr ? cols[r * C + j] : j;
+            out[r * ld_out + col] = g;
+        }
+    }
+}
+
+extern "C" int dr_softmax_ce_rows_bwd(const float* logits, const float* labels, int64_t B, int32_t C, float inv_temperature,
+                                      const float* sample_weight, float d_loss, const int64_t* cols, float* out, int64_t ld_out,
+                                      dr_stream_t stream) {
+    if (B <= 0 || C <= 0 || ld_out <= 0) return DR_EINVAL;
+    if (!logits || !labels || !out) return DR_EINVAL;
+    if (cols == nullptr && ld_out < C) return DR_EINVAL;
+    hipLaunchKernelGGL(softmax_ce_rows_bwd_kernel, dim3(dr_grid_for(B, 4)), dim3(256), 0, dr_s(stream), logits, labels, B, C,
+                       inv_temperature, sample_weight, d_loss, cols, out, ld_out);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
 extern "C" int dr_softmax_ce_rows(const float* logits, const float* labels, int64_t B, int32_t C, float inv_temperature,
                                   const float* sample_weight, float* row_loss, float* loss_out, dr_stream_t stream) {
     if (B <= 0 || C <= 0) return DR_EINVAL;

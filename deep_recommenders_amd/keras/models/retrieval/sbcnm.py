@@ -86,6 +86,41 @@ class _InBatchSoftmaxFn(torch.autograd.Function):
         return dq, dc, None, None, None, None
 
 
+class _HardNegativeSoftmaxFn(torch.autograd.Function):
+    """num_hard_negatives branch (sbcnm.py:145-151): scores -> corrections -> top-(h+1) by `logits + labels * MAX_FLOAT`
+    -> CCE(from_logits, SUM).  The selection is piecewise constant, so the gradient flows only through the kept scores:
+    G = scatter(softmax-CE gradient of the kept columns) into a zero [B, B] matrix, dq = G c, dc = G^T q."""
+
+    @staticmethod
+    def forward(ctx, q, c, sample_weight, cand_prob, cand_ids, inv_t, num_hard_negatives):
+        scores = ops.scores_nt(q, c).contiguous()
+        B = scores.shape[0]
+        labels = torch.eye(B, device=scores.device)
+        if cand_prob is not None or cand_ids is not None:
+            scores = ops.logits_adjust(scores, labels, cand_prob=cand_prob, cand_ids=cand_ids)
+        num_sampled = min(num_hard_negatives + 1, scores.shape[1])
+        boosted = ops.logits_adjust(scores, labels, add_label_scale=MAX_FLOAT)       # logits + labels * MAX_FLOAT (:44)
+        _, indices = ops.topk_select(boosted, num_sampled)
+        s_sel = _gather_elements_along_row(scores, indices)
+        l_sel = _gather_elements_along_row(labels, indices)
+        ctx.inv_t = inv_t
+        ctx.save_for_backward(q, c, s_sel, l_sel, indices, sample_weight)
+        return ops.softmax_ce_rows(s_sel, l_sel, inv_t, sample_weight)              # :148-151
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        q, c, s_sel, l_sel, indices, w = ctx.saved_tensors
+        B = q.shape[0]
+        G = torch.zeros((B, c.shape[0]), dtype=torch.float32, device=q.device)
+        ops.softmax_ce_rows_bwd(s_sel, l_sel, ctx.inv_t, w, float(d_loss), cols=indices, out=G)
+        dq = ops.linear_fwd(G, c) if ctx.needs_input_grad[0] else None              # dq = G @ c
+        dc = None
+        if ctx.needs_input_grad[1]:
+            dc = torch.zeros_like(c)
+            ops.linear_bwd_dw(G, q, 1.0, dc)                                          # dc = G^T @ q
+        return dq, dc, None, None, None, None, None
+
+
 class Retrieval(nn.Module):
     """Retrieval(loss=None, metrics=None, temperature=None, num_hard_negatives=None).call(query_embeddings,
     candidate_embeddings, sample_weight=None, candidate_sampling_probability=None, candidate_ids=None,
@@ -130,11 +165,4 @@ class Retrieval(nn.Module):
     forward = call
 
     def _hard_negative_loss(self, q, c, w, cp, ci, inv_t):
-        """num_hard_negatives branch (:145-146): explicit scores -> corrections -> top-(h+1) -> CCE (forward only)."""
-        scores = ops.scores_nt(q, c).contiguous()
-        B = scores.shape[0]
-        labels = torch.eye(B, device=scores.device)
-        if cp is not None or ci is not None:
-            scores = ops.logits_adjust(scores, labels, cand_prob=cp, cand_ids=ci)
-        s_sel, l_sel = HardNegativeMining(self._num_hard_negatives)(scores, labels)
-        return ops.softmax_ce_rows(s_sel, l_sel, inv_t, w)                               # :148-151
+        return _HardNegativeSoftmaxFn.apply(q, c, w, cp, ci, inv_t, int(self._num_hard_negatives))

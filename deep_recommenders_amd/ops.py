@@ -679,6 +679,19 @@ def softmax_ce_rows(logits, labels, inv_temperature=1.0, sample_weight=None):
     return loss.reshape(())
 
 
+def softmax_ce_rows_bwd(logits, labels, inv_temperature, sample_weight, d_loss, cols=None, out=None):
+    """gradient of softmax_ce_rows w.r.t. logits; with `cols` scattered into the pre-zeroed matrix `out`."""
+    logits = _c(logits, torch.float32)
+    labels = _c(labels, torch.float32)
+    B, C = logits.shape
+    if out is None:
+        out = torch.empty((B, C), dtype=torch.float32, device=logits.device)
+    check(lib().dr_softmax_ce_rows_bwd(ptr(logits), ptr(labels), B, C, float(inv_temperature), ptr(sample_weight), float(d_loss),
+                                       ptr(_c(cols, torch.int64)) if cols is not None else None, ptr(out), out.stride(0),
+                                       stream_ptr()), "dr_softmax_ce_rows_bwd")
+    return out
+
+
 def emb_pack_grads(pos, D, d_concat, concat, sum_x, d_fm_logit, out_rows, out_lin=None, bias_sum=None):
     pos = _c(pos, torch.int64)
     B, F = pos.shape

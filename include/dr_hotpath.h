@@ -384,6 +384,15 @@ int dr_logits_adjust(const float* logits, const float* labels, int64_t B, int32_
 int dr_softmax_ce_rows(const float* logits, const float* labels, int64_t B, int32_t C, float inv_temperature,
                        const float* sample_weight, float* row_loss, float* loss_out, dr_stream_t stream);
 
+/* Backward of dr_softmax_ce_rows: g[r][j] = w_r * inv_temperature * d_loss * (sum_j(labels) * softmax_j - labels[r][j]).
+ * cols == NULL: out is [B, >= C] dense.  cols [B, C] (the columns HardNegativeMining kept, sbcnm.py:41-49 of the reference):
+ * the gradient is scattered to out[r][cols[r][j]] of a pre-zeroed [B, ld_out] score-gradient matrix, from which
+ * dq = G c and dc = G^T q follow as in the default path. */
+int dr_softmax_ce_rows_bwd(const float* logits, const float* labels, int64_t B, int32_t C,
+                           float inv_temperature, const float* sample_weight, float d_loss,
+                           const int64_t* cols, float* out, int64_t ld_out, dr_stream_t stream);
+
+
 /* ------------------------------------------------------------------------------------------
  * Row-sharded tables over N ranks (new design — the reference is single-process; the
  * exchange mirrors no reference code).  owner(id) = id % world; on the owner, field f's shard holds
