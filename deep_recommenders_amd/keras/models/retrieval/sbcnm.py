@@ -86,6 +86,26 @@ class _InBatchSoftmaxFn(torch.autograd.Function):
         return dq, dc, None, None, None, None
 
 
+class _ScoresFn(torch.autograd.Function):
+    """scores = q c^T as an explicit [B, B] matrix with the MFMA GEMMs in both directions (for user-supplied losses)."""
+
+    @staticmethod
+    def forward(ctx, q, c):
+        ctx.save_for_backward(q, c)
+        return ops.scores_nt(q, c).contiguous()
+
+    @staticmethod
+    def backward(ctx, G):
+        q, c = ctx.saved_tensors
+        G = G.contiguous()
+        dq = ops.linear_fwd(G, c) if ctx.needs_input_grad[0] else None
+        dc = None
+        if ctx.needs_input_grad[1]:
+            dc = torch.zeros_like(c)
+            ops.linear_bwd_dw(G, q, 1.0, dc)
+        return dq, dc
+
+
 class _HardNegativeSoftmaxFn(torch.autograd.Function):
     """num_hard_negatives branch (sbcnm.py:145-151): scores -> corrections -> top-(h+1) by `logits + labels * MAX_FLOAT`
     -> CCE(from_logits, SUM).  The selection is piecewise constant, so the gradient flows only through the kept scores:
@@ -129,9 +149,9 @@ class Retrieval(nn.Module):
     def __init__(self, loss=None, metrics: Optional[FactorizedTopK] = None, temperature: Optional[float] = None,
                  num_hard_negatives: Optional[int] = None, **kwargs):
         super().__init__()
-        if loss is not None:
-            raise NotImplementedError("only the default CategoricalCrossentropy(from_logits=True, reduction=SUM) loss "
-                                      "(sbcnm.py:100-102) is fused")
+        # loss=None: CategoricalCrossentropy(from_logits=True, reduction=SUM) (sbcnm.py:100-102), fused.  Any other loss is a
+        # callable loss(y_true=labels, y_pred=scores, sample_weight=...) on torch tensors, evaluated on the explicit score matrix.
+        self._loss = loss
         self._factorized_metrics = metrics
         self._temperature = temperature
         self._num_hard_negatives = num_hard_negatives
@@ -153,7 +173,9 @@ class Retrieval(nn.Module):
             if candidate_sampling_probability is not None else None
         ci = _dev(candidate_ids, torch.int64).reshape(-1).contiguous() if candidate_ids is not None else None
         inv_t = 1.0 / self._temperature if self._temperature is not None else 1.0       # :148-149
-        if self._num_hard_negatives is None:
+        if self._loss is not None:
+            loss = self._custom_loss(q, c, w, cp, ci, inv_t)
+        elif self._num_hard_negatives is None:
             loss = _InBatchSoftmaxFn.apply(q, c, w, cp, ci, inv_t)                       # :129-151 fused
         else:
             loss = self._hard_negative_loss(q, c, w, cp, ci, inv_t)
@@ -163,6 +185,24 @@ class Retrieval(nn.Module):
         return loss
 
     forward = call
+
+    def _custom_loss(self, q, c, w, cp, ci, inv_t):
+        """user-supplied loss object (sbcnm.py:100-103,151): the call sequence of :129-151 on an explicit score matrix."""
+        scores = _ScoresFn.apply(q, c)
+        B = scores.shape[0]
+        labels = torch.eye(B, scores.shape[1], device=scores.device)
+        if cp is not None:
+            scores = scores - torch.log(cp)[None, :]                                          # :78-86
+        if ci is not None:
+            ident = ci.reshape(-1, 1)
+            dup = (ident[:B] == ident.t()).to(scores.dtype) - labels                         # :66-73
+            scores = scores + dup * MIN_FLOAT
+        if self._num_hard_negatives is not None:
+            k = min(self._num_hard_negatives + 1, scores.shape[1])
+            idx = torch.topk(scores.detach() + labels * MAX_FLOAT, k, dim=1).indices          # :41-44
+            scores, labels = torch.gather(scores, 1, idx), torch.gather(labels, 1, idx)
+        scores = scores * inv_t
+        return self._loss(y_true=labels, y_pred=scores, sample_weight=w)
 
     def _hard_negative_loss(self, q, c, w, cp, ci, inv_t):
         return _HardNegativeSoftmaxFn.apply(q, c, w, cp, ci, inv_t, int(self._num_hard_negatives))
