@@ -491,3 +491,38 @@ extern "C" int dr_adam_step(float* param, const float* grad, float* m, float* v,
     DR_CHECK_LAUNCH();
     return DR_OK;
 }
+
+__global__ __launch_bounds__(256) void ftrl_step_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ accum, float* __restrict__ linear, int64_t n,
+                                                        float lr, float lr_power, float l1, float l2, float gscale) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float gi = g[i] * gscale, a0 = accum[i], w = p[i];
+        const float a1 = a0 + gi * gi;
+        // accum^(-lr_power); lr_power = -0.5 (the default) is a square root
+        const float pa0 = lr_power == -0.5f ? sqrtf(a0) : powf(a0, -lr_power);
+        const float pa1 = lr_power == -0.5f ? sqrtf(a1) : powf(a1, -lr_power);
+        const float lin = linear[i] + gi - (pa1 - pa0) / lr * w;
+        const float quad = pa1 / lr + 2.f * l2;
+        const float sgn = lin > 0.f ? 1.f : (lin < 0.f ? -1.f : 0.f);
+        p[i] = fabsf(lin) > l1 ? (sgn * l1 - lin) / quad : 0.f;
+        accum[i] = a1;
+        linear[i] = lin;
+    }
+}
+
+// Dense FTRL-Proximal step, TensorFlow's formulation (tf.train.FtrlOptimizer, the "wide" optimizer of the reference's
+// examples/train_wdl_on_movielens_estimator.py:66-70: learning_rate 0.01, l1_regularization_strength 0.5; TF defaults
+// learning_rate_power -0.5, initial_accumulator_value 0.1, l2 0, no shrinkage):
+//   accum' = accum + g^2 ;  linear += g - (accum'^-p - accum^-p) / lr * w ;  quad = accum'^-p / lr + 2 l2
+//   w = |linear| > l1 ? (sign(linear) l1 - linear) / quad : 0            (p = learning_rate_power)
+extern "C" int dr_ftrl_step(float* param, const float* grad, float* accum, float* linear, int64_t n, float lr,
+                            float lr_power, float l1, float l2, float grad_scale, dr_stream_t stream) {
+    if (n < 0 || !(lr > 0.f)) return DR_EINVAL;
+    if (n == 0) return DR_OK;
+    if (!param || !grad || !accum || !linear) return DR_EINVAL;
+    hipLaunchKernelGGL(ftrl_step_kernel, dim3(dr_grid_for(n, 256 * 4)), dim3(256), 0, dr_s(stream), param, grad, accum, linear,
+                       n, lr, lr_power, l1, l2, grad_scale);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}

@@ -480,6 +480,15 @@ def adam_step(param, grad, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, grad_sc
                              float(grad_scale), stream_ptr()), "dr_adam_step")
 
 
+def ftrl_step(param, grad, accum, linear, lr, lr_power=-0.5, l1=0.0, l2=0.0, grad_scale=1.0):
+    """Dense FTRL-Proximal step, TensorFlow formulation, over flat fp32 buffers (in place)."""
+    assert param.is_contiguous() and grad.is_contiguous() and accum.is_contiguous() and linear.is_contiguous()
+    n = param.numel()
+    assert grad.numel() == n and accum.numel() == n and linear.numel() == n
+    check(lib().dr_ftrl_step(ptr(param), ptr(grad), ptr(accum), ptr(linear), n, float(lr), float(lr_power), float(l1), float(l2),
+                             float(grad_scale), stream_ptr()), "dr_ftrl_step")
+
+
 def linear_bwd_dx_fm(dy, W, d_fm_logit, sum_x, concat, D, FD, out):
     """First-layer dgrad with the FM second-order gradient folded into the epilogue."""
     dy = _rowmajor_ld4(dy)

@@ -183,6 +183,15 @@ int dr_emb_pool_bwd_sorted_adam(const int64_t* ids, const int64_t* row_base, con
 int dr_adam_step(float* param, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1,
                  float beta2, float eps, float grad_scale, dr_stream_t stream);
 
+/* Dense FTRL-Proximal step in TensorFlow's formulation -- tf.train.FtrlOptimizer(0.01, l1_regularization_strength=0.5), the
+ * optimizer of WDL's wide part in examples/train_wdl_on_movielens_estimator.py:66-70 (TF defaults: learning_rate_power -0.5,
+ * accumulators initialised to 0.1, l2 0):
+ *   accum' = accum + g^2 ;  linear += g - (accum'^-p - accum^-p) / lr * w ;  w = |linear| > l1 ? (sign(linear) l1 - linear) /
+ *   (accum'^-p / lr + 2 l2) : 0.   grad is multiplied by grad_scale first. */
+int dr_ftrl_step(float* param, const float* grad, float* accum, float* linear, int64_t n, float lr,
+                 float lr_power, float l1, float l2, float grad_scale, dr_stream_t stream);
+
+
 
 /* ------------------------------------------------------------------------------------------
  * K6  stand-alone FM second-order term on a caller-provided [B, F, D] tensor

@@ -161,3 +161,15 @@ def adam_rows_step(p, dense_grad, touched_rows, m, v, lr, step, beta1=0.9, beta2
     m[r] = beta1 * m[r] + (1 - beta1) * g
     v[r] = beta2 * v[r] + (1 - beta2) * g * g
     p[r] = p[r] - lr_t * m[r] / (v[r].sqrt() + eps)
+
+
+def ftrl_dense_step(p, g, accum, linear, lr, lr_power=-0.5, l1=0.0, l2=0.0):
+    """tf.train.FtrlOptimizer dense update (the reference's examples/train_wdl_on_movielens_estimator.py:66-70), in place:
+    accum' = accum + g^2; linear += g - (accum'^-p - accum^-p)/lr * w; w = |linear| > l1 ? (sign(linear) l1 - linear) /
+    (accum'^-p / lr + 2 l2) : 0."""
+    a1 = accum + g * g
+    pa0, pa1 = accum.pow(-lr_power), a1.pow(-lr_power)
+    linear.add_(g - (pa1 - pa0) / lr * p)
+    quad = pa1 / lr + 2 * l2
+    p.copy_(torch.where(linear.abs() > l1, (torch.sign(linear) * l1 - linear) / quad, torch.zeros_like(p)))
+    accum.copy_(a1)

@@ -524,6 +524,23 @@ def test_adam_step_dense(ops):
     np.testing.assert_allclose(vd.cpu().numpy(), tv.numpy(), rtol=1e-5, atol=1e-7)
 
 
+def test_ftrl_step_dense(ops):
+    rng = np.random.default_rng(35)
+    n = 50021
+    p = (rng.standard_normal(n) * 0.5).astype(np.float32)
+    pd, ad, ld = _dev(p).clone(), torch.full((n,), 0.1, device="cuda"), torch.zeros(n, device="cuda")
+    tp = torch.tensor(p, dtype=torch.float64)
+    ta, tl = torch.full((n,), 0.1, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
+    for _ in range(4):
+        g = (rng.standard_normal(n) * 2).astype(np.float32)
+        ops.ftrl_step(pd, _dev(g), ad, ld, 0.01, -0.5, 0.5, 0.001)
+        T.ftrl_dense_step(tp, torch.tensor(g, dtype=torch.float64), ta, tl, 0.01, -0.5, 0.5, 0.001)
+    np.testing.assert_allclose(pd.cpu().numpy(), tp.numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(ad.cpu().numpy(), ta.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(ld.cpu().numpy(), tl.numpy(), rtol=1e-4, atol=1e-4)
+    assert 0 < (pd == 0).float().mean().item() < 1                        # the l1 proximal step zeroes some weights
+
+
 def test_linear_bwd_dx_fm_epilogue(ops):
     rng = np.random.default_rng(22)
     M, F, D, Nd, N = 300, 5, 16, 3, 40

@@ -427,6 +427,73 @@ def test_estimator_wdl_and_fnn(tmp_path):
     assert float(fnn.slab.lin_w.grad.abs().sum()) > 0 and float(fnn.slab.table.grad.abs().sum()) > 0
 
 
+def test_wdl_example_training_recipe_ftrl_wide_adam_deep():
+    """examples/train_wdl_on_movielens_estimator.py:60-77 of the reference: log_loss, FtrlOptimizer(0.01, l1=0.5) on the
+    "wide" variables, AdamOptimizer(0.01) on the "deep" variables -- 3 steps with deep_recommenders_amd.optim against a
+    float64 restatement (oracle forward + autograd, T.ftrl_dense_step / T.adam_dense_step)."""
+    from deep_recommenders_amd import feature_column as fc, optim, losses
+    from deep_recommenders_amd.estimator.models.ranking import WDL
+    rng = np.random.default_rng(8)
+    ind, emb = _movielens_columns(fc)
+    torch.manual_seed(11)
+    wdl = WDL(ind, emb, dnn_units=[16, 8])
+    feats, labels = _movielens_batch(rng, 64)
+    wdl(feats)                                                           # materialise the dense variables
+    wide = [wdl.slab.lin_w, wdl.slab.lin_bias]
+    deep = [wdl.slab.table] + [p for p in wdl.store.parameters()]
+    opt_w = optim.Ftrl(wide, 0.01, l1_regularization_strength=0.5)
+    opt_d = optim.Adam(deep, 0.01, epsilon=1e-8)
+    # float64 mirror of every variable and optimizer slot
+    ref = {id(p): p.detach().cpu().double().clone() for p in wide + deep}
+    acc = {id(p): torch.full_like(ref[id(p)], 0.1) for p in wide}
+    lin = {id(p): torch.zeros_like(ref[id(p)]) for p in wide}
+    m = {id(p): torch.zeros_like(ref[id(p)]) for p in deep}
+    v = {id(p): torch.zeros_like(ref[id(p)]) for p in deep}
+    names = sorted(k for k in wdl.store.vars.keys())
+    for step in range(1, 4):
+        feats, labels = _movielens_batch(rng, 64)
+        y = torch.tensor(labels, device="cuda").reshape(-1, 1)
+        opt_w.zero_grad(); opt_d.zero_grad()
+        p = wdl(feats)
+        loss = losses.log_loss(y, p)                                     # :60
+        loss.backward()
+        opt_w.step(); opt_d.step()
+        # ---- restatement ----
+        ids = _oracle_ids(feats)
+        tvars = {k: t.clone().requires_grad_(True) for k, t in ref.items()}
+        tab, lw, lb = tvars[id(wdl.slab.table)], tvars[id(wdl.slab.lin_w)], tvars[id(wdl.slab.lin_bias)]
+        base = [wdl.slab.base[k] for k in KEYS]
+        embs, first = [], lb.clone()
+        for f, idf in enumerate(ids):
+            idt = torch.tensor(idf)
+            mask = (idt >= 0).double()
+            rows = base[f] + idt.clamp(min=0)
+            e = (tab[rows] * mask[..., None]).sum(1) / mask.sum(1).clamp(min=1)[:, None]      # [TF] B5 mean combiner
+            embs.append(e)
+            first = first + (lw[rows] * mask).sum(1)
+        x = torch.cat(embs, dim=1)
+        nl = len(names) // 2
+        for i in range(nl):
+            nm = "dnn__dense" + ("" if i == 0 else "_%d" % i)
+            x = x @ tvars[id(wdl.store.vars[nm + "__kernel"])] + tvars[id(wdl.store.vars[nm + "__bias"])]
+            if i < nl - 1:
+                x = torch.relu(x)
+        prob = torch.sigmoid(first.reshape(-1, 1) + x)
+        lo = T.log_loss(torch.tensor(labels, dtype=torch.float64).reshape(-1, 1), prob)
+        lo.backward()
+        assert abs(loss.item() - lo.item()) <= 1e-5 * abs(lo.item())
+        for pw in wide:
+            T.ftrl_dense_step(ref[id(pw)], tvars[id(pw)].grad, acc[id(pw)], lin[id(pw)], 0.01, -0.5, 0.5, 0.0)
+        for pd in deep:
+            T.adam_dense_step(ref[id(pd)], tvars[id(pd)].grad, m[id(pd)], v[id(pd)], 0.01, step, eps=1e-8)
+    for pw in wide:                                                      # FTRL with l1 = 0.5 keeps tiny weights at exactly 0
+        got, want = pw.detach().cpu().numpy(), ref[id(pw)].numpy()
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-6)
+        assert (got == 0).mean() > 0.5
+    for pd in deep:
+        np.testing.assert_allclose(pd.detach().cpu().numpy(), ref[id(pd)].numpy(), rtol=0, atol=2e-2 * 0.01)
+
+
 def test_tfrecord_batch_through_feature_columns_and_fm(tmp_path):
     """Input side -> hot path: a batch parsed by the native TFRecord / tf.Example reader (bytes features) through the
     reference-shaped feature columns and FM model equals the oracle evaluated on the same strings."""
