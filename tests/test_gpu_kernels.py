@@ -131,11 +131,8 @@ def test_emb_pool_fwd_padded_concat_and_no_fm(ops):
     assert float(concat[:, 80:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("D,Ls,strided", [(16, [1, 1, 3, 1], 1), (64, [1] * 26, 1), (64, [1] * 26, 0), (128, [2, 1], 1),
-                                          (12, [1, 2], 1)])
-def test_emb_pool_bwd_matches_autograd_oracle(ops, D, Ls, strided):
-    from deep_recommenders_amd import _lib
-    _lib.lib().dr_debug_set_bwd_strided(strided)
+@pytest.mark.parametrize("D,Ls", [(16, [1, 1, 3, 1]), (64, [1] * 26), (128, [2, 1]), (12, [1, 2])])
+def test_emb_pool_bwd_matches_autograd_oracle(ops, D, Ls):
     rng = np.random.default_rng(3)
     B = 300
     Vs = [int(v) for v in rng.integers(20, 400, size=len(Ls))]
@@ -156,7 +153,6 @@ def test_emb_pool_bwd_matches_autograd_oracle(ops, D, Ls, strided):
     g_lin = torch.zeros_like(_dev(lin_w))
     ops.emb_pool_bwd(d_ids, F, cs, rb, D, _dev(d_concat), concat, sum_x, _dev(d_fm), 1.0, g_table, g_lin)
     torch.cuda.synchronize()
-    _lib.lib().dr_debug_set_bwd_strided(1)
     gt = tt.grad.numpy()
     np.testing.assert_allclose(g_table.cpu().numpy(), gt, rtol=1e-4, atol=1e-5 * (np.abs(gt).max() + 1))
     np.testing.assert_allclose(g_lin.cpu().numpy(), tl.grad.numpy(), rtol=1e-4, atol=1e-5)

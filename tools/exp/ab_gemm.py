@@ -1,4 +1,4 @@
-"""EXPERIMENT: A/B of the first GEMM kernel (git history) vs the current one, same process, interleaved rounds."""
+"""EXPERIMENT (historical: the dr_debug_set_gemm_variant hook it drove was removed once the result was in DESIGN.md): A/B of the first GEMM kernel (git history) vs the current one, same process, interleaved rounds."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch

@@ -1,4 +1,4 @@
-"""EXPERIMENT: in-process A/B of GEMM variants (dr_debug_set_gemm_variant) on the L0 shapes."""
+"""EXPERIMENT (historical: the dr_debug_set_gemm_variant hook it drove was removed once the result was in DESIGN.md): in-process A/B of GEMM variants (dr_debug_set_gemm_variant) on the L0 shapes."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch

@@ -68,13 +68,8 @@ def main():
             d_concat = torch.randn((B, ld), device=dev, generator=g) * 1e-3
             d_fm = torch.randn((B,), device=dev, generator=g) * 1e-3
             alg = B * (12 * F * D + 16 * F)
-            for strided in (1, 0):
-                _lib.lib().dr_debug_set_bwd_strided(strided)
-                t = timeit(lambda: ops.emb_pool_bwd(ids, F, col_start, row_base, D, d_concat, concat, sum_x, d_fm, -1e-3,
-                                                    table, lin_w))
-                res["emb_pool_bwd_%s_strided%d" % (dist, strided)] = {"us": t * 1e6, "alg_GB/s": alg / t / 1e9,
-                                                                    "frac_of_8TB/s": alg / t / 8e12}
-            _lib.lib().dr_debug_set_bwd_strided(1)
+            t = timeit(lambda: ops.emb_pool_bwd(ids, F, col_start, row_base, D, d_concat, concat, sum_x, d_fm, -1e-3, table, lin_w))
+            res["emb_pool_bwd_atomic_%s" % dist] = {"us": t * 1e6, "alg_GB/s": alg / t / 1e9, "frac_of_8TB/s": alg / t / 8e12}
             NB = 4
             idsl = [ids] + [torch.randint(0, V, (B, F), device=dev, generator=g) for _ in range(NB - 1)] if dist == "uniform" else [ids]
             plan = ops.SortPlan(B * F, dev); fl = plan.flags
@@ -94,30 +89,6 @@ def main():
         t = timeit(lambda: dst.copy_(src))
         res["d2d_copy_256MB"] = {"us": t * 1e6, "GB/s": 2 * src.numel() * 4 / t / 1e9}
         del table, lin_w
-    if "gemmab" in what:
-        L = _lib.lib()
-        for (M, K, N) in [(B, 1677, 256), (B, 1677, 1677)]:
-            ldx = (K + 3) // 4 * 4
-            x = torch.randn((M, ldx), device=dev, generator=g)[:, :K]
-            W = torch.randn((K, N), device=dev, generator=g) / K ** 0.5
-            b = torch.zeros(N, device=dev)
-            y = torch.empty((M, (N + 3) // 4 * 4), device=dev)[:, :N]
-            dy = torch.randn((M, (N + 3) // 4 * 4), device=dev, generator=g)[:, :N]
-            dx = torch.empty((M, ldx), device=dev)[:, :K]
-            dW = torch.zeros((K, N), device=dev)
-            wsd = ops.linear_bwd_dw_workspace(M, K, N, dev)
-            fl = 2.0 * M * K * N
-            for rnd in range(3):
-                for var in (0, 1, 2, 3):
-                    L.dr_debug_set_gemm_variant(var)
-                    wsd = ops.linear_bwd_dw_workspace(M, K, N, dev)
-                    tf = timeit(lambda: ops.linear_fwd(x, W, b, 1, out=y), iters=4, warmup=1)
-                    td = timeit(lambda: ops.linear_bwd_dx(dy, W, x, out=dx), iters=4, warmup=1)
-                    tw = timeit(lambda: ops.linear_bwd_dw(x, dy, 1e-6, dW, b, workspace=wsd), iters=4, warmup=1)
-                    ta = timeit(lambda: ops.linear_bwd_dw(x, dy, 1e-6, dW, b), iters=4, warmup=1)
-                    print("AB %dx%dx%d var=%d round=%d fwd %.1f TF dx %.1f TF dw(ws) %.1f TF dw(atomic) %.1f TF" % (
-                        M, K, N, var, rnd, fl / tf / 1e12, fl / td / 1e12, fl / tw / 1e12, fl / ta / 1e12))
-            L.dr_debug_set_gemm_variant(0)
     if "gemm" in what:
         for (M, K, N) in [(B, 1677, 256), (B, 256, 32), (B, 1677, 1024), (B, 1024, 512), (B, 1677, 1677)]:
             ldx = (K + 3) // 4 * 4
