@@ -339,8 +339,9 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 size_t rocprim_temp_bytes(int64_t n) {
     size_t bytes = 0;
-    rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const int32_t*)nullptr,
-                              (int32_t*)nullptr, (size_t)n, 0u, 64u, (hipStream_t)0);
+    if (rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const int32_t*)nullptr,
+                                  (int32_t*)nullptr, (size_t)n, 0u, 64u, (hipStream_t)0) != hipSuccess)
+        return 0;
     return bytes;
 }
 

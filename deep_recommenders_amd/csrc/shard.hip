@@ -300,8 +300,7 @@ extern "C" int dr_shard_bucket_ids(const int64_t* ids, int64_t n, int32_t C, int
     if (n < 0 || C <= 0 || world <= 0 || world > MAXW || rows_per_shard <= 0) return DR_EINVAL;
     if (!counts) return DR_EINVAL;
     if (n == 0) {
-        hipMemsetAsync(counts, 0, sizeof(int64_t) * world, dr_s(stream));
-        return DR_OK;
+        return hipMemsetAsync(counts, 0, sizeof(int64_t) * world, dr_s(stream)) == hipSuccess ? DR_OK : DR_ELAUNCH;
     }
     if (!ids || !send_rows || !pos || !workspace) return DR_EINVAL;
     const int nblk = (int)((n + CHUNK - 1) / CHUNK);
