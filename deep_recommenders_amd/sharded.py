@@ -58,7 +58,8 @@ class Route:
     """Everything about one batch that depends only on its keys: where each slot's row lives, how many rows travel to /
     from each rank, the owner-side list of requested rows and its sort plan.  Built by ShardedEmbeddingExchange.route()
     on a dedicated stream, possibly one step ahead of its use."""
-    __slots__ = ("pos", "send_splits", "recv_splits", "n", "n_recv", "n_pad", "slot", "ready", "sorted", "key", "has_lin")
+    __slots__ = ("pos", "send_splits", "recv_splits", "n", "n_recv", "n_pad", "slot", "ready", "sorted", "key", "has_lin",
+                 "_send_rows", "_counts_host", "_counts_ev", "_finished")
 
 
 class ShardedEmbeddingExchange:
@@ -112,9 +113,9 @@ class ShardedEmbeddingExchange:
         return need
 
     # ---- steps 1-3 -------------------------------------------------------------------------------------------
-    def route(self, keys, hashed=True, wait_current=True):
-        """keys [B, F] int64 (raw keys if `hashed`, else ids).  Returns a Route; on CUDA the work is queued on the routing
-        stream and `route.ready` / `route.sorted` are events consumers wait on.  wait_current=False: the caller guarantees
+    def route_begin(self, keys, hashed=True, wait_current=True):
+        """First half of routing, never blocks the host: hash, bucket by owner, exchange the split sizes, start their copy to
+        pinned host memory.  keys [B, F] int64 (raw keys if `hashed`, else ids).  wait_current=False: the caller guarantees
         `keys` is already complete (a prefetched batch), so routing does not queue behind the training stream."""
         sl_i = self._next_slot
         self._next_slot = (sl_i + 1) % self.SLOTS
@@ -123,6 +124,7 @@ class ShardedEmbeddingExchange:
         r = Route()
         r.key = (keys.data_ptr(), tuple(keys.shape))
         r.slot = sl_i
+        r._finished = False
         ctx = torch.cuda.stream(self._rs) if self._cuda else _NullCtx()
         if self._cuda and wait_current:
             self._rs.wait_stream(torch.cuda.current_stream())        # keys may have been produced on the caller's stream
@@ -136,17 +138,40 @@ class ShardedEmbeddingExchange:
             else:
                 ids = keys
             B, F = ids.shape
+            r.n = B * F
             counts, send_rows, pos = self.p.shard_bucket_ids(ids, self.rows_per_shard, W)
             recv_counts = torch.empty_like(counts)
             dist.all_to_all_single(recv_counts, counts, group=self.group)                 # split sizes
-            r.send_splits = [int(v) for v in counts.tolist()]              # host sync of THIS stream only
-            r.recv_splits = [int(v) for v in recv_counts.tolist()]
-            r.n, r.n_recv = B * F, sum(r.recv_splits)
-            r.n_pad = self._ensure_capacity(sl, r.n_recv, ids.device)
+            both = torch.stack([counts, recv_counts])
+            if self._cuda:
+                if sl.get("counts_host") is None:
+                    sl["counts_host"] = torch.empty((2, W), dtype=torch.int64).pin_memory()
+                sl["counts_host"].copy_(both, non_blocking=True)
+                r._counts_host = sl["counts_host"]
+                r._counts_ev = torch.cuda.Event()
+                r._counts_ev.record(self._rs)
+            else:
+                r._counts_host, r._counts_ev = both, None
+            r.pos, r._send_rows = pos, send_rows
+        return r
+
+    def route_finish(self, r):
+        """Second half: read the split sizes (a host wait only for route_begin's small kernels), send the row ids to their
+        owners, sort the received list for the owner-side update."""
+        if r._finished:
+            return r
+        sl = self._slots[r.slot]
+        if r._counts_ev is not None:
+            r._counts_ev.synchronize()
+        r.send_splits = [int(v) for v in r._counts_host[0].tolist()]
+        r.recv_splits = [int(v) for v in r._counts_host[1].tolist()]
+        r.n_recv = sum(r.recv_splits)
+        ctx = torch.cuda.stream(self._rs) if self._cuda else _NullCtx()
+        with ctx:
+            r.n_pad = self._ensure_capacity(sl, r.n_recv, r.pos.device)
             rows_pad = sl["rows_pad"][:r.n_pad]
             rows_pad[r.n_recv:].fill_(-1)
-            self._a2a(rows_pad[:r.n_recv], send_rows, r.recv_splits, r.send_splits)      # C1
-            r.pos = pos
+            self._a2a(rows_pad[:r.n_recv], r._send_rows, r.recv_splits, r.send_splits)      # C1
             if self._cuda:
                 r.ready = torch.cuda.Event()
                 r.ready.record(self._rs)
@@ -155,7 +180,13 @@ class ShardedEmbeddingExchange:
             if self._cuda:
                 r.sorted = torch.cuda.Event()
                 r.sorted.record(self._rs)
+        r._send_rows = None
+        r._finished = True
         return r
+
+    def route(self, keys, hashed=True, wait_current=True):
+        """Both halves back to back (a step whose batch was not prefetched)."""
+        return self.route_finish(self.route_begin(keys, hashed=hashed, wait_current=wait_current))
 
     # ---- steps 4-5: owner gather + rows back (communication stream) ---------------------------------------------
     def fetch(self, route, table_local, lin_local):
@@ -343,8 +374,14 @@ class ShardedDeepFMEngine:
     def enable_kernel_events(self, on: bool):
         self._events = {} if (on and self._cuda) else None
 
+    # Phases that get HIP events in bench.py.  The sharded step issues ~3x the launches of the single-GPU step (two
+    # micro-batches, exchanges, routing) and its host thread is the scarcer resource: two event records around every small
+    # kernel were enough to leave ~30 us bubbles between kernels, so only the coarse phases are bracketed.
+    _TIMED = ("emb_fetch", "emb_pool_fwd", "linear_fwd_L0", "linear_bwd_dx_L0", "linear_bwd_dw_L0", "emb_pack_grads",
+              "emb_grads", "allreduce_dense_grads", "emb_route")
+
     def _k(self, name, bound, work, fn):
-        if self._events is None:
+        if self._events is None or not name.startswith(self._TIMED):
             return fn()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
@@ -371,10 +408,17 @@ class ShardedDeepFMEngine:
     def _route_batch(self, keys, wait_current):
         return [self.ex.route(keys[sl], hashed=True, wait_current=wait_current) for sl in self._mb_slices()]
 
-    def prefetch_route(self, next_keys):
-        """Route the NEXT batch (hash, bucket, id exchange, owner-side sort) now, on the routing stream.  `next_keys` must
-        already be complete (it is not ordered against the training stream)."""
-        self._route = (self._route_batch(next_keys, False), (next_keys.data_ptr(), tuple(next_keys.shape)))
+    def prefetch_route_begin(self, next_keys):
+        """Start routing the NEXT batch (hash, bucket, split-size exchange) on the routing stream; nothing blocks.
+        `next_keys` must already be complete (it is not ordered against the training stream)."""
+        self._route = ([self.ex.route_begin(next_keys[sl], hashed=True, wait_current=False) for sl in self._mb_slices()],
+                       (next_keys.data_ptr(), tuple(next_keys.shape)))
+
+    def prefetch_route_finish(self):
+        """Finish it (id exchange, owner-side sort).  The split sizes were exchanged long ago: the host wait is nominal."""
+        if self._route is not None:
+            for r in self._route[0]:
+                self.ex.route_finish(r)
 
     def train_step(self, keys, dense, labels, next_keys=None):
         """One step.  The rank's batch is processed as `self.mb` micro-batches that share one set of weights (all
@@ -389,6 +433,7 @@ class ShardedDeepFMEngine:
         # steps 1-3: use the prefetched routes if they were built for exactly these keys, else route now
         routes = None
         if self._route is not None and self._route[1] == (keys.data_ptr(), tuple(keys.shape)):
+            self.prefetch_route_finish()          # no-op when the previous step already finished it
             routes = self._route[0]
         self._route = None
         if routes is None:
@@ -411,6 +456,9 @@ class ShardedDeepFMEngine:
                     ev = torch.cuda.Event()
                     ev.record()
                     ev_rows.append(ev)
+        if next_keys is not None:
+            # split sizes of the NEXT batch: queued right behind this step's row fetches, long before they are needed
+            self.prefetch_route_begin(next_keys)
         self.flat_grads.zero_()
         if self.Nd:
             self.concat[:, F * D:F * D + self.Nd].copy_(dense)
@@ -474,10 +522,9 @@ class ShardedDeepFMEngine:
                                     lambda sl=sl, m=m: self.ex.pack(routes[m], self.d_concat[sl], self.d_logit[sl], self.concat[sl],
                                                                     self.sum_x[sl], self.g_lin_bias))
             if not prefetched and m == M - 1:
-                # Route the next batch now: the last micro-batch's whole tower is already enqueued, so the route's host sync
-                # (it waits for the collectives issued so far plus a handful of small kernels) overlaps queued GPU work, and
-                # its two small all-to-alls sit in front of the last gradient exchange instead of behind it.
-                self.prefetch_route(next_keys)
+                # Second half of the next batch's routing (id exchange + owner-side sort): its two small all-to-alls sit in
+                # front of the last gradient exchange instead of behind it; the split sizes it needs arrived long ago.
+                self.prefetch_route_finish()
                 prefetched = True
             if cuda:
                 ev_p = torch.cuda.Event()
