@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--optimizer", choices=["sgd", "adam"], default="sgd",
                     help="sgd: fused SGD (the headline line); adam: fused row-wise Adam in K4 + dense Adam (single GPU only)")
+    ap.add_argument("--model", choices=["deepfm", "dcn"], default="deepfm",
+                    help="deepfm: the headline (BASELINE config 3); dcn: config 4 (3 cross layers + MLP 1024,512,256), single GPU")
     ap.add_argument("--pool", type=int, default=8, help="number of distinct synthetic batches cycled through")
     return ap.parse_args()
 
@@ -133,7 +135,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
-    if world == 1 and not force_sharded:
+    if a.model == "dcn":
+        if world != 1:
+            raise SystemExit("--model dcn is a single-GPU line")
+        from deep_recommenders_amd.dcn_engine import DCNEngine
+        dnn_units = [int(x) for x in a.dnn.split(",") if x] if a.dnn != "256,32" else [1024, 512, 256]
+        eng = DCNEngine(a.fields, a.vocab, a.dim, 3, dnn_units, a.batch, num_dense=a.dense, lr=a.lr, device=device)
+    elif world == 1 and not force_sharded:
         from deep_recommenders_amd.engine import DeepFMEngine
         eng = DeepFMEngine(a.fields, a.vocab, a.dim, dnn_units, a.batch, num_dense=a.dense, lr=a.lr, device=device,
                            optimizer=a.optimizer)
@@ -216,7 +224,8 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "examples/sec/node DeepFM (26 sparse feats, 10M vocab, dim 64)",
+            "metric": "examples/sec/node DeepFM (26 sparse feats, 10M vocab, dim 64)" if a.model == "deepfm"
+            else "examples/sec DCN (26 sparse + 13 dense, 10M vocab, dim 64, 3 cross layers + MLP %s) -- BASELINE config 4" % dnn_units,
             "value": round(value, 1), "unit": "examples/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",

@@ -1,0 +1,161 @@
+"""Lean DCN training step (BASELINE.json config 4: Criteo-shaped, 3 cross layers + MLP [1024, 512, 256] + Dense(1)):
+
+    x0 = concat(field embeddings [, dense features])                        K1 hash -> K3 gather+pool
+    x_{l+1} = x0 * (x_l W_l + b_l + diag * x_l) + x_l,  l = 0..L-1           K8  keras/models/ranking/dcn.py:70-88 of the reference
+    logit = Dense(1)(relu-MLP(x_L))                                          K7
+    loss = sigmoid cross-entropy                                             K11
+
+stacked exactly like the reference's own test stacks `Cross` layers (tests/keras/test_dcn.py:27-32), with the same kernels the
+`Cross` / `dnn` classes use, no autograd tape, every update fused into the producing kernel (SGD: dst += -lr * grad).
+The reference ships the layer, not a DCN model class: this engine exists to put an end-to-end number on config 4."""
+import math
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import ops
+
+
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+class DCNEngine:
+    def __init__(self, num_fields: int, vocab_per_field: int, dim: int, num_cross: int, dnn_units: Sequence[int], batch: int,
+                 num_dense: int = 0, lr: float = 0.01, diag_scale: float = 0.0, device="cuda", seed: int = 42):
+        self.F, self.V, self.D, self.B, self.Nd, self.lr, self.diag = num_fields, vocab_per_field, dim, batch, num_dense, lr, diag_scale
+        F, V, D, B = num_fields, vocab_per_field, dim, batch
+        g = torch.Generator(device=device)
+        g.manual_seed(seed)
+        self.R = F * V
+        self.table = torch.empty((self.R, D), dtype=torch.float32, device=device)
+        std = 1.0 / math.sqrt(D)
+        for r0 in range(0, self.R, 1 << 24):
+            self.table[r0:r0 + (1 << 24)].normal_(0.0, std, generator=g).clamp_(-2 * std, 2 * std)
+        self.in_dim = F * D + num_dense
+        self.ld = _pad4(self.in_dim)
+        f32 = dict(dtype=torch.float32, device=device)
+        # cross layers: full-rank kernels [in_dim, in_dim] (dcn.py:55-68), truncated-normal init like the reference default
+        self.cross_W, self.cross_b = [], []
+        for _ in range(num_cross):
+            W = torch.empty((self.in_dim, self.ld), **f32)
+            W.normal_(0.0, 0.01, generator=g).clamp_(-0.02, 0.02)
+            self.cross_W.append(W[:, :self.in_dim])
+            self.cross_b.append(torch.zeros(self.in_dim, **f32))
+        units = list(dnn_units) + [1]
+        self.Ws: List[torch.Tensor] = []
+        self.bs: List[torch.Tensor] = []
+        d = self.in_dim
+        for u in units:                                                    # [TF] B8 glorot uniform
+            limit = math.sqrt(6.0 / (d + u))
+            W = (torch.rand((d, _pad4(u)), device=device, generator=g) * 2 - 1) * limit
+            self.Ws.append(W[:, :u])
+            self.bs.append(torch.zeros(u, **f32))
+            d = u
+        self.acts = [1] * len(dnn_units) + [0]
+        self.row_base = torch.arange(F, device=device, dtype=torch.int64) * V
+        self.col_buckets = torch.full((F,), V, dtype=torch.int64, device=device)
+        self.ids = torch.empty((B, F), dtype=torch.int64, device=device)
+        self.x0 = torch.zeros((B, self.ld), **f32)
+        self.hs = [torch.empty((B, _pad4(u)), **f32)[:, :u] for u in units]
+        self.dhs = [torch.empty((B, _pad4(u)), **f32)[:, :u] for u in units[:-1]]
+        self.d_top = torch.zeros((B, self.ld), **f32)
+        self.zero_logit = torch.zeros(B, **f32)
+        self.prob, self.d_logit, self.loss = torch.empty(B, **f32), torch.empty(B, **f32), torch.zeros(1, **f32)
+        self.ws = torch.empty(1024, **f32)
+        self.dw_ws = [ops.linear_bwd_dw_workspace(B, W.shape[0], W.shape[1], device) for W in self.Ws]
+        self.cross_ws = ops.linear_bwd_dw_workspace(B, self.in_dim, self.in_dim, device)
+        self.plan = ops.SortPlan(B * F, device)
+        self.side = torch.cuda.Stream(device=device)
+        self.ev_ids, self.ev_sorted = torch.cuda.Event(), torch.cuda.Event()
+        self._events = None
+
+    def enable_kernel_events(self, on: bool):
+        self._events = {} if on else None
+
+    def _k(self, name, bound, work, fn):
+        if self._events is None:
+            return fn()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = fn()
+        e.record()
+        self._events.setdefault(name, [bound, work, []])[2].append((s, e))
+        return r
+
+    def kernel_event_summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, (bound, work, evs) in (self._events or {}).items():
+            ms = sum(s.elapsed_time(e) for s, e in evs) / len(evs)
+            out[name] = {"bound": bound, "ms": ms, "n": len(evs), "alg_bytes" if bound in ("hbm", "overlap") else "alg_flops": work}
+        return out
+
+    def flops_step(self):
+        fl = len(self.cross_W) * 2 * self.B * self.in_dim * self.in_dim
+        for W in self.Ws:
+            fl += 2 * self.B * W.shape[0] * W.shape[1]
+        return 3 * fl
+
+    def train_step(self, keys, dense, labels, next_keys=None):
+        F, D, B, lr, n_in = self.F, self.D, self.B, self.lr, self.in_dim
+        # ---- forward -----------------------------------------------------------------------------------------------
+        self._k("hash_bucket_i64", "hbm", B * F * 16, lambda: ops.hash_bucket_i64(keys, self.col_buckets, out=self.ids))
+        self._k("emb_pool_fwd", "hbm", B * (8 * F * D + 8 * F),
+                lambda: ops.emb_pool_fwd(self.ids, F, None, self.row_base, self.table, None, None, ld_concat=self.ld, concat=self.x0,
+                                         want_sum_x=False, want_fm=False))
+        self.ev_ids.record()
+        with torch.cuda.stream(self.side):                   # slot sort for K4: hidden under the first cross GEMM
+            self.side.wait_event(self.ev_ids)
+            ops.emb_sort_slots(self.ids, self.row_base, self.R, self.plan)
+            self.ev_sorted.record(self.side)
+        if self.Nd:
+            self.x0[:, F * D:F * D + self.Nd].copy_(dense)
+        x0 = self.x0[:, :n_in]
+        xs, prods = [x0], []
+        fl_c = 2.0 * B * n_in * n_in
+        for l, (W, b) in enumerate(zip(self.cross_W, self.cross_b)):
+            out, prod = self._k("cross_fwd_L%d" % l, "mfma", fl_c,
+                                lambda x=xs[-1], W=W, b=b: ops.cross_fwd(x0, x, W, b, self.diag, want_prod=True))
+            xs.append(out)
+            prods.append(prod)
+        x = xs[-1]
+        for i, (W, b) in enumerate(zip(self.Ws, self.bs)):
+            self._k("linear_fwd_L%d" % i, "mfma", 2.0 * B * W.shape[0] * W.shape[1],
+                    lambda x=x, W=W, b=b, i=i: ops.linear_fwd(x, W, b, self.acts[i], out=self.hs[i]))
+            x = self.hs[i]
+        ops.bce_fwd_bwd(self.zero_logit, labels, ops.LOSS_SIGMOID_CE, workspace=self.ws, logits_b=self.hs[-1],
+                        out=(self.prob, self.d_logit, self.loss))
+        # ---- backward: MLP ---------------------------------------------------------------------------------------------
+        dy = self.d_logit.reshape(-1, 1)
+        for i in range(len(self.Ws) - 1, -1, -1):
+            xin = xs[-1] if i == 0 else self.hs[i - 1]
+            W = self.Ws[i]
+            fl = 2.0 * B * W.shape[0] * W.shape[1]
+            if i > 0:
+                dx, rs = self.dhs[i - 1], (self.hs[i - 1] if self.acts[i - 1] else None)
+            else:
+                dx, rs = self.d_top[:, :n_in], None
+            self._k("linear_bwd_dx_L%d" % i, "mfma", fl, lambda dy=dy, W=W, rs=rs, dx=dx: ops.linear_bwd_dx(dy, W, relu_src=rs, out=dx))
+            self._k("linear_bwd_dw_L%d" % i, "mfma", fl,
+                    lambda xin=xin, dy=dy, W=W, i=i: ops.linear_bwd_dw(xin, dy, -lr, W, self.bs[i], workspace=self.dw_ws[i]))
+            dy = dx
+        # ---- backward: cross stack.  d_out of layer l -> (d_x0 +=, d_x_l), W_l / b_l updated in place ------------------
+        d_out = self.d_top[:, :n_in]
+        d_x0 = torch.zeros((B, self.ld), dtype=torch.float32, device=d_out.device)[:, :n_in]
+        for l in range(len(self.cross_W) - 1, -1, -1):
+            W = self.cross_W[l]
+            d_x = torch.zeros((B, self.ld), dtype=torch.float32, device=d_out.device)[:, :n_in]
+            d_prod = self._k("cross_combine_bwd_L%d" % l, "hbm", 6.0 * 4 * B * n_in,
+                             lambda l=l, d_out=d_out, d_x=d_x: ops.cross_combine_bwd(x0, prods[l], d_out, self.diag, d_x0, d_x))
+            self._k("cross_bwd_dx_L%d" % l, "mfma", fl_c,
+                    lambda d_prod=d_prod, W=W, d_x=d_x: ops.linear_bwd_dx(d_prod, W, None, accumulate=True, out=d_x))
+            self._k("cross_bwd_dw_L%d" % l, "mfma", fl_c,
+                    lambda l=l, d_prod=d_prod, W=W: ops.linear_bwd_dw(xs[l], d_prod, -lr, W, self.cross_b[l], workspace=self.cross_ws))
+            d_out = d_x
+        d_x0.add_(d_out)                                     # the first layer's x IS x0
+        # ---- K4: scatter the embedding part of d_x0 (sorted, plain read-modify-write, fused SGD) ---------------------------
+        torch.cuda.current_stream().wait_event(self.ev_sorted)
+        self._k("emb_pool_bwd", "hbm", B * (12 * F * D + 8 * F),
+                lambda: ops.emb_pool_bwd_sorted(self.ids, self.row_base, self.plan, D, self.R, d_x0, None, -lr, self.table, None, None))
+        return self.loss

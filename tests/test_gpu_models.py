@@ -521,6 +521,60 @@ def test_tfrecord_batch_through_feature_columns_and_fm(tmp_path):
     np.testing.assert_allclose(logits.detach().cpu().numpy(), want_logit, rtol=1e-5, atol=1e-5)
 
 
+def test_dcn_engine_train_step_matches_oracle():
+    """DCNEngine (config 4 shape in small: cross stack -> MLP -> sigmoid CE, fused SGD everywhere) against the host
+    restatement: T.cross / dense layers under autograd, plain SGD."""
+    from deep_recommenders_amd.dcn_engine import DCNEngine
+    F, V, D, B, Nd, lr = 4, 60, 8, 96, 3, 0.05
+    eng = DCNEngine(F, V, D, 2, [16, 8], B, num_dense=Nd, lr=lr, diag_scale=0.1, seed=2)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    keys = torch.randint(0, 10**12, (B, F), device="cuda", generator=g)
+    dense = torch.rand((B, Nd), device="cuda", generator=g)
+    labels = (torch.rand(B, device="cuda", generator=g) < 0.3).float()
+    with torch.no_grad():
+        for b in eng.cross_b:
+            b.normal_(0, 0.05, generator=g)
+        # a non-zero output bias: with b = 0 a row whose last hidden layer is all-dead has logit exactly 0, where the loss
+        # formula max(x,0) - xz + log1p(exp(-|x|)) has kinks and autograd (torch: 1 - z, TF: -z) disagrees with the analytic
+        # sigmoid(0) - z = 0.5 - z the kernel uses
+        eng.bs[-1].fill_(0.03)
+    table0 = eng.table.cpu().double().clone()
+    cW0 = [w.cpu().double().clone() for w in eng.cross_W]
+    cb0 = [b.cpu().double().clone() for b in eng.cross_b]
+    Ws0 = [w.cpu().double().clone() for w in eng.Ws]
+    bs0 = [b.cpu().double().clone() for b in eng.bs]
+    loss = eng.train_step(keys, dense, labels).item()
+    ids = np.stack([O.hash_bucket_i64(keys[:, f].cpu().numpy(), V) for f in range(F)], axis=1)
+    np.testing.assert_array_equal(eng.ids.cpu().numpy(), ids)
+    tt = table0.clone().requires_grad_(True)
+    cW = [w.clone().requires_grad_(True) for w in cW0]
+    cb = [b.clone().requires_grad_(True) for b in cb0]
+    Ws = [w.clone().requires_grad_(True) for w in Ws0]
+    bs = [b.clone().requires_grad_(True) for b in bs0]
+    rows = torch.tensor(ids + np.arange(F)[None, :] * V)
+    x0 = torch.cat([tt[rows].reshape(B, F * D), dense.cpu().double()], dim=1)
+    x = x0
+    for W, b in zip(cW, cb):
+        x = T.cross(x0, x, W, b, 0.1)                                          # dcn.py:81-88
+    for i, (W, b) in enumerate(zip(Ws, bs)):
+        x = x @ W + b
+        if i < len(Ws) - 1:
+            x = torch.relu(x)
+    lo = T.sigmoid_cross_entropy(labels.cpu().double(), x.reshape(-1))
+    lo.backward()
+    assert abs(loss - lo.item()) <= 1e-5 * abs(lo.item())
+    np.testing.assert_allclose(eng.table.cpu().numpy(), (table0 - lr * tt.grad).numpy(), rtol=1e-4, atol=2e-6)
+    for got, w0, w in zip(eng.cross_W, cW0, cW):
+        np.testing.assert_allclose(got.cpu().numpy(), (w0 - lr * w.grad).numpy(), rtol=1e-4, atol=2e-6)
+    for got, b0, b in zip(eng.cross_b, cb0, cb):
+        np.testing.assert_allclose(got.cpu().numpy(), (b0 - lr * b.grad).numpy(), rtol=1e-4, atol=2e-6)
+    for got, w0, w in zip(eng.Ws, Ws0, Ws):
+        np.testing.assert_allclose(got.cpu().numpy(), (w0 - lr * w.grad).numpy(), rtol=1e-4, atol=2e-6)
+    for got, b0, b in zip(eng.bs, bs0, bs):
+        np.testing.assert_allclose(got.cpu().numpy(), (b0 - lr * b.grad).numpy(), rtol=1e-4, atol=2e-6)
+
+
 def test_engine_adam_steps_match_oracle():
     """optimizer="adam": 3 engine steps (fused row-wise Adam in K4 + dense Adam over the flat parameter buffer) against the
     host restatement ([TF] B15 formulas; tables updated on touched rows).  Parameters to 2 % of one Adam step."""
