@@ -9,7 +9,7 @@ stacked exactly like the reference's own test stacks `Cross` layers (tests/keras
 `Cross` / `dnn` classes use, no autograd tape, every update fused into the producing kernel (SGD: dst += -lr * grad).
 The reference ships the layer, not a DCN model class: this engine exists to put an end-to-end number on config 4."""
 import math
-from typing import List, Optional, Sequence
+from typing import List, Sequence
 
 import torch
 

@@ -1,7 +1,6 @@
 """Estimator-style DeepFM — same surface as the reference's estimator/models/ranking/deepfm.py:9-43."""
 from torch import nn
 
-from deep_recommenders_amd import layers as L
 from deep_recommenders_amd import losses
 from deep_recommenders_amd.estimator.models.feature_interaction import FM
 from deep_recommenders_amd.estimator.models.feature_interaction.dnn import VariableStore, dnn, relu

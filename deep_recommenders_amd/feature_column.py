@@ -9,7 +9,6 @@ examples/train_fm_on_movielens_estimator.py:10-34.  Semantics follow SURVEY.md A
 The id transformation itself (hash / vocabulary lookup) runs on the GPU through the C-ABI kernels
 dr_hash_bucket_* / dr_vocab_lookup_* — these objects only carry configuration.
 """
-from typing import List, Optional, Sequence
 
 import numpy as np
 import torch

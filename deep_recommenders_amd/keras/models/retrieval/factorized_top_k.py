@@ -2,7 +2,7 @@
 keras/models/retrieval/factorized_top_k.py (`_take_long_axis` :26-41, `_exclude` :44-67, `TopK` :70-136,
 `Streaming` :139-260, `BruteForce` :263-334, `Faiss` :337-461, `FactorizedTopK` :464-522), on the K10 kernels."""
 import abc
-from typing import Iterable, List, Optional, Sequence, Tuple, Union
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 from torch import nn

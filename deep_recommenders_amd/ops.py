@@ -5,7 +5,7 @@ Every function launches hand-written HIP kernels on torch's current stream; noth
 PyTorch.  Reference citations (relative to the reference root) are on the C-ABI declarations in
 include/dr_hotpath.h.
 """
-from typing import List, Optional, Sequence
+from typing import Optional, Sequence
 
 import torch
 

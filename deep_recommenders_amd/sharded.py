@@ -21,7 +21,7 @@ here) — the world_size-2 gloo tests substitute an oracle-backed implementation
 on CPU, where the kernels cannot run.
 """
 import math
-from typing import List, Optional, Sequence
+from typing import Sequence
 
 import torch
 import torch.distributed as dist

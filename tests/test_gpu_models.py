@@ -1,7 +1,6 @@
 """GPU tests of the reference-shaped classes.  Each test names the reference test it mirrors
 (paths relative to the reference root) and checks results against the CPU oracle."""
 import io
-import json
 import os
 
 import numpy as np

@@ -6,7 +6,7 @@ import sys
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from deep_recommenders_amd import ops, _lib
+from deep_recommenders_amd import ops
 
 
 def timeit(fn, iters=20, warmup=3):
