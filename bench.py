@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--optimizer", choices=["sgd", "adam"], default="sgd",
                     help="sgd: fused SGD (the headline line); adam: fused row-wise Adam in K4 + dense Adam (single GPU only)")
+    ap.add_argument("--micro-batches", type=int, default=int(os.environ.get("DR_MICRO_BATCHES", "2")),
+                    help="sharded engine only: micro-batches per step (exchange of one overlaps the tower of the other)")
     ap.add_argument("--model", choices=["deepfm", "dcn"], default="deepfm",
                     help="deepfm: the headline (BASELINE config 3); dcn: config 4 (3 cross layers + MLP 1024,512,256), single GPU")
     ap.add_argument("--pool", type=int, default=8, help="number of distinct synthetic batches cycled through")
@@ -148,7 +150,7 @@ def main():
     else:
         from deep_recommenders_amd.sharded import ShardedDeepFMEngine
         eng = ShardedDeepFMEngine(a.fields, a.vocab, a.dim, dnn_units, a.batch, num_dense=a.dense, lr=a.lr,
-                                  device=device, world=world, rank=rank)
+                                  device=device, world=world, rank=rank, micro_batches=a.micro_batches)
     batches = synth_batches(a, device, rank)
 
     nb = len(batches)
@@ -234,7 +236,7 @@ def main():
                                    "batch %d per GPU, ids %s; tables %s"
                                    % (a.fields, a.dense, a.vocab, a.dim, dnn_units, "SGD" if a.optimizer == "sgd" else "Adam (row-wise on the tables)", a.batch, a.ids,
                                       "on one GPU (%.1f GB)" % (a.fields * a.vocab * a.dim * 4 / 1e9) if world == 1
-                                      else "row-sharded over %d GPUs (id %% N), RCCL all-to-all" % world),
+                                      else "row-sharded over %d GPUs (id %% N), RCCL all-to-all, %d micro-batches per step" % (world, getattr(eng, "mb", 1))),
                        "global_batch": a.batch * world, "parallelism": "single" if world == 1 else "dp%d+row-sharded-tables" % world,
                        "final_loss": round(loss, 6)},
             "roofline": roofline,

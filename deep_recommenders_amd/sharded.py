@@ -93,6 +93,11 @@ class ShardedEmbeddingExchange:
         self._cuda = torch.device(device).type == "cuda"
         self._rs = torch.cuda.Stream(device=device) if self._cuda else None      # routing stream
         # per-slot owner-side buffers (the route of step t is still read by step t's backward while step t+1 is routed)
+        self.set_slots(self.SLOTS)
+
+    def set_slots(self, n):
+        """Number of routes that may be in flight (2 x micro-batches per step)."""
+        self.SLOTS = int(n)
         self._slots = [dict(cap=0, rows_pad=None, g_pad=None, gl_pad=None, plan=None, ids=None) for _ in range(self.SLOTS)]
         self._next_slot = 0
 
@@ -361,6 +366,7 @@ class ShardedDeepFMEngine:
         if not self.fuse_head or B % mb:
             mb = 1
         self.mb = mb
+        self.ex.set_slots(max(4, 2 * mb))
         Bm = B // mb
         self.narrow = [hasattr(self.p, "linear_bwd_narrow") and i > 0 and self.acts[i - 1] == 1
                        and self.p.linear_bwd_narrow_supported(Bm, Wt.shape[0], Wt.shape[1]) for i, Wt in enumerate(self.Ws)]
