@@ -19,6 +19,8 @@ import time
 # RCCL's own, sort) and two that share a queue serialize (seen in the kernel trace: the routing stream ran in-line with
 # the GEMMs).  Must be set before the HIP runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# dmabuf IPC for RCCL (the host driver has no legacy IPC): read when the ROCm runtime initialises, so set it here too
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch
 
