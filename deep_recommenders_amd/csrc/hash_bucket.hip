@@ -64,20 +64,76 @@ __device__ __forceinline__ uint64_t fp64_words(uint64_t w0, uint64_t w1, uint64_
 // [TF] as_string(int64): plain decimal, leading '-' for negatives, no padding.  Characters are
 // pushed least-significant first into a 192-bit little-endian shift register so byte 0 ends up
 // holding the first character of the text.
+// Non-negative keys, fast path: the 20-digit zero-padded decimal text is built RIGHT-aligned in the 24-byte register
+// (w0 | w1 | w2) with every digit at a compile-time byte position (32-bit digit extraction from three chunks of 4 / 8 / 8
+// digits), then left-aligned with ONE 192-bit byte shift -- instead of a 192-bit shift per digit and a 64-bit division per
+// digit.  Byte b of the text lives in word b / 8, bits 8 * (b % 8).
+__device__ __forceinline__ void put_digits8(uint32_t v, int first_byte, uint64_t& w0, uint64_t& w1, uint64_t& w2, int& top,
+                                            int digit_base) {
+    // v < 1e8: its 8 digits, least significant first, go to bytes first_byte + 7 ... first_byte
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t q = v / 10u;
+        const uint32_t d = v - q * 10u;
+        v = q;
+        const int b = first_byte + 7 - j;                 // compile-time after unrolling
+        const uint64_t ch = (uint64_t)(0x30u + d) << (8 * (b & 7));
+        if (b < 8) w0 |= ch; else if (b < 16) w1 |= ch; else w2 |= ch;
+        if (d != 0) top = digit_base + j + 1;             // number of significant digits so far
+    }
+}
+
+__device__ __forceinline__ void text_u64_fast(uint64_t mag, uint64_t& o0, uint64_t& o1, uint64_t& o2, int& olen) {
+    const uint64_t q8 = mag / 100000000ull;               // mag = q8 * 1e8 + lo
+    const uint32_t lo = (uint32_t)(mag - q8 * 100000000ull);
+    const uint64_t q16 = q8 / 100000000ull;               // q8 = q16 * 1e8 + mid,  q16 < 1845
+    const uint32_t mid = (uint32_t)(q8 - q16 * 100000000ull);
+    uint64_t w0 = 0, w1 = 0, w2 = 0;
+    int top = 1;                                          // "0" has one digit
+    put_digits8(lo, 16, w0, w1, w2, top, 0);              // text bytes 16..23
+    if (q8 != 0) put_digits8(mid, 8, w0, w1, w2, top, 8); // text bytes 8..15
+    else { w1 = 0x3030303030303030ull; }
+    uint32_t hi = (uint32_t)q16;                          // up to 4 digits: text bytes 4..7
+    uint64_t hw = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t q = hi / 10u;
+        const uint32_t d = hi - q * 10u;
+        hi = q;
+        hw |= (uint64_t)(0x30u + d) << (8 * (7 - j));
+        if (d != 0) top = 16 + j + 1;
+    }
+    w0 |= hw;                                             // bytes 0..3 stay 0 and are shifted out below
+    // left-align: drop the first (24 - top) bytes
+    const int drop = 24 - top;                            // 4 .. 23
+    uint64_t a = w0, b = w1, c = w2;
+    if (drop >= 16) { a = c; b = 0; c = 0; }
+    else if (drop >= 8) { a = b; b = c; c = 0; }
+    const int sh = (drop & 7) * 8;
+    if (sh != 0) {
+        a = (a >> sh) | (b << (64 - sh));
+        b = (b >> sh) | (c << (64 - sh));
+        c = c >> sh;
+    }
+    o0 = a; o1 = b; o2 = c; olen = top;
+}
+
 __device__ __forceinline__ uint64_t hash_i64_key(int64_t key) {
-    uint64_t mag = key < 0 ? (uint64_t)0 - (uint64_t)key : (uint64_t)key;
     uint64_t w0 = 0, w1 = 0, w2 = 0;
     int len = 0;
-    do {
-        uint64_t q = mag / 10;
-        uint64_t ch = (uint64_t)'0' + (mag - q * 10);
-        w2 = (w2 << 8) | (w1 >> 56);
-        w1 = (w1 << 8) | (w0 >> 56);
-        w0 = (w0 << 8) | ch;
-        mag = q;
-        ++len;
-    } while (mag != 0);
-    if (key < 0) {
+    if (key >= 0) {
+        text_u64_fast((uint64_t)key, w0, w1, w2, len);
+    } else {                                               // negative keys (rare): the simple digit-at-a-time form
+        uint64_t mag = (uint64_t)0 - (uint64_t)key;
+        do {
+            uint64_t q = mag / 10;
+            uint64_t ch = (uint64_t)'0' + (mag - q * 10);
+            w2 = (w2 << 8) | (w1 >> 56);
+            w1 = (w1 << 8) | (w0 >> 56);
+            w0 = (w0 << 8) | ch;
+            mag = q;
+            ++len;
+        } while (mag != 0);
         w2 = (w2 << 8) | (w1 >> 56);
         w1 = (w1 << 8) | (w0 >> 56);
         w0 = (w0 << 8) | (uint64_t)'-';
@@ -90,15 +146,34 @@ __global__ __launch_bounds__(256) void hash_bucket_i64_kernel(const int64_t* __r
                                                               int32_t C,
                                                               const uint64_t* __restrict__ col_buckets,
                                                               int64_t* __restrict__ out) {
+    // per-column Barrett constants: one 64-bit division per column per block instead of one per key
+    extern __shared__ uint64_t cb[];                       // [C] buckets, then [C] floor((2^64 - 1) / buckets)
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const uint64_t nb = col_buckets[c];
+        cb[c] = nb;
+        cb[C + c] = nb != 0 ? ~0ull / nb : 0;
+    }
+    __syncthreads();
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int col = (int)(i0 % C);
+    const int col_step = (int)(stride % C);
+    for (int64_t i = i0; i < n; i += stride) {
         const int64_t key = keys[i];
-        const uint64_t nb = col_buckets[i % C];
+        const uint64_t nb = cb[col];
         int64_t id;
         if (key == -1) id = -1;                    // [TF] dense int input: -1 entries are dropped
         else if (nb == 0) id = key;                // pass-through column (already an id)
-        else id = (int64_t)(hash_i64_key(key) % nb);
+        else {
+            const uint64_t h = hash_i64_key(key);
+            uint64_t r = h - __umul64hi(h, cb[C + col]) * nb;      // Barrett: quotient estimate is low by at most 2
+            if (r >= nb) r -= nb;
+            if (r >= nb) r -= nb;
+            id = (int64_t)r;
+        }
         out[i] = id;
+        col += col_step;
+        if (col >= C) col -= C;
     }
 }
 
@@ -250,7 +325,7 @@ extern "C" int dr_hash_bucket_i64(const int64_t* keys, int64_t B, int32_t C, con
     if (B == 0) return DR_OK;
     if (!keys || !col_buckets || !ids_out) return DR_EINVAL;
     const int64_t n = B * C;
-    hipLaunchKernelGGL(hash_bucket_i64_kernel, dim3(dr_grid_for(n, 256)), dim3(256), 0, dr_s(stream), keys, n, C,
+    hipLaunchKernelGGL(hash_bucket_i64_kernel, dim3(dr_grid_for(n, 256)), dim3(256), 2 * C * sizeof(uint64_t), dr_s(stream), keys, n, C,
                        col_buckets, ids_out);
     DR_CHECK_LAUNCH();
     return DR_OK;

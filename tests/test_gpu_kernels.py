@@ -47,6 +47,21 @@ def test_hash_bucket_i64_bit_exact(ops):
     np.testing.assert_array_equal(got, keys[:, :1])
 
 
+def test_hash_bucket_i64_digit_boundaries_and_bucket_shapes(ops):
+    """Every decimal length boundary (the device builds the text in 8/8/4-digit chunks) against bucket counts that stress the
+    Barrett reduction: 1, powers of two, 2^63, primes."""
+    ks = [0, 2**63 - 1, -2**63, -2, -10, -99999999, -100000000]
+    for e in range(1, 19):
+        ks += [10**e - 1, 10**e, 10**e + 1, 5 * 10**e, -(10**e)]
+    ks += [10**8 * 3, 10**16 * 7, 10**16 + 10**8, 12345678_00000000, 99999999_99999999, 1_00000000_00000000]
+    keys = np.array(ks, dtype=np.int64)
+    bks = [1, 2, 3, 4, 1024, 2**32, 2**32 + 1, 2**62, 2**63 - 1, 10_000_000, 6040, 2**40 + 7]
+    K = np.repeat(keys[:, None], len(bks), axis=1)
+    got = ops.hash_bucket_i64(_dev(K), _dev(np.array(bks, dtype=np.int64))).cpu().numpy()
+    for c, nb in enumerate(bks):
+        np.testing.assert_array_equal(got[:, c], O.hash_bucket_i64(keys, int(nb)), err_msg=f"buckets={nb}")
+
+
 def test_hash_bucket_upstream_vectors_on_device(ops):
     got = ops.hash_bucket_strings(["Hello", "TensorFlow", "2.x"], 3).cpu().tolist()
     assert got == [0, 2, 2]
