@@ -29,6 +29,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.3 TB/s achievable copy)
 MFMA_F32_PEAK_TF = 157.3  # dense fp32 MFMA peak (same guide)
+# the default GEMM mode forms every fp32 product from six v_mfma_f32_32x32x16_bf16 products: its ceiling is the dense bf16
+# peak (2.5 PFLOP/s, same guide) divided by six
+MFMA_BF16_PEAK_TF = 2500.0
+MFMA_BF16X3_PEAK_TF = MFMA_BF16_PEAK_TF / 6.0
 
 
 def parse():
@@ -45,6 +49,8 @@ def parse():
     ap.add_argument("--lr", type=float, default=0.01)
     ap.add_argument("--ids", choices=["uniform", "zipf"], default="uniform")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm", choices=["bf16x3", "native"], default="bf16x3",
+                    help="fp32 GEMM products: six bf16 MFMA products of exact three-way splits (default) or v_mfma_f32_32x32x2_f32")
     ap.add_argument("--optimizer", choices=["sgd", "adam"], default="sgd",
                     help="sgd: fused SGD (the headline line); adam: fused row-wise Adam in K4 + dense Adam (single GPU only)")
     ap.add_argument("--micro-batches", type=int, default=int(os.environ.get("DR_MICRO_BATCHES", "2")),
@@ -127,6 +133,8 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dnn_units = [int(x) for x in a.dnn.split(",") if x]
+    from deep_recommenders_amd import ops as dr_ops
+    dr_ops.set_gemm_mode(a.gemm)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -189,11 +197,12 @@ def main():
     traffic = {}
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+        bf3 = "true" if a.gemm == "bf16x3" else "false"
         name_map = {"emb_pool_fwd": "emb_pool_fwd_sv_kernel<16,8>", "emb_pool_bwd": "emb_bwd_unique_kernel<16,4,false>",
                     "hash_bucket_i64": "hash_bucket_i64_kernel",
-                    "linear_fwd_L0": "gemm_f32_mfma_kernel<true,false,0,false>",
-                    "linear_bwd_dx_L0": "gemm_f32_mfma_kernel<true,true,2,false>",
-                    "linear_bwd_dw_L0": "gemm_f32_mfma_kernel<false,false,3,false>"}
+                    "linear_fwd_L0": "gemm_f32_mfma_kernel<true,false,0,false,false,%s>" % bf3,
+                    "linear_bwd_dx_L0": "gemm_f32_mfma_kernel<true,true,4,false,false,%s>" % bf3,
+                    "linear_bwd_dw_L0": "gemm_f32_mfma_kernel<false,false,3,false,false,%s>" % bf3}
         default_cfg = (a.batch, a.fields, a.vocab, a.dim, a.dense, a.dnn) == (65536, 26, 10_000_000, 64, 13, "256,32")
         if default_cfg and world == 1:
             traffic = {ev: int(pmc[k]["hbm_bytes_corrected"]) for ev, k in name_map.items() if k in pmc}
@@ -219,10 +228,18 @@ def main():
         if k["bound"] == "hbm":
             ach, peak, unit = k["alg_bytes"] / sec / 1e9, HBM_PEAK_GBS, "GB/s"
         else:
-            ach, peak, unit = k["alg_flops"] / sec / 1e12, MFMA_F32_PEAK_TF, "TFLOP/s"
-        roof_all.append({"kernel": name, "bound": k["bound"], "achieved": round(ach, 2), "peak": peak, "unit": unit,
-                         "frac": round(ach / peak, 4), "traffic": traffic.get(name), "avg_us": round(k["ms"] * 1e3, 2),
-                         "launches": k["n"]})
+            # the wide-tile GEMMs run on the bf16 pipe in the default mode (6 products per fp32 product); the narrow-tile
+            # and fused-tail kernels always use the fp32 MFMA
+            on_bf16 = a.gemm == "bf16x3" and name.startswith("linear_") and name.endswith("_L0")
+            ach, peak, unit = k["alg_flops"] / sec / 1e12, (MFMA_BF16X3_PEAK_TF if on_bf16 else MFMA_F32_PEAK_TF), "TFLOP/s"
+        row = {"kernel": name, "bound": k["bound"], "achieved": round(ach, 2), "peak": round(peak, 1), "unit": unit,
+               "frac": round(ach / peak, 4), "traffic": traffic.get(name), "avg_us": round(k["ms"] * 1e3, 2),
+               "launches": k["n"]}
+        if k["bound"] == "mfma":
+            row["peak_basis"] = ("dense bf16 MFMA peak 2500 TFLOP/s / 6 products per fp32 product" if on_bf16
+                                 else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)")
+            row["frac_of_f32_mfma_peak"] = round(ach / MFMA_F32_PEAK_TF, 4)
+        roof_all.append(row)
     roof_all.sort(key=lambda r: -r["avg_us"])
     roofline = dict(roof_all[0]) if roof_all else None
 
@@ -239,6 +256,8 @@ def main():
                                    % (a.fields, a.dense, a.vocab, a.dim, dnn_units, "SGD" if a.optimizer == "sgd" else "Adam (row-wise on the tables)", a.batch, a.ids,
                                       "on one GPU (%.1f GB)" % (a.fields * a.vocab * a.dim * 4 / 1e9) if world == 1
                                       else "row-sharded over %d GPUs (id %% N), RCCL all-to-all, %d micro-batches per step" % (world, getattr(eng, "mb", 1))),
+                       "gemm_products": ("fp32 in / fp32 accumulate; products = 6 bf16 MFMA products of exact 3-way bf16 splits (error vs fp64 <= native fp32 MFMA, tests/test_gpu_kernels.py)"
+                                         if a.gemm == "bf16x3" else "native v_mfma_f32_32x32x2_f32"),
                        "global_batch": a.batch * world, "parallelism": "single" if world == 1 else "dp%d+row-sharded-tables" % world,
                        "final_loss": round(loss, 6)},
             "roofline": roofline,

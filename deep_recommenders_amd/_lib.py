@@ -75,6 +75,8 @@ SIGNATURES = {
     "dr_softmax_ce_rows": [_p, _p, _i64, _i32, _f32, _p, _p, _p, _p],
     "dr_softmax_ce_rows_bwd": [_p, _p, _i64, _i32, _f32, _p, _f32, _p, _p, _i64, _p],
     "dr_version": [],
+    "dr_set_gemm_mode": [_i32],
+    "dr_get_gemm_mode": [],
 }
 _RESTYPE = {"dr_version": ctypes.c_char_p, "dr_shard_bucket_workspace_bytes": ctypes.c_int64,
             "dr_emb_sort_workspace_bytes": ctypes.c_int64,

@@ -20,6 +20,9 @@
 // (same L2): dispatch places block b on XCD b % 8.
 #include "dr_common.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+#include <atomic>
+#include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -51,6 +54,7 @@ struct GemmArgs {
     int32_t split;            // ATOMIC: number of reduction splits (gridDim.y)
     float* partial;           // ATOMIC: if non-null, block (tile, y) stores its tile to partial[y][M][N] instead of atomics
     int32_t a_vec, b_vec;     // operand base 16-B aligned and ld % 4 == 0 -> float4 loads allowed
+    int32_t native_only;      // never take the bf16x3 product path (retrieval scores: must tie bit-exactly with the FILTER / LSE kernels)
     // FMGRAD: C = acc + dl[i] * (S[i][j % fm_D] - x[i][j]) for j < fm_FD   (e0 = x, e1 = S [M, fm_D])
     const float* vec; int32_t fm_D, fm_FD;
     // LSE / SMGRAD (in-batch softmax, Retrieval.call): score s_ij = (acc - log p_j + dupmask_ij * MIN_FLOAT) * inv_t
@@ -124,20 +128,64 @@ __device__ __forceinline__ float4 fix4(f4u v, EdgeFix e) {
     return o;
 }
 
+// ---- fp32 product emulation on the bf16 matrix pipe ("bf16x3", 6 of the 9 cross products) --------------------------
+// x = x0 + x1 + x2 with x0 = bf16_rn(x), x1 = bf16_rn(x - x0), x2 = bf16_rn(x - x0 - x1): |x1| <= 2^-8 |x|, |x2| <= 2^-16 |x|,
+// the two subtractions are exact in fp32.  a * b ~= a0b0 + (a0b1 + a1b0) + (a0b2 + a1b1 + a2b0); every bf16 x bf16 product
+// is exact in the MFMA's fp32 accumulator and the dropped terms (a1b2, a2b1, a2b2) are below 2^-24 |ab|.
+// compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, N) -- every index a constant expression
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// LDS image of an operand tile in bf16x3 mode: three planes [rows][PK] of bf16, k-contiguous.  PK = 40 (80-byte rows): the
+// ds_read_b128 fragment reads (lane -> row lane & 31, 16 bytes) are conflict-free for that instruction's 16-lane groups
+// (20 * row mod 64 is a permutation of the 4-bank slots over each group, MI355X_MICROARCH.md LDS table).
+constexpr int PK = 40;
+// four k-consecutive fp32 values of one row -> 4 bf16 in each plane (one ds_write_b64 per plane)
+__device__ __forceinline__ void put4_bf3(__bf16* __restrict__ plane0, int plane_stride, int row, int k, float v0, float v1,
+                                         float v2, float v3) {
+    const f32x2 a = {v0, v1}, b = {v2, v3};
+    const bf16x2 a0 = __builtin_convertvector(a, bf16x2), b0 = __builtin_convertvector(b, bf16x2);
+    const f32x2 ra = a - __builtin_convertvector(a0, f32x2), rb = b - __builtin_convertvector(b0, f32x2);
+    const bf16x2 a1 = __builtin_convertvector(ra, bf16x2), b1 = __builtin_convertvector(rb, bf16x2);
+    const f32x2 sa = ra - __builtin_convertvector(a1, f32x2), sb = rb - __builtin_convertvector(b1, f32x2);
+    const bf16x2 a2 = __builtin_convertvector(sa, bf16x2), b2 = __builtin_convertvector(sb, bf16x2);
+    __bf16* d = plane0 + row * PK + k;
+    *reinterpret_cast<bf16x4*>(d) = bf16x4{a0[0], a0[1], b0[0], b0[1]};
+    *reinterpret_cast<bf16x4*>(d + plane_stride) = bf16x4{a1[0], a1[1], b1[0], b1[1]};
+    *reinterpret_cast<bf16x4*>(d + 2 * plane_stride) = bf16x4{a2[0], a2[1], b2[0], b2[1]};
+}
+
 // Occupancy: 3 blocks per CU for the wide tile (168 VGPRs).  At 4 (128 VGPRs) the next k-tile's 8 prefetch registers
 // cannot stay live across the MFMA block without spilling, so the compiler sinks the global loads BELOW the 64 MFMAs
 // and their latency is exposed in front of every barrier; pinned ahead of the MFMAs at 3 blocks/CU is 2-4 % faster.
-template <bool A_RC, bool B_RC, int EPI, bool NARROW, bool OCC4 = false>
-__global__ __launch_bounds__(256, (NARROW || OCC4) ? 4 : 3) void gemm_f32_mfma_kernel(GemmArgs g) {
+template <bool A_RC, bool B_RC, int EPI, bool NARROW, bool OCC4 = false, bool BF3 = false>
+__global__ __launch_bounds__(256, BF3 ? 2 : ((NARROW || OCC4) ? 4 : 3)) void gemm_f32_mfma_kernel(GemmArgs g) {
     // wide: 2 x 2 waves, each 2 x 2 MFMA tiles (128 x 128);  narrow: 4 x 1 waves, each 1 x 1 tile (128 x 32)
     constexpr int BN = NARROW ? 32 : 128;
     constexpr int TM = NARROW ? 1 : 2, TN = NARROW ? 1 : 2;
+    constexpr int RCS = 32;                                  // rows between a thread's float4's of a reduction-contiguous operand
     constexpr int NQB = NARROW ? 1 : 4;                      // float4's of the B tile per thread
     constexpr int LDA = A_RC ? LD_T : LD_D;
     constexpr int LDB = B_RC ? (NARROW ? 33 : LD_T) : (NARROW ? 36 : LD_D);
-    __shared__ __attribute__((aligned(16))) float smem[BK * LDA + BK * LDB];
+    static_assert(!(BF3 && NARROW), "bf16x3 mode uses the wide tile");
+    constexpr int PLANE_A = BM * PK, PLANE_B = BN * PK;       // bf16 elements per plane (bf16x3 mode)
+    constexpr int BF3_BUF = 3 * (PLANE_A + PLANE_B);          // bf16 elements of the tile image
+    constexpr int SMEM_FLOATS = BF3 ? BF3_BUF / 2 : BK * LDA + BK * LDB;       // bf16x3: 60 KB, two blocks per CU
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     float* As = smem;
-    float* Bs = smem + BK * LDA;
+    float* Bs = smem + (BF3 ? 0 : BK * LDA);
+    __bf16* const Ap = reinterpret_cast<__bf16*>(smem);       // bf16x3: [3][BM][PK] then [3][BN][PK]
+    __bf16* const Bp = Ap + 3 * PLANE_A;
+    __bf16* const ApW = Ap; __bf16* const BpW = Bp;
+    const __bf16* const ApR = Ap; const __bf16* const BpR = Bp;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -171,46 +219,79 @@ __global__ __launch_bounds__(256, (NARROW || OCC4) ? 4 : 3) void gemm_f32_mfma_k
     // per-thread coordinates of its float4's.  RC operand: (i = tid>>3 (+32q), r4 = tid&7); reduction-major operand, wide:
     // (r = tid>>5 (+8q), c4 = tid&31), narrow B (32 columns): (r = tid>>3, c4 = tid&7), one float4 per thread.
     const int rc_i = tid >> 3, rc_r4 = tid & 7;
-    const int dr_r = tid >> 5, dr_c4 = tid & 31;
+    // bf16x3 mode, reduction-major operand: each thread owns a 4 (k) x 4 (i) block so that it can write k-contiguous bf16
+    // quads; a 16-lane group spans 4 column-quads x 4 k-quads (64-byte global segments, 2-way LDS store conflicts at most)
+    const int t_kq = (tid >> 7) * 4 + ((tid & 15) >> 2), t_c4 = ((tid >> 4) & 7) * 4 + (tid & 3);
+    const int dr_r0 = BF3 ? 4 * t_kq : (tid >> 5), dr_rs = BF3 ? 1 : 8;     // row of float4 q: dr_r0 + dr_rs * q
+    const int dr_c4 = BF3 ? t_c4 : (tid & 31);
     const int nb_r = tid >> 3, nb_c4 = tid & 7;
     f4u va[4], vb[NQB];
     auto load_tiles = [&](f4u (&va)[4], f4u (&vb)[NQB], int64_t r0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            if (A_RC) va[q] = ld4_raw(g.A, g.lda, m0 + rc_i + 32 * q, g.M, r0 + rc_r4 * 4, r_end);
-            else      va[q] = ld4_raw(g.A, g.lda, r0 + dr_r + 8 * q, r_end, m0 + dr_c4 * 4, g.M);
+            if (A_RC) va[q] = ld4_raw(g.A, g.lda, m0 + rc_i + RCS * q, g.M, r0 + rc_r4 * 4, r_end);
+            else      va[q] = ld4_raw(g.A, g.lda, r0 + dr_r0 + dr_rs * q, r_end, m0 + dr_c4 * 4, g.M);
         }
 #pragma unroll
         for (int q = 0; q < NQB; ++q) {
-            if (B_RC) vb[q] = ld4_raw(g.B, g.ldb, (int64_t)n0 + rc_i + 32 * q, g.N, r0 + rc_r4 * 4, r_end);
+            if (B_RC) vb[q] = ld4_raw(g.B, g.ldb, (int64_t)n0 + rc_i + RCS * q, g.N, r0 + rc_r4 * 4, r_end);
             else if (NARROW) vb[q] = ld4_raw(g.B, g.ldb, r0 + nb_r, r_end, (int64_t)n0 + nb_c4 * 4, g.N);
-            else      vb[q] = ld4_raw(g.B, g.ldb, r0 + dr_r + 8 * q, r_end, (int64_t)n0 + dr_c4 * 4, g.N);
+            else      vb[q] = ld4_raw(g.B, g.ldb, r0 + dr_r0 + dr_rs * q, r_end, (int64_t)n0 + dr_c4 * 4, g.N);
         }
     };
     auto store_tiles = [&](const f4u (&va)[4], const f4u (&vb)[NQB], int64_t r0) {     // r0 = offset the set was loaded for
+        if constexpr (BF3) {
+            float4 ta[4], tb[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (A_RC) ta[q] = fix4(va[q], edge_of(m0 + rc_i + RCS * q, g.M, r0 + rc_r4 * 4, r_end));
+                else      ta[q] = fix4(va[q], edge_of(r0 + dr_r0 + dr_rs * q, r_end, m0 + dr_c4 * 4, g.M));
+                if (B_RC) tb[q] = fix4(vb[q], edge_of((int64_t)n0 + rc_i + RCS * q, g.N, r0 + rc_r4 * 4, r_end));
+                else      tb[q] = fix4(vb[q], edge_of(r0 + dr_r0 + dr_rs * q, r_end, (int64_t)n0 + dr_c4 * 4, g.N));
+            }
+            if (A_RC) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) put4_bf3(ApW, PLANE_A, rc_i + RCS * q, rc_r4 * 4, ta[q].x, ta[q].y, ta[q].z, ta[q].w);
+            } else {
+                put4_bf3(ApW, PLANE_A, dr_c4 * 4 + 0, dr_r0, ta[0].x, ta[1].x, ta[2].x, ta[3].x);
+                put4_bf3(ApW, PLANE_A, dr_c4 * 4 + 1, dr_r0, ta[0].y, ta[1].y, ta[2].y, ta[3].y);
+                put4_bf3(ApW, PLANE_A, dr_c4 * 4 + 2, dr_r0, ta[0].z, ta[1].z, ta[2].z, ta[3].z);
+                put4_bf3(ApW, PLANE_A, dr_c4 * 4 + 3, dr_r0, ta[0].w, ta[1].w, ta[2].w, ta[3].w);
+            }
+            if (B_RC) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) put4_bf3(BpW, PLANE_B, rc_i + RCS * q, rc_r4 * 4, tb[q].x, tb[q].y, tb[q].z, tb[q].w);
+            } else {
+                put4_bf3(BpW, PLANE_B, dr_c4 * 4 + 0, dr_r0, tb[0].x, tb[1].x, tb[2].x, tb[3].x);
+                put4_bf3(BpW, PLANE_B, dr_c4 * 4 + 1, dr_r0, tb[0].y, tb[1].y, tb[2].y, tb[3].y);
+                put4_bf3(BpW, PLANE_B, dr_c4 * 4 + 2, dr_r0, tb[0].z, tb[1].z, tb[2].z, tb[3].z);
+                put4_bf3(BpW, PLANE_B, dr_c4 * 4 + 3, dr_r0, tb[0].w, tb[1].w, tb[2].w, tb[3].w);
+            }
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (A_RC) {
-                const float4 t = fix4(va[q], edge_of(m0 + rc_i + 32 * q, g.M, r0 + rc_r4 * 4, r_end));
-                float* d = As + (rc_r4 * 4) * LDA + rc_i + 32 * q;
+                const float4 t = fix4(va[q], edge_of(m0 + rc_i + RCS * q, g.M, r0 + rc_r4 * 4, r_end));
+                float* d = As + (rc_r4 * 4) * LDA + rc_i + RCS * q;
                 d[0] = t.x; d[LDA] = t.y; d[2 * LDA] = t.z; d[3 * LDA] = t.w;
             } else {
-                const float4 t = fix4(va[q], edge_of(r0 + dr_r + 8 * q, r_end, m0 + dr_c4 * 4, g.M));
-                *reinterpret_cast<float4*>(&As[(dr_r + 8 * q) * LDA + dr_c4 * 4]) = t;
+                const float4 t = fix4(va[q], edge_of(r0 + dr_r0 + dr_rs * q, r_end, m0 + dr_c4 * 4, g.M));
+                *reinterpret_cast<float4*>(&As[(dr_r0 + dr_rs * q) * LDA + dr_c4 * 4]) = t;
             }
         }
 #pragma unroll
         for (int q = 0; q < NQB; ++q) {
             if (B_RC) {
-                const float4 t = fix4(vb[q], edge_of((int64_t)n0 + rc_i + 32 * q, g.N, r0 + rc_r4 * 4, r_end));
-                float* d = Bs + (rc_r4 * 4) * LDB + rc_i + 32 * q;
+                const float4 t = fix4(vb[q], edge_of((int64_t)n0 + rc_i + RCS * q, g.N, r0 + rc_r4 * 4, r_end));
+                float* d = Bs + (rc_r4 * 4) * LDB + rc_i + RCS * q;
                 d[0] = t.x; d[LDB] = t.y; d[2 * LDB] = t.z; d[3 * LDB] = t.w;
             } else if (NARROW) {
                 const float4 t = fix4(vb[q], edge_of(r0 + nb_r, r_end, (int64_t)n0 + nb_c4 * 4, g.N));
                 *reinterpret_cast<float4*>(&Bs[nb_r * LDB + nb_c4 * 4]) = t;
             } else {
-                const float4 t = fix4(vb[q], edge_of(r0 + dr_r + 8 * q, r_end, (int64_t)n0 + dr_c4 * 4, g.N));
-                *reinterpret_cast<float4*>(&Bs[(dr_r + 8 * q) * LDB + dr_c4 * 4]) = t;
+                const float4 t = fix4(vb[q], edge_of(r0 + dr_r0 + dr_rs * q, r_end, (int64_t)n0 + dr_c4 * 4, g.N));
+                *reinterpret_cast<float4*>(&Bs[(dr_r0 + dr_rs * q) * LDB + dr_c4 * 4]) = t;
             }
         }
     };
@@ -220,10 +301,54 @@ __global__ __launch_bounds__(256, (NARROW || OCC4) ? 4 : 3) void gemm_f32_mfma_k
 
     const float* as = As + (lane >> 5) * LDA + wm * (TM * 32) + (lane & 31);
     const float* bs = Bs + (lane >> 5) * LDB + wn * (TN * 32) + (lane & 31);
-    auto mfma_block = [&]() {
+    // bf16x3 mode: column sums of the B tile from its three planes (x0 + x1 + x2 == x up to 2^-24)
+    auto bf3_colsum = [&]() {
         if (do_colsum) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int c = 0; c < BK / 8; ++c) {
+                    const bf16x8 v = *reinterpret_cast<const bf16x8*>(BpR + pl * PLANE_B + tid * PK + 8 * c);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) colsum += (float)v[j];
+                }
+        }
+    };
+    auto mfma_block = [&]() {
+        if constexpr (BF3) {
+            bf3_colsum();
+        } else {
+            if (do_colsum) {
 #pragma unroll 8
-            for (int r = 0; r < BK; ++r) colsum += Bs[r * LDB + tid];
+                for (int r = 0; r < BK; ++r) colsum += Bs[r * LDB + tid];
+            }
+        }
+        if constexpr (BF3) {
+            // fragment of a 32 x 16 sub-tile: lane (row = lane & 31, kg = lane >> 5) takes k = k0 + 8 * kg + 0..7, one ds_read_b128 per plane
+            const __bf16* ap = ApR + (wm * (TM * 32) + (lane & 31)) * PK + 8 * (lane >> 5);
+            const __bf16* bp = BpR + (wn * (TN * 32) + (lane & 31)) * PK + 8 * (lane >> 5);
+#pragma unroll
+            for (int k0 = 0; k0 < BK; k0 += 16) {
+                bf16x8 af[3][TM], bf[3][TN];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                    for (int t = 0; t < TM; ++t) af[pl][t] = *reinterpret_cast<const bf16x8*>(ap + pl * PLANE_A + t * 32 * PK + k0);
+#pragma unroll
+                    for (int t = 0; t < TN; ++t) bf[pl][t] = *reinterpret_cast<const bf16x8*>(bp + pl * PLANE_B + t * 32 * PK + k0);
+                }
+                // smallest terms first; the four accumulators are interleaved so that back-to-back MFMAs are independent
+#pragma unroll
+                for (int term = 0; term < 6; ++term) {
+                    constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int b = 0; b < TN; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[term]][a], bf[PB[term]][b], acc[a][b], 0, 0, 0);
+                }
+            }
+            return;
         }
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
@@ -257,30 +382,30 @@ __global__ __launch_bounds__(256, (NARROW || OCC4) ? 4 : 3) void gemm_f32_mfma_k
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (A_RC) {
-                int64_t row = m0 + rc_i + 32 * q;
+                int64_t row = m0 + rc_i + RCS * q;
                 row = row < g.M ? row : g.M - 1;
                 pa[q] = g.A + row * g.lda + r_begin + rc_r4 * 4;
             } else {
                 int64_t col = m0 + dr_c4 * 4;
                 col = col < g.M ? col : g.M - 4;             // fully outside -> anywhere legal; straddling -> unshifted
-                pa[q] = g.A + (r_begin + dr_r + 8 * q) * g.lda + col;
+                pa[q] = g.A + (r_begin + dr_r0 + dr_rs * q) * g.lda + col;
             }
         }
 #pragma unroll
         for (int q = 0; q < NQB; ++q) {
             if (B_RC) {
-                int64_t row = (int64_t)n0 + rc_i + 32 * q;
+                int64_t row = (int64_t)n0 + rc_i + RCS * q;
                 row = row < g.N ? row : g.N - 1;
                 pb[q] = g.B + row * g.ldb + r_begin + rc_r4 * 4;
             } else {
                 int64_t col = (int64_t)n0 + (NARROW ? nb_c4 : dr_c4) * 4;
                 col = col < g.N ? col : g.N - 4;
-                pb[q] = g.B + (r_begin + (NARROW ? nb_r : dr_r + 8 * q)) * g.ldb + col;
+                pb[q] = g.B + (r_begin + (NARROW ? nb_r : dr_r0 + dr_rs * q)) * g.ldb + col;
             }
         }
         const int64_t a_it = A_RC ? (int64_t)BK : BK * g.lda;
         const int64_t b_it = B_RC ? (int64_t)BK : BK * g.ldb;
-        auto load_fast = [&]() {
+        auto load_fast = [&](f4u (&va)[4], f4u (&vb)[NQB]) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 va[q] = *reinterpret_cast<const f4u*>(pa[q]);
@@ -292,39 +417,60 @@ __global__ __launch_bounds__(256, (NARROW || OCC4) ? 4 : 3) void gemm_f32_mfma_k
                 pb[q] += b_it;
             }
         };
-        auto store_fast = [&]() {
+        auto store_fast = [&](const f4u (&va)[4], const f4u (&vb)[NQB]) {
+            if constexpr (BF3) {
+                if (A_RC) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) put4_bf3(ApW, PLANE_A, rc_i + RCS * q, rc_r4 * 4, va[q].x, va[q].y, va[q].z, va[q].w);
+                } else {
+                    put4_bf3(ApW, PLANE_A, dr_c4 * 4 + 0, dr_r0, va[0].x, va[1].x, va[2].x, va[3].x);
+                    put4_bf3(ApW, PLANE_A, dr_c4 * 4 + 1, dr_r0, va[0].y, va[1].y, va[2].y, va[3].y);
+                    put4_bf3(ApW, PLANE_A, dr_c4 * 4 + 2, dr_r0, va[0].z, va[1].z, va[2].z, va[3].z);
+                    put4_bf3(ApW, PLANE_A, dr_c4 * 4 + 3, dr_r0, va[0].w, va[1].w, va[2].w, va[3].w);
+                }
+                if (B_RC) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) put4_bf3(BpW, PLANE_B, rc_i + RCS * q, rc_r4 * 4, vb[q].x, vb[q].y, vb[q].z, vb[q].w);
+                } else {
+                    put4_bf3(BpW, PLANE_B, dr_c4 * 4 + 0, dr_r0, vb[0].x, vb[1].x, vb[2].x, vb[3].x);
+                    put4_bf3(BpW, PLANE_B, dr_c4 * 4 + 1, dr_r0, vb[0].y, vb[1].y, vb[2].y, vb[3].y);
+                    put4_bf3(BpW, PLANE_B, dr_c4 * 4 + 2, dr_r0, vb[0].z, vb[1].z, vb[2].z, vb[3].z);
+                    put4_bf3(BpW, PLANE_B, dr_c4 * 4 + 3, dr_r0, vb[0].w, vb[1].w, vb[2].w, vb[3].w);
+                }
+                return;
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (A_RC) {
-                    float* d = As + (rc_r4 * 4) * LDA + rc_i + 32 * q;
+                    float* d = As + (rc_r4 * 4) * LDA + rc_i + RCS * q;
                     d[0] = va[q].x; d[LDA] = va[q].y; d[2 * LDA] = va[q].z; d[3 * LDA] = va[q].w;
                 } else {
-                    *reinterpret_cast<f4u*>(&As[(dr_r + 8 * q) * LDA + dr_c4 * 4]) = va[q];
+                    *reinterpret_cast<f4u*>(&As[(dr_r0 + dr_rs * q) * LDA + dr_c4 * 4]) = va[q];
                 }
             }
 #pragma unroll
             for (int q = 0; q < NQB; ++q) {
                 if (B_RC) {
-                    float* d = Bs + (rc_r4 * 4) * LDB + rc_i + 32 * q;
+                    float* d = Bs + (rc_r4 * 4) * LDB + rc_i + RCS * q;
                     d[0] = vb[q].x; d[LDB] = vb[q].y; d[2 * LDB] = vb[q].z; d[3 * LDB] = vb[q].w;
                 } else if (NARROW) {
                     *reinterpret_cast<f4u*>(&Bs[nb_r * LDB + nb_c4 * 4]) = vb[q];
                 } else {
-                    *reinterpret_cast<f4u*>(&Bs[(dr_r + 8 * q) * LDB + dr_c4 * 4]) = vb[q];
+                    *reinterpret_cast<f4u*>(&Bs[(dr_r0 + dr_rs * q) * LDB + dr_c4 * 4]) = vb[q];
                 }
             }
         };
-        load_fast();
+        load_fast(va, vb);
         for (int64_t t = 0; t + 1 < nfull; ++t) {
-            store_fast();
+            store_fast(va, vb);
             __syncthreads();
-            load_fast();
+            load_fast(va, vb);
             if (!OCC4) __builtin_amdgcn_sched_barrier(0);    // keep the global loads AHEAD of the MFMA block (needs > 128 VGPRs)
             mfma_block();
             __syncthreads();
         }
         // last whole tile (+ the clamped tail tile, if any), straight-line
-        store_fast();
+        store_fast(va, vb);
         __syncthreads();
         if (has_tail) load_tiles(va, vb, r_begin + nfull * BK);
         mfma_block();
@@ -550,6 +696,14 @@ __global__ __launch_bounds__(256, (NARROW || OCC4) ? 4 : 3) void gemm_f32_mfma_k
 }
 
 
+// process-wide GEMM mode (dr_set_gemm_mode); the default can be overridden with DR_GEMM_MODE=native|bf16x3
+static int gemm_mode_default() {
+    const char* e = getenv("DR_GEMM_MODE");
+    if (e != nullptr && (e[0] == 'n' || e[0] == 'N' || e[0] == '1')) return DR_GEMM_NATIVE_F32;
+    return DR_GEMM_BF16X3;
+}
+static std::atomic<int> g_gemm_mode{gemm_mode_default()};
+
 template <bool A_RC, bool B_RC, int EPI>
 int launch(GemmArgs& g, hipStream_t s) {
 
@@ -557,8 +711,9 @@ int launch(GemmArgs& g, hipStream_t s) {
     g.b_vec = ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0 && (g.ldb & 3) == 0) ? 1 : 0;
     const bool narrow = g.N <= 32 && (EPI == EPI_BIAS_ACT || EPI == EPI_MASK || EPI == EPI_ATOMIC || EPI == EPI_HEAD);
     const int bn = narrow ? 32 : BN;
+    const int bm = BM;
     const int tiles_n = (g.N + bn - 1) / bn;
-    const int64_t tiles_m = (g.M + BM - 1) / BM;
+    const int64_t tiles_m = (g.M + bm - 1) / bm;
     if (tiles_m * tiles_n > 0x7fffffff) return DR_EINVAL;
     dim3 grid((unsigned)(tiles_m * tiles_n), EPI == EPI_ATOMIC ? g.split : 1);
     if (narrow) {
@@ -572,6 +727,12 @@ int launch(GemmArgs& g, hipStream_t s) {
             // prefetch (measured: in-batch softmax forward 0.343 -> 0.320 ms, top-K scan 26.65 -> 25.65 ms; plain scores: no)
             if (g.R <= 256)
                 hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_RC, B_RC, EPI, false, true>), grid, dim3(256), 0, s, g);
+            else
+                hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_RC, B_RC, EPI, false>), grid, dim3(256), 0, s, g);
+        } else if constexpr (EPI == EPI_BIAS_ACT || EPI == EPI_CROSS || EPI == EPI_MASK || EPI == EPI_FMGRAD || EPI == EPI_ATOMIC) {
+            // the tower / cross-layer GEMMs: fp32 products on the bf16 matrix pipe unless the caller asked for the native one
+            if (!g.native_only && g_gemm_mode.load(std::memory_order_relaxed) == DR_GEMM_BF16X3)
+                hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_RC, B_RC, EPI, false, false, true>), grid, dim3(256), 0, s, g);
             else
                 hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_RC, B_RC, EPI, false>), grid, dim3(256), 0, s, g);
         } else hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_RC, B_RC, EPI, false>), grid, dim3(256), 0, s, g);
@@ -861,10 +1022,11 @@ extern "C" int dr_linear_bwd_dx_fm(const float* dy, int64_t ld_dy, const float* 
     return launch<true, true, EPI_FMGRAD>(g, dr_s(stream));
 }
 
-static int dw_split(int64_t M, int32_t K, int32_t N) {
+static int dw_split_for(int64_t M, int32_t K, int32_t N, int mode) {
     const int bn = N <= 32 ? 32 : BN;
     const int64_t tiles = ((int64_t)(K + BM - 1) / BM) * ((N + bn - 1) / bn);
-    const int64_t target = 768;      // 256 CUs x 3 resident blocks: one wave of blocks (measured faster than 1024)
+    // one wave of resident blocks: 256 CUs x 3 (native wide tile; measured faster than 1024) or x 2 (bf16x3: 60 KB of LDS)
+    const int64_t target = (mode == DR_GEMM_BF16X3 && N > 32) ? 512 : 768;
     int64_t split = target / tiles;
     const int64_t max_split = (M + 8 * BK - 1) / (8 * BK);     // at least 8 k-tiles per block
     if (split > max_split) split = max_split;
@@ -872,10 +1034,18 @@ static int dw_split(int64_t M, int32_t K, int32_t N) {
     if (split > 65535) split = 65535;
     return (int)split;
 }
+static int dw_split(int64_t M, int32_t K, int32_t N) {
+    return dw_split_for(M, K, N, g_gemm_mode.load(std::memory_order_relaxed));
+}
+// the workspace must be large enough for either mode (the mode may change between the allocation and the call)
+static int dw_split_max(int64_t M, int32_t K, int32_t N) {
+    const int a = dw_split_for(M, K, N, DR_GEMM_BF16X3), b = dw_split_for(M, K, N, DR_GEMM_NATIVE_F32);
+    return a > b ? a : b;
+}
 
 extern "C" int64_t dr_linear_bwd_dw_workspace_bytes(int64_t M, int32_t K, int32_t N) {
     if (M <= 0 || K <= 0 || N <= 0) return 0;
-    return (int64_t)dw_split(M, K, N) * K * N * (int64_t)sizeof(float);
+    return (int64_t)dw_split_max(M, K, N) * K * N * (int64_t)sizeof(float);
 }
 
 extern "C" int dr_linear_bwd_dw(const float* x, int64_t ld_x, const float* dy, int64_t ld_dy, int64_t M, int32_t K,
@@ -1047,8 +1217,16 @@ extern "C" int dr_scores_nt(const float* a, int64_t lda, const float* b, int64_t
     if (!a || !b || !out) return DR_EINVAL;
     GemmArgs g{};
     g.A = a; g.lda = lda; g.B = b; g.ldb = ldb; g.M = M; g.N = N; g.R = D; g.C = out; g.ldc = ld_out; g.split = 1;
+    g.native_only = 1;      // same products as the filtered / softmax score kernels: equal candidates must tie bit-exactly
     return launch<true, true, EPI_BIAS_ACT>(g, dr_s(stream));
 }
 
+
+extern "C" int32_t dr_set_gemm_mode(int32_t mode) {
+    if (mode != DR_GEMM_BF16X3 && mode != DR_GEMM_NATIVE_F32) return DR_EINVAL;
+    return g_gemm_mode.exchange(mode);
+}
+
+extern "C" int32_t dr_get_gemm_mode(void) { return g_gemm_mode.load(); }
 
 extern "C" const char* dr_version(void) { return "deep_recommenders_amd hot path / gfx950 / f32"; }

@@ -707,3 +707,22 @@ def emb_pack_grads(pos, D, d_concat, concat, sum_x, d_fm_logit, out_rows, out_li
     check(lib().dr_emb_pack_grads(ptr(pos), B, F, D, ptr(d_concat), d_concat.stride(0), ptr(concat),
                                   concat.stride(0) if concat is not None else 0, ptr(sum_x), ptr(d_fm_logit), ptr(out_rows),
                                   ptr(out_lin), ptr(bias_sum), stream_ptr()), "dr_emb_pack_grads")
+
+
+# ---- GEMM product mode (include/dr_hotpath.h: DR_GEMM_BF16X3 / DR_GEMM_NATIVE_F32) ------------------------------
+GEMM_BF16X3, GEMM_NATIVE_F32 = 0, 1
+_GEMM_MODES = {"bf16x3": GEMM_BF16X3, "native": GEMM_NATIVE_F32}
+
+
+def set_gemm_mode(mode):
+    """'bf16x3' (default: fp32 products as six bf16 MFMA products of exact three-way splits) or 'native'
+    (v_mfma_f32_32x32x2_f32).  Returns the previous mode's name.  Process-wide."""
+    m = _GEMM_MODES[mode] if isinstance(mode, str) else int(mode)
+    prev = _lib.lib().dr_set_gemm_mode(m)
+    if prev < 0:
+        raise ValueError("unknown GEMM mode %r" % (mode,))
+    return "native" if prev == GEMM_NATIVE_F32 else "bf16x3"
+
+
+def get_gemm_mode():
+    return "native" if _lib.lib().dr_get_gemm_mode() == GEMM_NATIVE_F32 else "bf16x3"

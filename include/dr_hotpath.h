@@ -39,6 +39,21 @@ typedef void* dr_stream_t; /* hipStream_t */
 /* Library self-description: returns the gfx arch string the kernels were compiled for. */
 const char* dr_version(void);
 
+/* How the fp32 GEMMs of the tower and cross layers (dr_linear_fwd / _bwd_dx / _bwd_dx_fm / _bwd_dw, dr_cross_fwd) form
+ * their products.  Inputs, outputs and accumulators are fp32 in both modes; the reference's own ops are tf.matmul on
+ * fp32 tensors (keras/models/ranking/deepfm.py:30-34, dcn.py:81-88), compared at 1e-5 on the loss.
+ *   DR_GEMM_BF16X3      (default) every operand value x is split exactly into three bf16 terms x0 + x1 + x2 and a * b is
+ *                       accumulated as a0b0 + a0b1 + a1b0 + a0b2 + a1b1 + a2b0 on v_mfma_f32_32x32x16_bf16 (each bf16
+ *                       product is exact in the fp32 accumulator; the dropped terms are < 2^-24 |ab|).  Measured error
+ *                       against an fp64 reference is equal to or below the native path's (tests/test_gpu_kernels.py).
+ *   DR_GEMM_NATIVE_F32  v_mfma_f32_32x32x2_f32 products.
+ * dr_set_gemm_mode returns the previous mode (DR_EINVAL for an unknown one); the setting is process-wide and read at
+ * launch time.  Environment override of the initial value: DR_GEMM_MODE=native | bf16x3. */
+#define DR_GEMM_BF16X3 0
+#define DR_GEMM_NATIVE_F32 1
+int32_t dr_set_gemm_mode(int32_t mode);
+int32_t dr_get_gemm_mode(void);
+
 /* ------------------------------------------------------------------------------------------
  * K1  hash-bucket column:  id = int64( FarmHash::Fingerprint64(as_string(key)) mod N )
  * replaces [TF] categorical_column_with_hash_bucket ->

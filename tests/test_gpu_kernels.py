@@ -594,3 +594,49 @@ def test_emb_bwd_sorted_with_fm_term_equals_atomic_kernel(ops):
     np.testing.assert_allclose(t2.cpu().numpy(), t1.cpu().numpy(), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(l2.cpu().numpy(), l1.cpu().numpy(), rtol=1e-5, atol=1e-5)
     assert abs(b1.item() - b2.item()) < 1e-3
+
+
+# ---------------------------------------------------------------- GEMM product modes
+def test_gemm_bf16x3_matches_fp64_as_well_as_native(ops):
+    """The default GEMM mode forms fp32 products from six bf16 MFMA products of exact three-way operand splits.  Its error
+    against an fp64 reference must not exceed the native fp32 MFMA path's (same accumulation order, same fp32 accumulators);
+    shapes cover the lean k-loop, the reduction tail (K % 32 != 0), edge tiles in M and N, and a wide dynamic range."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    M, K, N = 1000, 333, 200
+    x = torch.randn((M, K), device="cuda", generator=g) * torch.exp(3 * torch.randn((M, 1), device="cuda", generator=g))
+    W = torch.randn((K, N), device="cuda", generator=g) / K ** 0.5
+    b = torch.randn(N, device="cuda", generator=g)
+    dy = torch.randn((M, N), device="cuda", generator=g)
+    ref_y = x.double() @ W.double() + b.double()
+    ref_dx = dy.double() @ W.double().t()
+    ref_dw = x.double().t() @ dy.double()
+    ref_db = dy.double().sum(0)
+    errs = {}
+    prev = ops.get_gemm_mode()
+    try:
+        for mode in ("native", "bf16x3"):
+            ops.set_gemm_mode(mode)
+            assert ops.get_gemm_mode() == mode
+            y = ops.linear_fwd(x, W, b, 0)
+            dx = ops.linear_bwd_dx(dy, W, None)
+            dW = torch.zeros((K, N), device="cuda"); db = torch.zeros(N, device="cuda")
+            ops.linear_bwd_dw(x, dy, 1.0, dW, db, workspace=ops.linear_bwd_dw_workspace(M, K, N, "cuda"))
+            errs[mode] = [float((y.double() - ref_y).abs().max() / ref_y.abs().max()),
+                          float((dx.double() - ref_dx).abs().max() / ref_dx.abs().max()),
+                          float((dW.double() - ref_dw).abs().max() / ref_dw.abs().max()),
+                          float((db.double() - ref_db).abs().max() / ref_db.abs().max())]
+    finally:
+        ops.set_gemm_mode(prev)
+    for e_nat, e_bf3 in zip(errs["native"], errs["bf16x3"]):
+        assert e_bf3 <= 2e-6, errs                       # fp32-level agreement with fp64
+        assert e_bf3 <= 1.5 * e_nat + 1e-7, errs        # and no worse than the native fp32 MFMA path
+
+
+def test_gemm_mode_api(ops):
+    prev = ops.set_gemm_mode("native")
+    assert ops.set_gemm_mode("bf16x3") == "native"
+    assert ops.get_gemm_mode() == "bf16x3"
+    ops.set_gemm_mode(prev)
+    with pytest.raises(ValueError):
+        ops.set_gemm_mode(7)
+    assert ops.get_gemm_mode() == prev

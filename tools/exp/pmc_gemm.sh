@@ -10,7 +10,7 @@ R=os.environ["GRAFT_REPO_ROOT"]
 agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(R+"/gpurun_out/pmcg_*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        k=row["Kernel_Name"][:70]
+        k=row["Kernel_Name"][:120]
         if "gemm_f32" not in k: continue
         agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k,v in agg.items():
