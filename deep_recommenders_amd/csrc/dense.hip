@@ -460,6 +460,57 @@ __global__ __launch_bounds__(256, BF3 ? 2 : ((NARROW || OCC4) ? 4 : 3)) void gem
                 }
             }
         };
+        if constexpr (BF3) {
+            // Two register sets, so that a tile's global loads are issued two k-tiles before they are needed: with one set
+            // they have only the 48-MFMA block (~2000 cycles) to land and the store phase waits 1000-2000 cycles for them
+            // in most iterations (tools/exp/bf3_phases.py: clock64 timeline of one block).
+            f4u wa[4], wb[NQB];
+            load_fast(va, vb);                                 // tile 0
+            if (nfull > 1) load_fast(wa, wb);                  // tile 1
+            int64_t t = 0;
+            for (; t + 3 < nfull; t += 2) {
+                store_fast(va, vb);                            // tile t
+                __syncthreads();
+                load_fast(va, vb);                             // tile t + 2
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_block();
+                __syncthreads();
+                store_fast(wa, wb);                            // tile t + 1
+                __syncthreads();
+                load_fast(wa, wb);                             // tile t + 3
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_block();
+                __syncthreads();
+            }
+            // up to three whole tiles left: t (in va / vb), t + 1 (in wa / wb), t + 2 (not loaded yet), then the tail
+            const int64_t left = nfull - t;                    // 1, 2 or 3
+            store_fast(va, vb);
+            __syncthreads();
+            if (left == 3) load_fast(va, vb);
+            else if (left == 1 && has_tail) load_tiles(va, vb, r_begin + nfull * BK);
+            mfma_block();
+            __syncthreads();
+            if (left >= 2) {
+                store_fast(wa, wb);
+                __syncthreads();
+                if (left == 2 && has_tail) load_tiles(wa, wb, r_begin + nfull * BK);
+                mfma_block();
+                __syncthreads();
+            }
+            if (left == 3) {
+                store_fast(va, vb);
+                __syncthreads();
+                if (has_tail) load_tiles(wa, wb, r_begin + nfull * BK);
+                mfma_block();
+                __syncthreads();
+            }
+            if (has_tail) {
+                if (left == 1) store_tiles(va, vb, r_begin + nfull * BK); else store_tiles(wa, wb, r_begin + nfull * BK);
+                __syncthreads();
+                mfma_block();
+                __syncthreads();
+            }
+        } else {
         load_fast(va, vb);
         for (int64_t t = 0; t + 1 < nfull; ++t) {
             store_fast(va, vb);
@@ -480,6 +531,7 @@ __global__ __launch_bounds__(256, BF3 ? 2 : ((NARROW || OCC4) ? 4 : 3)) void gem
             __syncthreads();
             mfma_block();
             __syncthreads();
+        }
         }
     } else {
         load_tiles(va, vb, r_begin);
