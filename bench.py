@@ -201,7 +201,7 @@ def main():
         name_map = {"emb_pool_fwd": "emb_pool_fwd_sv_kernel<16,8>", "emb_pool_bwd": "emb_bwd_unique_kernel<16,4,false>",
                     "hash_bucket_i64": "hash_bucket_i64_kernel",
                     "linear_fwd_L0": "gemm_f32_mfma_kernel<true,false,0,false,false,%s>" % bf3,
-                    "linear_bwd_dx_L0": "gemm_f32_mfma_kernel<true,true,4,false,false,%s>" % bf3,
+                    "linear_bwd_dx_L0": "gemm_f32_mfma_kernel<true,true,2,false,false,%s>" % bf3,
                     "linear_bwd_dw_L0": "gemm_f32_mfma_kernel<false,false,3,false,false,%s>" % bf3}
         default_cfg = (a.batch, a.fields, a.vocab, a.dim, a.dense, a.dnn) == (65536, 26, 10_000_000, 64, 13, "256,32")
         if default_cfg and world == 1:
