@@ -12,6 +12,7 @@ Inputs (raw keys, dense features, labels) are resident in HBM before the timed r
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -230,7 +231,7 @@ def main():
         else:
             # the wide-tile GEMMs run on the bf16 pipe in the default mode (6 products per fp32 product); the narrow-tile
             # and fused-tail kernels always use the fp32 MFMA
-            on_bf16 = a.gemm == "bf16x3" and name.startswith("linear_") and name.endswith("_L0")
+            on_bf16 = a.gemm == "bf16x3" and re.match(r"^(linear|cross)_(fwd|bwd_dx|bwd_dw)_L\d+$", name) is not None
             ach, peak, unit = k["alg_flops"] / sec / 1e12, (MFMA_BF16X3_PEAK_TF if on_bf16 else MFMA_F32_PEAK_TF), "TFLOP/s"
         row = {"kernel": name, "bound": k["bound"], "achieved": round(ach, 2), "peak": round(peak, 1), "unit": unit,
                "frac": round(ach / peak, 4), "traffic": traffic.get(name), "avg_us": round(k["ms"] * 1e3, 2),

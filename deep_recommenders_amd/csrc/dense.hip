@@ -1077,14 +1077,24 @@ extern "C" int dr_linear_bwd_dx_fm(const float* dy, int64_t ld_dy, const float* 
 static int dw_split_for(int64_t M, int32_t K, int32_t N, int mode) {
     const int bn = N <= 32 ? 32 : BN;
     const int64_t tiles = ((int64_t)(K + BM - 1) / BM) * ((N + bn - 1) / bn);
-    // one wave of resident blocks: 256 CUs x 3 (native wide tile; measured faster than 1024) or x 2 (bf16x3: 60 KB of LDS)
-    const int64_t target = (mode == DR_GEMM_BF16X3 && N > 32) ? 512 : 768;
-    int64_t split = target / tiles;
-    const int64_t max_split = (M + 8 * BK - 1) / (8 * BK);     // at least 8 k-tiles per block
-    if (split > max_split) split = max_split;
-    if (split < 1) split = 1;
-    if (split > 65535) split = 65535;
-    return (int)split;
+    // resident blocks of one wave of the grid: 256 CUs x 3 (native wide tile) or x 2 (bf16x3: 60 KB of LDS per block)
+    const int64_t slots = (mode == DR_GEMM_BF16X3 && N > 32) ? 512 : 768;
+    int64_t max_split = (M + 8 * BK - 1) / (8 * BK);           // at least 8 k-tiles per block
+    if (max_split > 64) max_split = 64;
+    if (max_split < 1) max_split = 1;
+    // fill whole waves of resident blocks: the smallest split whose last wave is (nearly) as full as the best one
+    // (28 tiles: 18 or 27 splits = 98 %; 196 tiles (1677 x 1677 cross wgrad): 5 splits = 96 % instead of 2 = 77 %)
+    double best = 0.0;
+    for (int64_t sp = 1; sp <= max_split; ++sp) {
+        const int64_t blocks = tiles * sp, waves = (blocks + slots - 1) / slots;
+        const double eff = (double)blocks / (double)(waves * slots);
+        if (eff > best) best = eff;
+    }
+    for (int64_t sp = 1; sp <= max_split; ++sp) {
+        const int64_t blocks = tiles * sp, waves = (blocks + slots - 1) / slots;
+        if ((double)blocks / (double)(waves * slots) >= 0.95 * best) return (int)sp;
+    }
+    return 1;
 }
 static int dw_split(int64_t M, int32_t K, int32_t N) {
     return dw_split_for(M, K, N, g_gemm_mode.load(std::memory_order_relaxed));
