@@ -1,6 +1,11 @@
-// K7 / K8 — fp32 GEMMs on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact-f32 products, the
-// reference's parity bar is 1e-5 relative on the loss so no reduced-precision path) with the layer's
-// elementwise tail fused into the epilogue:
+// K7 / K8 — fp32 GEMMs on the gfx950 matrix cores with the layer's elementwise tail fused into the epilogue.  Inputs,
+// outputs and accumulators are fp32 (the reference's parity bar is 1e-5 relative on the loss: no reduced-precision
+// path).  Two ways of forming the products, same results to fp32 rounding (dr_set_gemm_mode, include/dr_hotpath.h):
+//   native   v_mfma_f32_32x32x2_f32
+//   bf16x3   every operand value split exactly into three bf16 terms on its way into LDS, six
+//            v_mfma_f32_32x32x16_bf16 products per fp32 product (the fp32 MFMA runs at 1/16 of the bf16 rate, so this
+//            has a 2.65x higher ceiling); default for the wide-tile tower / cross GEMMs
+// Entry points:
 //   fwd     y   = act(x @ W + b)                       (Dense: keras deepfm.py:30-34, estimator dnn.py:17-29)
 //   cross   out = x0 * (x @ W + b + diag*x) + x        (Cross.call: keras dcn.py:81-88)
 //   bwd_dx  dx  = (dy @ W^T) * (relu_src > 0) [+ dx]   (autodiff of the above)
@@ -16,13 +21,13 @@
 //   - an operand already reduction-major (a[r*ld + i]: W in fwd, x and dy in bwd_dw) goes in with
 //     ds_write_b128 at pitch 132 floats.
 // Fragment reads are ds_read_b32 of 32 consecutive floats per half-wave: conflict-free in both cases.
+// (bf16x3 mode keeps three bf16 planes [i][k] instead, see put4_bf3 below.)
 // Consecutive workgroup ids are remapped so that the tiles sharing an A row-panel run on the same XCD
 // (same L2): dispatch places block b on XCD b % 8.
 #include "dr_common.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 #include <atomic>
 #include <cstdlib>
-#include <type_traits>
 
 namespace {
 
@@ -132,14 +137,6 @@ __device__ __forceinline__ float4 fix4(f4u v, EdgeFix e) {
 // x = x0 + x1 + x2 with x0 = bf16_rn(x), x1 = bf16_rn(x - x0), x2 = bf16_rn(x - x0 - x1): |x1| <= 2^-8 |x|, |x2| <= 2^-16 |x|,
 // the two subtractions are exact in fp32.  a * b ~= a0b0 + (a0b1 + a1b0) + (a0b2 + a1b1 + a2b0); every bf16 x bf16 product
 // is exact in the MFMA's fp32 accumulator and the dropped terms (a1b2, a2b1, a2b2) are below 2^-24 |ab|.
-// compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, N) -- every index a constant expression
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
