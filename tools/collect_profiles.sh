@@ -13,6 +13,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$c -- $BENCH > /dev/null 2>&1
 done
 python $R/tools/pmc_traffic.py $R/gpurun_out/pmc_traffic.json $(find $R/gpurun_out/pmc_FETCH_SIZE $R/gpurun_out/pmc_WRITE_SIZE -name "*counter_collection.csv") > $R/gpurun_out/pmc_traffic.txt 2>&1
-STATS=$(find $R/gpurun_out/prof_stats -name "*kernel_stats.csv" | head -1)
+STATS=$(ls -t $(find $R/gpurun_out/prof_stats -name "*kernel_stats.csv") | head -1)
 [ -n "$STATS" ] && cp "$STATS" $R/gpurun_out/kernel_stats.csv
+TRACE=$(ls -t $(find $R/gpurun_out/prof_stats -name "*kernel_trace.csv") | head -1)
+[ -n "$TRACE" ] && python $R/tools/trace_timed_stats.py "$TRACE" --last 20 > $R/gpurun_out/kernel_stats_timed.csv
 tail -1 $R/gpurun_out/prof_stats_bench.log | cut -c1-300
