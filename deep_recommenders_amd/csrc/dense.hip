@@ -59,7 +59,6 @@ struct GemmArgs {
     int32_t split;            // ATOMIC: number of reduction splits (gridDim.y)
     float* partial;           // ATOMIC: if non-null, block (tile, y) stores its tile to partial[y][M][N] instead of atomics
     int32_t a_vec, b_vec;     // operand base 16-B aligned and ld % 4 == 0 -> float4 loads allowed
-    int32_t native_only;      // never take the bf16x3 product path (retrieval scores: must tie bit-exactly with the FILTER / LSE kernels)
     // FMGRAD: C = acc + dl[i] * (S[i][j % fm_D] - x[i][j]) for j < fm_FD   (e0 = x, e1 = S [M, fm_D])
     const float* vec; int32_t fm_D, fm_FD;
     // LSE / SMGRAD (in-batch softmax, Retrieval.call): score s_ij = (acc - log p_j + dupmask_ij * MIN_FLOAT) * inv_t
@@ -774,13 +773,19 @@ int launch(GemmArgs& g, hipStream_t s) {
             // short reductions with heavy epilogues (the two-tower rows: K = 128 = 4 k-tiles per output tile): the per-tile
             // prologue / epilogue weigh more than the steady-state loop, so a fourth resident block per CU beats the pinned
             // prefetch (measured: in-batch softmax forward 0.343 -> 0.320 ms, top-K scan 26.65 -> 25.65 ms; plain scores: no)
-            if (g.R <= 256)
+            // the top-K scan follows the GEMM mode (bf16x3 products: 25.7 -> 23.3 ms at 8192 x 1 M x 128) together with
+            // dr_scores_nt, which scores its first chunk: equal candidates must tie bit-exactly across the two kernels.
+            // The in-batch softmax pair (LSE forward / gradient) stays on the fp32 MFMA (bf16x3 measured 3 % slower there).
+            if (EPI == EPI_FILTER && g_gemm_mode.load(std::memory_order_relaxed) == DR_GEMM_BF16X3) {
+                if constexpr (EPI == EPI_FILTER)
+                    hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_RC, B_RC, EPI, false, false, true>), grid, dim3(256), 0, s, g);
+            } else if (g.R <= 256)
                 hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_RC, B_RC, EPI, false, true>), grid, dim3(256), 0, s, g);
             else
                 hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_RC, B_RC, EPI, false>), grid, dim3(256), 0, s, g);
         } else if constexpr (EPI == EPI_BIAS_ACT || EPI == EPI_CROSS || EPI == EPI_MASK || EPI == EPI_FMGRAD || EPI == EPI_ATOMIC) {
             // the tower / cross-layer GEMMs: fp32 products on the bf16 matrix pipe unless the caller asked for the native one
-            if (!g.native_only && g_gemm_mode.load(std::memory_order_relaxed) == DR_GEMM_BF16X3)
+            if (g_gemm_mode.load(std::memory_order_relaxed) == DR_GEMM_BF16X3)
                 hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_RC, B_RC, EPI, false, false, true>), grid, dim3(256), 0, s, g);
             else
                 hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_RC, B_RC, EPI, false>), grid, dim3(256), 0, s, g);
@@ -1276,7 +1281,6 @@ extern "C" int dr_scores_nt(const float* a, int64_t lda, const float* b, int64_t
     if (!a || !b || !out) return DR_EINVAL;
     GemmArgs g{};
     g.A = a; g.lda = lda; g.B = b; g.ldb = ldb; g.M = M; g.N = N; g.R = D; g.C = out; g.ldc = ld_out; g.split = 1;
-    g.native_only = 1;      // same products as the filtered / softmax score kernels: equal candidates must tie bit-exactly
     return launch<true, true, EPI_BIAS_ACT>(g, dr_s(stream));
 }
 

@@ -39,7 +39,8 @@ typedef void* dr_stream_t; /* hipStream_t */
 /* Library self-description: returns the gfx arch string the kernels were compiled for. */
 const char* dr_version(void);
 
-/* How the fp32 GEMMs of the tower and cross layers (dr_linear_fwd / _bwd_dx / _bwd_dx_fm / _bwd_dw, dr_cross_fwd) form
+/* How the fp32 GEMMs of the tower and cross layers (dr_linear_fwd / _bwd_dx / _bwd_dx_fm / _bwd_dw, dr_cross_fwd) and the
+ * top-K score kernels (dr_scores_nt, the scan inside dr_topk_mips -- always the same mode, so equal candidates tie) form
  * their products.  Inputs, outputs and accumulators are fp32 in both modes; the reference's own ops are tf.matmul on
  * fp32 tensors (keras/models/ranking/deepfm.py:30-34, dcn.py:81-88), compared at 1e-5 on the loss.
  *   DR_GEMM_BF16X3      (default) every operand value x is split exactly into three bf16 terms x0 + x1 + x2 and a * b is
