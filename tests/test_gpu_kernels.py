@@ -197,7 +197,7 @@ def test_fm2_fwd_bwd(ops):
 
 # ---------------------------------------------------------------- K7
 @pytest.mark.parametrize("M,K,N,act", [(1, 3, 1, 0), (130, 70, 33, 1), (257, 1677, 256, 1), (512, 256, 32, 1), (100, 32, 1, 0),
-                                       (300, 129, 131, 0)])
+                                       (300, 129, 131, 0), (64, 20, 40, 1), (33, 16, 72, 0), (200, 31, 36, 1)])
 def test_linear_fwd_bwd(ops, M, K, N, act):
     rng = np.random.default_rng(5)
     x = rng.standard_normal((M, K)).astype(np.float32)
