@@ -57,6 +57,7 @@ struct GemmArgs {
     int32_t accumulate;       // MASK: add to existing C
     float* colsum_dst;        // ATOMIC: dstb (may be null)
     int32_t split;            // ATOMIC: number of reduction splits (gridDim.y)
+    int64_t per;              // ATOMIC: reduction rows per split (multiple of BK)
     float* partial;           // ATOMIC: if non-null, block (tile, y) stores its tile to partial[y][M][N] instead of atomics
     int32_t a_vec, b_vec;     // operand base 16-B aligned and ld % 4 == 0 -> float4 loads allowed
     // FMGRAD: C = acc + dl[i] * (S[i][j % fm_D] - x[i][j]) for j < fm_FD   (e0 = x, e1 = S [M, fm_D])
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(256, BF3 ? 2 : ((NARROW || OCC4) ? 4 : 3)) void gem
     // reduction range of this block (split-K only for EPI_ATOMIC)
     int64_t r_begin = 0, r_end = g.R;
     if (EPI == EPI_ATOMIC) {
-        const int64_t per = ((g.R + g.split - 1) / g.split + BK - 1) / BK * BK;
+        const int64_t per = g.per;                                // host-computed: every launched slice is non-empty
         r_begin = (int64_t)blockIdx.y * per;
         r_end = r_begin + per < g.R ? r_begin + per : g.R;
         if (r_begin >= r_end) return;
@@ -1130,6 +1131,14 @@ extern "C" int dr_linear_bwd_dw(const float* x, int64_t ld_x, const float* dy, i
     g.A = x; g.lda = ld_x; g.B = dy; g.ldb = ld_dy; g.M = K; g.N = N; g.R = M; g.C = dstW; g.ldc = ld_w;
     g.alpha = scale; g.colsum_dst = dstb;
     g.split = dw_split(M, K, N);
+    {
+        // a grid.y slice covers `per` = roundup(ceil(M / split), BK) reduction rows, so trailing slices can be EMPTY
+        // (M = 8192, split = 31: per = 288, slices 29 and 30 start past M).  An empty block would return before storing
+        // its partial tile while the reduce still summed that (uninitialised) workspace slice: launch and reduce the
+        // effective number of slices only.
+        g.per = ((M + g.split - 1) / g.split + BK - 1) / BK * BK;
+        g.split = (int32_t)((M + g.per - 1) / g.per);
+    }
     const bool use_ws = workspace != nullptr && workspace_bytes >= dr_linear_bwd_dw_workspace_bytes(M, K, N) && g.split > 1;
     g.partial = use_ws ? workspace : nullptr;
     int rc = launch<false, false, EPI_ATOMIC>(g, dr_s(stream));

@@ -157,7 +157,14 @@ class IdentityCategoricalColumn(CategoricalColumn):
         return {"key": self.key, "num_buckets": self.num_buckets}
 
     def ids(self, value, device="cuda"):
-        return self._int_matrix(value, device)
+        ids = self._int_matrix(value, device)
+        # [TF] categorical_column_with_identity asserts 0 <= id < num_buckets (negative ids mean "missing" here, as in the
+        # hashed / vocabulary columns).  The gather / scatter kernels trust the range: an id past num_buckets would read or
+        # update another field's rows of the shared slab, so it is checked here (one small reduction + host read).
+        if ids.numel() and int(ids.max()) >= self.num_buckets:
+            raise ValueError("IdentityCategoricalColumn(%r): id %d is out of range [0, %d)"
+                             % (self.key, int(ids.max()), self.num_buckets))
+        return ids
 
 
 class IndicatorColumn:

@@ -106,6 +106,33 @@ class _ScoresFn(torch.autograd.Function):
         return dq, dc
 
 
+class _ExplicitSoftmaxFn(torch.autograd.Function):
+    """num_candidates != num_queries (labels = tf.eye(num_queries, num_candidates), sbcnm.py:131-134): the same call sequence
+    on the explicit [Bq, Nc] score matrix -- scores -> corrections -> CCE(from_logits, SUM) -- with the row-softmax kernels
+    and the MFMA GEMMs in both directions.  (The fused K9 kernels are square: one candidate per query.)"""
+
+    @staticmethod
+    def forward(ctx, q, c, sample_weight, cand_prob, cand_ids, inv_t):
+        scores = ops.scores_nt(q, c).contiguous()
+        labels = torch.eye(scores.shape[0], scores.shape[1], device=scores.device)
+        if cand_prob is not None or cand_ids is not None:
+            scores = ops.logits_adjust(scores, labels, cand_prob=cand_prob, cand_ids=cand_ids)
+        ctx.inv_t = inv_t
+        ctx.save_for_backward(q, c, scores, labels, sample_weight)
+        return ops.softmax_ce_rows(scores, labels, inv_t, sample_weight)
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        q, c, scores, labels, w = ctx.saved_tensors
+        G = ops.softmax_ce_rows_bwd(scores, labels, ctx.inv_t, w, float(d_loss))
+        dq = ops.linear_fwd(G, c) if ctx.needs_input_grad[0] else None              # dq = G @ c
+        dc = None
+        if ctx.needs_input_grad[1]:
+            dc = torch.zeros_like(c)
+            ops.linear_bwd_dw(G, q, 1.0, dc)                                          # dc = G^T @ q
+        return dq, dc, None, None, None, None
+
+
 class _HardNegativeSoftmaxFn(torch.autograd.Function):
     """num_hard_negatives branch (sbcnm.py:145-151): scores -> corrections -> top-(h+1) by `logits + labels * MAX_FLOAT`
     -> CCE(from_logits, SUM).  The selection is piecewise constant, so the gradient flows only through the kept scores:
@@ -115,7 +142,7 @@ class _HardNegativeSoftmaxFn(torch.autograd.Function):
     def forward(ctx, q, c, sample_weight, cand_prob, cand_ids, inv_t, num_hard_negatives):
         scores = ops.scores_nt(q, c).contiguous()
         B = scores.shape[0]
-        labels = torch.eye(B, device=scores.device)
+        labels = torch.eye(B, scores.shape[1], device=scores.device)
         if cand_prob is not None or cand_ids is not None:
             scores = ops.logits_adjust(scores, labels, cand_prob=cand_prob, cand_ids=cand_ids)
         num_sampled = min(num_hard_negatives + 1, scores.shape[1])
@@ -176,7 +203,14 @@ class Retrieval(nn.Module):
         if self._loss is not None:
             loss = self._custom_loss(q, c, w, cp, ci, inv_t)
         elif self._num_hard_negatives is None:
-            loss = _InBatchSoftmaxFn.apply(q, c, w, cp, ci, inv_t)                       # :129-151 fused
+            for name, t, n in (("sample_weight", w, q.shape[0]), ("candidate_sampling_probability", cp, c.shape[0]),
+                               ("candidate_ids", ci, c.shape[0])):
+                if t is not None and t.numel() != n:
+                    raise ValueError("%s must have %d elements, got %d" % (name, n, t.numel()))
+            if c.shape[0] == q.shape[0]:
+                loss = _InBatchSoftmaxFn.apply(q, c, w, cp, ci, inv_t)                   # :129-151 fused
+            else:
+                loss = _ExplicitSoftmaxFn.apply(q, c, w, cp, ci, inv_t)                  # eye(num_queries, num_candidates)
         else:
             loss = self._hard_negative_loss(q, c, w, cp, ci, inv_t)
         if compute_metrics is False or not self._factorized_metrics:                     # :153-157

@@ -420,6 +420,7 @@ class SortPlan:
     """Per-batch outputs of dr_emb_sort_slots (all preallocated, reusable across steps)."""
 
     def __init__(self, n, device):
+        self.n = int(n)                      # capacity in slots: a plan serves any batch of <= n slots
         self.rows = torch.empty(n, dtype=torch.int64, device=device)
         self.slots = torch.empty(n, dtype=torch.int32, device=device)
         self.flags = torch.empty(n, dtype=torch.uint8, device=device)
@@ -431,7 +432,7 @@ class SortPlan:
 def emb_sort_slots(ids, row_base, num_rows, plan=None):
     ids = _c(ids, torch.int64)
     B, F = ids.shape
-    if plan is None:
+    if plan is None or plan.n < B * F:       # a reused plan sized for a smaller batch would be rejected (DR_EINVAL)
         plan = SortPlan(B * F, ids.device)
     check(lib().dr_emb_sort_slots(ptr(ids), B, F, ptr(row_base), int(num_rows), ptr(plan.rows), ptr(plan.slots),
                                   ptr(plan.flags), ptr(plan.dup_heads), ptr(plan.dup_count), ptr(plan.workspace),
@@ -504,9 +505,21 @@ def linear_bwd_dx_fm(dy, W, d_fm_logit, sum_x, concat, D, FD, out):
 # ----------------------------------------------------------------------------------------------
 # K9 / K10   two-tower retrieval
 # ----------------------------------------------------------------------------------------------
+def _check_inbatch_shapes(q, c, cand_prob, cand_ids, sample_weight):
+    """The fused K9 kernels assume a square in-batch problem (one candidate per query): they take B from q and index every
+    per-candidate / per-query vector with it.  Anything else must go through the explicit score matrix (sbcnm.Retrieval does)."""
+    B, D = q.shape
+    if c.dim() != 2 or c.shape[0] != B or c.shape[1] != D:
+        raise ValueError("in-batch softmax kernels need candidates of shape %s, got %s" % ((B, D), tuple(c.shape)))
+    for name, t in (("candidate_sampling_probability", cand_prob), ("candidate_ids", cand_ids), ("sample_weight", sample_weight)):
+        if t is not None and t.numel() != B:
+            raise ValueError("%s must have %d elements, got %d" % (name, B, t.numel()))
+
+
 def inbatch_softmax_fwd(q, c, cand_prob=None, cand_ids=None, sample_weight=None, inv_temperature=1.0):
     q = _c(q, torch.float32)
     c = _c(c, torch.float32)
+    _check_inbatch_shapes(q, c, cand_prob, cand_ids, sample_weight)
     B, D = q.shape
     dev = q.device
     row_lse = torch.empty(B, dtype=torch.float32, device=dev)
@@ -522,6 +535,7 @@ def inbatch_softmax_fwd(q, c, cand_prob=None, cand_ids=None, sample_weight=None,
 
 def inbatch_softmax_grad_scores(q, c, row_lse, d_loss, cand_prob=None, cand_ids=None, sample_weight=None,
                                 inv_temperature=1.0):
+    _check_inbatch_shapes(q, c, cand_prob, cand_ids, sample_weight)
     B, D = q.shape
     G = torch.empty((B, _pad4(B)), dtype=torch.float32, device=q.device)[:, :B]
     check(lib().dr_inbatch_softmax_grad_scores(ptr(q), ptr(c), B, D, ptr(cand_prob), ptr(cand_ids), ptr(sample_weight),

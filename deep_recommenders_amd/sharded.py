@@ -43,6 +43,7 @@ class HipPrims:
     emb_pool_bwd = staticmethod(ops.emb_pool_bwd)
     emb_pack_grads = staticmethod(ops.emb_pack_grads)
     emb_sort_slots = staticmethod(ops.emb_sort_slots)
+    new_sort_plan = staticmethod(ops.SortPlan)
     emb_pool_bwd_sorted = staticmethod(ops.emb_pool_bwd_sorted)
     linear_fwd = staticmethod(ops.linear_fwd)
     linear_bwd_dx = staticmethod(ops.linear_bwd_dx)
@@ -113,7 +114,9 @@ class ShardedEmbeddingExchange:
             sl["rows_pad"] = torch.full((cap,), -1, dtype=torch.int64, device=device)
             sl["g_pad"] = torch.zeros((cap, self.D), dtype=torch.float32, device=device)
             sl["gl_pad"] = torch.zeros(cap, dtype=torch.float32, device=device)
-            sl["plan"] = None
+            # the sort plan is sized for the slot CAPACITY, not for the batch that triggered the growth: n_recv varies from
+            # batch to batch, and a later batch with old n_pad < need <= cap must find a large enough workspace
+            sl["plan"] = self.p.new_sort_plan(cap, device) if hasattr(self.p, "new_sort_plan") else None
             sl["cap"] = cap
         return need
 
@@ -414,11 +417,20 @@ class ShardedDeepFMEngine:
     def _route_batch(self, keys, wait_current):
         return [self.ex.route(keys[sl], hashed=True, wait_current=wait_current) for sl in self._mb_slices()]
 
-    def prefetch_route_begin(self, next_keys):
+    @staticmethod
+    def _keys_tag(keys):
+        # identity of a key batch: buffer, shape AND torch's in-place version counter -- a loader that refills the same device
+        # buffer between steps bumps the version, so a route prefetched for the old contents is not reused
+        return (keys.data_ptr(), tuple(keys.shape), keys._version)
+
+    def prefetch_route_begin(self, next_keys, ready_event=None):
         """Start routing the NEXT batch (hash, bucket, split-size exchange) on the routing stream; nothing blocks.
-        `next_keys` must already be complete (it is not ordered against the training stream)."""
+        `next_keys` must already be complete, or `ready_event` (recorded by the producer after writing it) must be given:
+        the routing stream is deliberately not ordered against the training stream."""
+        if ready_event is not None and self._cuda:
+            self.ex._rs.wait_event(ready_event)
         self._route = ([self.ex.route_begin(next_keys[sl], hashed=True, wait_current=False) for sl in self._mb_slices()],
-                       (next_keys.data_ptr(), tuple(next_keys.shape)))
+                       self._keys_tag(next_keys))
 
     def prefetch_route_finish(self):
         """Finish it (id exchange, owner-side sort).  The split sizes were exchanged long ago: the host wait is nominal."""
@@ -426,7 +438,7 @@ class ShardedDeepFMEngine:
             for r in self._route[0]:
                 self.ex.route_finish(r)
 
-    def train_step(self, keys, dense, labels, next_keys=None):
+    def train_step(self, keys, dense, labels, next_keys=None, next_keys_ready=None):
         """One step.  The rank's batch is processed as `self.mb` micro-batches that share one set of weights (all
         forwards read pre-update tables; the dense gradients are summed; the loss is the mean over world * B examples):
         micro-batch m+1's row exchange is in flight while micro-batch m runs its tower, and micro-batch m's gradient
@@ -438,7 +450,7 @@ class ShardedDeepFMEngine:
             self._done.pop(0).synchronize()
         # steps 1-3: use the prefetched routes if they were built for exactly these keys, else route now
         routes = None
-        if self._route is not None and self._route[1] == (keys.data_ptr(), tuple(keys.shape)):
+        if self._route is not None and self._route[1] == self._keys_tag(keys):
             self.prefetch_route_finish()          # no-op when the previous step already finished it
             routes = self._route[0]
         self._route = None
@@ -464,7 +476,7 @@ class ShardedDeepFMEngine:
                     ev_rows.append(ev)
         if next_keys is not None:
             # split sizes of the NEXT batch: queued right behind this step's row fetches, long before they are needed
-            self.prefetch_route_begin(next_keys)
+            self.prefetch_route_begin(next_keys, next_keys_ready)
         self.flat_grads.zero_()
         if self.Nd:
             self.concat[:, F * D:F * D + self.Nd].copy_(dense)

@@ -226,6 +226,30 @@ def test_linear_fwd_bwd(ops, M, K, N, act):
         np.testing.assert_allclose(db.cpu().numpy(), dy.astype(np.float64).sum(0), rtol=0, atol=1e-5 * np.sqrt(M) * 4)
 
 
+@pytest.mark.parametrize("M,K,N", [(8192, 512, 256), (16384, 256, 32), (10000, 300, 64), (5000, 512, 256)])
+@pytest.mark.parametrize("mode", ["bf16x3", "native"])
+def test_linear_bwd_dw_splitk_ignores_unwritten_workspace(ops, M, K, N, mode):
+    """Split-K wgrad with a workspace: trailing reduction slices can be empty (M = 8192, K = 512, N = 256 -> 31 slices of 288
+    rows, the last two start past M).  The reduce must not sum them: the workspace is poisoned with NaN."""
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    dy = rng.standard_normal((M, N)).astype(np.float32)
+    want = x.T.astype(np.float64) @ dy.astype(np.float64)
+    prev = ops.get_gemm_mode()
+    ops.set_gemm_mode(mode)
+    try:
+        ws = ops.linear_bwd_dw_workspace(M, K, N, "cuda")
+        ws.fill_(float("nan"))
+        dW = torch.zeros((K, N), device="cuda")
+        db = torch.zeros(N, device="cuda")
+        ops.linear_bwd_dw(_dev(x), _dev(dy), 1.0, dW, db, workspace=ws)
+    finally:
+        ops.set_gemm_mode(prev)
+    got = dW.cpu().numpy()
+    assert np.isfinite(got).all(), "an unwritten split-K slice was summed into the weights"
+    np.testing.assert_allclose(got, want, rtol=0, atol=4e-6 * np.sqrt(M) * (np.abs(want).max() + 1))
+
+
 @pytest.mark.parametrize("M,K,N,mask", [(32, 128, 32, True), (96, 256, 32, True), (4096, 256, 32, True),
                                           (640, 256, 17, False), (2048, 512, 32, True), (64, 128, 1, True),
                                           (32 * 700, 256, 32, True)])
