@@ -15,10 +15,13 @@
  *   where Fingerprint64 is FarmHash `farmhashna::Hash64` (Google FarmHash 1.1,
  *   published algorithm restated below from its specification).
  *
- * Pinning status: the 1-3 / 4-7 / 8-16 byte branches are pinned by the
- * upstream known-answer vectors in tests/golden/farmhash_vectors.json.  The 17-32,
- * 33-64 and >64 byte branches have NO external vector available in this container
- * ("parity unpinned" for keys longer than 16 bytes).
+ * Pinning status (oracle/README.md): the 1-3 / 4-7 / 8-16 byte branches are pinned by the upstream
+ * TensorFlow vectors in tests/golden/reference_kats.json; the whole 0..32-byte range (so every
+ * decimal rendering of an int64 key) by third-party CityHash64 answers in
+ * tests/golden/cityhash64_le32_vectors.json (farmhashna::Hash64 == CityHash64 v1.1 up to 32 bytes).
+ * The 33-64 and >64 byte branches have NO external vector available in this container: they are
+ * cross-checked against an independent Python restatement (tests/test_oracle_pinning.py) only --
+ * "parity unpinned" for byte strings longer than 32 bytes.
  */
 #include <stdint.h>
 #include <string.h>

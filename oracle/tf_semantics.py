@@ -61,7 +61,9 @@ def fingerprint64(data: bytes) -> int:
 
 
 def fingerprint64_py(data: bytes) -> int:
-    """Pure-Python second restatement (small inputs only) used to cross-check the C one."""
+    """Pure-Python second restatement of farmhashna::Hash64 (every length branch), written independently of the C one
+    (Python big ints masked to 64 bits, the long loop as a state dict) and used to cross-check it: tests fuzz C against
+    this over lengths 0..300.  Slow: small inputs only."""
     M = (1 << 64) - 1
     k0, k1, k2 = 0xC3A5C85C97CB3127, 0xB492B66FBE98F273, 0x9AE16A3B2F90404F
     f64 = lambda p: int.from_bytes(data[p:p + 8], "little")
@@ -101,7 +103,67 @@ def fingerprint64_py(data: bytes) -> int:
         d = (f64(n - 16) * k2) & M
         return hl16((rot((a + b) & M, 43) + rot(c, 30) + d) & M,
                     (a + rot((b + k2) & M, 18) + c) & M, mul)
-    raise NotImplementedError("pure-python cross-check covers keys up to 32 bytes")
+    if n <= 64:
+        mul = (k2 + n * 2) & M
+        a = (f64(0) * k2) & M
+        b = f64(8)
+        c = (f64(n - 8) * mul) & M
+        d = (f64(n - 16) * k2) & M
+        y = (rot((a + b) & M, 43) + rot(c, 30) + d) & M
+        z = hl16(y, (a + rot((b + k2) & M, 18) + c) & M, mul)
+        e = (f64(16) * mul) & M
+        f = f64(24)
+        g = ((y + f64(n - 32)) * mul) & M
+        h = ((z + f64(n - 24)) * mul) & M
+        return hl16((rot((e + f) & M, 43) + rot(g, 30) + h) & M, (e + rot((f + a) & M, 18) + g) & M, mul)
+
+    # > 64 bytes: 56 bytes of running state (x, y, z and the pairs v, w), 64-byte blocks, the last 64 bytes (overlapping)
+    # mixed with a multiplier derived from z
+    def weak(p, a, b):
+        w_, x_, y_, z_ = f64(p), f64(p + 8), f64(p + 16), f64(p + 24)
+        a = (a + w_) & M
+        b = rot((b + a + z_) & M, 21)
+        c = a
+        a = (a + x_ + y_) & M
+        b = (b + rot(a, 44)) & M
+        return (a + z_) & M, (b + c) & M
+
+    st = {"x": 81, "y": (81 * k1 + 113) & M}
+    st["z"] = (smix((st["y"] * k2 + 113) & M) * k2) & M
+    v, w = (0, 0), (0, 0)
+    st["x"] = (st["x"] * k2 + f64(0)) & M
+    end = ((n - 1) // 64) * 64
+    last64 = end + ((n - 1) & 63) - 63
+
+    def block(p, mul, tail):
+        nonlocal v, w
+        x, y, z = st["x"], st["y"], st["z"]
+        x = (rot((x + y + v[0] + f64(p + 8)) & M, 37) * mul) & M
+        y = (rot((y + v[1] + f64(p + 48)) & M, 42) * mul) & M
+        if tail:
+            x ^= (w[1] * 9) & M
+            y = (y + v[0] * 9 + f64(p + 40)) & M
+        else:
+            x ^= w[1]
+            y = (y + v[0] + f64(p + 40)) & M
+        z = (rot((z + w[0]) & M, 33) * mul) & M
+        v = weak(p, (v[1] * mul) & M, (x + w[0]) & M)
+        w = weak(p + 32, (z + w[1]) & M, (y + f64(p + 16)) & M)
+        st["x"], st["y"], st["z"] = z, y, x          # z and x trade places
+
+    p = 0
+    while True:
+        block(p, k1, False)
+        p += 64
+        if p == end:
+            break
+    mul = (k1 + ((st["z"] & 0xFF) << 1)) & M
+    w = ((w[0] + ((n - 1) & 63)) & M, w[1])
+    v = ((v[0] + w[0]) & M, v[1])
+    w = ((w[0] + v[0]) & M, w[1])
+    block(last64, mul, True)
+    x, y, z = st["x"], st["y"], st["z"]
+    return hl16((hl16(v[0], w[0], mul) + (smix(y) * k0) + z) & M, (hl16(v[1], w[1], mul) + x) & M, mul)
 
 
 def hash_bucket_i64(keys: np.ndarray, num_buckets: int) -> np.ndarray:

@@ -1,0 +1,323 @@
+"""Oracle parity of the EXACT configurations bench.py times.
+
+Every other engine-level test uses toy shapes, where the benched orchestration is switched off (first-layer wgrad on a
+second stream racing the fused K4, the wide-tile GEMM at K = 1677 / N = 256, the LPR = 16 single-valued gather kernel,
+the row-ordered K4 at 1.7 M slots, the fused tower head at 65 536 rows).  Here the engines run exactly as `bench.py` builds
+them -- B = 65 536, F = 26, D = 64, 13 dense, DNN [256, 32], hashed raw keys, default GEMM mode, `overlap_dw` on -- for two
+consecutive steps against the host oracle (oracle/torch_ref.py under torch autograd, fp32 like the reference's TF-CPU path).
+
+The host never holds the tables: the rows the two batches touch are gathered from HBM before the first step (at most
+2 x 1.7 M rows = 0.9 GB), the oracle trains that compact table, and afterwards (a) the touched rows are compared row by row,
+(b) a sample of untouched rows must be bit-identical to their initial values.  That makes the full-size table (V = 10 M per
+field, 66.6 GB: the bench's own) testable, not only V = 1 M.
+
+Tolerances (written where they are used): ids bit-exact; loss 1e-5 relative (north_star); parameters compared through their
+UPDATE (after - before) so that a wrong or missing gradient cannot hide behind the size of the weights: |d_gpu - d_cpu| <=
+2 ulp(weight) + 2e-3 * |d_cpu| + 1e-3 * rms(d_cpu) for SGD; 2 % of one Adam step for Adam (as in test_gpu_models.py).
+The SGD tests use lr = 1.0 instead of bench.py's 0.01: the learning rate is a scalar the kernels multiply by, and at 0.01 a row's
+update (~1e-8) is below the fp32 spacing of the row itself (7e-9), i.e. invisible to any comparison.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import tf_semantics as O
+from oracle import torch_ref as T
+
+F, D, ND, B, DNN = 26, 64, 13, 65536, [256, 32]
+
+
+def _batches(n, kind, seed):
+    """bench.py:synth_batches (same distributions), its own generator seed"""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    out = []
+    for _ in range(n):
+        if kind == "uniform":
+            keys = torch.randint(0, 10**16, (B, F), device="cuda", generator=g)
+        else:
+            u = torch.rand((B, F), device="cuda", generator=g, dtype=torch.float64)
+            al, nn = 1.05, float(10**12)
+            keys = (((nn ** (1 - al) - 1) * u + 1) ** (1 / (1 - al))).long().clamp(1, 10**12)
+        dense = torch.log1p(torch.randn((B, ND), device="cuda", generator=g).abs())
+        labels = (torch.rand(B, device="cuda", generator=g) < 0.25).float()
+        out.append((keys, dense, labels))
+    return out
+
+
+def _oracle_ids(keys, V):
+    k = keys.cpu().numpy()
+    return np.stack([O.hash_bucket_i64(k[:, f], V) for f in range(F)], axis=1)
+
+
+def _ulp(x):
+    return np.spacing(np.abs(x).astype(np.float32)).astype(np.float64)
+
+
+def _assert_update(name, before, after, want_after, rel=2e-3):
+    """after - before (device) against want_after - before (oracle), see the module docstring"""
+    b64 = before.astype(np.float64)
+    d_gpu, d_cpu = after.astype(np.float64) - b64, want_after.astype(np.float64) - b64
+    rms = float(np.sqrt(np.mean(d_cpu * d_cpu)))
+    assert rms > 0, name + ": the oracle update is identically zero (test is vacuous)"
+    tol = 2 * np.maximum(_ulp(before), _ulp(want_after)) + rel * np.abs(d_cpu) + 1e-3 * rms
+    bad = np.abs(d_gpu - d_cpu) > tol
+    assert not bad.any(), "%s: %d of %d elements off; worst |err| %.3e at update %.3e (rms update %.3e)" % (
+        name, int(bad.sum()), bad.size, float(np.abs(d_gpu - d_cpu)[bad].max()), float(np.abs(d_cpu)[bad].max()), rms)
+
+
+class _CompactOracle:
+    """DeepFM training steps on the rows a set of batches touches (oracle/torch_ref.py math, torch autograd for the gradients,
+    [TF] B15 Adam from the same module)."""
+
+    def __init__(self, eng, ids_list, V, optimizer, lr):
+        base = np.arange(F, dtype=np.int64)[None, :] * V
+        rows = [i + base for i in ids_list]
+        self.U = np.unique(np.concatenate([r.reshape(-1) for r in rows]))
+        self.cidx = [torch.from_numpy(np.searchsorted(self.U, r)) for r in rows]
+        Ud = torch.from_numpy(self.U).cuda()
+        self.Ud = Ud
+        self.table = eng.table[Ud].cpu()
+        self.lin = eng.lin_w[Ud].cpu()
+        self.bias = eng.lin_bias.cpu().clone()
+        self.Ws = [w.cpu().clone().contiguous() for w in eng.Ws]
+        self.bs = [b.cpu().clone() for b in eng.bs]
+        self.table0, self.lin0 = self.table.clone(), self.lin.clone()
+        self.Ws0, self.bs0, self.bias0 = [w.clone() for w in self.Ws], [b.clone() for b in self.bs], self.bias.clone()
+        self.opt, self.lr, self.t = optimizer, lr, 0
+        if optimizer == "adam":
+            z = torch.zeros_like
+            self.mt, self.vt, self.ml, self.vl = z(self.table), z(self.table), z(self.lin), z(self.lin)
+            self.mb, self.vb = z(self.bias), z(self.bias)
+            self.mW, self.vW = [z(w) for w in self.Ws], [z(w) for w in self.Ws]
+            self.mB, self.vB = [z(b) for b in self.bs], [z(b) for b in self.bs]
+
+    def step(self, i, dense, labels):
+        cidx = self.cidx[i]
+        emb = self.table[cidx].requires_grad_(True)                      # [B, F, D]  single-valued fields: x = the row ([TF] B5)
+        lw = self.lin[cidx].requires_grad_(True)
+        bias = self.bias.clone().requires_grad_(True)
+        ks = [k.clone().requires_grad_(True) for k in self.Ws]
+        bs = [b.clone().requires_grad_(True) for b in self.bs]
+        x = torch.cat([emb.reshape(B, F * D), dense], 1)
+        logit = T.fm_second_order(emb) + lw.sum(1) + bias + T.dnn(x, ks, bs).squeeze(1)     # deepfm.py:36-47
+        loss = T.sigmoid_cross_entropy(labels, logit)                                        # train_fm_on_movielens_estimator.py:46
+        grads = torch.autograd.grad(loss, [emb, lw, bias] + ks + bs)
+        gt = torch.zeros_like(self.table).index_add_(0, cidx.reshape(-1), grads[0].reshape(-1, D))
+        gl = torch.zeros_like(self.lin).index_add_(0, cidx.reshape(-1), grads[1].reshape(-1))
+        n = len(ks)
+        self.t += 1
+        with torch.no_grad():
+            if self.opt == "sgd":
+                self.table -= self.lr * gt
+                self.lin -= self.lr * gl
+                self.bias -= self.lr * grads[2]
+                for j in range(n):
+                    self.Ws[j] -= self.lr * grads[3 + j]
+                    self.bs[j] -= self.lr * grads[3 + n + j]
+            else:
+                touched = torch.unique(cidx.reshape(-1))
+                T.adam_rows_step(self.table, gt, touched, self.mt, self.vt, self.lr, self.t)
+                T.adam_rows_step(self.lin, gl, touched, self.ml, self.vl, self.lr, self.t)
+                T.adam_dense_step(self.bias, grads[2], self.mb, self.vb, self.lr, self.t)
+                for j in range(n):
+                    T.adam_dense_step(self.Ws[j], grads[3 + j], self.mW[j], self.vW[j], self.lr, self.t)
+                    T.adam_dense_step(self.bs[j], grads[3 + n + j], self.mB[j], self.vB[j], self.lr, self.t)
+        return float(loss)
+
+
+def _make_engine(V, optimizer, lr, overlap=None):
+    from deep_recommenders_amd.engine import DeepFMEngine
+    old = os.environ.get("DR_OVERLAP_DW")
+    if overlap is not None:
+        os.environ["DR_OVERLAP_DW"] = overlap
+    try:
+        eng = DeepFMEngine(F, V, D, DNN, B, num_dense=ND, lr=lr, seed=42, lin_init_std=0.01, optimizer=optimizer)
+    finally:
+        if overlap is not None:
+            if old is None:
+                os.environ.pop("DR_OVERLAP_DW", None)
+            else:
+                os.environ["DR_OVERLAP_DW"] = old
+    return eng
+
+
+def _run_deepfm(V, optimizer, kind, lr, steps=2):
+    from deep_recommenders_amd import ops
+    assert ops.get_gemm_mode() == "bf16x3"                 # bench.py's default product mode
+    eng = _make_engine(V, optimizer, lr)
+    assert eng.overlap_dw and eng.fuse_head and eng.sorted_bwd, "not the benched orchestration"
+    assert ops.linear_bwd_narrow_supported(B, 256, 32) and eng.narrow_ws[1] is not None
+    batches = _batches(steps, kind, seed=1234)
+    ids_list = [_oracle_ids(k, V) for k, _, _ in batches]
+    orc = _CompactOracle(eng, ids_list, V, optimizer, lr)
+    # untouched rows: a sample outside the touched set, must stay bit-identical
+    g = torch.Generator().manual_seed(5)
+    cand = torch.randint(0, F * V, (40000,), generator=g).numpy()
+    untouched = torch.from_numpy(cand[~np.isin(cand, orc.U)][:20000]).cuda()
+    assert untouched.numel() >= 10000
+    un_t0, un_l0 = eng.table[untouched].clone(), eng.lin_w[untouched].clone()
+    for i, (keys, dense, labels) in enumerate(batches):
+        loss = float(eng.train_step(keys, dense, labels).item())
+        np.testing.assert_array_equal(eng.ids.cpu().numpy(), ids_list[i])                     # integer path: bit-exact
+        want = orc.step(i, dense.cpu(), labels.cpu())
+        assert abs(loss - want) <= 1e-5 * abs(want), (i, loss, want)                          # north_star: 1e-5 relative
+    torch.cuda.synchronize()
+    assert torch.equal(eng.table[untouched], un_t0) and torch.equal(eng.lin_w[untouched], un_l0), "an untouched row changed"
+    got_t, got_l = eng.table[orc.Ud].cpu().numpy(), eng.lin_w[orc.Ud].cpu().numpy()
+    if optimizer == "sgd":
+        _assert_update("table rows", orc.table0.numpy(), got_t, orc.table.numpy())
+        _assert_update("first-order weights", orc.lin0.numpy(), got_l, orc.lin.numpy())
+        _assert_update("first-order bias", orc.bias0.numpy(), eng.lin_bias.cpu().numpy(), orc.bias.numpy())
+        for j in range(len(orc.Ws)):
+            _assert_update("W%d" % j, orc.Ws0[j].numpy(), eng.Ws[j].cpu().numpy(), orc.Ws[j].numpy())
+            _assert_update("b%d" % j, orc.bs0[j].numpy(), eng.bs[j].cpu().numpy(), orc.bs[j].numpy())
+    else:
+        tol = 2e-2 * lr          # 2 % of one Adam step: m / (sqrt(v) + eps) amplifies fp32 rounding of tiny gradients
+        np.testing.assert_allclose(got_t, orc.table.numpy(), rtol=0, atol=tol)
+        np.testing.assert_allclose(got_l, orc.lin.numpy(), rtol=0, atol=tol)
+        np.testing.assert_allclose(eng.lin_bias.cpu().numpy(), orc.bias.numpy(), rtol=0, atol=tol)
+        for j in range(len(orc.Ws)):
+            np.testing.assert_allclose(eng.Ws[j].cpu().numpy(), orc.Ws[j].numpy(), rtol=0, atol=tol)
+            np.testing.assert_allclose(eng.bs[j].cpu().numpy(), orc.bs[j].numpy(), rtol=0, atol=tol)
+        # and the update must not be vacuous: most touched rows moved by about one Adam step
+        moved = np.abs(got_t - orc.table0.numpy()).max(axis=1)
+        assert np.median(moved) > 0.2 * lr
+    return eng, batches
+
+
+def test_deepfm_bench_config_full_vocab_sgd_uniform():
+    """bench.py's default line: V = 10 M rows per field (66.6 GB slab), uniform keys, fused SGD."""
+    free, _ = torch.cuda.mem_get_info()
+    V = 10_000_000 if free > 90e9 else 1_000_000
+    _run_deepfm(V, "sgd", "uniform", lr=1.0)
+
+
+def test_deepfm_bench_config_sgd_zipf():
+    """Zipf(1.05) keys (bench.py --ids zipf): most slots are duplicates, the K4 segment-sum path carries the step."""
+    _run_deepfm(1_000_000, "sgd", "zipf", lr=1.0)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "zipf"])
+def test_deepfm_bench_config_adam(kind):
+    """bench.py --optimizer adam (the reference examples' optimizer, lr 0.01): fused row-wise Adam K4 + dense Adam."""
+    _run_deepfm(1_000_000, "adam", kind, lr=0.01)
+
+
+def test_deepfm_bench_config_overlap_on_off_agree():
+    """DR_OVERLAP_DW=0 / 1 (first-layer wgrad on the second stream next to K4, or in line) are the same computation: two steps
+    from identical parameters must give identical losses and bit-identical tables (K4 is deterministic for <= 32 hits per row)
+    and first-layer weights (the split-K wgrad reduces its slices in a fixed order)."""
+    V = 1_000_000
+    batches = _batches(2, "uniform", seed=99)
+    res = []
+    for ov in ("0", "1"):
+        eng = _make_engine(V, "sgd", 1.0, overlap=ov)
+        assert eng.overlap_dw == (ov == "1")
+        losses = [float(eng.train_step(*b).item()) for b in batches]
+        torch.cuda.synchronize()
+        rows = torch.unique(eng.ids.reshape(-1) + eng.row_base.repeat(B))
+        res.append((losses, eng.table[rows].clone(), eng.Ws[0].clone(), eng.lin_w[rows].clone()))
+        del eng
+        torch.cuda.empty_cache()
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][3], res[1][3])
+    assert torch.equal(res[0][2], res[1][2])
+
+
+def test_dcn_bench_config_matches_oracle():
+    """bench.py --model dcn (BASELINE config 4): Din = 26 * 64 + 13 = 1677, 3 full-rank cross layers, MLP [1024, 512, 256],
+    fused SGD; batch 8192 keeps the host side short (the GEMM tiles, split-K factors and epilogues are those of the config).
+    Oracle in float64 (T.cross / dense layers under autograd), as in test_gpu_models.py."""
+    from deep_recommenders_amd.dcn_engine import DCNEngine
+    V, Bd, lr = 200_000, 8192, 1.0
+    eng = DCNEngine(F, V, D, 3, [1024, 512, 256], Bd, num_dense=ND, lr=lr, seed=11)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    with torch.no_grad():
+        for b in eng.cross_b:
+            b.normal_(0, 0.05, generator=g)
+        eng.bs[-1].fill_(0.03)          # see test_gpu_models.py::test_dcn_engine_train_step_matches_oracle (loss kink at logit 0)
+    keys = torch.randint(0, 10**16, (Bd, F), device="cuda", generator=g)
+    dense = torch.log1p(torch.randn((Bd, ND), device="cuda", generator=g).abs())
+    labels = (torch.rand(Bd, device="cuda", generator=g) < 0.25).float()
+    k = keys.cpu().numpy()
+    ids = np.stack([O.hash_bucket_i64(k[:, f], V) for f in range(F)], axis=1)
+    rows = ids + np.arange(F, dtype=np.int64)[None, :] * V
+    U = np.unique(rows.reshape(-1))
+    cidx = torch.from_numpy(np.searchsorted(U, rows))
+    Ud = torch.from_numpy(U).cuda()
+    t0 = eng.table[Ud].cpu()
+    cW0 = [w.cpu().clone() for w in eng.cross_W]
+    cb0 = [b.cpu().clone() for b in eng.cross_b]
+    Ws0 = [w.cpu().clone() for w in eng.Ws]
+    bs0 = [b.cpu().clone() for b in eng.bs]
+    loss = float(eng.train_step(keys, dense, labels).item())
+    np.testing.assert_array_equal(eng.ids.cpu().numpy(), ids)
+    dd = torch.float64
+    emb = t0.to(dd)[cidx].requires_grad_(True)
+    cW = [w.to(dd).requires_grad_(True) for w in cW0]
+    cb = [b.to(dd).requires_grad_(True) for b in cb0]
+    Ws = [w.to(dd).requires_grad_(True) for w in Ws0]
+    bs = [b.to(dd).requires_grad_(True) for b in bs0]
+    x0 = torch.cat([emb.reshape(Bd, F * D), dense.cpu().to(dd)], 1)
+    x = x0
+    for W, b in zip(cW, cb):
+        x = T.cross(x0, x, W, b, 0.0)                                            # dcn.py:81-88
+    x = T.dnn(x, Ws, bs).reshape(-1)
+    lo = T.sigmoid_cross_entropy(labels.cpu().to(dd), x)
+    grads = torch.autograd.grad(lo, [emb] + cW + cb + Ws + bs)
+    assert abs(loss - lo.item()) <= 1e-5 * abs(lo.item()), (loss, lo.item())
+    gt = torch.zeros((len(U), D), dtype=dd).index_add_(0, cidx.reshape(-1), grads[0].reshape(-1, D))
+    # K = 1677-long fp32 reductions feeding three stacked cross layers: the device gradient carries ~1e-6 * sqrt(K) relative
+    # round-off per layer; 1e-2 of each update (+ the ulp / rms floor) still catches any missing term
+    _assert_update("table rows", t0.numpy(), eng.table[Ud].cpu().numpy(), (t0.to(dd) - lr * gt).float().numpy(), rel=1e-2)
+    n = 3
+    for j in range(n):
+        _assert_update("cross W%d" % j, cW0[j].numpy(), eng.cross_W[j].cpu().numpy(), (cW0[j].to(dd) - lr * grads[1 + j]).float().numpy(), rel=1e-2)
+        _assert_update("cross b%d" % j, cb0[j].numpy(), eng.cross_b[j].cpu().numpy(), (cb0[j].to(dd) - lr * grads[1 + n + j]).float().numpy(), rel=1e-2)
+    m = len(Ws)
+    for j in range(m):
+        _assert_update("mlp W%d" % j, Ws0[j].numpy(), eng.Ws[j].cpu().numpy(), (Ws0[j].to(dd) - lr * grads[1 + 2 * n + j]).float().numpy(), rel=1e-2)
+        _assert_update("mlp b%d" % j, bs0[j].numpy(), eng.bs[j].cpu().numpy(), (bs0[j].to(dd) - lr * grads[1 + 2 * n + m + j]).float().numpy(), rel=1e-2)
+
+
+@pytest.mark.parametrize("variant", ["plain", "corrections"])
+def test_retrieval_bench_config_matches_oracle(variant):
+    """Retrieval.call at BASELINE config 5's in-batch size: B = 8192 query / candidate pairs, D = 128, loss and both input
+    gradients against the float64 restatement of sbcnm.py:120-151 (`corrections`: temperature, sampling-probability
+    correction, accidental-negative removal and sample weights together)."""
+    from deep_recommenders_amd.keras.models.retrieval.sbcnm import Retrieval
+    Bq, Dq = 8192, 128
+    rng = np.random.default_rng(42)
+    q = (rng.standard_normal((Bq, Dq)) / np.sqrt(Dq)).astype(np.float32)
+    c = (rng.standard_normal((Bq, Dq)) / np.sqrt(Dq)).astype(np.float32)
+    kw, okw, temp = {}, {}, None
+    if variant == "corrections":
+        temp = 0.5
+        w = rng.uniform(0.5, 1.5, Bq).astype(np.float32)
+        p = rng.uniform(0.01, 0.9, Bq).astype(np.float32)
+        cid = rng.integers(0, Bq // 2, Bq).astype(np.int64)             # ~half the candidates share an id with another one
+        kw = dict(sample_weight=torch.tensor(w).cuda(), candidate_sampling_probability=torch.tensor(p).cuda(),
+                  candidate_ids=torch.tensor(cid).cuda())
+        okw = dict(sample_weight=torch.tensor(w, dtype=torch.float64), cand_prob=torch.tensor(p, dtype=torch.float64),
+                   cand_ids=torch.tensor(cid), temperature=temp)
+    qd = torch.tensor(q).cuda().requires_grad_(True)
+    cd = torch.tensor(c).cuda().requires_grad_(True)
+    task = Retrieval(temperature=temp)
+    loss = task(qd, cd, compute_metrics=False, **kw)
+    loss.backward()
+    qo = torch.tensor(q, dtype=torch.float64, requires_grad=True)
+    co = torch.tensor(c, dtype=torch.float64, requires_grad=True)
+    lo = T.inbatch_softmax_loss(qo, co, **okw)
+    lo.backward()
+    assert abs(float(loss) - lo.item()) <= 1e-5 * abs(lo.item()), (float(loss), lo.item())
+    for name, got, want in (("dq", qd.grad, qo.grad), ("dc", cd.grad, co.grad)):
+        want = want.numpy()
+        err = np.abs(got.cpu().numpy().astype(np.float64) - want)
+        # fp32 GEMM over 8192 terms: 2e-6 * sqrt(8192) relative to the largest gradient entry
+        assert err.max() <= 2e-6 * np.sqrt(Bq) * np.abs(want).max() + 1e-7, (name, err.max(), np.abs(want).max())

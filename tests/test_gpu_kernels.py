@@ -656,6 +656,76 @@ def test_gemm_bf16x3_matches_fp64_as_well_as_native(ops):
         assert e_bf3 <= 1.5 * e_nat + 1e-7, errs        # and no worse than the native fp32 MFMA path
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "native"])
+def test_gemm_componentwise_error_bound_per_row(ops, mode):
+    """Per-ELEMENT accuracy: rows of x span e^+-9 in magnitude, so a global max-norm would only see the
+    largest rows.  Every output element must satisfy the componentwise fp32 bound |err_ij| <= c * sqrt(K) * 2^-24 * (|x| |W|)_ij
+    (c = 4: the accumulation is a K-long fp32 chain; the bf16x3 split drops terms below 2^-24 |x_ik w_kj| each), i.e. each row
+    is judged against its own scale; same for dgrad (rows of dy scaled) and wgrad (columns inherit both operands' scales)."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    M, K, N = 1024, 333, 200
+    rs = torch.exp(3 * torch.randn((M, 1), device="cuda", generator=g))           # e^+-9 across rows
+    x = torch.randn((M, K), device="cuda", generator=g) * rs
+    W = torch.randn((K, N), device="cuda", generator=g) / K ** 0.5
+    dy = torch.randn((M, N), device="cuda", generator=g) * rs
+    prev = ops.get_gemm_mode()
+    ops.set_gemm_mode(mode)
+    try:
+        y = ops.linear_fwd(x, W, None, 0)
+        dx = ops.linear_bwd_dx(dy, W, None)
+        dW = torch.zeros((K, N), device="cuda")
+        ops.linear_bwd_dw(x, dy, 1.0, dW, None, workspace=ops.linear_bwd_dw_workspace(M, K, N, "cuda"))
+    finally:
+        ops.set_gemm_mode(prev)
+    u = 2.0 ** -24
+    for name, got, a, b, red in (("fwd", y, x, W, K), ("dgrad", dx, dy, W.t(), N), ("wgrad", dW, x.t(), dy, M)):
+        ref = a.double() @ b.double()
+        bound = 4 * red ** 0.5 * u * (a.double().abs() @ b.double().abs())
+        err = (got.double() - ref).abs()
+        worst = float((err / bound).max())
+        assert worst <= 1.0, (name, mode, worst)
+        # the smallest-magnitude rows are resolved as well as the largest ones
+        small = rs.reshape(-1).argsort()[:16]
+        if name != "wgrad":
+            rel = (err[small].max(dim=1).values / ref[small].abs().max(dim=1).values)
+            assert float(rel.max()) <= 4e-6, (name, mode, float(rel.max()))
+
+
+def test_gemm_bf16x3_special_operands(ops):
+    """What the bf16x3 product mode does with operands outside the normal range:
+    * fp32 subnormal operands: the split keeps at most bf16's 8 significant bits of a subnormal (absolute error < 2^-133 per
+      value), their products are far below the accumulator's rounding -- results stay within the ordinary bound, and a row
+      made only of subnormals yields a result of subnormal magnitude, finite;
+    * +-inf operand: the residual inf - inf is NaN, so that output ROW is non-finite (native: +-inf / NaN by IEEE rules);
+      every other row is untouched;
+    * values near FLT_MAX whose bf16 rounding overflows behave like inf (same row-local effect)."""
+    g = torch.Generator(device="cuda").manual_seed(12)
+    M, K, N = 256, 96, 64
+    x = torch.randn((M, K), device="cuda", generator=g)
+    W = torch.randn((K, N), device="cuda", generator=g) / K ** 0.5
+    x[3, ::7] = 1e-40
+    x[3, 1::7] = -3e-39
+    x[5, :] = 1e-40                                       # a row of subnormals only
+    x[9, 4] = float("inf")
+    x[11, 8] = 3.4e38                                     # bf16_rn overflows to inf
+    prev = ops.get_gemm_mode()
+    ops.set_gemm_mode("bf16x3")
+    try:
+        y = ops.linear_fwd(x, W, None, 0)
+    finally:
+        ops.set_gemm_mode(prev)
+    ok = torch.ones(M, dtype=torch.bool, device="cuda")
+    ok[9] = ok[11] = False
+    xr = x.clone()
+    ref = xr[ok].double() @ W.double()
+    bound = 4 * K ** 0.5 * 2.0 ** -24 * (xr[ok].double().abs() @ W.double().abs()) + 1e-37
+    assert bool(torch.isfinite(y[ok]).all())
+    assert float(((y[ok].double() - ref).abs() / bound).max()) <= 1.0
+    assert float(y[5].abs().max()) <= 1e-37
+    assert not bool(torch.isfinite(y[9]).all())           # inf operand: the row is poisoned (NaN / inf), documented
+    assert not bool(torch.isfinite(y[11]).all()) or float((y[11].double() - x[11].double() @ W.double()).abs().max()) < 1e33
+
+
 def test_gemm_mode_api(ops):
     prev = ops.set_gemm_mode("native")
     assert ops.set_gemm_mode("bf16x3") == "native"
