@@ -1,0 +1,549 @@
+// fp32 GEMMs of the first tower layer on PRE-SPLIT operands ("planes" form of the bf16x3 product mode, dense.hip).
+//
+// dense.hip's bf16x3 kernel splits every fp32 operand value into three bf16 terms on its way into LDS: per k-tile 24
+// v_cvt_pk + 48 exact subtractions + 24 ds_write_b64 per thread sit between the global loads and the 48 MFMAs, and the
+// kernel reaches 0.33-0.38 of the bf16 pipe's fp32-equivalent ceiling (2.5 PFLOP/s / 6).  Here the PRODUCERS of the
+// operands write the three planes once (K3 writes the pooled embeddings as planes, the tower-tail backward writes its
+// dx as planes, a small kernel splits W after each update), so the GEMM's staging is pure LDS-DMA
+// (global_load_lds_dwordx4: no VGPR round trip, no VALU, no ds_write) and its loop is
+//     barrier -> issue next k-tile's DMA -> 24 ds_read_b128 (or 48 ds_read_b64_tr_b16) + 48 MFMAs
+// with one barrier per k-tile and two LDS stages.  Three planes of x reproduce x exactly ((x2 + x1) + x0 == x), so the
+// results are those of the bf16x3 mode: fp32 operands, fp32 accumulation, dropped terms below 2^-24 |ab|.
+//
+// Replaces, for the first (wide) Dense layer of keras/models/ranking/deepfm.py:30-34 / estimator dnn.py:17-29 of the
+// reference and its autodiff:  y = act(x W + b),  dx = dy W^T,  dW = x^T dy,  db = colsum(dy).
+//
+// Operand format: planes[p][row][col], p = 0..2, bf16, `ld` elements per row (multiple of 8), plane stride `ps`.
+//   NT kernel  C[m][n] = sum_k A[m][k] B[n][k]   both operands reduction-contiguous; K % 32 == 0 with ZERO padding in
+//              both operands' planes (forward: A = x planes, B = W^T planes; dgrad: A = dy planes, B = W planes)
+//   TN kernel  C[f][n] = sum_r X[r][f] Y[r][n]   both operands reduction-major (wgrad: X = x planes, Y = dy planes);
+//              rows r >= R must exist up to the next multiple of 32 and be ZERO; split over r, fp32 partials + reduce
+// Tile 64*WM x 64*WN x 32, 8 waves (2 per SIMD), each wave 64 x 64 = 2 x 2 MFMA tiles of 32 x 32 x 16 (bf16), 6 MFMAs per
+// (A-fragment, B-fragment) pair.  LDS: 2 stages x 72 KB.
+//
+// LDS images (written by LDS-DMA: lane i of a wave-instruction lands at base + 16 i, so the image is lane-linear and
+// any swizzle is applied to the per-lane SOURCE address and, identically, to the fragment read address):
+//   NT: per plane [rows][32 k] = 64-byte rows; 16-byte chunk c of row r sits at chunk c ^ ((r >> 2) & 3)  -> the 16 rows
+//       of a ds_read_b128 lane group fall on 16 distinct 16-byte slots of the 256-byte bank row (conflict-free)
+//   TN: per plane [32 r][cols] = 256/512-byte rows; chunk c of row r sits at c ^ ((r & 3) << 2) -> the 4 rows x 64 bytes a
+//       32-lane half of ds_read_b64_tr_b16 touches fall on 4 distinct 64-byte quarters of the bank row
+#include "dr_common.h"
+#include "bf3_split.h"
+
+namespace {
+
+using bf3::bf16x4;
+using bf3::bf16x8;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+constexpr int BK = 32;
+constexpr int NWAVES = 8;
+constexpr int NTHREADS = 64 * NWAVES;
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {          // bijective, consecutive logical ids -> same XCD
+    const int q = nwg / 8, r = nwg % 8;
+    const int xcd = bid % 8, idx = bid / 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// the six products of one (A-fragment, B-fragment) pair, smallest terms first; the four accumulators of a wave are
+// interleaved so that back-to-back MFMAs are independent
+template <int TM, int TN>
+__device__ __forceinline__ void mma6(const bf16x8 (&af)[3][TM], const bf16x8 (&bf)[3][TN], f32x16 (&acc)[TM][TN]) {
+    constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+    for (int term = 0; term < 6; ++term)
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[term]][a], bf[PB[term]][b], acc[a][b], 0, 0, 0);
+}
+
+// =====================================================================================================================
+// NT:  C[m][n] = epilogue( sum_k A[m][k] B[n][k] )
+// =====================================================================================================================
+struct NtArgs {
+    const __bf16* A; int64_t a_ps, a_ld;
+    const __bf16* B; int64_t b_ps, b_ld;
+    int64_t M; int32_t N; int32_t K;
+    float* C; int64_t ldc;
+    const float* bias; int32_t act;              // C = act(acc + bias[n])
+    const float* mask; int64_t ld_mask;          // optional: C = 0 where mask[m][n] <= 0   (ReLU' of the layer below)
+};
+
+template <int WM, int WN>
+__global__ __launch_bounds__(NTHREADS, 2) void bf3_gemm_nt_kernel(NtArgs g) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;                 // bytes: rows x 64-byte rows
+    constexpr int STAGE = 3 * (A_PLANE + B_PLANE);
+    constexpr int NKB = STAGE / 1024, KB_A = 3 * A_PLANE / 1024, PER_WAVE = NKB / NWAVES;
+    static_assert(WM * WN == NWAVES && NKB % NWAVES == 0, "tile / wave layout");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int tiles_m = (int)((g.M + BM - 1) / BM);
+    const int ntiles = tiles_m * tiles_n;
+    const int nk = g.K / BK;
+
+    // fragment read offsets (bytes within a stage): row = 64 wm + 32 t + l31, logical chunk = 2 ks + hi
+    const int sw = (l31 >> 2) & 3;
+    const int a_off = (wm * 64 + l31) * 64 + ((hi ^ sw) << 4);
+    const int b_off = 3 * A_PLANE + (wn * 64 + l31) * 64 + ((hi ^ sw) << 4);
+
+    const __bf16* src[PER_WAVE];
+    int64_t m0 = 0;
+    int n0 = 0;
+    auto setup = [&](int tile) {
+        const int lid = xcd_remap(tile, ntiles);
+        m0 = (int64_t)(lid / tiles_n) * BM;
+        n0 = (lid % tiles_n) * BN;
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; ++i) {
+            const int j = wave + NWAVES * i;                            // 1-KB piece of the stage (wave-uniform)
+            const bool is_a = j < KB_A;
+            const int jj = is_a ? j : j - KB_A;
+            const int rows16 = is_a ? BM / 16 : BN / 16;
+            const int plane = jj / rows16, rb = jj % rows16;
+            const int row = rb * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ ((row >> 2) & 3);
+            int64_t grow = (is_a ? m0 : (int64_t)n0) + row;
+            const int64_t lim = is_a ? g.M : (int64_t)g.N;
+            grow = grow < lim ? grow : lim - 1;                         // rows past the edge only feed unstored outputs
+            src[i] = is_a ? g.A + plane * g.a_ps + grow * g.a_ld + c * 8 : g.B + plane * g.b_ps + grow * g.b_ld + c * 8;
+        }
+    };
+    auto issue = [&](int stage) {
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; ++i) {
+            unsigned char* dst = smem + stage * STAGE + (wave + NWAVES * i) * 1024;
+            __builtin_amdgcn_global_load_lds(src[i], (lds_ptr_t)dst, 16, 0, 0);
+            src[i] += BK;
+        }
+    };
+
+    f32x16 acc[2][2];
+    auto compute = [&](int stage) {
+        const unsigned char* sa = smem + stage * STAGE + a_off;
+        const unsigned char* sb = smem + stage * STAGE + b_off;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[3][2], bf[3][2];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    af[p][t] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(
+                        (uintptr_t)(sa + p * A_PLANE + t * 32 * 64) ^ (uintptr_t)(ks * 32)));
+                    bf[p][t] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(
+                        (uintptr_t)(sb + p * B_PLANE + t * 32 * 64) ^ (uintptr_t)(ks * 32)));
+                }
+            mma6<2, 2>(af, bf, acc);
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    int buf = 0;
+    setup(tile);
+    issue(buf);
+    for (;;) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[a][b][k] = 0.f;
+        const int64_t tm0 = m0;
+        const int tn0 = n0;
+        for (int kt = 0; kt < nk; ++kt) {
+            __syncthreads();              // this stage's DMA has landed (vmcnt(0) per wave, then the barrier); all waves are
+                                          // done reading the other stage
+            if (kt + 1 < nk) issue(buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(buf);
+            buf ^= 1;
+        }
+        // every wave is past the last barrier, i.e. done with stage `buf` (read in iteration nk - 2): the next tile's first
+        // k-tile streams into it under this tile's epilogue
+        const int next = tile + gridDim.x;
+        if (next < ntiles) {
+            setup(next);
+            issue(buf);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int col = tn0 + wn * 64 + ni * 32 + l31;
+                const bool cv = col < g.N;
+                const int colc = cv ? col : g.N - 1;
+                const float bj = g.bias != nullptr ? g.bias[colc] : 0.f;
+                const int64_t row_b = tm0 + wm * 64 + mi * 32 + 4 * hi;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int64_t row = row_b + (reg & 3) + 8 * (reg >> 2);
+                    if (!cv || row >= g.M) continue;
+                    float v = acc[mi][ni][reg] + bj;
+                    if (g.act == 1) v = fmaxf(v, 0.f);
+                    if (g.mask != nullptr && !(g.mask[row * g.ld_mask + col] > 0.f)) v = 0.f;
+                    g.C[row * g.ldc + col] = v;
+                }
+            }
+        if (next >= ntiles) break;
+        tile = next;
+    }
+}
+
+// =====================================================================================================================
+// TN split-K:  partial[s][f][n] = sum_{r in slice s} X[r][f] Y[r][n]
+// =====================================================================================================================
+struct TnArgs {
+    const __bf16* X; int64_t x_ps, x_ld;
+    const __bf16* Y; int64_t y_ps, y_ld;
+    int64_t R; int32_t F; int32_t N;
+    int64_t per; int32_t split;                  // reduction rows per slice (multiple of 32), number of slices
+    float* partial;                              // [split][F][N]
+};
+
+__device__ __forceinline__ bf16x8 tr_pair(const unsigned char* p0, const unsigned char* p1) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds_ptr_t)const_cast<unsigned char*>(p0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds_ptr_t)const_cast<unsigned char*>(p1));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int WM, int WN>
+__global__ __launch_bounds__(NTHREADS, 2) void bf3_gemm_tn_kernel(TnArgs g) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;                           // BM: columns of X (output rows f), BN: columns of Y
+    constexpr int ROW_A = BM * 2, ROW_B = BN * 2;                        // bytes per reduction row of a plane image
+    constexpr int A_PLANE = BK * ROW_A, B_PLANE = BK * ROW_B;
+    constexpr int STAGE = 3 * (A_PLANE + B_PLANE);
+    constexpr int NKB = STAGE / 1024, KB_A = 3 * A_PLANE / 1024, PER_WAVE = NKB / NWAVES;
+    static_assert(WM * WN == NWAVES && NKB % NWAVES == 0, "tile / wave layout");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, hi = lane >> 5, g16 = (lane >> 4) & 1, s = lane & 15;
+
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int tiles_f = (g.F + BM - 1) / BM;
+    const int per_slice = tiles_f * tiles_n;
+    const int ntiles = per_slice * g.split;
+
+    // transposing fragment reads: this lane supplies the address of row (8 hi + 4 q + (s >> 2)) of the k-step, 4 elements from
+    // column 16 g16 + 4 (s & 3) of the 32-column MFMA tile; it receives column 16 g16 + s, rows 8 hi + 4 q + 0..3
+    const int swz = (s >> 2) << 2;
+    const int a_off = (8 * hi + (s >> 2)) * ROW_A + ((((wm * 8) ^ swz) + 2 * g16 + ((s & 3) >> 1)) << 4) + ((s & 1) << 3);
+    const int b_off = 3 * A_PLANE + (8 * hi + (s >> 2)) * ROW_B + ((((wn * 8) ^ swz) + 2 * g16 + ((s & 3) >> 1)) << 4) + ((s & 1) << 3);
+
+    const __bf16* src[PER_WAVE];
+    int64_t src_step[2];
+    src_step[0] = (int64_t)BK * g.x_ld;
+    src_step[1] = (int64_t)BK * g.y_ld;
+    int f0 = 0, n0 = 0, slice = 0, nk = 0;
+    auto setup = [&](int tile) {
+        const int lid = xcd_remap(tile, ntiles);                        // consecutive logical ids share a reduction slice
+        slice = lid / per_slice;
+        const int t = lid % per_slice;
+        f0 = (t / tiles_n) * BM;
+        n0 = (t % tiles_n) * BN;
+        const int64_t r0 = (int64_t)slice * g.per;
+        int64_t r1 = r0 + g.per;
+        const int64_t rpad = (g.R + BK - 1) / BK * BK;
+        if (r1 > rpad) r1 = rpad;
+        nk = (int)((r1 - r0) / BK);
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; ++i) {
+            const int j = wave + NWAVES * i;
+            const bool is_a = j < KB_A;
+            const int jj = is_a ? j : j - KB_A;
+            const int kbs = is_a ? A_PLANE / 1024 : B_PLANE / 1024;
+            const int rowb = is_a ? ROW_A : ROW_B;
+            const int plane = jj / kbs, kb = jj % kbs;
+            const int o = kb * 1024 + lane * 16;
+            const int row = o / rowb;
+            const int pc = (o % rowb) >> 4;
+            const int c = pc ^ ((row & 3) << 2);
+            int64_t col = (is_a ? f0 : n0) + c * 8;
+            const int64_t ld = is_a ? g.x_ld : g.y_ld;
+            col = col <= ld - 8 ? col : ld - 8;                          // columns past the pitch only feed unstored outputs
+            src[i] = is_a ? g.X + plane * g.x_ps + (r0 + row) * g.x_ld + col : g.Y + plane * g.y_ps + (r0 + row) * g.y_ld + col;
+        }
+    };
+    auto issue = [&](int stage) {
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; ++i) {
+            const int j = wave + NWAVES * i;
+            unsigned char* dst = smem + stage * STAGE + j * 1024;
+            __builtin_amdgcn_global_load_lds(src[i], (lds_ptr_t)dst, 16, 0, 0);
+            src[i] += (j < KB_A) ? src_step[0] : src_step[1];
+        }
+    };
+
+    f32x16 acc[2][2];
+    auto compute = [&](int stage) {
+        const unsigned char* sa = smem + stage * STAGE + a_off;
+        const unsigned char* sb = smem + stage * STAGE + b_off;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[3][2], bf[3][2];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const unsigned char* pa = reinterpret_cast<const unsigned char*>((uintptr_t)(sa + p * A_PLANE) ^ (uintptr_t)(t * 64)) + ks * 16 * ROW_A;
+                    const unsigned char* pb = reinterpret_cast<const unsigned char*>((uintptr_t)(sb + p * B_PLANE) ^ (uintptr_t)(t * 64)) + ks * 16 * ROW_B;
+                    af[p][t] = tr_pair(pa, pa + 4 * ROW_A);
+                    bf[p][t] = tr_pair(pb, pb + 4 * ROW_B);
+                }
+            mma6<2, 2>(af, bf, acc);
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    int buf = 0;
+    setup(tile);
+    if (nk > 0) issue(buf);
+    for (;;) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[a][b][k] = 0.f;
+        const int tf0 = f0, tn0 = n0, tslice = slice;
+        const int tnk = nk;
+        for (int kt = 0; kt < tnk; ++kt) {
+            __syncthreads();
+            if (kt + 1 < tnk) issue(buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(buf);
+            buf ^= 1;
+        }
+        const int next = tile + gridDim.x;
+        if (next < ntiles) {
+            setup(next);
+            if (tnk == 1) __syncthreads();        // a one-k-tile tile: stage `buf` may still be read by a slower wave
+            if (nk > 0) issue(buf);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float* out = g.partial + (int64_t)tslice * g.F * g.N;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int col = tn0 + wn * 64 + ni * 32 + l31;
+                const int row_b = tf0 + wm * 64 + mi * 32 + 4 * hi;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = row_b + (reg & 3) + 8 * (reg >> 2);
+                    if (col < g.N && row < g.F) out[(int64_t)row * g.N + col] = acc[mi][ni][reg];
+                }
+            }
+        if (next >= ntiles) break;
+        tile = next;
+    }
+}
+
+// dst[f][n] += scale * sum_s partial[s][f][n]  (fixed order);  dstb[n] += scale * colsum[n]
+__global__ __launch_bounds__(256) void bf3_splitk_reduce_kernel(const float* __restrict__ partial, int32_t split, int64_t F,
+                                                                int32_t N, float scale, float* __restrict__ dst, int64_t ld,
+                                                                const float* __restrict__ colsum, float* __restrict__ dstb) {
+    const int64_t total = F * N;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        float acc = 0.f;
+        int sidx = 0;
+        for (; sidx + 4 <= split; sidx += 4) {       // four loads in flight, summed in slice order
+            const float v0 = partial[(int64_t)sidx * total + i], v1 = partial[(int64_t)(sidx + 1) * total + i];
+            const float v2 = partial[(int64_t)(sidx + 2) * total + i], v3 = partial[(int64_t)(sidx + 3) * total + i];
+            acc = (((acc + v0) + v1) + v2) + v3;
+        }
+        for (; sidx < split; ++sidx) acc += partial[(int64_t)sidx * total + i];
+        const int64_t f = i / N;
+        const int n = (int)(i - f * N);
+        dst[f * ld + n] = fmaf(scale, acc, dst[f * ld + n]);
+    }
+    if (blockIdx.x == 0 && colsum != nullptr && dstb != nullptr)
+        for (int n = threadIdx.x; n < N; n += blockDim.x) dstb[n] = fmaf(scale, colsum[n], dstb[n]);
+}
+
+// fp32 [R][C] -> planes[p][r0 + r][c0 + c]   (transpose = 0)   or   planes[p][r0 + c][c0 + r]   (transpose = 1)
+__global__ __launch_bounds__(256) void bf3_split_kernel(const float* __restrict__ src, int64_t ld_src, int64_t R, int32_t C,
+                                                        __bf16* __restrict__ planes, int64_t ps, int64_t ldp, int64_t r0,
+                                                        int64_t c0, int32_t transpose) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (!transpose) {
+        const int cq = (C + 3) / 4;
+        const int64_t total = R * cq;
+        const bool vec = (C & 3) == 0 && (c0 & 3) == 0 && (ldp & 3) == 0;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+            const int64_t r = i / cq;
+            const int c = (int)(i - r * cq) * 4;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = c + j < C ? src[r * ld_src + c + j] : 0.f;
+            const int64_t off = (r0 + r) * ldp + c0 + c;
+            if (vec) {
+                bf3::store4(planes, ps, off, v[0], v[1], v[2], v[3]);
+            } else {
+                bf3::bf16x4 p0, p1, p2;
+                bf3::split4(v[0], v[1], v[2], v[3], p0, p1, p2);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c + j < C) {
+                        planes[off + j] = p0[j];
+                        planes[ps + off + j] = p1[j];
+                        planes[2 * ps + off + j] = p2[j];
+                    }
+            }
+        }
+    } else {
+        // a thread takes 4 consecutive rows r of one column c: coalesced reads across c, one 8-byte store per plane
+        const int64_t rq = (R + 3) / 4;
+        const int64_t total = rq * C;
+        const bool vec = (c0 & 3) == 0 && (ldp & 3) == 0;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+            const int64_t q = i / C;
+            const int c = (int)(i - q * C);
+            const int64_t r = q * 4;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = r + j < R ? src[(r + j) * ld_src + c] : 0.f;
+            const int64_t off = (r0 + c) * ldp + c0 + r;
+            bf3::bf16x4 p0, p1, p2;
+            bf3::split4(v[0], v[1], v[2], v[3], p0, p1, p2);
+            if (vec && r + 4 <= R) {
+                *reinterpret_cast<bf3::bf16x4*>(planes + off) = p0;
+                *reinterpret_cast<bf3::bf16x4*>(planes + ps + off) = p1;
+                *reinterpret_cast<bf3::bf16x4*>(planes + 2 * ps + off) = p2;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (r + j < R) {
+                        planes[off + j] = p0[j];
+                        planes[ps + off + j] = p1[j];
+                        planes[2 * ps + off + j] = p2[j];
+                    }
+            }
+        }
+    }
+}
+
+// planes -> fp32 (tests, debugging): dst[r][c] = (p2 + p1) + p0
+__global__ __launch_bounds__(256) void bf3_join_kernel(const __bf16* __restrict__ planes, int64_t ps, int64_t ldp, int64_t R,
+                                                       int32_t C, float* __restrict__ dst, int64_t ld_dst) {
+    const int64_t total = R * C, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t r = i / C;
+        const int c = (int)(i - r * C);
+        const int64_t off = r * ldp + c;
+        dst[r * ld_dst + c] = bf3::join(planes[off], planes[ps + off], planes[2 * ps + off]);
+    }
+}
+
+bool planes_ok(const void* p, int64_t ps, int64_t ld) {
+    return p != nullptr && (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ld > 0 && (ld & 7) == 0 && (ps & 7) == 0;
+}
+
+int tn_split_for(int64_t R, int32_t F, int32_t N, int bm, int bn) {
+    const int64_t tiles = (int64_t)((F + bm - 1) / bm) * ((N + bn - 1) / bn);
+    int64_t max_split = (R + 16 * BK - 1) / (16 * BK);                  // at least 16 k-tiles per slice
+    if (max_split < 1) max_split = 1;
+    if (max_split > 128) max_split = 128;
+    int64_t sp = 256 / tiles;                                           // one block per CU: fill the chip once
+    if (sp < 1) sp = 1;
+    if (sp > max_split) sp = max_split;
+    return (int)sp;
+}
+
+}  // namespace
+
+extern "C" int dr_bf3_split(const float* src, int64_t ld_src, int64_t R, int32_t C, void* planes, int64_t plane_stride,
+                            int64_t ld_planes, int64_t row_offset, int64_t col_offset, int32_t transpose,
+                            dr_stream_t stream) {
+    if (R < 0 || C < 0 || ld_src < C || row_offset < 0 || col_offset < 0 || ld_planes <= 0 || plane_stride <= 0) return DR_EINVAL;
+    if (R == 0 || C == 0) return DR_OK;
+    if (!src || !planes) return DR_EINVAL;
+    if (!transpose && col_offset + C > ld_planes) return DR_EINVAL;
+    if (transpose && col_offset + R > ld_planes) return DR_EINVAL;
+    hipLaunchKernelGGL(bf3_split_kernel, dim3(dr_grid_for(R * ((C + 3) / 4), 256)), dim3(256), 0, dr_s(stream), src, ld_src, R, C,
+                       static_cast<__bf16*>(planes), plane_stride, ld_planes, row_offset, col_offset, transpose);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+extern "C" int dr_bf3_join(const void* planes, int64_t plane_stride, int64_t ld_planes, int64_t R, int32_t C, float* dst,
+                           int64_t ld_dst, dr_stream_t stream) {
+    if (R < 0 || C < 0 || ld_planes < C || ld_dst < C || plane_stride <= 0) return DR_EINVAL;
+    if (R == 0 || C == 0) return DR_OK;
+    if (!planes || !dst) return DR_EINVAL;
+    hipLaunchKernelGGL(bf3_join_kernel, dim3(dr_grid_for(R * C, 256)), dim3(256), 0, dr_s(stream),
+                       static_cast<const __bf16*>(planes), plane_stride, ld_planes, R, C, dst, ld_dst);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+// C[m][n] = act(sum_k A[m][k] B[n][k] + bias[n]) (* (mask[m][n] > 0)).  K is the PADDED reduction length (multiple of 32);
+// columns [true K, K) of both operands' planes must be zero.
+extern "C" int dr_bf3_gemm_nt(const void* a_planes, int64_t a_plane_stride, int64_t a_ld, const void* b_planes,
+                              int64_t b_plane_stride, int64_t b_ld, int64_t M, int32_t N, int32_t K, const float* bias,
+                              int32_t act, const float* mask, int64_t ld_mask, float* C, int64_t ldc, dr_stream_t stream) {
+    if (M < 0 || N <= 0 || K <= 0 || (K % BK) != 0 || act < 0 || act > 1) return DR_EINVAL;
+    if (M == 0) return DR_OK;
+    if (!planes_ok(a_planes, a_plane_stride, a_ld) || !planes_ok(b_planes, b_plane_stride, b_ld) || !C) return DR_EINVAL;
+    if (a_ld < K || b_ld < K || ldc < N || (mask != nullptr && ld_mask < N)) return DR_EINVAL;
+    NtArgs g{static_cast<const __bf16*>(a_planes), a_plane_stride, a_ld, static_cast<const __bf16*>(b_planes), b_plane_stride, b_ld,
+             M, N, K, C, ldc, bias, act, mask, ld_mask};
+    // 128 x 256 tiles: an A row-panel is read once when N <= 256 (the forward: x is the big operand)
+    const int64_t tiles = ((M + 127) / 128) * ((N + 255) / 256);
+    if (tiles > 0x7fffffff) return DR_EINVAL;
+    const int grid = (int)(tiles < 256 ? tiles : 256);                  // persistent: one block per CU
+    hipLaunchKernelGGL((bf3_gemm_nt_kernel<2, 4>), dim3(grid), dim3(NTHREADS), 0, dr_s(stream), g);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+extern "C" int64_t dr_bf3_gemm_tn_workspace_bytes(int64_t R, int32_t F, int32_t N) {
+    if (R <= 0 || F <= 0 || N <= 0) return 0;
+    return (int64_t)tn_split_for(R, F, N, 128, 256) * F * N * (int64_t)sizeof(float);
+}
+
+// dst[f][n] += scale * sum_r X[r][f] Y[r][n];  dstb[n] += scale * y_colsum[n] (both optional).  Planes must hold rows up to the
+// next multiple of 32 past R, zero-filled.
+extern "C" int dr_bf3_gemm_tn(const void* x_planes, int64_t x_plane_stride, int64_t x_ld, const void* y_planes,
+                              int64_t y_plane_stride, int64_t y_ld, int64_t R, int32_t F, int32_t N, float scale, float* dst,
+                              int64_t ld_dst, const float* y_colsum, float* dstb, void* workspace, int64_t workspace_bytes,
+                              dr_stream_t stream) {
+    if (R <= 0 || F <= 0 || N <= 0) return DR_EINVAL;
+    if (!planes_ok(x_planes, x_plane_stride, x_ld) || !planes_ok(y_planes, y_plane_stride, y_ld) || !dst || !workspace) return DR_EINVAL;
+    if (x_ld < F || y_ld < N || ld_dst < N) return DR_EINVAL;
+    if (workspace_bytes < dr_bf3_gemm_tn_workspace_bytes(R, F, N)) return DR_EINVAL;
+    TnArgs g{static_cast<const __bf16*>(x_planes), x_plane_stride, x_ld, static_cast<const __bf16*>(y_planes), y_plane_stride, y_ld,
+             R, F, N, 0, 0, static_cast<float*>(workspace)};
+    int split = tn_split_for(R, F, N, 128, 256);
+    const int64_t rpad = (R + BK - 1) / BK * BK;
+    g.per = ((rpad + split - 1) / split + BK - 1) / BK * BK;
+    g.split = (int32_t)((rpad + g.per - 1) / g.per);                    // every launched slice is non-empty
+    const int64_t tiles = (int64_t)((F + 127) / 128) * ((N + 255) / 256) * g.split;
+    const int grid = (int)(tiles < 256 ? tiles : 256);
+    hipLaunchKernelGGL((bf3_gemm_tn_kernel<2, 4>), dim3(grid), dim3(NTHREADS), 0, dr_s(stream), g);
+    hipLaunchKernelGGL(bf3_splitk_reduce_kernel, dim3(dr_grid_for((int64_t)F * N, 256)), dim3(256), 0, dr_s(stream), g.partial,
+                       g.split, (int64_t)F, N, scale, dst, ld_dst, y_colsum, dstb);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}

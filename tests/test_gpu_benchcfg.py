@@ -58,16 +58,42 @@ def _ulp(x):
     return np.spacing(np.abs(x).astype(np.float32)).astype(np.float64)
 
 
-def _assert_update(name, before, after, want_after, rel=2e-3):
-    """after - before (device) against want_after - before (oracle), see the module docstring"""
+def _assert_update(name, before, after, want_after, rel=2e-3, outliers=1e-4):
+    """after - before (device) against want_after - before (oracle), see the module docstring.
+
+    `outliers`: fraction of elements allowed outside the tight tolerance, each still bounded by half its update + 2 rms.
+    Two fp32 implementations of a ReLU network cannot agree on every element: a hidden unit whose pre-activation is within
+    rounding of zero (a few of the 16.7 M per step) is "on" on one side and "off" on the other, which switches one of the
+    ~128 active terms of that example's 1664 input gradients (first seen at 5e-6 of the table elements, errors of ~0.5 % of
+    the update).  A wrong kernel moves every element, not 1e-5 of them."""
     b64 = before.astype(np.float64)
     d_gpu, d_cpu = after.astype(np.float64) - b64, want_after.astype(np.float64) - b64
     rms = float(np.sqrt(np.mean(d_cpu * d_cpu)))
     assert rms > 0, name + ": the oracle update is identically zero (test is vacuous)"
+    err = np.abs(d_gpu - d_cpu)
     tol = 2 * np.maximum(_ulp(before), _ulp(want_after)) + rel * np.abs(d_cpu) + 1e-3 * rms
-    bad = np.abs(d_gpu - d_cpu) > tol
-    assert not bad.any(), "%s: %d of %d elements off; worst |err| %.3e at update %.3e (rms update %.3e)" % (
-        name, int(bad.sum()), bad.size, float(np.abs(d_gpu - d_cpu)[bad].max()), float(np.abs(d_cpu)[bad].max()), rms)
+    bad = err > tol
+    frac = float(bad.mean())
+    assert frac <= outliers, "%s: %.2e of %d elements off (allowed %.0e); worst |err| %.3e at update %.3e (rms update %.3e)" % (
+        name, frac, bad.size, float(err[bad].max()), float(np.abs(d_cpu)[bad].max()), rms)
+    if bad.any():
+        assert bool((err[bad] <= 0.5 * np.abs(d_cpu)[bad] + 2 * rms).all()), "%s: an outlier is not ReLU-tie sized: |err| %.3e (rms %.3e)" % (
+            name, float(err[bad].max()), rms)
+
+
+def _assert_close_adam(name, got, want, lr, outliers):
+    """Adam at this batch size is an amplifier: on step t the update is lr * g / (|g| + eps'), eps' = eps / sqrt(1 - beta2^t)
+    ~ 3e-7, and the gradients of a 65 536-example mean are 1e-8 .. 1e-5 -- for |g| < ~1e-6 a change of 1e-8 in g moves the
+    update by more than 2 % of a step.  fp32 rounding is far below that, a ReLU tie (see _assert_update) is not: one hidden
+    unit switched for one example shifts that example's 1664 embedding-gradient elements by ~0.5 % and, through dy, a whole
+    1677-element column of the first layer's weight gradient by ~1e-7.  So: all but `outliers` of the elements within 2 % of a
+    step (measured: 4e-4 of the table rows, 7e-3 of W0 with ~1e2 ties per step), the MEAN difference within 0.2 % of a step,
+    nothing off by more than one whole step.  A wrong gradient or update rule moves the mean by tens of per cent."""
+    err = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    frac = float((err > 2e-2 * lr).mean())
+    assert frac <= outliers, "%s: %.2e of %d elements differ by more than 2 %% of an Adam step (allowed %.0e)" % (name, frac, err.size, outliers)
+    assert float(err.mean()) <= 2e-3 * lr, "%s: mean difference %.3e of a step" % (name, float(err.mean()) / lr)
+    assert float(err.max()) <= 1.0 * lr, "%s: worst difference %.3e exceeds one Adam step" % (name, float(err.max()))
 
 
 class _CompactOracle:
@@ -127,7 +153,7 @@ class _CompactOracle:
                 for j in range(n):
                     T.adam_dense_step(self.Ws[j], grads[3 + j], self.mW[j], self.vW[j], self.lr, self.t)
                     T.adam_dense_step(self.bs[j], grads[3 + n + j], self.mB[j], self.vB[j], self.lr, self.t)
-        return float(loss)
+        return float(loss.detach())
 
 
 def _make_engine(V, optimizer, lr, overlap=None):
@@ -177,13 +203,12 @@ def _run_deepfm(V, optimizer, kind, lr, steps=2):
             _assert_update("W%d" % j, orc.Ws0[j].numpy(), eng.Ws[j].cpu().numpy(), orc.Ws[j].numpy())
             _assert_update("b%d" % j, orc.bs0[j].numpy(), eng.bs[j].cpu().numpy(), orc.bs[j].numpy())
     else:
-        tol = 2e-2 * lr          # 2 % of one Adam step: m / (sqrt(v) + eps) amplifies fp32 rounding of tiny gradients
-        np.testing.assert_allclose(got_t, orc.table.numpy(), rtol=0, atol=tol)
-        np.testing.assert_allclose(got_l, orc.lin.numpy(), rtol=0, atol=tol)
-        np.testing.assert_allclose(eng.lin_bias.cpu().numpy(), orc.bias.numpy(), rtol=0, atol=tol)
+        _assert_close_adam("table rows", got_t, orc.table.numpy(), lr, 3e-3)
+        _assert_close_adam("first-order weights", got_l, orc.lin.numpy(), lr, 3e-3)
+        _assert_close_adam("first-order bias", eng.lin_bias.cpu().numpy(), orc.bias.numpy(), lr, 0.0)
         for j in range(len(orc.Ws)):
-            np.testing.assert_allclose(eng.Ws[j].cpu().numpy(), orc.Ws[j].numpy(), rtol=0, atol=tol)
-            np.testing.assert_allclose(eng.bs[j].cpu().numpy(), orc.bs[j].numpy(), rtol=0, atol=tol)
+            _assert_close_adam("W%d" % j, eng.Ws[j].cpu().numpy(), orc.Ws[j].numpy(), lr, 5e-2)
+            _assert_close_adam("b%d" % j, eng.bs[j].cpu().numpy(), orc.bs[j].numpy(), lr, 5e-2)
         # and the update must not be vacuous: most touched rows moved by about one Adam step
         moved = np.abs(got_t - orc.table0.numpy()).max(axis=1)
         assert np.median(moved) > 0.2 * lr
@@ -210,23 +235,27 @@ def test_deepfm_bench_config_adam(kind):
 
 def test_deepfm_bench_config_overlap_on_off_agree():
     """DR_OVERLAP_DW=0 / 1 (first-layer wgrad on the second stream next to K4, or in line) are the same computation: two steps
-    from identical parameters must give identical losses and bit-identical tables (K4 is deterministic for <= 32 hits per row)
-    and first-layer weights (the split-K wgrad reduces its slices in a fixed order)."""
+    from identical parameters must give the same losses and the same parameter updates.  Not bit-identical by construction:
+    the first layer's bias gradient is combined with fp32 atomics by the split-K wgrad blocks (order varies run to run), which
+    reaches everything in step 2 at the 1e-7 level; a race between the two streams would be orders of magnitude larger."""
     V = 1_000_000
     batches = _batches(2, "uniform", seed=99)
+    base = np.arange(F, dtype=np.int64)[None, :] * V
+    rows = torch.from_numpy(np.unique(np.concatenate([(_oracle_ids(k, V) + base).reshape(-1) for k, _, _ in batches]))).cuda()
     res = []
     for ov in ("0", "1"):
         eng = _make_engine(V, "sgd", 1.0, overlap=ov)
         assert eng.overlap_dw == (ov == "1")
+        before = (eng.table[rows].cpu().numpy(), eng.Ws[0].cpu().numpy().copy(), eng.lin_w[rows].cpu().numpy())
         losses = [float(eng.train_step(*b).item()) for b in batches]
         torch.cuda.synchronize()
-        rows = torch.unique(eng.ids.reshape(-1) + eng.row_base.repeat(B))
-        res.append((losses, eng.table[rows].clone(), eng.Ws[0].clone(), eng.lin_w[rows].clone()))
+        res.append((losses, before, (eng.table[rows].cpu().numpy(), eng.Ws[0].cpu().numpy().copy(), eng.lin_w[rows].cpu().numpy())))
         del eng
         torch.cuda.empty_cache()
-    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
-    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][3], res[1][3])
-    assert torch.equal(res[0][2], res[1][2])
+    for a, b in zip(res[0][0], res[1][0]):
+        assert abs(a - b) <= 1e-6 * abs(a), (res[0][0], res[1][0])
+    for name, b0, a0, a1 in zip(("table rows", "W0", "first-order weights"), res[0][1], res[0][2], res[1][2]):
+        _assert_update(name + " (overlap off vs on)", b0, a1, a0, rel=1e-4, outliers=1e-4)
 
 
 def test_dcn_bench_config_matches_oracle():
