@@ -74,6 +74,11 @@ SIGNATURES = {
     "dr_logits_adjust": [_p, _p, _i64, _i32, _p, _p, _f32, _p, _p],
     "dr_softmax_ce_rows": [_p, _p, _i64, _i32, _f32, _p, _p, _p, _p],
     "dr_softmax_ce_rows_bwd": [_p, _p, _i64, _i32, _f32, _p, _f32, _p, _p, _i64, _p],
+    "dr_bf3_split": [_p, _i64, _i64, _i32, _p, _i64, _i64, _i64, _i64, _i32, _p],
+    "dr_bf3_join": [_p, _i64, _i64, _i64, _i32, _p, _i64, _p],
+    "dr_bf3_gemm_nt": [_p, _i64, _i64, _p, _i64, _i64, _i64, _i32, _i32, _p, _i32, _p, _i64, _p, _i64, _p],
+    "dr_bf3_gemm_tn_workspace_bytes": [_i64, _i32, _i32],
+    "dr_bf3_gemm_tn": [_p, _i64, _i64, _p, _i64, _i64, _i64, _i32, _i32, _f32, _p, _i64, _p, _p, _p, _i64, _p],
     "dr_version": [],
     "dr_set_gemm_mode": [_i32],
     "dr_get_gemm_mode": [],
@@ -81,6 +86,7 @@ SIGNATURES = {
 _RESTYPE = {"dr_version": ctypes.c_char_p, "dr_shard_bucket_workspace_bytes": ctypes.c_int64,
             "dr_emb_sort_workspace_bytes": ctypes.c_int64,
             "dr_linear_bwd_dw_workspace_bytes": ctypes.c_int64,
+            "dr_bf3_gemm_tn_workspace_bytes": ctypes.c_int64,
             "dr_linear_bwd_narrow_workspace_bytes": ctypes.c_int64,
             "dr_tower_head_workspace_bytes": ctypes.c_int64,
             "dr_inbatch_softmax_workspace_bytes": ctypes.c_int64, "dr_topk_workspace_bytes": ctypes.c_int64}

@@ -48,6 +48,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {          // bijecti
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// 16-byte LDS-DMA: lane i's 16 bytes at `src` land at `dst` (wave-uniform) + 16 i.  A plain (non-template) device function:
+// hipcc's host pass cannot substitute the builtin inside a kernel template and silently drops the instantiation.
+__device__ __forceinline__ void lds_dma16(const void* src, unsigned char* dst) {
+    __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)dst, 16, 0, 0);
+}
+
 // the six products of one (A-fragment, B-fragment) pair, smallest terms first; the four accumulators of a wave are
 // interleaved so that back-to-back MFMAs are independent
 template <int TM, int TN>
@@ -124,15 +130,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void bf3_gemm_nt_kernel(NtArgs g) {
 #pragma unroll
         for (int i = 0; i < PER_WAVE; ++i) {
             unsigned char* dst = smem + stage * STAGE + (wave + NWAVES * i) * 1024;
-            __builtin_amdgcn_global_load_lds(src[i], (lds_ptr_t)dst, 16, 0, 0);
+            lds_dma16(src[i], dst);
             src[i] += BK;
         }
     };
 
     f32x16 acc[2][2];
     auto compute = [&](int stage) {
-        const unsigned char* sa = smem + stage * STAGE + a_off;
-        const unsigned char* sb = smem + stage * STAGE + b_off;
+        // offsets into the __shared__ array itself (not generic pointers: an XOR on a generic pointer makes hipcc emit
+        // flat_load, which also drags the LDS-DMA's vmcnt into every fragment wait)
+        const int sa = stage * STAGE + a_off, sb = stage * STAGE + b_off;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 af[3][2], bf[3][2];
@@ -140,10 +147,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void bf3_gemm_nt_kernel(NtArgs g) {
             for (int p = 0; p < 3; ++p)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    af[p][t] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(
-                        (uintptr_t)(sa + p * A_PLANE + t * 32 * 64) ^ (uintptr_t)(ks * 32)));
-                    bf[p][t] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(
-                        (uintptr_t)(sb + p * B_PLANE + t * 32 * 64) ^ (uintptr_t)(ks * 32)));
+                    af[p][t] = *reinterpret_cast<const bf16x8*>(&smem[(sa ^ (ks * 32)) + p * A_PLANE + t * 32 * 64]);
+                    bf[p][t] = *reinterpret_cast<const bf16x8*>(&smem[(sb ^ (ks * 32)) + p * B_PLANE + t * 32 * 64]);
                 }
             mma6<2, 2>(af, bf, acc);
         }
@@ -288,15 +293,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void bf3_gemm_tn_kernel(TnArgs g) {
         for (int i = 0; i < PER_WAVE; ++i) {
             const int j = wave + NWAVES * i;
             unsigned char* dst = smem + stage * STAGE + j * 1024;
-            __builtin_amdgcn_global_load_lds(src[i], (lds_ptr_t)dst, 16, 0, 0);
+            lds_dma16(src[i], dst);
             src[i] += (j < KB_A) ? src_step[0] : src_step[1];
         }
     };
 
     f32x16 acc[2][2];
     auto compute = [&](int stage) {
-        const unsigned char* sa = smem + stage * STAGE + a_off;
-        const unsigned char* sb = smem + stage * STAGE + b_off;
+        const int sa = stage * STAGE + a_off, sb = stage * STAGE + b_off;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 af[3][2], bf[3][2];
@@ -304,8 +308,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void bf3_gemm_tn_kernel(TnArgs g) {
             for (int p = 0; p < 3; ++p)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const unsigned char* pa = reinterpret_cast<const unsigned char*>((uintptr_t)(sa + p * A_PLANE) ^ (uintptr_t)(t * 64)) + ks * 16 * ROW_A;
-                    const unsigned char* pb = reinterpret_cast<const unsigned char*>((uintptr_t)(sb + p * B_PLANE) ^ (uintptr_t)(t * 64)) + ks * 16 * ROW_B;
+                    const unsigned char* pa = &smem[(sa ^ (t * 64)) + p * A_PLANE + ks * 16 * ROW_A];
+                    const unsigned char* pb = &smem[(sb ^ (t * 64)) + p * B_PLANE + ks * 16 * ROW_B];
                     af[p][t] = tr_pair(pa, pa + 4 * ROW_A);
                     bf[p][t] = tr_pair(pb, pb + 4 * ROW_B);
                 }

@@ -740,3 +740,66 @@ def set_gemm_mode(mode):
 
 def get_gemm_mode():
     return "native" if _lib.lib().dr_get_gemm_mode() == GEMM_NATIVE_F32 else "bf16x3"
+
+
+# ---- K7p: first tower layer on pre-split operands ("planes": three bf16 terms per fp32 value, include/dr_hotpath.h) -------
+class Planes:
+    """planes[3][rows_alloc][ld] bf16 in HBM holding an fp32 matrix [rows, cols] exactly (v = (v2 + v1) + v0).
+    rows_alloc = roundup(rows, 32) and ld = roundup(cols, 32), zero-filled: both paddings are read by the GEMMs."""
+
+    def __init__(self, rows, cols, device):
+        self.rows, self.cols = int(rows), int(cols)
+        self.rows_alloc = (self.rows + 31) // 32 * 32
+        self.ld = (self.cols + 31) // 32 * 32
+        self.buf = torch.zeros((3, self.rows_alloc, self.ld), dtype=torch.bfloat16, device=device)
+
+    @property
+    def plane_stride(self):
+        return self.rows_alloc * self.ld
+
+
+def bf3_split(src, planes: Planes, row_offset=0, col_offset=0, transpose=False):
+    """fp32 [R, C] -> planes[p][row_offset + r][col_offset + c] (or [row_offset + c][col_offset + r] when transpose)."""
+    assert src.dim() == 2 and src.stride(1) == 1 and src.dtype == torch.float32
+    R, C = src.shape
+    check(lib().dr_bf3_split(ptr(src), src.stride(0), R, C, ptr(planes.buf), planes.plane_stride, planes.ld, row_offset,
+                             col_offset, 1 if transpose else 0, stream_ptr()), "dr_bf3_split")
+    return planes
+
+
+def bf3_join(planes: Planes, out=None):
+    if out is None:
+        out = torch.empty((planes.rows, planes.cols), dtype=torch.float32, device=planes.buf.device)
+    check(lib().dr_bf3_join(ptr(planes.buf), planes.plane_stride, planes.ld, planes.rows, planes.cols, ptr(out),
+                            out.stride(0), stream_ptr()), "dr_bf3_join")
+    return out
+
+
+def bf3_gemm_nt(a: Planes, b: Planes, bias=None, act=0, mask=None, out=None):
+    """out[m, n] = act(sum_k A[m, k] B[n, k] + bias[n]), zeroed where mask <= 0.  A = a (rows M), B = b (rows N)."""
+    M, N = a.rows, b.rows
+    assert a.ld == b.ld, "operands must share the padded reduction length"
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.buf.device)
+    assert out.shape == (M, N) and out.stride(1) == 1
+    check(lib().dr_bf3_gemm_nt(ptr(a.buf), a.plane_stride, a.ld, ptr(b.buf), b.plane_stride, b.ld, M, N, a.ld, ptr(bias),
+                               int(act), ptr(mask), mask.stride(0) if mask is not None else 0, ptr(out), out.stride(0),
+                               stream_ptr()), "dr_bf3_gemm_nt")
+    return out
+
+
+def bf3_gemm_tn_workspace(R, F, N, device):
+    return torch.empty(max(64, lib().dr_bf3_gemm_tn_workspace_bytes(int(R), int(F), int(N)) // 4), dtype=torch.float32,
+                       device=device)
+
+
+def bf3_gemm_tn(x: Planes, y: Planes, scale, dstW, y_colsum=None, dstb=None, workspace=None):
+    """dstW[f, n] += scale * sum_r X[r, f] Y[r, n];  dstb += scale * y_colsum."""
+    R, F, N = x.rows, x.cols, y.cols
+    assert y.rows == R and dstW.shape == (F, N) and dstW.stride(1) == 1
+    if workspace is None:
+        workspace = bf3_gemm_tn_workspace(R, F, N, x.buf.device)
+    check(lib().dr_bf3_gemm_tn(ptr(x.buf), x.plane_stride, x.ld, ptr(y.buf), y.plane_stride, y.ld, R, F, N, float(scale),
+                               ptr(dstW), dstW.stride(0), ptr(y_colsum), ptr(dstb), ptr(workspace), workspace.numel() * 4,
+                               stream_ptr()), "dr_bf3_gemm_tn")
+    return dstW

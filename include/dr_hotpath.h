@@ -453,6 +453,40 @@ int dr_emb_pack_grads(const int64_t* pos, int64_t B, int32_t F, int32_t D, const
                       const float* d_fm_logit, float* out_rows, float* out_lin, float* bias_sum,
                       dr_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * K7p  first (wide) tower layer on PRE-SPLIT operands -- the "planes" form of the bf16x3 product mode.
+ * Replaces the same reference ops as dr_linear_fwd / _bwd_dx / _bwd_dw (keras/models/ranking/deepfm.py:30-34,
+ * estimator/models/feature_interaction/dnn.py:17-29 and their autodiff) for the one layer whose operands are large:
+ * the producers of x (K3, dr_emb_pool_fwd_planes), of dy (dr_linear_bwd_narrow / dr_linear_bwd_dx with planes_out) and of W
+ * (dr_bf3_split after each update) write every fp32 value v as three bf16 planes v0 + v1 + v2 (v0 = bf16(v),
+ * v1 = bf16(v - v0), v2 = bf16(v - v0 - v1): exact, (v2 + v1) + v0 == v), so the GEMM stages tiles with LDS-DMA and does no
+ * conversion work.  Results equal the bf16x3 mode of dr_linear_*: fp32 operands, six bf16 products per fp32 product,
+ * fp32 accumulation.
+ * Operand format: planes[p][row][col], p = 0..2, bf16; `ld` elements per row (multiple of 8), `plane_stride` elements
+ * between planes (multiple of 8), base 16-byte aligned.
+ *   dr_bf3_split    fp32 [R, C] -> planes (transpose = 1 writes planes[p][row_offset + c][col_offset + r])
+ *   dr_bf3_join     planes -> fp32 (exact inverse; tests)
+ *   dr_bf3_gemm_nt  C[m, n] = act(sum_k A[m, k] B[n, k] + bias[n]) (then zeroed where mask[m, n] <= 0);  K = padded
+ *                   reduction length (multiple of 32), columns [true K, K) of BOTH operands' planes must be zero.
+ *                   forward: A = x planes, B = W^T planes;  dgrad: A = dy planes, B = W planes.
+ *   dr_bf3_gemm_tn  dst[f, n] += scale * sum_r X[r, f] Y[r, n];  dstb[n] += scale * y_colsum[n]  (split over r into
+ *                   `workspace`, fixed-order reduce: deterministic).  Rows [R, roundup(R, 32)) of both operands' planes must
+ *                   exist and be zero.  wgrad: X = x planes, Y = dy planes.
+ * ---------------------------------------------------------------------------------------- */
+int dr_bf3_split(const float* src, int64_t ld_src, int64_t R, int32_t C, void* planes, int64_t plane_stride,
+                 int64_t ld_planes, int64_t row_offset, int64_t col_offset, int32_t transpose,
+                 dr_stream_t stream);
+int dr_bf3_join(const void* planes, int64_t plane_stride, int64_t ld_planes, int64_t R, int32_t C, float* dst,
+                int64_t ld_dst, dr_stream_t stream);
+int dr_bf3_gemm_nt(const void* a_planes, int64_t a_plane_stride, int64_t a_ld, const void* b_planes,
+                   int64_t b_plane_stride, int64_t b_ld, int64_t M, int32_t N, int32_t K, const float* bias,
+                   int32_t act, const float* mask, int64_t ld_mask, float* C, int64_t ldc, dr_stream_t stream);
+int64_t dr_bf3_gemm_tn_workspace_bytes(int64_t R, int32_t F, int32_t N);
+int dr_bf3_gemm_tn(const void* x_planes, int64_t x_plane_stride, int64_t x_ld, const void* y_planes,
+                   int64_t y_plane_stride, int64_t y_ld, int64_t R, int32_t F, int32_t N, float scale, float* dst,
+                   int64_t ld_dst, const float* y_colsum, float* dstb, void* workspace, int64_t workspace_bytes,
+                   dr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
