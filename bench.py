@@ -56,10 +56,34 @@ def parse():
                     help="sgd: fused SGD (the headline line); adam: fused row-wise Adam in K4 + dense Adam (single GPU only)")
     ap.add_argument("--micro-batches", type=int, default=int(os.environ.get("DR_MICRO_BATCHES", "2")),
                     help="sharded engine only: micro-batches per step (exchange of one overlaps the tower of the other)")
-    ap.add_argument("--model", choices=["deepfm", "dcn"], default="deepfm",
-                    help="deepfm: the headline (BASELINE config 3); dcn: config 4 (3 cross layers + MLP 1024,512,256), single GPU")
+    ap.add_argument("--model", choices=["deepfm", "dcn", "dssm"], default="deepfm",
+                    help="deepfm: the headline (BASELINE config 3); dcn: config 4 (3 cross layers + MLP 1024,512,256); dssm: config 5 "
+                         "(two towers + in-batch softmax over the batch's 8192 candidates + FactorizedTopK pass over a 1 M corpus)")
+    ap.add_argument("--preset", choices=["c2"], default=None,
+                    help="c2: BASELINE config 2, the MovieLens-1M shape (7 sparse features, 10 K vocab, dim 16, batch 4096, no dense)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: the batch of the WHOLE job (BASELINE config 3 as worded: 65536 over 8 GPUs); per-GPU batch = this / N")
+    ap.add_argument("--events", choices=["auto", "on", "off"], default="auto",
+                    help="per-kernel HIP events in the timed region (roofline rows).  auto: off for steps too short to carry two event "
+                         "records per kernel (first-layer GEMM < 4 GFLOP, e.g. the MovieLens shape)")
+    ap.add_argument("--items", type=int, default=1_000_000, help="dssm: corpus size")
+    ap.add_argument("--users", type=int, default=1_000_000, help="dssm: user hash buckets")
+    ap.add_argument("--towers", type=str, default="256,128", help="dssm: tower widths (last = embedding dim of the retrieval space)")
+    ap.add_argument("--topk", type=int, default=100, help="dssm: k of the FactorizedTopK metric pass")
     ap.add_argument("--pool", type=int, default=8, help="number of distinct synthetic batches cycled through")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.preset == "c2":
+        a.fields, a.vocab, a.dim, a.dense, a.batch = 7, 10_000, 16, 0, 4096
+    if a.model == "dssm":
+        if a.batch == 65536:
+            a.batch = 8192
+        if a.dim == 64:
+            a.dim = 128
+    if a.global_batch:
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        assert a.global_batch % world == 0, "--global-batch must divide by the number of GPUs"
+        a.batch = a.global_batch // world
+    return a
 
 
 def synth_batches(a, device, rank):
@@ -81,12 +105,71 @@ def synth_batches(a, device, rank):
     return out
 
 
+def _median_rate(step_fn, batch, warmup, min_steps, cap_s):
+    """examples/s of step_fn: `warmup` untimed calls, then at least `min_steps` timed calls (more until `cap_s` seconds of
+    timed work, at most 20), median over the per-call times."""
+    for _ in range(warmup):
+        step_fn()
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < 20 and (len(times) < min_steps or time.perf_counter() - t_all < cap_s):
+        t0 = time.perf_counter()
+        step_fn()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    return batch / times[len(times) // 2], len(times)
+
+
 def cpu_baseline(a, dnn_units):
-    """The oracle port (oracle/torch_ref.py) of the same training step on the host cores, bounded sample."""
+    """The oracle port (oracle/torch_ref.py) of the same training step on the host cores, on a bounded sample of the workload
+    (SURVEY.md §8d / BASELINE.md §2: warm-up, median, forward-only and forward+backward separately).  The true reference
+    (TF-CPU) cannot run here (no TensorFlow): `kind` is "port"."""
     from oracle import torch_ref as T
     import math
     ncores = os.cpu_count() or 1
     torch.set_num_threads(ncores)
+    g = torch.Generator().manual_seed(42)
+    if a.model == "dssm":
+        D, B, units = a.dim, a.batch, [int(x) for x in a.towers.split(",") if x]
+        ut = torch.empty((a.users, D)).normal_(0, 1 / math.sqrt(D), generator=g)
+        it = torch.empty((a.items, D)).normal_(0, 1 / math.sqrt(D), generator=g)
+
+        def mk():
+            Ws, d = [], D
+            for u in units:
+                Ws.append(((torch.rand((d, u), generator=g) * 2 - 1) * math.sqrt(6.0 / (d + u)), torch.zeros(u)))
+                d = u
+            return Ws
+        qW, cW = mk(), mk()
+
+        def tower(x, Ws):
+            for i, (W, b) in enumerate(Ws):
+                x = x @ W + b
+                if i < len(Ws) - 1:
+                    x = torch.relu(x)
+            return x
+
+        def step(train):
+            uid, iid = torch.randint(0, a.users, (B,), generator=g), torch.randint(0, a.items, (B,), generator=g)
+            ue, ie = ut[uid].requires_grad_(train), it[iid].requires_grad_(train)
+            ps = [t.requires_grad_(train) for W, b in qW + cW for t in (W, b)]
+            loss = T.inbatch_softmax_loss(tower(ue, qW), tower(ie, cW), cand_ids=iid)
+            if train:
+                gs = torch.autograd.grad(loss, [ue, ie] + ps)
+                with torch.no_grad():
+                    ut.index_add_(0, uid, gs[0], alpha=-a.lr)
+                    it.index_add_(0, iid, gs[1], alpha=-a.lr)
+                    for t, gr in zip(ps, gs[2:]):
+                        t.sub_(a.lr * gr)
+            for t in ps:
+                t.requires_grad_(False)
+        full, n1 = _median_rate(lambda: step(True), B, 2, 5, 10.0)
+        with torch.no_grad():
+            fwd, n2 = _median_rate(lambda: step(False), B, 2, 5, 5.0)
+        return {"value": full, "unit": "examples/sec", "cores": ncores, "kind": "port", "forward_only_value": fwd,
+                "sample": "median of %d two-tower SGD steps (and %d forward-only passes) of batch %d on torch-CPU autograd over the "
+                          "oracle's restated Retrieval loss (oracle/torch_ref.py), 2 warm-up calls each; full-size tables (%d users, "
+                          "%d items, dim %d); ids pre-hashed; top-K metric pass not included" % (n1, n2, B, a.users, a.items, D)}
     V = min(a.vocab, 1_000_000)         # 26 x 1 M x 64 fp32 = 6.7 GB: the full 66.6 GB does not fit typical host RAM
     try:
         import psutil
@@ -94,8 +177,8 @@ def cpu_baseline(a, dnn_units):
             V = min(V, 100_000)
     except Exception:
         pass
-    F, D, B = a.fields, a.dim, a.batch
-    g = torch.Generator().manual_seed(42)
+    F, D = a.fields, a.dim
+    B = min(a.batch, 16384)             # bounded sample: a quarter of the GPU batch keeps two modes x (warm-up + 5 steps) in ~30 s
     table = torch.empty((F * V, D)).normal_(0, 1 / math.sqrt(D), generator=g)
     lin_w = torch.zeros(F * V)
     d = F * D + a.dense
@@ -106,21 +189,24 @@ def cpu_baseline(a, dnn_units):
         biases.append(torch.zeros(u))
         d = u
     row_base = [f * V for f in range(F)]
-    ids = torch.randint(0, V, (B, F), generator=g)
     dense = torch.log1p(torch.randn((B, a.dense), generator=g).abs()) if a.dense else None
     labels = (torch.rand(B, generator=g) < 0.25).float()
     params = (table, lin_w, torch.zeros(()), kernels, biases)
-    T.deepfm_train_step_sgd(params, ids, dense, labels, None, row_base, a.lr)       # warm-up
-    t0 = time.perf_counter()
-    n = 0
-    while n < 20 and (n < 2 or time.perf_counter() - t0 < 10.0):
+
+    def train():
         ids = torch.randint(0, V, (B, F), generator=g)
         T.deepfm_train_step_sgd(params, ids, dense, labels, None, row_base, a.lr)
-        n += 1
-    dt = (time.perf_counter() - t0) / n
-    return {"value": B / dt, "unit": "examples/sec", "cores": ncores, "kind": "port",
-            "sample": "%d DeepFM SGD steps of batch %d on torch-CPU (oracle/torch_ref.py), tables scaled to "
-                      "V=%d rows/field (%.1f GB); ids pre-hashed" % (n, B, V, F * V * D * 4 / 1e9)}
+
+    def fwd_only():
+        ids = torch.randint(0, V, (B, F), generator=g)
+        with torch.no_grad():
+            T.sigmoid_cross_entropy(labels, T.deepfm_logit(table, lin_w, params[2], ids, list(range(F + 1)), row_base, kernels, biases, dense))
+    full, n1 = _median_rate(train, B, 2, 5, 12.0)
+    fwd, n2 = _median_rate(fwd_only, B, 2, 5, 6.0)
+    return {"value": full, "unit": "examples/sec", "cores": ncores, "kind": "port", "forward_only_value": fwd,
+            "sample": "median of %d DeepFM SGD steps (and %d forward-only passes) of batch %d on torch-CPU (oracle/torch_ref.py), 2 warm-up "
+                      "calls each (time cap instead of BASELINE.md's 5 + 20: one step is ~1 s); tables scaled to V=%d rows/field (%.1f GB); "
+                      "ids pre-hashed; DeepFM tower also for --model dcn" % (n1, n2, B, V, F * V * D * 4 / 1e9)}
 
 
 def main():
@@ -148,38 +234,61 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
-    if a.model == "dcn":
-        if world != 1:
-            raise SystemExit("--model dcn is a single-GPU line")
-        from deep_recommenders_amd.dcn_engine import DCNEngine
-        dnn_units = [int(x) for x in a.dnn.split(",") if x] if a.dnn != "256,32" else [1024, 512, 256]
-        eng = DCNEngine(a.fields, a.vocab, a.dim, 3, dnn_units, a.batch, num_dense=a.dense, lr=a.lr, device=device)
-    elif world == 1 and not force_sharded:
-        from deep_recommenders_amd.engine import DeepFMEngine
-        eng = DeepFMEngine(a.fields, a.vocab, a.dim, dnn_units, a.batch, num_dense=a.dense, lr=a.lr, device=device,
-                           optimizer=a.optimizer)
+    sharded = world > 1 or force_sharded
+    extra = {}
+    if a.model == "dssm":
+        towers = [int(x) for x in a.towers.split(",") if x]
+        if sharded:
+            from deep_recommenders_amd.sharded_retrieval import ShardedTwoTowerEngine
+            eng = ShardedTwoTowerEngine(a.users, a.items, a.dim, towers, a.batch, lr=a.lr, k=a.topk, device=device, world=world, rank=rank)
+        else:
+            from deep_recommenders_amd.two_tower_engine import TwoTowerEngine
+            eng = TwoTowerEngine(a.users, a.items, a.dim, towers, a.batch, lr=a.lr, k=a.topk, device=device)
+        g = torch.Generator(device=device)
+        g.manual_seed(42 + rank)
+        batches = [(torch.randint(0, 10**16, (a.batch,), device=device, generator=g),
+                    torch.randint(0, a.items, (a.batch,), device=device, generator=g)) for _ in range(a.pool)]
+        step = lambda i: eng.train_step(*batches[i % len(batches)])
     else:
-        from deep_recommenders_amd.sharded import ShardedDeepFMEngine
-        eng = ShardedDeepFMEngine(a.fields, a.vocab, a.dim, dnn_units, a.batch, num_dense=a.dense, lr=a.lr,
-                                  device=device, world=world, rank=rank, micro_batches=a.micro_batches)
-    batches = synth_batches(a, device, rank)
+        if a.model == "dcn":
+            dnn_units = [int(x) for x in a.dnn.split(",") if x] if a.dnn != "256,32" else [1024, 512, 256]
+            if sharded:
+                from deep_recommenders_amd.sharded import ShardedDCNEngine
+                eng = ShardedDCNEngine(a.fields, a.vocab, a.dim, 3, dnn_units, a.batch, num_dense=a.dense, lr=a.lr, device=device,
+                                       world=world, rank=rank)
+            else:
+                from deep_recommenders_amd.dcn_engine import DCNEngine
+                eng = DCNEngine(a.fields, a.vocab, a.dim, 3, dnn_units, a.batch, num_dense=a.dense, lr=a.lr, device=device)
+        elif not sharded:
+            from deep_recommenders_amd.engine import DeepFMEngine
+            eng = DeepFMEngine(a.fields, a.vocab, a.dim, dnn_units, a.batch, num_dense=a.dense, lr=a.lr, device=device,
+                               optimizer=a.optimizer)
+        else:
+            from deep_recommenders_amd.sharded import ShardedDeepFMEngine
+            eng = ShardedDeepFMEngine(a.fields, a.vocab, a.dim, dnn_units, a.batch, num_dense=a.dense, lr=a.lr,
+                                      device=device, world=world, rank=rank, micro_batches=a.micro_batches, optimizer=a.optimizer)
+        batches = synth_batches(a, device, rank)
+        nb = len(batches)
+        # the data loader knows the next batch: its keys are handed over for route prefetch
+        step = lambda i: eng.train_step(*batches[i % nb], next_keys=batches[(i + 1) % nb][0])
 
-    nb = len(batches)
     for i in range(a.warmup):
-        eng.train_step(*batches[i % nb], next_keys=batches[(i + 1) % nb][0])
+        step(i)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     # ---- timed region: exactly K steps; per-kernel HIP events ride along on the launch stream -------
     prof = getattr(eng, "enable_kernel_events", None)
-    if os.environ.get("DR_BENCH_EVENTS", "1") == "0":      # measurement-overhead check only: no per-kernel numbers
+    first_gemm_flops = 2.0 * a.batch * (a.fields * a.dim + a.dense) * (dnn_units[0] if dnn_units else 1)
+    events_on = a.events == "on" or (a.events == "auto" and (a.model != "deepfm" or first_gemm_flops >= 4e9))
+    if os.environ.get("DR_BENCH_EVENTS", "1") == "0" or not events_on:
         prof = None
     if prof is not None:
         eng.enable_kernel_events(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(a.steps):          # the data loader knows the next batch: its keys are handed over for route prefetch
-        eng.train_step(*batches[(a.warmup + i) % nb], next_keys=batches[(a.warmup + i + 1) % nb][0])
+    for i in range(a.steps):
+        step(a.warmup + i)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -193,20 +302,43 @@ def main():
     value = a.batch * world * a.steps / dt
 
     kernels = eng.kernel_event_summary() if prof is not None else {}
-    # HBM traffic per launch from the PMC counters (collected in separate rocprofv3 --pmc passes of this same command,
-    # corrected as MI355X_MICROARCH.md prescribes; committed under profiles/): event name -> profiled kernel name
-    traffic = {}
+    pairs = eng.concurrent_pair_summary() if (prof is not None and hasattr(eng, "concurrent_pair_summary")) else []
+    if prof is not None:
+        eng.enable_kernel_events(False)
+    if a.model == "dssm":
+        # FactorizedTopK pass (factorized_top_k.py:489-512): corpus index = item tower over all items, then exact top-k of
+        # every query against it; reported next to the training step (Retrieval.call(compute_metrics=True) does both)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        eng.index_corpus()
+        torch.cuda.synchronize()
+        t_index = time.perf_counter() - t1
+        eng.metric_step(*batches[0])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        nm = 3
+        for i in range(nm):
+            hits = eng.metric_step(*batches[i % len(batches)])
+        torch.cuda.synchronize()
+        t_metric = (time.perf_counter() - t1) / nm
+        extra["metric_pass"] = {"index_corpus_ms": round(t_index * 1e3, 3), "topk_ms_per_batch": round(t_metric * 1e3, 3),
+                                "k": a.topk, "corpus_items": a.items,
+                                "scan_tflops": round(2.0 * a.batch * world * a.items * eng.out_dim / t_metric / 1e12, 2),
+                                "top_k_hits_last_batch": [int(h) for h in hits.cpu().tolist()],
+                                "note": "exact MIPS top-%d of %d queries against the item tower's outputs for all %d items%s"
+                                        % (a.topk, a.batch * world, a.items, " (corpus row-sharded, local top-k -> all-gather -> merge)" if sharded else "")}
+    # HBM traffic per launch from the PMC counters: NOT measured in this run -- replayed from the committed rocprofv3 --pmc
+    # passes of this same command (profiles/, see `traffic_source`), only for the default configuration they were taken on
+    traffic, traffic_source = {}, None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-        bf3 = "true" if a.gemm == "bf16x3" else "false"
-        name_map = {"emb_pool_fwd": "emb_pool_fwd_sv_kernel<16,8>", "emb_pool_bwd": "emb_bwd_unique_kernel<16,4,false>",
-                    "hash_bucket_i64": "hash_bucket_i64_kernel",
-                    "linear_fwd_L0": "gemm_f32_mfma_kernel<true,false,0,false,false,%s>" % bf3,
-                    "linear_bwd_dx_L0": "gemm_f32_mfma_kernel<true,true,2,false,false,%s>" % bf3,
-                    "linear_bwd_dw_L0": "gemm_f32_mfma_kernel<false,false,3,false,false,%s>" % bf3}
-        default_cfg = (a.batch, a.fields, a.vocab, a.dim, a.dense, a.dnn) == (65536, 26, 10_000_000, 64, 13, "256,32")
-        if default_cfg and world == 1:
-            traffic = {ev: int(pmc[k]["hbm_bytes_corrected"]) for ev, k in name_map.items() if k in pmc}
+        src = "profiles/r02_pmc_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) else "profiles/r01_pmc_traffic.json"
+        pmc = json.load(open(os.path.join(ROOT, src)))
+        name_map = pmc.get("event_names") or {}
+        default_cfg = (a.model, a.batch, a.fields, a.vocab, a.dim, a.dense, a.dnn, a.optimizer, a.gemm) == \
+            ("deepfm", 65536, 26, 10_000_000, 64, 13, "256,32", "sgd", "bf16x3")
+        if default_cfg and world == 1 and not force_sharded:
+            traffic = {ev: int(pmc["kernels"][k]["hbm_bytes_corrected"]) for ev, k in name_map.items() if k in pmc["kernels"]}
+            traffic_source = src + " (static: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run)"
     except Exception:
         traffic = {}
     roof_all = []
@@ -217,21 +349,15 @@ def main():
         if k["bound"] == "xgmi":      # exchange phases (all-to-all / all-reduce + their local halves): reported apart
             comm_phases[name] = {"avg_us": round(k["ms"] * 1e3, 2), "bytes_per_rank": k.get("alg_bytes"), "launches": k["n"]}
             continue
-        if k["bound"] == "overlap":   # side-stream work hidden under the main stream: its event time is stretched by the
-            notes = {"emb_sort_slots": (167.0, "rocPRIM radix sort of B*F slots + unique flags; runs concurrently with "
-                                               "emb_pool_fwd / linear_fwd_L0, not on the critical path"),
-                     "emb_pool_bwd": (336.0, "sorted scatter-add backward (HBM-bound) on its own stream, concurrent with the "
-                                             "MFMA-bound linear_bwd_dw_L0; standalone = in-process A/B at this shape")}
-            alone, note = next((v for kk, v in notes.items() if name.startswith(kk)), (None, ""))
-            overlapped[name] = {"event_us_while_overlapped": round(k["ms"] * 1e3, 2), "launches": k["n"],
-                                "standalone_us": alone, "alg_bytes": k.get("alg_bytes"), "note": note}
+        if k["bound"] == "overlap":   # side-stream work hidden under the main stream: its event time is stretched by the sharing
+            overlapped[name] = {"event_us_while_overlapped": round(k["ms"] * 1e3, 2), "launches": k["n"], "alg_bytes": k.get("alg_bytes")}
             continue
         if k["bound"] == "hbm":
             ach, peak, unit = k["alg_bytes"] / sec / 1e9, HBM_PEAK_GBS, "GB/s"
         else:
             # the wide-tile GEMMs run on the bf16 pipe in the default mode (6 products per fp32 product); the narrow-tile
             # and fused-tail kernels always use the fp32 MFMA
-            on_bf16 = a.gemm == "bf16x3" and re.match(r"^(linear|cross)_(fwd|bwd_dx|bwd_dw)_L\d+$", name) is not None
+            on_bf16 = a.gemm == "bf16x3" and re.match(r"^(linear|cross|[qc]_tower)_(fwd|bwd_dx|bwd_dw)_L\d+$", name) is not None
             ach, peak, unit = k["alg_flops"] / sec / 1e12, (MFMA_BF16X3_PEAK_TF if on_bf16 else MFMA_F32_PEAK_TF), "TFLOP/s"
         row = {"kernel": name, "bound": k["bound"], "achieved": round(ach, 2), "peak": round(peak, 1), "unit": unit,
                "frac": round(ach / peak, 4), "traffic": traffic.get(name), "avg_us": round(k["ms"] * 1e3, 2),
@@ -240,36 +366,73 @@ def main():
             row["peak_basis"] = ("dense bf16 MFMA peak 2500 TFLOP/s / 6 products per fp32 product" if on_bf16
                                  else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)")
             row["frac_of_f32_mfma_peak"] = round(ach / MFMA_F32_PEAK_TF, 4)
+        if k.get("note"):
+            row["note"] = k["note"]
         if k.get("concurrent_with"):
             row["concurrent_with"] = k["concurrent_with"]     # runs on a second stream next to that kernel: its event time
-                                                              # (and so `achieved`) is stretched by the sharing
+                                                              # (and so `achieved`) is stretched by the sharing -- see roofline_pairs
         roof_all.append(row)
     roof_all.sort(key=lambda r: -r["avg_us"])
-    # the dominant kernel for `roofline` is the longest one that has the chip to itself (a pair of concurrent kernels cannot
-    # be priced one by one); the concurrent ones stay in roofline_all, flagged
+    # kernels that run concurrently on two streams are priced as a PAIR: joint wall time (first start -> last end) against the
+    # sum of the two kernels' roofline times
+    roof_pairs = []
+    for pr in pairs:
+        ideal_us = 0.0
+        for nm_ in pr["kernels"]:
+            k = kernels[nm_]
+            if k["bound"] == "hbm":
+                ideal_us += k["alg_bytes"] / (HBM_PEAK_GBS * 1e9) * 1e6
+            else:
+                ideal_us += k["alg_flops"] / ((MFMA_BF16X3_PEAK_TF if a.gemm == "bf16x3" else MFMA_F32_PEAK_TF) * 1e12) * 1e6
+        roof_pairs.append({"kernels": pr["kernels"], "joint_us": round(pr["joint_us"], 2), "roofline_sum_us": round(ideal_us, 2),
+                           "frac": round(ideal_us / pr["joint_us"], 4)})
     solo = [r for r in roof_all if "concurrent_with" not in r]
     roofline = dict((solo or roof_all)[0]) if roof_all else None
+    if roofline is not None:
+        roofline["traffic_source"] = traffic_source
+        roofline["selection"] = "longest kernel of the timed region that has the chip to itself; concurrent kernels are priced jointly in roofline_pairs"
 
     if rank == 0:
+        opt_s = "SGD" if a.optimizer == "sgd" else "Adam (row-wise on the tables)"
+        par = "single" if world == 1 and not force_sharded else "dp%d+row-sharded-tables" % world
+        where = ("on one GPU (%.1f GB)" % (a.fields * a.vocab * a.dim * 4 / 1e9) if not sharded
+                 else "row-sharded over %d GPUs (id %% N), RCCL all-to-all" % world)
+        if a.model == "deepfm":
+            metric = "examples/sec/node DeepFM (26 sparse feats, 10M vocab, dim 64)"
+            cfgname = "BASELINE.json configs[1], MovieLens-1M shape" if a.preset == "c2" else "BASELINE.json configs[2]"
+            workload = ("DeepFM %s synthetic training step (%s): %d sparse + %d dense, %d vocab/field hashed on device, dim %d, DNN %s+[1] "
+                        "relu, sigmoid-CE, fused %s; batch %d per GPU, ids %s; tables %s%s"
+                        % ("MovieLens-shape" if a.preset == "c2" else "Criteo-shape", cfgname, a.fields, a.dense, a.vocab, a.dim, dnn_units, opt_s, a.batch,
+                           a.ids, where, ", %d micro-batches per step" % getattr(eng, "mb", 1) if sharded else ""))
+        elif a.model == "dcn":
+            metric = "examples/sec DCN (26 sparse + 13 dense, 10M vocab, dim 64, 3 cross layers + MLP %s) -- BASELINE config 4" % dnn_units
+            workload = ("DCN Criteo-shape synthetic training step (BASELINE.json configs[3]): %d sparse + %d dense, %d vocab/field hashed on "
+                        "device, dim %d, 3 full-rank cross layers %dx%d + MLP %s+[1] relu, sigmoid-CE, fused SGD; batch %d per GPU, ids %s; "
+                        "tables %s" % (a.fields, a.dense, a.vocab, a.dim, a.fields * a.dim + a.dense, a.fields * a.dim + a.dense, dnn_units,
+                                       a.batch, a.ids, where))
+        else:
+            metric = "examples/sec two-tower retrieval training step (1M-item corpus, dim 128, in-batch softmax over 8192 candidates) -- BASELINE config 5"
+            workload = ("DSSM-style two-tower synthetic training step (BASELINE.json configs[4]): user keys hashed on device into %d rows, %d "
+                        "items, embedding dim %d, towers %s (relu hidden, linear output), Retrieval loss = in-batch softmax over the batch's "
+                        "%d candidates with accidental-hit removal, CCE SUM, fused SGD; batch %d per GPU; FactorizedTopK pass over the corpus "
+                        "reported in metric_pass%s" % (a.users, a.items, a.dim, a.towers, a.batch * world, a.batch,
+                                                       "; item table and corpus row-sharded over %d GPUs" % world if sharded else ""))
         out = {
-            "metric": "examples/sec/node DeepFM (26 sparse feats, 10M vocab, dim 64)" if a.model == "deepfm"
-            else "examples/sec DCN (26 sparse + 13 dense, 10M vocab, dim 64, 3 cross layers + MLP %s) -- BASELINE config 4" % dnn_units,
+            "metric": metric,
             "value": round(value, 1), "unit": "examples/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong" if a.global_batch else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "DeepFM Criteo-shape synthetic training step (BASELINE.json configs[2]): %d sparse + %d "
-                                   "dense, %d vocab/field hashed on device, dim %d, DNN %s+[1] relu, sigmoid-CE, fused %s; "
-                                   "batch %d per GPU, ids %s; tables %s"
-                                   % (a.fields, a.dense, a.vocab, a.dim, dnn_units, "SGD" if a.optimizer == "sgd" else "Adam (row-wise on the tables)", a.batch, a.ids,
-                                      "on one GPU (%.1f GB)" % (a.fields * a.vocab * a.dim * 4 / 1e9) if world == 1
-                                      else "row-sharded over %d GPUs (id %% N), RCCL all-to-all, %d micro-batches per step" % (world, getattr(eng, "mb", 1))),
+            "config": {"workload": workload,
                        "gemm_products": ("fp32 in / fp32 accumulate; products = 6 bf16 MFMA products of exact 3-way bf16 splits (error vs fp64 <= native fp32 MFMA, tests/test_gpu_kernels.py)"
                                          if a.gemm == "bf16x3" else "native v_mfma_f32_32x32x2_f32"),
-                       "global_batch": a.batch * world, "parallelism": "single" if world == 1 else "dp%d+row-sharded-tables" % world,
-                       "final_loss": round(loss, 6)},
+                       "global_batch": a.batch * world, "parallelism": par, "final_loss": round(loss, 6),
+                       "per_kernel_events": prof is not None},
             "roofline": roofline,
             "roofline_all": roof_all,
         }
+        if roof_pairs:
+            out["roofline_pairs"] = roof_pairs
+        out.update(extra)
         if comm_phases:
             out["exchange_phases"] = comm_phases
         if overlapped:

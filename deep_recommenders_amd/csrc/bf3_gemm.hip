@@ -80,7 +80,9 @@ struct NtArgs {
     const float* mask; int64_t ld_mask;          // optional: C = 0 where mask[m][n] <= 0   (ReLU' of the layer below)
 };
 
-template <int WM, int WN>
+// DBG (tools/exp/bf3_ablate.hip only; 0 in the library): 1 = no LDS-DMA after the first k-tile, 2 = no MFMAs,
+// 4 = LDS-DMA re-reads the first k-tile (cache hits)
+template <int WM, int WN, int DBG = 0>
 __global__ __launch_bounds__(NTHREADS, 2) void bf3_gemm_nt_kernel(NtArgs g) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;                 // bytes: rows x 64-byte rows
@@ -131,27 +133,59 @@ __global__ __launch_bounds__(NTHREADS, 2) void bf3_gemm_nt_kernel(NtArgs g) {
         for (int i = 0; i < PER_WAVE; ++i) {
             unsigned char* dst = smem + stage * STAGE + (wave + NWAVES * i) * 1024;
             lds_dma16(src[i], dst);
-            src[i] += BK;
+            if constexpr (!(DBG & 4)) src[i] += BK;
         }
     };
 
     f32x16 acc[2][2];
-    auto compute = [&](int stage) {
+    // One k-tile: all 24 fragment reads are issued up front (the first k-step's MFMAs start as soon as its 12 have landed, the
+    // second k-step's land under them), and the next k-tile's LDS-DMA pieces are issued one at a time BETWEEN MFMAs of the
+    // first k-step, where the ~60-cycle issue cost of a piece sits in the shadow of the matrix pipe instead of in front of it
+    // (issued as a block after the barrier, the 9 pieces kept both waves of a SIMD off the pipe for ~1300 cycles per k-tile).
+    auto compute = [&](int stage, bool prefetch) {
         // offsets into the __shared__ array itself (not generic pointers: an XOR on a generic pointer makes hipcc emit
         // flat_load, which also drags the LDS-DMA's vmcnt into every fragment wait)
         const int sa = stage * STAGE + a_off, sb = stage * STAGE + b_off;
+        bf16x8 af[2][3][2], bf[2][3][2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[3][2], bf[3][2];
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int p = 0; p < 3; ++p)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    af[p][t] = *reinterpret_cast<const bf16x8*>(&smem[(sa ^ (ks * 32)) + p * A_PLANE + t * 32 * 64]);
-                    bf[p][t] = *reinterpret_cast<const bf16x8*>(&smem[(sb ^ (ks * 32)) + p * B_PLANE + t * 32 * 64]);
+                    af[ks][p][t] = *reinterpret_cast<const bf16x8*>(&smem[(sa ^ (ks * 32)) + p * A_PLANE + t * 32 * 64]);
+                    bf[ks][p][t] = *reinterpret_cast<const bf16x8*>(&smem[(sb ^ (ks * 32)) + p * B_PLANE + t * 32 * 64]);
                 }
-            mma6<2, 2>(af, bf, acc);
-        }
+        constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
+        unsigned char* const dma_dst = smem + (stage ^ 1) * STAGE + wave * 1024;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int term = 0; term < 6; ++term) {
+                if constexpr (DBG & 2) {
+                    acc[0][0][term] += (float)af[ks][PA[term]][0][0] + (float)af[ks][PA[term]][1][0];
+                    acc[0][1][term] += (float)bf[ks][PB[term]][0][0] + (float)bf[ks][PB[term]][1][0];
+                } else {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][PA[term]][a], bf[ks][PB[term]][b], acc[a][b], 0, 0, 0);
+                }
+                if constexpr (!(DBG & 1)) {
+                    // pieces 0..8 of the next k-tile after MFMA groups 0..8 (of 12): every piece has at least a quarter of a
+                    // k-tile of matrix-pipe time to land before the barrier that publishes it
+                    const int piece = ks * 6 + term;
+                    if (piece < PER_WAVE) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (prefetch) {
+                            lds_dma16(src[piece], dma_dst + NWAVES * piece * 1024);
+                            if constexpr (!(DBG & 4)) src[piece] += BK;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
     };
 
     int tile = blockIdx.x;
@@ -171,9 +205,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void bf3_gemm_nt_kernel(NtArgs g) {
         for (int kt = 0; kt < nk; ++kt) {
             __syncthreads();              // this stage's DMA has landed (vmcnt(0) per wave, then the barrier); all waves are
                                           // done reading the other stage
-            if (kt + 1 < nk) issue(buf ^ 1);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(buf);
+            compute(buf, kt + 1 < nk);
             buf ^= 1;
         }
         // every wave is past the last barrier, i.e. done with stage `buf` (read in iteration nk - 2): the next tile's first
@@ -299,22 +331,42 @@ __global__ __launch_bounds__(NTHREADS, 2) void bf3_gemm_tn_kernel(TnArgs g) {
     };
 
     f32x16 acc[2][2];
-    auto compute = [&](int stage) {
+    // same schedule as the NT kernel: fragment reads up front, the next k-tile's LDS-DMA pieces between the first MFMA groups
+    auto compute = [&](int stage, bool prefetch) {
         const int sa = stage * STAGE + a_off, sb = stage * STAGE + b_off;
+        bf16x8 af[2][3][2], bf[2][3][2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[3][2], bf[3][2];
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int p = 0; p < 3; ++p)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const unsigned char* pa = &smem[(sa ^ (t * 64)) + p * A_PLANE + ks * 16 * ROW_A];
                     const unsigned char* pb = &smem[(sb ^ (t * 64)) + p * B_PLANE + ks * 16 * ROW_B];
-                    af[p][t] = tr_pair(pa, pa + 4 * ROW_A);
-                    bf[p][t] = tr_pair(pb, pb + 4 * ROW_B);
+                    af[ks][p][t] = tr_pair(pa, pa + 4 * ROW_A);
+                    bf[ks][p][t] = tr_pair(pb, pb + 4 * ROW_B);
                 }
-            mma6<2, 2>(af, bf, acc);
-        }
+        constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
+        unsigned char* const dma_dst = smem + (stage ^ 1) * STAGE + wave * 1024;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int term = 0; term < 6; ++term) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][PA[term]][a], bf[ks][PB[term]][b], acc[a][b], 0, 0, 0);
+                const int piece = ks * 6 + term;
+                if (piece < PER_WAVE) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (prefetch) {
+                        lds_dma16(src[piece], dma_dst + NWAVES * piece * 1024);
+                        src[piece] += (wave + NWAVES * piece < KB_A) ? src_step[0] : src_step[1];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
     };
 
     int tile = blockIdx.x;
@@ -333,9 +385,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void bf3_gemm_tn_kernel(TnArgs g) {
         const int tnk = nk;
         for (int kt = 0; kt < tnk; ++kt) {
             __syncthreads();
-            if (kt + 1 < tnk) issue(buf ^ 1);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(buf);
+            compute(buf, kt + 1 < tnk);
             buf ^= 1;
         }
         const int next = tile + gridDim.x;
