@@ -266,7 +266,8 @@ def main():
         else:
             from deep_recommenders_amd.sharded import ShardedDeepFMEngine
             eng = ShardedDeepFMEngine(a.fields, a.vocab, a.dim, dnn_units, a.batch, num_dense=a.dense, lr=a.lr,
-                                      device=device, world=world, rank=rank, micro_batches=a.micro_batches, optimizer=a.optimizer)
+                                      device=device, world=world, rank=rank, micro_batches=a.micro_batches,
+                                      **({"optimizer": a.optimizer} if a.optimizer != "sgd" else {}))
         batches = synth_batches(a, device, rank)
         nb = len(batches)
         # the data loader knows the next batch: its keys are handed over for route prefetch

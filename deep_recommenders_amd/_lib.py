@@ -79,6 +79,10 @@ SIGNATURES = {
     "dr_bf3_gemm_nt": [_p, _i64, _i64, _p, _i64, _i64, _i64, _i32, _i32, _p, _i32, _p, _i64, _p, _i64, _p],
     "dr_bf3_gemm_tn_workspace_bytes": [_i64, _i32, _i32],
     "dr_bf3_gemm_tn": [_p, _i64, _i64, _p, _i64, _i64, _i64, _i32, _i32, _f32, _p, _i64, _p, _p, _p, _i64, _p],
+    "dr_cin_fwd": [_p, _p, _i64, _i32, _i32, _i32, _p, _i32, _p, _i32, _p, _p],
+    "dr_cin_bwd": [_p, _p, _i64, _i32, _i32, _i32, _p, _i32, _i32, _p, _p, _p, _p, _p, _p, _p],
+    "dr_din_concat_fwd": [_p, _p, _i64, _i32, _i32, _p, _i64, _p],
+    "dr_din_concat_bwd": [_p, _p, _i64, _i32, _i32, _p, _i64, _p, _p, _p],
     "dr_version": [],
     "dr_set_gemm_mode": [_i32],
     "dr_get_gemm_mode": [],

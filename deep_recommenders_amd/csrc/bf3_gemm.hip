@@ -29,6 +29,7 @@
 //       32-lane half of ds_read_b64_tr_b16 touches fall on 4 distinct 64-byte quarters of the bank row
 #include "dr_common.h"
 #include "bf3_split.h"
+#include <cstdlib>
 
 namespace {
 
@@ -238,6 +239,248 @@ __global__ __launch_bounds__(NTHREADS, 2) void bf3_gemm_nt_kernel(NtArgs g) {
             }
         if (next >= ntiles) break;
         tile = next;
+    }
+}
+
+// =====================================================================================================================
+// NT, three-stage pipeline ("pipe"): the same product on 128 x 128 x 32 tiles with THREE LDS stages, so that the HBM stream
+// of the big operand runs one to two k-tiles ahead of the matrix pipe instead of in lock step with it.
+//
+// What the two-stage kernel above measured (tools/exp/bf3_ablate.hip, M = 65536, K = 1696, N = 256): 369 us, of which the
+// pieces -- A stream from HBM 132 us (667 MB at 5.05 TB/s), B tiles from L2 75 us, barrier + fragment reads 106 us, MFMAs
+// ~165 us at the clock the chip holds -- run essentially back to back: with two 72 KB stages a k-tile's LDS-DMA is issued one
+// k-tile before the barrier that needs it, every wave waits vmcnt(0) there, and the two waves of a SIMD read fragments and
+// issue MFMAs in phase with each other.
+//
+// Here a block's k-tiles form ONE stream of steps g = 0, 1, 2, ... over all its output tiles (stage = g mod 3):
+//   H0(g):  fragment reads (g, k-step 1) -> set 1 | 12 MFMAs on set 0, pieces 3..5 of step g+2 between them
+//           lgkmcnt(0) (this wave is done with stage g)  ;  vmcnt(6)  (step g+1 has landed; step g+2 may be in flight)
+//           s_barrier                                     -> stage of step g+1 published, stage of step g free
+//   H1(g):  fragment reads (g+1, k-step 0) -> set 0 | 12 MFMAs on set 1, pieces 0..2 of step g+3 (into step g's stage) between them
+// One barrier per k-tile, fragment reads always one phase ahead of their MFMAs, every LDS-DMA piece one and a half to two
+// k-tiles ahead of its barrier, the next output tile's first k-tiles in flight under this tile's epilogue.
+// The fragment reads and the waits are inline asm: for a ds_read the compiler's wait-count pass conservatively waits for EVERY
+// outstanding LDS-DMA (it cannot tell which stage a read touches), which would serialise the pipeline again.
+// Ordering rules used (MI355X_MICROARCH.md, LDS-DMA): a staged buffer is read only after the issuing wave's counted vmcnt AND a
+// barrier the reader has passed; a stage is re-filled only after a barrier that every wave reaches with its reads of that
+// stage retired (the lgkmcnt(0) in front of it).  VMEM operations retire in issue order on gfx9 (one counter for loads and
+// stores), so the epilogue's stores only make the counted waits conservative.
+// =====================================================================================================================
+#define BF3_DS_READ_B128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+
+// NW = 8 (2 x 4 waves of 64 x 32 outputs) or 16 (4 x 4 waves of 32 x 32, four per SIMD): an LDS-DMA piece costs its wave
+// 100 - 350 cycles of issue time (address coalescer queue), during which only OTHER waves of the SIMD can feed the matrix
+// pipe -- with two waves per SIMD the pipe idles about half of the time, with four the stalls overlap.
+template <int NW, int DBG = 0>
+__global__ __launch_bounds__(64 * NW, NW / 4) void bf3_gemm_nt_pipe_kernel(NtArgs g) {
+    constexpr int BM = 128, BN = 128, NS = 3;
+    constexpr int WN = 4, WM = NW / WN, TM = BM / (32 * WM);            // wave grid, MFMA tiles per wave along m (n: one)
+    constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;                 // bytes: rows x 64-byte rows (32 bf16)
+    constexpr int STAGE = 3 * (A_PLANE + B_PLANE);                      // 48 KB
+    constexpr int KB_A = 3 * A_PLANE / 1024, PW = STAGE / 1024 / NW;    // 24 of the 48 1-KB pieces are A; PW pieces per wave
+    constexpr int P1 = (PW + 1) / 2, P0 = PW - P1;                      // issued in H1 (pieces 0..P1-1) / in H0 (the rest)
+    static_assert((NW == 8 || NW == 16) && PW * NW * 1024 == STAGE, "wave layout");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int tiles_m = (int)((g.M + BM - 1) / BM);
+    const int ntiles = tiles_m * tiles_n;
+    const int nk = g.K / BK;
+    if ((int)blockIdx.x >= ntiles) return;
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total = my_tiles * nk;                                    // steps of this block
+
+    // fragment read addresses (LDS byte address within stage 0), one per k-step: row = 32 TM wm + 32 t + l31 (A) / 32 wn + l31 (B),
+    // logical 16-byte chunk 2 ks + hi at physical chunk (2 ks + hi) ^ ((row >> 2) & 3)
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+    const int sw = (l31 >> 2) & 3;
+    unsigned a_addr[2], b_addr[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        a_addr[ks] = lds0 + (wm * 32 * TM + l31) * 64 + (((2 * ks + hi) ^ sw) << 4);
+        b_addr[ks] = lds0 + 3 * A_PLANE + (wn * 32 + l31) * 64 + (((2 * ks + hi) ^ sw) << 4);
+    }
+
+    // ---- producer: the block's LDS-DMA stream -----------------------------------------------------------------------
+    const __bf16* src[PW];
+    int p_tile = blockIdx.x, p_kt = 0, p_stage = 0;                     // next step to issue, its stage
+    auto setup_src = [&](int tile) {
+        const int lid = xcd_remap(tile, ntiles);
+        const int64_t m0 = (int64_t)(lid / tiles_n) * BM;
+        const int n0 = (lid % tiles_n) * BN;
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const int j = wave + NW * i;                                // 1-KB piece of the stage (wave-uniform)
+            const bool is_a = j < KB_A;
+            const int jj = is_a ? j : j - KB_A;
+            const int plane = jj >> 3, rb = jj & 7;                     // 8 pieces of 16 rows per plane
+            const int row = rb * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ ((row >> 2) & 3);
+            int64_t grow = (is_a ? m0 : (int64_t)n0) + row;
+            const int64_t lim = is_a ? g.M : (int64_t)g.N;
+            grow = grow < lim ? grow : lim - 1;                         // rows past the edge only feed unstored outputs
+            src[i] = is_a ? g.A + plane * g.a_ps + grow * g.a_ld + c * 8 : g.B + plane * g.b_ps + grow * g.b_ld + c * 8;
+        }
+    };
+    auto issue_piece = [&](int i) {
+        lds_dma16(src[i], smem + p_stage * STAGE + (wave + NW * i) * 1024);
+        if constexpr (!(DBG & 4)) src[i] += BK;
+    };
+    auto advance = [&]() {                                              // after the last piece of a step
+        p_stage = p_stage == NS - 1 ? 0 : p_stage + 1;
+        if (++p_kt == nk) {
+            p_kt = 0;
+            p_tile += gridDim.x;
+            if (p_tile < ntiles) setup_src(p_tile);
+        }
+    };
+
+    bf16x8 fa[2][3][TM], fb[2][3];                                      // [set][plane][t]: set s holds k-step s of a k-tile
+    auto read_set = [&](int set, int stage) {
+        const unsigned aa = a_addr[set] + stage * STAGE, bb = b_addr[set] + stage * STAGE;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            BF3_DS_READ_B128(fa[set][p][0], aa, p * A_PLANE);
+            if constexpr (TM == 2) BF3_DS_READ_B128(fa[set][p][TM - 1], aa, p * A_PLANE + 32 * 64);
+            BF3_DS_READ_B128(fb[set][p], bb, p * B_PLANE);
+        }
+    };
+    auto wait_set = [&](int set) {      // the reads into `set` have landed; ties the MFMAs that follow to the wait
+        if constexpr (TM == 2)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(fa[set][0][0]), "+v"(fa[set][0][TM - 1]), "+v"(fa[set][1][0]), "+v"(fa[set][1][TM - 1]),
+                           "+v"(fa[set][2][0]), "+v"(fa[set][2][TM - 1]), "+v"(fb[set][0]), "+v"(fb[set][1]), "+v"(fb[set][2]));
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(fa[set][0][0]), "+v"(fa[set][1][0]), "+v"(fa[set][2][0]), "+v"(fb[set][0]), "+v"(fb[set][1]),
+                           "+v"(fb[set][2]));
+    };
+    f32x16 acc[TM];
+    constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
+    // 6 TM MFMAs on `set`; the LDS-DMA pieces [i0, i0 + n) of the producer's current step after terms 0, 2 and 4
+    auto mma_phase = [&](int set, int i0, int n, bool dma) {
+#pragma unroll
+        for (int term = 0; term < 6; ++term) {
+            if constexpr (!(DBG & 2)) {
+#pragma unroll
+                for (int t = 0; t < TM; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][PA[term]][t], fb[set][PB[term]], acc[t], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int t = 0; t < TM; ++t) acc[t][term] += (float)fa[set][PA[term]][t][0] + (float)fb[set][PB[term]][0];
+            }
+            if ((term & 1) == 0 && (term >> 1) < n) {
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!(DBG & 1)) {
+                    if (dma) issue_piece(i0 + (term >> 1));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    // ---- prologue: steps 0 and 1 entirely, the first P1 pieces of step 2 ---------------------------------------------------
+    setup_src(p_tile);
+#pragma unroll
+    for (int i = 0; i < PW; ++i) issue_piece(i);
+    advance();
+    if (total > 1) {
+#pragma unroll
+        for (int i = 0; i < PW; ++i) issue_piece(i);
+        advance();
+    }
+    if (total > 2) {
+#pragma unroll
+        for (int i = 0; i < P1; ++i) issue_piece(i);
+    }
+    if (total > 2) __builtin_amdgcn_s_waitcnt(0x0F70 | ((PW + P1) & 15) | ((((PW + P1) >> 4) & 3) << 14));   // vmcnt(PW + P1)
+    else if (total > 1) __builtin_amdgcn_s_waitcnt(0x0F70 | PW);                                             // vmcnt(PW)
+    else __builtin_amdgcn_s_waitcnt(0x0F70);                                                                 // vmcnt(0)
+    asm volatile("s_barrier" ::: "memory");
+    read_set(0, 0);
+
+    int tile = blockIdx.x, kt = 0, stage = 0;
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+    for (int step = 0; step < total; ++step) {
+        // ---- H0 ----
+        wait_set(0);
+        read_set(1, stage);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_phase(0, P1, P0, step + 2 < total);                         // the last P0 pieces of step + 2
+        if (step + 2 < total) advance();
+        wait_set(1);
+        if (step + 2 < total) __builtin_amdgcn_s_waitcnt(0x0F70 | PW);  // vmcnt(PW): step + 1 landed, step + 2 may be in flight
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+        asm volatile("s_barrier" ::: "memory");
+        // ---- H1 ----
+        const int nstage = stage == NS - 1 ? 0 : stage + 1;
+        if (step + 1 < total) read_set(0, nstage);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_phase(1, 0, P1, step + 3 < total);                          // the first P1 pieces of step + 3 (into this step's stage)
+        stage = nstage;
+        if (++kt < nk) continue;
+        // ---- epilogue of an output tile: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+        kt = 0;
+        {
+            const int lid = xcd_remap(tile, ntiles);
+            const int64_t tm0 = (int64_t)(lid / tiles_n) * BM;
+            const int tn0 = (lid % tiles_n) * BN;
+            const int col = tn0 + wn * 32 + l31;
+            const bool cv = col < g.N;
+            const int colc = cv ? col : g.N - 1;
+            float bj = g.bias != nullptr ? g.bias[colc] : 0.f;
+            // consume the load HERE on every path: left pending into a branch, its register keeps hipcc's wait-count pass
+            // inserting a vmcnt(0) at the top of the main loop (which would drain the LDS-DMA pipeline every k-tile)
+            asm volatile("" : "+v"(bj));
+            const bool relu = g.act == 1;
+            // interior tiles (all but the last row / column of tiles): every store unconditional -- a store under a divergent
+            // branch makes hipcc wait vmcnt(0) in front of each one
+            if (tm0 + BM <= g.M && tn0 + BN <= g.N) {
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) {
+                    const int64_t r0 = tm0 + wm * 32 * TM + mi * 32 + 4 * hi;
+                    float* crow = g.C + r0 * g.ldc + col;
+                    float mk[16];
+                    if (g.mask != nullptr) {
+                        const float* mrow = g.mask + r0 * g.ld_mask + col;
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) mk[reg] = mrow[(int64_t)((reg & 3) + 8 * (reg >> 2)) * g.ld_mask];
+                    }
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        float v = acc[mi][reg] + bj;
+                        acc[mi][reg] = 0.f;
+                        v = relu ? fmaxf(v, 0.f) : v;
+                        if (g.mask != nullptr) v = mk[reg] > 0.f ? v : 0.f;
+                        crow[(int64_t)((reg & 3) + 8 * (reg >> 2)) * g.ldc] = v;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) {
+                    const int64_t row_b = tm0 + wm * 32 * TM + mi * 32 + 4 * hi;
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int64_t row = row_b + (reg & 3) + 8 * (reg >> 2);
+                        float v = acc[mi][reg] + bj;
+                        acc[mi][reg] = 0.f;
+                        if (!cv || row >= g.M) continue;
+                        v = relu ? fmaxf(v, 0.f) : v;
+                        if (g.mask != nullptr && !(g.mask[row * g.ld_mask + col] > 0.f)) v = 0.f;
+                        g.C[row * g.ldc + col] = v;
+                    }
+                }
+            }
+        }
+        tile += gridDim.x;
     }
 }
 
@@ -563,7 +806,19 @@ extern "C" int dr_bf3_gemm_nt(const void* a_planes, int64_t a_plane_stride, int6
     if (a_ld < K || b_ld < K || ldc < N || (mask != nullptr && ld_mask < N)) return DR_EINVAL;
     NtArgs g{static_cast<const __bf16*>(a_planes), a_plane_stride, a_ld, static_cast<const __bf16*>(b_planes), b_plane_stride, b_ld,
              M, N, K, C, ldc, bias, act, mask, ld_mask};
-    // 128 x 256 tiles: an A row-panel is read once when N <= 256 (the forward: x is the big operand)
+    static const bool pipe = [] { const char* e = getenv("DR_BF3_PIPE"); return e == nullptr || e[0] != '0'; }();
+    if (pipe) {
+        // three-stage 128 x 128 x 32 pipeline; consecutive tiles share an A row-panel (same XCD, L2)
+        const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
+        if (tiles > 0x7fffffff) return DR_EINVAL;
+        const int grid = (int)(tiles < 256 ? tiles : 256);              // persistent: one block per CU
+        static const bool w16 = [] { const char* e = getenv("DR_BF3_WAVES"); return e == nullptr || atoi(e) != 8; }();
+        if (w16) hipLaunchKernelGGL((bf3_gemm_nt_pipe_kernel<16>), dim3(grid), dim3(1024), 0, dr_s(stream), g);
+        else hipLaunchKernelGGL((bf3_gemm_nt_pipe_kernel<8>), dim3(grid), dim3(512), 0, dr_s(stream), g);
+        DR_CHECK_LAUNCH();
+        return DR_OK;
+    }
+    // DR_BF3_PIPE=0: the two-stage 128 x 256 kernel (A/B reference)
     const int64_t tiles = ((M + 127) / 128) * ((N + 255) / 256);
     if (tiles > 0x7fffffff) return DR_EINVAL;
     const int grid = (int)(tiles < 256 ? tiles : 256);                  // persistent: one block per CU

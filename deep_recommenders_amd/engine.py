@@ -167,6 +167,24 @@ class DeepFMEngine:
                 out[name]["concurrent_with"] = self.concurrent[name]     # event time stretched by the co-running kernel
         return out
 
+    def concurrent_pair_summary(self):
+        """Kernels that run concurrently on two streams (first-layer wgrad next to K4) cannot be priced one by one: their joint
+        wall time per step = first start -> last end, from the same HIP events."""
+        torch.cuda.synchronize()
+        done, out = set(), []
+        for a, b in getattr(self, "concurrent", {}).items():
+            if a in done or b in done or a not in (self._events or {}) or b not in (self._events or {}):
+                continue
+            done.update((a, b))
+            ea, eb = self._events[a][2], self._events[b][2]
+            n = min(len(ea), len(eb))
+            tot = 0.0
+            for (sa, fa), (sb, fb) in zip(ea[-n:], eb[-n:]):
+                first = sa if sa.elapsed_time(sb) >= 0 else sb
+                tot += max(first.elapsed_time(fa), first.elapsed_time(fb))
+            out.append({"kernels": [a, b], "joint_us": tot / n * 1e3})
+        return out
+
     # ------------------------------------------------------------------------------------------
     def forward(self, keys: torch.Tensor, dense: Optional[torch.Tensor], labels: Optional[torch.Tensor],
                 loss_mode: int = ops.LOSS_SIGMOID_CE):

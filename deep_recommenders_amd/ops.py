@@ -803,3 +803,49 @@ def bf3_gemm_tn(x: Planes, y: Planes, scale, dstW, y_colsum=None, dstb=None, wor
                                ptr(dstW), dstW.stride(0), ptr(y_colsum), ptr(dstb), ptr(workspace), workspace.numel() * 4,
                                stream_ptr()), "dr_bf3_gemm_tn")
     return dstW
+
+
+# ---- CIN (xDeepFM) and the DIN ActivationUnit input ---------------------------------------------------------------------------
+ACT_CODES = {None: 0, "linear": 0, "relu": 1, "sigmoid": 2, "tanh": 3}
+
+
+def cin_fwd(x0, x, W, bias=None, act=2):
+    """out[b, f, d] = act(sum_ij W[i * Hk + j, f] x0[b, i, d] x[b, j, d] + bias[f]);  x0 [B, H0, D], x [B, Hk, D], W [H0 * Hk, Fm]."""
+    x0, x, W = _c(x0, torch.float32), _c(x, torch.float32), _c(W, torch.float32)
+    B, H0, D = x0.shape
+    Hk = x.shape[1]
+    Fm = W.shape[1]
+    assert x.shape == (B, Hk, D) and W.shape[0] == H0 * Hk
+    out = torch.empty((B, Fm, D), dtype=torch.float32, device=x0.device)
+    check(lib().dr_cin_fwd(ptr(x0), ptr(x), B, H0, Hk, D, ptr(W), Fm, ptr(bias), int(act), ptr(out), stream_ptr()), "dr_cin_fwd")
+    return out
+
+
+def cin_bwd(x0, x, W, act, out, d_out, want_bias=False):
+    x0, x, W, d_out = _c(x0, torch.float32), _c(x, torch.float32), _c(W, torch.float32), _c(d_out, torch.float32)
+    B, H0, D = x0.shape
+    Hk, Fm = x.shape[1], W.shape[1]
+    d_x0, d_x, dW = torch.empty_like(x0), torch.empty_like(x), torch.empty_like(W)
+    dbias = torch.empty(Fm, dtype=torch.float32, device=x0.device) if want_bias else None
+    check(lib().dr_cin_bwd(ptr(x0), ptr(x), B, H0, Hk, D, ptr(W), Fm, int(act), ptr(out), ptr(d_out), ptr(d_x0), ptr(d_x), ptr(dW),
+                           ptr(dbias), stream_ptr()), "dr_cin_bwd")
+    return d_x0, d_x, dW, dbias
+
+
+def din_concat_fwd(x, y, mode):
+    x, y = _c(x, torch.float32), _c(y, torch.float32)
+    B, D = x.shape
+    assert y.shape == (B, D)
+    n = (3 if mode else 2) * D
+    out = torch.zeros((B, _pad4(n)), dtype=torch.float32, device=x.device)[:, :n]
+    check(lib().dr_din_concat_fwd(ptr(x), ptr(y), B, D, int(mode), ptr(out), out.stride(0), stream_ptr()), "dr_din_concat_fwd")
+    return out
+
+
+def din_concat_bwd(x, y, mode, d_out):
+    B, D = x.shape
+    assert d_out.stride(1) == 1
+    d_x, d_y = torch.empty_like(x), torch.empty_like(y)
+    check(lib().dr_din_concat_bwd(ptr(x), ptr(y), B, D, int(mode), ptr(d_out), d_out.stride(0), ptr(d_x), ptr(d_y), stream_ptr()),
+          "dr_din_concat_bwd")
+    return d_x, d_y

@@ -487,6 +487,30 @@ int dr_bf3_gemm_tn(const void* x_planes, int64_t x_plane_stride, int64_t x_ld, c
                    int64_t ld_dst, const float* y_colsum, float* dstb, void* workspace, int64_t workspace_bytes,
                    dr_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * CIN  Compressed Interaction Network layer of xDeepFM (keras/models/ranking/xdeepfm.py:71-96):
+ *   out[b, f, d] = act( sum_{i,j} W[i * Hk + j, f] * x0[b, i, d] * x[b, j, d] + bias[f] )
+ * x0 [B, H0, D], x [B, Hk, D], W [H0 * Hk, Fm] (the conv1d kernel [1, H0 * Hk, Fm] of :55-61), out [B, Fm, D], all fp32
+ * contiguous.  act: 0 none, 1 relu, 2 sigmoid (the layer's default), 3 tanh.  One MFMA GEMM whose left operand (the
+ * outer product :80-86) is formed on the fly from LDS.  DR_ESHAPE when (H0 + Hk) * 65 floats exceed the 160 KB LDS.
+ * dr_cin_bwd: autodiff of the above -- d_x0, d_x, dW [H0 * Hk, Fm], dbias [Fm] (may be NULL) from d_out and the saved out.
+ * ---------------------------------------------------------------------------------------- */
+int dr_cin_fwd(const float* x0, const float* x, int64_t B, int32_t H0, int32_t Hk, int32_t D, const float* W,
+               int32_t Fm, const float* bias, int32_t act, float* out, dr_stream_t stream);
+int dr_cin_bwd(const float* x0, const float* x, int64_t B, int32_t H0, int32_t Hk, int32_t D, const float* W,
+               int32_t Fm, int32_t act, const float* out, const float* d_out, float* d_x0, float* d_x, float* dW,
+               float* dbias, dr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * DIN ActivationUnit input (keras/models/ranking/din.py:59-67): out[b, :] = concat(x[b], y[b], interacter(x, y)[b])
+ * mode 0: no interacter (2 D columns), 1: x - y (keras Subtract, the reference test's interacter), 2: x * y (Multiply).
+ * The two Dense layers that follow (:69-70) are dr_linear_fwd / dr_linear_bwd_*.
+ * ---------------------------------------------------------------------------------------- */
+int dr_din_concat_fwd(const float* x, const float* y, int64_t B, int32_t D, int32_t mode, float* out, int64_t ld_out,
+                      dr_stream_t stream);
+int dr_din_concat_bwd(const float* x, const float* y, int64_t B, int32_t D, int32_t mode, const float* d_out,
+                      int64_t ld_dout, float* d_x, float* d_y, dr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

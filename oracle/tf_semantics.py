@@ -571,3 +571,51 @@ def factorized_top_k_accuracy(queries, true_candidates, candidates, ks, k=100):
     topk_scores, _ = brute_force_top_k(queries, candidates, k=min(k, candidates.shape[0]))
     y_pred = np.concatenate([pos, topk_scores], axis=1)
     return [float(in_top_k(np.zeros(len(y_pred), dtype=np.int64), y_pred, kk).mean()) for kk in ks]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# xDeepFM CIN (keras/models/ranking/xdeepfm.py:71-96) and DIN ActivationUnit (keras/models/ranking/din.py:59-70)
+# ---------------------------------------------------------------------------------------------------------------------------
+def _activation(name):
+    if name in (None, "linear"):
+        return lambda v: v
+    if name == "relu":
+        return lambda v: np.maximum(v, 0.0)
+    if name == "sigmoid":
+        return sigmoid
+    if name == "tanh":
+        return np.tanh
+    raise ValueError(name)
+
+
+def cin(x0, x, kernel, bias=None, activation="sigmoid"):
+    """Follows the reference's op sequence literally: split along D (:80-82), matmul(x0_d, x_d^T) per d (:84), reshape to
+    [D, B, H0 * Hk] (:85), transpose to [B, D, H0 * Hk] (:86), conv1d with a width-1 kernel [1, H0 * Hk, Fm] (:88),
+    bias_add (:90-91), activation (:93), transpose to [B, Fm, D] (:94).  kernel: [H0 * Hk, Fm] or [1, H0 * Hk, Fm]."""
+    x0 = np.asarray(x0)
+    x = np.asarray(x)
+    kernel = np.asarray(kernel)
+    if kernel.ndim == 3:
+        kernel = kernel[0]
+    B, H0, D = x0.shape
+    Hk = x.shape[1]
+    x0s = [x0[:, :, d:d + 1] for d in range(D)]                   # tf.split(x0, field_dim, axis=-1): D x [B, H0, 1]
+    xs = [x[:, :, d:d + 1] for d in range(D)]
+    outer = np.stack([np.matmul(a, np.transpose(b, (0, 2, 1))) for a, b in zip(x0s, xs)], axis=0)   # [D, B, H0, Hk]
+    outer = outer.reshape(D, B, H0 * Hk)
+    outer = np.transpose(outer, (1, 0, 2))                         # [B, D, H0 * Hk]
+    conv_out = outer @ kernel                                      # width-1 VALID conv1d == per-position matmul
+    if bias is not None:
+        conv_out = conv_out + np.asarray(bias)
+    return np.transpose(_activation(activation)(conv_out), (0, 2, 1))
+
+
+def activation_unit(x, y, kernel_w, kernel_b, output_w, output_b, interacter=None, activation="relu"):
+    """din.py:59-70: y defaults to x; concat([x, y(, interacter([x, y]))], axis=1) -> Dense(units, activation) -> Dense(1)."""
+    x = np.asarray(x)
+    y = x if y is None else np.asarray(y)
+    h = np.concatenate([x, y], axis=1)
+    if interacter is not None:
+        h = np.concatenate([h, interacter([x, y])], axis=1)
+    h = dense(h, kernel_w, kernel_b, activation)
+    return dense(h, output_w, output_b, None)

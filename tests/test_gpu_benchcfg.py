@@ -81,7 +81,7 @@ def _assert_update(name, before, after, want_after, rel=2e-3, outliers=1e-4):
             name, float(err[bad].max()), rms)
 
 
-def _assert_close_adam(name, got, want, lr, outliers):
+def _assert_close_adam(name, got, want, lr, outliers, mean_tol=2e-3):
     """Adam at this batch size is an amplifier: on step t the update is lr * g / (|g| + eps'), eps' = eps / sqrt(1 - beta2^t)
     ~ 3e-7, and the gradients of a 65 536-example mean are 1e-8 .. 1e-5 -- for |g| < ~1e-6 a change of 1e-8 in g moves the
     update by more than 2 % of a step.  fp32 rounding is far below that, a ReLU tie (see _assert_update) is not: one hidden
@@ -92,7 +92,7 @@ def _assert_close_adam(name, got, want, lr, outliers):
     err = np.abs(got.astype(np.float64) - want.astype(np.float64))
     frac = float((err > 2e-2 * lr).mean())
     assert frac <= outliers, "%s: %.2e of %d elements differ by more than 2 %% of an Adam step (allowed %.0e)" % (name, frac, err.size, outliers)
-    assert float(err.mean()) <= 2e-3 * lr, "%s: mean difference %.3e of a step" % (name, float(err.mean()) / lr)
+    assert float(err.mean()) <= mean_tol * lr, "%s: mean difference %.3e of a step" % (name, float(err.mean()) / lr)
     assert float(err.max()) <= 1.0 * lr, "%s: worst difference %.3e exceeds one Adam step" % (name, float(err.max()))
 
 
@@ -227,7 +227,9 @@ def _run_deepfm(V, optimizer, kind, lr, steps=2):
             for nm, got, want, ming in (("W%d" % j, eng.Ws[j], orc.Ws[j], orc.min_abs_g[j]), ("b%d" % j, eng.bs[j], orc.bs[j], orc.min_abs_g[nW + j])):
                 sel = (ming >= 1e-5).numpy()
                 if sel.sum() >= 16:
-                    _assert_close_adam(nm, got.cpu().numpy()[sel], want.numpy()[sel], lr, 5e-2)
+                    # second step: m / sqrt(v) mixes g1 and g2, so a ReLU-tie shift of ~1e-7 on |g| ~ 1e-5 (1 %, inside the gradient
+                    # tolerance above) moves the step by up to ~1 %: mean bound 1 % of a step, 10 % of the elements beyond 2 %
+                    _assert_close_adam(nm, got.cpu().numpy()[sel], want.numpy()[sel], lr, 0.10, mean_tol=1e-2)
                 err = np.abs(got.cpu().numpy().astype(np.float64) - want.numpy().astype(np.float64))
                 assert float(err.max()) <= 1.0 * lr, "%s: worst difference %.3e exceeds one Adam step" % (nm, float(err.max()))
         # and the update must not be vacuous: most touched rows moved by about one Adam step

@@ -176,3 +176,26 @@ def test_retrieval_loss_identity_labels():
     s2 = s / 0.5
     want2 = (np.log(np.exp(s2).sum(1)) - np.diag(s2)).sum()
     assert abs(O.retrieval_loss(q, c, temperature=0.5) - want2) < 1e-4
+
+
+def test_cin_oracle_reproduces_reference_known_answers():
+    """tests/keras/test_xdeepfm.py:30-60 (kernel ones, relu; bias ones): pins oracle.cin, the checker of the HIP CIN kernel."""
+    import json, os
+    G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kats.json")))
+    for kat, bias in (("cin_outputs", None), ("cin_bias", np.ones(2, np.float32))):
+        g = G[kat]
+        x0, x = np.asarray(g["x0"], np.float32), np.asarray(g["x"], np.float32)
+        out = O.cin(x0, x, np.ones((1, 4, g["feature_map"]), np.float32), bias, "relu")
+        np.testing.assert_allclose(out, np.asarray(g["expected"], np.float32), rtol=1e-6, atol=1e-6)
+
+
+def test_activation_unit_oracle_reproduces_reference_test_procedure():
+    """tests/keras/test_din.py:17-48: ones kernels => output == reduce_sum(relu(concat @ ones)) (Subtract interacter included)."""
+    rng = np.random.default_rng(1)
+    x, y = rng.normal(size=(3, 5)).astype(np.float32), rng.normal(size=(3, 5)).astype(np.float32)
+    for inter, cols in ((None, [x, y]), ((lambda xy: xy[0] - xy[1]), [x, y, x - y])):
+        h = np.concatenate(cols, axis=1)
+        want = np.maximum(h @ np.ones((h.shape[1], 10), np.float32), 0).sum(axis=1, keepdims=True)
+        got = O.activation_unit(x, y, np.ones((h.shape[1], 10), np.float32), np.zeros(10, np.float32), np.ones((10, 1), np.float32),
+                                np.zeros(1, np.float32), inter)
+        np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6)

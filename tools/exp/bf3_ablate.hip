@@ -13,6 +13,20 @@ __global__ void fill_kernel(uint16_t* p, int64_t n, uint32_t seed) {       // ra
     }
 }
 
+template <int NW, int DBG>
+static float run_pipe(const NtArgs& g, int grid, int reps) {
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((bf3_gemm_nt_pipe_kernel<NW, DBG>), dim3(grid), dim3(64 * NW), 0, 0, g);
+    (void)hipEventRecord(a, 0);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((bf3_gemm_nt_pipe_kernel<NW, DBG>), dim3(grid), dim3(64 * NW), 0, 0, g);
+    (void)hipEventRecord(b, 0);
+    (void)hipEventSynchronize(b);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, a, b);
+    return ms / reps * 1e3f;
+}
+
 template <int DBG>
 static float run(const NtArgs& g, int grid, int reps) {
     hipEvent_t a, b;
@@ -45,6 +59,14 @@ int main(int argc, char** argv) {
         t = run<4>(g, grid, 10); printf("N=%4d DMA cache hits  %8.1f us %6.1f TF/s\n", N, t, fl / t / 1e6);
         t = run<3>(g, grid, 10); printf("N=%4d no DMA no MFMA  %8.1f us %6.1f TF/s\n", N, t, fl / t / 1e6);
         t = run<6>(g, grid, 10); printf("N=%4d hits, no MFMA   %8.1f us %6.1f TF/s\n", N, t, fl / t / 1e6);
+        const int64_t ptiles = ((M + 127) / 128) * ((N + 127) / 128);
+        const int pgrid = ptiles < 256 ? (int)ptiles : 256;
+        t = run_pipe<8, 0>(g, pgrid, 10); printf("N=%4d PIPE8 base            %8.1f us %6.1f TF/s\n", N, t, fl / t / 1e6);
+        t = run_pipe<16, 0>(g, pgrid, 10); printf("N=%4d PIPE16 base           %8.1f us %6.1f TF/s\n", N, t, fl / t / 1e6);
+        t = run_pipe<16, 1>(g, pgrid, 10); printf("N=%4d PIPE16 no DMA         %8.1f us %6.1f TF/s\n", N, t, fl / t / 1e6);
+        t = run_pipe<16, 2>(g, pgrid, 10); printf("N=%4d PIPE16 no MFMA        %8.1f us %6.1f TF/s\n", N, t, fl / t / 1e6);
+        t = run_pipe<16, 4>(g, pgrid, 10); printf("N=%4d PIPE16 DMA cache hits %8.1f us %6.1f TF/s\n", N, t, fl / t / 1e6);
+        t = run_pipe<16, 6>(g, pgrid, 10); printf("N=%4d PIPE16 hits, no MFMA  %8.1f us %6.1f TF/s\n", N, t, fl / t / 1e6);
         (void)hipFree(A); (void)hipFree(B); (void)hipFree(C);
     }
     return 0;
