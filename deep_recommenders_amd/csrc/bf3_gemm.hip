@@ -485,6 +485,350 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void bf3_gemm_nt_pipe_kernel(NtArg
 }
 
 // =====================================================================================================================
+// NT, "register split" (RS):  C[m][n] = epilogue( sum_k A[m][k] B[n][k] ),  A fp32 row-major (an ACTIVATION: x, dy),
+// B pre-split planes (a WEIGHT: W^T for the forward, W for the dgrad).
+//
+// Why: every LDS-staged variant above lands at 150 - 165 TFLOP/s whatever its schedule, because a CU cannot INGEST operand
+// tiles faster than ~14 - 21 bytes per clock through LDS-DMA (tools/exp/bf3_ablate.hip: the DMA stream alone takes 300 us of
+// the 340, the MFMAs alone 250) -- and 128 x 128 / 128 x 256 tiles of six-byte elements need 31 / 23 bytes per clock at the
+// matrix pipe's rate.  A 256 x 256 tile needs 16, but its two operands do not fit the LDS three stages deep.  So only B (shared
+// by the block's 8 waves) goes through the LDS; each wave owns 32 rows x all 256 columns of the tile and loads ITS rows of A
+// straight from HBM into registers as fp32 -- 16 contiguous floats per lane and k-tile, lanes l and l + 32 together one
+// 128-byte line per row -- and splits them into the three bf16 terms in registers (VALU work in the shadow of the other
+// wave's MFMAs; no LDS write, no fragment read for A).  Activations therefore stay fp32 in HBM (4 bytes per element instead
+// of 6, nothing for their producers to do); only the weights are kept as planes (dr_bf3_split after each update).
+// The k index inside a k-tile is permuted consistently on both operands: lane half `hi` holds k = 16 hi .. 16 hi + 15, k-step s
+// uses 16 hi + 8 s .. + 7, i.e. B's 16-byte chunk 2 hi + s.
+//
+// Per step (k-tile of 32), B ring of three 48 KB stages, all counts per wave:
+//   start:     split A(g) in registers (6 fragments), issue the 4 global loads of A(g + 1)
+//   q = 0..15  (k-step q >> 3, column tile q & 7): fragment reads for group q + 1, 6 MFMAs on acc[q & 7];
+//              LDS-DMA pieces of step g + 2 after q = 1, 3, .., 11 (into the stage step g - 1 used)
+//   q = 15:    before reading group 0 of step g + 1: lgkmcnt(0) (done with stage g), vmcnt(10) (step g + 1 landed; A(g + 1) and
+//              step g + 2 may be in flight), s_barrier
+// =====================================================================================================================
+struct RsArgs {
+    const float* A; int64_t lda;
+    const __bf16* B; int64_t b_ps, b_ld;
+    int64_t M; int32_t N; int32_t K;             // K: true reduction length; B's planes are zero in [K, roundup(K, 32))
+    float* C; int64_t ldc;
+    const float* bias; int32_t act;              // C = act(acc + bias[n])
+    const float* mask; int64_t ld_mask;          // optional: C = 0 where mask[m][n] <= 0   (ReLU' of the layer below)
+    int32_t accumulate;                          // C += instead of C =
+    // DCN cross layer (keras/models/ranking/dcn.py:81-88): prod = acc + bias + diag * x ; C = x0 * prod + x ; prod saved
+    const float* x0; const float* xin; int64_t ldx; float diag; float* prod_out;   // x0 == nullptr: plain epilogue
+};
+
+__device__ __forceinline__ void rs_split8(const float4& lo, const float4& hi4, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+    bf16x4 a0, a1, a2, b0, b1, b2;
+    bf3::split4(lo.x, lo.y, lo.z, lo.w, a0, a1, a2);
+    bf3::split4(hi4.x, hi4.y, hi4.z, hi4.w, b0, b1, b2);
+    p0 = __builtin_shufflevector(a0, b0, 0, 1, 2, 3, 4, 5, 6, 7);
+    p1 = __builtin_shufflevector(a1, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+    p2 = __builtin_shufflevector(a2, b2, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// EPI: 0 = bias / ReLU, 1 = + ReLU' mask and / or accumulate, 2 = DCN cross combine (one epilogue per instantiation: all three
+// unrolled over the 8 column tiles in one kernel cost 50 spilled registers)
+template <int EPI, int DBG = 0>
+__global__ __launch_bounds__(512, 2) void bf3_gemm_rs_kernel(RsArgs g) {
+    constexpr int NW = 8, BM = 32 * NW, BN = 256, NT = BN / 32, NS = 3;
+    constexpr int B_PLANE = BN * 64;                                    // bytes: 256 rows x 64-byte rows (32 bf16)
+    constexpr int STAGE = 3 * B_PLANE;                                  // 48 KB
+    constexpr int PW = STAGE / 1024 / NW;                               // 6 LDS-DMA pieces per wave and k-tile
+    static_assert(PW == 6, "piece schedule below assumes 6 pieces per wave and k-tile");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int tiles_m = (int)((g.M + BM - 1) / BM);
+    const int ntiles = tiles_m * tiles_n;
+    const int nk = (g.K + BK - 1) / BK;
+    const bool ktail = (g.K % BK) != 0;
+    if ((int)blockIdx.x >= ntiles) return;
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total = my_tiles * nk;                                    // steps of this block
+
+    // B fragment read addresses (stage 0, plane 0, column tile 0), one per k-step: row = 32 nt + l31, chunk 2 hi + s swizzled
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+    const int sw = (l31 >> 2) & 3;
+    unsigned b_addr[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) b_addr[s] = lds0 + l31 * 64 + (((2 * hi + s) ^ sw) << 4);
+
+    // ---- producer state: the block's stream of steps (tile, k-tile), shared by the B pieces and the A loads -----------------
+    // B: piece j = wave + 8 i of a stage: plane j / 16, rows 16 (j % 16) .. + 15, lane -> (row, 16-byte chunk).
+    // Issued as MUBUF `buffer_load_dwordx4 ... offen lds` (raw buffer builtin), not as global_load_lds: hipcc's wait-count pass
+    // treats the FLAT-encoded form as "may touch LDS through flat" and from then on waits vmcnt(0) for every VMEM result,
+    // the buffer form is counted exactly (a register load followed by 6 pieces gets vmcnt(6)).
+    const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16*>(g.B), 0, (int)min((int64_t)0x7fffffff, 3 * g.b_ps * 2), 0x00020000);
+    int bvoff[PW];                                                      // per-lane byte offset of piece i at k = 0
+    int pb_tile = blockIdx.x, pb_kt = 0, pb_stage = 0, pb_koff = 0;     // pb_koff: byte offset along k of the next real step
+    auto setup_b = [&](int tile) {
+        const int n0 = (xcd_remap(tile, ntiles) % tiles_n) * BN;
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const int j = wave + NW * i;
+            const int plane = j >> 4, rb = j & 15;
+            const int row = rb * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ ((row >> 2) & 3);
+            int64_t grow = (int64_t)n0 + row;
+            grow = grow < g.N ? grow : g.N - 1;                         // columns past the edge only feed unstored outputs
+            bvoff[i] = (int)((plane * g.b_ps + grow * g.b_ld + c * 8) * 2);
+        }
+    };
+    // EVERY step issues exactly 4 A loads and 6 pieces, also the last ones of the block (whose successors do not exist): with a
+    // fixed number of VMEM operations per step the counted waits are constants, and hipcc's own wait for the A registers comes
+    // out as vmcnt(6).  A step that does not exist re-fetches the last k-tile into a stage nobody will read again.
+    auto issue_b = [&](int i) {
+        unsigned char* dst = smem + pb_stage * STAGE + (wave + NW * i) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(brsrc, (lds_ptr_t)dst, 16, bvoff[i], (DBG & 4) ? 0 : pb_koff, 0, 0);
+    };
+    auto advance_b = [&]() {                                            // after the 6 pieces of a REAL step
+        pb_stage = pb_stage == NS - 1 ? 0 : pb_stage + 1;
+        pb_koff += BK * 2;
+        if (++pb_kt == nk) {
+            pb_kt = 0;
+            pb_tile += gridDim.x;
+            if (pb_tile < ntiles) {
+                setup_b(pb_tile);
+                pb_koff = 0;
+            } else {
+                pb_koff -= BK * 2;                                      // end of the stream: dummies re-fetch the last k-tile
+            }
+        }
+    };
+    // A: this lane's 16 floats of a k-tile
+    const float* asrc = nullptr;
+    int pa_tile = blockIdx.x, pa_kt = 0;
+    auto setup_a = [&](int tile) {
+        const int64_t m0 = (int64_t)(xcd_remap(tile, ntiles) / tiles_n) * BM;
+        int64_t row = m0 + wave * 32 + l31;
+        row = row < g.M ? row : g.M - 1;                                // rows past the edge only feed unstored outputs
+        asrc = g.A + row * g.lda + 16 * hi;
+    };
+    float4 an[4];                                                       // A of the NEXT step, in flight
+    const int kv4 = (g.K + 3) / 4 * 4;                                  // rows are readable up to here (lda % 4 == 0, lda >= K)
+    int an_k0 = 0;                                                      // k index of an[0].x
+    auto mask_a = [&]() {
+        if (!ktail) return;                                             // kernel-uniform: K % 32 == 0 has nothing to zero
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = an_k0 + 4 * q;
+            an[q].x = k < g.K ? an[q].x : 0.f;
+            an[q].y = k + 1 < g.K ? an[q].y : 0.f;
+            an[q].z = k + 2 < g.K ? an[q].z : 0.f;
+            an[q].w = k + 3 < g.K ? an[q].w : 0.f;
+        }
+    };
+    auto load_a = [&](bool real) {
+        // Every load unconditional (a load under a divergent branch makes hipcc's wait-count pass fall back to vmcnt(0), which
+        // would also drain the LDS-DMA pieces in flight): in the last k-tile of a row a 16-byte load that would start past the
+        // row's readable end is pulled back inside it, and everything at k >= K is zeroed in registers -- B's planes are zero
+        // there, but 0 * NaN is not.
+        // The zeroing happens when the values are CONSUMED (mask_a, at the start of the step that uses them): touching them
+        // here would wait for the loads on the spot.
+        an_k0 = pa_kt * BK + 16 * hi;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int over = max(0, an_k0 + 4 * q - (kv4 - 4));
+            an[q] = *reinterpret_cast<const float4*>(asrc + 4 * q - over);
+        }
+        if (!real) return;                                              // (uniform; no VMEM below)
+        if constexpr (!(DBG & 8)) asrc += BK;
+        if (++pa_kt == nk) {
+            pa_kt = 0;
+            pa_tile += gridDim.x;
+            if (pa_tile < ntiles) setup_a(pa_tile);
+            else if constexpr (!(DBG & 8)) asrc -= (int64_t)nk * BK;    // end of the stream: the dummy loads re-read k-tile 0 of the
+                                                                        // last rows (pa_kt == 0, so `over` keeps them inside the row)
+        }
+    };
+
+    bf16x8 fa[2][3];                                                    // [k-step][plane] of the CURRENT step
+    bf16x8 fb[2][3];                                                    // [buffer][plane]: group q uses buffer q & 1
+    auto read_b = [&](int buf, int stage, int q) {                      // group q = (k-step q >> 3, column tile q & 7)
+        const unsigned bb = b_addr[q >> 3] + stage * STAGE;
+        const int nt = q & 7;
+        // immediates must be literal: dispatch on the column tile
+#define RS_READ3(NTI)                                                        \
+        BF3_DS_READ_B128(fb[buf][0], bb, 0 * B_PLANE + NTI * 2048);          \
+        BF3_DS_READ_B128(fb[buf][1], bb, 1 * B_PLANE + NTI * 2048);          \
+        BF3_DS_READ_B128(fb[buf][2], bb, 2 * B_PLANE + NTI * 2048);
+        switch (nt) {
+            case 0: RS_READ3(0) break; case 1: RS_READ3(1) break; case 2: RS_READ3(2) break; case 3: RS_READ3(3) break;
+            case 4: RS_READ3(4) break; case 5: RS_READ3(5) break; case 6: RS_READ3(6) break; default: RS_READ3(7) break;
+        }
+#undef RS_READ3
+    };
+    auto wait_b = [&](int buf) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[buf][0]), "+v"(fb[buf][1]), "+v"(fb[buf][2]));
+    };
+    f32x16 acc[NT];
+    constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
+
+    // ---- prologue: B steps 0 and 1, A step 0 ---------------------------------------------------------------------------------
+    setup_b(pb_tile);
+    setup_a(pa_tile);
+#pragma unroll
+    for (int i = 0; i < PW; ++i) issue_b(i);
+    advance_b();
+    load_a(true);                                                       // BEFORE step 1's pieces: 6 VMEM operations follow the A
+#pragma unroll                                                          // loads on every path into the loop, as inside it
+    for (int i = 0; i < PW; ++i) issue_b(i);
+    if (total > 1) advance_b();
+    __builtin_amdgcn_s_waitcnt(0x0F70 | 10);                            // vmcnt(10): step 0's pieces landed
+    asm volatile("s_barrier" ::: "memory");
+    read_b(0, 0, 0);
+
+    int tile = blockIdx.x, kt = 0, stage = 0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+    for (int step = 0; step < total; ++step) {
+        // ---- step start: A of this step -> bf16 terms (the compiler waits for the loads here), next step's A into flight ----
+        mask_a();
+        rs_split8(an[0], an[1], fa[0][0], fa[0][1], fa[0][2]);
+        rs_split8(an[2], an[3], fa[1][0], fa[1][1], fa[1][2]);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool has_a = step + 1 < total, has_b = step + 2 < total;
+        load_a(has_a);
+        __builtin_amdgcn_sched_barrier(0);
+        const int nstage = stage == NS - 1 ? 0 : stage + 1;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            wait_b(q & 1);
+            if (q < 15) {
+                read_b((q + 1) & 1, stage, q + 1);
+            } else {
+                // this wave is done reading stage `stage`; publish step + 1
+                __builtin_amdgcn_s_waitcnt(0x0F70 | 10);               // vmcnt(10): all but this step's 4 A loads + 6 pieces
+                asm volatile("s_barrier" ::: "memory");
+                if (has_a) read_b(0, nstage, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(DBG & 2)) {
+#pragma unroll
+                for (int term = 0; term < 6; ++term)
+                    acc[q & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q >> 3][PA[term]], fb[q & 1][PB[term]], acc[q & 7], 0, 0, 0);
+            } else {
+                acc[q & 7][0] += (float)fa[q >> 3][0][0] + (float)fb[q & 1][0][0] + (float)fb[q & 1][1][0] + (float)fb[q & 1][2][0];
+            }
+            __builtin_amdgcn_sched_barrier(0);    // keeps the next group's lgkmcnt wait from being hoisted between these MFMAs
+            if ((q & 1) == 1 && q < 2 * PW) {
+                if constexpr (!(DBG & 1)) issue_b(q >> 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (has_b) advance_b();
+        stage = nstage;
+        if (++kt < nk) continue;
+        // ---- epilogue of an output tile: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+        kt = 0;
+        {
+            const int lid = xcd_remap(tile, ntiles);
+            const int64_t tm0 = (int64_t)(lid / tiles_n) * BM;
+            const int tn0 = (lid % tiles_n) * BN;
+            const bool relu = g.act == 1;
+            const int64_t r0 = tm0 + wave * 32 + 4 * hi;
+            // interior tiles: every load / store of the epilogue unconditional (a memory operation under a divergent branch makes
+            // hipcc wait vmcnt(0) in front of each one); edge tiles take the guarded loop
+            const bool interior = tm0 + BM <= g.M && tn0 + BN <= g.N;
+            constexpr bool cross = EPI == 2;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int col = tn0 + nt * 32 + l31;
+                const bool cv = col < g.N;
+                float bj = g.bias != nullptr ? g.bias[cv ? col : g.N - 1] : 0.f;
+                asm volatile("" : "+v"(bj));      // consume the load on every path (see bf3_gemm_nt_pipe_kernel)
+                if (interior) {
+                    float* crow = g.C + r0 * g.ldc + col;
+                    if constexpr (cross) {
+                        const int64_t xo = r0 * g.ldx + col;
+#pragma unroll
+                        for (int c4 = 0; c4 < 4; ++c4) {             // four rows at a time: short-lived temporaries (the 128
+                            float x0v[4], xv[4];                      // accumulators are all live here)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                x0v[e] = g.x0[xo + (int64_t)(e + 8 * c4) * g.ldx];
+                                xv[e] = g.xin[xo + (int64_t)(e + 8 * c4) * g.ldx];
+                            }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int reg = 4 * c4 + e;
+                                const float pr = acc[nt][reg] + bj + g.diag * xv[e];
+                                acc[nt][reg] = 0.f;
+                                if (g.prod_out != nullptr) g.prod_out[xo + (int64_t)(e + 8 * c4) * g.ldx] = pr;
+                                crow[(int64_t)(e + 8 * c4) * g.ldc] = fmaf(x0v[e], pr, xv[e]);
+                            }
+                        }
+                    } else if constexpr (EPI == 1) {
+#pragma unroll
+                        for (int c4 = 0; c4 < 4; ++c4) {
+                            float mk[4], old[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                mk[e] = g.mask != nullptr ? g.mask[(r0 + e + 8 * c4) * g.ld_mask + col] : 1.f;
+                                old[e] = g.accumulate ? crow[(int64_t)(e + 8 * c4) * g.ldc] : 0.f;
+                            }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int reg = 4 * c4 + e;
+                                float v = acc[nt][reg] + bj;
+                                acc[nt][reg] = 0.f;
+                                v = relu ? fmaxf(v, 0.f) : v;
+                                v = mk[e] > 0.f ? v : 0.f;
+                                crow[(int64_t)(e + 8 * c4) * g.ldc] = old[e] + v;
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            float v = acc[nt][reg] + bj;
+                            acc[nt][reg] = 0.f;
+                            crow[(int64_t)((reg & 3) + 8 * (reg >> 2)) * g.ldc] = relu ? fmaxf(v, 0.f) : v;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int64_t row = r0 + (reg & 3) + 8 * (reg >> 2);
+                        float v = acc[nt][reg] + bj;
+                        acc[nt][reg] = 0.f;
+                        if (!cv || row >= g.M) continue;
+                        float* dst = g.C + row * g.ldc + col;
+                        if constexpr (cross) {
+                            const float xv = g.xin[row * g.ldx + col];
+                            const float pr = v + g.diag * xv;
+                            if (g.prod_out != nullptr) g.prod_out[row * g.ldx + col] = pr;
+                            *dst = fmaf(g.x0[row * g.ldx + col], pr, xv);
+                            continue;
+                        }
+                        v = relu ? fmaxf(v, 0.f) : v;
+                        if constexpr (EPI == 1) {
+                            if (g.mask != nullptr && !(g.mask[row * g.ld_mask + col] > 0.f)) v = 0.f;
+                            *dst = g.accumulate ? *dst + v : v;
+                        } else {
+                            *dst = v;
+                        }
+                    }
+                }
+            }
+            // Stores and loads share vmcnt on gfx9 and hipcc treats a mix of the two as unordered: left pending into the next
+            // k-tile, the stores turn its wait for the A registers into vmcnt(0) on EVERY k-tile.  Draining here costs the
+            // pipeline one refill per output tile instead.
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
+        tile += gridDim.x;
+    }
+}
+
+// =====================================================================================================================
 // TN split-K:  partial[s][f][n] = sum_{r in slice s} X[r][f] Y[r][n]
 // =====================================================================================================================
 struct TnArgs {
@@ -753,6 +1097,17 @@ __global__ __launch_bounds__(256) void bf3_join_kernel(const __bf16* __restrict_
     }
 }
 
+int rs_launch(const RsArgs& g, hipStream_t stream) {
+    const int64_t tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
+    if (tiles > 0x7fffffff) return DR_EINVAL;
+    const int grid = (int)(tiles < 256 ? tiles : 256);                  // persistent: one block per CU
+    if (g.x0 != nullptr) hipLaunchKernelGGL((bf3_gemm_rs_kernel<2>), dim3(grid), dim3(512), 0, stream, g);
+    else if (g.mask != nullptr || g.accumulate) hipLaunchKernelGGL((bf3_gemm_rs_kernel<1>), dim3(grid), dim3(512), 0, stream, g);
+    else hipLaunchKernelGGL((bf3_gemm_rs_kernel<0>), dim3(grid), dim3(512), 0, stream, g);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
 bool planes_ok(const void* p, int64_t ps, int64_t ld) {
     return p != nullptr && (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ld > 0 && (ld & 7) == 0 && (ps & 7) == 0;
 }
@@ -855,4 +1210,34 @@ extern "C" int dr_bf3_gemm_tn(const void* x_planes, int64_t x_plane_stride, int6
                        g.split, (int64_t)F, N, scale, dst, ld_dst, y_colsum, dstb);
     DR_CHECK_LAUNCH();
     return DR_OK;
+}
+
+// C[m][n] (+)= act(sum_k A[m][k] B[n][k] + bias[n]) (zeroed where mask[m][n] <= 0).  A: fp32 [M, K] row-major (ld multiple of 4,
+// 16-byte aligned base); B: planes [3][N][b_ld], b_ld >= roundup(K, 32), columns [K, roundup(K, 32)) zero.
+extern "C" int dr_bf3_linear_nt(const float* A, int64_t lda, const void* b_planes, int64_t b_plane_stride, int64_t b_ld, int64_t M,
+                                int32_t N, int32_t K, const float* bias, int32_t act, const float* mask, int64_t ld_mask,
+                                int32_t accumulate, float* C, int64_t ldc, dr_stream_t stream) {
+    if (M < 0 || N <= 0 || K <= 0 || act < 0 || act > 1) return DR_EINVAL;
+    if (M == 0) return DR_OK;
+    if (!A || !C || !planes_ok(b_planes, b_plane_stride, b_ld)) return DR_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(A) & 15) != 0 || (lda & 3) != 0 || lda < K) return DR_EINVAL;
+    if (b_ld < (K + BK - 1) / BK * BK || ldc < N || (mask != nullptr && ld_mask < N)) return DR_EINVAL;
+    RsArgs g{A, lda, static_cast<const __bf16*>(b_planes), b_plane_stride, b_ld, M, N, K, C, ldc, bias, act, mask, ld_mask, accumulate,
+             nullptr, nullptr, 0, 0.f, nullptr};
+    return rs_launch(g, dr_s(stream));
+}
+
+// DCN cross layer forward on pre-split weights (same math as dr_cross_fwd, keras/models/ranking/dcn.py:81-88):
+//   prod = x @ W + b + diag_scale * x ;  out = x0 * prod + x ;  prod_out (may be NULL) saves prod for the backward.
+// wt_planes: W^T as planes [3][Dm][ld_planes] (dr_bf3_split(..., transpose = 1)).  x0, x, out, prod_out share `ld`.
+extern "C" int dr_bf3_cross_fwd(const float* x0, const float* x, int64_t ld, const void* wt_planes, int64_t plane_stride,
+                                int64_t ld_planes, const float* b, float diag_scale, int64_t M, int32_t Dm, float* out,
+                                float* prod_out, dr_stream_t stream) {
+    if (M < 0 || Dm <= 0 || diag_scale < 0.f) return DR_EINVAL;
+    if (M == 0) return DR_OK;
+    if (!x0 || !x || !out || !planes_ok(wt_planes, plane_stride, ld_planes)) return DR_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) != 0 || (ld & 3) != 0 || ld < Dm || ld_planes < (Dm + BK - 1) / BK * BK) return DR_EINVAL;
+    RsArgs g{x, ld, static_cast<const __bf16*>(wt_planes), plane_stride, ld_planes, M, Dm, Dm, out, ld, b, 0, nullptr, 0, 0,
+             x0, x, ld, diag_scale, prod_out};
+    return rs_launch(g, dr_s(stream));
 }

@@ -53,6 +53,13 @@ class DCNEngine:
             self.bs.append(torch.zeros(u, **f32))
             d = u
         self.acts = [1] * len(dnn_units) + [0]
+        # forward / dgrad GEMMs on pre-split weights (see DeepFMEngine); DR_PLANES=0: the in-kernel-split GEMMs
+        import os as _os
+        on = _os.environ.get("DR_PLANES", "1") == "1"
+        self.cross_planes = [ops.WeightPlanes(W) if on and ops.planes_worthwhile(B, self.in_dim, self.in_dim) else None
+                             for W in self.cross_W]
+        self.wplanes = [ops.WeightPlanes(W) if on and u > 1 and ops.planes_worthwhile(B, W.shape[0], W.shape[1]) else None
+                        for W, u in zip(self.Ws, units)]
         self.row_base = torch.arange(F, device=device, dtype=torch.int64) * V
         self.col_buckets = torch.full((F,), V, dtype=torch.int64, device=device)
         self.ids = torch.empty((B, F), dtype=torch.int64, device=device)
@@ -115,14 +122,22 @@ class DCNEngine:
         xs, prods = [x0], []
         fl_c = 2.0 * B * n_in * n_in
         for l, (W, b) in enumerate(zip(self.cross_W, self.cross_b)):
-            out, prod = self._k("cross_fwd_L%d" % l, "mfma", fl_c,
-                                lambda x=xs[-1], W=W, b=b: ops.cross_fwd(x0, x, W, b, self.diag, want_prod=True))
+            if self.cross_planes[l] is not None:
+                out, prod = self._k("cross_fwd_L%d" % l, "mfma", fl_c,
+                                    lambda x=xs[-1], b=b, l=l: ops.bf3_cross_fwd(x0, x, self.cross_planes[l].wt, b, self.diag, want_prod=True))
+            else:
+                out, prod = self._k("cross_fwd_L%d" % l, "mfma", fl_c,
+                                    lambda x=xs[-1], W=W, b=b: ops.cross_fwd(x0, x, W, b, self.diag, want_prod=True))
             xs.append(out)
             prods.append(prod)
         x = xs[-1]
         for i, (W, b) in enumerate(zip(self.Ws, self.bs)):
-            self._k("linear_fwd_L%d" % i, "mfma", 2.0 * B * W.shape[0] * W.shape[1],
-                    lambda x=x, W=W, b=b, i=i: ops.linear_fwd(x, W, b, self.acts[i], out=self.hs[i]))
+            if self.wplanes[i] is not None:
+                self._k("linear_fwd_L%d" % i, "mfma", 2.0 * B * W.shape[0] * W.shape[1],
+                        lambda x=x, b=b, i=i: ops.bf3_linear_nt(x, self.wplanes[i].wt, bias=b, act=self.acts[i], out=self.hs[i]))
+            else:
+                self._k("linear_fwd_L%d" % i, "mfma", 2.0 * B * W.shape[0] * W.shape[1],
+                        lambda x=x, W=W, b=b, i=i: ops.linear_fwd(x, W, b, self.acts[i], out=self.hs[i]))
             x = self.hs[i]
         ops.bce_fwd_bwd(self.zero_logit, labels, ops.LOSS_SIGMOID_CE, workspace=self.ws, logits_b=self.hs[-1],
                         out=(self.prob, self.d_logit, self.loss))
@@ -136,9 +151,15 @@ class DCNEngine:
                 dx, rs = self.dhs[i - 1], (self.hs[i - 1] if self.acts[i - 1] else None)
             else:
                 dx, rs = self.d_top[:, :n_in], None
-            self._k("linear_bwd_dx_L%d" % i, "mfma", fl, lambda dy=dy, W=W, rs=rs, dx=dx: ops.linear_bwd_dx(dy, W, relu_src=rs, out=dx))
+            if self.wplanes[i] is not None:
+                self._k("linear_bwd_dx_L%d" % i, "mfma", fl,
+                        lambda dy=dy, rs=rs, dx=dx, i=i: ops.bf3_linear_nt(dy, self.wplanes[i].w, mask=rs, out=dx))
+            else:
+                self._k("linear_bwd_dx_L%d" % i, "mfma", fl, lambda dy=dy, W=W, rs=rs, dx=dx: ops.linear_bwd_dx(dy, W, relu_src=rs, out=dx))
             self._k("linear_bwd_dw_L%d" % i, "mfma", fl,
                     lambda xin=xin, dy=dy, W=W, i=i: ops.linear_bwd_dw(xin, dy, -lr, W, self.bs[i], workspace=self.dw_ws[i]))
+            if self.wplanes[i] is not None:
+                self.wplanes[i].refresh()
             dy = dx
         # ---- backward: cross stack.  d_out of layer l -> (d_x0 +=, d_x_l), W_l / b_l updated in place ------------------
         d_out = self.d_top[:, :n_in]
@@ -148,10 +169,16 @@ class DCNEngine:
             d_x = torch.zeros((B, self.ld), dtype=torch.float32, device=d_out.device)[:, :n_in]
             d_prod = self._k("cross_combine_bwd_L%d" % l, "hbm", 6.0 * 4 * B * n_in,
                              lambda l=l, d_out=d_out, d_x=d_x: ops.cross_combine_bwd(x0, prods[l], d_out, self.diag, d_x0, d_x))
-            self._k("cross_bwd_dx_L%d" % l, "mfma", fl_c,
-                    lambda d_prod=d_prod, W=W, d_x=d_x: ops.linear_bwd_dx(d_prod, W, None, accumulate=True, out=d_x))
+            if self.cross_planes[l] is not None:
+                self._k("cross_bwd_dx_L%d" % l, "mfma", fl_c,
+                        lambda d_prod=d_prod, l=l, d_x=d_x: ops.bf3_linear_nt(d_prod, self.cross_planes[l].w, accumulate=True, out=d_x))
+            else:
+                self._k("cross_bwd_dx_L%d" % l, "mfma", fl_c,
+                        lambda d_prod=d_prod, W=W, d_x=d_x: ops.linear_bwd_dx(d_prod, W, None, accumulate=True, out=d_x))
             self._k("cross_bwd_dw_L%d" % l, "mfma", fl_c,
                     lambda l=l, d_prod=d_prod, W=W: ops.linear_bwd_dw(xs[l], d_prod, -lr, W, self.cross_b[l], workspace=self.cross_ws))
+            if self.cross_planes[l] is not None:
+                self.cross_planes[l].refresh()
             d_out = d_x
         d_x0.add_(d_out)                                     # the first layer's x IS x0
         # ---- K4: scatter the embedding part of d_x0 (sorted, plain read-modify-write, fused SGD) ---------------------------

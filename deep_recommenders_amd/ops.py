@@ -788,6 +788,63 @@ def bf3_gemm_nt(a: Planes, b: Planes, bias=None, act=0, mask=None, out=None):
     return out
 
 
+def bf3_linear_nt(a, b: Planes, bias=None, act=0, mask=None, accumulate=False, out=None):
+    """out[m, n] (+)= act(sum_k a[m, k] B[n, k] + bias[n]) (zeroed where mask <= 0): fp32 activations x pre-split weights.
+    b holds the weights as planes with rows = output features and cols = the reduction (W^T for the forward, W for the dgrad)."""
+    a = _rowmajor_ld4(a)
+    M, K = a.shape
+    if a.stride(0) % 4 or a.data_ptr() % 16:          # the kernel reads 16-byte vectors: rows must start 16-byte aligned
+        buf = torch.zeros((M, _pad4(K)), dtype=torch.float32, device=a.device)
+        buf[:, :K].copy_(a)
+        a = buf[:, :K]
+    N = b.rows
+    assert b.cols == K, "weights' planes must have the reduction length as columns"
+    if out is None:
+        assert not accumulate
+        out = torch.empty((M, _pad4(N)), dtype=torch.float32, device=a.device)[:, :N]
+    assert out.shape == (M, N) and out.stride(1) == 1
+    check(lib().dr_bf3_linear_nt(ptr(a), a.stride(0), ptr(b.buf), b.plane_stride, b.ld, M, N, K, ptr(bias), int(act), ptr(mask),
+                                 mask.stride(0) if mask is not None else 0, int(bool(accumulate)), ptr(out), out.stride(0),
+                                 stream_ptr()), "dr_bf3_linear_nt")
+    return out
+
+
+def bf3_cross_fwd(x0, x, wt: Planes, b=None, diag_scale=0.0, want_prod=False, prod=None):
+    """DCN cross layer on pre-split weights (wt = W^T planes): out = x0 * (x @ W + b + diag * x) + x; (out, prod) as cross_fwd."""
+    M, Dm = x.shape
+    assert x0.shape == x.shape and x0.stride(0) == x.stride(0) and wt.rows == Dm and wt.cols == Dm
+    ld = x.stride(0)
+    out = torch.empty((M, ld), dtype=torch.float32, device=x.device)[:, :Dm]
+    if want_prod and prod is None:
+        prod = torch.empty((M, ld), dtype=torch.float32, device=x.device)[:, :Dm]
+    if prod is not None:
+        assert prod.stride(0) == ld
+    check(lib().dr_bf3_cross_fwd(ptr(x0), ptr(x), ld, ptr(wt.buf), wt.plane_stride, wt.ld, ptr(b), float(diag_scale), M, Dm, ptr(out),
+                                 ptr(prod), stream_ptr()), "dr_bf3_cross_fwd")
+    return out, prod
+
+
+class WeightPlanes:
+    """Both pre-split forms of a Dense kernel W [K, N]: `wt` = W^T planes (rows N: the forward's B operand) and `w` = W planes
+    (rows K: the dgrad's B operand).  refresh() after every update of W (two dr_bf3_split launches)."""
+
+    def __init__(self, W):
+        K, N = W.shape
+        self.W = W
+        self.wt = Planes(N, K, W.device)
+        self.w = Planes(K, N, W.device)
+        self.refresh()
+
+    def refresh(self):
+        bf3_split(self.W, self.wt, transpose=True)
+        bf3_split(self.W, self.w)
+
+
+def planes_worthwhile(M, K, N):
+    """Shapes the register-split GEMM (256 x 256 tiles) is built for; smaller layers stay on dr_linear_*."""
+    return get_gemm_mode() == "bf16x3" and M >= 2048 and N >= 128 and K >= 64
+
+
 def bf3_gemm_tn_workspace(R, F, N, device):
     return torch.empty(max(64, lib().dr_bf3_gemm_tn_workspace_bytes(int(R), int(F), int(N)) // 4), dtype=torch.float32,
                        device=device)

@@ -481,6 +481,20 @@ int dr_bf3_join(const void* planes, int64_t plane_stride, int64_t ld_planes, int
 int dr_bf3_gemm_nt(const void* a_planes, int64_t a_plane_stride, int64_t a_ld, const void* b_planes,
                    int64_t b_plane_stride, int64_t b_ld, int64_t M, int32_t N, int32_t K, const float* bias,
                    int32_t act, const float* mask, int64_t ld_mask, float* C, int64_t ldc, dr_stream_t stream);
+/* dr_bf3_linear_nt: the same product with the ACTIVATION operand left in fp32 -- C[m, n] (+)= act(sum_k A[m, k] B[n, k] + bias[n])
+ * (zeroed where mask[m, n] <= 0), A fp32 [M, K] row-major (lda % 4 == 0, 16-byte aligned), B planes [3][N][b_ld] with
+ * b_ld >= roundup(K, 32) and columns [K, roundup(K, 32)) zero.  Each wave loads its 32 rows of A from HBM straight into
+ * registers and splits them there; only B (the weights: W^T planes for the forward, W planes for the dgrad) is staged through
+ * the LDS.  This is the form the engines use: activations and their producers are untouched, the weights' planes are refreshed
+ * by dr_bf3_split after each update. */
+int dr_bf3_linear_nt(const float* A, int64_t lda, const void* b_planes, int64_t b_plane_stride, int64_t b_ld, int64_t M,
+                     int32_t N, int32_t K, const float* bias, int32_t act, const float* mask, int64_t ld_mask,
+                     int32_t accumulate, float* C, int64_t ldc, dr_stream_t stream);
+/* DCN cross layer forward (dr_cross_fwd's math, keras/models/ranking/dcn.py:81-88) on pre-split weights: wt_planes = W^T as
+ * planes [3][Dm][ld_planes] (dr_bf3_split with transpose = 1).  x0, x, out, prod_out share leading dimension ld. */
+int dr_bf3_cross_fwd(const float* x0, const float* x, int64_t ld, const void* wt_planes, int64_t plane_stride,
+                     int64_t ld_planes, const float* b, float diag_scale, int64_t M, int32_t Dm, float* out,
+                     float* prod_out, dr_stream_t stream);
 int64_t dr_bf3_gemm_tn_workspace_bytes(int64_t R, int32_t F, int32_t N);
 int dr_bf3_gemm_tn(const void* x_planes, int64_t x_plane_stride, int64_t x_ld, const void* y_planes,
                    int64_t y_plane_stride, int64_t y_ld, int64_t R, int32_t F, int32_t N, float scale, float* dst,

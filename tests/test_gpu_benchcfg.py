@@ -231,7 +231,8 @@ def _run_deepfm(V, optimizer, kind, lr, steps=2):
                     # tolerance above) moves the step by up to ~1 %: mean bound 1 % of a step, 10 % of the elements beyond 2 %
                     _assert_close_adam(nm, got.cpu().numpy()[sel], want.numpy()[sel], lr, 0.10, mean_tol=1e-2)
                 err = np.abs(got.cpu().numpy().astype(np.float64) - want.numpy().astype(np.float64))
-                assert float(err.max()) <= 1.0 * lr, "%s: worst difference %.3e exceeds one Adam step" % (nm, float(err.max()))
+                # an element whose gradient is ~0 can take +lr on one side and -lr on the other, on each of the two steps
+                assert float(err.max()) <= 2.05 * 2 * lr, "%s: worst difference %.3e exceeds what two Adam steps can differ by" % (nm, float(err.max()))
         # and the update must not be vacuous: most touched rows moved by about one Adam step
         moved = np.abs(got_t - orc.table0.numpy()).max(axis=1)
         assert np.median(moved) > 0.2 * lr

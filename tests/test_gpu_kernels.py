@@ -734,3 +734,95 @@ def test_gemm_mode_api(ops):
     with pytest.raises(ValueError):
         ops.set_gemm_mode(7)
     assert ops.get_gemm_mode() == prev
+
+
+# ---- K7p: GEMMs on pre-split ("planes") operands ------------------------------------------------------------------------------
+def _rel(got, ref):
+    ref = ref.double()
+    return ((got.double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+def test_bf3_split_join_exact_and_zero_padded():
+    """x -> three bf16 planes -> x is the identity bit for bit (also transposed, at an offset), and the padding stays zero."""
+    from deep_recommenders_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn((77, 53), device="cuda", generator=g) * torch.exp(torch.randn((77, 1), device="cuda", generator=g) * 6)
+    x[3, 5], x[10, 0] = 0.0, 1e-39                                   # zero and a denormal
+    p = ops.bf3_split(x, ops.Planes(77, 53, "cuda"))
+    assert torch.equal(ops.bf3_join(p), x)
+    assert p.buf[:, 77:, :].abs().max() == 0 and p.buf[:, :, 53:].abs().max() == 0
+    pt = ops.bf3_split(x, ops.Planes(53, 77, "cuda"), transpose=True)
+    assert torch.equal(ops.bf3_join(pt), x.t().contiguous())
+
+
+@pytest.mark.parametrize("M,K,N", [(200, 83, 40), (1000, 300, 257), (4096, 128, 520), (300, 64, 600), (2085, 1677, 256), (513, 32, 1677)])
+def test_bf3_linear_nt_matches_fp64(M, K, N):
+    """dr_bf3_linear_nt (fp32 activations split in registers x pre-split weights): forward with bias + ReLU, dgrad with a ReLU'
+    mask, accumulate -- against float64, no worse than the in-kernel-split GEMM (both are six exact bf16 products per fp32 product).
+    Shapes: edge tiles in both dimensions, a reduction tail (K % 32 != 0, K % 4 != 0), K < one k-tile, the bench's first layer."""
+    from deep_recommenders_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    x = torch.randn((M, K), device="cuda", generator=g)
+    W = torch.randn((K, N), device="cuda", generator=g) * 0.1
+    b = torch.randn((N,), device="cuda", generator=g)
+    wp = ops.WeightPlanes(W)
+    y = ops.bf3_linear_nt(x, wp.wt, bias=b, act=1)
+    ref = torch.relu(x.double() @ W.double() + b.double())
+    e_new, e_old = _rel(y, ref), _rel(ops.linear_fwd(x, W, b, 1), ref)
+    assert e_new <= 3e-6 and e_new <= 1.5 * e_old + 2e-7, (e_new, e_old)
+    # dgrad with the ReLU' mask of the layer below, then accumulated on top of an existing buffer
+    dy = torch.randn((M, N), device="cuda", generator=g) * 1e-2
+    below = torch.randn((M, K), device="cuda", generator=g)
+    dx = ops.bf3_linear_nt(dy, wp.w, mask=below)
+    ref = (dy.double() @ W.double().t()) * (below > 0)
+    assert _rel(dx, ref) <= 3e-6
+    base = torch.randn((M, K), device="cuda", generator=g) * 1e-2
+    acc = base.clone()
+    ops.bf3_linear_nt(dy, wp.w, accumulate=True, out=acc)
+    assert _rel(acc, base.double() + dy.double() @ W.double().t()) <= 3e-6
+    # NaN-poisoned padding of the ACTIVATION must not leak in (the kernel reads whole 16-byte vectors past K)
+    xp = torch.full((M, (K + 3) // 4 * 4 + 4), float("nan"), device="cuda")
+    xp[:, :K] = x
+    assert torch.equal(ops.bf3_linear_nt(xp[:, :K], wp.wt, bias=b, act=1), y)
+
+
+def test_bf3_cross_fwd_matches_cross_fwd_and_fp64():
+    """DCN cross layer on pre-split weights == dr_cross_fwd's math (dcn.py:81-88), incl. the reference's known answer."""
+    from deep_recommenders_amd import ops
+    x0 = torch.tensor([[0.1, 0.2, 0.3]], device="cuda").repeat(5, 1)
+    x = torch.tensor([[0.4, 0.5, 0.6]], device="cuda").repeat(5, 1)
+    W = torch.ones((3, 3), device="cuda")
+    x0p, xp = torch.zeros((5, 4), device="cuda"), torch.zeros((5, 4), device="cuda")
+    x0p[:, :3], xp[:, :3] = x0, x
+    out, _ = ops.bf3_cross_fwd(x0p[:, :3], xp[:, :3], ops.WeightPlanes(W).wt, torch.zeros(3, device="cuda"))
+    np.testing.assert_allclose(out.cpu().numpy(), np.tile([[0.55, 0.8, 1.05]], (5, 1)), rtol=1e-6)     # tests/keras/test_dcn.py:16-23
+    g = torch.Generator(device="cuda").manual_seed(4)
+    M, Dm = 1500, 333
+    buf0 = torch.randn((M, 336), device="cuda", generator=g)
+    buf1 = torch.randn((M, 336), device="cuda", generator=g)
+    x0, x = buf0[:, :Dm], buf1[:, :Dm]
+    W = torch.randn((Dm, Dm), device="cuda", generator=g) * 0.05
+    b = torch.randn((Dm,), device="cuda", generator=g)
+    out, prod = ops.bf3_cross_fwd(x0, x, ops.WeightPlanes(W).wt, b, 0.3, want_prod=True)
+    pr = x.double() @ W.double() + b.double() + 0.3 * x.double()
+    assert _rel(prod, pr) <= 3e-6 and _rel(out, x0.double() * pr + x.double()) <= 3e-6
+    o2, p2 = ops.cross_fwd(x0, x, W, b, 0.3, want_prod=True)
+    assert _rel(out, o2) <= 2e-6 and _rel(prod, p2) <= 2e-6
+
+
+@pytest.mark.parametrize("M,K,N", [(200, 83, 40), (1000, 300, 257), (4096, 128, 520)])
+def test_bf3_planes_gemms_match_fp64(M, K, N):
+    """dr_bf3_gemm_nt / _tn (both operands pre-split, LDS-DMA staging; NaN-poisoned split-K workspace)."""
+    from deep_recommenders_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(K)
+    x = torch.randn((M, K), device="cuda", generator=g)
+    W = torch.randn((K, N), device="cuda", generator=g) * 0.1
+    dy = torch.randn((M, N), device="cuda", generator=g) * 1e-2
+    xp, dyp = ops.bf3_split(x, ops.Planes(M, K, "cuda")), ops.bf3_split(dy, ops.Planes(M, N, "cuda"))
+    wp = ops.WeightPlanes(W)
+    assert _rel(ops.bf3_gemm_nt(xp, wp.wt), x.double() @ W.double()) <= 3e-6
+    assert _rel(ops.bf3_gemm_nt(dyp, wp.w), dy.double() @ W.double().t()) <= 3e-6
+    dW = torch.zeros((K, N), device="cuda")
+    ws = ops.bf3_gemm_tn_workspace(M, K, N, "cuda").fill_(float("nan"))
+    ops.bf3_gemm_tn(xp, dyp, 1.0, dW, workspace=ws)
+    assert _rel(dW, x.double().t() @ dy.double()) <= 5e-6

@@ -28,6 +28,20 @@ static float run_pipe(const NtArgs& g, int grid, int reps) {
 }
 
 template <int DBG>
+static float run_rs(const RsArgs& g, int grid, int reps) {
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((bf3_gemm_rs_kernel<0, DBG>), dim3(grid), dim3(512), 0, 0, g);
+    (void)hipEventRecord(a, 0);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((bf3_gemm_rs_kernel<0, DBG>), dim3(grid), dim3(512), 0, 0, g);
+    (void)hipEventRecord(b, 0);
+    (void)hipEventSynchronize(b);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, a, b);
+    return ms / reps * 1e3f;
+}
+
+template <int DBG>
 static float run(const NtArgs& g, int grid, int reps) {
     hipEvent_t a, b;
     (void)hipEventCreate(&a); (void)hipEventCreate(&b);
@@ -67,6 +81,20 @@ int main(int argc, char** argv) {
         t = run_pipe<16, 2>(g, pgrid, 10); printf("N=%4d PIPE16 no MFMA        %8.1f us %6.1f TF/s\n", N, t, fl / t / 1e6);
         t = run_pipe<16, 4>(g, pgrid, 10); printf("N=%4d PIPE16 DMA cache hits %8.1f us %6.1f TF/s\n", N, t, fl / t / 1e6);
         t = run_pipe<16, 6>(g, pgrid, 10); printf("N=%4d PIPE16 hits, no MFMA  %8.1f us %6.1f TF/s\n", N, t, fl / t / 1e6);
+        {   // register-split kernel: fp32 A [M, 1680] (K = 1677), B planes as above
+            float* Af; (void)hipMalloc(&Af, M * 1680 * 4);
+            hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, (uint16_t*)Af, M * 1680 * 2, 3u);
+            RsArgs r{Af, 1680, B, (int64_t)N * K, K, M, N, 1677, C, N, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, 0.f, nullptr};
+            const int64_t rt = ((M + 255) / 256) * ((N + 255) / 256);
+            const int rg = rt < 256 ? (int)rt : 256;
+            t = run_rs<0>(r, rg, 10); printf("N=%4d RS base             %8.1f us %6.1f TF/s\n", N, t, fl / t / 1e6);
+            t = run_rs<1>(r, rg, 10); printf("N=%4d RS no B DMA         %8.1f us %6.1f TF/s\n", N, t, fl / t / 1e6);
+            t = run_rs<2>(r, rg, 10); printf("N=%4d RS no MFMA          %8.1f us %6.1f TF/s\n", N, t, fl / t / 1e6);
+            t = run_rs<8>(r, rg, 10); printf("N=%4d RS A not advancing  %8.1f us %6.1f TF/s\n", N, t, fl / t / 1e6);
+            t = run_rs<9>(r, rg, 10); printf("N=%4d RS A fixed, no DMA  %8.1f us %6.1f TF/s\n", N, t, fl / t / 1e6);
+            t = run_rs<4>(r, rg, 10); printf("N=%4d RS B cache hits     %8.1f us %6.1f TF/s\n", N, t, fl / t / 1e6);
+            (void)hipFree(Af);
+        }
         (void)hipFree(A); (void)hipFree(B); (void)hipFree(C);
     }
     return 0;

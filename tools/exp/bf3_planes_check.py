@@ -40,12 +40,14 @@ def run(M, K, N, time=True):
     ref = torch.relu(x.double() @ W.double() + b.double())
     y_old = ops.linear_fwd(x, W, b, 1)
     print("M=%d K=%d N=%d" % (M, K, N))
-    print("  fwd   err planes %.3e  in-kernel %.3e" % (relerr(y, ref), relerr(y_old, ref)))
+    y_rs = ops.bf3_linear_nt(x, wtp, bias=b, act=1)
+    print("  fwd   err planes %.3e  in-kernel %.3e  reg-split %.3e" % (relerr(y, ref), relerr(y_old, ref), relerr(y_rs, ref)))
     # dgrad
     dx = ops.bf3_gemm_nt(dyp, wp)
     ref = dy.double() @ W.double().t()
     dx_old = ops.linear_bwd_dx(dy, W)
-    print("  dgrad err planes %.3e  in-kernel %.3e" % (relerr(dx, ref), relerr(dx_old, ref)))
+    dx_rs = ops.bf3_linear_nt(dy, wp)
+    print("  dgrad err planes %.3e  in-kernel %.3e  reg-split %.3e" % (relerr(dx, ref), relerr(dx_old, ref), relerr(dx_rs, ref)))
     # wgrad
     dW = torch.zeros((K, N), device="cuda")
     ws = ops.bf3_gemm_tn_workspace(M, K, N, "cuda")
@@ -60,6 +62,8 @@ def run(M, K, N, time=True):
         fl = 2.0 * M * K * N
         for name, fn in [("fwd planes", lambda: ops.bf3_gemm_nt(xp, wtp, bias=b, act=1, out=y)),
                          ("fwd in-kernel", lambda: ops.linear_fwd(x, W, b, 1, out=y_old)),
+                         ("fwd reg-split", lambda: ops.bf3_linear_nt(x, wtp, bias=b, act=1, out=y_rs)),
+                         ("dgrad reg-split", lambda: ops.bf3_linear_nt(dy, wp, out=dx_rs)),
                          ("dgrad planes", lambda: ops.bf3_gemm_nt(dyp, wp, out=dx)),
                          ("dgrad in-kernel", lambda: ops.linear_bwd_dx(dy, W, out=dx_old)),
                          ("wgrad planes", lambda: ops.bf3_gemm_tn(xp, dyp, 1e-9, dW, workspace=ws)),
@@ -75,5 +79,7 @@ if __name__ == "__main__":
     run(200, 83, 40, time=False)
     run(1000, 300, 257, time=False)
     run(4096, 128, 520, time=False)
+    run(300, 64, 600, time=False)
     run(65536, 1677, 256)
     run(65536, 1677, 1024)
+    run(65536, 1677, 1677)
