@@ -829,6 +829,214 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_rs_kernel(RsArgs g) {
 }
 
 // =====================================================================================================================
+// TN, "register split" wgrad:  dst[f][n] += scale * sum_r X[r][f] Y[r][n],  dstb[n] += scale * sum_r Y[r][n]
+// Both operands are fp32 ACTIVATIONS, reduction-major (x [R, F] and dy [R, N] as their producers write them); nothing is
+// pre-split.  A block owns a 256 (f) x 256 (n) tile of one reduction slice; each of its 8 waves owns 32 f x all 256 n.
+//   A (x):  every lane loads the 16 reduction elements of ITS column f for a k-tile with 16 dword loads (the 32 lanes of a half
+//           wave cover 128 contiguous bytes of one row) and splits them in registers -- the transposition MFMA's A operand
+//           needs ("8 consecutive k per lane") is free because the lane index runs along f.
+//   B (dy): the same loads with the lane index along n give every lane 8 consecutive r of its column, i.e. exactly one
+//           16-byte fragment chunk per plane: wave w splits the 32 columns 32 w .. 32 w + 31 of the tile once and writes the
+//           three planes as ds_write_b128 into the [n][32 r] image the fragment reads of the NT kernels use; the 8 waves'
+//           pieces make the tile that all of them read.  Two LDS stages: step g's MFMAs read stage g while stage g + 1 is
+//           written from registers loaded during step g - 1.
+// The in-kernel-split wgrad of dense.hip re-stages BOTH operands through the LDS per 128 x 128 tile; here x never touches
+// it and each dy element is split once per 256 rows of x.
+// Partials go to a padded workspace [split][tiles_f * 256][tiles_n * 256] (+ [split][tiles_n * 256] column sums): every store of
+// the epilogue is unconditional; a fixed-order reduce applies them (deterministic).
+// =====================================================================================================================
+struct TnRsArgs {
+    const float* X; int64_t ldx;
+    const float* Y; int64_t ldy;
+    int64_t R; int32_t F; int32_t N;
+    int64_t per; int32_t split;                  // reduction rows per slice (multiple of 32), number of slices
+    float* partial; float* colsum;               // [split][Fp][Np], [split][Np] (colsum may be null)
+};
+
+__device__ __forceinline__ void rs_split8v(const float (&v)[8], bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+    rs_split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), p0, p1, p2);
+}
+
+__global__ __launch_bounds__(512, 2) void bf3_gemm_tn_rs_kernel(TnRsArgs g) {
+    constexpr int NW = 8, BMF = 32 * NW, BN = 256, NT = BN / 32;
+    constexpr int B_PLANE = BN * 64;                                    // bytes: 256 n-rows x 64 bytes (32 r)
+    constexpr int STAGE = 3 * B_PLANE;                                  // 48 KB
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int tiles_n = (g.N + BN - 1) / BN, tiles_f = (g.F + BMF - 1) / BMF;
+    const int per_slice = tiles_f * tiles_n;
+    const int Fp = tiles_f * BMF, Np = tiles_n * BN;
+    const int lid = xcd_remap(blockIdx.x, per_slice * g.split);         // consecutive logical ids share a reduction slice
+    const int slice = lid / per_slice, t = lid % per_slice;
+    const int f0 = (t / tiles_n) * BMF, n0 = (t % tiles_n) * BN;
+    const int64_t r_begin = (int64_t)slice * g.per;
+    int64_t r_end = r_begin + g.per;
+    if (r_end > g.R) r_end = g.R;
+    const int nk = (int)((r_end - r_begin + BK - 1) / BK);              // >= 1 by construction of split
+    const bool want_cs = g.colsum != nullptr && f0 == 0;
+
+    // this lane's columns (clamped: columns past the edge only feed outputs nobody reads)
+    const int fcol = min(f0 + wave * 32 + l31, g.F - 1);
+    const int ncol = min(n0 + wave * 32 + l31, g.N - 1);
+    // fragment read addresses as in bf3_gemm_rs_kernel: B row = 32 nt + l31, chunk (2 hi + s) ^ ((row >> 2) & 3)
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+    const int sw = (l31 >> 2) & 3;
+    unsigned b_addr[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) b_addr[s] = lds0 + l31 * 64 + (((2 * hi + s) ^ sw) << 4);
+    // where this lane writes its own column's chunks: row 32 wave + l31 of the image, same swizzle
+    unsigned char* const wrow = smem + (wave * 32 + l31) * 64;
+
+    // raw operand values of one k-tile: element e = 8 s + j  <->  reduction row r0 + 16 hi + 8 s + j   (the k permutation of
+    // the RS kernels: lane half hi holds k = 16 hi .. 16 hi + 15, k-step s uses 16 hi + 8 s .. + 7 = chunk 2 hi + s)
+    float xa[16], yb[16];
+    // per-lane byte offset inside a k-tile's rows (32-bit) + a wave-uniform row pointer per load: one address register, the
+    // row stepping stays on the scalar unit
+    const unsigned xoff = (unsigned)((16 * hi * g.ldx + fcol) * 4), yoff = (unsigned)((16 * hi * g.ldy + ncol) * 4);
+    auto load_raw = [&](float (&dst)[16], const float* base, int64_t ld, unsigned voff, int64_t r0) {
+        if (r0 + BK <= r_end) {                                         // (wave-uniform) a full k-tile: no checks
+            const char* rowp = reinterpret_cast<const char*>(base + r0 * ld);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dst[e] = *reinterpret_cast<const float*>(rowp + (int64_t)e * ld * 4 + voff);
+        } else {                                                        // the slice's last, partial k-tile (or past its end)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t r = r0 + 16 * hi + e;
+                const bool ok = r < r_end;
+                const float v = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base + (ok ? r : r_end - 1) * ld) +
+                                                                (voff - (unsigned)(16 * hi * ld * 4)));
+                dst[e] = ok ? v : 0.f;
+            }
+        }
+    };
+    bf16x8 fa[2][3];
+    bf16x8 fb[2][3];
+    float cs = 0.f;
+    auto stage_b = [&](int stage) {                                     // yb -> three planes of this lane's column
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 p0, p1, p2;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[j] = yb[8 * s + j]; cs += v[j]; }
+            rs_split8v(v, p0, p1, p2);
+            unsigned char* w = wrow + stage * STAGE + (((2 * hi + s) ^ sw) << 4);
+            *reinterpret_cast<bf16x8*>(w) = p0;
+            *reinterpret_cast<bf16x8*>(w + B_PLANE) = p1;
+            *reinterpret_cast<bf16x8*>(w + 2 * B_PLANE) = p2;
+        }
+    };
+    auto read_b = [&](int buf, int stage, int q) {
+        const unsigned bb = b_addr[q >> 3] + stage * STAGE;
+        const int nt = q & 7;
+#define RS_READ3(NTI)                                                        \
+        BF3_DS_READ_B128(fb[buf][0], bb, 0 * B_PLANE + NTI * 2048);          \
+        BF3_DS_READ_B128(fb[buf][1], bb, 1 * B_PLANE + NTI * 2048);          \
+        BF3_DS_READ_B128(fb[buf][2], bb, 2 * B_PLANE + NTI * 2048);
+        switch (nt) {
+            case 0: RS_READ3(0) break; case 1: RS_READ3(1) break; case 2: RS_READ3(2) break; case 3: RS_READ3(3) break;
+            case 4: RS_READ3(4) break; case 5: RS_READ3(5) break; case 6: RS_READ3(6) break; default: RS_READ3(7) break;
+        }
+#undef RS_READ3
+    };
+    auto wait_b = [&](int buf) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[buf][0]), "+v"(fb[buf][1]), "+v"(fb[buf][2]));
+    };
+    f32x16 acc[NT];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[tt][k] = 0.f;
+    constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
+
+    // ---- prologue: B(0) into stage 0, A(0) and B(1) into registers -------------------------------------------------------------
+    load_raw(yb, g.Y, g.ldy, yoff, r_begin);
+    stage_b(0);
+    load_raw(xa, g.X, g.ldx, xoff, r_begin);
+    load_raw(yb, g.Y, g.ldy, yoff, r_begin + BK);                       // (all zeros when nk == 1)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    read_b(0, 0, 0);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int stage = kt & 1;
+        // A of this k-tile -> bf16 terms; B of the next k-tile -> the other stage (its readers passed the barrier at the end of
+        // the previous step); the loads of the k-tile after that go into flight
+        {
+            float v[8];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = xa[8 * s + j];
+                rs_split8v(v, fa[s][0], fa[s][1], fa[s][2]);
+            }
+        }
+        if (kt + 1 < nk) stage_b(stage ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_raw(xa, g.X, g.ldx, xoff, r_begin + (int64_t)(kt + 1) * BK);
+        load_raw(yb, g.Y, g.ldy, yoff, r_begin + (int64_t)(kt + 2) * BK);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            wait_b(q & 1);
+            if (q < 15) {
+                read_b((q + 1) & 1, stage, q + 1);
+            } else {
+                // done reading this stage, and this wave's ds_writes of the next one have retired (lgkmcnt(0) above covers
+                // both): publish
+                asm volatile("s_barrier" ::: "memory");
+                if (kt + 1 < nk) read_b(0, stage ^ 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int term = 0; term < 6; ++term)
+                acc[q & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q >> 3][PA[term]], fb[q & 1][PB[term]], acc[q & 7], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // ---- epilogue: partial tile (padded workspace: unconditional stores); C/D layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 hi
+    float* out = g.partial + ((int64_t)slice * Fp + f0 + wave * 32 + 4 * hi) * Np + n0 + l31;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) out[(int64_t)((reg & 3) + 8 * (reg >> 2)) * Np + nt * 32] = acc[nt][reg];
+    if (want_cs) {
+        cs += __shfl_xor(cs, 32, 64);
+        if (hi == 0) g.colsum[(int64_t)slice * Np + n0 + wave * 32 + l31] = cs;
+    }
+}
+
+// dst[f][n] += scale * sum_s partial[s][f][n]  (fixed order);  dstb[n] += scale * sum_s colsum[s][n]
+__global__ __launch_bounds__(256) void bf3_tn_rs_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ colsum,
+                                                               int32_t split, int32_t F, int32_t N, int32_t Fp, int32_t Np,
+                                                               float scale, float* __restrict__ dst, int64_t ld,
+                                                               float* __restrict__ dstb) {
+    const int64_t total = (int64_t)F * N, stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t ps = (int64_t)Fp * Np;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t f = i / N;
+        const int n = (int)(i - f * N);
+        const float* p = partial + f * Np + n;
+        float acc = 0.f;
+        int s = 0;
+        for (; s + 4 <= split; s += 4) {             // four loads in flight, summed in slice order
+            const float v0 = p[s * ps], v1 = p[(s + 1) * ps], v2 = p[(s + 2) * ps], v3 = p[(s + 3) * ps];
+            acc = (((acc + v0) + v1) + v2) + v3;
+        }
+        for (; s < split; ++s) acc += p[s * ps];
+        dst[f * ld + n] = fmaf(scale, acc, dst[f * ld + n]);
+    }
+    if (blockIdx.x == 0 && colsum != nullptr && dstb != nullptr)
+        for (int n = threadIdx.x; n < N; n += blockDim.x) {
+            float acc = 0.f;
+            for (int s = 0; s < split; ++s) acc += colsum[(int64_t)s * Np + n];
+            dstb[n] = fmaf(scale, acc, dstb[n]);
+        }
+}
+
+// =====================================================================================================================
 // TN split-K:  partial[s][f][n] = sum_{r in slice s} X[r][f] Y[r][n]
 // =====================================================================================================================
 struct TnArgs {
@@ -1240,4 +1448,48 @@ extern "C" int dr_bf3_cross_fwd(const float* x0, const float* x, int64_t ld, con
     RsArgs g{x, ld, static_cast<const __bf16*>(wt_planes), plane_stride, ld_planes, M, Dm, Dm, out, ld, b, 0, nullptr, 0, 0,
              x0, x, ld, diag_scale, prod_out};
     return rs_launch(g, dr_s(stream));
+}
+
+namespace {
+void tn_rs_plan(int64_t R, int32_t F, int32_t N, int& split, int64_t& per, int& Fp, int& Np) {
+    const int tf = (F + 255) / 256, tn = (N + 255) / 256;
+    Fp = tf * 256;
+    Np = tn * 256;
+    int64_t sp = 256 / ((int64_t)tf * tn);                              // about one block per CU
+    const int64_t max_split = (R + 16 * BK - 1) / (16 * BK);            // at least 16 k-tiles per slice
+    if (sp > max_split) sp = max_split;
+    if (sp < 1) sp = 1;
+    per = ((R + sp - 1) / sp + BK - 1) / BK * BK;
+    split = (int)((R + per - 1) / per);                                 // every slice non-empty
+}
+}  // namespace
+
+extern "C" int64_t dr_bf3_wgrad_workspace_bytes(int64_t R, int32_t F, int32_t N) {
+    if (R <= 0 || F <= 0 || N <= 0) return 0;
+    int split, Fp, Np;
+    int64_t per;
+    tn_rs_plan(R, F, N, split, per, Fp, Np);
+    return ((int64_t)split * Fp * Np + (int64_t)split * Np) * (int64_t)sizeof(float);
+}
+
+// dstW[f][n] += scale * sum_r x[r][f] dy[r][n];  dstb[n] += scale * sum_r dy[r][n] (dstb may be NULL).  x [R, F], dy [R, N] fp32
+// row-major; the bf16x3 product mode, deterministic (fixed-order reduce over the reduction slices).
+extern "C" int dr_bf3_wgrad(const float* x, int64_t ld_x, const float* dy, int64_t ld_dy, int64_t R, int32_t F, int32_t N,
+                            float scale, float* dstW, int64_t ld_w, float* dstb, void* workspace, int64_t workspace_bytes,
+                            dr_stream_t stream) {
+    if (R <= 0 || F <= 0 || N <= 0) return DR_EINVAL;
+    if (!x || !dy || !dstW || !workspace || ld_x < F || ld_dy < N || ld_w < N) return DR_EINVAL;
+    if (workspace_bytes < dr_bf3_wgrad_workspace_bytes(R, F, N)) return DR_EINVAL;
+    int split, Fp, Np;
+    int64_t per;
+    tn_rs_plan(R, F, N, split, per, Fp, Np);
+    float* partial = static_cast<float*>(workspace);
+    float* colsum = partial + (int64_t)split * Fp * Np;
+    TnRsArgs g{x, ld_x, dy, ld_dy, R, F, N, per, split, partial, dstb != nullptr ? colsum : nullptr};
+    const int grid = (Fp / 256) * (Np / 256) * split;
+    hipLaunchKernelGGL(bf3_gemm_tn_rs_kernel, dim3(grid), dim3(512), 0, dr_s(stream), g);
+    hipLaunchKernelGGL(bf3_tn_rs_reduce_kernel, dim3(dr_grid_for((int64_t)F * N, 256)), dim3(256), 0, dr_s(stream), partial,
+                       dstb != nullptr ? colsum : nullptr, split, F, N, Fp, Np, scale, dstW, ld_w, dstb);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
 }

@@ -72,6 +72,10 @@ class DCNEngine:
         self.ws = torch.empty(1024, **f32)
         self.dw_ws = [ops.linear_bwd_dw_workspace(B, W.shape[0], W.shape[1], device) for W in self.Ws]
         self.cross_ws = ops.linear_bwd_dw_workspace(B, self.in_dim, self.in_dim, device)
+        # wide layers: the register-split wgrad (dr_bf3_wgrad) on the same condition as the planes forward / dgrad
+        self.wg_ws = [ops.bf3_wgrad_workspace(B, W.shape[0], W.shape[1], device) if wp is not None else None
+                      for W, wp in zip(self.Ws, self.wplanes)]
+        self.cross_wg_ws = ops.bf3_wgrad_workspace(B, self.in_dim, self.in_dim, device) if self.cross_planes and self.cross_planes[0] is not None else None
         self.plan = ops.SortPlan(B * F, device)
         self.side = torch.cuda.Stream(device=device)
         self.ev_ids, self.ev_sorted = torch.cuda.Event(), torch.cuda.Event()
@@ -156,8 +160,12 @@ class DCNEngine:
                         lambda dy=dy, rs=rs, dx=dx, i=i: ops.bf3_linear_nt(dy, self.wplanes[i].w, mask=rs, out=dx))
             else:
                 self._k("linear_bwd_dx_L%d" % i, "mfma", fl, lambda dy=dy, W=W, rs=rs, dx=dx: ops.linear_bwd_dx(dy, W, relu_src=rs, out=dx))
-            self._k("linear_bwd_dw_L%d" % i, "mfma", fl,
-                    lambda xin=xin, dy=dy, W=W, i=i: ops.linear_bwd_dw(xin, dy, -lr, W, self.bs[i], workspace=self.dw_ws[i]))
+            if self.wg_ws[i] is not None:
+                self._k("linear_bwd_dw_L%d" % i, "mfma", fl,
+                        lambda xin=xin, dy=dy, W=W, i=i: ops.bf3_wgrad(xin, dy, -lr, W, self.bs[i], workspace=self.wg_ws[i]))
+            else:
+                self._k("linear_bwd_dw_L%d" % i, "mfma", fl,
+                        lambda xin=xin, dy=dy, W=W, i=i: ops.linear_bwd_dw(xin, dy, -lr, W, self.bs[i], workspace=self.dw_ws[i]))
             if self.wplanes[i] is not None:
                 self.wplanes[i].refresh()
             dy = dx
@@ -175,8 +183,12 @@ class DCNEngine:
             else:
                 self._k("cross_bwd_dx_L%d" % l, "mfma", fl_c,
                         lambda d_prod=d_prod, W=W, d_x=d_x: ops.linear_bwd_dx(d_prod, W, None, accumulate=True, out=d_x))
-            self._k("cross_bwd_dw_L%d" % l, "mfma", fl_c,
-                    lambda l=l, d_prod=d_prod, W=W: ops.linear_bwd_dw(xs[l], d_prod, -lr, W, self.cross_b[l], workspace=self.cross_ws))
+            if self.cross_wg_ws is not None:
+                self._k("cross_bwd_dw_L%d" % l, "mfma", fl_c,
+                        lambda l=l, d_prod=d_prod, W=W: ops.bf3_wgrad(xs[l], d_prod, -lr, W, self.cross_b[l], workspace=self.cross_wg_ws))
+            else:
+                self._k("cross_bwd_dw_L%d" % l, "mfma", fl_c,
+                        lambda l=l, d_prod=d_prod, W=W: ops.linear_bwd_dw(xs[l], d_prod, -lr, W, self.cross_b[l], workspace=self.cross_ws))
             if self.cross_planes[l] is not None:
                 self.cross_planes[l].refresh()
             d_out = d_x

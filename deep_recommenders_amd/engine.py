@@ -93,6 +93,9 @@ class DeepFMEngine:
                                                 and ops.planes_worthwhile(B, W.shape[0], W.shape[1])) else None
                         for W, u in zip(self.Ws, units)]
         self.dw_ws = [ops.linear_bwd_dw_workspace(B, W.shape[0], W.shape[1], device) for W in self.Ws]
+        # wide layers: the register-split wgrad (dr_bf3_wgrad) on the same condition as the planes forward / dgrad
+        self.wg_ws = [ops.bf3_wgrad_workspace(B, W.shape[0], W.shape[1], device) if wp is not None else None
+                      for W, wp in zip(self.Ws, self.wplanes)]
         # narrow layers (N <= 32, K in {128,256,512}) below the first: dx + dW + db fused in one pass over the activations
         self.fuse_narrow = _os.environ.get("DR_FUSE_NARROW", "1") == "1"
         # last hidden layer (<= 32 units, relu) + Dense(1) + loss + Dense(1) backward fused into one GEMM epilogue
@@ -191,6 +194,12 @@ class DeepFMEngine:
             out.append({"kernels": [a, b], "joint_us": tot / n * 1e3})
         return out
 
+    def _wgrad(self, i, x, dy, sc, dstW, dstb):
+        if self.wg_ws[i] is not None:
+            ops.bf3_wgrad(x, dy, sc, dstW, dstb, workspace=self.wg_ws[i])
+        else:
+            ops.linear_bwd_dw(x, dy, sc, dstW, dstb, workspace=self.dw_ws[i])
+
     # ------------------------------------------------------------------------------------------
     def forward(self, keys: torch.Tensor, dense: Optional[torch.Tensor], labels: Optional[torch.Tensor],
                 loss_mode: int = ops.LOSS_SIGMOID_CE):
@@ -283,14 +292,14 @@ class DeepFMEngine:
                 with torch.cuda.stream(self.side2):
                     self.side2.wait_event(self.ev_dx)
                     self._k("linear_bwd_dw_L%d" % i, "mfma", fl,
-                            lambda x=x, dy=dy, i=i, dstW=dstW, dstb=dstb: ops.linear_bwd_dw(x, dy, sc, dstW, dstb, workspace=self.dw_ws[i]))
+                            lambda x=x, dy=dy, i=i, dstW=dstW, dstb=dstb: self._wgrad(i, x, dy, sc, dstW, dstb))
                     if self.wplanes[i] is not None and not adam:
                         self.wplanes[i].refresh()                    # the weight just moved: its planes follow (same stream)
                     self.ev_dw.record(self.side2)
                 dy = dx
                 continue
             self._k("linear_bwd_dw_L%d" % i, "mfma", fl,
-                    lambda x=x, dy=dy, i=i, dstW=dstW, dstb=dstb: ops.linear_bwd_dw(x, dy, sc, dstW, dstb, workspace=self.dw_ws[i]))
+                    lambda x=x, dy=dy, i=i, dstW=dstW, dstb=dstb: self._wgrad(i, x, dy, sc, dstW, dstb))
             if self.wplanes[i] is not None and not adam:
                 self.wplanes[i].refresh()
             dy = dx

@@ -824,6 +824,22 @@ def bf3_cross_fwd(x0, x, wt: Planes, b=None, diag_scale=0.0, want_prod=False, pr
     return out, prod
 
 
+def bf3_wgrad_workspace(R, F, N, device):
+    return torch.empty(max(64, lib().dr_bf3_wgrad_workspace_bytes(int(R), int(F), int(N)) // 4), dtype=torch.float32, device=device)
+
+
+def bf3_wgrad(x, dy, scale, dstW, dstb=None, workspace=None):
+    """dstW += scale * x^T @ dy ; dstb += scale * colsum(dy): register-split wgrad on fp32 activations (deterministic)."""
+    R, F = x.shape
+    N = dy.shape[1]
+    assert x.stride(1) == 1 and dy.stride(1) == 1 and dstW.shape == (F, N) and dstW.stride(1) == 1 and dy.shape[0] == R
+    if workspace is None:
+        workspace = bf3_wgrad_workspace(R, F, N, x.device)
+    check(lib().dr_bf3_wgrad(ptr(x), x.stride(0), ptr(dy), dy.stride(0), R, F, N, float(scale), ptr(dstW), dstW.stride(0),
+                             ptr(dstb), ptr(workspace), workspace.numel() * 4, stream_ptr()), "dr_bf3_wgrad")
+    return dstW
+
+
 class WeightPlanes:
     """Both pre-split forms of a Dense kernel W [K, N]: `wt` = W^T planes (rows N: the forward's B operand) and `w` = W planes
     (rows K: the dgrad's B operand).  refresh() after every update of W (two dr_bf3_split launches)."""

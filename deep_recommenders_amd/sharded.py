@@ -45,6 +45,8 @@ class HipPrims:
     emb_sort_slots = staticmethod(ops.emb_sort_slots)
     new_sort_plan = staticmethod(ops.SortPlan)
     emb_pool_bwd_sorted = staticmethod(ops.emb_pool_bwd_sorted)
+    emb_pool_bwd_sorted_adam = staticmethod(ops.emb_pool_bwd_sorted_adam)
+    adam_step = staticmethod(ops.adam_step)
     linear_fwd = staticmethod(ops.linear_fwd)
     linear_bwd_dx = staticmethod(ops.linear_bwd_dx)
     linear_bwd_dw = staticmethod(ops.linear_bwd_dw)
@@ -237,8 +239,10 @@ class ShardedEmbeddingExchange:
         self.p.emb_pack_grads(r.pos, self.D, d_concat, concat, sum_x, d_fm_logit, g_rows, g_lin, g_bias)
         return g_rows, g_lin
 
-    def exchange_and_apply(self, route, g_rows, g_lin, scale, table_local, lin_local):
-        """C3 + owner-side update (runs on the communication stream, overlapped with the tower)"""
+    def exchange_and_apply(self, route, g_rows, g_lin, scale, table_local, lin_local, adam=None):
+        """C3 + owner-side update (runs on the communication stream, overlapped with the tower).  adam = (lr_t, beta1, beta2,
+        eps, m_table, v_table, m_lin, v_lin): one row-wise Adam update per touched row from the SUM of the gradients every
+        rank sent for it (the gradients must already be those of the global-mean loss); otherwise dst += scale * sum."""
         r = route
         sl = self._slots[r.slot]
         D, G = self.D, self.GROUP
@@ -253,9 +257,16 @@ class ShardedEmbeddingExchange:
             self._a2a(gl_pad[:r.n_recv], g_lin, r.recv_splits, r.send_splits)
         if self._cuda:
             torch.cuda.current_stream().wait_event(r.sorted)
-        self.p.emb_pool_bwd_sorted(rows_pad.view(-1, G), self._zero_base_g, sl["plan"], D, self.local_rows,
-                                   g_pad.view(-1, G * D), None, scale, table_local, lin_local if r.has_lin else None, None,
-                                   slot_lin_grad=gl_pad if r.has_lin else None)
+        if adam is not None:
+            lr_t, b1, b2, eps, m_t, v_t, m_l, v_l = adam
+            self.p.emb_pool_bwd_sorted_adam(rows_pad.view(-1, G), self._zero_base_g, sl["plan"], D, self.local_rows,
+                                            g_pad.view(-1, G * D), None, lr_t, b1, b2, eps, table_local, m_t, v_t,
+                                            lin_local if r.has_lin else None, m_l, v_l,
+                                            slot_lin_grad=gl_pad if r.has_lin else None)
+        else:
+            self.p.emb_pool_bwd_sorted(rows_pad.view(-1, G), self._zero_base_g, sl["plan"], D, self.local_rows,
+                                       g_pad.view(-1, G * D), None, scale, table_local, lin_local if r.has_lin else None, None,
+                                       slot_lin_grad=gl_pad if r.has_lin else None)
         if self._cuda:
             sl["free_ev"] = torch.cuda.Event()
             sl["free_ev"].record()
@@ -275,7 +286,9 @@ class ShardedDeepFMEngine:
 
     def __init__(self, num_fields, vocab_per_field, dim, dnn_units: Sequence[int], batch, num_dense=0, lr=0.01,
                  device="cuda", world=None, rank=None, seed=42, prims=None, group=None, lin_init_std=0.0,
-                 init_tables=None, micro_batches=None):
+                 init_tables=None, micro_batches=None, optimizer="sgd", beta1=0.9, beta2=0.999, eps=1e-8):
+        assert optimizer in ("sgd", "adam")
+        self.optimizer, self.beta1, self.beta2, self.eps, self.t = optimizer, beta1, beta2, eps, 0
         self.world = world if world is not None else dist.get_world_size(group)
         self.rank = rank if rank is not None else dist.get_rank(group)
         self.F, self.V, self.D, self.B = num_fields, vocab_per_field, dim, batch
@@ -368,6 +381,13 @@ class ShardedDeepFMEngine:
         mb = int(micro_batches) if micro_batches else 2
         if not self.fuse_head or B % mb:
             mb = 1
+        if optimizer == "adam":
+            # Adam is not linear in the gradient: a row hit by both micro-batches must get ONE update from the summed gradient,
+            # like the single-GPU engine (and TF) -- so the whole rank batch travels as one exchange
+            mb = 1
+            self.m_table, self.v_table = torch.zeros_like(self.table), torch.zeros_like(self.table)
+            self.m_lin, self.v_lin = torch.zeros_like(self.lin_w), torch.zeros_like(self.lin_w)
+            self.flat_m, self.flat_v = torch.zeros_like(self.flat_params), torch.zeros_like(self.flat_params)
         self.mb = mb
         self.ex.set_slots(max(4, 2 * mb))
         Bm = B // mb
@@ -446,6 +466,16 @@ class ShardedDeepFMEngine:
         p, F, D, W, B, M = self.p, self.F, self.D, self.world, self.B, self.mb
         Bm = B // M
         cuda = self._cuda
+        adam = self.optimizer == "adam"
+        # SGD: gradients of the RANK-mean loss travel, the 1 / W of the global mean is folded into the step (-lr / W).
+        # Adam: the update is not linear in the gradient, so the head normalises by the global batch and every gradient that
+        # travels is already that of the global-mean loss.
+        n_total = B * W if adam else B
+        adam_args = None
+        if adam:
+            self.t += 1
+            lr_t = ops.adam_lr_t(self.lr, self.beta1, self.beta2, self.t)
+            adam_args = (lr_t, self.beta1, self.beta2, self.eps, self.m_table, self.v_table, self.m_lin, self.v_lin)
         if cuda and len(self._done) >= 2:                 # bound the host's run-ahead to two steps
             self._done.pop(0).synchronize()
         # steps 1-3: use the prefetched routes if they were built for exactly these keys, else route now
@@ -507,7 +537,7 @@ class ShardedDeepFMEngine:
                             x, self.Ws[-2], self.bs[-2], self.Ws[-1], self.bs[-1], self.fm_logit[sl], labels[sl],
                             ops.LOSS_SIGMOID_CE, 1.0, act=1, prob=self.prob[sl], d_logit=self.d_logit[sl], d_h=self.dhs[-1][sl],
                             loss=self.loss_parts[m:m + 1], workspace=self.head_ws, dst_W2=self.gWs[-1], dst_b2=self.gbs[-1],
-                            n_total=B))
+                            n_total=n_total))
             else:                                          # M == 1 here (see __init__)
                 p.bce_fwd_bwd(self.fm_logit, labels, ops.LOSS_SIGMOID_CE, workspace=self.ws, logits_b=self.hs[-1],
                               out=(self.prob, self.d_logit, self.loss_parts[0:1]))
@@ -551,12 +581,12 @@ class ShardedDeepFMEngine:
                     self.comm.wait_event(ev_p)
                     self._k("emb_grads(a2a+sorted K4)", "xgmi", Bm * F * (4 * D + 4),
                             lambda m=m, g_rows=g_rows, g_lin=g_lin: self.ex.exchange_and_apply(routes[m], g_rows, g_lin, -self.lr / W,
-                                                                                               self.table, self.lin_w))
+                                                                                               self.table, self.lin_w, adam=adam_args))
                     if m == M - 1:
                         ev_last_apply = torch.cuda.Event()
                         ev_last_apply.record()
             else:
-                self.ex.exchange_and_apply(routes[m], g_rows, g_lin, -self.lr / W, self.table, self.lin_w)
+                self.ex.exchange_and_apply(routes[m], g_rows, g_lin, -self.lr / W, self.table, self.lin_w, adam=adam_args)
         # ---- wgrads over the WHOLE rank batch (activations of all micro-batches are contiguous): under the last exchange --
         dys[0] = self.dhs[0] if n_layers > 1 else self.d_logit.reshape(-1, 1)
         for i in dw_todo:
@@ -567,8 +597,13 @@ class ShardedDeepFMEngine:
         # ---- dense tower: one all-reduce, then w += -(lr / W) * sum_r g_r  (mean over the global batch) ------
         self._k("allreduce_dense_grads", "xgmi", self.flat_grads.numel() * 4,
                 lambda: dist.all_reduce(self.flat_grads, group=self.group))
-        p.axpy(-self.lr / W, self.flat_grads, self.flat_params)
+        if adam:
+            p.adam_step(self.flat_params, self.flat_grads, self.flat_m, self.flat_v, adam_args[0], self.beta1, self.beta2, self.eps)
+        else:
+            p.axpy(-self.lr / W, self.flat_grads, self.flat_params)
         torch.sum(self.loss_parts, dim=0, keepdim=True, out=self.loss)
+        if adam:
+            self.loss.mul_(W)          # loss_parts were normalised by the global batch: report the rank's mean like the SGD mode
         if cuda:
             main.wait_event(ev_last_apply)                 # the step ends when every owner has applied its updates
             ev = torch.cuda.Event()

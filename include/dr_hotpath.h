@@ -495,6 +495,14 @@ int dr_bf3_linear_nt(const float* A, int64_t lda, const void* b_planes, int64_t 
 int dr_bf3_cross_fwd(const float* x0, const float* x, int64_t ld, const void* wt_planes, int64_t plane_stride,
                      int64_t ld_planes, const float* b, float diag_scale, int64_t M, int32_t Dm, float* out,
                      float* prod_out, dr_stream_t stream);
+/* dr_bf3_wgrad: dstW[f, n] += scale * sum_r x[r, f] dy[r, n];  dstb[n] += scale * sum_r dy[r, n] (dstb may be NULL) -- the wgrad of
+ * a wide layer on its fp32 activations as they are (x [R, F], dy [R, N] row-major): x goes from HBM straight into registers
+ * (lane index along f), dy is split once per 256 x-columns into a two-stage LDS image; bf16x3 product mode; split over r into
+ * `workspace` (dr_bf3_wgrad_workspace_bytes) with a fixed-order reduce: deterministic. */
+int64_t dr_bf3_wgrad_workspace_bytes(int64_t R, int32_t F, int32_t N);
+int dr_bf3_wgrad(const float* x, int64_t ld_x, const float* dy, int64_t ld_dy, int64_t R, int32_t F, int32_t N,
+                 float scale, float* dstW, int64_t ld_w, float* dstb, void* workspace, int64_t workspace_bytes,
+                 dr_stream_t stream);
 int64_t dr_bf3_gemm_tn_workspace_bytes(int64_t R, int32_t F, int32_t N);
 int dr_bf3_gemm_tn(const void* x_planes, int64_t x_plane_stride, int64_t x_ld, const void* y_planes,
                    int64_t y_plane_stride, int64_t y_ld, int64_t R, int32_t F, int32_t N, float scale, float* dst,

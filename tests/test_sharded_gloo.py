@@ -108,6 +108,30 @@ class OraclePrims:
             dst_lin.index_add_(0, flat[m], slot_lin_grad[m], alpha=scale)
 
     @staticmethod
+    def emb_pool_bwd_sorted_adam(ids, row_base, plan, D, num_rows, grad, d_fm, lr_t, beta1, beta2, eps, table, m_table, v_table,
+                                 lin_w=None, m_lin=None, v_lin=None, concat=None, sum_x=None, slot_lin_grad=None):
+        """one row-wise Adam update per touched row from the sum of its slots' gradients ([TF] B15 with lr_t given)"""
+        flat = ids.reshape(-1)
+        m = flat >= 0
+        rows = torch.unique(flat[m])
+        g = torch.zeros_like(table).index_add_(0, flat[m], grad.reshape(-1, D)[m])[rows]
+        m_table[rows] = beta1 * m_table[rows] + (1 - beta1) * g
+        v_table[rows] = beta2 * v_table[rows] + (1 - beta2) * g * g
+        table[rows] = table[rows] - lr_t * m_table[rows] / (v_table[rows].sqrt() + eps)
+        if lin_w is not None and slot_lin_grad is not None:
+            gl = torch.zeros_like(lin_w).index_add_(0, flat[m], slot_lin_grad[m])[rows]
+            m_lin[rows] = beta1 * m_lin[rows] + (1 - beta1) * gl
+            v_lin[rows] = beta2 * v_lin[rows] + (1 - beta2) * gl * gl
+            lin_w[rows] = lin_w[rows] - lr_t * m_lin[rows] / (v_lin[rows].sqrt() + eps)
+
+    @staticmethod
+    def adam_step(param, grad, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+        g = grad * grad_scale
+        m.mul_(beta1).add_(g, alpha=1 - beta1)
+        v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+        param.sub_(lr_t * m / (v.sqrt() + eps))
+
+    @staticmethod
     def linear_fwd(x, W, b, act, out=None):
         y = x @ W + b
         if act:
@@ -207,7 +231,7 @@ def _global_problem():
     return table, lin, batches
 
 
-def _worker(rank, world, port, outdir, micro_batches):
+def _worker(rank, world, port, outdir, micro_batches, optimizer="sgd"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -217,8 +241,8 @@ def _worker(rank, world, port, outdir, micro_batches):
         table, lin, batches = _global_problem()
         eng = ShardedDeepFMEngine(c["F"], c["V"], c["D"], c["units"], c["B"], num_dense=c["Nd"], lr=c["lr"], device="cpu",
                                   world=world, rank=rank, seed=5, prims=OraclePrims, init_tables=(table, lin),
-                                  micro_batches=micro_batches)
-        assert eng.mb == micro_batches
+                                  micro_batches=micro_batches, optimizer=optimizer)
+        assert eng.mb == (1 if optimizer == "adam" else micro_batches)
         sl = slice(rank * c["B"], (rank + 1) * c["B"])
         Ws0 = [w.clone() for w in eng.Ws]
         bs0 = [b.clone() for b in eng.bs]
@@ -283,6 +307,65 @@ def test_two_rank_sharded_steps_equal_single_process_oracle(tmp_path, micro_batc
             np.testing.assert_allclose(Ws_r[i].numpy(), Wc[i].numpy(), rtol=2e-5, atol=2e-6)
             np.testing.assert_allclose(bs_r[i].numpy(), bc[i].numpy(), rtol=2e-5, atol=2e-6)
         np.testing.assert_allclose(bias_r.numpy(), bias.numpy(), rtol=2e-5, atol=2e-7)
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharded_adam_steps_equal_single_process_oracle(tmp_path):
+    """Adam in the sharded engine: 2 ranks x NSTEPS steps == row-wise Adam on the global batches in one process
+    (oracle/torch_ref.py adam_rows_step / adam_dense_step, [TF] B15): every touched row gets ONE update from the gradient summed
+    over both ranks' slots, the dense tower one update from the all-reduced gradient."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path), 2, "adam")) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    res = {}
+    for r in range(world):
+        item = torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r))
+        res[item[0]] = item[1:]
+    c = CFG
+    table, lin, batches = _global_problem()
+    F, V, D, lr = c["F"], c["V"], c["D"], c["lr"]
+    Ws0, bs0 = res[0][6], res[0][7]
+    tab, li, bias = table.clone(), lin.clone(), torch.zeros(1)
+    Wc, bc = [w.clone() for w in Ws0], [b.clone() for b in bs0]
+    z = torch.zeros_like
+    mt, vt, ml, vl, mb_, vb_ = z(tab), z(tab), z(li), z(li), z(bias), z(bias)
+    mW, vW, mB, vB = [z(w) for w in Wc], [z(w) for w in Wc], [z(b) for b in bc], [z(b) for b in bc]
+    for t, (keys, dense, labels) in enumerate(batches):
+        ids = np.stack([O.hash_bucket_i64(keys[:, f].numpy(), V) for f in range(F)], axis=1)
+        tt, tl, tb = tab.clone().requires_grad_(True), li.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+        Ws = [w.clone().requires_grad_(True) for w in Wc]
+        bs = [b.clone().requires_grad_(True) for b in bc]
+        logit = T.deepfm_logit(tt, tl, tb, torch.tensor(ids), list(range(F + 1)), [f * V for f in range(F)], Ws, bs, dense)
+        lo = T.sigmoid_cross_entropy(labels, logit)
+        lo.backward()
+        assert abs(0.5 * (res[0][0][t] + res[1][0][t]) - lo.item()) < 2e-6
+        rows = torch.tensor(ids + np.arange(F)[None, :] * V).reshape(-1)
+        rows = rows[torch.tensor(ids.reshape(-1) >= 0)]
+        T.adam_rows_step(tab, tt.grad, rows, mt, vt, lr, t + 1)
+        T.adam_rows_step(li, tl.grad, rows, ml, vl, lr, t + 1)
+        T.adam_dense_step(bias, tb.grad, mb_, vb_, lr, t + 1)
+        for i in range(len(Wc)):
+            T.adam_dense_step(Wc[i], Ws[i].grad, mW[i], vW[i], lr, t + 1)
+            T.adam_dense_step(bc[i], bs[i].grad, mB[i], vB[i], lr, t + 1)
+    rps = (V + world - 1) // world
+    # Adam divides by sqrt(v): tolerances are a fraction of one step (lr), not of the weight
+    tol = dict(rtol=0, atol=2e-3 * lr)
+    for r in range(world):
+        _, tab_r, lin_r, Ws_r, bs_r, bias_r, _, _ = res[r]
+        for f in range(F):
+            gid = torch.arange(r, V, world)
+            np.testing.assert_allclose(tab_r[f * rps:f * rps + len(gid)].numpy(), tab[f * V + gid].numpy(), **tol)
+            np.testing.assert_allclose(lin_r[f * rps:f * rps + len(gid)].numpy(), li[f * V + gid].numpy(), **tol)
+        for i in range(len(Wc)):
+            np.testing.assert_allclose(Ws_r[i].numpy(), Wc[i].numpy(), **tol)
+            np.testing.assert_allclose(bs_r[i].numpy(), bc[i].numpy(), **tol)
+        np.testing.assert_allclose(bias_r.numpy(), bias.numpy(), **tol)
 
 
 def test_bucketing_oracle_matches_owner_rule():

@@ -25,8 +25,8 @@ def relerr(got, ref):
 
 def run(M, K, N, time=True):
     g = torch.Generator(device="cuda"); g.manual_seed(1)
-    x = torch.randn((M, K), device="cuda", generator=g)
-    x = torch.relu(x)                                       # ReLU-sparse-ish like activations
+    x = torch.zeros((M, (K + 3) // 4 * 4), device="cuda")[:, :K]
+    x.copy_(torch.relu(torch.randn((M, K), device="cuda", generator=g)))    # ReLU-sparse-ish like activations; 16-byte aligned rows
     W = torch.randn((K, N), device="cuda", generator=g) * 0.05
     b = torch.randn((N,), device="cuda", generator=g)
     dy = torch.randn((M, N), device="cuda", generator=g) * 1e-3
@@ -57,7 +57,13 @@ def run(M, K, N, time=True):
     dW_old = torch.zeros((K, N), device="cuda")
     ws_old = ops.linear_bwd_dw_workspace(M, K, N, "cuda")
     ops.linear_bwd_dw(x, dy, 1.0, dW_old, None, workspace=ws_old)
-    print("  wgrad err planes %.3e  in-kernel %.3e" % (relerr(dW, ref), relerr(dW_old, ref)))
+    dW_rs = torch.zeros((K, N), device="cuda")
+    db_rs = torch.zeros((N,), device="cuda")
+    ws_rs = ops.bf3_wgrad_workspace(M, K, N, "cuda")
+    ws_rs.fill_(float("nan"))
+    ops.bf3_wgrad(x, dy, 1.0, dW_rs, db_rs, workspace=ws_rs)
+    print("  wgrad err planes %.3e  in-kernel %.3e  reg-split %.3e  (db %.3e)" % (relerr(dW, ref), relerr(dW_old, ref), relerr(dW_rs, ref),
+                                                                               relerr(db_rs, dy.double().sum(0))))
     if time:
         fl = 2.0 * M * K * N
         for name, fn in [("fwd planes", lambda: ops.bf3_gemm_nt(xp, wtp, bias=b, act=1, out=y)),
@@ -68,6 +74,7 @@ def run(M, K, N, time=True):
                          ("dgrad in-kernel", lambda: ops.linear_bwd_dx(dy, W, out=dx_old)),
                          ("wgrad planes", lambda: ops.bf3_gemm_tn(xp, dyp, 1e-9, dW, workspace=ws)),
                          ("wgrad in-kernel", lambda: ops.linear_bwd_dw(x, dy, 1e-9, dW_old, None, workspace=ws_old)),
+                         ("wgrad reg-split", lambda: ops.bf3_wgrad(x, dy, 1e-9, dW_rs, db_rs, workspace=ws_rs)),
                          ("split x", lambda: ops.bf3_split(x, xp)),
                          ("split W^T", lambda: ops.bf3_split(W, wtp, transpose=True)),
                          ("split W", lambda: ops.bf3_split(W, wp))]:
