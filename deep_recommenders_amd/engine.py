@@ -136,13 +136,13 @@ class DeepFMEngine:
             self.side = torch.cuda.Stream(device=device)
             self.ev_ids = torch.cuda.Event()
             self.ev_sorted = torch.cuda.Event()
-        # First-layer wgrad (matrix pipe, 2 blocks / CU in bf16x3 mode) on a second stream, concurrent with the HBM-bound K4 on
-        # the training stream: 1.91 -> 1.84 ms / step (A/B/A/B on one box).  With the native fp32 GEMM (3 blocks / CU, higher
-        # MFMA occupancy) the same overlap measured neutral to negative.  Only for steps whose first-layer GEMM is worth the
-        # stream fork / join (>= 4 GFLOP): at the MovieLens shape (B = 4096, 0.23 GFLOP) the eager step is 0.177 ms without
-        # and 0.212 ms with it.  DR_OVERLAP_DW=0 / 1 force it off / on.
-        _ov = _os.environ.get("DR_OVERLAP_DW", "auto")
-        self.overlap_dw = _ov == "1" or (_ov != "0" and 2.0 * B * self.in_dim * units[0] >= 4e9)
+        # First-layer wgrad on a second stream, concurrent with the HBM-bound K4 on the training stream.  It paid next to the
+        # in-kernel-split wgrad (2 blocks / CU, matrix pipe ~35 % busy: 1.91 -> 1.84 ms / step); next to the register-split wgrad
+        # (one 512-thread block per CU holding all its registers and 96 KB of LDS) the two kernels only time-slice the CUs: the
+        # pair takes 740 - 750 us against 340 + 310 back to back, the step 1.764 vs 1.746 ms (round 2, A/B on one box).  So it
+        # is OFF unless DR_OVERLAP_DW=1 asks for it.
+        _ov = _os.environ.get("DR_OVERLAP_DW", "0")
+        self.overlap_dw = _ov == "1"
         self.concurrent = {}
         if self.overlap_dw:
             k4 = "emb_pool_bwd_adam" if optimizer == "adam" else "emb_pool_bwd"

@@ -3,7 +3,8 @@
 Every other engine-level test uses toy shapes, where the benched orchestration is switched off (first-layer wgrad on a
 second stream racing the fused K4, the wide-tile GEMM at K = 1677 / N = 256, the LPR = 16 single-valued gather kernel,
 the row-ordered K4 at 1.7 M slots, the fused tower head at 65 536 rows).  Here the engines run exactly as `bench.py` builds
-them -- B = 65 536, F = 26, D = 64, 13 dense, DNN [256, 32], hashed raw keys, default GEMM mode, `overlap_dw` on -- for two
+them -- B = 65 536, F = 26, D = 64, 13 dense, DNN [256, 32], hashed raw keys, default GEMM mode (register-split GEMMs on
+pre-split weights for the first layer; the wgrad / K4 overlap is covered by its own on / off test) -- for two
 consecutive steps against the host oracle (oracle/torch_ref.py under torch autograd, fp32 like the reference's TF-CPU path).
 
 The host never holds the tables: the rows the two batches touch are gathered from HBM before the first step (at most
@@ -180,7 +181,7 @@ def _run_deepfm(V, optimizer, kind, lr, steps=2):
     from deep_recommenders_amd import ops
     assert ops.get_gemm_mode() == "bf16x3"                 # bench.py's default product mode
     eng = _make_engine(V, optimizer, lr)
-    assert eng.overlap_dw and eng.fuse_head and eng.sorted_bwd, "not the benched orchestration"
+    assert eng.fuse_head and eng.sorted_bwd and eng.wplanes[0] is not None and eng.wg_ws[0] is not None, "not the benched orchestration"
     assert ops.linear_bwd_narrow_supported(B, 256, 32) and eng.narrow_ws[1] is not None
     batches = _batches(steps, kind, seed=1234)
     ids_list = [_oracle_ids(k, V) for k, _, _ in batches]
