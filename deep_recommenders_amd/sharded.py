@@ -55,6 +55,8 @@ class HipPrims:
     tower_head_fwd_bwd = staticmethod(ops.tower_head_fwd_bwd)
     linear_bwd_narrow = staticmethod(ops.linear_bwd_narrow)
     linear_bwd_narrow_supported = staticmethod(ops.linear_bwd_narrow_supported)
+    cross_fwd = staticmethod(ops.cross_fwd)
+    cross_combine_bwd = staticmethod(ops.cross_combine_bwd)
 
 
 class Route:
@@ -609,4 +611,141 @@ class ShardedDeepFMEngine:
             ev = torch.cuda.Event()
             ev.record()
             self._done.append(ev)
+        return self.loss
+
+
+class ShardedDCNEngine:
+    """DCN (BASELINE config 4: 3 full-rank cross layers + MLP + Dense(1)) with row-sharded tables and data-parallel batch; same
+    model / loss / SGD as dcn_engine.DCNEngine.  The cross / MLP weights are replicated: their gradients live in ONE flat bucket
+    (3 x (1677^2 + 1677) + 2.37 M floats = 43 MB at config 4) that is all-reduced asynchronously while the
+    embedding gradients travel back to their owners.  `batch` is the per-rank batch; the loss is the mean over world * batch."""
+
+    def __init__(self, num_fields, vocab_per_field, dim, num_cross, dnn_units: Sequence[int], batch, num_dense=0, lr=0.01,
+                 diag_scale=0.0, device="cuda", world=None, rank=None, seed=42, prims=None, group=None, init_tables=None):
+        self.world = world if world is not None else dist.get_world_size(group)
+        self.rank = rank if rank is not None else dist.get_rank(group)
+        self.F, self.V, self.D, self.B, self.Nd, self.lr, self.diag = num_fields, vocab_per_field, dim, batch, num_dense, lr, diag_scale
+        self.group, self.dev = group, device
+        self.p = prims if prims is not None else HipPrims
+        F, V, D, B, W = num_fields, vocab_per_field, dim, batch, self.world
+        self.ex = ShardedEmbeddingExchange(F, V, D, W, self.rank, device, self.p, group)
+        rps = self.ex.rows_per_shard
+        g = torch.Generator(device=device)
+        g.manual_seed(seed)                       # replicated weights: same seed on every rank
+        f32 = dict(dtype=torch.float32, device=device)
+        self.in_dim = F * D + num_dense
+        self.ld = _pad4(self.in_dim)
+        units = list(dnn_units) + [1]
+        n_in, ld = self.in_dim, self.ld
+        total = num_cross * (n_in * ld + ld)
+        d = n_in
+        for u in units:
+            total += d * _pad4(u) + _pad4(u)
+            d = u
+        self.flat_params = torch.zeros(total + 4, **f32)
+        self.flat_grads = torch.zeros(total + 4, **f32)
+        off = 0
+        self.cross_W, self.cross_b, self.g_cross_W, self.g_cross_b = [], [], [], []
+        for _ in range(num_cross):
+            Wc = self.flat_params[off:off + n_in * ld].view(n_in, ld)[:, :n_in]
+            Wc.copy_(torch.empty((n_in, n_in), **f32).normal_(0.0, 0.01, generator=g).clamp_(-0.02, 0.02))
+            self.cross_W.append(Wc)
+            self.g_cross_W.append(self.flat_grads[off:off + n_in * ld].view(n_in, ld)[:, :n_in])
+            off += n_in * ld
+            self.cross_b.append(self.flat_params[off:off + n_in])
+            self.g_cross_b.append(self.flat_grads[off:off + n_in])
+            off += ld
+        self.Ws, self.bs, self.gWs, self.gbs = [], [], [], []
+        d = n_in
+        for u in units:
+            pu = _pad4(u)
+            Wm = self.flat_params[off:off + d * pu].view(d, pu)[:, :u]
+            Wm.copy_((torch.rand((d, u), device=device, generator=g) * 2 - 1) * math.sqrt(6.0 / (d + u)))
+            self.Ws.append(Wm)
+            self.gWs.append(self.flat_grads[off:off + d * pu].view(d, pu)[:, :u])
+            off += d * pu
+            self.bs.append(self.flat_params[off:off + u])
+            self.gbs.append(self.flat_grads[off:off + u])
+            off += pu
+            d = u
+        self.acts = [1] * len(dnn_units) + [0]
+        self.table = torch.empty((F * rps, D), **f32)
+        if init_tables is not None:
+            full_table = init_tables
+            for f in range(F):
+                ids = torch.arange(self.rank, V, W)
+                self.table[f * rps:f * rps + len(ids)] = full_table[f * V + ids].to(device)
+        else:
+            gt = torch.Generator(device=device)
+            gt.manual_seed(seed * 1000 + 17 + self.rank)
+            std = 1.0 / math.sqrt(D)
+            for r0 in range(0, F * rps, 1 << 24):
+                self.table[r0:r0 + (1 << 24)].normal_(0.0, std, generator=gt).clamp_(-2 * std, 2 * std)
+        self.x0 = torch.zeros((B, ld), **f32)
+        self.zero_logit = torch.zeros(B, **f32)
+        self.prob, self.d_logit, self.loss = torch.empty(B, **f32), torch.empty(B, **f32), torch.zeros(1, **f32)
+        self.ws = torch.empty(1024, **f32)
+        self._cuda = torch.device(device).type == "cuda"
+        self.mb = 1
+
+    def enable_kernel_events(self, on):           # bench.py contract; the sharded DCN step reports no per-kernel rows
+        pass
+
+    def kernel_event_summary(self):
+        return {}
+
+    def train_step(self, keys, dense, labels, next_keys=None):
+        p, F, D, B, W, lr, n_in, ld = self.p, self.F, self.D, self.B, self.world, self.lr, self.in_dim, self.ld
+        f32 = dict(dtype=torch.float32, device=self.x0.device)
+        # ---- embeddings: route, owner-side gather, rows back, K3 over the received rows -------------------------------------------
+        route = self.ex.route(keys, hashed=True)
+        got_rows, _ = self.ex.fetch(route, self.table, None)
+        p.emb_pool_fwd(route.pos, F, None if F <= 64 else self.ex._col_start, self.ex._zero_base, got_rows, None, None,
+                       ld_concat=ld, concat=self.x0, want_sum_x=False, want_fm=False)
+        if self.Nd:
+            self.x0[:, F * D:F * D + self.Nd].copy_(dense)
+        x0 = self.x0[:, :n_in]
+        # ---- forward: cross stack, MLP, loss (mean over the rank's batch; the 1 / W of the global mean is folded into the step) --
+        xs, prods = [x0], []
+        for Wc, bc in zip(self.cross_W, self.cross_b):
+            out, prod = p.cross_fwd(x0, xs[-1], Wc, bc, self.diag, want_prod=True)
+            xs.append(out)
+            prods.append(prod)
+        hs, x = [], xs[-1]
+        for i, (Wm, bm) in enumerate(zip(self.Ws, self.bs)):
+            h = torch.empty((B, _pad4(Wm.shape[1])), **f32)[:, :Wm.shape[1]]
+            x = p.linear_fwd(x, Wm, bm, self.acts[i], out=h)
+            hs.append(x)
+        p.bce_fwd_bwd(self.zero_logit, labels, ops.LOSS_SIGMOID_CE, workspace=self.ws, logits_b=hs[-1],
+                      out=(self.prob, self.d_logit, self.loss))
+        # ---- backward: MLP, then the cross stack; every weight gradient goes into the bucket --------------------------------------
+        self.flat_grads.zero_()
+        dy = self.d_logit.reshape(-1, 1)
+        d_top = torch.zeros((B, ld), **f32)[:, :n_in]
+        for i in range(len(self.Ws) - 1, -1, -1):
+            xin = xs[-1] if i == 0 else hs[i - 1]
+            if i > 0:
+                dx = torch.empty((B, _pad4(xin.shape[1])), **f32)[:, :xin.shape[1]]
+                rs = hs[i - 1] if self.acts[i - 1] else None
+            else:
+                dx, rs = d_top, None
+            p.linear_bwd_dx(dy, self.Ws[i], relu_src=rs, out=dx)
+            p.linear_bwd_dw(xin, dy, 1.0, self.gWs[i], self.gbs[i])
+            dy = dx
+        d_out = d_top
+        d_x0 = torch.zeros((B, ld), **f32)[:, :n_in]
+        for l in range(len(self.cross_W) - 1, -1, -1):
+            d_x = torch.zeros((B, ld), **f32)[:, :n_in]
+            d_prod = p.cross_combine_bwd(x0, prods[l], d_out, self.diag, d_x0, d_x)
+            p.linear_bwd_dx(d_prod, self.cross_W[l], None, accumulate=True, out=d_x)
+            p.linear_bwd_dw(xs[l], d_prod, 1.0, self.g_cross_W[l], self.g_cross_b[l])
+            d_out = d_x
+        d_x0.add_(d_out)                                  # the first layer's x IS x0
+        # ---- C4: the replicated weights' gradients (asynchronous: the embedding gradients travel meanwhile) ------------------------
+        work = dist.all_reduce(self.flat_grads, group=self.group, async_op=True)
+        # ---- C3: embedding-row gradients to their owners + sorted scatter with the SGD step --------------------------------------------
+        g_rows, _ = self.ex.pack(route, d_x0, None, None, None)
+        self.ex.exchange_and_apply(route, g_rows, None, -lr / W, self.table, None)
+        work.wait()
+        p.axpy(-lr / W, self.flat_grads, self.flat_params)
         return self.loss

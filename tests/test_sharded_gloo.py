@@ -62,8 +62,13 @@ class OraclePrims:
 
     @staticmethod
     def emb_pool_fwd(ids, F, col_start, row_base, table, lin_w, lin_bias, ld_concat=None, concat=None, sum_x=None,
-                     fm_logit=None, **kw):
+                     fm_logit=None, want_sum_x=True, want_fm=True, **kw):
         cs = list(range(F + 1)) if col_start is None else col_start.tolist()
+        if not want_fm:                                    # gather + pool only (DCN: no first-order / FM term)
+            embs = T.pool_fields(table, ids, cs, row_base.tolist())
+            c = torch.cat(embs, 1)
+            concat[:, :c.shape[1]].copy_(c)
+            return concat, None, None
         c, s, l = T.emb_fm_forward(table, lin_w, lin_bias[0] if lin_bias is not None else 0.0, ids, cs, row_base.tolist())
         concat[:, :c.shape[1]].copy_(c)
         sum_x.copy_(s)
@@ -86,7 +91,9 @@ class OraclePrims:
     def emb_pack_grads(pos, D, d_concat, concat, sum_x, d_fm, out_rows, out_lin=None, bias_sum=None):
         B, F = pos.shape
         for f in range(F):
-            g = d_concat[:, f * D:(f + 1) * D] + d_fm[:, None] * (sum_x - concat[:, f * D:(f + 1) * D])
+            g = d_concat[:, f * D:(f + 1) * D]
+            if d_fm is not None:
+                g = g + d_fm[:, None] * (sum_x - concat[:, f * D:(f + 1) * D])
             out_rows[pos[:, f]] = g
             if out_lin is not None:
                 out_lin[pos[:, f]] = d_fm
@@ -144,8 +151,23 @@ class OraclePrims:
         dx = dy @ W.t()
         if relu_src is not None:
             dx = dx * (relu_src > 0)
-        out.copy_(dx)
+        if accumulate:
+            out.add_(dx)
+        else:
+            out.copy_(dx)
         return out
+
+    @staticmethod
+    def cross_fwd(x0, x, W, b, diag_scale=0.0, want_prod=False, prod=None):
+        pr = x @ W + b + diag_scale * x                     # keras/models/ranking/dcn.py:81,85-86
+        return x0 * pr + x, pr                              # :88
+
+    @staticmethod
+    def cross_combine_bwd(x0, prod, d_out, diag_scale, d_x0_accum, d_x_accum):
+        d_prod = d_out * x0
+        d_x0_accum.add_(d_out * prod)
+        d_x_accum.add_(d_out + diag_scale * d_prod)
+        return d_prod
 
     @staticmethod
     def linear_bwd_dw(x, dy, scale, dstW, dstb=None, workspace=None):
@@ -366,6 +388,108 @@ def test_two_rank_sharded_adam_steps_equal_single_process_oracle(tmp_path):
             np.testing.assert_allclose(Ws_r[i].numpy(), Wc[i].numpy(), **tol)
             np.testing.assert_allclose(bs_r[i].numpy(), bc[i].numpy(), **tol)
         np.testing.assert_allclose(bias_r.numpy(), bias.numpy(), **tol)
+
+
+DCN_CFG = dict(F=3, V=29, D=4, B=16, Nd=2, units=[8, 4], L=2, lr=0.2, diag=0.1)
+
+
+def _dcn_problem():
+    g = torch.Generator().manual_seed(9)
+    c = DCN_CFG
+    table = torch.randn((c["F"] * c["V"], c["D"]), generator=g) * 0.4
+    batches = []
+    for _ in range(NSTEPS):
+        keys = torch.randint(0, 10**9, (2 * c["B"], c["F"]), generator=g)
+        dense = torch.rand((2 * c["B"], c["Nd"]), generator=g)
+        labels = (torch.rand(2 * c["B"], generator=g) < 0.3).float()
+        batches.append((keys, dense, labels))
+    return table, batches
+
+
+def _dcn_worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from deep_recommenders_amd.sharded import ShardedDCNEngine
+        c = DCN_CFG
+        table, batches = _dcn_problem()
+        eng = ShardedDCNEngine(c["F"], c["V"], c["D"], c["L"], c["units"], c["B"], num_dense=c["Nd"], lr=c["lr"], diag_scale=c["diag"],
+                               device="cpu", world=world, rank=rank, seed=5, prims=OraclePrims, init_tables=table)
+        with torch.no_grad():
+            for b in eng.cross_b:
+                b.fill_(0.05)
+            eng.bs[-1].fill_(0.03)        # keeps logits off the kink of the restated loss at exactly 0 (dead-ReLU examples would sit
+                                          # on it with a zero bias; autograd's subgradient there is not the kernels' sigmoid(0) - z)
+        params0 = eng.flat_params.clone()
+        sl = slice(rank * c["B"], (rank + 1) * c["B"])
+        losses = [eng.train_step(k[sl].contiguous(), d[sl].contiguous(), l[sl].contiguous()).item() for k, d, l in batches]
+        torch.save((rank, losses, eng.table.clone(), eng.flat_params.clone(), params0), os.path.join(outdir, "rank%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharded_dcn_equals_single_process_oracle(tmp_path):
+    """ShardedDCNEngine: 2 ranks x NSTEPS steps == plain SGD on the global batches in one process, with the
+    cross stack of keras/models/ranking/dcn.py:81-88 (T.cross) under torch autograd."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_dcn_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    res = {}
+    for r in range(world):
+        item = torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r))
+        res[item[0]] = item[1:]
+    c = DCN_CFG
+    table, batches = _dcn_problem()
+    F, V, D, lr, L = c["F"], c["V"], c["D"], c["lr"], c["L"]
+    n_in = F * D + c["Nd"]
+    ld = (n_in + 3) // 4 * 4
+    assert torch.equal(res[0][3], res[1][3])
+    flat = res[0][3].clone()
+
+    def unpack(P):
+        off, cW, cb, Ws, bs = 0, [], [], [], []
+        for _ in range(L):
+            cW.append(P[off:off + n_in * ld].view(n_in, ld)[:, :n_in]); off += n_in * ld
+            cb.append(P[off:off + n_in]); off += ld
+        d = n_in
+        for u in c["units"] + [1]:
+            pu = (u + 3) // 4 * 4
+            Ws.append(P[off:off + d * pu].view(d, pu)[:, :u]); off += d * pu
+            bs.append(P[off:off + u]); off += pu
+            d = u
+        return cW, cb, Ws, bs
+    tab = table.clone()
+    for t, (keys, dense, labels) in enumerate(batches):
+        ids = np.stack([O.hash_bucket_i64(keys[:, f].numpy(), V) for f in range(F)], axis=1)
+        P = flat.clone().requires_grad_(True)
+        tt = tab.clone().requires_grad_(True)
+        cW, cb, Ws, bs = unpack(P)
+        emb = T.pool_fields(tt, torch.tensor(ids), list(range(F + 1)), [f * V for f in range(F)])
+        x0 = torch.cat(emb + [dense], 1)
+        x = x0
+        for Wc, bc in zip(cW, cb):
+            x = T.cross(x0, x, Wc, bc, c["diag"])
+        logit = T.dnn(x, Ws, bs).squeeze(1)
+        lo = T.sigmoid_cross_entropy(labels, logit)
+        lo.backward()
+        assert abs(0.5 * (res[0][0][t] + res[1][0][t]) - lo.item()) < 2e-6
+        flat = (flat - lr * P.grad).detach()
+        tab = (tab - lr * tt.grad).detach()
+    rps = (V + world - 1) // world
+    for r in range(world):
+        _, tab_r, flat_r, _ = res[r]
+        np.testing.assert_allclose(flat_r.numpy(), flat.numpy(), rtol=2e-5, atol=2e-6)
+        for f in range(F):
+            gid = torch.arange(r, V, world)
+            np.testing.assert_allclose(tab_r[f * rps:f * rps + len(gid)].numpy(), tab[f * V + gid].numpy(), rtol=2e-5, atol=2e-6)
 
 
 def test_bucketing_oracle_matches_owner_rule():
