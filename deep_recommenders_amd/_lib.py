@@ -87,6 +87,11 @@ SIGNATURES = {
     "dr_cin_bwd": [_p, _p, _i64, _i32, _i32, _i32, _p, _i32, _i32, _p, _p, _p, _p, _p, _p, _p],
     "dr_din_concat_fwd": [_p, _p, _i64, _i32, _i32, _p, _i64, _p],
     "dr_din_concat_bwd": [_p, _p, _i64, _i32, _i32, _p, _i64, _p, _p, _p],
+    "dr_act_fwd": [_p, _i64, _i32, _i64, _i32, _p],
+    "dr_act_bwd": [_p, _i64, _p, _i64, _i64, _i32, _i32, _p],
+    "dr_dropout_fwd": [_p, _i64, _i64, _i32, _f32, _u64, _p, _i64, _p, _p],
+    "dr_dropout_bwd": [_p, _i64, _p, _i64, _i32, _f32, _p, _i64, _p],
+    "dr_reduce_sum": [_p, _i64, _i32, _f32, _i32, _p, _p, _p],
     "dr_version": [],
     "dr_set_gemm_mode": [_i32],
     "dr_get_gemm_mode": [],

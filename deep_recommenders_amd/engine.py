@@ -339,7 +339,7 @@ class DeepFMEngine:
                                                      self.d_logit, lr_t, self.beta1, self.beta2, self.eps, self.table,
                                                      self.m_table, self.v_table, self.lin_w, self.m_lin, self.v_lin,
                                                      concat=self.concat, sum_x=self.sum_x))
-        torch.sum(self.d_logit, dim=0, keepdim=True, out=self.g_lin_bias)       # d loss / d (first-order bias)
+        ops.reduce_sum(self.d_logit, out=self.g_lin_bias)                       # d loss / d (first-order bias), fixed order
         if self.overlap_dw:
             torch.cuda.current_stream().wait_event(self.ev_dw)     # the dense step needs the first layer's gradient
         self._k("adam_step_dense", "hbm", 28.0 * self.flat_params.numel(),

@@ -27,6 +27,19 @@ def _init(name, shape, device):
     return t
 
 
+def _l2_coeff(regu):
+    """None -> 0; 'l2' -> Keras' default factor 0.01; a float -> that factor; {'l2': f} -> f; anything else -> None (rejected)"""
+    if regu is None:
+        return 0.0
+    if regu == "l2":
+        return 0.01
+    if isinstance(regu, (int, float)):
+        return float(regu)
+    if isinstance(regu, dict) and set(regu) == {"l2"}:
+        return float(regu["l2"])
+    return None
+
+
 class Cross(nn.Module):
     """Cross(projection_dim=None, diag_scale=0.0, use_bias=True, kernel_init="truncated_normal", kernel_regu=None,
     bias_init="zeros", bias_regu=None).call(x0, x=None) = x0 * (W x + b + diag_scale * x) + x   (dcn.py:70-88)."""
@@ -42,8 +55,9 @@ class Cross(nn.Module):
         self._bias_init = bias_init
         self._bias_regu = bias_regu
         self._kwargs = kwargs
-        if kernel_regu is not None or bias_regu is not None:
-            raise NotImplementedError("regularizers are not used by any reference model/test")
+        for r in (kernel_regu, bias_regu):
+            if r is not None and _l2_coeff(r) is None:
+                raise ValueError("regularizer must be None, 'l2', a float (the l2 factor) or {'l2': factor}; got %r" % (r,))
         assert self._diag_scale >= 0, ValueError(
             "diag scale must be non-negative, got {}".format(self._diag_scale))       # dcn.py:32-33
         self.built = False
@@ -77,14 +91,26 @@ class Cross(nn.Module):
             self.build(x0.shape, x0.device)
         if self._projection_dim is None:
             return L.cross(x0, x, self.kernel, self.bias, self._diag_scale or 0.0)     # dcn.py:81,85-88
-        # low-rank: prod = Dense_v(Dense_u(x)) (dcn.py:83); the combine is elementwise in autograd-visible form
-        u = L.mlp(x, [self.kernel_u], [None], [0])
-        prod = L.mlp(u, [self.kernel], [self.bias], [0])
-        if self._diag_scale:
-            prod = prod + self._diag_scale * x
-        return x0 * prod + x
+        # low-rank: prod = (x U) V + b (dcn.py:83), combined by dr_cross_fwd(W = NULL)
+        return L.cross_low_rank(x0, x, self.kernel_u, self.kernel, self.bias, self._diag_scale or 0.0)
 
     forward = call
+
+    @property
+    def losses(self):
+        """Regularization terms like a Keras layer's `.losses` (kernel_regularizer on every kernel, bias_regularizer on the
+        bias; dcn.py:39-45,55-68): a list of scalar tensors to add to the training loss."""
+        out = []
+        if not self.built:
+            return out
+        kc, bc = _l2_coeff(self._kernel_regu), _l2_coeff(self._bias_regu)
+        if kc:
+            out.append(L.l2_penalty(self.kernel, kc))
+            if self.kernel_u is not None:
+                out.append(L.l2_penalty(self.kernel_u, kc))
+        if bc and self.bias is not None:
+            out.append(L.l2_penalty(self.bias, bc))
+        return out
 
     def get_config(self):
         config = {

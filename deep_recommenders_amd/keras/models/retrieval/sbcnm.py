@@ -86,6 +86,19 @@ class _InBatchSoftmaxFn(torch.autograd.Function):
         return dq, dc, None, None, None, None
 
 
+class _AdjustFn(torch.autograd.Function):
+    """scores - log p_j + (dup_ij - labels_ij) * MIN_FLOAT (sbcnm.py:66-86) on an explicit matrix: additive constants, so the
+    gradient passes through unchanged."""
+
+    @staticmethod
+    def forward(ctx, scores, labels, cand_prob, cand_ids):
+        return ops.logits_adjust(scores.contiguous(), labels, cand_prob=cand_prob, cand_ids=cand_ids)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None, None, None
+
+
 class _ScoresFn(torch.autograd.Function):
     """scores = q c^T as an explicit [B, B] matrix with the MFMA GEMMs in both directions (for user-supplied losses)."""
 
@@ -221,20 +234,19 @@ class Retrieval(nn.Module):
     forward = call
 
     def _custom_loss(self, q, c, w, cp, ci, inv_t):
-        """user-supplied loss object (sbcnm.py:100-103,151): the call sequence of :129-151 on an explicit score matrix."""
+        """user-supplied loss object (sbcnm.py:100-103,151): the call sequence of :129-151 on an explicit score matrix.  The
+        score GEMMs, the corrections (dr_logits_adjust) and the hard-negative selection (dr_topk_select) are the kernels of the
+        default path; the loss itself is the user's torch callable, so the kept scores are handed to it as autograd tensors."""
         scores = _ScoresFn.apply(q, c)
         B = scores.shape[0]
         labels = torch.eye(B, scores.shape[1], device=scores.device)
-        if cp is not None:
-            scores = scores - torch.log(cp)[None, :]                                          # :78-86
-        if ci is not None:
-            ident = ci.reshape(-1, 1)
-            dup = (ident[:B] == ident.t()).to(scores.dtype) - labels                         # :66-73
-            scores = scores + dup * MIN_FLOAT
+        if cp is not None or ci is not None:
+            scores = _AdjustFn.apply(scores, labels, cp, ci)                                  # :78-86, :66-75
         if self._num_hard_negatives is not None:
             k = min(self._num_hard_negatives + 1, scores.shape[1])
-            idx = torch.topk(scores.detach() + labels * MAX_FLOAT, k, dim=1).indices          # :41-44
-            scores, labels = torch.gather(scores, 1, idx), torch.gather(labels, 1, idx)
+            boosted = ops.logits_adjust(scores.detach(), labels, add_label_scale=MAX_FLOAT)   # logits + labels * MAX_FLOAT (:44)
+            _, idx = ops.topk_select(boosted, k)                                              # :41-44
+            scores, labels = torch.gather(scores, 1, idx), torch.gather(labels, 1, idx)       # :45-47 (selection only)
         scores = scores * inv_t
         return self._loss(y_true=labels, y_pred=scores, sample_weight=w)
 

@@ -96,8 +96,9 @@ class _Fm2Fn(torch.autograd.Function):
 
 
 class _MlpFn(torch.autograd.Function):
-    """K7: a whole Dense tower (relu hidden layers are fused into the GEMM epilogues; relu' is folded
-    into the dx epilogue of the layer above).  args: x, n_layers, acts tuple, then W0, b0, W1, b1, ..."""
+    """K7: a whole Dense tower.  acts[i] in {0: linear, 1: relu (fused into the GEMM epilogue; relu' is folded into the dx epilogue
+    of the layer above), 2: sigmoid, 3: tanh (dr_act_fwd on the linear output, dr_act_bwd through the saved output)}.
+    args: x, acts tuple, then W0, b0, W1, b1, ..."""
 
     @staticmethod
     def forward(ctx, x, acts, *params):
@@ -105,7 +106,9 @@ class _MlpFn(torch.autograd.Function):
         hs = [x]
         h = x
         for i in range(n):
-            h = ops.linear_fwd(h, params[2 * i], params[2 * i + 1], acts[i])
+            h = ops.linear_fwd(h, params[2 * i], params[2 * i + 1], 1 if acts[i] == 1 else 0)
+            if acts[i] in (2, 3):
+                ops.act_fwd_(h, acts[i])
             hs.append(h)
         ctx.acts = acts
         ctx.save_for_backward(*hs, *params)
@@ -117,12 +120,13 @@ class _MlpFn(torch.autograd.Function):
         n = len(acts)
         saved = ctx.saved_tensors
         hs, params = saved[:n + 1], saved[n + 1:]
-        if acts[n - 1] == 1:
-            raise NotImplementedError("the last layer of a tower is linear in every reference model")
         grads = [None] * (2 * n)
         dy = dy.contiguous()
         for i in range(n - 1, -1, -1):
             W, b = params[2 * i], params[2 * i + 1]
+            if acts[i] in (2, 3) or (acts[i] == 1 and i == n - 1):
+                # the activation's derivative through the saved output (a relu BELOW the top layer is folded into the dx GEMM)
+                dy = ops.act_bwd_(hs[i + 1], dy.clone() if i == n - 1 else dy, acts[i])
             gW = torch.zeros_like(W)
             gb = torch.zeros_like(b) if b is not None else None
             ops.linear_bwd_dw(hs[i], dy, 1.0, gW, gb)
@@ -132,6 +136,80 @@ class _MlpFn(torch.autograd.Function):
                 relu_src = hs[i] if (i > 0 and acts[i - 1] == 1) else None
                 dy = ops.linear_bwd_dx(dy, W, relu_src)
         return (dy if ctx.needs_input_grad[0] else None, None, *grads)
+
+
+class _DropoutFn(torch.autograd.Function):
+    """tf.nn.dropout(x, rate) (estimator/models/feature_interaction/dnn.py:26-27 of the reference)."""
+
+    @staticmethod
+    def forward(ctx, x, rate, seed):
+        y, mask = ops.dropout_fwd(x if x.stride(1) == 1 else x.contiguous(), rate, seed)
+        ctx.rate = rate
+        ctx.save_for_backward(mask)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        mask, = ctx.saved_tensors
+        return ops.dropout_bwd(dy if dy.stride(1) == 1 else dy.contiguous(), mask, ctx.rate), None, None
+
+
+class _L2Fn(torch.autograd.Function):
+    """coeff * sum(w^2): the term a Keras `l2(coeff)` kernel / bias regularizer adds to the model's losses."""
+
+    @staticmethod
+    def forward(ctx, w, coeff):
+        ctx.coeff = coeff
+        ctx.save_for_backward(w)
+        return ops.reduce_sum(w, squared=True, alpha=coeff).reshape(())
+
+    @staticmethod
+    def backward(ctx, d):
+        w, = ctx.saved_tensors
+        g = torch.zeros_like(w, memory_format=torch.contiguous_format)
+        ops.axpy(2.0 * ctx.coeff * float(d), w.contiguous(), g)
+        return g, None
+
+
+class _CrossLowRankFn(torch.autograd.Function):
+    """Low-rank DCN cross layer (keras/models/ranking/dcn.py:83-88): prod = (x U) V + b + diag x ; out = x0 * prod + x, with the
+    two GEMMs on dr_linear_* and the combine on dr_cross_fwd(W = NULL) / dr_cross_combine_bwd."""
+
+    @staticmethod
+    def forward(ctx, x0, x, U, V, b, diag):
+        u = ops.linear_fwd(x, U)                                            # [B, p]
+        prod = torch.empty((x.shape[0], x.stride(0)), dtype=torch.float32, device=x.device)[:, :x.shape[1]]
+        ops.linear_fwd(u, V, None, 0, out=prod)                             # x U V  (bias and diag are added by the combine)
+        out, prod = ops.cross_fwd(x0, x, None, b, diag, prod=prod)
+        ctx.diag = diag
+        ctx.has_b = b is not None
+        ctx.save_for_backward(x0, x, U, V, u, prod)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x0, x, U, V, u, prod = ctx.saved_tensors
+        ld = x.stride(0)
+        d_out = _ld_like(d_out, ld)
+        d_x0 = torch.zeros((x.shape[0], ld), dtype=torch.float32, device=x.device)[:, :x.shape[1]]
+        d_x = torch.zeros((x.shape[0], ld), dtype=torch.float32, device=x.device)[:, :x.shape[1]]
+        d_prod = ops.cross_combine_bwd(x0, prod, d_out, ctx.diag, d_x0, d_x)
+        gV, gU = torch.zeros_like(V), torch.zeros_like(U)
+        gb = torch.zeros(x.shape[1], dtype=torch.float32, device=x.device) if ctx.has_b else None
+        ops.linear_bwd_dw(u, d_prod, 1.0, gV, gb)                           # dV = u^T d_prod ; db = colsum(d_prod)
+        d_u = ops.linear_bwd_dx(d_prod, V)
+        ops.linear_bwd_dw(x, d_u, 1.0, gU)                                  # dU = x^T d_u
+        ops.linear_bwd_dx(d_u, U, None, accumulate=True, out=d_x)           # d_x += d_u U^T
+        return d_x0, d_x, gU, gV, gb, None
+
+
+def _ld_like(t, ld):
+    """a [M, N] tensor with leading dimension `ld` (the cross kernels want x0 / x / prod / gradients on one pitch)"""
+    if t.stride(1) == 1 and t.stride(0) == ld:
+        return t
+    buf = torch.zeros((t.shape[0], ld), dtype=torch.float32, device=t.device)
+    buf[:, :t.shape[1]].copy_(t)
+    return buf[:, :t.shape[1]]
 
 
 class _CrossFn(torch.autograd.Function):
@@ -183,6 +261,20 @@ def mlp(x: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequence[Optio
 
 def cross(x0, x, W, b, diag_scale=0.0):
     return _CrossFn.apply(x0, x, W, b, float(diag_scale))
+
+
+def cross_low_rank(x0, x, U, V, b, diag_scale=0.0):
+    x0 = ops._rowmajor_ld4(x0)
+    x = _ld_like(ops._rowmajor_ld4(x), x0.stride(0))
+    return _CrossLowRankFn.apply(x0, x, U, V, b, float(diag_scale))
+
+
+def dropout(x, rate, seed):
+    return _DropoutFn.apply(x, float(rate), int(seed))
+
+
+def l2_penalty(w, coeff):
+    return _L2Fn.apply(w, float(coeff))
 
 
 # --------------------------------------------------------------------------------------------------

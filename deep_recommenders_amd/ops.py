@@ -922,3 +922,48 @@ def din_concat_bwd(x, y, mode, d_out):
     check(lib().dr_din_concat_bwd(ptr(x), ptr(y), B, D, int(mode), ptr(d_out), d_out.stride(0), ptr(d_x), ptr(d_y), stream_ptr()),
           "dr_din_concat_bwd")
     return d_x, d_y
+
+
+# ---- element-wise pieces around the GEMM path (csrc/elementwise.hip) ------------------------------------------------------------
+def act_fwd_(x, act):
+    """in place: x = act(x) for act in {2: sigmoid, 3: tanh} (1 = relu also accepted); x [M, N] with unit column stride"""
+    assert x.dim() == 2 and x.stride(1) == 1
+    check(lib().dr_act_fwd(ptr(x), x.shape[0], x.shape[1], x.stride(0), int(act), stream_ptr()), "dr_act_fwd")
+    return x
+
+
+def act_bwd_(y, dy, act):
+    """in place: dy *= act'(.) expressed through the saved output y"""
+    assert y.shape == dy.shape and y.stride(1) == 1 and dy.stride(1) == 1
+    check(lib().dr_act_bwd(ptr(y), y.stride(0), ptr(dy), dy.stride(0), y.shape[0], y.shape[1], int(act), stream_ptr()), "dr_act_bwd")
+    return dy
+
+
+def dropout_fwd(x, rate, seed):
+    assert x.dim() == 2 and x.stride(1) == 1
+    M, N = x.shape
+    y = torch.empty((M, _pad4(N)), dtype=torch.float32, device=x.device)[:, :N]
+    mask = torch.empty(M * N, dtype=torch.uint8, device=x.device)
+    check(lib().dr_dropout_fwd(ptr(x), x.stride(0), M, N, float(rate), int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(y), y.stride(0), ptr(mask),
+                               stream_ptr()), "dr_dropout_fwd")
+    return y, mask
+
+
+def dropout_bwd(dy, mask, rate):
+    assert dy.dim() == 2 and dy.stride(1) == 1
+    M, N = dy.shape
+    dx = torch.empty((M, _pad4(N)), dtype=torch.float32, device=dy.device)[:, :N]
+    check(lib().dr_dropout_bwd(ptr(dy), dy.stride(0), ptr(mask), M, N, float(rate), ptr(dx), dx.stride(0), stream_ptr()),
+          "dr_dropout_bwd")
+    return dx
+
+
+def reduce_sum(x, squared=False, alpha=1.0, out=None, accumulate=False):
+    """out[0] (+)= alpha * sum(x) or alpha * sum(x^2) over a contiguous fp32 tensor (deterministic)."""
+    x = x if x.is_contiguous() else x.contiguous()
+    if out is None:
+        out = torch.zeros(1, dtype=torch.float32, device=x.device)
+    ws = torch.empty(1024, dtype=torch.float32, device=x.device)
+    check(lib().dr_reduce_sum(ptr(x), x.numel(), int(bool(squared)), float(alpha), int(bool(accumulate)), ptr(out), ptr(ws),
+                              stream_ptr()), "dr_reduce_sum")
+    return out

@@ -533,6 +533,27 @@ int dr_din_concat_fwd(const float* x, const float* y, int64_t B, int32_t D, int3
 int dr_din_concat_bwd(const float* x, const float* y, int64_t B, int32_t D, int32_t mode, const float* d_out,
                       int64_t ld_dout, float* d_x, float* d_y, dr_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Element-wise pieces around the GEMM path (deep_recommenders_amd/csrc/elementwise.hip):
+ * dr_act_fwd / _bwd   a Dense activation other than ReLU (keras/models/ranking/deepfm.py:30-34 `dnn_activation`,
+ *                     estimator/models/feature_interaction/dnn.py:9-14): act 1 relu, 2 sigmoid, 3 tanh, in place on the linear
+ *                     layer's output [M, N] (leading dimension ld); backward dy *= act'(y) through the saved output.
+ * dr_dropout_fwd/_bwd tf.nn.dropout(x, rate) of estimator/.../dnn.py:26-27 (always on there): keep iff hash(seed, index) >=
+ *                     rate * 2^32, kept elements * 1 / (1 - rate); mask [M * N] bytes saved for the backward.
+ * dr_reduce_sum       out[0] (+)= alpha * sum x (squared = 0) / alpha * sum x^2 (squared = 1: the L2 term of a Keras
+ *                     kernel_regularizer / bias_regularizer, dcn.py:27-30,39-45); fixed-order two-stage reduction;
+ *                     workspace: 1024 floats.
+ * ---------------------------------------------------------------------------------------- */
+int dr_act_fwd(float* x, int64_t M, int32_t N, int64_t ld, int32_t act, dr_stream_t stream);
+int dr_act_bwd(const float* y, int64_t ld_y, float* dy, int64_t ld_dy, int64_t M, int32_t N, int32_t act,
+               dr_stream_t stream);
+int dr_dropout_fwd(const float* x, int64_t ld_x, int64_t M, int32_t N, float rate, uint64_t seed, float* y,
+                   int64_t ld_y, uint8_t* mask, dr_stream_t stream);
+int dr_dropout_bwd(const float* dy, int64_t ld_dy, const uint8_t* mask, int64_t M, int32_t N, float rate, float* dx,
+                   int64_t ld_dx, dr_stream_t stream);
+int dr_reduce_sum(const float* x, int64_t n, int32_t squared, float alpha, int32_t accumulate, float* out,
+                  float* workspace, dr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
