@@ -79,6 +79,8 @@ def parse():
             a.batch = 8192
         if a.dim == 64:
             a.dim = 128
+        if a.lr == 0.01:
+            a.lr = 1e-5        # Retrieval's loss is a SUM over the batch (sbcnm.py:100-102): plain SGD at 0.01 diverges within a few steps
     if a.global_batch:
         world = int(os.environ.get("WORLD_SIZE", "1"))
         assert a.global_batch % world == 0, "--global-batch must divide by the number of GPUs"

@@ -528,8 +528,8 @@ __device__ __forceinline__ void rs_split8(const float4& lo, const float4& hi4, b
     p2 = __builtin_shufflevector(a2, b2, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-// EPI: 0 = bias / ReLU, 1 = + ReLU' mask and / or accumulate, 2 = DCN cross combine (one epilogue per instantiation: all three
-// unrolled over the 8 column tiles in one kernel cost 50 spilled registers)
+// EPI: 0 = bias / ReLU, 1 = + ReLU' mask, 3 = accumulate (C +=), 2 = DCN cross combine (one epilogue per instantiation: all of
+// them unrolled over the 8 column tiles in one kernel cost 50 spilled registers)
 template <int EPI, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void bf3_gemm_rs_kernel(RsArgs g) {
     constexpr int NW = 8, BM = 32 * NW, BN = 256, NT = BN / 32, NS = 3;
@@ -650,7 +650,8 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_rs_kernel(RsArgs g) {
     };
 
     bf16x8 fa[2][3];                                                    // [k-step][plane] of the CURRENT step
-    bf16x8 fb[2][3];                                                    // [buffer][plane]: group q uses buffer q & 1
+    bf16x8 fb[4][3];                                                    // [buffer][plane]: group q uses buffer q & 3; the
+                                                                        // reads run TWO groups (12 MFMAs) ahead of their use
     auto read_b = [&](int buf, int stage, int q) {                      // group q = (k-step q >> 3, column tile q & 7)
         const unsigned bb = b_addr[q >> 3] + stage * STAGE;
         const int nt = q & 7;
@@ -665,8 +666,9 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_rs_kernel(RsArgs g) {
         }
 #undef RS_READ3
     };
-    auto wait_b = [&](int buf) {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[buf][0]), "+v"(fb[buf][1]), "+v"(fb[buf][2]));
+    auto wait_b = [&](int buf, bool all) {   // group's fragments landed; `all`: every LDS read of this wave retired
+        if (all) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[buf][0]), "+v"(fb[buf][1]), "+v"(fb[buf][2]));
+        else asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fb[buf][0]), "+v"(fb[buf][1]), "+v"(fb[buf][2]));   // the next group's 3 may fly
     };
     f32x16 acc[NT];
     constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
@@ -684,6 +686,7 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_rs_kernel(RsArgs g) {
     __builtin_amdgcn_s_waitcnt(0x0F70 | 10);                            // vmcnt(10): step 0's pieces landed
     asm volatile("s_barrier" ::: "memory");
     read_b(0, 0, 0);
+    read_b(1, 0, 1);
 
     int tile = blockIdx.x, kt = 0, stage = 0;
 #pragma unroll
@@ -702,22 +705,25 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_rs_kernel(RsArgs g) {
         const int nstage = stage == NS - 1 ? 0 : stage + 1;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            wait_b(q & 1);
-            if (q < 15) {
-                read_b((q + 1) & 1, stage, q + 1);
-            } else {
-                // this wave is done reading stage `stage`; publish step + 1
+            if (q < 14) {
+                wait_b(q & 3, false);
+                read_b((q + 2) & 3, stage, q + 2);
+            } else if (q == 14) {
+                // groups 14 and 15 are in registers and this wave is done reading stage `stage`; publish step + 1
+                wait_b(2, true);
                 __builtin_amdgcn_s_waitcnt(0x0F70 | 10);               // vmcnt(10): all but this step's 4 A loads + 6 pieces
                 asm volatile("s_barrier" ::: "memory");
                 if (has_a) read_b(0, nstage, 0);
+            } else {
+                if (has_a) read_b(1, nstage, 1);
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (!(DBG & 2)) {
 #pragma unroll
                 for (int term = 0; term < 6; ++term)
-                    acc[q & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q >> 3][PA[term]], fb[q & 1][PB[term]], acc[q & 7], 0, 0, 0);
+                    acc[q & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q >> 3][PA[term]], fb[q & 3][PB[term]], acc[q & 7], 0, 0, 0);
             } else {
-                acc[q & 7][0] += (float)fa[q >> 3][0][0] + (float)fb[q & 1][0][0] + (float)fb[q & 1][1][0] + (float)fb[q & 1][2][0];
+                acc[q & 7][0] += (float)fa[q >> 3][0][0] + (float)fb[q & 3][0][0] + (float)fb[q & 3][1][0] + (float)fb[q & 3][2][0];
             }
             __builtin_amdgcn_sched_barrier(0);    // keeps the next group's lgkmcnt wait from being hoisted between these MFMAs
             if ((q & 1) == 1 && q < 2 * PW) {
@@ -767,23 +773,20 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_rs_kernel(RsArgs g) {
                                 crow[(int64_t)(e + 8 * c4) * g.ldc] = fmaf(x0v[e], pr, xv[e]);
                             }
                         }
-                    } else if constexpr (EPI == 1) {
+                    } else if constexpr (EPI == 1 || EPI == 3) {
 #pragma unroll
                         for (int c4 = 0; c4 < 4; ++c4) {
-                            float mk[4], old[4];
+                            float aux[4];                              // EPI 1: the mask values, EPI 3: the old outputs
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                mk[e] = g.mask != nullptr ? g.mask[(r0 + e + 8 * c4) * g.ld_mask + col] : 1.f;
-                                old[e] = g.accumulate ? crow[(int64_t)(e + 8 * c4) * g.ldc] : 0.f;
-                            }
+                            for (int e = 0; e < 4; ++e)
+                                aux[e] = EPI == 1 ? g.mask[(r0 + e + 8 * c4) * g.ld_mask + col] : crow[(int64_t)(e + 8 * c4) * g.ldc];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const int reg = 4 * c4 + e;
                                 float v = acc[nt][reg] + bj;
                                 acc[nt][reg] = 0.f;
                                 v = relu ? fmaxf(v, 0.f) : v;
-                                v = mk[e] > 0.f ? v : 0.f;
-                                crow[(int64_t)(e + 8 * c4) * g.ldc] = old[e] + v;
+                                crow[(int64_t)(e + 8 * c4) * g.ldc] = EPI == 1 ? (aux[e] > 0.f ? v : 0.f) : aux[e] + v;
                             }
                         }
                     } else {
@@ -811,8 +814,10 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_rs_kernel(RsArgs g) {
                         }
                         v = relu ? fmaxf(v, 0.f) : v;
                         if constexpr (EPI == 1) {
-                            if (g.mask != nullptr && !(g.mask[row * g.ld_mask + col] > 0.f)) v = 0.f;
-                            *dst = g.accumulate ? *dst + v : v;
+                            if (!(g.mask[row * g.ld_mask + col] > 0.f)) v = 0.f;
+                            *dst = v;
+                        } else if constexpr (EPI == 3) {
+                            *dst = *dst + v;
                         } else {
                             *dst = v;
                         }
@@ -913,7 +918,7 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_tn_rs_kernel(TnRsArgs g) {
         }
     };
     bf16x8 fa[2][3];
-    bf16x8 fb[2][3];
+    bf16x8 fb[4][3];                                                    // group q uses buffer q & 3, read two groups ahead
     float cs = 0.f;
     auto stage_b = [&](int stage) {                                     // yb -> three planes of this lane's column
 #pragma unroll
@@ -942,8 +947,9 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_tn_rs_kernel(TnRsArgs g) {
         }
 #undef RS_READ3
     };
-    auto wait_b = [&](int buf) {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[buf][0]), "+v"(fb[buf][1]), "+v"(fb[buf][2]));
+    auto wait_b = [&](int buf, bool all) {
+        if (all) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[buf][0]), "+v"(fb[buf][1]), "+v"(fb[buf][2]));
+        else asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fb[buf][0]), "+v"(fb[buf][1]), "+v"(fb[buf][2]));
     };
     f32x16 acc[NT];
 #pragma unroll
@@ -959,6 +965,7 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_tn_rs_kernel(TnRsArgs g) {
     load_raw(yb, g.Y, g.ldy, yoff, r_begin + BK);                       // (all zeros when nk == 1)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     read_b(0, 0, 0);
+    read_b(1, 0, 1);
 
     for (int kt = 0; kt < nk; ++kt) {
         const int stage = kt & 1;
@@ -980,19 +987,22 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_tn_rs_kernel(TnRsArgs g) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            wait_b(q & 1);
-            if (q < 15) {
-                read_b((q + 1) & 1, stage, q + 1);
-            } else {
-                // done reading this stage, and this wave's ds_writes of the next one have retired (lgkmcnt(0) above covers
-                // both): publish
+            if (q < 14) {
+                wait_b(q & 3, false);
+                read_b((q + 2) & 3, stage, q + 2);
+            } else if (q == 14) {
+                // groups 14 and 15 are in registers, this wave is done reading this stage and its ds_writes of the next one
+                // have retired (lgkmcnt(0) covers both): publish
+                wait_b(2, true);
                 asm volatile("s_barrier" ::: "memory");
                 if (kt + 1 < nk) read_b(0, stage ^ 1, 0);
+            } else {
+                if (kt + 1 < nk) read_b(1, stage ^ 1, 1);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int term = 0; term < 6; ++term)
-                acc[q & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q >> 3][PA[term]], fb[q & 1][PB[term]], acc[q & 7], 0, 0, 0);
+                acc[q & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q >> 3][PA[term]], fb[q & 3][PB[term]], acc[q & 7], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -1310,7 +1320,9 @@ int rs_launch(const RsArgs& g, hipStream_t stream) {
     if (tiles > 0x7fffffff) return DR_EINVAL;
     const int grid = (int)(tiles < 256 ? tiles : 256);                  // persistent: one block per CU
     if (g.x0 != nullptr) hipLaunchKernelGGL((bf3_gemm_rs_kernel<2>), dim3(grid), dim3(512), 0, stream, g);
-    else if (g.mask != nullptr || g.accumulate) hipLaunchKernelGGL((bf3_gemm_rs_kernel<1>), dim3(grid), dim3(512), 0, stream, g);
+    else if (g.mask != nullptr && g.accumulate) return DR_EINVAL;       // (no caller needs both)
+    else if (g.mask != nullptr) hipLaunchKernelGGL((bf3_gemm_rs_kernel<1>), dim3(grid), dim3(512), 0, stream, g);
+    else if (g.accumulate) hipLaunchKernelGGL((bf3_gemm_rs_kernel<3>), dim3(grid), dim3(512), 0, stream, g);
     else hipLaunchKernelGGL((bf3_gemm_rs_kernel<0>), dim3(grid), dim3(512), 0, stream, g);
     DR_CHECK_LAUNCH();
     return DR_OK;

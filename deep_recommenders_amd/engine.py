@@ -131,6 +131,11 @@ class DeepFMEngine:
         # what remains here is the best measured schedule plus DR_SORT_INLINE=1 (sort on the training stream, for profiling).
         self.sorted_bwd = sorted_bwd
         self.sort_inline = _os.environ.get("DR_SORT_INLINE", "0") == "1"
+        # Where the side-stream sort starts.  Round 1: after K3, hidden under the in-kernel-split GEMMs (2 blocks / CU left room for
+        # it).  The register-split GEMMs are persistent 512-thread blocks that own their CU (144 KB of LDS, all registers): the
+        # sort only advances in the gaps between them (1.1 ms instead of 0.17) and K4 ends up waiting for it.  Started with K3 it
+        # shares HBM with the gather instead (round 1 measured +46 us on K3).  DR_SORT_WITH_K3=0 / 1 selects.
+        self.sort_with_k3 = _os.environ.get("DR_SORT_WITH_K3", "1") == "1"
         if sorted_bwd:
             self.plan = ops.SortPlan(B * F, device)
             self.side = torch.cuda.Stream(device=device)
@@ -213,12 +218,14 @@ class DeepFMEngine:
             self._k("emb_sort_slots", "hbm", B * F * 36,
                     lambda: ops.emb_sort_slots(self.ids, self.row_base, self.R, self.plan))
             self.ev_sorted.record()
+        if self.sorted_bwd and not self.sort_inline and self.sort_with_k3:
+            self._launch_sort()              # next to K3 (both HBM-bound, small blocks: they do share the machine)
         self._k("emb_pool_fwd", "hbm", self.alg_bytes_fwd(),                                          # K3+K5+K6
                 lambda: ops.emb_pool_fwd(self.ids, F, None, self.row_base, self.table, self.lin_w, self.lin_bias,
                                          ld_concat=self.ld, concat=self.concat, sum_x=self.sum_x,
                                          fm_logit=self.fm_logit))
-        if self.sorted_bwd and not self.sort_inline:
-            self._launch_sort()              # after K3: shares the machine with the MFMA-bound first GEMM, not with the gather
+        if self.sorted_bwd and not self.sort_inline and not self.sort_with_k3:
+            self._launch_sort()              # after K3: under the first GEMM and the tower tail
         if self.Nd:
             self.concat[:, F * D:F * D + self.Nd].copy_(dense)                         # layout: append dense feats
         x = self.concat[:, :self.in_dim]
