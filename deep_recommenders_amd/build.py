@@ -14,6 +14,8 @@ LIBDIR = os.path.join(HERE, "lib")
 SO = os.path.join(LIBDIR, "libdr_hotpath.so")
 HOST_SRC = os.path.join(HERE, "csrc_host")
 HOST_SO = os.path.join(LIBDIR, "libdr_input.so")          # host-side input boundary (include/dr_input.h), plain g++
+COLL_SRC = os.path.join(HERE, "csrc_coll")
+COLL_SO = os.path.join(LIBDIR, "libdr_collectives.so")    # exchange steps over RCCL (include/dr_collectives.h), host C++
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
          "-Wno-unused-function", "-Wno-unused-result"]
 
@@ -52,7 +54,22 @@ def build(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd)
     build_host(force=force, verbose=verbose)
+    build_collectives(force=force, verbose=verbose)
     return SO
+
+
+def build_collectives(force=False, verbose=False):
+    """libdr_collectives.so: the C-ABI exchange steps over RCCL (host code only; linked against ROCm's librccl)."""
+    srcs = sorted(glob.glob(os.path.join(COLL_SRC, "*.cpp")))
+    headers = glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    if force or _stale(COLL_SO, srcs + headers):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        cmd = [hipcc, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I/opt/rocm/include"] + srcs + \
+              ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib", "-o", COLL_SO]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return COLL_SO
 
 
 def build_host(force=False, verbose=False):

@@ -57,3 +57,17 @@ def test_product_never_imports_oracle():
             if fn.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dp, fn)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, fn
+
+
+def test_collectives_library_exports_every_declared_symbol():
+    """include/dr_collectives.h (the exchange steps over RCCL, SURVEY section 8b's proposal): builds, loads, exports what it declares."""
+    from deep_recommenders_amd import build, _coll_lib
+    so = build.build_collectives()
+    src = open(os.path.join(ROOT, "include", "dr_collectives.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b(dr_coll_[a-z0-9_]+)\s*\(", src)))
+    assert len(names) >= 9 and sorted(_coll_lib.SIGNATURES) == names
+    L = ctypes.CDLL(so)
+    for n in names:
+        assert hasattr(L, n), "libdr_collectives.so does not export %s" % n
+    assert _coll_lib.lib().dr_coll_world(None) == 0 and _coll_lib.lib().dr_coll_rank(None) == -1

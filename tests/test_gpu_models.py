@@ -740,3 +740,35 @@ def test_surface_gaps_activations_dropout_regularizers_low_rank_cross():
     # --- the plain sum used for the first-order bias gradient
     v = torch.randn(100000, device="cuda", generator=g)
     assert float(ops.reduce_sum(v)) == pytest.approx(float(v.double().sum()), abs=1e-2)
+
+
+def test_cabi_collectives_single_rank_roundtrip():
+    """include/dr_collectives.h on one GPU: a communicator of one rank (what one process of N would create), the fixed and the
+    variable all-to-all (to itself), all-reduce and all-gather deliver the right bytes on the caller's stream."""
+    import ctypes
+    from deep_recommenders_amd import _coll_lib as C
+    L = C.lib()
+    idb = ctypes.create_string_buffer(C.ID_BYTES)
+    C.check(L.dr_coll_unique_id(idb), "dr_coll_unique_id")
+    comm = ctypes.c_void_p()
+    C.check(L.dr_coll_init(ctypes.byref(comm), 1, 0, idb), "dr_coll_init")
+    try:
+        assert L.dr_coll_world(comm) == 1 and L.dr_coll_rank(comm) == 0
+        st = torch.cuda.current_stream().cuda_stream
+        a = torch.arange(7, dtype=torch.int64, device="cuda")
+        b = torch.zeros_like(a)
+        C.check(L.dr_coll_alltoall_i64(comm, a.data_ptr(), b.data_ptr(), 7, st), "dr_coll_alltoall_i64")
+        rows = torch.randn((5, 16), device="cuda")
+        got = torch.zeros_like(rows)
+        cnt = (ctypes.c_int64 * 1)(5)
+        C.check(L.dr_coll_alltoallv(comm, rows.data_ptr(), cnt, got.data_ptr(), cnt, 64, st), "dr_coll_alltoallv")
+        g = torch.randn(1000, device="cuda")
+        g0 = g.clone()
+        C.check(L.dr_coll_allreduce_f32(comm, g.data_ptr(), g.numel(), st), "dr_coll_allreduce_f32")
+        ag = torch.zeros_like(rows)
+        C.check(L.dr_coll_allgather(comm, rows.data_ptr(), ag.data_ptr(), rows.numel() * 4, st), "dr_coll_allgather")
+        torch.cuda.synchronize()
+        assert torch.equal(b, a) and torch.equal(got, rows) and torch.equal(g, g0) and torch.equal(ag, rows)
+        assert L.dr_coll_alltoallv(comm, rows.data_ptr(), cnt, got.data_ptr(), cnt, 0, st) == -1      # DRC_EINVAL
+    finally:
+        C.check(L.dr_coll_destroy(comm), "dr_coll_destroy")
