@@ -360,7 +360,7 @@ def main():
         else:
             # the wide-tile GEMMs run on the bf16 pipe in the default mode (6 products per fp32 product); the narrow-tile
             # and fused-tail kernels always use the fp32 MFMA
-            on_bf16 = a.gemm == "bf16x3" and re.match(r"^(linear|cross|[qc]_tower)_(fwd|bwd_dx|bwd_dw)_L\d+$", name) is not None
+            on_bf16 = a.gemm == "bf16x3" and re.match(r"^(linear|emb_linear|cross|[qc]_tower)_(fwd|bwd_dx|bwd_dw)_L\d+$", name) is not None
             ach, peak, unit = k["alg_flops"] / sec / 1e12, (MFMA_BF16X3_PEAK_TF if on_bf16 else MFMA_F32_PEAK_TF), "TFLOP/s"
         row = {"kernel": name, "bound": k["bound"], "achieved": round(ach, 2), "peak": round(peak, 1), "unit": unit,
                "frac": round(ach / peak, 4), "traffic": traffic.get(name), "avg_us": round(k["ms"] * 1e3, 2),
@@ -369,6 +369,10 @@ def main():
             row["peak_basis"] = ("dense bf16 MFMA peak 2500 TFLOP/s / 6 products per fp32 product" if on_bf16
                                  else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)")
             row["frac_of_f32_mfma_peak"] = round(ach / MFMA_F32_PEAK_TF, 4)
+        if name == "emb_linear_fwd_L0":      # K3 fused into the first layer's GEMM: priced on the MFMA side, its HBM side stated too
+            alg = eng.alg_bytes_fwd() + 4.0 * a.batch * int(dnn_units[0]) if hasattr(eng, "alg_bytes_fwd") else None
+            row["note"] = ("K3 (gather + concat + first-order + FM) runs inside this GEMM: besides the flops it moves K3's algorithmic "
+                           "bytes + the layer output%s" % (" = %.0f MB -> %.0f GB/s, %.3f of the HBM peak" % (alg / 1e6, alg / sec / 1e9, alg / sec / 1e9 / HBM_PEAK_GBS) if alg else ""))
         if k.get("note"):
             row["note"] = k["note"]
         if k.get("concurrent_with"):

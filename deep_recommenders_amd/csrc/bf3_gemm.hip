@@ -834,6 +834,400 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_rs_kernel(RsArgs g) {
 }
 
 // =====================================================================================================================
+// Fused first layer of the DeepFM / DCN tower:  hash ids -> [gather + stack/concat + first-order + FM second-order] -> Dense.
+// The register-split GEMM (bf3_gemm_rs_kernel's tile: 256 x 256 x 32, 8 waves x 32 rows, weights pre-split in an LDS ring) whose
+// activation operand is GATHERED: k-tile kt of example b is dims 32 (kt & 1) .. + 31 of table row row_base[f] + ids[b][f],
+// f = kt >> 1 (D == 64) -- the same 128-byte lines K3 (dr_emb_pool_fwd) reads -- so the kernel that multiplies the concatenated
+// embeddings by the first Dense kernel is also the one that fetches them.  On their way through the CU the values are (1) stored
+// to `concat` (the backward kernels read it) and (2) summed into the FM terms K3 produced (sum_x, sum of squares, first-order
+// weights): keras/models/ranking/fm.py:23-37 and deepfm.py:36-47 of the reference in ONE launch with deepfm.py:30-34's first
+// Dense.  K3's 0.9 GB of HBM traffic moves in the shadow of an MFMA-bound kernel instead of in a 220 us kernel of its own.
+//
+// How the rows travel (what the first two versions of this kernel taught):
+//   * A load in which every lane addresses its own row costs the CU's address path one request per LANE: 256 per wave and
+//     k-tile for the row loads, as many again for the concat stores.  With ids and first-order weights on top the REQUEST rate
+//     -- not HBM, not the matrix pipe -- set the pace: 437 us (273 for the plain GEMM + 218 for K3 = 491), and 488 us with an
+//     L2 prefetch added (+128 requests per wave and k-tile => +0.9 us per k-tile).
+//   * So the rows are fetched by LDS-DMA, 8 lanes x 16 bytes per 128-byte line (8 requests per instruction, 32 per wave and
+//     k-tile), two k-tiles ahead, into a wave-private 2 x 4 KB LDS image -- no destination VGPRs, which is what allows the
+//     two-step lead.  Each field is addressed as a STRUCTURED buffer (base = its first row, index = bucket id, stride 256 B;
+//     buffer offsets are 32 bits wide, so a field may have 2^24 rows).  The image is XOR-swizzled by the choice of which (row, chunk) each DMA lane fetches, so that
+//     both readers are conflict-free: the MFMA-operand read (lane = row, 4 x ds_read_b128) and the position-wise read that
+//     feeds the COALESCED concat stores (8 lanes per 128-byte line again).
+//   * LDS: 2 x 48 KB weight stages + 2 x 32 KB activation stages = all 160 KB.  The weight pieces of k-tile s + 1 are issued first
+//     in step s, the gather of s + 2 and the id / weight loads after them, so the one counted wait per step (vmcnt(10) in front
+//     of the barrier) covers exactly the pieces and leaves the younger gather in flight.
+// Single-valued fields, D == 64, at most 32 dense features (one more k-tile, read from `dense_pad` [M, 32], zero-padded; the
+// caller also places them in concat[:, 64 F : K) for the backward).  Any N works: only the first column tile of a row panel
+// stores the side outputs.
+// =====================================================================================================================
+struct EmbArgs {
+    const int64_t* ids; int32_t F;               // [M, F] bucket ids (-1 = missing -> zero embedding, no first-order term)
+    const int64_t* row_base;                     // [F] first row of each field in the slab
+    const float* table;                          // [R, 64]
+    const float* lin_w; const float* lin_bias;   // first-order weights [R] / bias [1] (may be null)
+    const float* dense_pad;                      // [M, 32] dense features, zero-padded (null when K == 64 F)
+    float* concat; int64_t ld_concat;            // out: [M, ld], columns [0, 64 F)
+    float* sum_x; float* fm_logit;               // out: [M, 64], [M]
+};
+
+__device__ __forceinline__ int sload_i32(const void* base, int byte_off) {      // scalar load of a wave-uniform word, on the spot
+    int v;
+    asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(base), "s"(byte_off) : "memory");
+    return v;
+}
+
+__global__ __launch_bounds__(512, 2) void bf3_emb_linear_kernel(RsArgs g, EmbArgs e) {
+    constexpr int NW = 8, BM = 32 * NW, BN = 256, NT = BN / 32, NS = 2;
+    constexpr int B_PLANE = BN * 64;                                    // bytes: 256 rows x 64-byte rows (32 bf16)
+    constexpr int STAGE = 3 * B_PLANE;                                  // 48 KB
+    constexpr int PW = STAGE / 1024 / NW;                               // 6 LDS-DMA pieces per wave and k-tile
+    constexpr int A_WAVE = 32 * 128, A_STAGE = NW * A_WAVE;             // 4 KB per wave, 32 KB per stage
+    constexpr int A_BASE = NS * STAGE;
+    static_assert(PW == 6, "piece schedule below assumes 6 pieces per wave and k-tile");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE + 2 * A_STAGE];
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int grow = lane >> 3;                                         // gather layout: DMA i of this lane fetches row 8 i + grow,
+    const int gchunk = (lane & 7) ^ grow;                               // 16-byte chunk gchunk (image slot lane & 7: XOR swizzle)
+
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int tiles_m = (int)((g.M + BM - 1) / BM);
+    const int ntiles = tiles_m * tiles_n;
+    const int nk = (g.K + BK - 1) / BK;
+    const int nke = 2 * e.F;                                            // gathered k-tiles (nk == nke or nke + 1)
+    if ((int)blockIdx.x >= ntiles) return;
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total = my_tiles * nk;                                    // steps of this block
+
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+    const int sw = (l31 >> 2) & 3;
+    unsigned b_addr[2];                                                 // B fragment reads: row 32 nt + l31, chunk 2 hi + s swizzled
+#pragma unroll
+    for (int s = 0; s < 2; ++s) b_addr[s] = lds0 + l31 * 64 + (((2 * hi + s) ^ sw) << 4);
+    // A image of this wave: position p = 8 row + (chunk ^ (row & 7)), 16 bytes each
+    const unsigned a_rd = lds0 + A_BASE + wave * A_WAVE + l31 * 128 + (((4 * hi) ^ (l31 & 7)) << 4);    // own row, chunk 4 hi (^ c << 4)
+    const unsigned a_st = lds0 + A_BASE + wave * A_WAVE + lane * 16;                                    // position 64 i + lane
+
+    const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16*>(g.B), 0, (int)min((int64_t)0x7fffffff, 3 * g.b_ps * 2), 0x00020000);
+    // (the table resource is built per FIELD, base = its first row: a buffer offset -- index x stride included -- is 32 bits
+    // wide, so one resource reaches 4 GB = 2^24 rows; a resource over the whole 66 GB slab wraps, measured)
+    const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(e.dense_pad != nullptr ? e.dense_pad : e.table), 128, 0x7fffffff, 0x00020000);
+    const int b_lane = (int)((((int64_t)(wave * 16 + (lane >> 2))) * g.b_ld + ((lane & 3) ^ ((((wave * 16 + (lane >> 2))) >> 2) & 3)) * 8) * 2);
+
+    // ---- the block's stream of steps (tile, k-tile): iterators for steps s + 1, s + 2, s + 3 ---------------------------------
+    auto m0_of = [&](int tile) -> int { return (xcd_remap(tile, ntiles) / tiles_n) * BM; };
+    auto n0_of = [&](int tile) -> int { return (xcd_remap(tile, ntiles) % tiles_n) * BN; };
+    int kt1, tile1, m01, kt2, tile2, m02, kt3, tile3, m03;
+    auto advance = [&](int& kt, int& tile, int& m0) {                   // past the end of the stream: stay on the last step
+        if (kt + 1 < nk) { ++kt; return; }
+        if (tile + (int)gridDim.x < ntiles) { tile += gridDim.x; kt = 0; m0 = m0_of(tile); }
+    };
+    auto grow_row = [&](int m0, int i) -> int { return min(m0 + wave * 32 + 8 * i + grow, (int)g.M - 1); };
+    auto own_row = [&](int m0) -> int { return min(m0 + wave * 32 + l31, (int)g.M - 1); };
+    const int* ids32 = reinterpret_cast<const int*>(e.ids);             // low words: bucket ids fit 31 bits, -1 stays negative
+    int idg[4], ido = 0;                                                // ids in flight: gather layout (step s + 3), own row (step s + 2)
+    auto load_idg = [&](int kt, int m0) {
+        const int f = min(kt >> 1, e.F - 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) idg[i] = ids32[2 * ((int64_t)grow_row(m0, i) * e.F + f)];
+    };
+    auto load_ido = [&](int kt, int m0) { ido = ids32[2 * ((int64_t)own_row(m0) * e.F + min(kt >> 1, e.F - 1))]; };
+    int rb_next = 0;                                                    // row_base of step s + 1's field (step s + 2's when loaded)
+    int m4q = 0;                                                        // missing bits of the gathers in flight: step s low nibble, s + 1 next
+    bool mo_cur = false, mo_nxt = false;                                // own row missing: step s / s + 1
+    float lwn = 0.f;                                                    // own row's first-order weight of the next step
+    // gather of step (kt, m0) into A stage `ast` from the ids in idg; returns the 4 missing bits
+    auto issue_gather = [&](int kt, int m0, int rb, int ast) -> int {
+        const bool dense = kt >= nke;                                   // (wave-uniform)
+        const __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(e.table + (int64_t)rb * 64), 256, 0x7fffffff, 0x00020000);
+        int m4 = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool miss = !dense && idg[i] < 0;
+            m4 |= (miss ? 1 : 0) << i;
+            const int idx = dense ? grow_row(m0, i) : max(idg[i], 0);
+            unsigned char* dst = smem + A_BASE + ast * A_STAGE + wave * A_WAVE + i * 1024;
+            // (one DMA with a selected resource, not one under each arm of a branch: with the branch hipcc's wait for anything
+            // older than these DMAs comes out as vmcnt(0))
+            __builtin_amdgcn_struct_ptr_buffer_load_lds(dense ? drsrc : trsrc, (lds_ptr_t)dst, 16, idx,
+                                                        gchunk * 16 + (dense ? 0 : (kt & 1) * 128), 0, 0, 0);
+        }
+        return m4;
+    };
+    // (without first-order weights the load still happens, from the table: every step issues the same number of VMEM operations,
+    // which is what makes the counted wait in front of the barrier a constant)
+    const bool has_lw = e.lin_w != nullptr;
+    const float* const lwp = has_lw ? e.lin_w : e.table;
+    auto issue_lw = [&](int kt, int rb) {                               // own row of step (kt, .): first-order weight, missing flag
+        const bool dense = kt >= nke;
+        mo_nxt = !dense && ido < 0;
+        lwn = lwp[dense ? 0 : rb + max(ido, 0)];
+    };
+    auto issue_b = [&](int i, int kt, int n0, int stage) {              // piece wave + 8 i of step (kt, tile with column base n0)
+        unsigned char* dst = smem + stage * STAGE + (wave + NW * i) * 1024;
+        const int uni = (int)(((int64_t)(i >> 1) * g.b_ps + ((int64_t)(i & 1) * 128 + n0) * g.b_ld) * 2) + kt * (BK * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(brsrc, (lds_ptr_t)dst, 16, b_lane, uni, 0, 0);
+    };
+
+    float S0[16], S1[16], ssq = 0.f, lin = 0.f;                         // FM terms of the lane's row (its 16 dims of each half row)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { S0[j] = 0.f; S1[j] = 0.f; }
+    bf16x8 fa[2][3];                                                    // [k-step][plane] of the CURRENT step
+    bf16x8 fb[2][3];                                                    // [buffer][plane]: group q uses buffer q & 1 (one group ahead)
+    auto read_b = [&](int buf, int stage, int q) {                      // group q = (k-step q >> 3, column tile q & 7)
+        const unsigned bb = b_addr[q >> 3] + stage * STAGE;
+        const int nt = q & 7;
+#define RS_READ3(NTI)                                                        \
+        BF3_DS_READ_B128(fb[buf][0], bb, 0 * B_PLANE + NTI * 2048);          \
+        BF3_DS_READ_B128(fb[buf][1], bb, 1 * B_PLANE + NTI * 2048);          \
+        BF3_DS_READ_B128(fb[buf][2], bb, 2 * B_PLANE + NTI * 2048);
+        switch (nt) {
+            case 0: RS_READ3(0) break; case 1: RS_READ3(1) break; case 2: RS_READ3(2) break; case 3: RS_READ3(3) break;
+            case 4: RS_READ3(4) break; case 5: RS_READ3(5) break; case 6: RS_READ3(6) break; default: RS_READ3(7) break;
+        }
+#undef RS_READ3
+    };
+    auto wait_b = [&](int buf) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[buf][0]), "+v"(fb[buf][1]), "+v"(fb[buf][2]));
+    };
+    f32x16 acc[NT];
+    constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
+
+    // ---- prologue: pieces of step 0, gathers of steps 0 and 1, ids of step 2 in flight --------------------------------------
+    int kt = 0, tile = blockIdx.x, m0c = m0_of(tile);                   // consumer: step s
+    kt1 = 0; tile1 = tile; m01 = m0c;
+#pragma unroll
+    for (int i = 0; i < PW; ++i) issue_b(i, 0, n0_of(tile), 0);
+    {
+        int rb = sload_i32(e.row_base, 0);
+        load_idg(0, m0c);
+        load_ido(0, m0c);
+        m4q = issue_gather(0, m0c, rb, 0);
+        issue_lw(0, rb);
+        mo_cur = mo_nxt;
+        advance(kt1, tile1, m01);                                       // step 1
+        rb = sload_i32(e.row_base, 8 * min(kt1 >> 1, e.F - 1));
+        load_idg(kt1, m01);
+        m4q |= issue_gather(kt1, m01, rb, 1) << 4;
+        load_ido(kt1, m01);                                             // consumed by step 0's clump (own row of step 1)
+        rb_next = rb;
+        kt2 = kt1; tile2 = tile1; m02 = m01;
+        advance(kt2, tile2, m02);                                       // step 2
+        load_idg(kt2, m02);                                             // consumed by step 0's clump (gather of step 2)
+        kt3 = kt2; tile3 = tile2; m03 = m02;
+        advance(kt3, tile3, m03);                                       // step 3
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                 // everything landed (once per block)
+    asm volatile("s_barrier" ::: "memory");
+    read_b(0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+
+    int stage = 0;
+    for (int step = 0; step < total; ++step) {
+        const int astage = step & 1;
+        const bool gathered = kt < nke;                                 // (wave-uniform)
+        const bool c_fm = (xcd_remap(tile, ntiles) % tiles_n) == 0;     // the first column tile of a row panel owns concat / FM
+        // ---- step start: this step's rows out of the LDS image ----------------------------------------------------------------
+        f32x4 an[4];
+        {
+            const unsigned ra = a_rd + astage * A_STAGE;
+            const unsigned r1 = ra ^ 16u, r2 = ra ^ 32u, r3 = ra ^ 48u;
+            BF3_DS_READ_B128(an[0], ra, 0); BF3_DS_READ_B128(an[1], r1, 0);
+            BF3_DS_READ_B128(an[2], r2, 0); BF3_DS_READ_B128(an[3], r3, 0);
+        }
+        if (gathered && c_fm) {
+            // the image position-wise (8 lanes per 128-byte line) -> concat, for the backward kernels; missing ids store zeros
+            const unsigned sa = a_st + astage * A_STAGE;
+            f32x4 st[4];
+            BF3_DS_READ_B128(st[0], sa, 0); BF3_DS_READ_B128(st[1], sa, 1024);
+            BF3_DS_READ_B128(st[2], sa, 2048); BF3_DS_READ_B128(st[3], sa, 3072);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(st[0]), "+v"(st[1]), "+v"(st[2]), "+v"(st[3]));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = m0c + wave * 32 + 8 * i + grow;
+                if (row < g.M) {
+                    float* dst = e.concat + (int64_t)row * e.ld_concat + kt * BK + 4 * gchunk;
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    const f32x4 v = ((m4q >> i) & 1) ? z : st[i];
+                    // inline asm on purpose: stores the compiler can see make it treat vmcnt as unordered (loads + stores
+                    // pending) and wait vmcnt(0) for everything in flight
+                    // (s_nop: a VALU write to the data registers of a > 64-bit store needs a wait state after the store; the
+                    // hazard recogniser does not look inside inline asm, and the next instruction did reuse v.x)
+                    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(dst), "v"(v) : "memory");
+                }
+            }
+        }
+        // ("memory": the gather DMA that refills this A stage further down must not be moved above these reads)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(an[0]), "+v"(an[1]), "+v"(an[2]), "+v"(an[3]), "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2])
+                     :: "memory");
+        if (gathered && mo_cur) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            an[0] = z; an[1] = z; an[2] = z; an[3] = z;
+        }
+        if (gathered && c_fm) {
+            if ((kt & 1) == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { S0[4 * q] += an[q][0]; S0[4 * q + 1] += an[q][1]; S0[4 * q + 2] += an[q][2]; S0[4 * q + 3] += an[q][3]; }
+                lin += (hi == 0 && !mo_cur && has_lw) ? lwn : 0.f;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { S1[4 * q] += an[q][0]; S1[4 * q + 1] += an[q][1]; S1[4 * q + 2] += an[q][2]; S1[4 * q + 3] += an[q][3]; }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ssq += (an[q][0] * an[q][0] + an[q][1] * an[q][1]) + (an[q][2] * an[q][2] + an[q][3] * an[q][3]);
+        }
+        asm volatile("" : "+v"(lwn));                                   // the weight load is consumed on every path
+        {
+            const float4 a0 = make_float4(an[0][0], an[0][1], an[0][2], an[0][3]), a1 = make_float4(an[1][0], an[1][1], an[1][2], an[1][3]);
+            const float4 a2 = make_float4(an[2][0], an[2][1], an[2][2], an[2][3]), a3 = make_float4(an[3][0], an[3][1], an[3][2], an[3][3]);
+            rs_split8(a0, a1, fa[0][0], fa[0][1], fa[0][2]);
+            rs_split8(a2, a3, fa[1][0], fa[1][1], fa[1][2]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int nstage = stage ^ 1;
+        const int n01 = n0_of(tile1);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            wait_b(q & 1);
+            if (q < 15) {
+                read_b((q + 1) & 1, stage, q + 1);
+            } else {
+                // this wave is done reading the stages of step `step`; publish step + 1.  vmcnt(10): the 6 weight pieces of step + 1
+                // (and everything older: the gather of step + 1) have landed, the clump issued after them (5 id loads, the
+                // first-order weight, the 4 gather DMAs of step + 2) stays in flight
+                __builtin_amdgcn_s_waitcnt(0x0F70 | 10);
+                asm volatile("s_barrier" ::: "memory");
+                if (step + 1 < total) read_b(0, nstage, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int term = 0; term < 6; ++term)
+                acc[q & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q >> 3][PA[term]], fb[q & 1][PB[term]], acc[q & 7], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);    // keeps the next group's lgkmcnt wait from being hoisted between these MFMAs
+            if (q < PW) {
+                issue_b(q, kt1, n01, nstage);                           // weight pieces of step + 1 (a dummy re-fetch at the end of the stream)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (q == PW) {
+                // the clump: ids first (they are needed one step from now), then the weight, then the DMAs -- a wait for an
+                // older operation never forces a younger one
+                const int rb1 = rb_next;                                // field of step + 1
+                const int rb2 = sload_i32(e.row_base, 8 * min(kt2 >> 1, e.F - 1));
+                const int ido_use = ido;
+                int idg_use[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) idg_use[i] = idg[i];
+                load_idg(kt3, m03);                                     // gather layout, step + 3
+                load_ido(kt2, m02);                                     // own row, step + 2
+                {   // own row of step + 1
+                    const bool dense = kt1 >= nke;
+                    mo_nxt = !dense && ido_use < 0;
+                    lwn = lwp[dense ? 0 : rb1 + max(ido_use, 0)];
+                }
+                {   // gather of step + 2 into the A stage this step has just consumed
+                    const bool dense = kt2 >= nke;
+                    const __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<float*>(e.table + (int64_t)rb2 * 64), 256, 0x7fffffff, 0x00020000);
+                    int m4 = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const bool miss = !dense && idg_use[i] < 0;
+                        m4 |= (miss ? 1 : 0) << i;
+                        const int idx = dense ? grow_row(m02, i) : max(idg_use[i], 0);
+                        unsigned char* dst = smem + A_BASE + astage * A_STAGE + wave * A_WAVE + i * 1024;
+                        __builtin_amdgcn_struct_ptr_buffer_load_lds(dense ? drsrc : trsrc, (lds_ptr_t)dst, 16, idx,
+                                                                    gchunk * 16 + (dense ? 0 : (kt2 & 1) * 128), 0, 0, 0);
+                    }
+                    m4q = (m4q >> 4) | (m4 << 4);
+                }
+                rb_next = rb2;
+                kt1 = kt2; tile1 = tile2; m01 = m02;
+                kt2 = kt3; tile2 = tile3; m02 = m03;
+                advance(kt3, tile3, m03);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        mo_cur = mo_nxt;
+        stage = nstage;
+        if (++kt < nk) continue;
+        // ---- epilogue of an output tile: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+        kt = 0;
+        {
+            const int lid = xcd_remap(tile, ntiles);
+            const int64_t tm0 = (int64_t)(lid / tiles_n) * BM;
+            const int tn0 = (lid % tiles_n) * BN;
+            const bool relu = g.act == 1;
+            const int64_t r0 = tm0 + wave * 32 + 4 * hi;
+            // interior tiles: every load / store of the epilogue unconditional (a memory operation under a divergent branch makes
+            // hipcc wait vmcnt(0) in front of each one); edge tiles take the guarded loop
+            const bool interior = tm0 + BM <= g.M && tn0 + BN <= g.N;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int col = tn0 + nt * 32 + l31;
+                const bool cv = col < g.N;
+                float bj = g.bias != nullptr ? g.bias[cv ? col : g.N - 1] : 0.f;
+                asm volatile("" : "+v"(bj));      // consume the load on every path (see bf3_gemm_nt_pipe_kernel)
+                if (interior) {
+                    float* crow = g.C + r0 * g.ldc + col;
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        float v = acc[nt][reg] + bj;
+                        acc[nt][reg] = 0.f;
+                        crow[(int64_t)((reg & 3) + 8 * (reg >> 2)) * g.ldc] = relu ? fmaxf(v, 0.f) : v;
+                    }
+                } else {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int64_t row = r0 + (reg & 3) + 8 * (reg >> 2);
+                        float v = acc[nt][reg] + bj;
+                        acc[nt][reg] = 0.f;
+                        if (!cv || row >= g.M) continue;
+                        g.C[row * g.ldc + col] = relu ? fmaxf(v, 0.f) : v;
+                    }
+                }
+            }
+            if (c_fm) {
+                // this row panel's FM outputs (keras/models/ranking/fm.py:28-37): sum_x for the backward, the logit part
+                float t2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) t2 += S0[j] * S0[j] + S1[j] * S1[j];
+                t2 += __shfl_xor(t2, 32, 64);
+                const float ss_all = ssq + __shfl_xor(ssq, 32, 64);
+                const int64_t row = tm0 + wave * 32 + l31;
+                if (row < g.M) {
+                    float* sx = e.sum_x + row * 64 + 16 * hi;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        *reinterpret_cast<float4*>(sx + 4 * q) = make_float4(S0[4 * q], S0[4 * q + 1], S0[4 * q + 2], S0[4 * q + 3]);
+                        *reinterpret_cast<float4*>(sx + 32 + 4 * q) = make_float4(S1[4 * q], S1[4 * q + 1], S1[4 * q + 2], S1[4 * q + 3]);
+                    }
+                    if (hi == 0) e.fm_logit[row] = (e.lin_bias != nullptr ? e.lin_bias[0] : 0.f) + lin + 0.5f * (t2 - ss_all);
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { S0[j] = 0.f; S1[j] = 0.f; }
+                ssq = 0.f;
+                lin = 0.f;
+            }
+            // Stores and loads share vmcnt on gfx9 and hipcc treats a mix of the two as unordered: left pending into the next
+            // k-tile, the stores turn every wait of the loop into vmcnt(0).  Draining here costs one refill per output tile.
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
+        tile += gridDim.x;
+        if (tile < ntiles) m0c = m0_of(tile);
+    }
+}
+
+// =====================================================================================================================
 // TN, "register split" wgrad:  dst[f][n] += scale * sum_r X[r][f] Y[r][n],  dstb[n] += scale * sum_r Y[r][n]
 // Both operands are fp32 ACTIVATIONS, reduction-major (x [R, F] and dy [R, N] as their producers write them); nothing is
 // pre-split.  A block owns a 256 (f) x 256 (n) tile of one reduction slice; each of its 8 waves owns 32 f x all 256 n.
@@ -1502,6 +1896,36 @@ extern "C" int dr_bf3_wgrad(const float* x, int64_t ld_x, const float* dy, int64
     hipLaunchKernelGGL(bf3_gemm_tn_rs_kernel, dim3(grid), dim3(512), 0, dr_s(stream), g);
     hipLaunchKernelGGL(bf3_tn_rs_reduce_kernel, dim3(dr_grid_for((int64_t)F * N, 256)), dim3(256), 0, dr_s(stream), partial,
                        dstb != nullptr ? colsum : nullptr, split, F, N, Fp, Np, scale, dstW, ld_w, dstb);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+// Fused K3 + first Dense layer (see bf3_emb_linear_kernel): h[m][n] = act(sum_k x[m][k] W[k][n] + bias[n]) with
+// x = concat(field embeddings of ids[m], dense features = dense_pad[m, : K - 64 F]); also writes concat[:, : 64 F],
+// sum_x [M, 64] and fm_logit [M] = lin_bias + sum_f lin_w[row] + 0.5 sum_d ((sum_f x_fd)^2 - sum_f x_fd^2).
+extern "C" int dr_bf3_emb_linear_fwd(const int64_t* ids, int64_t M, int32_t F, const int64_t* row_base, int64_t field_rows_max,
+                                     const float* table, int32_t D, const float* lin_w, const float* lin_bias, const float* dense_pad, float* concat,
+                                     int64_t ld_concat, int32_t K, const void* wt_planes, int64_t plane_stride, int64_t ld_planes, int32_t N,
+                                     const float* bias, int32_t act, float* sum_x, float* fm_logit, float* out, int64_t ld_out,
+                                     dr_stream_t stream) {
+    if (M < 0 || M > 0x7fffff00 || F <= 0 || N <= 0 || K < 64 * F || act < 0 || act > 1) return DR_EINVAL;
+    // the k-tile <-> (field, half row) map is built for 64-wide rows; the dense features are one k-tile; a field is one 4 GB buffer
+    if (D != 64 || K > 64 * F + 32 || field_rows_max <= 0 || field_rows_max > (1 << 24)) return DR_ESHAPE;
+    if (M == 0) return DR_OK;
+    if (!ids || !row_base || !table || !concat || !sum_x || !fm_logit || !out || !planes_ok(wt_planes, plane_stride, ld_planes))
+        return DR_EINVAL;
+    if (K > 64 * F && (!dense_pad || (reinterpret_cast<uintptr_t>(dense_pad) & 15) != 0)) return DR_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(concat) & 15) != 0 || (ld_concat & 3) != 0 || ld_concat < K ||
+        (reinterpret_cast<uintptr_t>(table) & 15) != 0 || (reinterpret_cast<uintptr_t>(sum_x) & 15) != 0)
+        return DR_EINVAL;
+    if (ld_planes < (K + BK - 1) / BK * BK || ld_out < N) return DR_EINVAL;
+    RsArgs g{nullptr, 0, static_cast<const __bf16*>(wt_planes), plane_stride, ld_planes, M, N, K, out, ld_out, bias, act, nullptr, 0, 0,
+             nullptr, nullptr, 0, 0.f, nullptr};
+    EmbArgs e{ids, F, row_base, table, lin_w, lin_bias, K > 64 * F ? dense_pad : nullptr, concat, ld_concat, sum_x, fm_logit};
+    const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
+    if (tiles > 0x7fffffff) return DR_EINVAL;
+    const int grid = (int)(tiles < 256 ? tiles : 256);
+    hipLaunchKernelGGL(bf3_emb_linear_kernel, dim3(grid), dim3(512), 0, dr_s(stream), g, e);
     DR_CHECK_LAUNCH();
     return DR_OK;
 }

@@ -136,6 +136,11 @@ class DeepFMEngine:
         # sort only advances in the gaps between them (1.1 ms instead of 0.17) and K4 ends up waiting for it.  Started with K3 it
         # shares HBM with the gather instead (round 1 measured +46 us on K3).  DR_SORT_WITH_K3=0 / 1 selects.
         self.sort_with_k3 = _os.environ.get("DR_SORT_WITH_K3", "1") == "1"
+        # K3 fused into the first layer's GEMM (dr_bf3_emb_linear_fwd: the register-split kernel gathers its activation rows from
+        # the tables and produces concat / sum_x / fm_logit on the way).  Needs D == 64 and the planes path; DR_FUSE_K3=0: K3 as
+        # its own kernel.
+        self.fuse_k3 = _os.environ.get("DR_FUSE_K3", "1") == "1" and D == 64 and self.Nd <= 32 and V <= (1 << 24)
+        self.dense_pad = torch.zeros((B, 32), dtype=torch.float32, device=device) if (self.fuse_k3 and self.Nd) else None
         if sorted_bwd:
             self.plan = ops.SortPlan(B * F, device)
             self.side = torch.cuda.Stream(device=device)
@@ -220,21 +225,32 @@ class DeepFMEngine:
             self.ev_sorted.record()
         if self.sorted_bwd and not self.sort_inline and self.sort_with_k3:
             self._launch_sort()              # next to K3 (both HBM-bound, small blocks: they do share the machine)
-        self._k("emb_pool_fwd", "hbm", self.alg_bytes_fwd(),                                          # K3+K5+K6
-                lambda: ops.emb_pool_fwd(self.ids, F, None, self.row_base, self.table, self.lin_w, self.lin_bias,
-                                         ld_concat=self.ld, concat=self.concat, sum_x=self.sum_x,
-                                         fm_logit=self.fm_logit))
+        fused_l0 = self.fuse_k3 and self.wplanes[0] is not None
+        if not fused_l0:
+            self._k("emb_pool_fwd", "hbm", self.alg_bytes_fwd(),                                      # K3+K5+K6
+                    lambda: ops.emb_pool_fwd(self.ids, F, None, self.row_base, self.table, self.lin_w, self.lin_bias,
+                                             ld_concat=self.ld, concat=self.concat, sum_x=self.sum_x,
+                                             fm_logit=self.fm_logit))
         if self.sorted_bwd and not self.sort_inline and not self.sort_with_k3:
             self._launch_sort()              # after K3: under the first GEMM and the tower tail
         if self.Nd:
             self.concat[:, F * D:F * D + self.Nd].copy_(dense)                         # layout: append dense feats
+            if fused_l0:
+                self.dense_pad[:, :self.Nd].copy_(dense)                               # the fused kernel's own (k-tile wide) copy
         x = self.concat[:, :self.in_dim]
         head = self.fuse_head and labels is not None
         nl = len(self.Ws)
         for i, (W, b) in enumerate(zip(self.Ws, self.bs)):                             # K7
             if head and i == nl - 2:
                 break
-            if self.wplanes[i] is not None:
+            if i == 0 and fused_l0:
+                # K3 + first Dense in one launch: the GEMM gathers its activation operand from the tables, writes concat and the
+                # FM terms on the way (the dense features were placed in concat above)
+                self._k("emb_linear_fwd_L0", "mfma", 2.0 * B * W.shape[0] * W.shape[1],
+                        lambda b=b: ops.bf3_emb_linear_fwd(self.ids, self.row_base, self.V, self.table, self.lin_w, self.lin_bias, self.dense_pad, self.concat,
+                                                           self.in_dim, self.wplanes[0].wt, b, self.acts[0], self.sum_x, self.fm_logit,
+                                                           self.hs[0]))
+            elif self.wplanes[i] is not None:
                 self._k("linear_fwd_L%d" % i, "mfma", 2.0 * B * W.shape[0] * W.shape[1],
                         lambda x=x, b=b, i=i: ops.bf3_linear_nt(x, self.wplanes[i].wt, bias=b, act=self.acts[i], out=self.hs[i]))
             else:

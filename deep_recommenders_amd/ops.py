@@ -824,6 +824,23 @@ def bf3_cross_fwd(x0, x, wt: Planes, b=None, diag_scale=0.0, want_prod=False, pr
     return out, prod
 
 
+def bf3_emb_linear_fwd(ids, row_base, field_rows_max, table, lin_w, lin_bias, dense_pad, concat, K, wt: Planes, bias, act, sum_x, fm_logit, out):
+    """K3 + first Dense in one launch (dr_bf3_emb_linear_fwd): gathers the field embeddings of ids [M, F] from table [R, 64] as the
+    GEMM's activation operand, writes them to concat[:, :64 F], the FM terms to sum_x / fm_logit, and
+    out = act([embeddings, dense_pad[:, :K - 64 F]] @ W + bias).  dense_pad: [M, 32] zero-padded dense features (None iff
+    K == 64 F); field_rows_max: the longest field's row count.  Raises RuntimeError(DR_ESHAPE) for D != 64, more than 32 dense
+    features or a field of more than 2^24 rows."""
+    ids = _c(ids, torch.int64)
+    M, F = ids.shape
+    assert concat.stride(1) == 1 and out.stride(1) == 1 and wt.cols == K and out.shape == (M, wt.rows)
+    assert dense_pad is None or (dense_pad.shape == (M, 32) and dense_pad.is_contiguous())
+    check(lib().dr_bf3_emb_linear_fwd(ptr(ids), M, F, ptr(row_base), int(field_rows_max), ptr(table), table.shape[1], ptr(lin_w), ptr(lin_bias),
+                                      ptr(dense_pad), ptr(concat), concat.stride(0), int(K), ptr(wt.buf), wt.plane_stride, wt.ld,
+                                      wt.rows, ptr(bias), int(act), ptr(sum_x), ptr(fm_logit), ptr(out), out.stride(0), stream_ptr()),
+          "dr_bf3_emb_linear_fwd")
+    return out
+
+
 def bf3_wgrad_workspace(R, F, N, device):
     return torch.empty(max(64, lib().dr_bf3_wgrad_workspace_bytes(int(R), int(F), int(N)) // 4), dtype=torch.float32, device=device)
 

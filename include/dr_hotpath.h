@@ -499,6 +499,23 @@ int dr_bf3_cross_fwd(const float* x0, const float* x, int64_t ld, const void* wt
  * a wide layer on its fp32 activations as they are (x [R, F], dy [R, N] row-major): x goes from HBM straight into registers
  * (lane index along f), dy is split once per 256 x-columns into a two-stage LDS image; bf16x3 product mode; split over r into
  * `workspace` (dr_bf3_wgrad_workspace_bytes) with a fixed-order reduce: deterministic. */
+/* dr_bf3_emb_linear_fwd: K3 and the first Dense layer in ONE launch -- the register-split GEMM gathers its activation operand
+ * straight from the embedding tables: k-tile kt of example m is dims 32 (kt & 1) .. + 31 of row row_base[f] + ids[m, f], f = kt / 2
+ * (single-valued fields, D == 64, at most 32 dense features, no field longer than field_rows_max <= 2^24 rows -- the kernel
+ * addresses a field as one buffer with 32-bit offsets; anything else returns DR_ESHAPE and the caller uses dr_emb_pool_fwd +
+ * dr_bf3_linear_nt).
+ * Replaces, together: the F DenseFeatures lookups + tf.stack / tf.concat + the first-order Dense(1) + FM.call
+ * (keras/models/ranking/fm.py:23-37,47-64, deepfm.py:36-45) AND deepfm.py:30-34's first Dense(u, relu).
+ *   in : ids [M, F] (-1 = missing), table [R, 64] (R < 2^31), lin_w [R] / lin_bias [1] (may be NULL), dense_pad [M, 32] = the
+ *        K - 64 F dense features of every example, zero-padded to 32 (NULL iff K == 64 F), W^T planes [3][N][ld_planes]
+ *        (columns [K, roundup(K, 32)) zero), bias [N]
+ *   out: concat[:, 0 : 64 F) (for the backward kernels; the caller places the dense features in concat[:, 64 F : K) itself),
+ *        sum_x [M, 64], fm_logit [M] (as dr_emb_pool_fwd), out [M, N] = act(x W + bias), x = [embeddings, dense features]. */
+int dr_bf3_emb_linear_fwd(const int64_t* ids, int64_t M, int32_t F, const int64_t* row_base, int64_t field_rows_max,
+                          const float* table, int32_t D, const float* lin_w, const float* lin_bias, const float* dense_pad, float* concat,
+                          int64_t ld_concat, int32_t K, const void* wt_planes, int64_t plane_stride, int64_t ld_planes, int32_t N,
+                          const float* bias, int32_t act, float* sum_x, float* fm_logit, float* out, int64_t ld_out,
+                          dr_stream_t stream);
 int64_t dr_bf3_wgrad_workspace_bytes(int64_t R, int32_t F, int32_t N);
 int dr_bf3_wgrad(const float* x, int64_t ld_x, const float* dy, int64_t ld_dy, int64_t R, int32_t F, int32_t N,
                  float scale, float* dstW, int64_t ld_w, float* dstb, void* workspace, int64_t workspace_bytes,

@@ -790,6 +790,74 @@ def test_bf3_linear_nt_matches_fp64(M, K, N):
     assert torch.equal(ops.bf3_linear_nt(xp[:, :K], wp.wt, bias=b, act=1), y)
 
 
+@pytest.mark.parametrize("M,F,Nd,N", [(300, 3, 0, 40), (2085, 26, 13, 256), (4096, 7, 5, 300), (257, 1, 2, 64)])
+def test_bf3_emb_linear_fwd_equals_pool_then_linear(M, F, Nd, N):
+    """dr_bf3_emb_linear_fwd (K3 fused into the first Dense layer) == dr_emb_pool_fwd followed by dr_bf3_linear_nt:
+    concat's embedding part bit for bit (it is a copy of table rows; missing ids give zeros), sum_x / fm_logit within fp32
+    summation-order noise, and the layer output bit for bit (same splits, same k order, same accumulation as dr_bf3_linear_nt)."""
+    from deep_recommenders_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + F)
+    D, V = 64, 97
+    table = torch.randn((F * V, D), device="cuda", generator=g) * 0.3
+    lin_w = torch.randn((F * V,), device="cuda", generator=g)
+    lin_b = torch.tensor([0.37], device="cuda")
+    row_base = (torch.arange(F, device="cuda") * V).to(torch.int64)
+    ids = torch.randint(0, V, (M, F), device="cuda", generator=g)
+    ids[torch.rand((M, F), device="cuda", generator=g) < 0.05] = -1                     # missing values
+    K = F * D + Nd
+    ld = (K + 3) // 4 * 4
+    dense = torch.randn((M, Nd), device="cuda", generator=g)
+    W = torch.randn((K, N), device="cuda", generator=g) * 0.1
+    b = torch.randn((N,), device="cuda", generator=g)
+    wp = ops.WeightPlanes(W)
+    # the two-kernel path
+    concat0 = torch.zeros((M, ld), device="cuda")
+    sum0, fm0 = torch.empty((M, D), device="cuda"), torch.empty((M,), device="cuda")
+    ops.emb_pool_fwd(ids, F, None, row_base, table, lin_w, lin_b, ld_concat=ld, concat=concat0, sum_x=sum0, fm_logit=fm0)
+    concat0[:, F * D:K] = dense
+    y0 = ops.bf3_linear_nt(concat0[:, :K], wp.wt, bias=b, act=1)
+    # the fused kernel; its concat starts NaN-poisoned in the part it must write
+    concat1 = torch.zeros((M, ld), device="cuda")
+    concat1[:, :F * D] = float("nan")
+    concat1[:, F * D:K] = dense
+    sum1, fm1 = torch.full((M, D), float("nan"), device="cuda"), torch.full((M,), float("nan"), device="cuda")
+    y1 = torch.full((M, N), float("nan"), device="cuda")
+    dpad = None
+    if Nd:
+        dpad = torch.zeros((M, 32), device="cuda")
+        dpad[:, :Nd] = dense
+    ops.bf3_emb_linear_fwd(ids, row_base, V, table, lin_w, lin_b, dpad, concat1, K, wp.wt, b, 1, sum1, fm1, y1)
+    assert torch.equal(concat1, concat0)
+    assert torch.equal(y1, y0)
+    assert (sum1 - sum0).abs().max().item() <= 1e-5 * max(1.0, sum0.abs().max().item())
+    assert (fm1 - fm0).abs().max().item() <= 2e-5 * max(1.0, fm0.abs().max().item())
+    # D != 64 and fields of more than 2^24 rows are refused, the caller falls back to the two kernels
+    with pytest.raises(RuntimeError):
+        ops.bf3_emb_linear_fwd(ids, row_base, (1 << 24) + 1, table, lin_w, lin_b, dpad, concat1, K, wp.wt, b, 1, sum1, fm1, y1)
+    with pytest.raises(RuntimeError):
+        ops.bf3_emb_linear_fwd(ids, row_base, V, torch.zeros((F * V, 32), device="cuda"), lin_w, lin_b, dpad, concat1, K, wp.wt, b, 1, sum1, fm1, y1)
+
+
+def test_bf3_emb_linear_fwd_reaches_past_4gb():
+    """A slab larger than 4 GB: the fused kernel addresses every field through its own buffer resource (32-bit offsets), rows
+    whose byte offset in the slab is beyond 2^32 must come out right (a resource over the whole slab wraps there)."""
+    from deep_recommenders_amd import ops
+    R, F, M, N, K = 20_000_000, 2, 1024, 64, 128
+    table = torch.empty((R, 64), device="cuda")
+    table.copy_(torch.arange(R, device="cuda", dtype=torch.float32).view(-1, 1).expand(R, 64) * 1e-6)
+    row_base = torch.tensor([0, R // 2], device="cuda", dtype=torch.int64)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    ids = torch.randint(0, R // 2, (M, F), device="cuda", generator=g)
+    ids[:4, 1] = torch.tensor([R // 2 - 1, R // 2 - 2, 6777216, 6777215], device="cuda")      # slab rows around 2^24 and the last one
+    wp = ops.WeightPlanes(torch.randn((K, N), device="cuda", generator=g) * 0.1)
+    concat = torch.zeros((M, K), device="cuda")
+    sx, fm, y = torch.empty((M, 64), device="cuda"), torch.empty((M,), device="cuda"), torch.empty((M, N), device="cuda")
+    ops.bf3_emb_linear_fwd(ids, row_base, R // 2, table, None, None, None, concat, K, wp.wt, torch.zeros((N,), device="cuda"), 0, sx, fm, y)
+    want = torch.cat([table[ids[:, 0]], table[ids[:, 1] + R // 2]], dim=1)
+    assert torch.equal(concat, want)
+    assert torch.equal(y, ops.bf3_linear_nt(want, wp.wt, bias=torch.zeros((N,), device="cuda"), act=0))
+
+
 def test_bf3_cross_fwd_matches_cross_fwd_and_fp64():
     """DCN cross layer on pre-split weights == dr_cross_fwd's math (dcn.py:81-88), incl. the reference's known answer."""
     from deep_recommenders_amd import ops
