@@ -1,0 +1,27 @@
+#!/bin/bash
+# Everything the round's profiles/ needs, in one gpurun call: full GPU tests, rocprofv3 stats + PMC traffic of the default
+# bench command, the bench lines of every configuration.  Results land in gpurun_out/; copy them into profiles/ afterwards.
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $R
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -4 > gpurun_out/pytest_gpu.log
+cat gpurun_out/pytest_gpu.log
+bash tools/collect_profiles.sh
+cd $R
+timeout 400 python bench.py > gpurun_out/line_default.log 2>&1
+timeout 200 python bench.py --optimizer adam --no-cpu-baseline > gpurun_out/line_adam.log 2>&1
+timeout 200 python bench.py --ids zipf --no-cpu-baseline > gpurun_out/line_zipf.log 2>&1
+timeout 200 python bench.py --preset c2 --no-cpu-baseline > gpurun_out/line_c2.log 2>&1
+timeout 300 python bench.py --model dcn --no-cpu-baseline > gpurun_out/line_dcn.log 2>&1
+timeout 300 python bench.py --model dssm --no-cpu-baseline > gpurun_out/line_dssm.log 2>&1
+DR_FUSE_K3=0 timeout 200 python bench.py --no-cpu-baseline > gpurun_out/line_unfused.log 2>&1
+for f in default adam zipf c2 dcn dssm unfused; do
+  python - $f <<'PY'
+import json, sys
+try:
+    d = json.loads(open("gpurun_out/line_%s.log" % sys.argv[1]).read().strip().splitlines()[-1])
+    print(sys.argv[1], d["value"], d["ms_per_step"], d["roofline"]["kernel"], d["roofline"]["frac"], (d.get("cpu_baseline") or {}).get("value"))
+except Exception as e:
+    print(sys.argv[1], "FAILED", e)
+PY
+done
