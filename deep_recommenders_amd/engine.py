@@ -113,7 +113,12 @@ class DeepFMEngine:
         self.col_buckets = torch.full((F,), V if hashed else 0, dtype=torch.int64, device=device)
         # ---- activations / gradients (preallocated once) ---------------------------------------------
         f32 = dict(dtype=torch.float32, device=device)
-        self.ids = torch.empty((B, F), dtype=torch.int64, device=device)
+        # ids / slot plan are double-buffered: with next_keys handed to train_step, the NEXT batch's hash + slot sort run on the side
+        # stream beside this step's K4 (see _prefetch_next); `ids` / `plan` are the current buffers
+        self._ids = [torch.empty((B, F), dtype=torch.int64, device=device) for _ in range(2)]
+        self.cur = 0
+        self._pref = None            # identity of the keys whose ids / plan sit in buffer cur ^ 1
+        self._next_keys = None
         self.concat = torch.zeros((B, self.ld), **f32)
         self.sum_x = torch.empty((B, D), **f32)
         self.fm_logit = torch.empty((B,), **f32)
@@ -141,11 +146,18 @@ class DeepFMEngine:
         # its own kernel.
         self.fuse_k3 = _os.environ.get("DR_FUSE_K3", "1") == "1" and D == 64 and self.Nd <= 32 and V <= (1 << 24)
         self.dense_pad = torch.zeros((B, 32), dtype=torch.float32, device=device) if (self.fuse_k3 and self.Nd) else None
+        # The slot sort of batch s + 1 next to K4 of batch s (DR_PREFETCH_PLAN=0: every step hashes and sorts its own batch).  K4 is
+        # the one long kernel of the step that is HBM-bound with small blocks, i.e. that shares the machine; beside the persistent
+        # GEMMs (the fused first layer occupies all 160 KB of LDS on every CU) the sort chain's ~20 small launches only advance in
+        # the gaps: 1.2 ms instead of 0.17, and K4 waited 74 us for it (round 2, rocprofv3: K4 305 us, its event 379 us).
+        self.prefetch_plan = _os.environ.get("DR_PREFETCH_PLAN", "1") == "1"
         if sorted_bwd:
-            self.plan = ops.SortPlan(B * F, device)
+            self._plans = [ops.SortPlan(B * F, device) for _ in range(2)]
             self.side = torch.cuda.Stream(device=device)
             self.ev_ids = torch.cuda.Event()
-            self.ev_sorted = torch.cuda.Event()
+            self._ev_sorted = [torch.cuda.Event(), torch.cuda.Event()]
+            self._ev_hashed = [torch.cuda.Event(), torch.cuda.Event()]
+            self.ev_k4 = torch.cuda.Event()
         # First-layer wgrad on a second stream, concurrent with the HBM-bound K4 on the training stream.  It paid next to the
         # in-kernel-split wgrad (2 blocks / CU, matrix pipe ~35 % busy: 1.91 -> 1.84 ms / step); next to the register-split wgrad
         # (one 512-thread block per CU holding all its registers and 96 KB of LDS) the two kernels only time-slice the CUs: the
@@ -160,6 +172,41 @@ class DeepFMEngine:
             self.side2 = torch.cuda.Stream(device=device)
             self.ev_dx = torch.cuda.Event()
             self.ev_dw = torch.cuda.Event()
+
+    @property
+    def ids(self):
+        return self._ids[self.cur]
+
+    @property
+    def plan(self):
+        return self._plans[self.cur]
+
+    @property
+    def ev_sorted(self):
+        return self._ev_sorted[self.cur]
+
+    @staticmethod
+    def _token(keys):
+        return (keys.data_ptr(), keys._version, tuple(keys.shape))
+
+    def _prefetch_next(self):
+        """Hash + slot sort of the next batch on the side stream, started when K4 starts (both HBM-bound, small blocks).  The
+        next forward() picks the buffers up if it is called with the same keys tensor (unmodified); otherwise it recomputes."""
+        nk = self._next_keys
+        if nk is None or not (self.sorted_bwd and not self.sort_inline and self.prefetch_plan):
+            return
+        nxt = self.cur ^ 1
+        self.ev_k4.record()
+        nk.record_stream(self.side)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.ev_k4)
+            self._k("next_batch: hash_bucket_i64(side stream, overlapped)", "overlap", self.B * self.F * 16,
+                    lambda: ops.hash_bucket_i64(nk, self.col_buckets, out=self._ids[nxt]))
+            self._ev_hashed[nxt].record(self.side)
+            self._k("next_batch: emb_sort_slots(side stream, overlapped)", "overlap", self.B * self.F * 36,
+                    lambda: ops.emb_sort_slots(self._ids[nxt], self.row_base, self.R, self._plans[nxt]))
+            self._ev_sorted[nxt].record(self.side)
+        self._pref = self._token(nk)
 
     # ---- per-kernel HIP events on the launch stream (bench.py's roofline numbers) ----------------------
     def enable_kernel_events(self, on: bool):
@@ -217,13 +264,20 @@ class DeepFMEngine:
         B = self.B
         if self.optimizer == "adam":
             self.flat_grads.zero_()          # the fused head already writes Dense(1) gradients during the forward
-        self._k("hash_bucket_i64", "hbm", B * F * 16,
-                lambda: ops.hash_bucket_i64(keys, self.col_buckets, out=self.ids))                    # K1
+        prefetched = self._pref is not None and self._pref == self._token(keys)
+        self._pref = None
+        if prefetched:
+            # K1 + the slot sort of this batch ran beside the previous step's K4
+            self.cur ^= 1
+            torch.cuda.current_stream().wait_event(self._ev_hashed[self.cur])
+        else:
+            self._k("hash_bucket_i64", "hbm", B * F * 16,
+                    lambda: ops.hash_bucket_i64(keys, self.col_buckets, out=self.ids))                # K1
         if self.sorted_bwd and self.sort_inline:
             self._k("emb_sort_slots", "hbm", B * F * 36,
                     lambda: ops.emb_sort_slots(self.ids, self.row_base, self.R, self.plan))
             self.ev_sorted.record()
-        if self.sorted_bwd and not self.sort_inline and self.sort_with_k3:
+        if self.sorted_bwd and not self.sort_inline and self.sort_with_k3 and not prefetched:
             self._launch_sort()              # next to K3 (both HBM-bound, small blocks: they do share the machine)
         fused_l0 = self.fuse_k3 and self.wplanes[0] is not None
         if not fused_l0:
@@ -231,7 +285,7 @@ class DeepFMEngine:
                     lambda: ops.emb_pool_fwd(self.ids, F, None, self.row_base, self.table, self.lin_w, self.lin_bias,
                                              ld_concat=self.ld, concat=self.concat, sum_x=self.sum_x,
                                              fm_logit=self.fm_logit))
-        if self.sorted_bwd and not self.sort_inline and not self.sort_with_k3:
+        if self.sorted_bwd and not self.sort_inline and not self.sort_with_k3 and not prefetched:
             self._launch_sort()              # after K3: under the first GEMM and the tower tail
         if self.Nd:
             self.concat[:, F * D:F * D + self.Nd].copy_(dense)                         # layout: append dense feats
@@ -330,6 +384,7 @@ class DeepFMEngine:
             self._adam_finish()
         elif self.sorted_bwd:
             torch.cuda.current_stream().wait_event(self.ev_sorted)
+            self._prefetch_next()
             self._k("emb_pool_bwd", "hbm", self.alg_bytes_bwd(),                                      # K4 (sorted)
                     lambda: ops.emb_pool_bwd_sorted(self.ids, self.row_base, self.plan, D, self.R, self.d_concat, self.d_logit,
                                                     -lr, self.table, self.lin_w, self.lin_bias, concat=self.concat,
@@ -357,6 +412,7 @@ class DeepFMEngine:
         self.t += 1
         lr_t = ops.adam_lr_t(self.lr, self.beta1, self.beta2, self.t)
         torch.cuda.current_stream().wait_event(self.ev_sorted)
+        self._prefetch_next()
         self._k("emb_pool_bwd_adam", "hbm", self.B * (28 * self.F * self.D + 40 * self.F),                # K4 + optimizer
                 lambda: ops.emb_pool_bwd_sorted_adam(self.ids, self.row_base, self.plan, self.D, self.R, self.d_concat,
                                                      self.d_logit, lr_t, self.beta1, self.beta2, self.eps, self.table,
@@ -373,9 +429,12 @@ class DeepFMEngine:
                 wp.refresh()
 
     def train_step(self, keys, dense, labels, next_keys=None):
-        # next_keys: accepted for interface parity with ShardedDeepFMEngine (which routes the next batch ahead); unused here
+        """One training step.  next_keys (optional): the raw keys of the batch the NEXT call will train on (the data loader knows
+        it; ShardedDeepFMEngine uses the same argument to route ahead): its K1 + slot sort then run beside this step's K4."""
+        self._next_keys = next_keys
         self.forward(keys, dense, labels)
         self.backward_and_update()
+        self._next_keys = None
         return self.loss
 
     # algorithmic bytes of the two embedding kernels per step (SURVEY.md §8d)

@@ -308,6 +308,37 @@ def test_estimator_fm_and_deepfm():
         dnn(torch.randn(4, 8), [4, 1], batch_normalization=True)      # reference quirk, dnn.py:23-24
 
 
+@pytest.mark.parametrize("optimizer,D,V", [("sgd", 16, 1000), ("adam", 16, 1000), ("sgd", 64, 3000)])
+def test_engine_next_batch_prefetch_is_bit_identical(optimizer, D, V):
+    """train_step(..., next_keys=) runs the next batch's K1 + slot sort beside this step's K4 (double-buffered ids / plan).  The
+    trained parameters must be bit-identical to the engine that hashes and sorts every batch in its own step (the sorted backward
+    is deterministic), also when a prefetched batch is NOT the one that comes next, and when the keys tensor is modified in
+    between.  D = 64 takes the fused first layer (dr_bf3_emb_linear_fwd reads the prefetched ids)."""
+    from deep_recommenders_amd.engine import DeepFMEngine
+    F, B, Nd = 4, 2304, 3
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    batches = [(torch.randint(0, 10**12, (B, F), device="cuda", generator=g), torch.rand((B, Nd), device="cuda", generator=g),
+                (torch.rand(B, device="cuda", generator=g) < 0.3).float()) for _ in range(4)]
+    engs = [DeepFMEngine(F, V, D, [256, 16], B, num_dense=Nd, lr=0.05 if optimizer == "sgd" else 0.01, seed=3, lin_init_std=0.1,
+                         optimizer=optimizer) for _ in range(2)]
+    order = [0, 1, 2, 3, 1, 0]
+    for n, i in enumerate(order):
+        engs[0].train_step(*batches[i])
+        nxt = order[n + 1] if n + 1 < len(order) else None
+        if n == 2:
+            nxt = 0                                     # announced batch 0, batch 1 comes: the prefetched plan must be dropped
+        engs[1].train_step(*batches[i], next_keys=None if nxt is None else batches[nxt][0])
+        if n == 0:
+            # the announced tensor is modified before it is used: its version changes, the prefetched ids are stale
+            batches[1][0].add_(1)
+    torch.cuda.synchronize()
+    assert engs[1].prefetch_plan
+    assert torch.equal(engs[0].table, engs[1].table) and torch.equal(engs[0].lin_w, engs[1].lin_w)
+    assert torch.equal(engs[0].flat_params, engs[1].flat_params)
+    assert engs[0].loss.item() == engs[1].loss.item()
+
+
 def test_engine_train_step_matches_oracle():
     """The fused engine step (what bench.py times) against the host restatement: loss and updated weights."""
     from deep_recommenders_amd.engine import DeepFMEngine
