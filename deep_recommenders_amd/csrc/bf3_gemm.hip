@@ -542,6 +542,17 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_rs_kernel(RsArgs g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
+    // STG (DBG bit 16): STAGGERED wave groups.  Waves w and w + 4 share a SIMD; with one barrier per k-tile they run in phase, so the
+    // non-MFMA part of a step (waiting for and splitting the activation registers, issuing the next loads: ~1.5 us of a 5.1 us
+    // step) is paid by both at the same time with the matrix pipe idle.  Here waves 4..7 lag waves 0..3 by 6 of the 16 MFMA groups
+    // (one extra barrier before their first step, one extra for waves 0..3 after their last; a second barrier per step at group
+    // 6): while one group splits, the other multiplies.  The three-stage ring still suffices: stage s % 3 is refilled for step
+    // s + 3 only after the barrier at which the lagging group ends step s, which is the leading group's mid barrier of step s + 1
+    // -- so every wave issues its pieces in groups 6..11, behind its own mid barrier -- and a wave has its pieces of step t + 1
+    // landed before its mid barrier of step t (vmcnt(4): only this step's 4 activation loads are younger), which is the barrier
+    // in front of the leading group's first read of that stage.  Bit-identical results; no gain measured (see rs_launch).
+    constexpr bool STG = (DBG & 16) != 0;
+    const int grp = STG ? (wave >> 2) : 0;
 
     const int tiles_n = (g.N + BN - 1) / BN;
     const int tiles_m = (int)((g.M + BM - 1) / BM);
@@ -685,6 +696,7 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_rs_kernel(RsArgs g) {
     if (total > 1) advance_b();
     __builtin_amdgcn_s_waitcnt(0x0F70 | 10);                            // vmcnt(10): step 0's pieces landed
     asm volatile("s_barrier" ::: "memory");
+    if (STG && grp) asm volatile("s_barrier" ::: "memory");             // the lagging group starts at the leading group's first mid barrier
     read_b(0, 0, 0);
     read_b(1, 0, 1);
 
@@ -705,6 +717,10 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_rs_kernel(RsArgs g) {
         const int nstage = stage == NS - 1 ? 0 : stage + 1;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
+            if (STG && q == 6) {
+                __builtin_amdgcn_s_waitcnt(0x0F70 | 4);                // vmcnt(4): the pieces of step + 1 (issued a step ago) landed
+                asm volatile("s_barrier" ::: "memory");
+            }
             if (q < 14) {
                 wait_b(q & 3, false);
                 read_b((q + 2) & 3, stage, q + 2);
@@ -726,8 +742,8 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_rs_kernel(RsArgs g) {
                 acc[q & 7][0] += (float)fa[q >> 3][0][0] + (float)fb[q & 3][0][0] + (float)fb[q & 3][1][0] + (float)fb[q & 3][2][0];
             }
             __builtin_amdgcn_sched_barrier(0);    // keeps the next group's lgkmcnt wait from being hoisted between these MFMAs
-            if ((q & 1) == 1 && q < 2 * PW) {
-                if constexpr (!(DBG & 1)) issue_b(q >> 1);
+            if (STG ? (q >= 6 && q < 6 + PW) : ((q & 1) == 1 && q < 2 * PW)) {
+                if constexpr (!(DBG & 1)) issue_b(STG ? q - 6 : q >> 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -831,6 +847,7 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_rs_kernel(RsArgs g) {
         }
         tile += gridDim.x;
     }
+    if (STG && !grp) asm volatile("s_barrier" ::: "memory");            // the leading group's extra barrier (see STG above)
 }
 
 // =====================================================================================================================
@@ -1713,11 +1730,22 @@ int rs_launch(const RsArgs& g, hipStream_t stream) {
     const int64_t tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
     if (tiles > 0x7fffffff) return DR_EINVAL;
     const int grid = (int)(tiles < 256 ? tiles : 256);                  // persistent: one block per CU
-    if (g.x0 != nullptr) hipLaunchKernelGGL((bf3_gemm_rs_kernel<2>), dim3(grid), dim3(512), 0, stream, g);
-    else if (g.mask != nullptr && g.accumulate) return DR_EINVAL;       // (no caller needs both)
-    else if (g.mask != nullptr) hipLaunchKernelGGL((bf3_gemm_rs_kernel<1>), dim3(grid), dim3(512), 0, stream, g);
-    else if (g.accumulate) hipLaunchKernelGGL((bf3_gemm_rs_kernel<3>), dim3(grid), dim3(512), 0, stream, g);
-    else hipLaunchKernelGGL((bf3_gemm_rs_kernel<0>), dim3(grid), dim3(512), 0, stream, g);
+    // staggered wave groups (see STG in bf3_gemm_rs_kernel): measured neutral to slightly negative (DeepFM step 1.628 vs 1.605 ms, DCN
+    // 26.93 vs 26.67 ms, same box, alternating) -- the kernel sits at the clock the power budget allows, keeping the pipe busier
+    // buys nothing -- so it is opt-in (DR_BF3_STAGGER=1)
+    static const bool stg = [] { const char* e = getenv("DR_BF3_STAGGER"); return e != nullptr && e[0] == '1'; }();
+    if (g.mask != nullptr && g.accumulate) return DR_EINVAL;            // (no caller needs both)
+    if (stg) {
+        if (g.x0 != nullptr) hipLaunchKernelGGL((bf3_gemm_rs_kernel<2, 16>), dim3(grid), dim3(512), 0, stream, g);
+        else if (g.mask != nullptr) hipLaunchKernelGGL((bf3_gemm_rs_kernel<1, 16>), dim3(grid), dim3(512), 0, stream, g);
+        else if (g.accumulate) hipLaunchKernelGGL((bf3_gemm_rs_kernel<3, 16>), dim3(grid), dim3(512), 0, stream, g);
+        else hipLaunchKernelGGL((bf3_gemm_rs_kernel<0, 16>), dim3(grid), dim3(512), 0, stream, g);
+    } else {
+        if (g.x0 != nullptr) hipLaunchKernelGGL((bf3_gemm_rs_kernel<2>), dim3(grid), dim3(512), 0, stream, g);
+        else if (g.mask != nullptr) hipLaunchKernelGGL((bf3_gemm_rs_kernel<1>), dim3(grid), dim3(512), 0, stream, g);
+        else if (g.accumulate) hipLaunchKernelGGL((bf3_gemm_rs_kernel<3>), dim3(grid), dim3(512), 0, stream, g);
+        else hipLaunchKernelGGL((bf3_gemm_rs_kernel<0>), dim3(grid), dim3(512), 0, stream, g);
+    }
     DR_CHECK_LAUNCH();
     return DR_OK;
 }

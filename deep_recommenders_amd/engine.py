@@ -158,6 +158,9 @@ class DeepFMEngine:
             self._ev_sorted = [torch.cuda.Event(), torch.cuda.Event()]
             self._ev_hashed = [torch.cuda.Event(), torch.cuda.Event()]
             self.ev_k4 = torch.cuda.Event()
+            self.ev_dw_done = torch.cuda.Event()
+            self.ev_planes = torch.cuda.Event()
+        self._planes_pending = False
         # First-layer wgrad on a second stream, concurrent with the HBM-bound K4 on the training stream.  It paid next to the
         # in-kernel-split wgrad (2 blocks / CU, matrix pipe ~35 % busy: 1.91 -> 1.84 ms / step); next to the register-split wgrad
         # (one 512-thread block per CU holding all its registers and 96 KB of LDS) the two kernels only time-slice the CUs: the
@@ -264,6 +267,9 @@ class DeepFMEngine:
         B = self.B
         if self.optimizer == "adam":
             self.flat_grads.zero_()          # the fused head already writes Dense(1) gradients during the forward
+        if self._planes_pending:         # the previous step's weight planes were refreshed on the side stream
+            torch.cuda.current_stream().wait_event(self.ev_planes)
+            self._planes_pending = False
         prefetched = self._pref is not None and self._pref == self._token(keys)
         self._pref = None
         if prefetched:
@@ -378,7 +384,17 @@ class DeepFMEngine:
             self._k("linear_bwd_dw_L%d" % i, "mfma", fl,
                     lambda x=x, dy=dy, i=i, dstW=dstW, dstb=dstb: self._wgrad(i, x, dy, sc, dstW, dstb))
             if self.wplanes[i] is not None and not adam:
-                self.wplanes[i].refresh()
+                if self.sorted_bwd and not self.sort_inline:
+                    # the weight just moved: its planes follow -- on the side stream, beside whatever comes next on this one (the
+                    # two split launches are needed only by the next step's forward / dgrad, which wait for ev_planes)
+                    self.ev_dw_done.record()
+                    with torch.cuda.stream(self.side):
+                        self.side.wait_event(self.ev_dw_done)
+                        self.wplanes[i].refresh()
+                        self.ev_planes.record(self.side)
+                    self._planes_pending = True
+                else:
+                    self.wplanes[i].refresh()
             dy = dx
         if adam:
             self._adam_finish()
