@@ -79,6 +79,8 @@ SIGNATURES = {
     "dr_bf3_gemm_nt": [_p, _i64, _i64, _p, _i64, _i64, _i64, _i32, _i32, _p, _i32, _p, _i64, _p, _i64, _p],
     "dr_bf3_linear_nt": [_p, _i64, _p, _i64, _i64, _i64, _i32, _i32, _p, _i32, _p, _i64, _i32, _p, _i64, _p],
     "dr_bf3_cross_fwd": [_p, _p, _i64, _p, _i64, _i64, _p, _f32, _i64, _i32, _p, _p, _p],
+    "dr_linear_fwd_splitk_workspace_bytes": [_i64, _i32, _i32],
+    "dr_linear_fwd_splitk": [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _i64, _p, _i64, _p],
     "dr_bf3_emb_linear_fwd": [_p, _i64, _i32, _p, _i64, _p, _i32, _p, _p, _p, _p, _i64, _i32, _p, _i64, _i64, _i32, _p, _i32, _p, _p, _p, _i64, _p],
     "dr_bf3_wgrad_workspace_bytes": [_i64, _i32, _i32],
     "dr_bf3_wgrad": [_p, _i64, _p, _i64, _i64, _i32, _i32, _f32, _p, _i64, _p, _p, _i64, _p],
@@ -100,6 +102,7 @@ SIGNATURES = {
 _RESTYPE = {"dr_version": ctypes.c_char_p, "dr_shard_bucket_workspace_bytes": ctypes.c_int64,
             "dr_emb_sort_workspace_bytes": ctypes.c_int64,
             "dr_linear_bwd_dw_workspace_bytes": ctypes.c_int64,
+            "dr_linear_fwd_splitk_workspace_bytes": ctypes.c_int64,
             "dr_bf3_gemm_tn_workspace_bytes": ctypes.c_int64,
             "dr_bf3_wgrad_workspace_bytes": ctypes.c_int64,
             "dr_linear_bwd_narrow_workspace_bytes": ctypes.c_int64,

@@ -1151,6 +1151,37 @@ extern "C" int dr_linear_bwd_dw(const float* x, int64_t ld_x, const float* dy, i
     return DR_OK;
 }
 
+// y[m][n] += sum_k x[m][k] W[k][n] for SHORT-AND-WIDE problems (few output tiles, long reduction: the two-tower dq = G c with
+// G [B, B], c [B, 128] has 64 tiles of 128 x 128 for 256 CUs): the reduction is split over grid.y into a workspace and the
+// slices are summed in a fixed order (deterministic), exactly as the weight gradients do.
+extern "C" int64_t dr_linear_fwd_splitk_workspace_bytes(int64_t M, int32_t K, int32_t N) {
+    if (M <= 0 || K <= 0 || N <= 0 || M > 0x7fffffff) return 0;
+    return (int64_t)dw_split_max(K, (int32_t)M, N) * M * N * (int64_t)sizeof(float);
+}
+
+extern "C" int dr_linear_fwd_splitk(const float* x, int64_t ld_x, const float* W, int64_t ld_w, int64_t M, int32_t K, int32_t N,
+                                    float* y, int64_t ld_y, float* workspace, int64_t workspace_bytes, dr_stream_t stream) {
+    if (M < 0 || M > 0x7fffffff || K < 4 || N < 4) return DR_EINVAL;
+    if (M == 0) return DR_OK;
+    if (!x || !W || !y || !workspace || bad_ld(ld_x, K) || bad_ld(ld_w, N) || ld_y < N || misaligned(x) || misaligned(W))
+        return DR_EINVAL;
+    if (workspace_bytes < dr_linear_fwd_splitk_workspace_bytes(M, K, N)) return DR_EINVAL;
+    // A(i = m, r = k) = x[m ld_x + k] (row-contiguous), B(r = k, j = n) = W[k ld_w + n]
+    GemmArgs g{};
+    g.A = x; g.lda = ld_x; g.B = W; g.ldb = ld_w; g.M = M; g.N = N; g.R = K; g.C = y; g.ldc = ld_y;
+    g.alpha = 1.f;
+    g.split = dw_split(K, (int32_t)M, N);
+    g.per = ((K + g.split - 1) / g.split + BK - 1) / BK * BK;      // launch and reduce the non-empty slices only (see dr_linear_bwd_dw)
+    g.split = (int32_t)((K + g.per - 1) / g.per);
+    g.partial = workspace;
+    int rc = launch<true, false, EPI_ATOMIC>(g, dr_s(stream));
+    if (rc != DR_OK) return rc;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(dr_grid_for(M * N, 256)), dim3(256), 0, dr_s(stream), workspace, g.split, M, N,
+                       1.f, y, ld_y);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
 extern "C" int dr_cross_fwd(const float* x0, const float* x, int64_t ld, const float* W, int64_t ld_w, const float* b,
                             float diag_scale, int64_t M, int32_t Dm, float* out, float* prod_out,
                             dr_stream_t stream) {

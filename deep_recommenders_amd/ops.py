@@ -192,6 +192,25 @@ def linear_bwd_dx(dy, W, relu_src=None, accumulate=False, out=None):
     return out
 
 
+def linear_fwd_splitk_workspace(M, K, N, device):
+    return torch.empty(max(1, lib().dr_linear_fwd_splitk_workspace_bytes(int(M), int(K), int(N)) // 4), dtype=torch.float32,
+                       device=device)
+
+
+def linear_fwd_splitk(x, W, out, workspace=None):
+    """out += x @ W with the reduction split over the grid (few output tiles, long K); slices summed in a fixed order."""
+    x = _rowmajor_ld4(x)
+    W = _rowmajor_ld4(W)
+    M, K = x.shape
+    N = W.shape[1]
+    assert W.shape[0] == K and out.shape == (M, N) and out.stride(1) == 1
+    if workspace is None or workspace.numel() * 4 < lib().dr_linear_fwd_splitk_workspace_bytes(M, K, N):
+        workspace = linear_fwd_splitk_workspace(M, K, N, x.device)
+    check(lib().dr_linear_fwd_splitk(ptr(x), x.stride(0), ptr(W), W.stride(0), M, K, N, ptr(out), out.stride(0), ptr(workspace),
+                                     workspace.numel() * 4, stream_ptr()), "dr_linear_fwd_splitk")
+    return out
+
+
 def linear_bwd_dw_workspace(M, K, N, device):
     return torch.empty(max(1, lib().dr_linear_bwd_dw_workspace_bytes(int(M), int(K), int(N)) // 4), dtype=torch.float32,
                        device=device)

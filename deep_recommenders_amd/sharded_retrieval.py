@@ -43,6 +43,7 @@ class RetrievalPrims(HipPrims):
     rowdot = staticmethod(ops.rowdot)
     topk_hits = staticmethod(ops.topk_hits)
     gather_i64 = staticmethod(ops.gather_i64)
+    linear_fwd_wide = staticmethod(lambda x, W, out: ops.linear_fwd_splitk(x, W, out))   # out += x W, reduction split over the grid
 
 
 def _all_gather(t, world, group):
@@ -200,8 +201,13 @@ class ShardedTwoTowerEngine:
             scores = p.logits_adjust(scores, labels, cand_ids=ids_all)                 # :66-75
         self.loss = p.softmax_ce_rows(scores, labels, self.inv_t)                      # :148-151
         G = p.softmax_ce_rows_bwd(scores, labels, self.inv_t, None, 1.0)
-        dq = torch.empty((B, _pad4(self.out_dim)), dtype=torch.float32, device=q.device)[:, :self.out_dim]
-        p.linear_fwd(G, c_all, None, 0, out=dq)                                        # dq = G c_all
+        wide = getattr(p, "linear_fwd_wide", None)       # [B, W B] x [W B, out]: few output tiles, long reduction -> split over the grid
+        if wide is not None and B >= 2048:
+            dq = torch.zeros((B, _pad4(self.out_dim)), dtype=torch.float32, device=q.device)[:, :self.out_dim]
+            wide(G, c_all, dq)                                                         # dq = G c_all
+        else:
+            dq = torch.empty((B, _pad4(self.out_dim)), dtype=torch.float32, device=q.device)[:, :self.out_dim]
+            p.linear_fwd(G, c_all, None, 0, out=dq)                                    # dq = G c_all
         dc_all = torch.zeros((W * B, _pad4(self.out_dim)), dtype=torch.float32, device=q.device)[:, :self.out_dim]
         p.linear_bwd_dw(G, q, 1.0, dc_all)                                             # this rank's part of G^T q
         dc_buf = dc_all if dc_all.is_contiguous() else dc_all.contiguous()

@@ -102,6 +102,8 @@ class TwoTowerEngine:
         self.d_i_emb = torch.empty((batch, dim), **f32)
         self.dq = torch.empty((batch, _pad4(self.out_dim)), **f32)[:, :self.out_dim]
         self.dc = torch.empty((batch, _pad4(self.out_dim)), **f32)[:, :self.out_dim]
+        tiles = ((batch + 127) // 128) * ((self.out_dim + 127) // 128)
+        self.dq_ws = ops.linear_fwd_splitk_workspace(batch, batch, self.out_dim, device) if (tiles < 256 and batch >= 2048) else None
         self.loss = torch.zeros(1, **f32)
         self.u_plan = ops.SortPlan(batch, device)
         self.i_plan = ops.SortPlan(batch, device)
@@ -174,7 +176,13 @@ class TwoTowerEngine:
                     lambda: ops.inbatch_softmax_grad_scores(q, c, row_lse, 1.0, candidate_sampling_probability, cand_ids,
                                                             sample_weight, self.inv_t))
         dq, dc = self.dq[:B], self.dc[:B]
-        self._k("retrieval_dq", "mfma", fl_s, lambda: ops.linear_fwd(G, c, out=dq))                      # dq = G c
+        # dq = G c: [B, B] x [B, out] has only B / 128 output tiles (64 at B = 8192) for 256 CUs -> reduction split over the grid,
+        # slices summed in a fixed order (393 -> ~120 us at B = 8192; the plain GEMM when the tiles alone fill the machine)
+        if self.dq_ws is not None:
+            dq.zero_()
+            self._k("retrieval_dq", "mfma", fl_s, lambda: ops.linear_fwd_splitk(G, c, dq, workspace=self.dq_ws))
+        else:
+            self._k("retrieval_dq", "mfma", fl_s, lambda: ops.linear_fwd(G, c, out=dq))
         dc.zero_()
         self._k("retrieval_dc", "mfma", fl_s, lambda: ops.linear_bwd_dw(G, q, 1.0, dc))                 # dc = G^T q
         if self.q_tower.Ws:

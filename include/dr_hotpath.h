@@ -244,6 +244,14 @@ int dr_linear_fwd(const float* x, int64_t ld_x, const float* W, int64_t ld_w, co
 int dr_linear_bwd_dx(const float* dy, int64_t ld_dy, const float* W, int64_t ld_w, int64_t M,
                      int32_t K, int32_t N, const float* relu_src, int64_t ld_relu_src,
                      int32_t accumulate, float* dx, int64_t ld_dx, dr_stream_t stream);
+/* dr_linear_fwd_splitk: y += x W for few output tiles and a long reduction (the in-batch softmax's dq = G c of
+ * keras/models/retrieval/sbcnm.py:120-163's backward: G [B, B], c [B, 128]): the reduction is split over the grid into `workspace`
+ * (dr_linear_fwd_splitk_workspace_bytes) and the slices are summed in a fixed order.  Accumulates into y (zero it for a plain
+ * product). */
+int64_t dr_linear_fwd_splitk_workspace_bytes(int64_t M, int32_t K, int32_t N);
+int dr_linear_fwd_splitk(const float* x, int64_t ld_x, const float* W, int64_t ld_w, int64_t M, int32_t K, int32_t N,
+                         float* y, int64_t ld_y, float* workspace, int64_t workspace_bytes, dr_stream_t stream);
+
 /* dgrad of the first tower layer with the FM second-order gradient folded into the epilogue:
  *   dx[m, j] = (dy @ W^T)[m, j] + d_fm_logit[m] * (sum_x[m, j % D] - concat[m, j])   for j < FD (= F*D)
  * (autodiff of keras/models/ranking/fm.py:28-35 + deepfm.py:46 in one stream), so K4 reads one gradient. */

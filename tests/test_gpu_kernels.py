@@ -344,6 +344,24 @@ def test_tower_head_fused(ops, M, K, H, mode):
     np.testing.assert_allclose(b2d.cpu().numpy(), b2 + scale * tb2.grad.numpy(), rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize("M,K,N", [(8192, 8192, 128), (300, 5000, 40), (2048, 2049, 130)])
+def test_linear_fwd_splitk_matches_fp64_and_is_deterministic(ops, M, K, N):
+    """dr_linear_fwd_splitk (the two-tower dq = G c: few output tiles, long reduction split over the grid): accumulates into y,
+    agrees with float64 as well as dr_linear_fwd does, and two runs are bit-identical (fixed-order reduce, no atomics)."""
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    x = torch.randn((M, K), device="cuda", generator=g) * 0.05
+    W = torch.randn((K, N), device="cuda", generator=g)
+    base = torch.randn((M, N), device="cuda", generator=g)
+    y1, y2 = base.clone(), base.clone()
+    ops.linear_fwd_splitk(x, W, y1)
+    ops.linear_fwd_splitk(x, W, y2)
+    assert torch.equal(y1, y2)
+    ref = base.double() + x.double() @ W.double()
+    e_new = ((y1.double() - ref).abs().max() / ref.abs().max()).item()
+    e_old = (((base + ops.linear_fwd(x, W, None, 0)).double() - ref).abs().max() / ref.abs().max()).item()
+    assert e_new <= 2e-6 and e_new <= 2.0 * e_old + 1e-7, (e_new, e_old)
+
+
 def test_linear_transpose_detecting(ops):
     # A = I with an ASYMMETRIC B catches a swapped C/D fragment layout
     K = N = 64
