@@ -102,6 +102,8 @@ class TwoTowerEngine:
         self.d_i_emb = torch.empty((batch, dim), **f32)
         self.dq = torch.empty((batch, _pad4(self.out_dim)), **f32)[:, :self.out_dim]
         self.dc = torch.empty((batch, _pad4(self.out_dim)), **f32)[:, :self.out_dim]
+        self.side = torch.cuda.Stream(device=device)
+        self.ev_fork, self.ev_c = torch.cuda.Event(), torch.cuda.Event()
         tiles = ((batch + 127) // 128) * ((self.out_dim + 127) // 128)
         self.dq_ws = ops.linear_fwd_splitk_workspace(batch, batch, self.out_dim, device) if (tiles < 256 and batch >= 2048) else None
         self.loss = torch.zeros(1, **f32)
@@ -141,23 +143,28 @@ class TwoTowerEngine:
         return fl + 4 * 2.0 * B * B * D                    # scores in the forward, again in the gradient, dq, dc
 
     # ---- embeddings ---------------------------------------------------------------------------------------------------
-    def _embed(self, user_keys, item_ids):
+    def embeddings(self, user_keys, item_ids):
+        """(query embeddings, candidate embeddings) of a batch, no gradient state kept beyond the engine buffers.
+        The two towers are independent until the score matrix and each of their GEMMs is small (64 - 128 blocks at B = 8192 for
+        256 CUs): the candidate side (gather + tower) runs on a second stream beside the query side."""
         B, D = user_keys.shape[0], self.D
+        main = torch.cuda.current_stream()
+        self.ev_fork.record(main)
+        item_ids.record_stream(self.side)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.ev_fork)
+            self._k("emb_gather_items", "hbm", B * (8 * D + 8),
+                    lambda: ops.emb_pool_fwd(item_ids.reshape(B, 1), 1, None, self.zero_base, self.item_table, None, None,
+                                             ld_concat=D, concat=self.i_emb[:B], want_sum_x=False, want_fm=False))
+            c = self.c_tower.forward(self.i_emb[:B], self._k, "c_tower") if self.c_tower.Ws else self.i_emb[:B]
+            self.ev_c.record(self.side)
         self._k("hash_bucket_i64", "hbm", B * 16,
                 lambda: ops.hash_bucket_i64(user_keys.reshape(B, 1), self.user_buckets, out=self.uid[:B]))
         self._k("emb_gather_users", "hbm", B * (8 * D + 8),
                 lambda: ops.emb_pool_fwd(self.uid[:B], 1, None, self.zero_base, self.user_table, None, None, ld_concat=D,
                                          concat=self.u_emb[:B], want_sum_x=False, want_fm=False))
-        self._k("emb_gather_items", "hbm", B * (8 * D + 8),
-                lambda: ops.emb_pool_fwd(item_ids.reshape(B, 1), 1, None, self.zero_base, self.item_table, None, None,
-                                         ld_concat=D, concat=self.i_emb[:B], want_sum_x=False, want_fm=False))
-
-    def embeddings(self, user_keys, item_ids):
-        """(query embeddings, candidate embeddings) of a batch, no gradient state kept beyond the engine buffers."""
-        self._embed(user_keys, item_ids)
-        B = user_keys.shape[0]
         q = self.q_tower.forward(self.u_emb[:B], self._k, "q_tower") if self.q_tower.Ws else self.u_emb[:B]
-        c = self.c_tower.forward(self.i_emb[:B], self._k, "c_tower") if self.c_tower.Ws else self.i_emb[:B]
+        main.wait_event(self.ev_c)
         return q, c
 
     # ---- training step ------------------------------------------------------------------------------------------------
@@ -176,6 +183,12 @@ class TwoTowerEngine:
                     lambda: ops.inbatch_softmax_grad_scores(q, c, row_lse, 1.0, candidate_sampling_probability, cand_ids,
                                                             sample_weight, self.inv_t))
         dq, dc = self.dq[:B], self.dc[:B]
+        # the candidate side of the backward (dc = G^T q, tower, sort + scatter into the item table) on the second stream, the query
+        # side here; the next step's candidate gather follows on that same stream, the caller's stream waits for both
+        main = torch.cuda.current_stream()
+        self.ev_fork.record(main)
+        for t in (G, q, c, item_ids):
+            t.record_stream(self.side)
         # dq = G c: [B, B] x [B, out] has only B / 128 output tiles (64 at B = 8192) for 256 CUs -> reduction split over the grid,
         # slices summed in a fixed order (393 -> ~120 us at B = 8192; the plain GEMM when the tiles alone fill the machine)
         if self.dq_ws is not None:
@@ -183,22 +196,23 @@ class TwoTowerEngine:
             self._k("retrieval_dq", "mfma", fl_s, lambda: ops.linear_fwd_splitk(G, c, dq, workspace=self.dq_ws))
         else:
             self._k("retrieval_dq", "mfma", fl_s, lambda: ops.linear_fwd(G, c, out=dq))
-        dc.zero_()
-        self._k("retrieval_dc", "mfma", fl_s, lambda: ops.linear_bwd_dw(G, q, 1.0, dc))                 # dc = G^T q
-        if self.q_tower.Ws:
-            d_u = self.q_tower.backward(dq, self.d_u_emb[:B], -lr, self._k, "q_tower")
-            d_i = self.c_tower.backward(dc, self.d_i_emb[:B], -lr, self._k, "c_tower")
-        else:
-            d_u, d_i = dq, dc
-        # K4: both tables, rows sorted so that each touched row gets one plain read-modify-write (fused SGD)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.ev_fork)
+            dc.zero_()
+            self._k("retrieval_dc", "mfma", fl_s, lambda: ops.linear_bwd_dw(G, q, 1.0, dc))             # dc = G^T q
+            d_i = self.c_tower.backward(dc, self.d_i_emb[:B], -lr, self._k, "c_tower") if self.c_tower.Ws else dc
+            ops.emb_sort_slots(item_ids, self.zero_base, self.Ni, self.i_plan)
+            self._k("emb_scatter_items", "hbm", B * (12 * D + 8),
+                    lambda: ops.emb_pool_bwd_sorted(item_ids, self.zero_base, self.i_plan, D, self.Ni, d_i, None, -lr,
+                                                    self.item_table, None, None))
+            self.ev_c.record(self.side)
+        d_u = self.q_tower.backward(dq, self.d_u_emb[:B], -lr, self._k, "q_tower") if self.q_tower.Ws else dq
+        # K4: rows sorted so that each touched row gets one plain read-modify-write (fused SGD)
         ops.emb_sort_slots(self.uid[:B], self.zero_base, self.Vu, self.u_plan)
         self._k("emb_scatter_users", "hbm", B * (12 * D + 8),
                 lambda: ops.emb_pool_bwd_sorted(self.uid[:B], self.zero_base, self.u_plan, D, self.Vu, d_u, None, -lr,
                                                 self.user_table, None, None))
-        ops.emb_sort_slots(item_ids, self.zero_base, self.Ni, self.i_plan)
-        self._k("emb_scatter_items", "hbm", B * (12 * D + 8),
-                lambda: ops.emb_pool_bwd_sorted(item_ids, self.zero_base, self.i_plan, D, self.Ni, d_i, None, -lr,
-                                                self.item_table, None, None))
+        main.wait_event(self.ev_c)
         return self.loss
 
     # ---- corpus index + FactorizedTopK metric pass (factorized_top_k.py:275-334, 489-512) -------------------------------
