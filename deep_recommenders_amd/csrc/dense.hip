@@ -889,7 +889,9 @@ __global__ __launch_bounds__(256) void skinny_dx_kernel(const float* __restrict_
 }
 // dst[k][n] += scale * sum_m x[m][k] dy[m][n] ; dstb[n] += scale * sum_m dy[m][n].  A block owns a slab of rows and
 // all (k, n) pairs (strided over its threads), accumulates in registers, then one atomic per (k, n) per block.
-constexpr int SK_ROWS = 1024;
+// (128 rows per block: 512 blocks at M = 65536.  With 1024 the Dense(1) weight gradient of the DCN tower ran on 64 of 256 CUs,
+// every thread a 1024-long dependent chain: 258 us for a 67 MB read)
+constexpr int SK_ROWS = 128;
 __global__ __launch_bounds__(256) void skinny_dw_kernel(const float* __restrict__ x, int64_t ldx,
                                                         const float* __restrict__ dy, int64_t lddy, int64_t M, int32_t K,
                                                         int32_t N, float scale, float* __restrict__ dst, int64_t ldw,
