@@ -183,7 +183,9 @@ def test_tower_tail_full_size_consistency():
     torch.testing.assert_close(dlog_b * M, dlog_a * M, rtol=0, atol=5e-6)
     torch.testing.assert_close(dh1_b * M, dh1_a * M, rtol=0, atol=2e-5)
     torch.testing.assert_close(dh0_b * M, dh0_a * M, rtol=0, atol=1e-4)
-    torch.testing.assert_close(W2b_buf, W2a_buf, rtol=0, atol=1e-6)
+    # (the op-by-op Dense(1) weight gradient is a sum of 65 536 fp32 products in slab order + atomics, the fused one a fixed-order
+    # block reduction: ~17 ulp of a 0.57 weight apart at worst)
+    torch.testing.assert_close(W2b_buf, W2a_buf, rtol=0, atol=3e-6)
     torch.testing.assert_close(b2b, b2a, rtol=0, atol=1e-6)
     torch.testing.assert_close(W1b, W1a, rtol=0, atol=1e-6)
     torch.testing.assert_close(b1b, b1a, rtol=0, atol=1e-6)
