@@ -151,6 +151,11 @@ class DeepFMEngine:
         # GEMMs (the fused first layer occupies all 160 KB of LDS on every CU) the sort chain's ~20 small launches only advance in
         # the gaps: 1.2 ms instead of 0.17, and K4 waited 74 us for it (round 2, rocprofv3: K4 305 us, its event 379 us).
         self.prefetch_plan = _os.environ.get("DR_PREFETCH_PLAN", "1") == "1"
+        # Fewer cross-stream packets in front of K4 (rocprofv3 showed a 31 us gap there against 11 - 13 us between the other
+        # dependent kernels): the side chain is ordered behind the plane refresh instead of an event of its own, and the wait for
+        # a PREFETCHED plan -- long complete by then -- sits in front of the first-layer wgrad.  DR_LEAN_EVENTS=0: as before.
+        self.lean_events = _os.environ.get("DR_LEAN_EVENTS", "1") == "1"
+        self._plan_prefetched = False
         if sorted_bwd:
             self._plans = [ops.SortPlan(B * F, device) for _ in range(2)]
             self.side = torch.cuda.Stream(device=device)
@@ -199,10 +204,13 @@ class DeepFMEngine:
         if nk is None or not (self.sorted_bwd and not self.sort_inline and self.prefetch_plan):
             return
         nxt = self.cur ^ 1
-        self.ev_k4.record()
+        ordered = self._planes_pending and self.lean_events   # the side stream already waits for the last wgrad (plane refresh)
+        if not ordered:
+            self.ev_k4.record()
         nk.record_stream(self.side)
         with torch.cuda.stream(self.side):
-            self.side.wait_event(self.ev_k4)
+            if not ordered:
+                self.side.wait_event(self.ev_k4)
             self._k("next_batch: hash_bucket_i64(side stream, overlapped)", "overlap", self.B * self.F * 16,
                     lambda: ops.hash_bucket_i64(nk, self.col_buckets, out=self._ids[nxt]))
             self._ev_hashed[nxt].record(self.side)
@@ -272,6 +280,7 @@ class DeepFMEngine:
             self._planes_pending = False
         prefetched = self._pref is not None and self._pref == self._token(keys)
         self._pref = None
+        self._plan_prefetched = prefetched
         if prefetched:
             # K1 + the slot sort of this batch ran beside the previous step's K4
             self.cur ^= 1
@@ -369,6 +378,8 @@ class DeepFMEngine:
             else:
                 self._k("linear_bwd_dx_L%d" % i, "mfma", fl,
                         lambda dy=dy, W=W, rs=rs, dx=dx: ops.linear_bwd_dx(dy, W, relu_src=rs, out=dx))
+            if i == 0 and self.sorted_bwd and self._plan_prefetched and self.lean_events:
+                torch.cuda.current_stream().wait_event(self.ev_sorted)     # (see lean_events)
             if i == 0 and self.overlap_dw:
                 # first-layer wgrad on the second stream; K4 follows on this one as soon as dx is out
                 self.ev_dx.record()
@@ -399,7 +410,8 @@ class DeepFMEngine:
         if adam:
             self._adam_finish()
         elif self.sorted_bwd:
-            torch.cuda.current_stream().wait_event(self.ev_sorted)
+            if not (self._plan_prefetched and self.lean_events):
+                torch.cuda.current_stream().wait_event(self.ev_sorted)
             self._prefetch_next()
             self._k("emb_pool_bwd", "hbm", self.alg_bytes_bwd(),                                      # K4 (sorted)
                     lambda: ops.emb_pool_bwd_sorted(self.ids, self.row_base, self.plan, D, self.R, self.d_concat, self.d_logit,
@@ -427,7 +439,8 @@ class DeepFMEngine:
         """Adam mode: fused row-wise Adam K4, first-order bias gradient, one dense Adam step over the flat parameters."""
         self.t += 1
         lr_t = ops.adam_lr_t(self.lr, self.beta1, self.beta2, self.t)
-        torch.cuda.current_stream().wait_event(self.ev_sorted)
+        if not (self._plan_prefetched and self.lean_events):
+            torch.cuda.current_stream().wait_event(self.ev_sorted)
         self._prefetch_next()
         self._k("emb_pool_bwd_adam", "hbm", self.B * (28 * self.F * self.D + 40 * self.F),                # K4 + optimizer
                 lambda: ops.emb_pool_bwd_sorted_adam(self.ids, self.row_base, self.plan, self.D, self.R, self.d_concat,

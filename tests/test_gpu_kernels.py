@@ -808,11 +808,14 @@ def test_bf3_linear_nt_matches_fp64(M, K, N):
     assert torch.equal(ops.bf3_linear_nt(xp[:, :K], wp.wt, bias=b, act=1), y)
 
 
-@pytest.mark.parametrize("M,F,Nd,N", [(300, 3, 0, 40), (2085, 26, 13, 256), (4096, 7, 5, 300), (257, 1, 2, 64)])
+@pytest.mark.parametrize("M,F,Nd,N", [(300, 3, 0, 40), (2085, 26, 13, 256), (4096, 7, 5, 300), (257, 1, 2, 64),
+                                      (70000, 2, 3, 64), (40001, 1, 0, 600)])
 def test_bf3_emb_linear_fwd_equals_pool_then_linear(M, F, Nd, N):
     """dr_bf3_emb_linear_fwd (K3 fused into the first Dense layer) == dr_emb_pool_fwd followed by dr_bf3_linear_nt:
     concat's embedding part bit for bit (it is a copy of table rows; missing ids give zeros), sum_x / fm_logit within fp32
-    summation-order noise, and the layer output bit for bit (same splits, same k order, same accumulation as dr_bf3_linear_nt)."""
+    summation-order noise, and the layer output bit for bit (same splits, same k order, same accumulation as dr_bf3_linear_nt).
+    The last two shapes have more output tiles than the 256 persistent blocks (274; 157 x 3 = 471 with three column tiles per row
+    panel, of which only the first stores concat / the FM terms): the gather pipeline runs across tile boundaries."""
     from deep_recommenders_amd import ops
     g = torch.Generator(device="cuda").manual_seed(M + F)
     D, V = 64, 97
