@@ -85,7 +85,7 @@ __device__ __forceinline__ float adam_elem(float g, float& m, float& v, const Ad
 }
 
 template <int LPR, int U, bool ADAM>
-__global__ __launch_bounds__(256) void emb_bwd_unique_kernel(const int64_t* __restrict__ ids,
+__device__ __forceinline__ void emb_bwd_unique_body(const int bid, const int nblk, const int64_t* __restrict__ ids,
                                                               const uint8_t* __restrict__ flags, int64_t B, int32_t F,
                                                               const int64_t* __restrict__ row_base, int32_t D,
                                                               const float* __restrict__ grad, int64_t ld,
@@ -106,12 +106,12 @@ __global__ __launch_bounds__(256) void emb_bwd_unique_kernel(const int64_t* __re
     const float* dlsrc = d_fm_logit != nullptr ? d_fm_logit : grad;       // idem
     const float* sxsrc = fm ? sum_x : grad;                               // idem
     const int64_t sx_pitch = fm ? D : 0;
-    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)nblk * (blockDim.x >> 6);
+    const int64_t wave0 = (int64_t)bid * (blockDim.x >> 6) + (threadIdx.x >> 6);
     // Bias gradient = scale * sum_b d_fm_logit[b].  One same-address atomic per wave (32 K of them at ~88/us on one L2
     // channel) used to cost more than the whole scatter; block 0 now sums the B values itself, in a fixed order
     // (deterministic), overlapped with every other block's work, and is the only writer of lin_bias.
-    if (!ADAM && blockIdx.x == 0 && lin_bias != nullptr && d_fm_logit != nullptr) dr_block_sum_axpy(d_fm_logit, B, scale, lin_bias);
+    if (!ADAM && bid == 0 && lin_bias != nullptr && d_fm_logit != nullptr) dr_block_sum_axpy(d_fm_logit, B, scale, lin_bias);
     const float* mlsrc = (ADAM && ad.m_lin != nullptr) ? ad.m_lin : table;        // values unused when there is no first-order state
     const float* vlsrc = (ADAM && ad.v_lin != nullptr) ? ad.v_lin : table;
     if (wave0 >= B) return;
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void emb_bwd_unique_kernel(const int64_t* __re
 // order.  A segment of <= CH slots is always owned by ONE group (plain RMW, deterministic); a hotter row is cut at
 // CH-aligned positions that lie >= CH past its start, those pieces combine with fp32 atomics.
 template <int LPR, bool ADAM>
-__global__ __launch_bounds__(256) void emb_bwd_dups_kernel(const uint64_t* __restrict__ rows,
+__device__ __forceinline__ void emb_bwd_dups_body(const int bid, const int nblk, const uint64_t* __restrict__ rows,
                                                            const int32_t* __restrict__ slots, int64_t n,
                                                            const int32_t* __restrict__ dup_heads,
                                                            const int32_t* __restrict__ dup_count, int32_t F,
@@ -229,8 +229,8 @@ __global__ __launch_bounds__(256) void emb_bwd_dups_kernel(const uint64_t* __res
     const float* sxsrc = fm ? sum_x : grad;
     const int64_t sxp = fm ? (int64_t)D : 0;
     const float* dlsrc = d_fm_logit != nullptr ? d_fm_logit : grad;
-    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)nblk * (blockDim.x >> 6);
+    const int64_t wave0 = (int64_t)bid * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nheads = dup_count[0];
     const uint64_t gmask = LPR == 64 ? ~0ull : ((1ull << LPR) - 1ull);
     for (int64_t h0 = wave0 * NS; h0 < nheads; h0 += nwaves * NS) {
@@ -329,6 +329,27 @@ __global__ __launch_bounds__(256) void emb_bwd_dups_kernel(const uint64_t* __res
     }
 }
 
+// K4 in ONE launch: the first `grid_d` blocks walk the duplicate segments, the rest stream the examples and update the rows
+// that are unique in the batch.  The two touch disjoint rows (a row is unique or it is not), so nothing orders them; as two
+// launches the duplicate pass (11 - 18 us on uniform ids, the longest part of K4 on Zipf ids) ran after the unique pass and a
+// 12 us launch gap.  The duplicate blocks come first in the grid so that hot rows start early.
+struct BwdSortedArgs {
+    const int64_t* ids; const uint8_t* flags; int64_t B; int32_t F; const int64_t* row_base; int32_t D;
+    const float* grad; int64_t ld; const float* concat; int64_t ldc; const float* sum_x; const float* d_fm_logit;
+    const float* slot_lin; float scale; float* table; float* lin_w; float* lin_bias;
+    const uint64_t* rows; const int32_t* slots; int64_t n; const int32_t* dup_heads; const int32_t* dup_count; uint64_t num_rows;
+};
+template <int LPR, int U, bool ADAM>
+__global__ __launch_bounds__(256) void emb_bwd_sorted_kernel(BwdSortedArgs a, AdamArgs ad, int grid_d) {
+    if ((int)blockIdx.x < grid_d)
+        emb_bwd_dups_body<LPR, ADAM>(blockIdx.x, grid_d, a.rows, a.slots, a.n, a.dup_heads, a.dup_count, a.F, a.D, a.num_rows, a.grad,
+                                     a.ld, a.concat, a.ldc, a.sum_x, a.d_fm_logit, a.slot_lin, a.scale, a.table, a.lin_w, ad);
+    else
+        emb_bwd_unique_body<LPR, U, ADAM>(blockIdx.x - grid_d, gridDim.x - grid_d, a.ids, a.flags, a.B, a.F, a.row_base, a.D, a.grad,
+                                          a.ld, a.concat, a.ldc, a.sum_x, a.d_fm_logit, a.slot_lin, a.scale, a.table, a.lin_w,
+                                          a.lin_bias, ad);
+}
+
 unsigned bits_for(uint64_t v) {
     unsigned b = 1;
     while (b < 64 && (v >> b) != 0) ++b;
@@ -404,16 +425,14 @@ static int bwd_sorted_impl(const int64_t* ids, const int64_t* row_base, const in
                                 // blocks exit at once), skewed ids fill it
     AdamArgs ad{};
     if (adam != nullptr) ad = *adam;
+    const BwdSortedArgs ba{ids, unique_flags, B, F, row_base, D, grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit, slot_lin_grad,
+                           scale, dst_table, dst_lin, dst_bias, rows, sorted_slots, n, dup_heads, dup_count, (uint64_t)num_rows};
 #define LAUNCH(L, ADAM_)                                                                                              \
     {                                                                                                                 \
         constexpr int NS_ = 64 / L;                                                                                   \
         constexpr int U_ = NS_ >= 16 ? 2 : 4;                                                                         \
-        hipLaunchKernelGGL((emb_bwd_unique_kernel<L, U_, ADAM_>), dim3(grid_u), dim3(256), 0, dr_s(stream), ids,      \
-                           unique_flags, B, F, row_base, D, grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit,      \
-                           slot_lin_grad, scale, dst_table, dst_lin, dst_bias, ad);                                   \
-        hipLaunchKernelGGL((emb_bwd_dups_kernel<L, ADAM_>), dim3(grid_d), dim3(256), 0, dr_s(stream), rows,           \
-                           sorted_slots, n, dup_heads, dup_count, F, D, (uint64_t)num_rows, grad, ld_grad, concat,    \
-                           ld_concat, sum_x, d_fm_logit, slot_lin_grad, scale, dst_table, dst_lin, ad);               \
+        hipLaunchKernelGGL((emb_bwd_sorted_kernel<L, U_, ADAM_>), dim3(grid_d + grid_u), dim3(256), 0, dr_s(stream), ba, ad,    \
+                           grid_d);                                                                                   \
     }
 #define CALL(L)                                                                                                       \
     if (adam != nullptr) LAUNCH(L, true) else LAUNCH(L, false)

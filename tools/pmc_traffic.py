@@ -56,7 +56,7 @@ def main():
     # bench.py event name -> profiled kernel (with DR_FUSE_K3=0 the forward and the dgrad of the first layer are the same kernel
     # instantiation: their traffic is then the average of the two; names absent from the profile are dropped by bench.py)
     event_names = {"emb_linear_fwd_L0": "bf3_emb_linear_kernel", "emb_pool_fwd": "emb_pool_fwd_sv_kernel<16,8>",
-                   "emb_pool_bwd": "emb_bwd_unique_kernel<16,4,false>", "hash_bucket_i64": "hash_bucket_i64_kernel",
+                   "emb_pool_bwd": "emb_bwd_sorted_kernel<16,4,false>", "hash_bucket_i64": "hash_bucket_i64_kernel",
                    "linear_fwd_L0": "bf3_gemm_rs_kernel<0,0>", "linear_bwd_dx_L0": "bf3_gemm_rs_kernel<0,0>",
                    "linear_bwd_dw_L0": "bf3_gemm_tn_rs_kernel"}
     json.dump({"_note": note, "kernels": kernels, "event_names": event_names}, open(out_path, "w"), indent=1, sort_keys=True)
