@@ -280,7 +280,11 @@ def main():
         batches = synth_batches(a, device, rank)
         nb = len(batches)
         # the data loader knows the next batch: its keys are handed over for route prefetch
-        step = lambda i: eng.train_step(*batches[i % nb], next_keys=batches[(i + 1) % nb][0])
+        if isinstance(eng, __import__("deep_recommenders_amd.engine", fromlist=["DeepFMEngine"]).DeepFMEngine):
+            # (single-GPU engine: the next batch's dense features ride along, they are placed while this step's K4 runs)
+            step = lambda i: eng.train_step(*batches[i % nb], next_keys=batches[(i + 1) % nb][0], next_dense=batches[(i + 1) % nb][1])
+        else:
+            step = lambda i: eng.train_step(*batches[i % nb], next_keys=batches[(i + 1) % nb][0])
 
     for i in range(a.warmup):
         step(i)

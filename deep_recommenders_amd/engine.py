@@ -118,7 +118,9 @@ class DeepFMEngine:
         self._ids = [torch.empty((B, F), dtype=torch.int64, device=device) for _ in range(2)]
         self.cur = 0
         self._pref = None            # identity of the keys whose ids / plan sit in buffer cur ^ 1
+        self._pref_dense = None      # identity of the dense features already placed in concat / dense_pad for that batch
         self._next_keys = None
+        self._next_dense = None
         self.concat = torch.zeros((B, self.ld), **f32)
         self.sum_x = torch.empty((B, D), **f32)
         self.fm_logit = torch.empty((B,), **f32)
@@ -213,7 +215,17 @@ class DeepFMEngine:
                 self.side.wait_event(self.ev_k4)
             self._k("next_batch: hash_bucket_i64(side stream, overlapped)", "overlap", self.B * self.F * 16,
                     lambda: ops.hash_bucket_i64(nk, self.col_buckets, out=self._ids[nxt]))
-            self._ev_hashed[nxt].record(self.side)
+            nd = self._next_dense
+            self._pref_dense = None
+            if nd is not None and self.Nd and not self.overlap_dw:
+                # the dense features of that batch too: this step's wgrad (the last reader of concat's dense columns) and forward
+                # (dense_pad) are behind us on the training stream, which the side stream has waited for
+                nd.record_stream(self.side)
+                self.concat[:, self.F * self.D:self.F * self.D + self.Nd].copy_(nd)
+                if self.dense_pad is not None:
+                    self.dense_pad[:, :self.Nd].copy_(nd)
+                self._pref_dense = self._token(nd)
+            self._ev_hashed[nxt].record(self.side)          # what the next forward waits for: ids (+ dense features) in place
             self._k("next_batch: emb_sort_slots(side stream, overlapped)", "overlap", self.B * self.F * 36,
                     lambda: ops.emb_sort_slots(self._ids[nxt], self.row_base, self.R, self._plans[nxt]))
             self._ev_sorted[nxt].record(self.side)
@@ -302,10 +314,11 @@ class DeepFMEngine:
                                              fm_logit=self.fm_logit))
         if self.sorted_bwd and not self.sort_inline and not self.sort_with_k3 and not prefetched:
             self._launch_sort()              # after K3: under the first GEMM and the tower tail
-        if self.Nd:
+        if self.Nd and not (prefetched and self._pref_dense is not None and self._pref_dense == self._token(dense)):
             self.concat[:, F * D:F * D + self.Nd].copy_(dense)                         # layout: append dense feats
-            if fused_l0:
+            if self.dense_pad is not None:
                 self.dense_pad[:, :self.Nd].copy_(dense)                               # the fused kernel's own (k-tile wide) copy
+        self._pref_dense = None
         x = self.concat[:, :self.in_dim]
         head = self.fuse_head and labels is not None
         nl = len(self.Ws)
@@ -457,13 +470,14 @@ class DeepFMEngine:
             if wp is not None:
                 wp.refresh()
 
-    def train_step(self, keys, dense, labels, next_keys=None):
+    def train_step(self, keys, dense, labels, next_keys=None, next_dense=None):
         """One training step.  next_keys (optional): the raw keys of the batch the NEXT call will train on (the data loader knows
-        it; ShardedDeepFMEngine uses the same argument to route ahead): its K1 + slot sort then run beside this step's K4."""
-        self._next_keys = next_keys
+        it; ShardedDeepFMEngine uses the same argument to route ahead): its K1 + slot sort then run beside this step's K4.
+        next_dense (optional, with next_keys): that batch's dense features, placed into the input buffers at the same time."""
+        self._next_keys, self._next_dense = next_keys, next_dense
         self.forward(keys, dense, labels)
         self.backward_and_update()
-        self._next_keys = None
+        self._next_keys = self._next_dense = None
         return self.loss
 
     # algorithmic bytes of the two embedding kernels per step (SURVEY.md §8d)

@@ -328,7 +328,8 @@ def test_engine_next_batch_prefetch_is_bit_identical(optimizer, D, V):
         nxt = order[n + 1] if n + 1 < len(order) else None
         if n == 2:
             nxt = 0                                     # announced batch 0, batch 1 comes: the prefetched plan must be dropped
-        engs[1].train_step(*batches[i], next_keys=None if nxt is None else batches[nxt][0])
+        engs[1].train_step(*batches[i], next_keys=None if nxt is None else batches[nxt][0],
+                           next_dense=None if nxt is None else batches[nxt][1])
         if n == 0:
             # the announced tensor is modified before it is used: its version changes, the prefetched ids are stale
             batches[1][0].add_(1)
