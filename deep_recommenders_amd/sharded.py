@@ -396,6 +396,16 @@ class ShardedDeepFMEngine:
         self.narrow = [hasattr(self.p, "linear_bwd_narrow") and i > 0 and self.acts[i - 1] == 1
                        and self.p.linear_bwd_narrow_supported(Bm, Wt.shape[0], Wt.shape[1]) for i, Wt in enumerate(self.Ws)]
         self.loss_parts = torch.zeros(mb, **f32)
+        # Wide layers on the register-split GEMMs of engine.DeepFMEngine (weights kept as bf16 planes, refreshed after the update):
+        # the dgrad of a micro-batch and the wgrad over the whole rank batch.  The forward stays on the in-kernel-split GEMM below
+        # 65 536 rows: its 256-row tiles number 128 at a 32 768-row micro-batch, half a machine (267 us either way, measured).
+        import os as _os
+        use_planes = self._cuda and self.p is HipPrims and _os.environ.get("DR_PLANES", "1") == "1"
+        self.wplanes = [ops.WeightPlanes(Wt) if (use_planes and ops.planes_worthwhile(Bm, Wt.shape[0], Wt.shape[1])) else None
+                        for Wt in self.Ws]
+        self.wg_ws = [ops.bf3_wgrad_workspace(B, Wt.shape[0], Wt.shape[1], device) if self.wplanes[i] is not None else None
+                      for i, Wt in enumerate(self.Ws)]
+        self.planes_fwd_rows = 65536
         self._events = None
         self._route = None
         self._done = []
@@ -530,8 +540,13 @@ class ShardedDeepFMEngine:
             for i, (Wt, b) in enumerate(zip(self.Ws, self.bs)):
                 if self.fuse_head and i == n_layers - 2:
                     break
-                self._k("linear_fwd_L%d" % i, "mfma", 2.0 * Bm * Wt.shape[0] * Wt.shape[1],
-                        lambda x=x, Wt=Wt, b=b, i=i, sl=sl: p.linear_fwd(x, Wt, b, self.acts[i], out=self.hs[i][sl]))
+                if self.wplanes[i] is not None and Bm >= self.planes_fwd_rows:
+                    self._k("linear_fwd_L%d" % i, "mfma", 2.0 * Bm * Wt.shape[0] * Wt.shape[1],
+                            lambda x=x, b=b, i=i, sl=sl: ops.bf3_linear_nt(x, self.wplanes[i].wt, bias=b, act=self.acts[i],
+                                                                           out=self.hs[i][sl]))
+                else:
+                    self._k("linear_fwd_L%d" % i, "mfma", 2.0 * Bm * Wt.shape[0] * Wt.shape[1],
+                            lambda x=x, Wt=Wt, b=b, i=i, sl=sl: p.linear_fwd(x, Wt, b, self.acts[i], out=self.hs[i][sl]))
                 x = self.hs[i][sl]
             if self.fuse_head:
                 self._k("tower_head_fwd_bwd", "hbm", 4.0 * Bm * (self.Ws[-2].shape[0] + self.Ws[-2].shape[1] + 4),
@@ -562,8 +577,12 @@ class ShardedDeepFMEngine:
                                                                                 self.gbs[i], dx, relu_mask=True,
                                                                                 workspace=self.narrow_ws[i]))
                 else:
-                    self._k("linear_bwd_dx_L%d" % i, "mfma", 2.0 * Bm * self.Ws[i].shape[0] * self.Ws[i].shape[1],
-                            lambda dy=dy, i=i, rs=rs, dx=dx: p.linear_bwd_dx(dy, self.Ws[i], relu_src=rs, out=dx))
+                    if self.wplanes[i] is not None:
+                        self._k("linear_bwd_dx_L%d" % i, "mfma", 2.0 * Bm * self.Ws[i].shape[0] * self.Ws[i].shape[1],
+                                lambda dy=dy, i=i, rs=rs, dx=dx: ops.bf3_linear_nt(dy, self.wplanes[i].w, mask=rs, out=dx))
+                    else:
+                        self._k("linear_bwd_dx_L%d" % i, "mfma", 2.0 * Bm * self.Ws[i].shape[0] * self.Ws[i].shape[1],
+                                lambda dy=dy, i=i, rs=rs, dx=dx: p.linear_bwd_dx(dy, self.Ws[i], relu_src=rs, out=dx))
                     if m == 0:
                         dw_todo.append(i)
                 dy = dx
@@ -594,8 +613,12 @@ class ShardedDeepFMEngine:
         for i in dw_todo:
             xin = x_in if i == 0 else self.hs[i - 1]
             dyi = self.dhs[i] if i < n_layers - 1 else self.d_logit.reshape(-1, 1)
-            self._k("linear_bwd_dw_L%d" % i, "mfma", 2.0 * B * self.Ws[i].shape[0] * self.Ws[i].shape[1],
-                    lambda xin=xin, dyi=dyi, i=i: p.linear_bwd_dw(xin, dyi, 1.0, self.gWs[i], self.gbs[i], workspace=self.dw_ws[i]))
+            if self.wg_ws[i] is not None:
+                self._k("linear_bwd_dw_L%d" % i, "mfma", 2.0 * B * self.Ws[i].shape[0] * self.Ws[i].shape[1],
+                        lambda xin=xin, dyi=dyi, i=i: ops.bf3_wgrad(xin, dyi, 1.0, self.gWs[i], self.gbs[i], workspace=self.wg_ws[i]))
+            else:
+                self._k("linear_bwd_dw_L%d" % i, "mfma", 2.0 * B * self.Ws[i].shape[0] * self.Ws[i].shape[1],
+                        lambda xin=xin, dyi=dyi, i=i: p.linear_bwd_dw(xin, dyi, 1.0, self.gWs[i], self.gbs[i], workspace=self.dw_ws[i]))
         # ---- dense tower: one all-reduce, then w += -(lr / W) * sum_r g_r  (mean over the global batch) ------
         self._k("allreduce_dense_grads", "xgmi", self.flat_grads.numel() * 4,
                 lambda: dist.all_reduce(self.flat_grads, group=self.group))
@@ -603,6 +626,9 @@ class ShardedDeepFMEngine:
             p.adam_step(self.flat_params, self.flat_grads, self.flat_m, self.flat_v, adam_args[0], self.beta1, self.beta2, self.eps)
         else:
             p.axpy(-self.lr / W, self.flat_grads, self.flat_params)
+        for wp in self.wplanes:
+            if wp is not None:
+                wp.refresh()                               # the weights just moved: their planes follow
         torch.sum(self.loss_parts, dim=0, keepdim=True, out=self.loss)
         if adam:
             self.loss.mul_(W)          # loss_parts were normalised by the global batch: report the rank's mean like the SGD mode
