@@ -275,8 +275,8 @@ __global__ __launch_bounds__(256) void pack_grads_kernel(const int64_t* __restri
     }
 }
 
-__global__ __launch_bounds__(256) void axpy_kernel(int64_t n, float alpha, const float* __restrict__ x,
-                                                   float* __restrict__ y) {
+// (no __restrict__: x == y is a legal call, y *= 1 + alpha)
+__global__ __launch_bounds__(256) void axpy_kernel(int64_t n, float alpha, const float* x, float* y) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = fmaf(alpha, x[i], y[i]);
 }

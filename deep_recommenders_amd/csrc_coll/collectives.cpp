@@ -63,17 +63,29 @@ extern "C" int dr_coll_destroy(dr_comm_t comm) {
 extern "C" int32_t dr_coll_world(dr_comm_t comm) { return comm ? static_cast<Comm*>(comm)->world : 0; }
 extern "C" int32_t dr_coll_rank(dr_comm_t comm) { return comm ? static_cast<Comm*>(comm)->rank : -1; }
 
+// Inside an open ncclGroupStart a failing call must still be followed by ncclGroupEnd, or the communicator stays in an open group
+// and every later collective queues behind it: errors are remembered, the group is always closed.
+#define RCCL_IN_GROUP(call, what)                                  \
+    do {                                                           \
+        if (rc == DRC_OK) {                                        \
+            ncclResult_t r__ = (call);                             \
+            if (r__ != ncclSuccess) rc = fail(r__, what);          \
+        }                                                          \
+    } while (0)
+
 extern "C" int dr_coll_alltoall_i64(dr_comm_t comm, const int64_t* send, int64_t* recv, int64_t per_peer, drc_stream_t stream) {
     if (!comm || !send || !recv || per_peer < 0) return DRC_EINVAL;
     Comm* c = static_cast<Comm*>(comm);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc = DRC_OK;
     RCCL_TRY(ncclGroupStart(), "ncclGroupStart");
     for (int p = 0; p < c->world; ++p) {
-        RCCL_TRY(ncclSend(send + (int64_t)p * per_peer, (size_t)per_peer, ncclInt64, p, c->nccl, s), "ncclSend");
-        RCCL_TRY(ncclRecv(recv + (int64_t)p * per_peer, (size_t)per_peer, ncclInt64, p, c->nccl, s), "ncclRecv");
+        RCCL_IN_GROUP(ncclSend(send + (int64_t)p * per_peer, (size_t)per_peer, ncclInt64, p, c->nccl, s), "ncclSend");
+        RCCL_IN_GROUP(ncclRecv(recv + (int64_t)p * per_peer, (size_t)per_peer, ncclInt64, p, c->nccl, s), "ncclRecv");
     }
-    RCCL_TRY(ncclGroupEnd(), "ncclGroupEnd");
-    return DRC_OK;
+    const ncclResult_t re = ncclGroupEnd();
+    if (rc == DRC_OK && re != ncclSuccess) rc = fail(re, "ncclGroupEnd");
+    return rc;
 }
 
 extern "C" int dr_coll_alltoallv(dr_comm_t comm, const void* send, const int64_t* send_counts, void* recv,
@@ -83,25 +95,24 @@ extern "C" int dr_coll_alltoallv(dr_comm_t comm, const void* send, const int64_t
     hipStream_t s = static_cast<hipStream_t>(stream);
     const char* sp = static_cast<const char*>(send);
     char* rp = static_cast<char*>(recv);
-    for (int p = 0; p < c->world; ++p)
+    // every argument is validated BEFORE the group opens
+    for (int p = 0; p < c->world; ++p) {
         if (send_counts[p] < 0 || recv_counts[p] < 0) return DRC_EINVAL;
+        if ((send_counts[p] > 0 && !sp) || (recv_counts[p] > 0 && !rp)) return DRC_EINVAL;
+    }
+    int rc = DRC_OK;
     RCCL_TRY(ncclGroupStart(), "ncclGroupStart");
     int64_t so = 0, ro = 0;
     for (int p = 0; p < c->world; ++p) {
         const int64_t sb = send_counts[p] * elem_bytes, rb = recv_counts[p] * elem_bytes;
-        if (sb > 0) {
-            if (!sp) return DRC_EINVAL;
-            RCCL_TRY(ncclSend(sp + so, (size_t)sb, ncclInt8, p, c->nccl, s), "ncclSend");
-        }
-        if (rb > 0) {
-            if (!rp) return DRC_EINVAL;
-            RCCL_TRY(ncclRecv(rp + ro, (size_t)rb, ncclInt8, p, c->nccl, s), "ncclRecv");
-        }
+        if (sb > 0) RCCL_IN_GROUP(ncclSend(sp + so, (size_t)sb, ncclInt8, p, c->nccl, s), "ncclSend");
+        if (rb > 0) RCCL_IN_GROUP(ncclRecv(rp + ro, (size_t)rb, ncclInt8, p, c->nccl, s), "ncclRecv");
         so += sb;
         ro += rb;
     }
-    RCCL_TRY(ncclGroupEnd(), "ncclGroupEnd");
-    return DRC_OK;
+    const ncclResult_t re = ncclGroupEnd();
+    if (rc == DRC_OK && re != ncclSuccess) rc = fail(re, "ncclGroupEnd");
+    return rc;
 }
 
 extern "C" int dr_coll_allreduce_f32(dr_comm_t comm, float* buf, int64_t n, drc_stream_t stream) {

@@ -108,8 +108,17 @@ class DCNEngine:
             fl += 2 * self.B * W.shape[0] * W.shape[1]
         return 3 * fl
 
+    def refresh_planes(self):
+        """Re-split every cross / MLP weight into its bf16 planes (see ops.WeightPlanes.ensure_fresh for when this is needed)."""
+        for wp in list(self.cross_planes) + list(self.wplanes):
+            if wp is not None:
+                wp.refresh()
+
     def train_step(self, keys, dense, labels, next_keys=None):
         F, D, B, lr, n_in = self.F, self.D, self.B, self.lr, self.in_dim
+        for wp in list(self.cross_planes) + list(self.wplanes):     # weights written from outside since the last refresh: re-split
+            if wp is not None:
+                wp.ensure_fresh()
         # ---- forward -----------------------------------------------------------------------------------------------
         self._k("hash_bucket_i64", "hbm", B * F * 16, lambda: ops.hash_bucket_i64(keys, self.col_buckets, out=self.ids))
         self._k("emb_pool_fwd", "hbm", B * (8 * F * D + 8 * F),

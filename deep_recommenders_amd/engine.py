@@ -168,6 +168,7 @@ class DeepFMEngine:
             self.ev_dw_done = torch.cuda.Event()
             self.ev_planes = torch.cuda.Event()
         self._planes_pending = False
+        self._planes_pending_l0 = False
         # First-layer wgrad on a second stream, concurrent with the HBM-bound K4 on the training stream.  It paid next to the
         # in-kernel-split wgrad (2 blocks / CU, matrix pipe ~35 % busy: 1.91 -> 1.84 ms / step); next to the register-split wgrad
         # (one 512-thread block per CU holding all its registers and 96 KB of LDS) the two kernels only time-slice the CUs: the
@@ -206,7 +207,10 @@ class DeepFMEngine:
         if nk is None or not (self.sorted_bwd and not self.sort_inline and self.prefetch_plan):
             return
         nxt = self.cur ^ 1
-        ordered = self._planes_pending and self.lean_events   # the side stream already waits for the last wgrad (plane refresh)
+        # the side stream already waits for the LAYER-0 wgrad (the last reader of concat's dense columns) iff the plane refresh
+        # queued last was layer 0's; with e.g. dnn_units [64, 256] layer 0 has no planes and the last refresh waited only for
+        # layer 1's wgrad: then the side chain takes its own event behind everything on the training stream
+        ordered = self._planes_pending and self._planes_pending_l0 and self.lean_events
         if not ordered:
             self.ev_k4.record()
         nk.record_stream(self.side)
@@ -290,7 +294,11 @@ class DeepFMEngine:
         if self._planes_pending:         # the previous step's weight planes were refreshed on the side stream
             torch.cuda.current_stream().wait_event(self.ev_planes)
             self._planes_pending = False
-        prefetched = self._pref is not None and self._pref == self._token(keys)
+        for wp in self.wplanes:          # weights written from outside since the last refresh (load / copy_ / fill_): re-split
+            if wp is not None:
+                wp.ensure_fresh()
+        pref_tok = self._pref
+        prefetched = pref_tok is not None and pref_tok == self._token(keys)
         self._pref = None
         self._plan_prefetched = prefetched
         if prefetched:
@@ -298,6 +306,10 @@ class DeepFMEngine:
             self.cur ^= 1
             torch.cuda.current_stream().wait_event(self._ev_hashed[self.cur])
         else:
+            if pref_tok is not None:
+                # a prefetch was issued for OTHER keys and is discarded: its side-stream copy of that batch's dense features into
+                # concat / dense_pad must be behind us before this forward writes its own
+                torch.cuda.current_stream().wait_event(self._ev_hashed[self.cur ^ 1])
             self._k("hash_bucket_i64", "hbm", B * F * 16,
                     lambda: ops.hash_bucket_i64(keys, self.col_buckets, out=self.ids))                # K1
         if self.sorted_bwd and self.sort_inline:
@@ -417,6 +429,7 @@ class DeepFMEngine:
                         self.wplanes[i].refresh()
                         self.ev_planes.record(self.side)
                     self._planes_pending = True
+                    self._planes_pending_l0 = (i == 0)
                 else:
                     self.wplanes[i].refresh()
             dy = dx
@@ -466,6 +479,13 @@ class DeepFMEngine:
         self._k("adam_step_dense", "hbm", 28.0 * self.flat_params.numel(),
                 lambda: ops.adam_step(self.flat_params, self.flat_grads, self.flat_m, self.flat_v, lr_t, self.beta1, self.beta2,
                                       self.eps))
+        for wp in self.wplanes:
+            if wp is not None:
+                wp.refresh()
+
+    def refresh_planes(self):
+        """Re-split every wide layer's weight into its bf16 planes.  Needed only after writing eng.Ws / eng.flat_params through a path
+        torch's version counter does not see (a raw-pointer kernel); torch-side writes are picked up by forward() itself."""
         for wp in self.wplanes:
             if wp is not None:
                 wp.refresh()

@@ -890,6 +890,14 @@ class WeightPlanes:
     def refresh(self):
         bf3_split(self.W, self.wt, transpose=True)
         bf3_split(self.W, self.w)
+        self._ver = self.W._version
+
+    def ensure_fresh(self):
+        """Planes are SHADOW copies: forward / dgrad read them, not W.  The engines refresh them after their own (kernel-side)
+        updates; a write to W from outside -- checkpoint restore, W.copy_ / fill_ in a test, a broadcast -- bumps torch's version
+        counter of the parameter buffer, which is what this checks at the top of every step (host compare, no launch)."""
+        if self.W._version != self._ver:
+            self.refresh()
 
 
 def planes_worthwhile(M, K, N):

@@ -470,6 +470,12 @@ class ShardedDeepFMEngine:
             for r in self._route[0]:
                 self.ex.route_finish(r)
 
+    def refresh_planes(self):
+        """Re-split the wide layers' weights into their bf16 planes (see ops.WeightPlanes.ensure_fresh)."""
+        for wp in self.wplanes:
+            if wp is not None:
+                wp.refresh()
+
     def train_step(self, keys, dense, labels, next_keys=None, next_keys_ready=None):
         """One step.  The rank's batch is processed as `self.mb` micro-batches that share one set of weights (all
         forwards read pre-update tables; the dense gradients are summed; the loss is the mean over world * B examples):
@@ -478,6 +484,9 @@ class ShardedDeepFMEngine:
         p, F, D, W, B, M = self.p, self.F, self.D, self.world, self.B, self.mb
         Bm = B // M
         cuda = self._cuda
+        for wp in self.wplanes:          # weights written from outside since the last refresh (load / copy_ / broadcast): re-split
+            if wp is not None:
+                wp.ensure_fresh()
         adam = self.optimizer == "adam"
         # SGD: gradients of the RANK-mean loss travel, the 1 / W of the global mean is folded into the step (-lr / W).
         # Adam: the update is not linear in the gradient, so the head normalises by the global batch and every gradient that
@@ -558,6 +567,11 @@ class ShardedDeepFMEngine:
             else:                                          # M == 1 here (see __init__)
                 p.bce_fwd_bwd(self.fm_logit, labels, ops.LOSS_SIGMOID_CE, workspace=self.ws, logits_b=self.hs[-1],
                               out=(self.prob, self.d_logit, self.loss_parts[0:1]))
+                if adam and W > 1:
+                    # this loss kernel normalises by the RANK batch; Adam needs every travelling gradient to be that of the
+                    # global-mean loss (what the fused head does through n_total): d_logit *= 1 / W.  loss_parts stays the
+                    # rank mean, which is what train_step reports.
+                    p.axpy(1.0 / W - 1.0, self.d_logit, self.d_logit)
             # ---- dgrad chain (produces d_concat, the input of the embedding exchange) ------------------------------
             dy = self.d_logit[sl].reshape(-1, 1)
             top = n_layers - 1
@@ -630,7 +644,7 @@ class ShardedDeepFMEngine:
             if wp is not None:
                 wp.refresh()                               # the weights just moved: their planes follow
         torch.sum(self.loss_parts, dim=0, keepdim=True, out=self.loss)
-        if adam:
+        if adam and self.fuse_head:
             self.loss.mul_(W)          # loss_parts were normalised by the global batch: report the rank's mean like the SGD mode
         if cuda:
             main.wait_event(ev_last_apply)                 # the step ends when every owner has applied its updates

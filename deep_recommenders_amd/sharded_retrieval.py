@@ -58,9 +58,24 @@ def sharded_topk(q_local, corpus_shard, shard_item_ids, k, world, rank, prims=Re
     B = q_local.shape[0]
     q_all = _all_gather(q_local, world, group)                                   # [world * B, Do]
     n_loc = corpus_shard.shape[0]
-    k_loc = min(k, n_loc)
-    s_loc, i_loc = prims.topk_mips(q_all, corpus_shard, k_loc)                   # local row numbers
-    gid = prims.gather_i64(shard_item_ids, i_loc.reshape(-1)).reshape(i_loc.shape)   # row number -> item id (k_loc <= n_loc: no empty slots)
+    # ONE list length on every rank: the equal-split all-to-all below needs identically shaped tensors, and shard sizes differ by
+    # one row when the corpus does not divide by the world size.  The length is min(k, LARGEST shard); a smaller shard
+    # pads its lists with (-inf, -1), which every merge ranks last.
+    n_max = n_loc
+    if world > 1:
+        nm = torch.tensor([n_loc], dtype=torch.int64, device=q_local.device)
+        dist.all_reduce(nm, op=dist.ReduceOp.MAX, group=group)
+        n_max = int(nm.item())
+    k_loc = min(k, n_max)
+    k_own = min(k_loc, n_loc)
+    s_loc, i_loc = prims.topk_mips(q_all, corpus_shard, k_own)                   # local row numbers
+    gid = prims.gather_i64(shard_item_ids, i_loc.reshape(-1)).reshape(i_loc.shape)   # row number -> item id (k_own <= n_loc: no empty slots)
+    if k_own < k_loc:
+        pad_s = torch.full((s_loc.shape[0], k_loc), float("-inf"), dtype=s_loc.dtype, device=s_loc.device)
+        pad_i = torch.full((s_loc.shape[0], k_loc), -1, dtype=gid.dtype, device=gid.device)
+        pad_s[:, :k_own].copy_(s_loc)
+        pad_i[:, :k_own].copy_(gid)
+        s_loc, gid = pad_s, pad_i
     recv_s = torch.empty_like(s_loc)
     recv_i = torch.empty_like(gid)
     dist.all_to_all_single(recv_s, s_loc.contiguous(), group=group)              # chunk r (the lists of rank r's queries) -> rank r

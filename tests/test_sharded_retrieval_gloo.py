@@ -127,7 +127,8 @@ def _worker(rank, world, port, outdir):
         hits = eng.metric_step(k[sl].contiguous(), i[sl].contiguous(), ks=(1, 3, 5))
         _, _, q, cemb = eng.embeddings(k[sl].contiguous(), i[sl].contiguous())
         s, ids = eng.topk(q, 5)
-        torch.save(dict(rank=rank, losses=losses, user_table=eng.user_table.clone(), item_table=eng.item_table.clone(),
+        s24, ids24 = eng.topk(q, 24)         # k > the smaller shard's 23 rows (47 items over 2 ranks): padded lists
+        torch.save(dict(rank=rank, topk24_s=s24.clone(), topk24_i=ids24.clone(), losses=losses, user_table=eng.user_table.clone(), item_table=eng.item_table.clone(),
                         params=eng.flat_params.clone(), params0=params0, hits=hits.clone(), q=q.clone(), c=cemb.clone(),
                         topk_s=s.clone(), topk_i=ids.clone(), corpus=eng.corpus.clone()), os.path.join(outdir, "rank%d.pt" % rank))
     finally:
@@ -201,6 +202,9 @@ def test_two_rank_two_tower_equals_single_process_oracle(tmp_path):
         ws, wi = O.brute_force_top_k(res[r]["q"].numpy(), corpus.numpy(), k=5)
         np.testing.assert_allclose(res[r]["topk_s"].numpy(), ws, rtol=1e-6, atol=1e-7)
         assert np.array_equal(res[r]["topk_i"].numpy(), wi)
+        ws, wi = O.brute_force_top_k(res[r]["q"].numpy(), corpus.numpy(), k=24)
+        np.testing.assert_allclose(res[r]["topk24_s"].numpy(), ws, rtol=1e-6, atol=1e-7)
+        assert np.array_equal(res[r]["topk24_i"].numpy(), wi)
         want = O.factorized_top_k_accuracy(res[r]["q"].numpy(), res[r]["c"].numpy(), corpus.numpy(), (1, 3, 5), k=5)
         # the positive is itself in the corpus: its score as rowdot(q, c) and as a corpus score can differ in the last bit
         # (different matmul shapes), which flips a strict comparison -- allow one example per k
