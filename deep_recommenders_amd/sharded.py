@@ -59,6 +59,56 @@ class HipPrims:
     cross_combine_bwd = staticmethod(ops.cross_combine_bwd)
 
 
+class TorchDistTransport:
+    """The exchange steps over torch.distributed: backend "nccl" == RCCL over xGMI on the GPUs, "gloo" in the CPU tests."""
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def alltoall(self, out, inp, out_splits=None, in_splits=None):
+        dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
+        return out
+
+    def allreduce(self, t, async_op=False, op=None):
+        return dist.all_reduce(t, op=op if op is not None else dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+
+    def allgather(self, out, inp):
+        dist.all_gather_into_tensor(out, inp, group=self.group)
+        return out
+
+
+class _DoneWork:
+    def wait(self):
+        return True
+
+
+class HostStagedTransport(TorchDistTransport):
+    """Device buffers through host memory over a CPU (gloo) group.  RCCL refuses two ranks on one device; this lets TWO ranks share
+    ONE GPU, so the N > 1 exchange logic runs with the real HIP kernels on a single-GPU box (tests/test_gpu_sharded_two_rank.py).
+    Blocking and slow by construction -- verification only, never a bench path."""
+
+    def _to_host(self, t):
+        return t.detach().to("cpu")            # enqueued on the current stream, the host waits for it
+
+    def alltoall(self, out, inp, out_splits=None, in_splits=None):
+        h_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(h_out, self._to_host(inp).contiguous(), out_splits, in_splits, group=self.group)
+        out.copy_(h_out)
+        return out
+
+    def allreduce(self, t, async_op=False, op=None):
+        h = self._to_host(t).contiguous()
+        dist.all_reduce(h, op=op if op is not None else dist.ReduceOp.SUM, group=self.group)
+        t.copy_(h)
+        return _DoneWork() if async_op else None
+
+    def allgather(self, out, inp):
+        h_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(h_out, self._to_host(inp).contiguous(), group=self.group)
+        out.copy_(h_out)
+        return out
+
+
 class Route:
     """Everything about one batch that depends only on its keys: where each slot's row lives, how many rows travel to /
     from each rank, the owner-side list of requested rows and its sort plan.  Built by ShardedEmbeddingExchange.route()
@@ -84,13 +134,20 @@ class ShardedEmbeddingExchange:
     GROUP = 32      # pseudo-fields per pseudo-example of the owner-side slot list
     SLOTS = 4       # routes in flight: (micro-batches per step = 2) x (the step being trained + the prefetched one)
 
-    def __init__(self, num_fields, vocab_per_field, dim, world, rank, device, prims=None, group=None):
+    def __init__(self, num_fields, vocab_per_field, dim, world, rank, device, prims=None, group=None, transport=None,
+                 alias_world1=True):
         self.F, self.V, self.D = num_fields, vocab_per_field, dim
         self.world, self.rank, self.dev = world, rank, device
         self.rows_per_shard = (vocab_per_field + world - 1) // world
         self.local_rows = num_fields * self.rows_per_shard
         self.p = prims if prims is not None else HipPrims
         self.group = group
+        self.tr = transport if transport is not None else TorchDistTransport(group)
+        # One rank owns everything: every "exchange" is the identity.  The buffers then ALIAS (bucketing writes the owner-side row
+        # list, the gather output is the receive buffer, the packed gradients are written where the owner-side K4 reads them) and
+        # no collective is issued -- RCCL used to copy 2 x 443 MB to itself per step.  alias_world1=False keeps the
+        # collectives (a group of one), which is how the tests push the N > 1 code through RCCL on a single GPU.
+        self.local = world == 1 and alias_world1 and (prims is None or prims is HipPrims)
         self._zero_base = torch.zeros(num_fields, dtype=torch.int64, device=device)
         self._zero_base_g = torch.zeros(self.GROUP, dtype=torch.int64, device=device)
         self._col_start = torch.arange(num_fields + 1, dtype=torch.int32, device=device)
@@ -107,8 +164,7 @@ class ShardedEmbeddingExchange:
         self._next_slot = 0
 
     def _a2a(self, out, inp, out_splits, in_splits):
-        dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
-        return out
+        return self.tr.alltoall(out, inp, out_splits, in_splits)
 
     def _ensure_capacity(self, sl, n_recv, device):
         G = self.GROUP
@@ -151,9 +207,21 @@ class ShardedEmbeddingExchange:
                 ids = keys
             B, F = ids.shape
             r.n = B * F
+            if self.local:
+                # no peers: the bucketed row list IS the owner-side list (written straight into the padded slot buffer), the split
+                # sizes are known without asking the device
+                r.n_recv = r.n
+                r.n_pad = self._ensure_capacity(sl, r.n, ids.device)
+                rows_pad = sl["rows_pad"][:r.n_pad]
+                rows_pad[r.n:].fill_(-1)
+                _, send_rows, pos = self.p.shard_bucket_ids(ids, self.rows_per_shard, W, send_rows=rows_pad[:r.n])
+                r.send_splits = r.recv_splits = [r.n]
+                r._counts_host = r._counts_ev = None
+                r.pos, r._send_rows = pos, None
+                return r
             counts, send_rows, pos = self.p.shard_bucket_ids(ids, self.rows_per_shard, W)
             recv_counts = torch.empty_like(counts)
-            dist.all_to_all_single(recv_counts, counts, group=self.group)                 # split sizes
+            self.tr.alltoall(recv_counts, counts)                                         # split sizes
             both = torch.stack([counts, recv_counts])
             if self._cuda:
                 if sl.get("counts_host") is None:
@@ -173,17 +241,21 @@ class ShardedEmbeddingExchange:
         if r._finished:
             return r
         sl = self._slots[r.slot]
-        if r._counts_ev is not None:
-            r._counts_ev.synchronize()
-        r.send_splits = [int(v) for v in r._counts_host[0].tolist()]
-        r.recv_splits = [int(v) for v in r._counts_host[1].tolist()]
-        r.n_recv = sum(r.recv_splits)
+        if not self.local:
+            if r._counts_ev is not None:
+                r._counts_ev.synchronize()
+            r.send_splits = [int(v) for v in r._counts_host[0].tolist()]
+            r.recv_splits = [int(v) for v in r._counts_host[1].tolist()]
+            r.n_recv = sum(r.recv_splits)
         ctx = torch.cuda.stream(self._rs) if self._cuda else _NullCtx()
         with ctx:
-            r.n_pad = self._ensure_capacity(sl, r.n_recv, r.pos.device)
-            rows_pad = sl["rows_pad"][:r.n_pad]
-            rows_pad[r.n_recv:].fill_(-1)
-            self._a2a(rows_pad[:r.n_recv], r._send_rows, r.recv_splits, r.send_splits)      # C1
+            if not self.local:
+                r.n_pad = self._ensure_capacity(sl, r.n_recv, r.pos.device)
+                rows_pad = sl["rows_pad"][:r.n_pad]
+                rows_pad[r.n_recv:].fill_(-1)
+                self._a2a(rows_pad[:r.n_recv], r._send_rows, r.recv_splits, r.send_splits)      # C1
+            else:
+                rows_pad = sl["rows_pad"][:r.n_pad]
             if self._cuda:
                 r.ready = torch.cuda.Event()
                 r.ready.record(self._rs)
@@ -208,6 +280,9 @@ class ShardedEmbeddingExchange:
             torch.cuda.current_stream().wait_event(r.ready)
         recv_rows = sl["rows_pad"][:r.n_recv]
         rows_buf, lin_buf = self.p.rows_gather(recv_rows, table_local, lin_local)     # owner-side gather
+        r.has_lin = lin_local is not None
+        if self.local:
+            return rows_buf, lin_buf                                                   # the gather output IS the receive buffer
         got_rows = torch.empty((r.n, self.D), dtype=torch.float32, device=recv_rows.device)
         self._a2a(got_rows, rows_buf, r.send_splits, r.recv_splits)                   # C2
         got_lin = None
@@ -236,8 +311,13 @@ class ShardedEmbeddingExchange:
     def pack(self, route, d_concat, d_fm_logit, concat, sum_x, g_bias=None):
         """requesting side: per-slot gradients into the send layout (local, HBM-bound)"""
         r = route
-        g_rows = torch.empty((r.n, self.D), dtype=torch.float32, device=r.pos.device)
-        g_lin = torch.empty(r.n, dtype=torch.float32, device=r.pos.device) if r.has_lin else None
+        if self.local:                       # straight into the buffers the owner-side K4 reads (nothing travels)
+            sl = self._slots[r.slot]
+            g_rows = sl["g_pad"][:r.n]
+            g_lin = sl["gl_pad"][:r.n] if r.has_lin else None
+        else:
+            g_rows = torch.empty((r.n, self.D), dtype=torch.float32, device=r.pos.device)
+            g_lin = torch.empty(r.n, dtype=torch.float32, device=r.pos.device) if r.has_lin else None
         self.p.emb_pack_grads(r.pos, self.D, d_concat, concat, sum_x, d_fm_logit, g_rows, g_lin, g_bias)
         return g_rows, g_lin
 
@@ -254,9 +334,10 @@ class ShardedEmbeddingExchange:
             g_rows.record_stream(cur)
             if g_lin is not None:
                 g_lin.record_stream(cur)
-        self._a2a(g_pad[:r.n_recv], g_rows, r.recv_splits, r.send_splits)             # C3
-        if r.has_lin:
-            self._a2a(gl_pad[:r.n_recv], g_lin, r.recv_splits, r.send_splits)
+        if not self.local:
+            self._a2a(g_pad[:r.n_recv], g_rows, r.recv_splits, r.send_splits)         # C3
+            if r.has_lin:
+                self._a2a(gl_pad[:r.n_recv], g_lin, r.recv_splits, r.send_splits)
         if self._cuda:
             torch.cuda.current_stream().wait_event(r.sorted)
         if adam is not None:
@@ -288,7 +369,8 @@ class ShardedDeepFMEngine:
 
     def __init__(self, num_fields, vocab_per_field, dim, dnn_units: Sequence[int], batch, num_dense=0, lr=0.01,
                  device="cuda", world=None, rank=None, seed=42, prims=None, group=None, lin_init_std=0.0,
-                 init_tables=None, micro_batches=None, optimizer="sgd", beta1=0.9, beta2=0.999, eps=1e-8):
+                 init_tables=None, micro_batches=None, optimizer="sgd", beta1=0.9, beta2=0.999, eps=1e-8, transport=None,
+                 alias_world1=True):
         assert optimizer in ("sgd", "adam")
         self.optimizer, self.beta1, self.beta2, self.eps, self.t = optimizer, beta1, beta2, eps, 0
         self.world = world if world is not None else dist.get_world_size(group)
@@ -297,7 +379,9 @@ class ShardedDeepFMEngine:
         self.Nd, self.lr, self.dev, self.group = num_dense, lr, device, group
         self.p = prims if prims is not None else HipPrims
         F, V, D, B, W = self.F, self.V, self.D, self.B, self.world
-        self.ex = ShardedEmbeddingExchange(F, V, D, W, self.rank, device, self.p, group)
+        self.ex = ShardedEmbeddingExchange(F, V, D, W, self.rank, device, self.p, group, transport=transport,
+                                           alias_world1=alias_world1)
+        self.tr = self.ex.tr
         rps = self.ex.rows_per_shard
         g = torch.Generator(device=device)
         g.manual_seed(seed)               # dense tower: same seed on every rank -> identical replicas
@@ -406,6 +490,12 @@ class ShardedDeepFMEngine:
         self.wg_ws = [ops.bf3_wgrad_workspace(B, Wt.shape[0], Wt.shape[1], device) if self.wplanes[i] is not None else None
                       for i, Wt in enumerate(self.Ws)]
         self.planes_fwd_rows = 65536
+        # K3 inside the first layer's GEMM, over the RECEIVED rows: the register-split kernel gathers its activation operand by
+        # LDS-DMA and does not care where the rows live -- table := the receive buffer, ids := each slot's position in it, one
+        # "field" of n rows (engine.DeepFMEngine's fused first layer; DR_FUSE_K3=0: K3 + a separate GEMM as in round 2).
+        self.fuse_k3 = (use_planes and _os.environ.get("DR_FUSE_K3", "1") == "1" and D == 64 and self.Nd <= 32
+                        and self.wplanes[0] is not None and B * F <= (1 << 24) and self.acts[0] in (0, 1))
+        self.dense_pad = torch.zeros((B, 32), **f32) if (self.fuse_k3 and self.Nd) else None
         self._events = None
         self._route = None
         self._done = []
@@ -418,7 +508,7 @@ class ShardedDeepFMEngine:
     # Phases that get HIP events in bench.py.  The sharded step issues ~3x the launches of the single-GPU step (two
     # micro-batches, exchanges, routing) and its host thread is the scarcer resource: two event records around every small
     # kernel were enough to leave ~30 us bubbles between kernels, so only the coarse phases are bracketed.
-    _TIMED = ("emb_fetch", "emb_pool_fwd", "linear_fwd_L0", "linear_bwd_dx_L0", "linear_bwd_dw_L0", "emb_pack_grads",
+    _TIMED = ("emb_fetch", "emb_pool_fwd", "emb_linear_fwd_L0", "linear_fwd_L0", "linear_bwd_dx_L0", "linear_bwd_dw_L0", "emb_pack_grads",
               "emb_grads", "allreduce_dense_grads", "emb_route")
 
     def _k(self, name, bound, work, fn):
@@ -531,6 +621,8 @@ class ShardedDeepFMEngine:
         self.flat_grads.zero_()
         if self.Nd:
             self.concat[:, F * D:F * D + self.Nd].copy_(dense)
+            if self.dense_pad is not None:
+                self.dense_pad[:, :self.Nd].copy_(dense)               # the fused kernel's own (k-tile wide) copy
         n_layers = len(self.Ws)
         x_in = self.concat[:, :self.in_dim]
         dys = [None] * n_layers
@@ -542,14 +634,26 @@ class ShardedDeepFMEngine:
             # ---- step 6 + tower forward + loss ----------------------------------------------------------------------
             if cuda:
                 main.wait_event(ev_rows[m])
-            self._k("emb_pool_fwd", "hbm", Bm * (8 * F * D + 12 * F + 8),
-                    lambda m=m, sl=sl: self.ex.pool(routes[m], got[m][0], got[m][1], self.lin_bias, self.ld, concat=self.concat[sl],
-                                                   sum_x=self.sum_x[sl], fm_logit=self.fm_logit[sl]))
+            fused_l0 = self.fuse_k3 and not (self.fuse_head and n_layers - 2 == 0)
+            if not fused_l0:
+                self._k("emb_pool_fwd", "hbm", Bm * (8 * F * D + 12 * F + 8),
+                        lambda m=m, sl=sl: self.ex.pool(routes[m], got[m][0], got[m][1], self.lin_bias, self.ld, concat=self.concat[sl],
+                                                       sum_x=self.sum_x[sl], fm_logit=self.fm_logit[sl]))
             x = x_in[sl]
             for i, (Wt, b) in enumerate(zip(self.Ws, self.bs)):
                 if self.fuse_head and i == n_layers - 2:
                     break
-                if self.wplanes[i] is not None and Bm >= self.planes_fwd_rows:
+                if i == 0 and fused_l0:
+                    rows_m, lin_m = got[m]
+                    for t in (routes[m].pos, rows_m, lin_m):
+                        if t is not None:
+                            t.record_stream(main)
+                    self._k("emb_linear_fwd_L0", "mfma", 2.0 * Bm * Wt.shape[0] * Wt.shape[1],
+                            lambda m=m, sl=sl, b=b, rows_m=rows_m, lin_m=lin_m: ops.bf3_emb_linear_fwd(
+                                routes[m].pos, self.ex._zero_base, rows_m.shape[0], rows_m, lin_m, self.lin_bias,
+                                self.dense_pad[sl] if self.dense_pad is not None else None, self.concat[sl], self.in_dim,
+                                self.wplanes[0].wt, b, self.acts[0], self.sum_x[sl], self.fm_logit[sl], self.hs[0][sl]))
+                elif self.wplanes[i] is not None and Bm >= self.planes_fwd_rows:
                     self._k("linear_fwd_L%d" % i, "mfma", 2.0 * Bm * Wt.shape[0] * Wt.shape[1],
                             lambda x=x, b=b, i=i, sl=sl: ops.bf3_linear_nt(x, self.wplanes[i].wt, bias=b, act=self.acts[i],
                                                                            out=self.hs[i][sl]))
@@ -634,8 +738,8 @@ class ShardedDeepFMEngine:
                 self._k("linear_bwd_dw_L%d" % i, "mfma", 2.0 * B * self.Ws[i].shape[0] * self.Ws[i].shape[1],
                         lambda xin=xin, dyi=dyi, i=i: p.linear_bwd_dw(xin, dyi, 1.0, self.gWs[i], self.gbs[i], workspace=self.dw_ws[i]))
         # ---- dense tower: one all-reduce, then w += -(lr / W) * sum_r g_r  (mean over the global batch) ------
-        self._k("allreduce_dense_grads", "xgmi", self.flat_grads.numel() * 4,
-                lambda: dist.all_reduce(self.flat_grads, group=self.group))
+        if not self.ex.local:
+            self._k("allreduce_dense_grads", "xgmi", self.flat_grads.numel() * 4, lambda: self.tr.allreduce(self.flat_grads))
         if adam:
             p.adam_step(self.flat_params, self.flat_grads, self.flat_m, self.flat_v, adam_args[0], self.beta1, self.beta2, self.eps)
         else:
@@ -661,14 +765,17 @@ class ShardedDCNEngine:
     embedding gradients travel back to their owners.  `batch` is the per-rank batch; the loss is the mean over world * batch."""
 
     def __init__(self, num_fields, vocab_per_field, dim, num_cross, dnn_units: Sequence[int], batch, num_dense=0, lr=0.01,
-                 diag_scale=0.0, device="cuda", world=None, rank=None, seed=42, prims=None, group=None, init_tables=None):
+                 diag_scale=0.0, device="cuda", world=None, rank=None, seed=42, prims=None, group=None, init_tables=None,
+                 transport=None, alias_world1=True):
         self.world = world if world is not None else dist.get_world_size(group)
         self.rank = rank if rank is not None else dist.get_rank(group)
         self.F, self.V, self.D, self.B, self.Nd, self.lr, self.diag = num_fields, vocab_per_field, dim, batch, num_dense, lr, diag_scale
         self.group, self.dev = group, device
         self.p = prims if prims is not None else HipPrims
         F, V, D, B, W = num_fields, vocab_per_field, dim, batch, self.world
-        self.ex = ShardedEmbeddingExchange(F, V, D, W, self.rank, device, self.p, group)
+        self.ex = ShardedEmbeddingExchange(F, V, D, W, self.rank, device, self.p, group, transport=transport,
+                                           alias_world1=alias_world1)
+        self.tr = self.ex.tr
         rps = self.ex.rows_per_shard
         g = torch.Generator(device=device)
         g.manual_seed(seed)                       # replicated weights: same seed on every rank
@@ -782,10 +889,11 @@ class ShardedDCNEngine:
             d_out = d_x
         d_x0.add_(d_out)                                  # the first layer's x IS x0
         # ---- C4: the replicated weights' gradients (asynchronous: the embedding gradients travel meanwhile) ------------------------
-        work = dist.all_reduce(self.flat_grads, group=self.group, async_op=True)
+        work = self.tr.allreduce(self.flat_grads, async_op=True) if not self.ex.local else None
         # ---- C3: embedding-row gradients to their owners + sorted scatter with the SGD step --------------------------------------------
         g_rows, _ = self.ex.pack(route, d_x0, None, None, None)
         self.ex.exchange_and_apply(route, g_rows, None, -lr / W, self.table, None)
-        work.wait()
+        if work is not None:
+            work.wait()
         p.axpy(-lr / W, self.flat_grads, self.flat_params)
         return self.loss

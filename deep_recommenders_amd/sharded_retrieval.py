@@ -30,7 +30,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
-from .sharded import HipPrims, ShardedEmbeddingExchange, _pad4
+from .sharded import HipPrims, ShardedEmbeddingExchange, TorchDistTransport, _pad4
 
 
 class RetrievalPrims(HipPrims):
@@ -46,17 +46,17 @@ class RetrievalPrims(HipPrims):
     linear_fwd_wide = staticmethod(lambda x, W, out: ops.linear_fwd_splitk(x, W, out))   # out += x W, reduction split over the grid
 
 
-def _all_gather(t, world, group):
+def _all_gather(t, world, tr):
     out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, t.contiguous(), group=group)
-    return out
+    return tr.allgather(out, t.contiguous())
 
 
-def sharded_topk(q_local, corpus_shard, shard_item_ids, k, world, rank, prims=RetrievalPrims, group=None):
+def sharded_topk(q_local, corpus_shard, shard_item_ids, k, world, rank, prims=RetrievalPrims, group=None, transport=None):
     """Exact top-k of every local query against a corpus sharded over the ranks; shard_item_ids[j] = item id of local row j.
     Returns (scores [B, k], item ids [B, k]) for the LOCAL queries; identical on any world size up to the order of equal scores."""
     B = q_local.shape[0]
-    q_all = _all_gather(q_local, world, group)                                   # [world * B, Do]
+    tr = transport if transport is not None else TorchDistTransport(group)
+    q_all = _all_gather(q_local, world, tr)                                      # [world * B, Do]
     n_loc = corpus_shard.shape[0]
     # ONE list length on every rank: the equal-split all-to-all below needs identically shaped tensors, and shard sizes differ by
     # one row when the corpus does not divide by the world size (ADVICE r2).  The length is min(k, LARGEST shard); a smaller shard
@@ -64,7 +64,7 @@ def sharded_topk(q_local, corpus_shard, shard_item_ids, k, world, rank, prims=Re
     n_max = n_loc
     if world > 1:
         nm = torch.tensor([n_loc], dtype=torch.int64, device=q_local.device)
-        dist.all_reduce(nm, op=dist.ReduceOp.MAX, group=group)
+        tr.allreduce(nm, op=dist.ReduceOp.MAX)
         n_max = int(nm.item())
     k_loc = min(k, n_max)
     k_own = min(k_loc, n_loc)
@@ -78,8 +78,8 @@ def sharded_topk(q_local, corpus_shard, shard_item_ids, k, world, rank, prims=Re
         s_loc, gid = pad_s, pad_i
     recv_s = torch.empty_like(s_loc)
     recv_i = torch.empty_like(gid)
-    dist.all_to_all_single(recv_s, s_loc.contiguous(), group=group)              # chunk r (the lists of rank r's queries) -> rank r
-    dist.all_to_all_single(recv_i, gid.contiguous(), group=group)
+    tr.alltoall(recv_s, s_loc.contiguous())                                      # chunk r (the lists of rank r's queries) -> rank r
+    tr.alltoall(recv_i, gid.contiguous())
     recv_s, recv_i = recv_s.view(world, B, k_loc), recv_i.view(world, B, k_loc)
     s, i = recv_s[0].contiguous(), recv_i[0].contiguous()
     for w in range(1, world):                                                    # Streaming.top_k's reduce, ranks as batches
@@ -137,7 +137,7 @@ class _ReplicatedTower:
 class ShardedTwoTowerEngine:
     def __init__(self, num_users: int, num_items: int, dim: int = 128, tower_units: Sequence[int] = (256, 128), batch: int = 1024,
                  lr: float = 0.01, temperature: Optional[float] = None, remove_accidental_hits: bool = True, k: int = 100,
-                 device="cuda", world=None, rank=None, seed: int = 42, prims=None, group=None, init_tables=None):
+                 device="cuda", world=None, rank=None, seed: int = 42, prims=None, group=None, init_tables=None, transport=None):
         self.world = world if world is not None else dist.get_world_size(group)
         self.rank = rank if rank is not None else dist.get_rank(group)
         self.Vu, self.Ni, self.D, self.B, self.lr, self.k, self.group = num_users, num_items, dim, batch, lr, k, group
@@ -145,8 +145,11 @@ class ShardedTwoTowerEngine:
         self.remove_accidental_hits = remove_accidental_hits
         self.p = prims if prims is not None else RetrievalPrims
         W = self.world
-        self.ex_u = ShardedEmbeddingExchange(1, num_users, dim, W, self.rank, device, self.p, group)
-        self.ex_i = ShardedEmbeddingExchange(1, num_items, dim, W, self.rank, device, self.p, group)
+        self.tr = transport if transport is not None else TorchDistTransport(group)
+        # (alias_world1 off: the two-tower exchanges are 4 MB, and this engine's world-1 GPU test is the one that pushes the
+        # exchange code through an RCCL group of one)
+        self.ex_u = ShardedEmbeddingExchange(1, num_users, dim, W, self.rank, device, self.p, group, transport=self.tr, alias_world1=False)
+        self.ex_i = ShardedEmbeddingExchange(1, num_items, dim, W, self.rank, device, self.p, group, transport=self.tr, alias_world1=False)
         f32 = dict(dtype=torch.float32, device=device)
         g = torch.Generator(device=device)
         g.manual_seed(seed)                       # towers: same seed on every rank -> identical replicas
@@ -206,8 +209,8 @@ class ShardedTwoTowerEngine:
         the reference's loss value)."""
         p, W, B, lr = self.p, self.world, user_keys.shape[0], self.lr
         ru, ri, q, c = self.embeddings(user_keys, item_ids)
-        c_all = _all_gather(c, W, self.group)                                          # C5
-        ids_all = _all_gather(item_ids.reshape(B), W, self.group)
+        c_all = _all_gather(c, W, self.tr)                                             # C5
+        ids_all = _all_gather(item_ids.reshape(B), W, self.tr)
         scores = p.scores_nt(q, c_all).contiguous()                                    # sbcnm.py:129 (this rank's rows)
         labels = torch.zeros((B, W * B), dtype=torch.float32, device=q.device)
         ar = torch.arange(B, device=q.device)
@@ -226,12 +229,12 @@ class ShardedTwoTowerEngine:
         dc_all = torch.zeros((W * B, _pad4(self.out_dim)), dtype=torch.float32, device=q.device)[:, :self.out_dim]
         p.linear_bwd_dw(G, q, 1.0, dc_all)                                             # this rank's part of G^T q
         dc_buf = dc_all if dc_all.is_contiguous() else dc_all.contiguous()
-        dist.all_reduce(dc_buf, group=self.group)                                      # candidates' gradients from every rank's queries
+        self.tr.allreduce(dc_buf)                                                      # candidates' gradients from every rank's queries
         dc = dc_buf[self.rank * B:(self.rank + 1) * B]
         self.flat_grads.zero_()
         d_u = self.q_tower.backward(p, dq) if self.q_tower.Ws else dq
         d_i = self.c_tower.backward(p, dc) if self.c_tower.Ws else dc
-        dist.all_reduce(self.flat_grads, group=self.group)                             # C4
+        self.tr.allreduce(self.flat_grads)                                             # C4
         p.axpy(-lr, self.flat_grads, self.flat_params)
         for ex, r, d_emb, table in ((self.ex_u, ru, d_u, self.user_table), (self.ex_i, ri, d_i, self.item_table)):
             d_emb = d_emb if d_emb.stride(1) == 1 else d_emb.contiguous()
@@ -252,7 +255,7 @@ class ShardedTwoTowerEngine:
         return self.corpus
 
     def topk(self, q, k=None):
-        return sharded_topk(q, self.corpus, self.shard_item_ids, k or self.k, self.world, self.rank, self.p, self.group)
+        return sharded_topk(q, self.corpus, self.shard_item_ids, k or self.k, self.world, self.rank, self.p, self.group, self.tr)
 
     def metric_step(self, user_keys, item_ids, ks=(1, 5, 10, 50, 100)):
         assert self.corpus is not None, "The `index_corpus` method must be called first"

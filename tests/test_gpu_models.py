@@ -651,8 +651,10 @@ def test_engine_adam_steps_match_oracle():
         np.testing.assert_allclose(eng.bs[i].cpu().numpy(), bs[i].numpy(), rtol=0, atol=tol)
 
 
-def test_sharded_engine_world1_matches_unsharded_engine():
-    """HIP prims through the exchange plan (RCCL process group of size 1): one step must equal the plain engine's."""
+@pytest.mark.parametrize("alias_world1", [False, True])
+def test_sharded_engine_world1_matches_unsharded_engine(alias_world1):
+    """HIP prims through the exchange plan: steps must equal the plain engine's.  alias_world1=False: every exchange through an
+    RCCL process group of size 1; True (the default of a one-rank job): the buffers alias and no collective is issued."""
     import torch.distributed as dist
     from deep_recommenders_amd.engine import DeepFMEngine
     from deep_recommenders_amd.sharded import ShardedDeepFMEngine
@@ -663,8 +665,9 @@ def test_sharded_engine_world1_matches_unsharded_engine():
         F, V, D, B, Nd = 6, 3000, 16, 768, 3
         ref = DeepFMEngine(F, V, D, [32, 16], B, num_dense=Nd, lr=0.05, seed=9, lin_init_std=0.1)
         sh = ShardedDeepFMEngine(F, V, D, [32, 16], B, num_dense=Nd, lr=0.05, device="cuda", world=1, rank=0, seed=9,
-                                 init_tables=(ref.table.clone(), ref.lin_w.clone()))
+                                 init_tables=(ref.table.clone(), ref.lin_w.clone()), alias_world1=alias_world1)
         assert sh.mb == 2                                   # two micro-batches per step
+        assert sh.ex.local == alias_world1
         for a, b in zip(sh.Ws, ref.Ws):
             a.copy_(b)
         g = torch.Generator(device="cuda")

@@ -231,21 +231,21 @@ def _free_port():
     return port
 
 
-CFG = dict(F=4, V=37, D=8, B=24, Nd=3, units=[16, 8], lr=0.1)
+CFG = dict(F=4, V=37, D=8, B=24, Nd=3, units=[16, 8], lr=0.1, key_max=10**9, steps=2)
 
 
 NSTEPS = 2
 
 
-def _global_problem():
-    """NSTEPS global batches of 2 * B examples (rank r trains on rows [r*B, (r+1)*B) of each)."""
+def _global_problem(cfg=None):
+    """`steps` global batches of 2 * B examples (rank r trains on rows [r*B, (r+1)*B) of each)."""
     g = torch.Generator().manual_seed(123)
-    c = CFG
+    c = cfg or CFG
     table = torch.randn((c["F"] * c["V"], c["D"]), generator=g) * 0.3
     lin = torch.randn(c["F"] * c["V"], generator=g) * 0.1
     batches = []
-    for _ in range(NSTEPS):
-        keys = torch.randint(0, 10**9, (2 * c["B"], c["F"]), generator=g)
+    for _ in range(c.get("steps", NSTEPS)):
+        keys = torch.randint(0, c.get("key_max", 10**9), (2 * c["B"], c["F"]), generator=g)
         keys[3, 1] = -1                            # a missing id travels through the exchange as a zero row
         dense = torch.rand((2 * c["B"], c["Nd"]), generator=g)
         labels = (torch.rand(2 * c["B"], generator=g) < 0.3).float()
@@ -253,31 +253,111 @@ def _global_problem():
     return table, lin, batches
 
 
-def _worker(rank, world, port, outdir, micro_batches, optimizer="sgd", units=None):
+def _engine_kwargs(gpu):
+    """CPU: oracle-backed primitives over gloo.  gpu=True (tests/test_gpu_sharded_two_rank.py): the HIP kernels, both ranks on
+    cuda:0, device buffers staged through the host over the same gloo group (RCCL refuses two ranks on one device)."""
+    if not gpu:
+        return dict(device="cpu", prims=OraclePrims)
+    from deep_recommenders_amd.sharded import HostStagedTransport
+    torch.cuda.set_device(0)
+    return dict(device="cuda", transport=HostStagedTransport())
+
+
+def _worker(rank, world, port, outdir, micro_batches, optimizer="sgd", units=None, gpu=False, cfg=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from deep_recommenders_amd.sharded import ShardedDeepFMEngine
-        c = CFG
-        table, lin, batches = _global_problem()
-        eng = ShardedDeepFMEngine(c["F"], c["V"], c["D"], units or c["units"], c["B"], num_dense=c["Nd"], lr=c["lr"], device="cpu",
-                                  world=world, rank=rank, seed=5, prims=OraclePrims, init_tables=(table, lin),
-                                  micro_batches=micro_batches, optimizer=optimizer)
+        c = cfg or CFG
+        table, lin, batches = _global_problem(c)
+        kw = _engine_kwargs(gpu)
+        dev = kw["device"]
+        eng = ShardedDeepFMEngine(c["F"], c["V"], c["D"], units or c["units"], c["B"], num_dense=c["Nd"], lr=c["lr"],
+                                  world=world, rank=rank, seed=5, init_tables=(table, lin),
+                                  micro_batches=micro_batches, optimizer=optimizer, **kw)
         assert eng.mb == (1 if (optimizer == "adam" or not eng.fuse_head) else micro_batches)
         assert eng.fuse_head == (units is None)         # the [16, 40] tower of the unfused-head test cannot take the fused head
+        if gpu and c.get("expect_fused_l0") is not None:
+            assert bool(eng.fuse_k3) == c["expect_fused_l0"]
         sl = slice(rank * c["B"], (rank + 1) * c["B"])
-        Ws0 = [w.clone() for w in eng.Ws]
-        bs0 = [b.clone() for b in eng.bs]
-        local = [(k[sl].contiguous(), d[sl].contiguous(), l[sl].contiguous()) for k, d, l in batches]
+        Ws0 = [w.cpu().clone() for w in eng.Ws]
+        bs0 = [b.cpu().clone() for b in eng.bs]
+        local = [(k[sl].contiguous().to(dev), d[sl].contiguous().to(dev), l[sl].contiguous().to(dev)) for k, d, l in batches]
         losses = []
         for t, (k, d, l) in enumerate(local):       # every step but the last hands over the next batch's keys (route prefetch)
             nk = local[t + 1][0] if t + 1 < len(local) else None
             losses.append(eng.train_step(k, d, l, next_keys=nk).item())
-        torch.save((rank, losses, eng.table.clone(), eng.lin_w.clone(), [w.clone() for w in eng.Ws],
-                    [b.clone() for b in eng.bs], eng.lin_bias.clone(), Ws0, bs0), os.path.join(outdir, "rank%d.pt" % rank))
+        torch.save((rank, losses, eng.table.cpu().clone(), eng.lin_w.cpu().clone(), [w.cpu().clone() for w in eng.Ws],
+                    [b.cpu().clone() for b in eng.bs], eng.lin_bias.cpu().clone(), Ws0, bs0), os.path.join(outdir, "rank%d.pt" % rank))
     finally:
         dist.destroy_process_group()
+
+
+def _spawn(worker, args, tmp_path, world=2, timeout=240):
+    """runs `worker(rank, world, port, outdir, *args)` on `world` spawned processes, returns {rank: saved tuple[1:]}"""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=worker, args=(r, world, port, str(tmp_path)) + tuple(args)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout)
+        assert p.exitcode == 0
+    res = {}
+    for r in range(world):
+        item = torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r))
+        res[item[0]] = item[1:]
+    return res
+
+
+def _reference_deepfm(cfg, Ws0, bs0, optimizer="sgd", dtype=torch.float32):
+    """Single-process oracle: plain SGD (or row-wise Adam, [TF] B15 -- oracle/torch_ref.py adam_rows_step / adam_dense_step) on the
+    GLOBAL batches.  Returns (per-step losses, table, lin, bias, Ws, bs) after the last step."""
+    c = cfg
+    table, lin, batches = _global_problem(c)
+    F, V, lr = c["F"], c["V"], c["lr"]
+    tab, li, bias = table.to(dtype), lin.to(dtype), torch.zeros(1, dtype=dtype)
+    Wc, bc = [w.to(dtype).clone() for w in Ws0], [b.to(dtype).clone() for b in bs0]
+    z = torch.zeros_like
+    mt, vt, ml, vl, mb_, vb_ = z(tab), z(tab), z(li), z(li), z(bias), z(bias)
+    mW, vW, mB, vB = [z(w) for w in Wc], [z(w) for w in Wc], [z(b) for b in bc], [z(b) for b in bc]
+    losses = []
+    for t, (keys, dense, labels) in enumerate(batches):
+        ids = np.stack([O.hash_bucket_i64(keys[:, f].numpy(), V) for f in range(F)], axis=1)
+        tt, tl, tb = tab.clone().requires_grad_(True), li.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+        Ws = [w.clone().requires_grad_(True) for w in Wc]
+        bs = [b.clone().requires_grad_(True) for b in bc]
+        logit = T.deepfm_logit(tt, tl, tb, torch.tensor(ids), list(range(F + 1)), [f * V for f in range(F)], Ws, bs, dense.to(dtype))
+        lo = T.sigmoid_cross_entropy(labels.to(dtype), logit)
+        lo.backward()
+        losses.append(lo.item())
+        if optimizer == "sgd":
+            tab, li, bias = (tab - lr * tt.grad).detach(), (li - lr * tl.grad).detach(), (bias - lr * tb.grad).detach()
+            Wc = [(w - lr * g.grad).detach() for w, g in zip(Wc, Ws)]
+            bc = [(b - lr * g.grad).detach() for b, g in zip(bc, bs)]
+        else:
+            rows = torch.tensor(ids + np.arange(F)[None, :] * V).reshape(-1)
+            rows = rows[torch.tensor(ids.reshape(-1) >= 0)]
+            T.adam_rows_step(tab, tt.grad, rows, mt, vt, lr, t + 1)
+            T.adam_rows_step(li, tl.grad, rows, ml, vl, lr, t + 1)
+            T.adam_dense_step(bias, tb.grad, mb_, vb_, lr, t + 1)
+            for i in range(len(Wc)):
+                T.adam_dense_step(Wc[i], Ws[i].grad, mW[i], vW[i], lr, t + 1)
+                T.adam_dense_step(bc[i], bs[i].grad, mB[i], vB[i], lr, t + 1)
+    return losses, tab, li, bias, Wc, bc
+
+
+def _shard_views(cfg, world, r, tab_r, lin_r, tab, li):
+    """(got, want) pairs of rank r's table / first-order shard against the global oracle tables (row id -> rank id % world)"""
+    F, V = cfg["F"], cfg["V"]
+    rps = (V + world - 1) // world
+    out = []
+    for f in range(F):
+        gid = torch.arange(r, V, world)
+        out.append((tab_r[f * rps:f * rps + len(gid)], tab[f * V + gid]))
+        out.append((lin_r[f * rps:f * rps + len(gid)], li[f * V + gid]))
+    return out
 
 
 @pytest.mark.timeout(300)
@@ -285,47 +365,18 @@ def _worker(rank, world, port, outdir, micro_batches, optimizer="sgd", units=Non
 def test_two_rank_sharded_steps_equal_single_process_oracle(tmp_path, micro_batches):
     """2 ranks x NSTEPS steps (prefetched routes, micro-batches) == plain SGD on the global batches in one process."""
     world = 2
-    port = _free_port()
-    ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path), micro_batches)) for r in range(world)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(240)
-        assert p.exitcode == 0
-    res = {}
-    for r in range(world):
-        item = torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r))
-        res[item[0]] = item[1:]
+    res = _spawn(_worker, (micro_batches,), tmp_path)
     c = CFG
-    table, lin, batches = _global_problem()
-    F, V, D, lr = c["F"], c["V"], c["D"], c["lr"]
     Ws0, bs0 = res[0][6], res[0][7]
     for a, b in zip(Ws0, res[1][6]):
         assert torch.equal(a, b)                    # replicas start identical
-    # ---- single-process oracle: NSTEPS plain SGD steps on the global batches ----
-    tab, li, bias = table.clone(), lin.clone(), torch.zeros(1)
-    Wc, bc = [w.clone() for w in Ws0], [b.clone() for b in bs0]
-    for t, (keys, dense, labels) in enumerate(batches):
-        ids = np.stack([O.hash_bucket_i64(keys[:, f].numpy(), V) for f in range(F)], axis=1)
-        tt, tl, tb = tab.clone().requires_grad_(True), li.clone().requires_grad_(True), bias.clone().requires_grad_(True)
-        Ws = [w.clone().requires_grad_(True) for w in Wc]
-        bs = [b.clone().requires_grad_(True) for b in bc]
-        logit = T.deepfm_logit(tt, tl, tb, torch.tensor(ids), list(range(F + 1)), [f * V for f in range(F)], Ws, bs, dense)
-        lo = T.sigmoid_cross_entropy(labels, logit)
-        lo.backward()
-        # global loss = mean of the per-rank means (equal batch sizes)
-        assert abs(0.5 * (res[0][0][t] + res[1][0][t]) - lo.item()) < 2e-6
-        tab, li, bias = (tab - lr * tt.grad).detach(), (li - lr * tl.grad).detach(), (bias - lr * tb.grad).detach()
-        Wc = [(w - lr * g.grad).detach() for w, g in zip(Wc, Ws)]
-        bc = [(b - lr * g.grad).detach() for b, g in zip(bc, bs)]
-    rps = (V + world - 1) // world
+    losses, tab, li, bias, Wc, bc = _reference_deepfm(c, Ws0, bs0, "sgd")
+    for t, lo in enumerate(losses):                 # global loss = mean of the per-rank means (equal batch sizes)
+        assert abs(0.5 * (res[0][0][t] + res[1][0][t]) - lo) < 2e-6
     for r in range(world):
         _, tab_r, lin_r, Ws_r, bs_r, bias_r, _, _ = res[r]
-        for f in range(F):
-            gid = torch.arange(r, V, world)
-            np.testing.assert_allclose(tab_r[f * rps:f * rps + len(gid)].numpy(), tab[f * V + gid].numpy(), rtol=2e-5, atol=2e-6)
-            np.testing.assert_allclose(lin_r[f * rps:f * rps + len(gid)].numpy(), li[f * V + gid].numpy(), rtol=2e-5, atol=2e-6)
+        for got, want in _shard_views(c, world, r, tab_r, lin_r, tab, li):
+            np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=2e-5, atol=2e-6)
         for i in range(len(Wc)):
             np.testing.assert_allclose(Ws_r[i].numpy(), Wc[i].numpy(), rtol=2e-5, atol=2e-6)
             np.testing.assert_allclose(bs_r[i].numpy(), bc[i].numpy(), rtol=2e-5, atol=2e-6)
@@ -341,53 +392,19 @@ def test_two_rank_sharded_adam_steps_equal_single_process_oracle(tmp_path, units
     fused head does not take (> 32 units) -- the stand-alone loss kernel normalises by the rank batch and the engine rescales
     (that branch used to leave every gradient W times too large)."""
     world = 2
-    port = _free_port()
-    ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path), 2, "adam", units)) for r in range(world)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(240)
-        assert p.exitcode == 0
-    res = {}
-    for r in range(world):
-        item = torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r))
-        res[item[0]] = item[1:]
+    res = _spawn(_worker, (2, "adam", units), tmp_path)
     c = CFG
-    table, lin, batches = _global_problem()
-    F, V, D, lr = c["F"], c["V"], c["D"], c["lr"]
+    lr = c["lr"]
     Ws0, bs0 = res[0][6], res[0][7]
-    tab, li, bias = table.clone(), lin.clone(), torch.zeros(1)
-    Wc, bc = [w.clone() for w in Ws0], [b.clone() for b in bs0]
-    z = torch.zeros_like
-    mt, vt, ml, vl, mb_, vb_ = z(tab), z(tab), z(li), z(li), z(bias), z(bias)
-    mW, vW, mB, vB = [z(w) for w in Wc], [z(w) for w in Wc], [z(b) for b in bc], [z(b) for b in bc]
-    for t, (keys, dense, labels) in enumerate(batches):
-        ids = np.stack([O.hash_bucket_i64(keys[:, f].numpy(), V) for f in range(F)], axis=1)
-        tt, tl, tb = tab.clone().requires_grad_(True), li.clone().requires_grad_(True), bias.clone().requires_grad_(True)
-        Ws = [w.clone().requires_grad_(True) for w in Wc]
-        bs = [b.clone().requires_grad_(True) for b in bc]
-        logit = T.deepfm_logit(tt, tl, tb, torch.tensor(ids), list(range(F + 1)), [f * V for f in range(F)], Ws, bs, dense)
-        lo = T.sigmoid_cross_entropy(labels, logit)
-        lo.backward()
-        assert abs(0.5 * (res[0][0][t] + res[1][0][t]) - lo.item()) < 2e-6
-        rows = torch.tensor(ids + np.arange(F)[None, :] * V).reshape(-1)
-        rows = rows[torch.tensor(ids.reshape(-1) >= 0)]
-        T.adam_rows_step(tab, tt.grad, rows, mt, vt, lr, t + 1)
-        T.adam_rows_step(li, tl.grad, rows, ml, vl, lr, t + 1)
-        T.adam_dense_step(bias, tb.grad, mb_, vb_, lr, t + 1)
-        for i in range(len(Wc)):
-            T.adam_dense_step(Wc[i], Ws[i].grad, mW[i], vW[i], lr, t + 1)
-            T.adam_dense_step(bc[i], bs[i].grad, mB[i], vB[i], lr, t + 1)
-    rps = (V + world - 1) // world
+    losses, tab, li, bias, Wc, bc = _reference_deepfm(c, Ws0, bs0, "adam")
+    for t, lo in enumerate(losses):
+        assert abs(0.5 * (res[0][0][t] + res[1][0][t]) - lo) < 2e-6
     # Adam divides by sqrt(v): tolerances are a fraction of one step (lr), not of the weight
     tol = dict(rtol=0, atol=2e-3 * lr)
     for r in range(world):
         _, tab_r, lin_r, Ws_r, bs_r, bias_r, _, _ = res[r]
-        for f in range(F):
-            gid = torch.arange(r, V, world)
-            np.testing.assert_allclose(tab_r[f * rps:f * rps + len(gid)].numpy(), tab[f * V + gid].numpy(), **tol)
-            np.testing.assert_allclose(lin_r[f * rps:f * rps + len(gid)].numpy(), li[f * V + gid].numpy(), **tol)
+        for got, want in _shard_views(c, world, r, tab_r, lin_r, tab, li):
+            np.testing.assert_allclose(got.numpy(), want.numpy(), **tol)
         for i in range(len(Wc)):
             np.testing.assert_allclose(Ws_r[i].numpy(), Wc[i].numpy(), **tol)
             np.testing.assert_allclose(bs_r[i].numpy(), bc[i].numpy(), **tol)
@@ -397,9 +414,9 @@ def test_two_rank_sharded_adam_steps_equal_single_process_oracle(tmp_path, units
 DCN_CFG = dict(F=3, V=29, D=4, B=16, Nd=2, units=[8, 4], L=2, lr=0.2, diag=0.1)
 
 
-def _dcn_problem():
+def _dcn_problem(cfg=None):
     g = torch.Generator().manual_seed(9)
-    c = DCN_CFG
+    c = cfg or DCN_CFG
     table = torch.randn((c["F"] * c["V"], c["D"]), generator=g) * 0.4
     batches = []
     for _ in range(NSTEPS):
@@ -410,53 +427,40 @@ def _dcn_problem():
     return table, batches
 
 
-def _dcn_worker(rank, world, port, outdir):
+def _dcn_worker(rank, world, port, outdir, gpu=False, cfg=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from deep_recommenders_amd.sharded import ShardedDCNEngine
-        c = DCN_CFG
-        table, batches = _dcn_problem()
+        c = cfg or DCN_CFG
+        table, batches = _dcn_problem(c)
+        kw = _engine_kwargs(gpu)
+        dev = kw["device"]
         eng = ShardedDCNEngine(c["F"], c["V"], c["D"], c["L"], c["units"], c["B"], num_dense=c["Nd"], lr=c["lr"], diag_scale=c["diag"],
-                               device="cpu", world=world, rank=rank, seed=5, prims=OraclePrims, init_tables=table)
+                               world=world, rank=rank, seed=5, init_tables=table, **kw)
         with torch.no_grad():
             for b in eng.cross_b:
                 b.fill_(0.05)
             eng.bs[-1].fill_(0.03)        # keeps logits off the kink of the restated loss at exactly 0 (dead-ReLU examples would sit
                                           # on it with a zero bias; autograd's subgradient there is not the kernels' sigmoid(0) - z)
-        params0 = eng.flat_params.clone()
+        params0 = eng.flat_params.cpu().clone()
         sl = slice(rank * c["B"], (rank + 1) * c["B"])
-        losses = [eng.train_step(k[sl].contiguous(), d[sl].contiguous(), l[sl].contiguous()).item() for k, d, l in batches]
-        torch.save((rank, losses, eng.table.clone(), eng.flat_params.clone(), params0), os.path.join(outdir, "rank%d.pt" % rank))
+        losses = [eng.train_step(k[sl].contiguous().to(dev), d[sl].contiguous().to(dev), l[sl].contiguous().to(dev)).item()
+                  for k, d, l in batches]
+        torch.save((rank, losses, eng.table.cpu().clone(), eng.flat_params.cpu().clone(), params0), os.path.join(outdir, "rank%d.pt" % rank))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(300)
-def test_two_rank_sharded_dcn_equals_single_process_oracle(tmp_path):
-    """ShardedDCNEngine (VERDICT r1 item 5): 2 ranks x NSTEPS steps == plain SGD on the global batches in one process, with the
-    cross stack of keras/models/ranking/dcn.py:81-88 (T.cross) under torch autograd."""
-    world = 2
-    port = _free_port()
-    ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_dcn_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(240)
-        assert p.exitcode == 0
-    res = {}
-    for r in range(world):
-        item = torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r))
-        res[item[0]] = item[1:]
-    c = DCN_CFG
-    table, batches = _dcn_problem()
+def _reference_dcn(cfg, flat0, dtype=torch.float32):
+    """Single-process oracle of the DCN step (cross stack of keras/models/ranking/dcn.py:81-88 = T.cross, under torch autograd):
+    plain SGD on the global batches.  Returns (losses, flat parameters, table) after the last step."""
+    c = cfg
+    table, batches = _dcn_problem(c)
     F, V, D, lr, L = c["F"], c["V"], c["D"], c["lr"], c["L"]
     n_in = F * D + c["Nd"]
     ld = (n_in + 3) // 4 * 4
-    assert torch.equal(res[0][3], res[1][3])
-    flat = res[0][3].clone()
 
     def unpack(P):
         off, cW, cb, Ws, bs = 0, [], [], [], []
@@ -470,23 +474,40 @@ def test_two_rank_sharded_dcn_equals_single_process_oracle(tmp_path):
             bs.append(P[off:off + u]); off += pu
             d = u
         return cW, cb, Ws, bs
-    tab = table.clone()
+    flat = flat0.to(dtype).clone()
+    tab = table.to(dtype).clone()
+    losses = []
     for t, (keys, dense, labels) in enumerate(batches):
         ids = np.stack([O.hash_bucket_i64(keys[:, f].numpy(), V) for f in range(F)], axis=1)
         P = flat.clone().requires_grad_(True)
         tt = tab.clone().requires_grad_(True)
         cW, cb, Ws, bs = unpack(P)
         emb = T.pool_fields(tt, torch.tensor(ids), list(range(F + 1)), [f * V for f in range(F)])
-        x0 = torch.cat(emb + [dense], 1)
+        x0 = torch.cat(emb + [dense.to(dtype)], 1)
         x = x0
         for Wc, bc in zip(cW, cb):
             x = T.cross(x0, x, Wc, bc, c["diag"])
         logit = T.dnn(x, Ws, bs).squeeze(1)
-        lo = T.sigmoid_cross_entropy(labels, logit)
+        lo = T.sigmoid_cross_entropy(labels.to(dtype), logit)
         lo.backward()
-        assert abs(0.5 * (res[0][0][t] + res[1][0][t]) - lo.item()) < 2e-6
+        losses.append(lo.item())
         flat = (flat - lr * P.grad).detach()
         tab = (tab - lr * tt.grad).detach()
+    return losses, flat, tab
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharded_dcn_equals_single_process_oracle(tmp_path):
+    """ShardedDCNEngine (VERDICT r1 item 5): 2 ranks x NSTEPS steps == plain SGD on the global batches in one process, with the
+    cross stack of keras/models/ranking/dcn.py:81-88 (T.cross) under torch autograd."""
+    world = 2
+    res = _spawn(_dcn_worker, (), tmp_path)
+    c = DCN_CFG
+    F, V = c["F"], c["V"]
+    assert torch.equal(res[0][3], res[1][3])
+    losses, flat, tab = _reference_dcn(c, res[0][3])
+    for t, lo in enumerate(losses):
+        assert abs(0.5 * (res[0][0][t] + res[1][0][t]) - lo) < 2e-6
     rps = (V + world - 1) // world
     for r in range(world):
         _, tab_r, flat_r, _ = res[r]

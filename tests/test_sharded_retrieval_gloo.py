@@ -108,7 +108,7 @@ def _problem():
     return ut, it, batches
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, gpu=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -116,31 +116,46 @@ def _worker(rank, world, port, outdir):
         from deep_recommenders_amd.sharded_retrieval import ShardedTwoTowerEngine
         c = CFG
         ut, it, batches = _problem()
+        if gpu:      # the HIP kernels, both ranks on cuda:0, buffers staged through the host (tests/test_gpu_sharded_two_rank.py)
+            from deep_recommenders_amd.sharded import HostStagedTransport
+            torch.cuda.set_device(0)
+            kw = dict(device="cuda", transport=HostStagedTransport())
+        else:
+            kw = dict(device="cpu", prims=RetrievalOraclePrims)
+        dev = kw["device"]
         eng = ShardedTwoTowerEngine(c["Vu"], c["Ni"], c["D"], c["units"], c["B"], lr=c["lr"], temperature=c["temperature"], k=5,
-                                    device="cpu", world=world, rank=rank, seed=3, prims=RetrievalOraclePrims, init_tables=(ut, it))
-        params0 = eng.flat_params.clone()
+                                    world=world, rank=rank, seed=3, init_tables=(ut, it), **kw)
+        params0 = eng.flat_params.cpu().clone()
         sl = slice(rank * c["B"], (rank + 1) * c["B"])
-        losses = [float(eng.train_step(k[sl].contiguous(), i[sl].contiguous())) for k, i in batches]
+        losses = [float(eng.train_step(k[sl].contiguous().to(dev), i[sl].contiguous().to(dev))) for k, i in batches]
         # metric pass on the trained model
         eng.index_corpus(chunk=16)
         k, i = batches[0]
-        hits = eng.metric_step(k[sl].contiguous(), i[sl].contiguous(), ks=(1, 3, 5))
-        _, _, q, cemb = eng.embeddings(k[sl].contiguous(), i[sl].contiguous())
+        k, i = k[sl].contiguous().to(dev), i[sl].contiguous().to(dev)
+        hits = eng.metric_step(k, i, ks=(1, 3, 5))
+        _, _, q, cemb = eng.embeddings(k, i)
         s, ids = eng.topk(q, 5)
         s24, ids24 = eng.topk(q, 24)         # k > the smaller shard's 23 rows (47 items over 2 ranks): padded lists
-        torch.save(dict(rank=rank, topk24_s=s24.clone(), topk24_i=ids24.clone(), losses=losses, user_table=eng.user_table.clone(), item_table=eng.item_table.clone(),
-                        params=eng.flat_params.clone(), params0=params0, hits=hits.clone(), q=q.clone(), c=cemb.clone(),
-                        topk_s=s.clone(), topk_i=ids.clone(), corpus=eng.corpus.clone()), os.path.join(outdir, "rank%d.pt" % rank))
+        cpu = lambda t: t.detach().cpu().clone()
+        torch.save(dict(rank=rank, topk24_s=cpu(s24), topk24_i=cpu(ids24), losses=losses, user_table=cpu(eng.user_table), item_table=cpu(eng.item_table),
+                        params=cpu(eng.flat_params), params0=params0, hits=cpu(hits), q=cpu(q), c=cpu(cemb),
+                        topk_s=cpu(s), topk_i=cpu(ids), corpus=cpu(eng.corpus)), os.path.join(outdir, "rank%d.pt" % rank))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
 def test_two_rank_two_tower_equals_single_process_oracle(tmp_path):
+    run_and_check(tmp_path, gpu=False)
+
+
+def run_and_check(tmp_path, gpu):
+    """gpu=False: oracle-backed primitives over gloo (exact index agreement).  gpu=True: the HIP kernels on two ranks sharing cuda:0
+    -- scores to fp32-GEMM tolerance, returned ids checked through the scores they must reproduce (near-ties may swap)."""
     world = 2
     port = _free_port()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path), gpu)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -199,12 +214,16 @@ def test_two_rank_two_tower_equals_single_process_oracle(tmp_path):
         corpus[torch.arange(r, c["Ni"], world)] = res[r]["corpus"]
     np.testing.assert_allclose(corpus.numpy(), tower(it, cW, cb, flat).numpy(), rtol=1e-5, atol=1e-6)
     for r in range(world):
-        ws, wi = O.brute_force_top_k(res[r]["q"].numpy(), corpus.numpy(), k=5)
-        np.testing.assert_allclose(res[r]["topk_s"].numpy(), ws, rtol=1e-6, atol=1e-7)
-        assert np.array_equal(res[r]["topk_i"].numpy(), wi)
-        ws, wi = O.brute_force_top_k(res[r]["q"].numpy(), corpus.numpy(), k=24)
-        np.testing.assert_allclose(res[r]["topk24_s"].numpy(), ws, rtol=1e-6, atol=1e-7)
-        assert np.array_equal(res[r]["topk24_i"].numpy(), wi)
+        for k_, ks_, ki_ in ((5, "topk_s", "topk_i"), (24, "topk24_s", "topk24_i")):
+            ws, wi = O.brute_force_top_k(res[r]["q"].numpy(), corpus.numpy(), k=k_)
+            if not gpu:
+                np.testing.assert_allclose(res[r][ks_].numpy(), ws, rtol=1e-6, atol=1e-7)
+                assert np.array_equal(res[r][ki_].numpy(), wi)
+            else:
+                np.testing.assert_allclose(res[r][ks_].numpy(), ws, rtol=1e-5, atol=1e-5)
+                own = np.take_along_axis(res[r]["q"].numpy().astype(np.float64) @ corpus.numpy().astype(np.float64).T,
+                                         res[r][ki_].numpy(), axis=1)
+                np.testing.assert_allclose(own, res[r][ks_].numpy(), rtol=1e-5, atol=1e-5)     # the ids are the ones that scored so
         want = O.factorized_top_k_accuracy(res[r]["q"].numpy(), res[r]["c"].numpy(), corpus.numpy(), (1, 3, 5), k=5)
         # the positive is itself in the corpus: its score as rowdot(q, c) and as a corpus score can differ in the last bit
         # (different matmul shapes), which flips a strict comparison -- allow one example per k
