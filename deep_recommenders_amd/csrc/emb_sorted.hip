@@ -1,65 +1,22 @@
-// K4, deterministic form — row-sorted, de-duplicated scatter of the embedding gradients with the SGD step
-// fused (dst_row += scale * sum of the gradients of every (example, field) slot that looked the row up).
+// K4, deterministic form -- de-duplicated scatter of the embedding gradients with the SGD step fused
+// (dst_row += scale * sum of the gradients of every (example, field) slot that looked the row up).
 //
 // Why (measured on MI355X, profiles/r01_exp_emb_variants.log): fp32 atomics on 66 GB of random rows run at
-// 2.7 TB/s algorithmic; a plain 16-byte load / add / store of each touched row runs at 5.2 TB/s — but is only
-// legal when exactly one lane group owns the row.  Sorting the B*F slots by table row makes ownership explicit,
+// 2.7 TB/s algorithmic; a plain 16-byte load / add / store of each touched row runs at 5.2 TB/s -- but is only
+// legal when exactly one lane group owns the row.  The slot plan (csrc/emb_plan.hip, dr_emb_sort_slots: hand-written claim
+// table + LDS sort of the shared-row slots; a radix sort of all slots for skewed batches) makes ownership explicit,
 // turns hot (Zipf) rows into a segmented sum instead of an atomic pile-up, and makes the update bit-reproducible
-// run to run.  The sort depends only on the ids, so the engine runs it on a side stream under the MFMA-bound
-// tower; it is plumbing (rocPRIM radix sort, header-only, compiled into this library) — the gather / segment-sum /
-// read-modify-write kernel is ours.
+// run to run.  The plan depends only on the ids, so the engine builds it on a side stream.
 //
 // Replaces the autodiff of [TF] safe_embedding_lookup_sparse (IndexedSlices -> unsorted_segment_sum into the
 // variable) reached from optimizer.minimize (examples/train_fm_on_movielens_estimator.py:51-52, reference root).
 #include "dr_common.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
 
 namespace {
 
 constexpr int CH = 32;   // a lane group sums at most CH consecutive sorted slots (bounds hot-row serialisation)
-
-__global__ __launch_bounds__(256) void make_sort_keys_kernel(const int64_t* __restrict__ ids, int64_t n, int32_t F,
-                                                             const int64_t* __restrict__ row_base, uint64_t sentinel,
-                                                             uint64_t* __restrict__ keys, int32_t* __restrict__ vals) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
-        const int64_t id = ids[p];
-        keys[p] = id >= 0 ? (uint64_t)(row_base[p % F] + id) : sentinel;   // missing ids sort to the end
-        vals[p] = (int32_t)p;
-    }
-}
-
-// flag[p] = 1 iff slot p is the only slot of the batch that touches its row (valid id, no duplicate)
-// Also compacts the work list of the duplicate pass: every sorted position that heads a piece of a row touched by
-// >= 2 slots (the segment start, plus each CH-aligned position >= CH past it) is appended to dup_heads.
-__global__ __launch_bounds__(256) void mark_unique_kernel(const uint64_t* __restrict__ rows,
-                                                          const int32_t* __restrict__ slots, int64_t n,
-                                                          uint64_t num_rows, uint8_t* __restrict__ flags,
-                                                          int32_t* __restrict__ dup_heads, int32_t* __restrict__ dup_count) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint64_t k = rows[i];
-        const bool valid = k < num_rows;
-        const bool seg_start = (i == 0) || (rows[i - 1] != k);
-        const bool has_next = (i + 1 < n) && (rows[i + 1] == k);
-        flags[slots[i]] = (valid && seg_start && !has_next) ? 1 : 0;
-        const bool head = valid && ((seg_start && has_next) ||
-                                    (!seg_start && (i % CH) == 0 && i >= CH && rows[i - CH] == k));
-        // append to the head list: ONE atomic per wave (ballot + prefix rank), not one per head -- a skewed batch has ~1e5
-        // heads and same-address atomics retire at ~88 per microsecond
-        const uint64_t bal = __ballot(head);
-        if (bal != 0) {
-            const int lane = threadIdx.x & 63;
-            const int leader = __ffsll((unsigned long long)bal) - 1;
-            int base = 0;
-            if (lane == leader) base = atomicAdd(dup_count, __popcll(bal));
-            base = __shfl(base, leader, 64);
-            if (head) dup_heads[base + __popcll(bal & ((1ull << lane) - 1ull))] = (int32_t)i;
-        }
-    }
-}
 
 // Fast path: streams the gradient in example order (coalesced), one wave per example; every slot whose row is
 // unique in the batch gets ONE plain 16-byte-per-lane load / fma / store of its table row.  No atomics.
@@ -232,6 +189,7 @@ __device__ __forceinline__ void emb_bwd_dups_body(const int bid, const int nblk,
     const int64_t nwaves = (int64_t)nblk * (blockDim.x >> 6);
     const int64_t wave0 = (int64_t)bid * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nheads = dup_count[0];
+    n = dup_count[1];          // length of the sorted arrays: all B*F slots (radix path) or only the shared-row slots (claim path)
     const uint64_t gmask = LPR == 64 ? ~0ull : ((1ull << LPR) - 1ull);
     for (int64_t h0 = wave0 * NS; h0 < nheads; h0 += nwaves * NS) {
         const int64_t h = h0 + slot;
@@ -350,58 +308,7 @@ __global__ __launch_bounds__(256) void emb_bwd_sorted_kernel(BwdSortedArgs a, Ad
                                           a.lin_bias, ad);
 }
 
-unsigned bits_for(uint64_t v) {
-    unsigned b = 1;
-    while (b < 64 && (v >> b) != 0) ++b;
-    return b;
-}
-
-size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-
-size_t rocprim_temp_bytes(int64_t n) {
-    size_t bytes = 0;
-    if (rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const int32_t*)nullptr,
-                                  (int32_t*)nullptr, (size_t)n, 0u, 64u, (hipStream_t)0) != hipSuccess)
-        return 0;
-    return bytes;
-}
-
 }  // namespace
-
-// workspace layout: [keys_in n*8][vals_in n*4 (padded)][rocprim temp]
-extern "C" int64_t dr_emb_sort_workspace_bytes(int64_t n) {
-    if (n <= 0) return 256;
-    return (int64_t)(align_up((size_t)n * 8, 256) + align_up((size_t)n * 4, 256) + align_up(rocprim_temp_bytes(n), 256));
-}
-
-extern "C" int dr_emb_sort_slots(const int64_t* ids, int64_t B, int32_t F, const int64_t* row_base, int64_t num_rows,
-                                 int64_t* sorted_rows, int32_t* sorted_slots, uint8_t* unique_flags, int32_t* dup_heads,
-                                 int32_t* dup_count, void* workspace, int64_t workspace_bytes, dr_stream_t stream) {
-    if (B < 0 || F <= 0 || num_rows <= 0) return DR_EINVAL;
-    const int64_t n = B * F;
-    if (n == 0) return DR_OK;
-    if (n > 0x7fffffff) return DR_EINVAL;
-    if (!ids || !row_base || !sorted_rows || !sorted_slots || !unique_flags || !dup_heads || !dup_count || !workspace)
-        return DR_EINVAL;
-    if (workspace_bytes < dr_emb_sort_workspace_bytes(n)) return DR_EINVAL;
-    char* w = static_cast<char*>(workspace);
-    uint64_t* keys_in = reinterpret_cast<uint64_t*>(w);
-    int32_t* vals_in = reinterpret_cast<int32_t*>(w + align_up((size_t)n * 8, 256));
-    void* temp = w + align_up((size_t)n * 8, 256) + align_up((size_t)n * 4, 256);
-    size_t temp_bytes = rocprim_temp_bytes(n);
-    hipLaunchKernelGGL(make_sort_keys_kernel, dim3(dr_grid_for(n, 256)), dim3(256), 0, dr_s(stream), ids, n, F, row_base,
-                       (uint64_t)num_rows, keys_in, vals_in);
-    const unsigned end_bit = bits_for((uint64_t)num_rows);      // the sentinel == num_rows needs these bits too
-    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, reinterpret_cast<uint64_t*>(sorted_rows), vals_in,
-                                             sorted_slots, (size_t)n, 0u, end_bit, dr_s(stream));
-    if (e != hipSuccess) return DR_ELAUNCH;
-    if (hipMemsetAsync(dup_count, 0, sizeof(int32_t), dr_s(stream)) != hipSuccess) return DR_ELAUNCH;
-    hipLaunchKernelGGL(mark_unique_kernel, dim3(dr_grid_for(n, 256)), dim3(256), 0, dr_s(stream),
-                       reinterpret_cast<const uint64_t*>(sorted_rows), sorted_slots, n, (uint64_t)num_rows, unique_flags,
-                       dup_heads, dup_count);
-    DR_CHECK_LAUNCH();
-    return DR_OK;
-}
 
 static int bwd_sorted_impl(const int64_t* ids, const int64_t* row_base, const int64_t* sorted_rows,
                            const int32_t* sorted_slots, const uint8_t* unique_flags, const int32_t* dup_heads,

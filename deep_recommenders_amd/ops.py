@@ -444,8 +444,13 @@ class SortPlan:
         self.slots = torch.empty(n, dtype=torch.int32, device=device)
         self.flags = torch.empty(n, dtype=torch.uint8, device=device)
         self.dup_heads = torch.empty(n, dtype=torch.int32, device=device)
-        self.dup_count = torch.zeros(1, dtype=torch.int32, device=device)
+        self.dup_count = torch.zeros(4, dtype=torch.int32, device=device)     # [work-list entries, length of the sorted arrays]
         self.workspace = emb_sort_workspace(n, device)
+
+    def sorted_len(self):
+        """Length of the sorted (rows, slots) arrays of the last plan built here: only the slots of shared rows (claim path) or
+        all slots (radix path).  Host read -- tests / debugging."""
+        return int(self.dup_count[1].item())
 
 
 def emb_sort_slots(ids, row_base, num_rows, plan=None):
@@ -457,6 +462,11 @@ def emb_sort_slots(ids, row_base, num_rows, plan=None):
                                   ptr(plan.flags), ptr(plan.dup_heads), ptr(plan.dup_count), ptr(plan.workspace),
                                   plan.workspace.numel(), stream_ptr()), "dr_emb_sort_slots")
     return plan
+
+
+def emb_plan_set_small_limit(limit):
+    """largest shared-row list the plan's one-block LDS sort takes (0: radix path whenever a row is shared); returns the previous"""
+    return int(lib().dr_emb_plan_set_small_limit(int(limit)))
 
 
 def emb_pool_bwd_sorted(ids, row_base, plan, D, num_rows, grad, d_fm_logit, scale, dst_table, dst_lin=None, dst_bias=None,

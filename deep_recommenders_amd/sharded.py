@@ -496,6 +496,9 @@ class ShardedDeepFMEngine:
         self.fuse_k3 = (use_planes and _os.environ.get("DR_FUSE_K3", "1") == "1" and D == 64 and self.Nd <= 32
                         and self.wplanes[0] is not None and B * F <= (1 << 24) and self.acts[0] in (0, 1))
         self.dense_pad = torch.zeros((B, 32), **f32) if (self.fuse_k3 and self.Nd) else None
+        # streams for the later micro-batches' fused first layers (see train_step); DR_FWD_STREAMS=0: all on the training stream
+        self.fwd_streams = ([torch.cuda.Stream(device=device) for _ in range(max(0, min(mb - 1, 3)))]
+                            if (self.fuse_k3 and _os.environ.get("DR_FWD_STREAMS", "1") == "1") else [])
         self._events = None
         self._route = None
         self._done = []
@@ -630,11 +633,43 @@ class ShardedDeepFMEngine:
         slices = self._mb_slices()
         prefetched = next_keys is None
         ev_last_apply = None
+        fused_l0 = self.fuse_k3 and not (self.fuse_head and n_layers - 2 == 0)
+
+        def fused_first_layer(m, sl, stream):
+            rows_m, lin_m = got[m]
+            for t in (routes[m].pos, rows_m, lin_m):
+                if t is not None:
+                    t.record_stream(stream)
+            Wt, b = self.Ws[0], self.bs[0]
+            self._k("emb_linear_fwd_L0", "mfma", 2.0 * Bm * Wt.shape[0] * Wt.shape[1],
+                    lambda: ops.bf3_emb_linear_fwd(
+                        routes[m].pos, self.ex._zero_base, rows_m.shape[0], rows_m, lin_m, self.lin_bias,
+                        self.dense_pad[sl] if self.dense_pad is not None else None, self.concat[sl], self.in_dim,
+                        self.wplanes[0].wt, b, self.acts[0], self.sum_x[sl], self.fm_logit[sl], self.hs[0][sl]))
+
+        # The fused first layer of a micro-batch is 256-row tiles x ONE column tile: B / M / 256 blocks, i.e. half of the 256 CUs at
+        # M = 2 -- and a persistent block owns its CU (160 KB of LDS), so each launch takes as long as the full batch's.  The later
+        # micro-batches' first layers therefore run on their own streams, each as soon as ITS rows have arrived: they fill the CUs
+        # the first one leaves idle (world-1, M = 2: 2 x 380 us back to back -> both done ~120 us after the first would be alone),
+        # and with real peers the second forward overlaps the first micro-batch's tower tail instead of queueing behind it.
+        ev_fwd = [None] * M
+        if fused_l0 and cuda and M > 1 and self.fwd_streams:
+            ev_in = torch.cuda.Event()
+            ev_in.record()                       # dense features placed, last step's weight / plane updates behind us
+            for m in range(1, M):
+                st = self.fwd_streams[(m - 1) % len(self.fwd_streams)]
+                with torch.cuda.stream(st):
+                    st.wait_event(ev_in)
+                    st.wait_event(ev_rows[m])
+                    fused_first_layer(m, slices[m], st)
+                    ev_fwd[m] = torch.cuda.Event()
+                    ev_fwd[m].record()
         for m, sl in enumerate(slices):
             # ---- step 6 + tower forward + loss ----------------------------------------------------------------------
             if cuda:
                 main.wait_event(ev_rows[m])
-            fused_l0 = self.fuse_k3 and not (self.fuse_head and n_layers - 2 == 0)
+                if ev_fwd[m] is not None:
+                    main.wait_event(ev_fwd[m])
             if not fused_l0:
                 self._k("emb_pool_fwd", "hbm", Bm * (8 * F * D + 12 * F + 8),
                         lambda m=m, sl=sl: self.ex.pool(routes[m], got[m][0], got[m][1], self.lin_bias, self.ld, concat=self.concat[sl],
@@ -644,15 +679,8 @@ class ShardedDeepFMEngine:
                 if self.fuse_head and i == n_layers - 2:
                     break
                 if i == 0 and fused_l0:
-                    rows_m, lin_m = got[m]
-                    for t in (routes[m].pos, rows_m, lin_m):
-                        if t is not None:
-                            t.record_stream(main)
-                    self._k("emb_linear_fwd_L0", "mfma", 2.0 * Bm * Wt.shape[0] * Wt.shape[1],
-                            lambda m=m, sl=sl, b=b, rows_m=rows_m, lin_m=lin_m: ops.bf3_emb_linear_fwd(
-                                routes[m].pos, self.ex._zero_base, rows_m.shape[0], rows_m, lin_m, self.lin_bias,
-                                self.dense_pad[sl] if self.dense_pad is not None else None, self.concat[sl], self.in_dim,
-                                self.wplanes[0].wt, b, self.acts[0], self.sum_x[sl], self.fm_logit[sl], self.hs[0][sl]))
+                    if ev_fwd[m] is None:
+                        fused_first_layer(m, sl, main)
                 elif self.wplanes[i] is not None and Bm >= self.planes_fwd_rows:
                     self._k("linear_fwd_L%d" % i, "mfma", 2.0 * Bm * Wt.shape[0] * Wt.shape[1],
                             lambda x=x, b=b, i=i, sl=sl: ops.bf3_linear_nt(x, self.wplanes[i].wt, bias=b, act=self.acts[i],

@@ -149,23 +149,29 @@ int dr_emb_pool_bwd(const int64_t* ids, int64_t B, int32_t F, int32_t C, const i
                     float* dst_table, float* dst_lin, float* dst_bias, dr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
- * K4, deterministic form (single-valued fields, C == F <= 64): sort the B*F slots by table row once per
- * batch (dr_emb_sort_slots — depends only on ids, so it can run on a side stream) and flag the slots whose row
- * is unique in the batch; dr_emb_pool_bwd_sorted then applies
+ * K4, deterministic form (single-valued fields, C == F <= 64): build the slot plan once per batch
+ * (dr_emb_sort_slots -- depends only on ids, so it can run on a side stream): flag the slots whose row is unique in
+ * the batch and group the slots of shared rows by row; dr_emb_pool_bwd_sorted then applies
  *     dst_table[row,:] += scale * sum_slots grad[b, f*D:(f+1)*D]      dst_lin[row] += scale * sum_slots d_fm_logit[b]
  *     dst_bias[0]      += scale * sum_b d_fm_logit[b]
  * with (a) a streaming pass in example order doing ONE plain read-modify-write per unique row, and (b) a
  * segmented pass in sorted order for rows hit by several slots.  Per-slot gradient = grad[b, f*D:(f+1)*D]
  * (+ d_fm_logit[b] * (sum_x[b,:] - concat[b, f*D:(f+1)*D]) when concat / sum_x are given, as in
  * dr_emb_pool_bwd; pass NULL when `grad` already holds it).  slot_lin_grad[n] (may be NULL) replaces d_fm_logit[b]
- * as the per-slot first-order gradient — the owner side of the sharded exchange receives gradients per slot.  Rows hit by <= 32 slots are bit-reproducible; hotter rows are cut into
+ * as the per-slot first-order gradient -- the owner side of the sharded exchange receives gradients per slot.  Rows hit by <= 32 slots are bit-reproducible; hotter rows are cut into
  * pieces that combine with fp32 atomics.
- * sorted_rows[n] int64 (missing ids carry num_rows and sort last), sorted_slots[n] int32 (slot = b*F + f),
- * unique_flags[n] uint8 (indexed by slot); dup_heads[n] int32 + dup_count[1] int32 = compact work list of the
- * duplicate pass (sorted positions heading a piece of a multiply-hit row); workspace >=
- * dr_emb_sort_workspace_bytes(n) bytes.
+ * The plan (csrc/emb_plan.hip; hand-written, no library sort): unique_flags[n] uint8 (indexed by slot = b*F + f);
+ * dup_count[2] int32 = {number of work-list entries, length L of the sorted arrays}; sorted_rows[0..L) int64 ascending with
+ * sorted_slots[0..L) int32 ordered by slot inside a row; dup_heads[n] int32 = the duplicate pass's work list (sorted positions
+ * heading a piece of a multiply-hit row).  L is either the number of slots on shared rows (claim path: an open-addressed
+ * table claims every row, the few shared-row slots are sorted by one block in LDS -- uniform ids) or n with missing ids
+ * carrying num_rows at the end (radix path: shared-row slots beyond the LDS list, n > 2^24 or num_rows >= 2^31 - 1); the
+ * choice is made on the device, the host never waits.  Arrays must hold n entries either way.  workspace >=
+ * dr_emb_sort_workspace_bytes(n) bytes.  dr_emb_plan_set_small_limit(limit): largest shared-row list the LDS sort takes
+ * (default / maximum 16384; 0 forces the radix path whenever a row is shared) -- returns the previous value, process-wide.
  * ---------------------------------------------------------------------------------------- */
 int64_t dr_emb_sort_workspace_bytes(int64_t n);
+int32_t dr_emb_plan_set_small_limit(int32_t limit);
 int dr_emb_sort_slots(const int64_t* ids, int64_t B, int32_t F, const int64_t* row_base, int64_t num_rows,
                       int64_t* sorted_rows, int32_t* sorted_slots, uint8_t* unique_flags,
                       int32_t* dup_heads, int32_t* dup_count, void* workspace, int64_t workspace_bytes,

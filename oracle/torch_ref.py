@@ -77,8 +77,11 @@ def cross(x0, x, W, b, diag_scale=0.0):
 
 
 def sigmoid_cross_entropy(labels, logits):
-    """[TF] B9"""
-    return (torch.clamp(logits, min=0) - logits * labels + torch.log1p(torch.exp(-logits.abs()))).mean()
+    """[TF] B9: mean of max(x, 0) - x z + log1p(exp(-|x|)).  max(x, 0) + log1p(exp(-|x|)) is the stable evaluation of
+    softplus(x) = log(1 + e^x); written here as logaddexp(x, 0) -- the same value -- because autograd's subgradients of max / abs
+    at EXACTLY x = 0 sum to 1 instead of sigmoid(0) = 1/2 (found by pinning the gradient against torch's BCEWithLogitsLoss,
+    tests/test_oracle_third_party_pins.py; TF registers the analytic gradient sigmoid(x) - z, as the kernels compute)."""
+    return (torch.logaddexp(logits, torch.zeros_like(logits)) - logits * labels).mean()
 
 
 def log_loss(labels, p, eps=1e-7):

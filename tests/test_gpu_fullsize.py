@@ -6,7 +6,8 @@ on a sampled subset:
     equals the closed form recomputed from the kernel's own concat output;
   * scatter update: linearity / checksum — sum over the table of (after - before) equals scale * sum of the slot
     gradients, only rows named by the batch change, and applying +g then -g restores every row to <= 1 ulp-level error;
-  * sort plan: keys ascending, payload a permutation, unique flags consistent with neighbour equality;
+  * slot plan: unique flags consistent with neighbour equality of the sorted key list; the sorted arrays are exactly the
+    shared-row slots in (row, slot) order (claim path, uniform keys) or a stable sort of all slots (radix path, Zipf keys);
   * top-K: scores descending, idempotent, and no sampled non-selected candidate beats the k-th score."""
 import numpy as np
 import pytest
@@ -73,20 +74,50 @@ def test_gather_pool_full_size_properties(big):
     assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max() + 1)
 
 
+def test_slot_plan_full_size_zipf_takes_the_radix_path(big):
+    """Zipf(1.05) raw keys at the bench size: most slots share rows, the plan falls through to its radix sort of all 1.7 M slots
+    (device-side decision); the result must be the stable sort by row, bit for bit, and the flags the neighbour rule."""
+    ops, rb, R, g = big["ops"], big["row_base"], big["R"], big["g"]
+    u = torch.rand((B, F), device="cuda", generator=g, dtype=torch.float64)
+    al, nn = 1.05, float(10**12)
+    keys = (((nn ** (1 - al) - 1) * u + 1) ** (1 / (1 - al))).long().clamp(1, 10**12)
+    keys[::977, 5] = -1
+    ids = ops.hash_bucket_i64(keys, big["buckets"])
+    plan = ops.emb_sort_slots(ids, rb, R)
+    rows = torch.where(ids >= 0, ids + rb[None, :], torch.full((), R, device="cuda")).reshape(-1)
+    skeys, order = torch.sort(rows, stable=True)
+    assert plan.sorted_len() == B * F                                           # radix path
+    assert torch.equal(plan.rows, skeys) and torch.equal(plan.slots.long(), order)
+    same_prev = torch.cat([torch.zeros(1, dtype=torch.bool, device="cuda"), skeys[1:] == skeys[:-1]])
+    same_next = torch.cat([skeys[1:] == skeys[:-1], torch.zeros(1, dtype=torch.bool, device="cuda")])
+    want_flags = torch.zeros(B * F, dtype=torch.uint8, device="cuda")
+    want_flags[order] = ((~same_prev) & (~same_next) & (skeys < R)).to(torch.uint8)
+    assert torch.equal(plan.flags, want_flags)
+    i = torch.arange(B * F, device="cuda")
+    back = torch.zeros(B * F, dtype=torch.bool, device="cuda")
+    back[32:] = skeys[32:] == skeys[:-32]
+    want_heads = torch.nonzero((skeys < R) & (((~same_prev) & same_next) | (same_prev & (i % 32 == 0) & (i >= 32) & back))).reshape(-1)
+    nh = int(plan.dup_count[0].item())
+    assert torch.equal(torch.sort(plan.dup_heads[:nh].long()).values, want_heads)
+
+
 def test_sorted_update_full_size_properties(big):
     ops, table, lin, ids, rb, R = big["ops"], big["table"], big["lin"], big["ids"], big["row_base"], big["R"]
     g = big["g"]
     plan = ops.emb_sort_slots(ids, rb, R)
-    rows, slots, flags = plan.rows, plan.slots, plan.flags
-    # sort plan invariants
-    assert bool((rows[1:] >= rows[:-1]).all())
-    assert torch.equal(torch.sort(slots.long()).values, torch.arange(B * F, device="cuda"))
+    # plan invariants (uniform ids at the bench size: the claim path -- the sorted arrays hold only the slots of shared rows)
     keys = torch.where(ids >= 0, ids + rb[None, :], torch.full((), R, device="cuda")).reshape(-1)
-    assert torch.equal(rows, keys[slots.long()])
-    same_prev = torch.cat([torch.zeros(1, dtype=torch.bool, device="cuda"), rows[1:] == rows[:-1]])
-    same_next = torch.cat([rows[1:] == rows[:-1], torch.zeros(1, dtype=torch.bool, device="cuda")])
-    uniq_sorted = (~same_prev) & (~same_next) & (rows < R)
-    assert torch.equal(flags[slots.long()].bool(), uniq_sorted)
+    skeys, order = torch.sort(keys, stable=True)
+    same_prev = torch.cat([torch.zeros(1, dtype=torch.bool, device="cuda"), skeys[1:] == skeys[:-1]])
+    same_next = torch.cat([skeys[1:] == skeys[:-1], torch.zeros(1, dtype=torch.bool, device="cuda")])
+    uniq_sorted = (~same_prev) & (~same_next) & (skeys < R)
+    want_flags = torch.zeros(B * F, dtype=torch.uint8, device="cuda")
+    want_flags[order] = uniq_sorted.to(torch.uint8)
+    assert torch.equal(plan.flags, want_flags)
+    L = plan.sorted_len()
+    shared_sorted = (same_prev | same_next) & (skeys < R)
+    assert 0 < L < B * F and L == int(shared_sorted.sum().item())
+    assert torch.equal(plan.rows[:L], skeys[shared_sorted]) and torch.equal(plan.slots[:L].long(), order[shared_sorted])
     # update: checksum / linearity, touched set, round trip
     grad = torch.randn((B, F * D), device="cuda", generator=g) * 1e-2
     dl = torch.randn(B, device="cuda", generator=g) * 1e-2

@@ -467,8 +467,56 @@ def test_rows_gather_scatter_axpy(ops):
 
 
 # ---------------------------------------------------------------- K4 deterministic (sorted) form
+def check_slot_plan(plan, keys, R, expect_path=None):
+    """Invariants of dr_emb_sort_slots' output against the key list `keys` [n] (row per slot, R = missing):
+    flags == "my row is touched by exactly one slot"; the sorted arrays hold either exactly the slots of shared rows (claim path)
+    or all slots with the missing ones last (radix path), ascending by row and by slot inside a row; the work list holds every
+    segment start of a shared row plus the 32-aligned cut points of rows hit more than 32 times."""
+    n = keys.size
+    cnt = np.bincount(keys, minlength=R + 1)
+    want_flags = ((cnt[keys] == 1) & (keys < R)).astype(np.uint8)
+    np.testing.assert_array_equal(plan.flags.cpu().numpy()[:n], want_flags)
+    L = plan.sorted_len()
+    shared = np.nonzero((cnt[keys] > 1) & (keys < R))[0]
+    path = "radix" if L == n else "claim"
+    if expect_path is not None and shared.size > 0:
+        assert path == expect_path or (L == n == shared.size), (path, expect_path, L, n, shared.size)
+    sr, ss = plan.rows.cpu().numpy()[:L], plan.slots.cpu().numpy()[:L]
+    if L == n:      # radix path (or every slot shared): a full stable sort by row
+        order = np.argsort(keys, kind="stable")
+    else:           # claim path: only the shared-row slots, by (row, slot)
+        assert L == shared.size
+        order = shared[np.argsort(keys[shared], kind="stable")]
+    np.testing.assert_array_equal(ss, order.astype(np.int32))
+    np.testing.assert_array_equal(sr, keys[order])
+    nh = int(plan.dup_count[0].item())
+    heads = np.sort(plan.dup_heads.cpu().numpy()[:nh])
+    i = np.arange(L)
+    valid = sr < R
+    seg_start = np.ones(L, dtype=bool)
+    seg_start[1:] = sr[1:] != sr[:-1]
+    has_next = np.zeros(L, dtype=bool)
+    has_next[:-1] = sr[1:] == sr[:-1]
+    back = np.zeros(L, dtype=bool)
+    back[32:] = sr[32:] == sr[:-32]
+    want_heads = np.nonzero(valid & ((seg_start & has_next) | (~seg_start & (i % 32 == 0) & (i >= 32) & back)))[0]
+    np.testing.assert_array_equal(heads, want_heads)
+    return path
+
+
+@pytest.mark.parametrize("path", ["claim", "radix"])
 @pytest.mark.parametrize("D,F,V,hot", [(64, 26, 5000, False), (16, 7, 50, True), (128, 3, 7, True), (12, 5, 1000, False)])
-def test_emb_bwd_sorted_matches_oracle_and_is_deterministic(ops, D, F, V, hot):
+def test_emb_bwd_sorted_matches_oracle_and_is_deterministic(ops, D, F, V, hot, path):
+    """path: the plan's claim table + one-block LDS sort of the shared-row slots (default for short lists), or -- forced through
+    dr_emb_plan_set_small_limit(0) -- the radix sort of all slots that skewed batches take."""
+    prev = ops.emb_plan_set_small_limit(0 if path == "radix" else 16384)
+    try:
+        _emb_bwd_sorted_case(ops, D, F, V, hot, path)
+    finally:
+        ops.emb_plan_set_small_limit(prev)
+
+
+def _emb_bwd_sorted_case(ops, D, F, V, hot, path):
     rng = np.random.default_rng(21)
     B = 1500
     ids = rng.integers(0, V, size=(B, F))
@@ -483,14 +531,12 @@ def test_emb_bwd_sorted_matches_oracle_and_is_deterministic(ops, D, F, V, hot):
     lin = rng.standard_normal(R).astype(np.float32)
     d_ids, d_rb = _dev(ids), _dev(row_base)
     plan = ops.emb_sort_slots(d_ids, d_rb, R)
-    srows, sslots, flags = plan.rows, plan.slots, plan.flags
-    # the sort itself: keys ascending, payload is a permutation, missing ids last
-    sr, ss = srows.cpu().numpy(), sslots.cpu().numpy()
     keys = np.where(ids.reshape(-1) >= 0, (ids + row_base[None, :]).reshape(-1), R)
-    assert np.all(np.diff(sr) >= 0) and sorted(ss.tolist()) == list(range(B * F))
-    np.testing.assert_array_equal(sr, keys[ss])
-    cnt = np.bincount(keys, minlength=R + 1)
-    np.testing.assert_array_equal(flags.cpu().numpy(), ((cnt[keys] == 1) & (keys < R)).astype(np.uint8))
+    check_slot_plan(plan, keys, R, expect_path=path)
+    plan2 = ops.emb_sort_slots(d_ids, d_rb, R)          # the plan itself is bit-reproducible (no arrival-order dependence)
+    L = plan.sorted_len()
+    assert plan2.sorted_len() == L and torch.equal(plan.rows[:L], plan2.rows[:L]) and torch.equal(plan.slots[:L], plan2.slots[:L])
+    assert torch.equal(plan.flags, plan2.flags)
     outs = []
     for _ in range(2):
         t_dev, l_dev, b_dev = _dev(table).clone(), _dev(lin).clone(), torch.zeros(1, device="cuda")
