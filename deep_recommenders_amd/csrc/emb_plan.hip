@@ -8,15 +8,23 @@
 //              probing): atomicCAS(EMPTY -> row) claims, a slot that finds its own row already there sets the entry's DUP bit.
 //   2. FLAGS   slot p is unique  <=>  its entry's DUP bit is clear.  Slots of shared rows are appended (one atomic per wave) to a
 //              short list of composite keys  row << 24 | slot.
-//   3. SMALL   m = |list| <= 16384 (uniform ids at config 3: ~5.3 K): ONE block sorts the list in LDS (bitonic, the composite key
-//              orders by row, then slot: the arrival order of step 2's atomics does not matter -> bit-reproducible plan) and emits
-//              the duplicate pass's work list (segment heads).  The "sorted" arrays then hold ONLY the m shared-row slots;
-//              dup_count[1] = m tells K4 how long they are.
-//   4. LARGE   m beyond the LDS list (skewed / Zipf keys, where most slots share rows) or geometry the composite key cannot hold
+//   3. SMALL   the shared-row slots are dropped into 128 row-range buckets (bucket = row * 128 / num_rows: monotone in the row, so
+//              bucket order is row order; 128 counters instead of one -- 5 K same-address atomics cost 60 us on this chip).  If
+//              no bucket overflows its 256 entries and m = their total <= the limit (uniform ids at config 3: m ~ 11 K), ONE
+//              launch of 128 blocks sorts each bucket in LDS (bitonic; the composite key orders by row, then slot, so the arrival
+//              order of the atomics does not matter -> bit-reproducible plan), writes it at its offset and emits the duplicate
+//              pass's work list (segment heads).  The "sorted" arrays then hold ONLY the m shared-row slots; dup_count[1] = m
+//              tells K4 how long they are.
+//   4. LARGE   m beyond that (skewed / Zipf keys, where most slots share rows) or geometry the composite key cannot hold
 //              (n > 2^24 slots, >= 2^31 - 1 rows): a plain LSD radix sort of ALL n slots by row (8-bit digits; per pass
-//              histogram -> single-block scan -> stable scatter), then the same head / flag marking over the full list.  Every
-//              kernel of this path is always launched and returns at once unless the device-side switch says LARGE (m lives on
-//              the device; the host never waits for it).
+//              per-block histograms -> one scan block per digit -> stable scatter), then the same head / flag marking over the
+//              full list.  Every kernel of this path is always launched and returns at once unless the device-side switch says
+//              LARGE (m lives on the device; the host never waits for it).
+//
+// Measured (tools/exp/plan_bench.py + rocprofv3, config 3's 1.7 M slots): the first version of this file -- one counter for the
+// list, one 1024-thread block sorting it, a single-block histogram scan -- took 412 us (uniform) / 1300 us (Zipf) against
+// rocPRIM's 167 / ~200: 111 us of it were 5.6 K same-address atomics, 80 us the one-block sort, 100 us PER PASS the single-block
+// scan of 65 K histogram entries.  The claim kernel itself is 96 us (1.7 M returning device-scope atomics on random lines).
 //
 // Replaces the ordering half of the autodiff of [TF] safe_embedding_lookup_sparse (IndexedSlices -> unsorted_segment_sum into the
 // variable) reached from optimizer.minimize (examples/train_fm_on_movielens_estimator.py:51-52, reference root); K4 itself is
@@ -29,15 +37,21 @@ namespace {
 constexpr int CH = 32;                       // must equal emb_sorted.hip's CH (piece length of hot rows)
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t DUPBIT = 0x80000000u;
-constexpr int SMALL_CAP = 16384;             // composite keys one block sorts in LDS (128 KB)
+constexpr int SMALL_CAP = 16384;             // largest shared-row list the SMALL path takes
+constexpr int NBK = 128, CAPB = 256;         // row-range buckets of the SMALL path and their capacity (NBK * CAPB >= SMALL_CAP)
 constexpr int RADIX_BITS = 8, RADIX = 1 << RADIX_BITS;
+constexpr int MAX_PASSES = 8;
+constexpr int RADIX_CHUNK = 1664, RADIX_MAX_BLOCKS = 1024;
+constexpr int MARK_BLOCKS = 512;
 
 std::atomic<int> g_small_limit{SMALL_CAP};
 
-struct Ctrl {            // device-side state of one plan build
-    int32_t m;           // shared-row slots found by the claim pass
+struct Ctrl {            // device-side state of one plan build (zeroed at its start)
     int32_t large;       // != 0: the LARGE path runs
+    int32_t overflow;    // hint: some bucket of the SMALL path is full (later slots stop counting)
     int32_t pad[2];
+    int32_t bcnt[NBK];   // shared-row slots per row-range bucket
+    uint32_t gtot[MAX_PASSES][RADIX];   // LARGE: digit totals of each radix pass
 };
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -55,8 +69,8 @@ int64_t table_entries(int64_t n) {
 }
 
 int radix_blocks(int64_t n) {
-    int64_t nb = (n + 2047) / 2048;
-    return (int)(nb < 1 ? 1 : (nb > 256 ? 256 : nb));
+    int64_t nb = (n + RADIX_CHUNK - 1) / RADIX_CHUNK;
+    return (int)(nb < 1 ? 1 : (nb > RADIX_MAX_BLOCKS ? RADIX_MAX_BLOCKS : nb));
 }
 
 struct Layout {
@@ -67,10 +81,10 @@ Layout layout_for(int64_t n) {
     size_t off = 0;
     L.tab = off;    off += align_up((size_t)table_entries(n) * 4, 256);
     L.entry = off;  off += align_up((size_t)n * 4, 256);
-    L.keys_x = off; off += align_up((size_t)n * 8, 256);       // SMALL: the composite-key list; LARGE: radix ping-pong keys
+    L.keys_x = off; off += align_up((size_t)(n > NBK * CAPB ? n : NBK * CAPB) * 8, 256);   // SMALL: the bucket lists; LARGE: radix ping-pong keys
     L.vals_x = off; off += align_up((size_t)n * 4, 256);
-    L.ghist = off;  off += align_up((size_t)RADIX * 256 * 4, 256);
-    L.ctrl = off;   off += 256;
+    L.ghist = off;  off += align_up((size_t)RADIX * RADIX_MAX_BLOCKS * 4, 256);
+    L.ctrl = off;   off += align_up(sizeof(Ctrl), 256);
     L.total = off;
     return L;
 }
@@ -102,92 +116,97 @@ __global__ __launch_bounds__(256) void plan_claim_kernel(const int64_t* __restri
     }
 }
 
-// ---- 2. flags + the list of shared-row slots --------------------------------------------------------------------------------
+// ---- 2. flags + the shared-row slots into their row-range buckets -----------------------------------------------------------
 __global__ __launch_bounds__(256) void plan_flags_kernel(const uint32_t* __restrict__ tab, const uint32_t* __restrict__ entry,
-                                                         int32_t n, uint8_t* __restrict__ flags, uint64_t* __restrict__ list,
-                                                         Ctrl* __restrict__ ctrl) {
+                                                         int32_t n, uint32_t bucket_mul, uint8_t* __restrict__ flags,
+                                                         uint64_t* __restrict__ blist, Ctrl* __restrict__ ctrl) {
     const int32_t stride = gridDim.x * blockDim.x;
-    const int lane = threadIdx.x & 63;
-    const int32_t n_up = (n + 63) & ~63;                              // whole waves stay in the loop (ballot below)
-    for (int32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n_up; p += stride) {
-        const bool in = p < n;
-        const uint32_t e = in ? entry[p] : EMPTY;
+    for (int32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+        const uint32_t e = entry[p];
         const uint32_t v = e != EMPTY ? tab[e] : 0u;
         const bool dup = e != EMPTY && (v & DUPBIT);
-        if (in) flags[p] = (e != EMPTY && !dup) ? 1 : 0;
-        const uint64_t bal = __ballot(dup);
-        if (bal != 0) {
-            const int leader = __ffsll((unsigned long long)bal) - 1;
-            int base = 0;
-            if (lane == leader) base = atomicAdd(&ctrl->m, __popcll(bal));
-            base = __shfl(base, leader, 64);
-            if (dup) list[base + __popcll(bal & ((1ull << lane) - 1ull))] = ((uint64_t)(v & ~DUPBIT) << 24) | (uint32_t)p;
+        flags[p] = (e != EMPTY && !dup) ? 1 : 0;
+        // (a full bucket means the LARGE path will redo everything: stop counting -- a Zipf batch would otherwise queue 1.5 M
+        // atomics on 128 words)
+        if (dup && *reinterpret_cast<volatile const int32_t*>(&ctrl->overflow) == 0) {
+            const uint32_t r = v & ~DUPBIT;
+            const int b = (int)(((uint64_t)r * bucket_mul) >> 32);                  // r * NBK / num_rows, monotone in r
+            const int pos = atomicAdd(&ctrl->bcnt[b], 1);
+            if (pos < CAPB) blist[b * CAPB + pos] = ((uint64_t)r << 24) | (uint32_t)p;
+            else ctrl->overflow = 1;
         }
     }
 }
 
-// ---- 3. SMALL: one block sorts the list in LDS and emits the duplicate pass's work list ------------------------------------------
-__global__ __launch_bounds__(1024) void plan_small_sort_kernel(const uint64_t* __restrict__ list, Ctrl* __restrict__ ctrl,
+// ---- 3. SMALL: one block per bucket sorts it in LDS, writes it at its offset, emits the duplicate pass's work list -----------------
+__global__ __launch_bounds__(256) void plan_bucket_sort_kernel(const uint64_t* __restrict__ blist, Ctrl* __restrict__ ctrl,
                                                                int32_t small_limit, uint64_t* __restrict__ rows,
                                                                int32_t* __restrict__ slots, int32_t* __restrict__ dup_heads,
                                                                int32_t* __restrict__ dup_count) {
-    __shared__ uint64_t s[SMALL_CAP];
-    __shared__ int32_t nheads;
-    const int t = threadIdx.x;
+    __shared__ uint64_t s[CAPB];
+    __shared__ int32_t cnts[NBK];
+    __shared__ int32_t nheads, hbase;
+    const int t = threadIdx.x, b = blockIdx.x;
     if (ctrl->large != 0) return;                                     // geometry forced the LARGE path
-    const int32_t m = ctrl->m;
-    if (m > small_limit) {
-        if (t == 0) ctrl->large = 1;
+    if (t < NBK) cnts[t] = ctrl->bcnt[t];
+    if (t == 0) nheads = 0;
+    __syncthreads();
+    int32_t m = 0, off = 0;
+    bool over = false;
+    for (int i = 0; i < NBK; ++i) {                                   // 128 LDS broadcasts: every thread gets the same totals
+        const int32_t c = cnts[i];
+        over |= c > CAPB;
+        if (i < b) off += c;
+        m += c;
+    }
+    if (over || m > small_limit) {                                    // every block reaches the same verdict
+        if (b == 0 && t == 0) ctrl->large = 1;
         return;
     }
-    int n2 = 1024;
-    while (n2 < m) n2 <<= 1;
-    for (int i = t; i < n2; i += 1024) s[i] = i < m ? list[i] : ~0ull;
-    if (t == 0) nheads = 0;
+    const int cnt = cnts[b];
+    int n2 = 64;
+    while (n2 < cnt) n2 <<= 1;
+    if (t < n2) s[t] = t < cnt ? blist[b * CAPB + t] : ~0ull;
     __syncthreads();
     for (int k = 2; k <= n2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int q = t; q < (n2 >> 1); q += 1024) {
-                const int i = ((q & ~(j - 1)) << 1) | (q & (j - 1));   // the pair (i, i | j), i has bit j clear
+            if (t < (n2 >> 1)) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // the pair (i, i | j), i has bit j clear
                 const int ixj = i | j;
-                const uint64_t a = s[i], b = s[ixj];
+                const uint64_t x = s[i], y = s[ixj];
                 const bool asc = (i & k) == 0;
-                if ((a > b) == asc) {
-                    s[i] = b;
-                    s[ixj] = a;
+                if ((x > y) == asc) {
+                    s[i] = y;
+                    s[ixj] = x;
                 }
             }
             __syncthreads();
         }
     }
-    for (int i0 = 0; i0 < n2; i0 += 1024) {                           // uniform trip count: the ballots below need whole waves
-        const int i = i0 + t;
-        const bool in = i < m;
-        const uint64_t key = in ? s[i] : 0ull;
-        const uint64_t k = key >> 24;
-        bool head = false;
-        if (in) {
-            rows[i] = k;
-            slots[i] = (int32_t)(key & 0xFFFFFFu);
-            const bool seg_start = (i == 0) || ((s[i - 1] >> 24) != k);
-            // every listed slot shares its row with at least one other: a segment start always has a successor
-            head = seg_start || ((i % CH) == 0 && i >= CH && (s[i - CH] >> 24) == k);
-        }
-        const uint64_t bal = __ballot(head);
-        if (bal != 0) {
-            const int lane = t & 63;
-            const int leader = __ffsll((unsigned long long)bal) - 1;
-            int base = 0;
-            if (lane == leader) base = atomicAdd(&nheads, __popcll(bal));
-            base = __shfl(base, leader, 64);
-            if (head) dup_heads[base + __popcll(bal & ((1ull << lane) - 1ull))] = i;
-        }
+    // every listed slot shares its row with at least one other, and a row lives in exactly one bucket: segments never straddle
+    // blocks.  Positions are global (off + t): the 32-aligned cut points of hot rows are those of the concatenated list.
+    const bool in = t < cnt;
+    const int gi = off + t;
+    bool head = false;
+    if (in) {
+        const uint64_t k = s[t] >> 24;
+        rows[gi] = k;
+        slots[gi] = (int32_t)(s[t] & 0xFFFFFFu);
+        const bool seg_start = (t == 0) || ((s[t - 1] >> 24) != k);
+        head = seg_start || ((gi % CH) == 0 && t >= CH && (s[t - CH] >> 24) == k);
     }
+    const uint64_t bal = __ballot(head);
+    const int lane = t & 63;
+    int wbase = 0;
+    if (bal != 0 && lane == __ffsll((unsigned long long)bal) - 1) wbase = atomicAdd(&nheads, __popcll(bal));
     __syncthreads();
-    if (t == 0) {
-        dup_count[0] = nheads;
-        dup_count[1] = m;                                             // length of the sorted arrays K4's duplicate pass walks
+    if (t == 0) hbase = nheads > 0 ? atomicAdd(&dup_count[0], nheads) : 0;        // ONE global atomic per bucket
+    __syncthreads();
+    if (bal != 0) {
+        wbase = __shfl(wbase, __ffsll((unsigned long long)bal) - 1, 64);
+        if (head) dup_heads[hbase + wbase + __popcll(bal & ((1ull << lane) - 1ull))] = gi;
     }
+    if (b == 0 && t == 0) dup_count[1] = m;                           // length of the sorted arrays K4's duplicate pass walks
 }
 
 // ---- 4. LARGE: LSD radix sort of all n (row, slot) pairs + marking --------------------------------------------------------------
@@ -204,8 +223,8 @@ __global__ __launch_bounds__(256) void radix_make_keys_kernel(const int64_t* __r
     }
 }
 
-__global__ __launch_bounds__(256) void radix_hist_kernel(const uint64_t* __restrict__ keys, int32_t n, int shift,
-                                                         uint32_t* __restrict__ ghist, const Ctrl* __restrict__ ctrl) {
+__global__ __launch_bounds__(256) void radix_hist_kernel(const uint64_t* __restrict__ keys, int32_t n, int shift, int pass,
+                                                         uint32_t* __restrict__ ghist, Ctrl* __restrict__ ctrl) {
     if (ctrl->large == 0) return;
     __shared__ uint32_t h[RADIX];
     const int nb = gridDim.x, t = threadIdx.x;
@@ -216,30 +235,42 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const uint64_t* __restr
     for (int32_t i = beg + t; i < end; i += 256) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & (RADIX - 1)], 1u);
     __syncthreads();
     ghist[t * nb + blockIdx.x] = h[t];
+    if (h[t] != 0) atomicAdd(&ctrl->gtot[pass][t], h[t]);            // digit totals: nb atomics per word, 256 words
 }
 
-// exclusive scan of ghist[RADIX * nb] in place (digit-major: all keys of smaller digits, then the same digit in earlier blocks)
-__global__ __launch_bounds__(1024) void radix_scan_kernel(uint32_t* __restrict__ ghist, int32_t total,
-                                                          const Ctrl* __restrict__ ctrl) {
+// One block per digit d: ghist[d][0 .. nb) -> exclusive scan over the blocks + the number of keys with a smaller digit
+// (digit-major order of the destination: all keys of smaller digits, then the same digit in earlier blocks).
+__global__ __launch_bounds__(256) void radix_scan_kernel(uint32_t* __restrict__ ghist, int32_t nb, int pass,
+                                                         const Ctrl* __restrict__ ctrl) {
     if (ctrl->large == 0) return;
-    __shared__ uint32_t part[1024];
-    const int t = threadIdx.x;
-    const int32_t per = (total + 1023) / 1024;
-    const int32_t beg = t * per, end = beg + per < total ? beg + per : total;
+    __shared__ uint32_t part[256];
+    __shared__ uint32_t wsum[4];
+    const int t = threadIdx.x, d = blockIdx.x, lane = t & 63, w = t >> 6;
+    // base = sum of the totals of the digits below d
+    uint32_t v = t < d ? ctrl->gtot[pass][t] : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) wsum[w] = v;
+    __syncthreads();
+    const uint32_t base = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    // this thread's run of the column
+    const int32_t per = (nb + 255) / 256;
+    const int32_t beg = t * per, end = beg + per < nb ? beg + per : nb;
+    uint32_t* col = ghist + (int64_t)d * nb;
     uint32_t sum = 0;
-    for (int32_t i = beg; i < end; ++i) sum += ghist[i];
+    for (int32_t i = beg; i < end; ++i) sum += col[i];
     part[t] = sum;
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {                              // Hillis-Steele inclusive scan of the 1024 partials
-        const uint32_t v = t >= o ? part[t - o] : 0u;
+    for (int o = 1; o < 256; o <<= 1) {                               // Hillis-Steele inclusive scan of the 256 partials
+        const uint32_t x = t >= o ? part[t - o] : 0u;
         __syncthreads();
-        part[t] += v;
+        part[t] += x;
         __syncthreads();
     }
-    uint32_t run = part[t] - sum;                                     // exclusive prefix of this thread's range
+    uint32_t run = base + part[t] - sum;
     for (int32_t i = beg; i < end; ++i) {
-        const uint32_t c = ghist[i];
-        ghist[i] = run;
+        const uint32_t c = col[i];
+        col[i] = run;
         run += c;
     }
 }
@@ -294,18 +325,25 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* __re
 
 // LARGE path's marking over the fully sorted list: flag[p] = 1 iff slot p is the only slot of the batch that touches its row;
 // every sorted position that heads a piece of a row touched by >= 2 slots (the segment start, plus each CH-aligned position
-// >= CH past it) is appended to dup_heads -- ONE atomic per wave (a skewed batch has ~1e5 heads and same-address atomics retire
-// at ~88 per microsecond).
+// >= CH past it) goes to dup_heads.  A block owns a contiguous chunk, collects its heads in LDS and reserves their place with ONE
+// global atomic (a Zipf batch has ~1e5 heads; one same-address atomic per wave cost 300 us, they retire at ~88 per microsecond).
+constexpr int MARK_MAX_CHUNK = 8192;
 __global__ __launch_bounds__(256) void radix_mark_kernel(const uint64_t* __restrict__ rows, const int32_t* __restrict__ slots,
                                                          int32_t n, uint64_t num_rows, uint8_t* __restrict__ flags,
                                                          int32_t* __restrict__ dup_heads, int32_t* __restrict__ dup_count,
                                                          const Ctrl* __restrict__ ctrl) {
     if (ctrl->large == 0) return;
-    const int32_t stride = gridDim.x * blockDim.x;
-    const int32_t n_up = (n + 63) & ~63;
-    if (blockIdx.x == 0 && threadIdx.x == 0) dup_count[1] = n;
-    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_up; i += stride) {
-        const bool in = i < n;
+    __shared__ int32_t hl[MARK_MAX_CHUNK];
+    __shared__ int32_t nh, gbase;
+    const int t = threadIdx.x, lane = t & 63;
+    const int32_t chunk = (n + (int32_t)gridDim.x - 1) / (int32_t)gridDim.x;        // <= MARK_MAX_CHUNK by the launch
+    const int32_t beg = (int32_t)blockIdx.x * chunk, end = beg + chunk < n ? beg + chunk : n;
+    if (blockIdx.x == 0 && t == 0) dup_count[1] = n;
+    if (t == 0) nh = 0;
+    __syncthreads();
+    for (int32_t i0 = beg; i0 < end; i0 += 256) {                     // block-uniform trip count (ballots below)
+        const int32_t i = i0 + t;
+        const bool in = i < end;
         const uint64_t k = in ? rows[i] : ~0ull;
         const bool valid = in && k < num_rows;
         const bool seg_start = in && ((i == 0) || (rows[i - 1] != k));
@@ -314,14 +352,17 @@ __global__ __launch_bounds__(256) void radix_mark_kernel(const uint64_t* __restr
         const bool head = valid && ((seg_start && has_next) || (!seg_start && (i % CH) == 0 && i >= CH && rows[i - CH] == k));
         const uint64_t bal = __ballot(head);
         if (bal != 0) {
-            const int lane = threadIdx.x & 63;
             const int leader = __ffsll((unsigned long long)bal) - 1;
             int base = 0;
-            if (lane == leader) base = atomicAdd(dup_count, __popcll(bal));
+            if (lane == leader) base = atomicAdd(&nh, __popcll(bal));
             base = __shfl(base, leader, 64);
-            if (head) dup_heads[base + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+            if (head) hl[base + __popcll(bal & ((1ull << lane) - 1ull))] = i;
         }
     }
+    __syncthreads();
+    if (t == 0) gbase = nh > 0 ? atomicAdd(dup_count, nh) : 0;
+    __syncthreads();
+    for (int j = t; j < nh; j += 256) dup_heads[gbase + j] = hl[j];
 }
 
 }  // namespace
@@ -371,10 +412,11 @@ extern "C" int dr_emb_sort_slots(const int64_t* ids, int64_t B, int32_t F, const
         const int64_t T = table_entries(n64);
         int log_t = 0;
         while ((1ll << log_t) < T) ++log_t;
+        const uint32_t bucket_mul = (uint32_t)((((uint64_t)NBK) << 32) / (uint64_t)num_rows);     // floor: row * mul >> 32 < NBK
         if (hipMemsetAsync(tab, 0xFF, (size_t)T * 4, s) != hipSuccess) return DR_ELAUNCH;
         hipLaunchKernelGGL(plan_claim_kernel, dim3(grid), dim3(256), 0, s, ids, n, F, row_base, tab, log_t, entry);
-        hipLaunchKernelGGL(plan_flags_kernel, dim3(grid), dim3(256), 0, s, tab, entry, n, unique_flags, keys_x, ctrl);
-        hipLaunchKernelGGL(plan_small_sort_kernel, dim3(1), dim3(1024), 0, s, keys_x, ctrl, (int32_t)g_small_limit.load(), rows_y,
+        hipLaunchKernelGGL(plan_flags_kernel, dim3(grid), dim3(256), 0, s, tab, entry, n, bucket_mul, unique_flags, keys_x, ctrl);
+        hipLaunchKernelGGL(plan_bucket_sort_kernel, dim3(NBK), dim3(256), 0, s, keys_x, ctrl, (int32_t)g_small_limit.load(), rows_y,
                            sorted_slots, dup_heads, dup_count);
     } else {
         if (hipMemsetAsync(&ctrl->large, 1, sizeof(int32_t), s) != hipSuccess) return DR_ELAUNCH;
@@ -390,14 +432,16 @@ extern "C" int dr_emb_sort_slots(const int64_t* ids, int64_t B, int32_t F, const
                        vbuf[cur], ctrl);
     for (int p = 0; p < passes; ++p) {
         const int shift = p * RADIX_BITS;
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(256), 0, s, kbuf[cur], n, shift, ghist, ctrl);
-        hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, s, ghist, (int32_t)(RADIX * nb), ctrl);
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(256), 0, s, kbuf[cur], n, shift, p, ghist, ctrl);
+        hipLaunchKernelGGL(radix_scan_kernel, dim3(RADIX), dim3(256), 0, s, ghist, (int32_t)nb, p, ctrl);
         hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(256), 0, s, kbuf[cur], vbuf[cur], kbuf[cur ^ 1], vbuf[cur ^ 1], n,
                            shift, ghist, ctrl);
         cur ^= 1;
     }
-    hipLaunchKernelGGL(radix_mark_kernel, dim3(grid), dim3(256), 0, s, rows_y, sorted_slots, n, (uint64_t)num_rows, unique_flags,
-                       dup_heads, dup_count, ctrl);
+    int mark_blocks = MARK_BLOCKS;
+    while ((n + mark_blocks - 1) / mark_blocks > MARK_MAX_CHUNK) mark_blocks *= 2;
+    hipLaunchKernelGGL(radix_mark_kernel, dim3(mark_blocks), dim3(256), 0, s, rows_y, sorted_slots, n, (uint64_t)num_rows,
+                       unique_flags, dup_heads, dup_count, ctrl);
     DR_CHECK_LAUNCH();
     return DR_OK;
 }

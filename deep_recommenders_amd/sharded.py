@@ -109,6 +109,78 @@ class HostStagedTransport(TorchDistTransport):
         return out
 
 
+class CApiTransport:
+    """The exchange steps through the C-ABI library (include/dr_collectives.h -> lib/libdr_collectives.so: RCCL underneath, raw
+    device pointers + the current hipStream_t) -- what a host that is not PyTorch would call.  torch.distributed is used once, to
+    hand rank 0's RCCL rendezvous id to the other ranks (any side channel would do); every exchange of the training step then
+    goes through dr_coll_*.  DR_TRANSPORT=capi selects it in bench.py / the engines' default."""
+
+    def __init__(self, world, rank, group=None, id_bytes=None):
+        import ctypes
+        from . import _coll_lib
+        self._C, self._ct = _coll_lib, ctypes
+        L = _coll_lib.lib()
+        if id_bytes is None:
+            buf = ctypes.create_string_buffer(_coll_lib.ID_BYTES)
+            if rank == 0:
+                _coll_lib.check(L.dr_coll_unique_id(buf), "dr_coll_unique_id")
+            box = [bytes(buf.raw)]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0, group=group)
+            id_bytes = box[0]
+        self.world, self.rank = world, rank
+        self._comm = ctypes.c_void_p()
+        _coll_lib.check(L.dr_coll_init(ctypes.byref(self._comm), world, rank, ctypes.create_string_buffer(id_bytes, _coll_lib.ID_BYTES)),
+                        "dr_coll_init")
+
+    def close(self):
+        if self._comm:
+            self._C.lib().dr_coll_destroy(self._comm)
+            self._comm = self._ct.c_void_p()
+
+    @staticmethod
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    def alltoall(self, out, inp, out_splits=None, in_splits=None):
+        assert out.is_contiguous() and inp.is_contiguous() and out.dtype == inp.dtype
+        L, W = self._C.lib(), self.world
+        row = inp.element_size() * (inp[0].numel() if inp.dim() > 1 else 1)          # bytes per leading-dimension element
+        if out_splits is None:
+            per = inp.shape[0] // W
+            in_splits = out_splits = [per] * W
+        arr = self._ct.c_int64 * W
+        self._C.check(L.dr_coll_alltoallv(self._comm, inp.data_ptr(), arr(*in_splits), out.data_ptr(), arr(*out_splits), row,
+                                          self._stream()), "dr_coll_alltoallv")
+        return out
+
+    def allreduce(self, t, async_op=False, op=None):
+        assert t.is_contiguous()
+        if (op is not None and op != dist.ReduceOp.SUM) or t.dtype != torch.float32:
+            # the library reduces fp32 sums (the dense-gradient bucket); the odd small reduction (a shard-size MAX) is an all-gather
+            # followed by a local reduce
+            allv = self.allgather(torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device), t)
+            red = {dist.ReduceOp.MAX: allv.amax(0), dist.ReduceOp.MIN: allv.amin(0)}.get(op)
+            t.copy_(red if red is not None else allv.sum(0))
+            return _DoneWork() if async_op else None
+        self._C.check(self._C.lib().dr_coll_allreduce_f32(self._comm, t.data_ptr(), t.numel(), self._stream()), "dr_coll_allreduce_f32")
+        return _DoneWork() if async_op else None          # stream-ordered: nothing for the host to wait for
+
+    def allgather(self, out, inp):
+        assert out.is_contiguous() and inp.is_contiguous()
+        self._C.check(self._C.lib().dr_coll_allgather(self._comm, inp.data_ptr(), out.data_ptr(), inp.numel() * inp.element_size(),
+                                                      self._stream()), "dr_coll_allgather")
+        return out
+
+
+def default_transport(world, rank, group=None):
+    """torch.distributed unless DR_TRANSPORT=capi asks for the C-ABI exchange library."""
+    import os as _os
+    if _os.environ.get("DR_TRANSPORT", "torch") == "capi":
+        return CApiTransport(world, rank, group)
+    return TorchDistTransport(group)
+
+
 class Route:
     """Everything about one batch that depends only on its keys: where each slot's row lives, how many rows travel to /
     from each rank, the owner-side list of requested rows and its sort plan.  Built by ShardedEmbeddingExchange.route()
@@ -142,7 +214,7 @@ class ShardedEmbeddingExchange:
         self.local_rows = num_fields * self.rows_per_shard
         self.p = prims if prims is not None else HipPrims
         self.group = group
-        self.tr = transport if transport is not None else TorchDistTransport(group)
+        self.tr = transport if transport is not None else default_transport(world, rank, group)
         # One rank owns everything: every "exchange" is the identity.  The buffers then ALIAS (bucketing writes the owner-side row
         # list, the gather output is the receive buffer, the packed gradients are written where the owner-side K4 reads them) and
         # no collective is issued -- RCCL used to copy 2 x 443 MB to itself per step.  alias_world1=False keeps the

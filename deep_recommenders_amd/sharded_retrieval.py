@@ -30,7 +30,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
-from .sharded import HipPrims, ShardedEmbeddingExchange, TorchDistTransport, _pad4
+from .sharded import HipPrims, ShardedEmbeddingExchange, TorchDistTransport, default_transport, _pad4
 
 
 class RetrievalPrims(HipPrims):
@@ -145,7 +145,7 @@ class ShardedTwoTowerEngine:
         self.remove_accidental_hits = remove_accidental_hits
         self.p = prims if prims is not None else RetrievalPrims
         W = self.world
-        self.tr = transport if transport is not None else TorchDistTransport(group)
+        self.tr = transport if transport is not None else default_transport(self.world, self.rank, group)
         # (alias_world1 off: the two-tower exchanges are 4 MB, and this engine's world-1 GPU test is the one that pushes the
         # exchange code through an RCCL group of one)
         self.ex_u = ShardedEmbeddingExchange(1, num_users, dim, W, self.rank, device, self.p, group, transport=self.tr, alias_world1=False)
