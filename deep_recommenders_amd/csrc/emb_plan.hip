@@ -2,29 +2,26 @@
 // and -- for the rows several slots share -- those slots grouped by row in a fixed order.  Hand-written for gfx950; replaces the
 // general-purpose 64-bit rocPRIM radix sort of rounds 1-2 ("a library call on the hot path").
 //
-// Criteo-shaped batches are almost duplicate-free (uniform hashed ids: 99.7 % of the B*F slots are the only slot of their row),
-// so sorting all 1.7 M (row, slot) pairs to find 5 K duplicates is the wrong algorithm.  Instead:
-//   1. CLAIM   every slot inserts its row into an open-addressed table (2n .. 4n 32-bit entries, multiplicative hash, linear
-//              probing): atomicCAS(EMPTY -> row) claims, a slot that finds its own row already there sets the entry's DUP bit.
-//   2. FLAGS   slot p is unique  <=>  its entry's DUP bit is clear.  Slots of shared rows are appended (one atomic per wave) to a
-//              short list of composite keys  row << 24 | slot.
-//   3. SMALL   the shared-row slots are dropped into 128 row-range buckets (bucket = row * 128 / num_rows: monotone in the row, so
-//              bucket order is row order; 128 counters instead of one -- 5 K same-address atomics cost 60 us on this chip).  If
-//              no bucket overflows its 256 entries and m = their total <= the limit (uniform ids at config 3: m ~ 11 K), ONE
-//              launch of 128 blocks sorts each bucket in LDS (bitonic; the composite key orders by row, then slot, so the arrival
-//              order of the atomics does not matter -> bit-reproducible plan), writes it at its offset and emits the duplicate
-//              pass's work list (segment heads).  The "sorted" arrays then hold ONLY the m shared-row slots; dup_count[1] = m
-//              tells K4 how long they are.
-//   4. LARGE   m beyond that (skewed / Zipf keys, where most slots share rows) or geometry the composite key cannot hold
-//              (n > 2^24 slots, >= 2^31 - 1 rows): a plain LSD radix sort of ALL n slots by row (8-bit digits; per pass
-//              per-block histograms -> one scan block per digit -> stable scatter), then the same head / flag marking over the
-//              full list.  Every kernel of this path is always launched and returns at once unless the device-side switch says
-//              LARGE (m lives on the device; the host never waits for it).
-//
-// Measured (tools/exp/plan_bench.py + rocprofv3, config 3's 1.7 M slots): the first version of this file -- one counter for the
-// list, one 1024-thread block sorting it, a single-block histogram scan -- took 412 us (uniform) / 1300 us (Zipf) against
-// rocPRIM's 167 / ~200: 111 us of it were 5.6 K same-address atomics, 80 us the one-block sort, 100 us PER PASS the single-block
-// scan of 65 K histogram entries.  The claim kernel itself is 96 us (1.7 M returning device-scope atomics on random lines).
+// Criteo-shaped batches are almost duplicate-free (uniform hashed ids: 99.3 % of the B*F slots are the only slot of their row),
+// so sorting all 1.7 M (row, slot) pairs four digits deep to find 11 K duplicates is the wrong algorithm.  Instead:
+//   SMALL  1. PARTITION  one counting-sort pass (per-block histogram -> scan -> stable scatter, the radix machinery below with the
+//                        digit "row * 256 / num_rows") splits the slots into 256 row-range partitions of ~6.6 K slots.
+//          2. CLAIM      one block per partition inserts its rows into an open-addressed table IN LDS (32 K entries, ds_cmpst):
+//                        a slot that finds its row already there sets the entry's DUP bit.  A second sweep over the partition
+//                        writes flag[slot] = "DUP bit clear" and collects the shared-row slots (composite key row << 24 | slot)
+//                        in the partition's bucket.  No device-scope atomics on data: the first version of this file claimed
+//                        rows in a GLOBAL table -- 1.7 M returning atomics on random lines cost 96 us, 11 K appends to
+//                        128 counters (4 cache lines) another 100+ (tools/exp/plan_bench.py under rocprofv3).
+//          3. SORT       if no bucket overflows and the m shared-row slots are <= the limit (uniform ids at config 3: m ~ 11 K),
+//                        ONE launch of 256 blocks sorts each bucket in LDS (bitonic; the composite key orders by row, then slot,
+//                        so nothing depends on arrival order -> bit-reproducible plan), writes it at its offset (partitions are
+//                        row ranges: bucket order is row order) and emits the duplicate pass's work list (segment heads).  The
+//                        "sorted" arrays then hold ONLY the m shared-row slots; dup_count[1] = m tells K4 how long they are.
+//   LARGE  m beyond that or a partition beyond its LDS table (skewed / Zipf keys, where most slots share rows), or geometry the
+//          composite key cannot hold (n > 2^24 slots, >= 2^31 - 1 rows): a plain LSD radix sort of ALL n slots by row (8-bit
+//          digits; per pass per-block histograms -> one scan block per digit -> stable scatter), then the same head / flag
+//          marking over the full list.  Every kernel of this path is always launched and returns at once unless the device-side
+//          switch says LARGE (the verdict lives on the device; the host never waits for it).
 //
 // Replaces the ordering half of the autodiff of [TF] safe_embedding_lookup_sparse (IndexedSlices -> unsorted_segment_sum into the
 // variable) reached from optimizer.minimize (examples/train_fm_on_movielens_estimator.py:51-52, reference root); K4 itself is
@@ -38,20 +35,20 @@ constexpr int CH = 32;                       // must equal emb_sorted.hip's CH (
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t DUPBIT = 0x80000000u;
 constexpr int SMALL_CAP = 16384;             // largest shared-row list the SMALL path takes
-constexpr int NBK = 128, CAPB = 256;         // row-range buckets of the SMALL path and their capacity (NBK * CAPB >= SMALL_CAP)
 constexpr int RADIX_BITS = 8, RADIX = 1 << RADIX_BITS;
-constexpr int MAX_PASSES = 8;
+constexpr int NBK = RADIX, CAPB = 128;       // row-range partitions (= buckets of the shared-row list) and a bucket's capacity
+constexpr int LDS_TAB = 32768;               // entries of a partition's claim table (128 KB of LDS)
+constexpr int PART_CAP = 20000;              // slots one partition may hold (table load <= 0.61); beyond: LARGE
 constexpr int RADIX_CHUNK = 1664, RADIX_MAX_BLOCKS = 1024;
-constexpr int MARK_BLOCKS = 512;
+constexpr int MARK_BLOCKS = 512, MARK_MAX_CHUNK = 8192;
+static_assert(NBK * CAPB >= SMALL_CAP, "buckets must hold the largest SMALL list");
 
 std::atomic<int> g_small_limit{SMALL_CAP};
 
 struct Ctrl {            // device-side state of one plan build (zeroed at its start)
     int32_t large;       // != 0: the LARGE path runs
-    int32_t overflow;    // hint: some bucket of the SMALL path is full (later slots stop counting)
-    int32_t pad[2];
-    int32_t bcnt[NBK];   // shared-row slots per row-range bucket
-    uint32_t gtot[MAX_PASSES][RADIX];   // LARGE: digit totals of each radix pass
+    int32_t pad[3];
+    int32_t bcnt[NBK];   // shared-row slots per partition
 };
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -62,47 +59,187 @@ unsigned bits_for(uint64_t v) {
     return b;
 }
 
-int64_t table_entries(int64_t n) {
-    int64_t t = 1024;
-    while (t < 2 * n) t <<= 1;
-    return t;
-}
-
 int radix_blocks(int64_t n) {
     int64_t nb = (n + RADIX_CHUNK - 1) / RADIX_CHUNK;
     return (int)(nb < 1 ? 1 : (nb > RADIX_MAX_BLOCKS ? RADIX_MAX_BLOCKS : nb));
 }
 
 struct Layout {
-    size_t tab, entry, keys_x, vals_x, ghist, ctrl, total;
+    size_t keys_x, vals_x, blist, ghist, tot, ctrl, total;
 };
 Layout layout_for(int64_t n) {
     Layout L{};
     size_t off = 0;
-    L.tab = off;    off += align_up((size_t)table_entries(n) * 4, 256);
-    L.entry = off;  off += align_up((size_t)n * 4, 256);
-    L.keys_x = off; off += align_up((size_t)(n > NBK * CAPB ? n : NBK * CAPB) * 8, 256);   // SMALL: the bucket lists; LARGE: radix ping-pong keys
+    L.keys_x = off; off += align_up((size_t)n * 8, 256);          // partition pass output / radix ping-pong keys
     L.vals_x = off; off += align_up((size_t)n * 4, 256);
+    L.blist = off;  off += align_up((size_t)NBK * CAPB * 8, 256);  // the shared-row slots, one bucket per partition
     L.ghist = off;  off += align_up((size_t)RADIX * RADIX_MAX_BLOCKS * 4, 256);
+    L.tot = off;    off += align_up((size_t)RADIX * 4, 256);       // digit totals of the current pass
     L.ctrl = off;   off += align_up(sizeof(Ctrl), 256);
     L.total = off;
     return L;
 }
 
-// ---- 1. claim -----------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void plan_claim_kernel(const int64_t* __restrict__ ids, int32_t n, int32_t F,
-                                                         const int64_t* __restrict__ row_base, uint32_t* __restrict__ tab,
-                                                         int32_t log_t, uint32_t* __restrict__ entry) {
-    const uint32_t mask = (1u << log_t) - 1u;
+// digit of a key: MODE 0 = bits [shift, shift + 8) (LSD radix pass); MODE 1 = row * 256 / num_rows through a multiply-shift
+// (the argument carries the multiplier), the missing-id sentinel (== num_rows) lands in the last partition
+template <int MODE>
+__device__ __forceinline__ uint32_t digit_of(uint64_t k, uint32_t shift_or_mul) {
+    if (MODE == 0) return (uint32_t)(k >> shift_or_mul) & (RADIX - 1);
+    const uint32_t d = (uint32_t)((k * shift_or_mul) >> 32);
+    return d < RADIX - 1 ? d : RADIX - 1;
+}
+
+// ---- the counting-sort pass: keys, per-block histograms, per-digit scan, stable scatter ---------------------------------------------
+// GATED = 0: always runs (the SMALL path's partition pass); 1: only when ctrl->large (the LARGE path)
+template <int GATED>
+__global__ __launch_bounds__(256) void radix_make_keys_kernel(const int64_t* __restrict__ ids, int32_t n, int32_t F,
+                                                              const int64_t* __restrict__ row_base, uint64_t sentinel,
+                                                              uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                              const Ctrl* __restrict__ ctrl) {
+    if (GATED && ctrl->large == 0) return;
     const int32_t stride = gridDim.x * blockDim.x;
     for (int32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
         const int64_t id = ids[p];
-        if (id < 0) {
-            entry[p] = EMPTY;
-            continue;
+        keys[p] = id >= 0 ? (uint64_t)(row_base[p % F] + id) : sentinel;   // missing ids sort to the end
+        vals[p] = (uint32_t)p;
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void radix_hist_kernel(const uint64_t* __restrict__ keys, int32_t n, uint32_t shift_or_mul,
+                                                         uint32_t* __restrict__ ghist, const Ctrl* __restrict__ ctrl) {
+    if (MODE == 0 && ctrl->large == 0) return;
+    __shared__ uint32_t h[RADIX];
+    const int nb = gridDim.x, t = threadIdx.x;
+    const int32_t chunk = (n + nb - 1) / nb;
+    const int32_t beg = (int32_t)blockIdx.x * chunk, end = beg + chunk < n ? beg + chunk : n;
+    h[t] = 0;
+    __syncthreads();
+    for (int32_t i = beg + t; i < end; i += 256) atomicAdd(&h[digit_of<MODE>(keys[i], shift_or_mul)], 1u);
+    __syncthreads();
+    ghist[t * nb + blockIdx.x] = h[t];
+}
+
+// One block per digit d: ghist[d][0 .. nb) -> exclusive scan over the blocks (position inside the digit's range); the digit's
+// total goes to tot[d] -- the scatter blocks turn the 256 totals into range starts themselves (an LDS scan), so no block here
+// needs another digit's column and nothing is combined with atomics.
+template <int GATED>
+__global__ __launch_bounds__(256) void radix_scan_kernel(uint32_t* __restrict__ ghist, int32_t nb, uint32_t* __restrict__ tot,
+                                                         const Ctrl* __restrict__ ctrl) {
+    if (GATED && ctrl->large == 0) return;
+    __shared__ uint32_t part[256];
+    const int t = threadIdx.x, d = blockIdx.x;
+    const int32_t per = (nb + 255) / 256;
+    const int32_t beg = t * per, end = beg + per < nb ? beg + per : nb;
+    uint32_t* col = ghist + (int64_t)d * nb;
+    uint32_t sum = 0;
+    for (int32_t i = beg; i < end; ++i) sum += col[i];
+    part[t] = sum;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {                               // Hillis-Steele inclusive scan of the 256 partials
+        const uint32_t x = t >= o ? part[t - o] : 0u;
+        __syncthreads();
+        part[t] += x;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - sum;
+    for (int32_t i = beg; i < end; ++i) {
+        const uint32_t c = col[i];
+        col[i] = run;
+        run += c;
+    }
+    if (t == 255) tot[d] = part[255];
+}
+
+// stable scatter: block b re-reads its chunk in order, 256 keys at a time; a key's destination = start of its digit's range
+// + the scanned histogram entry of its digit for this block, advanced by the tiles already written + the number of EARLIER keys
+// of the tile with the same digit (wave-level match by eight ballots, earlier waves' counts through LDS).
+template <int MODE>
+__global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin,
+                                                            uint64_t* __restrict__ kout, uint32_t* __restrict__ vout, int32_t n,
+                                                            uint32_t shift_or_mul, const uint32_t* __restrict__ ghist,
+                                                            const uint32_t* __restrict__ tot, const Ctrl* __restrict__ ctrl) {
+    if (MODE == 0 && ctrl->large == 0) return;
+    __shared__ uint32_t running[RADIX];
+    __shared__ uint32_t wcnt[4][RADIX];
+    const int nb = gridDim.x, t = threadIdx.x, w = t >> 6, lane = t & 63;
+    const int32_t chunk = (n + nb - 1) / nb;
+    const int32_t beg = (int32_t)blockIdx.x * chunk, end = beg + chunk < n ? beg + chunk : n;
+    {   // range starts = exclusive scan of the 256 digit totals
+        const uint32_t mine = tot[t];
+        running[t] = mine;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const uint32_t x = t >= o ? running[t - o] : 0u;
+            __syncthreads();
+            running[t] += x;
+            __syncthreads();
         }
-        const uint32_t r = (uint32_t)(row_base[p % F] + id);
-        uint32_t h = (r * 2654435761u) >> (32 - log_t);
+        const uint32_t start = running[t] - mine;
+        __syncthreads();
+        running[t] = start + ghist[t * nb + blockIdx.x];
+    }
+    __syncthreads();
+    for (int32_t base = beg; base < end; base += 256) {
+        const int32_t i = base + t;
+        const bool live = i < end;
+        const uint64_t k = live ? kin[i] : 0ull;
+        const uint32_t v = live ? vin[i] : 0u;
+        const uint32_t d = digit_of<MODE>(k, shift_or_mul);
+        wcnt[0][t] = 0; wcnt[1][t] = 0; wcnt[2][t] = 0; wcnt[3][t] = 0;
+        __syncthreads();
+        uint64_t mask = __ballot(live);                               // lanes with my digit (dead lanes never match)
+#pragma unroll
+        for (int b = 0; b < RADIX_BITS; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t vote = __ballot(bit);
+            mask &= bit ? vote : ~vote;
+        }
+        const uint32_t rank_in_wave = __popcll(mask & ((1ull << lane) - 1ull));
+        if (live && rank_in_wave == 0) wcnt[w][d] = __popcll(mask);
+        __syncthreads();
+        uint32_t pos = 0;
+        if (live) {
+            pos = running[d] + rank_in_wave;
+            for (int ww = 0; ww < w; ++ww) pos += wcnt[ww][d];
+        }
+        __syncthreads();                                              // every read of running[] precedes its update
+        running[t] += wcnt[0][t] + wcnt[1][t] + wcnt[2][t] + wcnt[3][t];
+        if (live) {
+            kout[pos] = k;
+            vout[pos] = v;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- SMALL 2: one block per partition claims its rows in an LDS table, flags the slots, collects the shared-row slots -------------
+__global__ __launch_bounds__(512) void plan_lds_claim_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                             const uint32_t* __restrict__ tot, uint64_t num_rows,
+                                                             uint8_t* __restrict__ flags, uint64_t* __restrict__ blist,
+                                                             Ctrl* __restrict__ ctrl) {
+    __shared__ uint32_t tab[LDS_TAB];
+    __shared__ uint32_t starts[RADIX];
+    __shared__ int32_t ndup;
+    const int t = threadIdx.x, b = blockIdx.x;
+    // this partition's range = [sum of the totals below b, + tot[b])
+    if (t < RADIX) starts[t] = tot[t];
+    if (t == 0) ndup = 0;
+    for (int i = t; i < LDS_TAB; i += 512) tab[i] = EMPTY;
+    __syncthreads();
+    uint32_t beg = 0;
+    for (int i = 0; i < b; ++i) beg += starts[i];                     // (LDS broadcasts; b <= 255)
+    const uint32_t cnt = starts[b];
+    if (cnt > (uint32_t)PART_CAP) {                                   // a partition the table cannot take (skewed keys): LARGE
+        if (t == 0) ctrl->large = 1;
+        return;
+    }
+    // sweep 1: insert
+    for (uint32_t i = t; i < cnt; i += 512) {
+        const uint64_t k = keys[beg + i];
+        if (k >= num_rows) continue;                                  // missing id
+        const uint32_t r = (uint32_t)k;
+        uint32_t h = (r * 2654435761u) >> (32 - 15);
         for (;;) {
             const uint32_t old = atomicCAS(&tab[h], EMPTY, r);
             if (old == EMPTY) break;                                  // claimed: first slot of this row (so far the only one)
@@ -110,35 +247,36 @@ __global__ __launch_bounds__(256) void plan_claim_kernel(const int64_t* __restri
                 if (!(old & DUPBIT)) atomicOr(&tab[h], DUPBIT);
                 break;
             }
-            h = (h + 1) & mask;
-        }
-        entry[p] = h;
-    }
-}
-
-// ---- 2. flags + the shared-row slots into their row-range buckets -----------------------------------------------------------
-__global__ __launch_bounds__(256) void plan_flags_kernel(const uint32_t* __restrict__ tab, const uint32_t* __restrict__ entry,
-                                                         int32_t n, uint32_t bucket_mul, uint8_t* __restrict__ flags,
-                                                         uint64_t* __restrict__ blist, Ctrl* __restrict__ ctrl) {
-    const int32_t stride = gridDim.x * blockDim.x;
-    for (int32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
-        const uint32_t e = entry[p];
-        const uint32_t v = e != EMPTY ? tab[e] : 0u;
-        const bool dup = e != EMPTY && (v & DUPBIT);
-        flags[p] = (e != EMPTY && !dup) ? 1 : 0;
-        // (a full bucket means the LARGE path will redo everything: stop counting -- a Zipf batch would otherwise queue 1.5 M
-        // atomics on 128 words)
-        if (dup && *reinterpret_cast<volatile const int32_t*>(&ctrl->overflow) == 0) {
-            const uint32_t r = v & ~DUPBIT;
-            const int b = (int)(((uint64_t)r * bucket_mul) >> 32);                  // r * NBK / num_rows, monotone in r
-            const int pos = atomicAdd(&ctrl->bcnt[b], 1);
-            if (pos < CAPB) blist[b * CAPB + pos] = ((uint64_t)r << 24) | (uint32_t)p;
-            else ctrl->overflow = 1;
+            h = (h + 1) & (LDS_TAB - 1);
         }
     }
+    __syncthreads();
+    // sweep 2: flags + the shared-row slots (composite key row << 24 | slot) into this partition's bucket
+    for (uint32_t i = t; i < cnt; i += 512) {
+        const uint64_t k = keys[beg + i];
+        const uint32_t slot = vals[beg + i];
+        bool dup = false;
+        if (k < num_rows) {
+            const uint32_t r = (uint32_t)k;
+            uint32_t h = (r * 2654435761u) >> (32 - 15);
+            uint32_t v = tab[h];
+            while ((v & ~DUPBIT) != r) {
+                h = (h + 1) & (LDS_TAB - 1);
+                v = tab[h];
+            }
+            dup = (v & DUPBIT) != 0;
+            if (dup) {
+                const int pos = atomicAdd(&ndup, 1);
+                if (pos < CAPB) blist[b * CAPB + pos] = ((uint64_t)r << 24) | slot;
+            }
+        }
+        flags[slot] = (k < num_rows && !dup) ? 1 : 0;
+    }
+    __syncthreads();
+    if (t == 0) ctrl->bcnt[b] = ndup;                                 // (> CAPB: the sort kernel sends the batch to LARGE)
 }
 
-// ---- 3. SMALL: one block per bucket sorts it in LDS, writes it at its offset, emits the duplicate pass's work list -----------------
+// ---- SMALL 3: one block per bucket sorts it in LDS, writes it at its offset, emits the duplicate pass's work list ------------------
 __global__ __launch_bounds__(256) void plan_bucket_sort_kernel(const uint64_t* __restrict__ blist, Ctrl* __restrict__ ctrl,
                                                                int32_t small_limit, uint64_t* __restrict__ rows,
                                                                int32_t* __restrict__ slots, int32_t* __restrict__ dup_heads,
@@ -147,13 +285,13 @@ __global__ __launch_bounds__(256) void plan_bucket_sort_kernel(const uint64_t* _
     __shared__ int32_t cnts[NBK];
     __shared__ int32_t nheads, hbase;
     const int t = threadIdx.x, b = blockIdx.x;
-    if (ctrl->large != 0) return;                                     // geometry forced the LARGE path
+    if (ctrl->large != 0) return;                                     // geometry or a partition forced the LARGE path
     if (t < NBK) cnts[t] = ctrl->bcnt[t];
     if (t == 0) nheads = 0;
     __syncthreads();
     int32_t m = 0, off = 0;
     bool over = false;
-    for (int i = 0; i < NBK; ++i) {                                   // 128 LDS broadcasts: every thread gets the same totals
+    for (int i = 0; i < NBK; ++i) {                                   // LDS broadcasts: every thread gets the same totals
         const int32_t c = cnts[i];
         over |= c > CAPB;
         if (i < b) off += c;
@@ -209,125 +347,11 @@ __global__ __launch_bounds__(256) void plan_bucket_sort_kernel(const uint64_t* _
     if (b == 0 && t == 0) dup_count[1] = m;                           // length of the sorted arrays K4's duplicate pass walks
 }
 
-// ---- 4. LARGE: LSD radix sort of all n (row, slot) pairs + marking --------------------------------------------------------------
-__global__ __launch_bounds__(256) void radix_make_keys_kernel(const int64_t* __restrict__ ids, int32_t n, int32_t F,
-                                                              const int64_t* __restrict__ row_base, uint64_t sentinel,
-                                                              uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                              const Ctrl* __restrict__ ctrl) {
-    if (ctrl->large == 0) return;
-    const int32_t stride = gridDim.x * blockDim.x;
-    for (int32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
-        const int64_t id = ids[p];
-        keys[p] = id >= 0 ? (uint64_t)(row_base[p % F] + id) : sentinel;   // missing ids sort to the end
-        vals[p] = (uint32_t)p;
-    }
-}
-
-__global__ __launch_bounds__(256) void radix_hist_kernel(const uint64_t* __restrict__ keys, int32_t n, int shift, int pass,
-                                                         uint32_t* __restrict__ ghist, Ctrl* __restrict__ ctrl) {
-    if (ctrl->large == 0) return;
-    __shared__ uint32_t h[RADIX];
-    const int nb = gridDim.x, t = threadIdx.x;
-    const int32_t chunk = (n + nb - 1) / nb;
-    const int32_t beg = (int32_t)blockIdx.x * chunk, end = beg + chunk < n ? beg + chunk : n;
-    h[t] = 0;
-    __syncthreads();
-    for (int32_t i = beg + t; i < end; i += 256) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & (RADIX - 1)], 1u);
-    __syncthreads();
-    ghist[t * nb + blockIdx.x] = h[t];
-    if (h[t] != 0) atomicAdd(&ctrl->gtot[pass][t], h[t]);            // digit totals: nb atomics per word, 256 words
-}
-
-// One block per digit d: ghist[d][0 .. nb) -> exclusive scan over the blocks + the number of keys with a smaller digit
-// (digit-major order of the destination: all keys of smaller digits, then the same digit in earlier blocks).
-__global__ __launch_bounds__(256) void radix_scan_kernel(uint32_t* __restrict__ ghist, int32_t nb, int pass,
-                                                         const Ctrl* __restrict__ ctrl) {
-    if (ctrl->large == 0) return;
-    __shared__ uint32_t part[256];
-    __shared__ uint32_t wsum[4];
-    const int t = threadIdx.x, d = blockIdx.x, lane = t & 63, w = t >> 6;
-    // base = sum of the totals of the digits below d
-    uint32_t v = t < d ? ctrl->gtot[pass][t] : 0u;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if (lane == 0) wsum[w] = v;
-    __syncthreads();
-    const uint32_t base = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    // this thread's run of the column
-    const int32_t per = (nb + 255) / 256;
-    const int32_t beg = t * per, end = beg + per < nb ? beg + per : nb;
-    uint32_t* col = ghist + (int64_t)d * nb;
-    uint32_t sum = 0;
-    for (int32_t i = beg; i < end; ++i) sum += col[i];
-    part[t] = sum;
-    __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {                               // Hillis-Steele inclusive scan of the 256 partials
-        const uint32_t x = t >= o ? part[t - o] : 0u;
-        __syncthreads();
-        part[t] += x;
-        __syncthreads();
-    }
-    uint32_t run = base + part[t] - sum;
-    for (int32_t i = beg; i < end; ++i) {
-        const uint32_t c = col[i];
-        col[i] = run;
-        run += c;
-    }
-}
-
-// stable scatter: block b re-reads its chunk in order, 256 keys at a time; a key's destination = (scanned histogram entry of its
-// digit for this block, advanced by the tiles already written) + the number of EARLIER keys of the tile with the same digit
-// (wave-level match by eight ballots, earlier waves' counts through LDS)
-__global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin,
-                                                            uint64_t* __restrict__ kout, uint32_t* __restrict__ vout, int32_t n,
-                                                            int shift, const uint32_t* __restrict__ ghist,
-                                                            const Ctrl* __restrict__ ctrl) {
-    if (ctrl->large == 0) return;
-    __shared__ uint32_t running[RADIX];
-    __shared__ uint32_t wcnt[4][RADIX];
-    const int nb = gridDim.x, t = threadIdx.x, w = t >> 6, lane = t & 63;
-    const int32_t chunk = (n + nb - 1) / nb;
-    const int32_t beg = (int32_t)blockIdx.x * chunk, end = beg + chunk < n ? beg + chunk : n;
-    running[t] = ghist[t * nb + blockIdx.x];
-    __syncthreads();
-    for (int32_t base = beg; base < end; base += 256) {
-        const int32_t i = base + t;
-        const bool live = i < end;
-        const uint64_t k = live ? kin[i] : 0ull;
-        const uint32_t v = live ? vin[i] : 0u;
-        const uint32_t d = (uint32_t)(k >> shift) & (RADIX - 1);
-        wcnt[0][t] = 0; wcnt[1][t] = 0; wcnt[2][t] = 0; wcnt[3][t] = 0;
-        __syncthreads();
-        uint64_t mask = __ballot(live);                               // lanes with my digit (dead lanes never match)
-#pragma unroll
-        for (int b = 0; b < RADIX_BITS; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const uint64_t vote = __ballot(bit);
-            mask &= bit ? vote : ~vote;
-        }
-        const uint32_t rank_in_wave = __popcll(mask & ((1ull << lane) - 1ull));
-        if (live && rank_in_wave == 0) wcnt[w][d] = __popcll(mask);
-        __syncthreads();
-        uint32_t pos = 0;
-        if (live) {
-            pos = running[d] + rank_in_wave;
-            for (int ww = 0; ww < w; ++ww) pos += wcnt[ww][d];
-        }
-        __syncthreads();                                              // every read of running[] precedes its update
-        running[t] += wcnt[0][t] + wcnt[1][t] + wcnt[2][t] + wcnt[3][t];
-        if (live) {
-            kout[pos] = k;
-            vout[pos] = v;
-        }
-        __syncthreads();
-    }
-}
-
-// LARGE path's marking over the fully sorted list: flag[p] = 1 iff slot p is the only slot of the batch that touches its row;
-// every sorted position that heads a piece of a row touched by >= 2 slots (the segment start, plus each CH-aligned position
-// >= CH past it) goes to dup_heads.  A block owns a contiguous chunk, collects its heads in LDS and reserves their place with ONE
-// global atomic (a Zipf batch has ~1e5 heads; one same-address atomic per wave cost 300 us, they retire at ~88 per microsecond).
-constexpr int MARK_MAX_CHUNK = 8192;
+// ---- LARGE: marking over the fully sorted list ---------------------------------------------------------------------------------
+// flag[p] = 1 iff slot p is the only slot of the batch that touches its row; every sorted position that heads a piece of a row
+// touched by >= 2 slots (the segment start, plus each CH-aligned position >= CH past it) goes to dup_heads.  A block owns a
+// contiguous chunk, collects its heads in LDS and reserves their place with ONE global atomic (a Zipf batch has ~1e5 heads; one
+// same-address atomic per wave cost 300 us, they retire at ~88 per microsecond).
 __global__ __launch_bounds__(256) void radix_mark_kernel(const uint64_t* __restrict__ rows, const int32_t* __restrict__ slots,
                                                          int32_t n, uint64_t num_rows, uint8_t* __restrict__ flags,
                                                          int32_t* __restrict__ dup_heads, int32_t* __restrict__ dup_count,
@@ -367,8 +391,8 @@ __global__ __launch_bounds__(256) void radix_mark_kernel(const uint64_t* __restr
 
 }  // namespace
 
-// Test / tuning hook: the largest shared-row list the one-block LDS sort takes (default and maximum 16384); 0 sends every batch
-// that has any shared row down the LARGE (radix sort) path.  Process-wide; returns the previous value.
+// Test / tuning hook: the largest shared-row list the SMALL path takes (default and maximum 16384); 0 sends every batch that has
+// any shared row down the LARGE (radix sort) path.  Process-wide; returns the previous value.
 extern "C" int32_t dr_emb_plan_set_small_limit(int32_t limit) {
     if (limit < 0) limit = 0;
     if (limit > SMALL_CAP) limit = SMALL_CAP;
@@ -393,30 +417,34 @@ extern "C" int dr_emb_sort_slots(const int64_t* ids, int64_t B, int32_t F, const
     const int32_t n = (int32_t)n64;
     const Layout L = layout_for(n64);
     char* w = static_cast<char*>(workspace);
-    uint32_t* tab = reinterpret_cast<uint32_t*>(w + L.tab);
-    uint32_t* entry = reinterpret_cast<uint32_t*>(w + L.entry);
     uint64_t* keys_x = reinterpret_cast<uint64_t*>(w + L.keys_x);
     uint32_t* vals_x = reinterpret_cast<uint32_t*>(w + L.vals_x);
+    uint64_t* blist = reinterpret_cast<uint64_t*>(w + L.blist);
     uint32_t* ghist = reinterpret_cast<uint32_t*>(w + L.ghist);
+    uint32_t* tot = reinterpret_cast<uint32_t*>(w + L.tot);
     Ctrl* ctrl = reinterpret_cast<Ctrl*>(w + L.ctrl);
     uint64_t* rows_y = reinterpret_cast<uint64_t*>(sorted_rows);
     uint32_t* slots_y = reinterpret_cast<uint32_t*>(sorted_slots);
     hipStream_t s = dr_s(stream);
     const int grid = dr_grid_for(n, 256);
+    const int nb = radix_blocks(n);
 
     if (hipMemsetAsync(ctrl, 0, sizeof(Ctrl), s) != hipSuccess) return DR_ELAUNCH;
     if (hipMemsetAsync(dup_count, 0, 2 * sizeof(int32_t), s) != hipSuccess) return DR_ELAUNCH;
-    // the composite key holds 24 bits of slot and the table 31 bits of row; anything larger sorts all slots
+    // the composite key holds 24 bits of slot and the LDS table 31 bits of row; anything larger sorts all slots
     const bool claimable = n64 <= (1 << 24) && num_rows < 0x7fffffffLL;
     if (claimable) {
-        const int64_t T = table_entries(n64);
-        int log_t = 0;
-        while ((1ll << log_t) < T) ++log_t;
-        const uint32_t bucket_mul = (uint32_t)((((uint64_t)NBK) << 32) / (uint64_t)num_rows);     // floor: row * mul >> 32 < NBK
-        if (hipMemsetAsync(tab, 0xFF, (size_t)T * 4, s) != hipSuccess) return DR_ELAUNCH;
-        hipLaunchKernelGGL(plan_claim_kernel, dim3(grid), dim3(256), 0, s, ids, n, F, row_base, tab, log_t, entry);
-        hipLaunchKernelGGL(plan_flags_kernel, dim3(grid), dim3(256), 0, s, tab, entry, n, bucket_mul, unique_flags, keys_x, ctrl);
-        hipLaunchKernelGGL(plan_bucket_sort_kernel, dim3(NBK), dim3(256), 0, s, keys_x, ctrl, (int32_t)g_small_limit.load(), rows_y,
+        // row * 256 / num_rows as a multiply-shift; floor, so that row * mul >> 32 <= 255 for every row < num_rows
+        const uint32_t mul = (uint32_t)((((uint64_t)RADIX) << 32) / (uint64_t)num_rows);
+        hipLaunchKernelGGL((radix_make_keys_kernel<0>), dim3(grid), dim3(256), 0, s, ids, n, F, row_base, (uint64_t)num_rows, rows_y,
+                           slots_y, ctrl);
+        hipLaunchKernelGGL((radix_hist_kernel<1>), dim3(nb), dim3(256), 0, s, rows_y, n, mul, ghist, ctrl);
+        hipLaunchKernelGGL((radix_scan_kernel<0>), dim3(RADIX), dim3(256), 0, s, ghist, (int32_t)nb, tot, ctrl);
+        hipLaunchKernelGGL((radix_scatter_kernel<1>), dim3(nb), dim3(256), 0, s, rows_y, slots_y, keys_x, vals_x, n, mul, ghist, tot,
+                           ctrl);
+        hipLaunchKernelGGL(plan_lds_claim_kernel, dim3(NBK), dim3(512), 0, s, keys_x, vals_x, tot, (uint64_t)num_rows, unique_flags,
+                           blist, ctrl);
+        hipLaunchKernelGGL(plan_bucket_sort_kernel, dim3(NBK), dim3(256), 0, s, blist, ctrl, (int32_t)g_small_limit.load(), rows_y,
                            sorted_slots, dup_heads, dup_count);
     } else {
         if (hipMemsetAsync(&ctrl->large, 1, sizeof(int32_t), s) != hipSuccess) return DR_ELAUNCH;
@@ -424,18 +452,17 @@ extern "C" int dr_emb_sort_slots(const int64_t* ids, int64_t B, int32_t F, const
     // LARGE path (each kernel returns at once unless ctrl->large): the final pass must land in the output arrays
     const unsigned bits = bits_for((uint64_t)num_rows);            // the sentinel == num_rows needs these bits too
     const int passes = (int)((bits + RADIX_BITS - 1) / RADIX_BITS);
-    const int nb = radix_blocks(n);
     uint64_t* kbuf[2] = {keys_x, rows_y};
     uint32_t* vbuf[2] = {vals_x, slots_y};
     int cur = (passes & 1) ? 0 : 1;                                // passes odd: start in the workspace, end in the outputs
-    hipLaunchKernelGGL(radix_make_keys_kernel, dim3(grid), dim3(256), 0, s, ids, n, F, row_base, (uint64_t)num_rows, kbuf[cur],
+    hipLaunchKernelGGL((radix_make_keys_kernel<1>), dim3(grid), dim3(256), 0, s, ids, n, F, row_base, (uint64_t)num_rows, kbuf[cur],
                        vbuf[cur], ctrl);
     for (int p = 0; p < passes; ++p) {
-        const int shift = p * RADIX_BITS;
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(256), 0, s, kbuf[cur], n, shift, p, ghist, ctrl);
-        hipLaunchKernelGGL(radix_scan_kernel, dim3(RADIX), dim3(256), 0, s, ghist, (int32_t)nb, p, ctrl);
-        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(256), 0, s, kbuf[cur], vbuf[cur], kbuf[cur ^ 1], vbuf[cur ^ 1], n,
-                           shift, ghist, ctrl);
+        const uint32_t shift = (uint32_t)(p * RADIX_BITS);
+        hipLaunchKernelGGL((radix_hist_kernel<0>), dim3(nb), dim3(256), 0, s, kbuf[cur], n, shift, ghist, ctrl);
+        hipLaunchKernelGGL((radix_scan_kernel<1>), dim3(RADIX), dim3(256), 0, s, ghist, (int32_t)nb, tot, ctrl);
+        hipLaunchKernelGGL((radix_scatter_kernel<0>), dim3(nb), dim3(256), 0, s, kbuf[cur], vbuf[cur], kbuf[cur ^ 1], vbuf[cur ^ 1], n,
+                           shift, ghist, tot, ctrl);
         cur ^= 1;
     }
     int mark_blocks = MARK_BLOCKS;
