@@ -37,8 +37,8 @@ constexpr uint32_t DUPBIT = 0x80000000u;
 constexpr int SMALL_CAP = 16384;             // largest shared-row list the SMALL path takes
 constexpr int RADIX_BITS = 8, RADIX = 1 << RADIX_BITS;
 constexpr int NBK = RADIX, CAPB = 128;       // row-range partitions (= buckets of the shared-row list) and a bucket's capacity
-constexpr int LDS_TAB = 32768;               // entries of a partition's claim table (128 KB of LDS)
-constexpr int PART_CAP = 20000;              // slots one partition may hold (table load <= 0.61); beyond: LARGE
+constexpr int LDS_TAB_MAX_LOG = 15;          // a partition's claim table: 2^12 .. 2^15 entries (16 .. 128 KB of LDS), sized so that
+                                             // the MEAN partition loads it to <= 0.5; a partition beyond load 0.7 sends the batch to LARGE
 constexpr int RADIX_CHUNK = 1664, RADIX_MAX_BLOCKS = 1024;
 constexpr int MARK_BLOCKS = 512, MARK_MAX_CHUNK = 8192;
 static_assert(NBK * CAPB >= SMALL_CAP, "buckets must hold the largest SMALL list");
@@ -85,12 +85,15 @@ Layout layout_for(int64_t n) {
 template <int MODE>
 __device__ __forceinline__ uint32_t digit_of(uint64_t k, uint32_t shift_or_mul) {
     if (MODE == 0) return (uint32_t)(k >> shift_or_mul) & (RADIX - 1);
-    const uint32_t d = (uint32_t)((k * shift_or_mul) >> 32);
+    const uint32_t d = (uint32_t)(((k >> 24) * shift_or_mul) >> 32);           // MODE 1: k = row << 24 | slot
     return d < RADIX - 1 ? d : RADIX - 1;
 }
 
 // ---- the counting-sort pass: keys, per-block histograms, per-digit scan, stable scatter ---------------------------------------------
 // GATED = 0: always runs (the SMALL path's partition pass); 1: only when ctrl->large (the LARGE path)
+// (the SMALL path moves ONE 8-byte word per slot, the composite key row << 24 | slot: n <= 2^24 slots, rows < 2^31.  A scattered
+// store is a partial-line read-modify-write in HBM once the partitions' write frontiers fall out of the L2 -- the first version
+// moved 12 bytes in two stores from 1024 blocks and cost the K4 it runs beside 77 us)
 template <int GATED>
 __global__ __launch_bounds__(256) void radix_make_keys_kernel(const int64_t* __restrict__ ids, int32_t n, int32_t F,
                                                               const int64_t* __restrict__ row_base, uint64_t sentinel,
@@ -100,8 +103,13 @@ __global__ __launch_bounds__(256) void radix_make_keys_kernel(const int64_t* __r
     const int32_t stride = gridDim.x * blockDim.x;
     for (int32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
         const int64_t id = ids[p];
-        keys[p] = id >= 0 ? (uint64_t)(row_base[p % F] + id) : sentinel;   // missing ids sort to the end
-        vals[p] = (uint32_t)p;
+        const uint64_t row = id >= 0 ? (uint64_t)(row_base[p % F] + id) : sentinel;   // missing ids sort to the end
+        if (GATED) {
+            keys[p] = row;
+            vals[p] = (uint32_t)p;
+        } else {
+            keys[p] = (row << 24) | (uint32_t)p;
+        }
     }
 }
 
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* __re
         const int32_t i = base + t;
         const bool live = i < end;
         const uint64_t k = live ? kin[i] : 0ull;
-        const uint32_t v = live ? vin[i] : 0u;
+        const uint32_t v = (MODE == 0 && live) ? vin[i] : 0u;
         const uint32_t d = digit_of<MODE>(k, shift_or_mul);
         wcnt[0][t] = 0; wcnt[1][t] = 0; wcnt[2][t] = 0; wcnt[3][t] = 0;
         __syncthreads();
@@ -207,21 +215,23 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* __re
         running[t] += wcnt[0][t] + wcnt[1][t] + wcnt[2][t] + wcnt[3][t];
         if (live) {
             kout[pos] = k;
-            vout[pos] = v;
+            if (MODE == 0) vout[pos] = v;
         }
         __syncthreads();
     }
 }
 
 // ---- SMALL 2: one block per partition claims its rows in an LDS table, flags the slots, collects the shared-row slots -------------
-__global__ __launch_bounds__(512) void plan_lds_claim_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                             const uint32_t* __restrict__ tot, uint64_t num_rows,
+__global__ __launch_bounds__(512) void plan_lds_claim_kernel(const uint64_t* __restrict__ keys,
+                                                             const uint32_t* __restrict__ tot, uint64_t num_rows, int32_t log_tab,
                                                              uint8_t* __restrict__ flags, uint64_t* __restrict__ blist,
                                                              Ctrl* __restrict__ ctrl) {
-    __shared__ uint32_t tab[LDS_TAB];
+    extern __shared__ uint32_t tab[];                                 // 2^log_tab entries (dynamic: sized for the batch)
     __shared__ uint32_t starts[RADIX];
     __shared__ int32_t ndup;
     const int t = threadIdx.x, b = blockIdx.x;
+    const int LDS_TAB = 1 << log_tab;
+    const int hsh = 32 - log_tab;
     // this partition's range = [sum of the totals below b, + tot[b])
     if (t < RADIX) starts[t] = tot[t];
     if (t == 0) ndup = 0;
@@ -230,16 +240,16 @@ __global__ __launch_bounds__(512) void plan_lds_claim_kernel(const uint64_t* __r
     uint32_t beg = 0;
     for (int i = 0; i < b; ++i) beg += starts[i];                     // (LDS broadcasts; b <= 255)
     const uint32_t cnt = starts[b];
-    if (cnt > (uint32_t)PART_CAP) {                                   // a partition the table cannot take (skewed keys): LARGE
+    if (cnt > (uint32_t)(LDS_TAB / 10 * 7)) {                         // a partition the table cannot take (skewed keys): LARGE
         if (t == 0) ctrl->large = 1;
         return;
     }
     // sweep 1: insert
     for (uint32_t i = t; i < cnt; i += 512) {
-        const uint64_t k = keys[beg + i];
+        const uint64_t k = keys[beg + i] >> 24;
         if (k >= num_rows) continue;                                  // missing id
         const uint32_t r = (uint32_t)k;
-        uint32_t h = (r * 2654435761u) >> (32 - 15);
+        uint32_t h = (r * 2654435761u) >> hsh;
         for (;;) {
             const uint32_t old = atomicCAS(&tab[h], EMPTY, r);
             if (old == EMPTY) break;                                  // claimed: first slot of this row (so far the only one)
@@ -253,12 +263,13 @@ __global__ __launch_bounds__(512) void plan_lds_claim_kernel(const uint64_t* __r
     __syncthreads();
     // sweep 2: flags + the shared-row slots (composite key row << 24 | slot) into this partition's bucket
     for (uint32_t i = t; i < cnt; i += 512) {
-        const uint64_t k = keys[beg + i];
-        const uint32_t slot = vals[beg + i];
+        const uint64_t ck = keys[beg + i];
+        const uint64_t k = ck >> 24;
+        const uint32_t slot = (uint32_t)(ck & 0xFFFFFFu);
         bool dup = false;
         if (k < num_rows) {
             const uint32_t r = (uint32_t)k;
-            uint32_t h = (r * 2654435761u) >> (32 - 15);
+            uint32_t h = (r * 2654435761u) >> hsh;
             uint32_t v = tab[h];
             while ((v & ~DUPBIT) != r) {
                 h = (h + 1) & (LDS_TAB - 1);
@@ -436,14 +447,22 @@ extern "C" int dr_emb_sort_slots(const int64_t* ids, int64_t B, int32_t F, const
     if (claimable) {
         // row * 256 / num_rows as a multiply-shift; floor, so that row * mul >> 32 <= 255 for every row < num_rows
         const uint32_t mul = (uint32_t)((((uint64_t)RADIX) << 32) / (uint64_t)num_rows);
+        // one block per CU: the 256 x 256 write frontiers of the partitions stay resident in the L2s
+        const int nbs = nb < 256 ? nb : 256;
         hipLaunchKernelGGL((radix_make_keys_kernel<0>), dim3(grid), dim3(256), 0, s, ids, n, F, row_base, (uint64_t)num_rows, rows_y,
                            slots_y, ctrl);
-        hipLaunchKernelGGL((radix_hist_kernel<1>), dim3(nb), dim3(256), 0, s, rows_y, n, mul, ghist, ctrl);
-        hipLaunchKernelGGL((radix_scan_kernel<0>), dim3(RADIX), dim3(256), 0, s, ghist, (int32_t)nb, tot, ctrl);
-        hipLaunchKernelGGL((radix_scatter_kernel<1>), dim3(nb), dim3(256), 0, s, rows_y, slots_y, keys_x, vals_x, n, mul, ghist, tot,
+        hipLaunchKernelGGL((radix_hist_kernel<1>), dim3(nbs), dim3(256), 0, s, rows_y, n, mul, ghist, ctrl);
+        hipLaunchKernelGGL((radix_scan_kernel<0>), dim3(RADIX), dim3(256), 0, s, ghist, (int32_t)nbs, tot, ctrl);
+        hipLaunchKernelGGL((radix_scatter_kernel<1>), dim3(nbs), dim3(256), 0, s, rows_y, slots_y, keys_x, vals_x, n, mul, ghist, tot,
                            ctrl);
-        hipLaunchKernelGGL(plan_lds_claim_kernel, dim3(NBK), dim3(512), 0, s, keys_x, vals_x, tot, (uint64_t)num_rows, unique_flags,
-                           blist, ctrl);
+        // (dynamic LDS beyond 64 KB needs the opt-in)
+        static const hipError_t lds_optin = hipFuncSetAttribute(reinterpret_cast<const void*>(plan_lds_claim_kernel),
+                                                                hipFuncAttributeMaxDynamicSharedMemorySize, 4 << LDS_TAB_MAX_LOG);
+        if (lds_optin != hipSuccess) return DR_ELAUNCH;
+        int log_tab = 12;
+        while (log_tab < LDS_TAB_MAX_LOG && (1 << log_tab) < 2 * ((n + NBK - 1) / NBK)) ++log_tab;
+        hipLaunchKernelGGL(plan_lds_claim_kernel, dim3(NBK), dim3(512), (size_t)4 << log_tab, s, keys_x, tot, (uint64_t)num_rows,
+                           (int32_t)log_tab, unique_flags, blist, ctrl);
         hipLaunchKernelGGL(plan_bucket_sort_kernel, dim3(NBK), dim3(256), 0, s, blist, ctrl, (int32_t)g_small_limit.load(), rows_y,
                            sorted_slots, dup_heads, dup_count);
     } else {

@@ -532,7 +532,8 @@ def _emb_bwd_sorted_case(ops, D, F, V, hot, path):
     d_ids, d_rb = _dev(ids), _dev(row_base)
     plan = ops.emb_sort_slots(d_ids, d_rb, R)
     keys = np.where(ids.reshape(-1) >= 0, (ids + row_base[None, :]).reshape(-1), R)
-    check_slot_plan(plan, keys, R, expect_path=path)
+    # (hot batches overflow a partition's bucket of the claim path: the device then takes the radix path by itself)
+    check_slot_plan(plan, keys, R, expect_path=path if (path == "radix" or not hot) else None)
     plan2 = ops.emb_sort_slots(d_ids, d_rb, R)          # the plan itself is bit-reproducible (no arrival-order dependence)
     L = plan.sorted_len()
     assert plan2.sorted_len() == L and torch.equal(plan.rows[:L], plan2.rows[:L]) and torch.equal(plan.slots[:L], plan2.slots[:L])
