@@ -517,6 +517,10 @@ struct RsArgs {
     int32_t accumulate;                          // C += instead of C =
     // DCN cross layer (keras/models/ranking/dcn.py:81-88): prod = acc + bias + diag * x ; C = x0 * prod + x ; prod saved
     const float* x0; const float* xin; int64_t ldx; float diag; float* prod_out;   // x0 == nullptr: plain epilogue
+    // top-K scan (factorized_top_k.py:201-233 of the reference: scores of a corpus chunk that can still enter a row's top k): C is not
+    // written; a score is kept only if it beats its row's current k-th best tau[row], appended to the row's candidate list
+    // cand_s / cand_c [M][cand_cap] through the cursor cand_cnt[row] (one atomic per (row, 32 columns) that has any)
+    const float* tau; float* cand_s; int32_t* cand_c; int32_t* cand_cnt; int64_t cand_cap;
 };
 
 __device__ __forceinline__ void rs_split8(const float4& lo, const float4& hi4, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
@@ -528,8 +532,8 @@ __device__ __forceinline__ void rs_split8(const float4& lo, const float4& hi4, b
     p2 = __builtin_shufflevector(a2, b2, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-// EPI: 0 = bias / ReLU, 1 = + ReLU' mask, 3 = accumulate (C +=), 2 = DCN cross combine (one epilogue per instantiation: all of
-// them unrolled over the 8 column tiles in one kernel cost 50 spilled registers)
+// EPI: 0 = bias / ReLU, 1 = + ReLU' mask, 3 = accumulate (C +=), 2 = DCN cross combine, 4 = top-K filter (one epilogue per
+// instantiation: all of them unrolled over the 8 column tiles in one kernel cost 50 spilled registers)
 template <int EPI, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void bf3_gemm_rs_kernel(RsArgs g) {
     constexpr int NW = 8, BM = 32 * NW, BN = 256, NT = BN / 32, NS = 3;
@@ -762,6 +766,37 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_rs_kernel(RsArgs g) {
             // hipcc wait vmcnt(0) in front of each one); edge tiles take the guarded loop
             const bool interior = tm0 + BM <= g.M && tn0 + BN <= g.N;
             constexpr bool cross = EPI == 2;
+            if constexpr (EPI == 4) {
+                // top-K filter: nothing is stored unless a score beats its row's threshold -- rare once tau has warmed up (expected
+                // k / items_seen of a chunk), so the tile's epilogue is 128 compares + ballots and a handful of appends
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int64_t row = r0 + (reg & 3) + 8 * (reg >> 2);
+                    const bool rv = row < g.M;
+                    const float t = g.tau[rv ? row : g.M - 1];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int col = tn0 + nt * 32 + l31;
+                        const float v = acc[nt][reg];
+                        acc[nt][reg] = 0.f;
+                        const bool pass = rv && col < g.N && v > t;
+                        const unsigned half = (unsigned)((__ballot(pass) >> (32 * hi)) & 0xffffffffull);
+                        if (half != 0u) {
+                            const int leader = 32 * hi + __ffs((int)half) - 1;
+                            int base = 0;
+                            if (lane == leader) base = atomicAdd(g.cand_cnt + row, __popc(half));
+                            base = __shfl(base, leader, 64);
+                            if (pass) {
+                                const int64_t pos = base + __popc(half & ((1u << l31) - 1u));
+                                if (pos < g.cand_cap) {
+                                    g.cand_s[row * g.cand_cap + pos] = v;
+                                    g.cand_c[row * g.cand_cap + pos] = col;
+                                }
+                            }
+                        }
+                    }
+                }
+            } else {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int col = tn0 + nt * 32 + l31;
@@ -840,6 +875,7 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_rs_kernel(RsArgs g) {
                     }
                 }
             }
+            }   // EPI != 4
             // Stores and loads share vmcnt on gfx9 and hipcc treats a mix of the two as unordered: left pending into the next
             // k-tile, the stores turn its wait for the A registers into vmcnt(0) on EVERY k-tile.  Draining here costs the
             // pipeline one refill per output tile instead.
@@ -1735,6 +1771,11 @@ int rs_launch(const RsArgs& g, hipStream_t stream) {
     // buys nothing -- so it is opt-in (DR_BF3_STAGGER=1)
     static const bool stg = [] { const char* e = getenv("DR_BF3_STAGGER"); return e != nullptr && e[0] == '1'; }();
     if (g.mask != nullptr && g.accumulate) return DR_EINVAL;            // (no caller needs both)
+    if (g.tau != nullptr) {
+        hipLaunchKernelGGL((bf3_gemm_rs_kernel<4>), dim3(grid), dim3(512), 0, stream, g);
+        DR_CHECK_LAUNCH();
+        return DR_OK;
+    }
     if (stg) {
         if (g.x0 != nullptr) hipLaunchKernelGGL((bf3_gemm_rs_kernel<2, 16>), dim3(grid), dim3(512), 0, stream, g);
         else if (g.mask != nullptr) hipLaunchKernelGGL((bf3_gemm_rs_kernel<1, 16>), dim3(grid), dim3(512), 0, stream, g);
@@ -1866,6 +1907,21 @@ extern "C" int dr_bf3_linear_nt(const float* A, int64_t lda, const void* b_plane
     if (b_ld < (K + BK - 1) / BK * BK || ldc < N || (mask != nullptr && ld_mask < N)) return DR_EINVAL;
     RsArgs g{A, lda, static_cast<const __bf16*>(b_planes), b_plane_stride, b_ld, M, N, K, C, ldc, bias, act, mask, ld_mask, accumulate,
              nullptr, nullptr, 0, 0.f, nullptr};
+    return rs_launch(g, dr_s(stream));
+}
+
+// internal (C++ linkage, used by retrieval.hip): the top-K scan's scores = a @ B^T on the register-split kernel -- a [M, K] fp32
+// queries, B = a corpus chunk as planes [3][N rows][b_ld] -- filtered against tau into per-row candidate lists (the epilogue of
+// dense.hip's dr_scores_nt_filter on this file's tile: 256 x 256, weights through the LDS ring, activations split in registers)
+int dr_bf3_scores_filter(const float* a, int64_t lda, const void* b_planes, int64_t b_plane_stride, int64_t b_ld, int64_t M, int32_t N,
+                         int32_t K, const float* tau, float* cand_s, int32_t* cand_c, int32_t* cand_cnt, int64_t cand_cap,
+                         dr_stream_t stream) {
+    if (M < 0 || N <= 0 || K <= 0 || cand_cap <= 0) return DR_EINVAL;
+    if (M == 0) return DR_OK;
+    if (!a || !tau || !cand_s || !cand_c || !cand_cnt || !planes_ok(b_planes, b_plane_stride, b_ld)) return DR_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(a) & 15) != 0 || (lda & 3) != 0 || lda < K || b_ld < (K + BK - 1) / BK * BK) return DR_EINVAL;
+    RsArgs g{a, lda, static_cast<const __bf16*>(b_planes), b_plane_stride, b_ld, M, N, K, nullptr, 0, nullptr, 0, nullptr, 0, 0,
+             nullptr, nullptr, 0, 0.f, nullptr, tau, cand_s, cand_c, cand_cnt, cand_cap};
     return rs_launch(g, dr_s(stream));
 }
 

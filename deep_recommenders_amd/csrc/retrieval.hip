@@ -226,19 +226,38 @@ extern "C" int dr_topk_select(const float* scores, int64_t ld, int64_t Bq, int64
 // [Bq, chunk] for the first chunk and as candidate lists (scores + columns, capacity = chunk: cannot overflow) afterwards
 static int64_t topk_hdr_bytes(int64_t Bq) { return (Bq * 8 + 255) / 256 * 256; }
 
-extern "C" int64_t dr_topk_workspace_bytes(int64_t Bq, int64_t N, int32_t k) {
-    (void)k;
-    int64_t chunk = (int64_t)(128ll << 20) / (Bq > 0 ? Bq * 4 : 4);     // ~128 MB of scores per chunk: Infinity-Cache sized
-    chunk = chunk / 128 * 128;
-    if (chunk < 128) chunk = 128;
+// corpus chunk of the scan: ~256 MB of [Bq, chunk] scores (1024 output tiles of the register-split GEMM at Bq = 8192: 4 per CU)
+static int64_t topk_chunk_for(int64_t Bq, int64_t N) {
+    int64_t chunk = (int64_t)(256ll << 20) / (Bq > 0 ? Bq * 4 : 4);
+    chunk = chunk / 256 * 256;
+    if (chunk < 256) chunk = 256;
     if (chunk > N) chunk = (N + 3) / 4 * 4;
     if (chunk < 4) chunk = 4;
-    return topk_hdr_bytes(Bq) + Bq * chunk * 8;
+    return chunk;
+}
+// bf16 planes of one corpus chunk for the register-split scan: [3][roundup(chunk, 32)][roundup(D, 32)]; D is not known to
+// dr_topk_workspace_bytes, so the planes are budgeted for D <= TOPK_PLANES_MAX_D (larger D scans on the generic kernel)
+constexpr int TOPK_PLANES_MAX_D = 512;
+static int64_t topk_planes_bytes(int64_t chunk) { return ((3 * ((chunk + 31) / 32 * 32) * TOPK_PLANES_MAX_D * 2) + 255) / 256 * 256; }
+
+extern "C" int64_t dr_topk_workspace_bytes(int64_t Bq, int64_t N, int32_t k) {
+    (void)k;
+    const int64_t chunk = topk_chunk_for(Bq, N);
+    return topk_hdr_bytes(Bq) + Bq * chunk * 8 + topk_planes_bytes(chunk);
 }
 
 int dr_scores_nt_filter(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t M, int32_t N, int32_t D,
                         const float* tau, float* cand_s, int32_t* cand_c, int32_t* cand_cnt, int64_t cand_cap,
                         dr_stream_t stream);        // dense.hip
+int dr_bf3_scores_filter(const float* a, int64_t lda, const void* b_planes, int64_t b_plane_stride, int64_t b_ld, int64_t M, int32_t N,
+                         int32_t K, const float* tau, float* cand_s, int32_t* cand_c, int32_t* cand_cnt, int64_t cand_cap,
+                         dr_stream_t stream);       // bf3_gemm.hip
+extern "C" int dr_bf3_split(const float* src, int64_t ld_src, int64_t R, int32_t C, void* planes, int64_t plane_stride, int64_t ld_planes,
+                            int64_t row_offset, int64_t col_offset, int32_t transpose, dr_stream_t stream);
+extern "C" int dr_bf3_linear_nt(const float* A, int64_t lda, const void* b_planes, int64_t b_plane_stride, int64_t b_ld, int64_t M,
+                                int32_t N, int32_t K, const float* bias, int32_t act, const float* mask, int64_t ld_mask,
+                                int32_t accumulate, float* C, int64_t ldc, dr_stream_t stream);
+extern "C" int32_t dr_get_gemm_mode(void);
 
 __global__ __launch_bounds__(256) void zero_i32_kernel(int32_t* __restrict__ p, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -258,8 +277,19 @@ extern "C" int dr_topk_mips(const float* q, int64_t Bq, const float* cand, int64
     if (!q || !out_scores || !out_index || !workspace || (N > 0 && !cand)) return DR_EINVAL;
     if (init && k > N) return DR_ESHAPE;                 // "input must have at least k columns"
     const int64_t hdr = topk_hdr_bytes(Bq);
-    int64_t chunk = (workspace_bytes - hdr) / (Bq * 8);
-    chunk = chunk >= 128 ? chunk / 128 * 128 : chunk / 4 * 4;
+    // Register-split scan (bf16x3 product mode, D a multiple of 4 up to TOPK_PLANES_MAX_D, a workspace of dr_topk_workspace_bytes):
+    // every chunk of the corpus is split into bf16 planes once (6 bytes per element, ~5 us per 8192 x 128 chunk) and BOTH the
+    // dense first chunk and the filtered later chunks run on bf3_gemm_rs_kernel -- one kernel, so equal candidates tie
+    // bit-exactly whichever chunk they sit in (the lower-index rule of tf.math.top_k depends on it).  Round 2 scanned with the
+    // generic 128 x 128 kernel: 95 us per 4096-item chunk, 0.21 of the bf16x3 ceiling (24 ms per 8192 queries x 1 M items).
+    int64_t chunk = topk_chunk_for(Bq, N);
+    const bool rs_scan = dr_get_gemm_mode() == DR_GEMM_BF16X3 && (D % 4) == 0 && D <= TOPK_PLANES_MAX_D && N > 0 &&
+                         (reinterpret_cast<uintptr_t>(q) & 15) == 0 &&
+                         workspace_bytes >= hdr + Bq * chunk * 8 + topk_planes_bytes(chunk);
+    if (!rs_scan) {
+        chunk = (workspace_bytes - hdr) / (Bq * 8);
+        chunk = chunk >= 128 ? chunk / 128 * 128 : chunk / 4 * 4;
+    }
     if (chunk < 4 && N > 0) return DR_EINVAL;
     char* wsb = reinterpret_cast<char*>(workspace);
     int32_t* cnt = reinterpret_cast<int32_t*>(wsb);
@@ -267,6 +297,10 @@ extern "C" int dr_topk_mips(const float* q, int64_t Bq, const float* cand, int64
     float* dense = reinterpret_cast<float*>(wsb + hdr);                       // [Bq, chunk] scores (chunk 0)
     float* cand_s = dense;                                                    // [Bq, chunk] candidate scores (later chunks)
     int32_t* cand_c = reinterpret_cast<int32_t*>(wsb + hdr + Bq * chunk * 4); // [Bq, chunk] candidate columns
+    void* planes = wsb + hdr + Bq * chunk * 8;
+    const int64_t p_rows = (chunk + 31) / 32 * 32, p_ld = ((int64_t)D + 31) / 32 * 32, p_ps = p_rows * p_ld;
+    if (rs_scan && (D % 32) != 0)      // the reduction padding of the planes must be zero (the kernel multiplies it)
+        if (hipMemsetAsync(planes, 0, (size_t)(3 * p_ps * 2), dr_s(stream)) != hipSuccess) return DR_ELAUNCH;
     const unsigned sel_grid = (unsigned)((Bq + 3) / 4);
     if (N == 0 && init) {
         hipLaunchKernelGGL(fill_topk_kernel, dim3(dr_grid_for(Bq * k, 256)), dim3(256), 0, dr_s(stream), out_scores, out_index,
@@ -275,14 +309,20 @@ extern "C" int dr_topk_mips(const float* q, int64_t Bq, const float* cand, int64
     int first = init;
     for (int64_t c0 = 0; c0 < N; c0 += chunk) {
         const int64_t nc = N - c0 < chunk ? N - c0 : chunk;
+        if (rs_scan) {
+            int rc = dr_bf3_split(cand + c0 * D, D, nc, D, planes, p_ps, p_ld, 0, 0, 0, stream);
+            if (rc != DR_OK) return rc;
+        }
         if (c0 == 0) {
-            int rc = dr_scores_nt(q, D, cand, D, Bq, (int32_t)nc, D, dense, chunk, stream);
+            int rc = rs_scan ? dr_bf3_linear_nt(q, D, planes, p_ps, p_ld, Bq, (int32_t)nc, D, nullptr, 0, nullptr, 0, 0, dense, chunk, stream)
+                             : dr_scores_nt(q, D, cand, D, Bq, (int32_t)nc, D, dense, chunk, stream);
             if (rc != DR_OK) return rc;
             if (N > chunk) hipLaunchKernelGGL(zero_i32_kernel, dim3(dr_grid_for(Bq, 256)), dim3(256), 0, dr_s(stream), cnt, Bq);
             hipLaunchKernelGGL(topk_select_kernel, dim3(sel_grid), dim3(256), 0, dr_s(stream), dense, chunk, Bq, nc, k,
                                index_base, first, out_scores, out_index, (const int32_t*)nullptr, (int32_t*)nullptr, tau);
         } else {
-            int rc = dr_scores_nt_filter(q, D, cand + c0 * D, D, Bq, (int32_t)nc, D, tau, cand_s, cand_c, cnt, chunk, stream);
+            int rc = rs_scan ? dr_bf3_scores_filter(q, D, planes, p_ps, p_ld, Bq, (int32_t)nc, D, tau, cand_s, cand_c, cnt, chunk, stream)
+                             : dr_scores_nt_filter(q, D, cand + c0 * D, D, Bq, (int32_t)nc, D, tau, cand_s, cand_c, cnt, chunk, stream);
             if (rc != DR_OK) return rc;
             hipLaunchKernelGGL(topk_select_kernel, dim3(sel_grid), dim3(256), 0, dr_s(stream), cand_s, chunk, Bq, nc, k,
                                index_base + c0, 0, out_scores, out_index, cand_c, cnt, tau);

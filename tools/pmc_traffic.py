@@ -12,13 +12,12 @@ import sys
 
 
 # The guide's x2 is calibrated on wide coalesced STREAMING reads and says to calibrate other patterns on a known byte count.
-# Kernels whose reads are a known byte count that the raw counter already matches are listed here with factor 1.
-FETCH_FACTOR = {"bf3_emb_linear_kernel": 1}
-FETCH_FACTOR_BASIS = {
-    "bf3_emb_linear_kernel": "reads = 65536 x 26 table rows x 256 B (436 MB) + 1.7 M first-order weights x 64-B sector (109 MB) + ids "
-                             "(2 x 13.6 MB) + weight planes (2.6 MB) = 0.57 GB; raw FETCH_SIZE = 0.57 GB: the 8-lanes-per-128-B-line "
-                             "LDS-DMA gather is tallied in full, doubling it would claim 0.55 GB of reads that have no source",
-}
+# Round 2 assumed the fused first layer's gather (LDS-DMA, 8 lanes x 16 B per 128-byte line, structured buffer resource, random rows)
+# was tallied in full because the raw counter happened to equal that kernel's byte budget.  Round 3 calibrated exactly that
+# instruction and lane mapping on a known byte count (tools/exp/ldsdma_fetch_calib.hip, profiles/r03_fetch_calib.json): FETCH_SIZE
+# reports 0.500 of the bytes for the gather, as for the plain streaming read -- the x2 applies to every kernel here.
+FETCH_FACTOR = {}
+FETCH_FACTOR_BASIS = {}
 
 
 def short(name):
