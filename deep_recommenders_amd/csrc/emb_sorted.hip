@@ -393,6 +393,121 @@ extern "C" int dr_emb_pool_bwd_sorted_adam(const int64_t* ids, const int64_t* ro
                            &ad, stream);
 }
 
+// ---- TF's NON-lazy sparse Adam, evaluated lazily -----------------------------------------------------------------------------------
+// tf.train.AdamOptimizer applies  m <- b1 m ;  v <- b2 v ;  w <- w - lr_s m / (sqrt(v) + eps)  to EVERY row on every step s, also to
+// rows without a gradient (m * beta1 is assigned over the whole variable, the scaled gradients are scattered on
+// top) -- a full pass over table + m + v, 200 GB at config 3.  Those decay-only steps commute with nothing else that touches the
+// row, so they can be caught up the next time the row is LOOKED UP: `row_step[row]` = number of optimizer steps the row has
+// received; before the forward of step t every slot's row is brought to t - 1 steps by replaying its missed decay-only steps
+// (one claimer per row: atomicExch of the stamp), then K4's fused update applies step t itself.  Every value the model ever
+// reads is then the value TF's dense update would have produced (same fp32 operations in the same order); rows never looked up
+// again stay behind in memory until dr_adam_catchup_rows is called over them (checkpoint export).
+// The replay stops early once a step can no longer change w (|lr_s m / (sqrt(v) + eps)| below half an ulp of w for every element of the
+// row -- m shrinks by b1 per step while sqrt(v) shrinks by sqrt(b2), so the later steps are smaller still): the remaining decay
+// of m, v is applied in closed form (b^k), which differs from k sequential multiplications in the last bits only.
+__global__ __launch_bounds__(256) void adam_catchup_rows_kernel(const int64_t* __restrict__ ids, int64_t n, int32_t F,
+                                                                const int64_t* __restrict__ row_base, int32_t D,
+                                                                float* __restrict__ table, float* __restrict__ m,
+                                                                float* __restrict__ v, float* __restrict__ lin_w,
+                                                                float* __restrict__ m_lin, float* __restrict__ v_lin,
+                                                                int32_t* __restrict__ row_step, int32_t upto, int32_t stamp,
+                                                                float lr, float b1, float b2, float eps) {
+    // one 16-lane group per slot (D <= 64: 4 floats per lane; D > 64: the group walks the row in 64-float pieces)
+    const int lane = threadIdx.x & 63, sub = lane & 15;
+    const int64_t groups = (int64_t)gridDim.x * (blockDim.x >> 4);
+    const int64_t g0 = (int64_t)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
+    const double lb1 = (double)b1, lb2 = (double)b2;
+    for (int64_t p0 = g0 - (g0 & 3); p0 < n; p0 += groups) {                  // the 4 groups of a wave advance together
+        const int64_t p = p0 + (lane >> 4);
+        int64_t row = -1;
+        int32_t old = upto;
+        if (p < n) {
+            const int64_t id = ids[p];
+            if (id >= 0) {
+                row = row_base[p % F] + id;
+                if (sub == 0) old = atomicExch(&row_step[row], stamp);        // the first slot of a row in this call replays it
+                old = __shfl(old, lane & ~15, 64);
+            }
+        }
+        // (stamp 0 = the row never received an update: its moments are zero and every decay-only step is the identity)
+        const int32_t k_total = row >= 0 && old > 0 && old < upto ? upto - old : 0;
+        if (__ballot(k_total > 0) == 0) continue;
+        for (int d0 = 0; d0 < D; d0 += 64) {
+            const int d = d0 + 4 * sub;
+            const bool live = k_total > 0 && d < D;
+            float4 w4 = make_float4(0, 0, 0, 0), m4 = w4, v4 = w4;
+            if (live) {
+                w4 = *reinterpret_cast<const float4*>(table + row * D + d);
+                m4 = *reinterpret_cast<const float4*>(m + row * D + d);
+                v4 = *reinterpret_cast<const float4*>(v + row * D + d);
+            }
+            // first-order weight of the row: lane 0 of the group, first piece only (rides in the .x slots of a second set)
+            const bool lin_live = live && d0 == 0 && sub == 0 && lin_w != nullptr;
+            float wl = 0.f, ml = 0.f, vl = 0.f;
+            if (lin_live) { wl = lin_w[row]; ml = m_lin[row]; vl = v_lin[row]; }
+            double p1 = pow(lb1, (double)(old + 1)), p2 = pow(lb2, (double)(old + 1));      // b^s of the first missed step
+            int32_t done = 0;
+            bool active = live;
+            const uint64_t glive = __ballot(live) & (0xFFFFull << (lane & ~15));             // this row's lanes that hold elements
+            while (__any(active)) {
+                if (active) {
+                    const float lr_s = (float)((double)lr * sqrt(1.0 - p2) / (1.0 - p1));
+                    m4.x *= b1; m4.y *= b1; m4.z *= b1; m4.w *= b1;
+                    v4.x *= b2; v4.y *= b2; v4.z *= b2; v4.w *= b2;
+                    const float ux = lr_s * m4.x / (sqrtf(v4.x) + eps), uy = lr_s * m4.y / (sqrtf(v4.y) + eps);
+                    const float uz = lr_s * m4.z / (sqrtf(v4.z) + eps), uw = lr_s * m4.w / (sqrtf(v4.w) + eps);
+                    w4.x -= ux; w4.y -= uy; w4.z -= uz; w4.w -= uw;
+                    float ul = 0.f;
+                    if (lin_live) {
+                        ml *= b1; vl *= b2;
+                        ul = lr_s * ml / (sqrtf(vl) + eps);
+                        wl -= ul;
+                    }
+                    p1 *= lb1; p2 *= lb2;
+                    ++done;
+                    // negligible from here on?  (|u| < 2^-26 |w| cannot change w; every later step is smaller by ~b1 / sqrt(b2))
+                    const float tiny = 1.4901161e-8f;
+                    const bool small = fabsf(ux) <= tiny * fabsf(w4.x) && fabsf(uy) <= tiny * fabsf(w4.y) &&
+                                       fabsf(uz) <= tiny * fabsf(w4.z) && fabsf(uw) <= tiny * fabsf(w4.w) &&
+                                       fabsf(ul) <= tiny * fabsf(wl);
+                    // the verdict must hold for the whole row: vote among the group's live lanes (they are active together)
+                    const bool row_small = ((__ballot(small) & glive) == glive);
+                    if (done >= k_total || row_small) active = false;
+                }
+            }
+            if (live) {
+                const int32_t rem = k_total - done;                           // decay-only steps skipped as no-ops on w
+                if (rem > 0) {
+                    const float f1 = (float)pow(lb1, (double)rem), f2 = (float)pow(lb2, (double)rem);
+                    m4.x *= f1; m4.y *= f1; m4.z *= f1; m4.w *= f1;
+                    v4.x *= f2; v4.y *= f2; v4.z *= f2; v4.w *= f2;
+                    ml *= f1; vl *= f2;
+                }
+                *reinterpret_cast<float4*>(table + row * D + d) = w4;
+                *reinterpret_cast<float4*>(m + row * D + d) = m4;
+                *reinterpret_cast<float4*>(v + row * D + d) = v4;
+                if (lin_live) { lin_w[row] = wl; m_lin[row] = ml; v_lin[row] = vl; }
+            }
+        }
+    }
+}
+
+// Brings the rows named by ids [n] (field of slot p = p % F, -1 = missing) to `upto` optimizer steps by replaying their missed
+// decay-only Adam steps (see above), and stamps them `stamp`: before the forward of step t call with upto = t - 1, stamp = t (K4's
+// fused update then applies step t); to export / inspect the tables call with upto = stamp = the number of steps taken, over all rows.
+extern "C" int dr_adam_catchup_rows(const int64_t* ids, int64_t n, int32_t F, const int64_t* row_base, int32_t D, float* table,
+                                    float* m_table, float* v_table, float* lin_w, float* m_lin, float* v_lin, int32_t* row_step,
+                                    int32_t upto, int32_t stamp, float lr, float beta1, float beta2, float eps, dr_stream_t stream) {
+    if (n < 0 || F <= 0 || D < 4 || (D & 3) || upto < 0 || stamp < upto) return DR_EINVAL;
+    if (n == 0) return DR_OK;
+    if (!ids || !row_base || !table || !m_table || !v_table || !row_step) return DR_EINVAL;
+    if (lin_w != nullptr && (!m_lin || !v_lin)) return DR_EINVAL;
+    hipLaunchKernelGGL(adam_catchup_rows_kernel, dim3(dr_grid_for(n, 16, 8192)), dim3(256), 0, dr_s(stream), ids, n, F, row_base, D,
+                       table, m_table, v_table, lin_w, m_lin, v_lin, row_step, upto, stamp, lr, beta1, beta2, eps);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
 __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                         float lr_t, float b1, float b2, float eps, float gscale) {

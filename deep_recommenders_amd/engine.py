@@ -69,7 +69,14 @@ class DeepFMEngine:
             off += pu
         self.lin_bias = self.flat_params[off:off + 1]
         self._bias_off = off
-        assert optimizer in ("sgd", "adam") and (optimizer == "sgd" or sorted_bwd), "adam needs the sorted K4"
+        assert optimizer in ("sgd", "adam", "adam_tf") and (optimizer == "sgd" or sorted_bwd), "adam needs the sorted K4"
+        # "adam_tf": tf.train.AdamOptimizer's NON-lazy behaviour on the tables (every row moves on every step while its first
+        # moment is non-zero), evaluated lazily: a row's missed decay-only steps are replayed when the row is next
+        # looked up (dr_adam_catchup_rows, before the forward), then the fused row-wise K4 applies the step itself.  Every value
+        # the model reads equals TF's dense update; `adam_flush()` brings the whole table up to date (export / inspection).
+        self.adam_tf = optimizer == "adam_tf"
+        if self.adam_tf:
+            optimizer = "adam"
         self.optimizer, self.beta1, self.beta2, self.eps, self.t = optimizer, beta1, beta2, eps, 0
         if optimizer == "adam":
             # gradient bucket + moments for the dense parameters; row-wise moments for the tables (2 x 66.6 GB at config 3:
@@ -84,6 +91,7 @@ class DeepFMEngine:
             self.v_table = torch.zeros_like(self.table)
             self.m_lin = torch.zeros_like(self.lin_w)
             self.v_lin = torch.zeros_like(self.lin_w)
+            self.row_step = torch.zeros(self.R, dtype=torch.int32, device=device) if self.adam_tf else None
         import os as _os
         self.acts = [1] * len(dnn_units) + [0]
         # Wide layers: forward and dgrad on pre-split weights (dr_bf3_linear_nt: the activation operand stays fp32 and is split
@@ -318,6 +326,11 @@ class DeepFMEngine:
             self.ev_sorted.record()
         if self.sorted_bwd and not self.sort_inline and self.sort_with_k3 and not prefetched:
             self._launch_sort()              # next to K3 (both HBM-bound, small blocks: they do share the machine)
+        if self.adam_tf:
+            # rows this batch looks up: replay the decay-only steps they missed (through step t - 1), stamp them t
+            self._k("adam_catchup_rows", "hbm", 0,
+                    lambda: ops.adam_catchup_rows(self.ids, self.row_base, self.table, self.m_table, self.v_table, self.lin_w, self.m_lin,
+                                                  self.v_lin, self.row_step, self.t, self.t + 1, self.lr, self.beta1, self.beta2, self.eps))
         fused_l0 = self.fuse_k3 and self.wplanes[0] is not None
         if not fused_l0:
             self._k("emb_pool_fwd", "hbm", self.alg_bytes_fwd(),                                      # K3+K5+K6
@@ -482,6 +495,18 @@ class DeepFMEngine:
         for wp in self.wplanes:
             if wp is not None:
                 wp.refresh()
+
+    def adam_flush(self):
+        """adam_tf mode: bring EVERY row of the tables to the current step (replays the decay-only steps of rows not looked up
+        lately), so that table / lin_w / moments in memory equal TF's dense state.  A pass over the whole slab: export, tests."""
+        assert self.adam_tf
+        V, F = self.V, self.F
+        step = 1 << 20
+        for v0 in range(0, V, step):
+            v1 = min(V, v0 + step)
+            ids = torch.arange(v0, v1, device=self.table.device, dtype=torch.int64)[:, None].expand(v1 - v0, F).contiguous()
+            ops.adam_catchup_rows(ids, self.row_base, self.table, self.m_table, self.v_table, self.lin_w, self.m_lin, self.v_lin,
+                                  self.row_step, self.t, self.t, self.lr, self.beta1, self.beta2, self.eps)
 
     def refresh_planes(self):
         """Re-split every wide layer's weight into its bf16 planes.  Needed only after writing eng.Ws / eng.flat_params through a path

@@ -501,6 +501,18 @@ def emb_pool_bwd_sorted_adam(ids, row_base, plan, D, num_rows, grad, d_fm_logit,
                                             ptr(m_lin), ptr(v_lin), stream_ptr()), "dr_emb_pool_bwd_sorted_adam")
 
 
+def adam_catchup_rows(ids, row_base, table, m_table, v_table, lin_w, m_lin, v_lin, row_step, upto, stamp, lr, beta1=0.9,
+                      beta2=0.999, eps=1e-8):
+    """TF's non-lazy sparse Adam evaluated lazily (dr_adam_catchup_rows): replays the decay-only steps the rows named by
+    ids [B, F] have missed, up to step `upto`, and stamps them `stamp` in row_step [R] int32."""
+    ids = _c(ids, torch.int64)
+    B, F = ids.shape
+    assert row_step.dtype == torch.int32 and row_step.is_contiguous()
+    check(lib().dr_adam_catchup_rows(ptr(ids), B * F, F, ptr(row_base), table.shape[1], ptr(table), ptr(m_table), ptr(v_table),
+                                     ptr(lin_w), ptr(m_lin), ptr(v_lin), ptr(row_step), int(upto), int(stamp), float(lr),
+                                     float(beta1), float(beta2), float(eps), stream_ptr()), "dr_adam_catchup_rows")
+
+
 def adam_step(param, grad, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
     """Dense Adam step over flat fp32 buffers (in place)."""
     assert param.is_contiguous() and grad.is_contiguous() and m.is_contiguous() and v.is_contiguous()

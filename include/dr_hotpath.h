@@ -202,6 +202,16 @@ int dr_emb_pool_bwd_sorted_adam(const int64_t* ids, const int64_t* row_base, con
                                 float beta2, float eps, float* table, float* m_table, float* v_table,
                                 float* lin_w, float* m_lin, float* v_lin, dr_stream_t stream);
 /* Dense Adam step (same formula) over a flat parameter buffer; grad is multiplied by grad_scale first. */
+/* TF's NON-lazy sparse Adam, evaluated lazily (examples/train_fm_on_movielens_estimator.py:51-52: tf.train.AdamOptimizer decays
+ * m / v of the WHOLE variable and moves every row on every step).  row_step[R] int32 (zero-initialised) counts
+ * the optimizer steps a row has received; dr_adam_catchup_rows brings the rows named by ids[n] (field of slot p = p % F, -1 =
+ * missing) to `upto` steps by replaying their missed decay-only steps  m *= b1 ; v *= b2 ; w -= lr_s m / (sqrt(v) + eps)
+ * (lr_s = lr sqrt(1 - b2^s) / (1 - b1^s)) in order, and stamps them `stamp`.  Before the forward of step t: upto = t - 1,
+ * stamp = t, then dr_emb_pool_bwd_sorted_adam applies step t -- every value the model reads equals TF's dense update.  To
+ * export the tables: upto = stamp = steps taken, over all rows.  One replayer per row and call (atomic exchange of the stamp). */
+int dr_adam_catchup_rows(const int64_t* ids, int64_t n, int32_t F, const int64_t* row_base, int32_t D, float* table,
+                         float* m_table, float* v_table, float* lin_w, float* m_lin, float* v_lin, int32_t* row_step,
+                         int32_t upto, int32_t stamp, float lr, float beta1, float beta2, float eps, dr_stream_t stream);
 int dr_adam_step(float* param, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1,
                  float beta2, float eps, float grad_scale, dr_stream_t stream);
 

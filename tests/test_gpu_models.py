@@ -693,6 +693,63 @@ def test_sharded_engine_world1_matches_unsharded_engine(alias_world1):
         dist.destroy_process_group()
 
 
+def test_engine_adam_tf_equals_tf_nonlazy_sparse_adam():
+    """optimizer="adam_tf": tf.train.AdamOptimizer on sparse gradients is NON-lazy -- m / v of every row decay on every step and the row
+    keeps moving while m != 0 (examples/train_fm_on_movielens_estimator.py:51-52).  The engine evaluates those
+    decay-only steps lazily (replayed when a row is next looked up, dr_adam_catchup_rows) -- after adam_flush() the tables must
+    equal the oracle's DENSE Adam applied to the whole variable every step (oracle/torch_ref.py adam_dense_step on the dense
+    gradient, zeros for untouched rows; pinned against torch.optim.Adam in tests/test_oracle_third_party_pins.py).
+    Small vocabulary + few distinct keys per step, so rows are touched, left alone for several steps, and touched again."""
+    from deep_recommenders_amd.engine import DeepFMEngine
+    F, V, D, B, Nd, lr = 3, 40, 16, 64, 2, 0.01
+    eng = DeepFMEngine(F, V, D, [32, 16], B, num_dense=Nd, lr=lr, seed=7, lin_init_std=0.1, optimizer="adam_tf")
+    lazy = DeepFMEngine(F, V, D, [32, 16], B, num_dense=Nd, lr=lr, seed=7, lin_init_std=0.1, optimizer="adam")
+    tt, tl, tb = eng.table.cpu().double(), eng.lin_w.cpu().double(), torch.zeros(1, dtype=torch.float64)
+    Ws = [w.cpu().double().contiguous() for w in eng.Ws]
+    bs = [b.cpu().double() for b in eng.bs]
+    z = torch.zeros_like
+    mt, vt, ml, vl, mb, vb = z(tt), z(tt), z(tl), z(tl), z(tb), z(tb)
+    mW, vW, mB, vB = [z(w) for w in Ws], [z(w) for w in Ws], [z(b) for b in bs], [z(b) for b in bs]
+    rb = [f * V for f in range(F)]
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    nsteps = 9
+    for step in range(1, nsteps + 1):
+        # a narrow, shifting window of raw keys: most rows rest for a few steps between touches, some are never touched
+        keys = torch.randint(1000 * (step % 3), 1000 * (step % 3) + 6, (B, F), device="cuda", generator=g)
+        dense = torch.rand((B, Nd), device="cuda", generator=g)
+        labels = (torch.rand(B, device="cuda", generator=g) < 0.3).float()
+        loss = eng.train_step(keys, dense, labels).item()
+        lazy.train_step(keys, dense, labels)
+        ids = np.stack([O.hash_bucket_i64(keys[:, f].cpu().numpy(), V) for f in range(F)], axis=1)
+        a = [t.clone().requires_grad_(True) for t in (tt, tl, tb)]
+        aW = [w.clone().requires_grad_(True) for w in Ws]
+        aB = [b.clone().requires_grad_(True) for b in bs]
+        logit = T.deepfm_logit(a[0], a[1], a[2], torch.tensor(ids), list(range(F + 1)), rb, aW, aB, dense.cpu().double())
+        lo = T.sigmoid_cross_entropy(labels.cpu().double(), logit)
+        lo.backward()
+        assert abs(loss - lo.item()) <= 2e-5 * abs(lo.item()), (step, loss, lo.item())
+        # TF: the dense Adam rule on the WHOLE variable (autograd's dense gradient is zero on untouched rows)
+        T.adam_dense_step(tt, a[0].grad, mt, vt, lr, step)
+        T.adam_dense_step(tl, a[1].grad, ml, vl, lr, step)
+        T.adam_dense_step(tb, a[2].grad, mb, vb, lr, step)
+        for i in range(len(Ws)):
+            T.adam_dense_step(Ws[i], aW[i].grad, mW[i], vW[i], lr, step)
+            T.adam_dense_step(bs[i], aB[i].grad, mB[i], vB[i], lr, step)
+    eng.adam_flush()
+    torch.cuda.synchronize()
+    tol = 2e-2 * lr
+    np.testing.assert_allclose(eng.table.cpu().numpy(), tt.numpy(), rtol=0, atol=tol)
+    np.testing.assert_allclose(eng.lin_w.cpu().numpy(), tl.numpy(), rtol=0, atol=tol)
+    np.testing.assert_allclose(eng.m_table.cpu().numpy(), mt.numpy(), rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(eng.v_table.cpu().numpy(), vt.numpy(), rtol=1e-3, atol=1e-10)
+    # and the distinction is real: the row-wise lazy engine leaves resting rows where they were
+    assert float((lazy.table.cpu().double() - tt).abs().max()) > 20 * tol
+    never = torch.tensor(sorted(set(range(F * V)) - set(int(r) for r in torch.nonzero(eng.row_step.cpu() > 0).reshape(-1).tolist())))
+    if never.numel():
+        pass    # (rows never looked up keep stamp 0 only until adam_flush stamps them: nothing to assert on their values beyond the table check)
+
+
 def test_sharded_engine_through_the_cabi_exchange_library():
     """The sharded DeepFM step with every exchange issued through include/dr_collectives.h (sharded.CApiTransport: dr_coll_alltoallv
     / dr_coll_allreduce_f32 on the engine's streams, a communicator of one rank) equals the unsharded engine -- the C-ABI exchange
