@@ -183,9 +183,16 @@ class DCNEngine:
         d_x0 = torch.zeros((B, self.ld), dtype=torch.float32, device=d_out.device)[:, :n_in]
         for l in range(len(self.cross_W) - 1, -1, -1):
             W = self.cross_W[l]
-            d_x = torch.zeros((B, self.ld), dtype=torch.float32, device=d_out.device)[:, :n_in]
-            d_prod = self._k("cross_combine_bwd_L%d" % l, "hbm", 6.0 * 4 * B * n_in,
-                             lambda l=l, d_out=d_out, d_x=d_x: ops.cross_combine_bwd(x0, prods[l], d_out, self.diag, d_x0, d_x))
+            if self.diag == 0.0:
+                # d_x = d_out + d_prod W^T: the dgrad below ACCUMULATES into the d_out buffer itself (d_out's last reader is the
+                # combine kernel) -- no zero-filled d_x, no read-modify-write of it in the combine pass: -1.3 GB per layer
+                d_x = d_out
+                d_prod = self._k("cross_combine_bwd_L%d" % l, "hbm", 6.0 * 4 * B * n_in,
+                                 lambda l=l, d_out=d_out: ops.cross_combine_bwd(x0, prods[l], d_out, 0.0, d_x0, None))
+            else:
+                d_x = torch.zeros((B, self.ld), dtype=torch.float32, device=d_out.device)[:, :n_in]
+                d_prod = self._k("cross_combine_bwd_L%d" % l, "hbm", 6.0 * 4 * B * n_in,
+                                 lambda l=l, d_out=d_out, d_x=d_x: ops.cross_combine_bwd(x0, prods[l], d_out, self.diag, d_x0, d_x))
             if self.cross_planes[l] is not None:
                 self._k("cross_bwd_dx_L%d" % l, "mfma", fl_c,
                         lambda d_prod=d_prod, l=l, d_x=d_x: ops.bf3_linear_nt(d_prod, self.cross_planes[l].w, accumulate=True, out=d_x))

@@ -208,19 +208,30 @@ class DeepFMEngine:
     def _token(keys):
         return (keys.data_ptr(), keys._version, tuple(keys.shape))
 
-    def _prefetch_next(self):
-        """Hash + slot sort of the next batch on the side stream, started when K4 starts (both HBM-bound, small blocks).  The
-        next forward() picks the buffers up if it is called with the same keys tensor (unmodified); otherwise it recomputes."""
+    def _prefetch_mark(self):
+        """First half of the next batch's prefetch, BEFORE K4 is launched: the point on the training stream the side chain may
+        start behind (K4's own start).  Returns the token _prefetch_issue needs, or None when nothing is to be prefetched."""
         nk = self._next_keys
         if nk is None or not (self.sorted_bwd and not self.sort_inline and self.prefetch_plan):
-            return
-        nxt = self.cur ^ 1
+            return None
         # the side stream already waits for the LAYER-0 wgrad (the last reader of concat's dense columns) iff the plane refresh
         # queued last was layer 0's; with e.g. dnn_units [64, 256] layer 0 has no planes and the last refresh waited only for
         # layer 1's wgrad (ADVICE r2): then the side chain takes its own event behind everything on the training stream
         ordered = self._planes_pending and self._planes_pending_l0 and self.lean_events
         if not ordered:
             self.ev_k4.record()
+        return (ordered,)
+
+    def _prefetch_issue(self, mark):
+        """Second half, AFTER K4 has been handed to the GPU: hash + slot plan of the next batch on the side stream, beside K4
+        (both HBM-bound, small blocks).  The chain is ~30 launches; issued before K4 (rounds 1-2) the host spent 100 - 230 us on
+        them while the training stream sat idle in front of K4 (rocprofv3: a 233 us gap between the wgrad's reduce and K4).  The
+        next forward() picks the buffers up if it is called with the same keys tensor (unmodified); otherwise it recomputes."""
+        if mark is None:
+            return
+        (ordered,) = mark
+        nk = self._next_keys
+        nxt = self.cur ^ 1
         nk.record_stream(self.side)
         with torch.cuda.stream(self.side):
             if not ordered:
@@ -451,11 +462,12 @@ class DeepFMEngine:
         elif self.sorted_bwd:
             if not (self._plan_prefetched and self.lean_events):
                 torch.cuda.current_stream().wait_event(self.ev_sorted)
-            self._prefetch_next()
+            mark = self._prefetch_mark()
             self._k("emb_pool_bwd", "hbm", self.alg_bytes_bwd(),                                      # K4 (sorted)
                     lambda: ops.emb_pool_bwd_sorted(self.ids, self.row_base, self.plan, D, self.R, self.d_concat, self.d_logit,
                                                     -lr, self.table, self.lin_w, self.lin_bias, concat=self.concat,
                                                     sum_x=self.sum_x))
+            self._prefetch_issue(mark)
         else:
             self._k("emb_pool_bwd", "hbm", self.alg_bytes_bwd(),                                      # K4 (atomics)
                     lambda: ops.emb_pool_bwd(self.ids, F, self.col_start, self.row_base, D, self.d_concat, self.concat,
@@ -480,12 +492,13 @@ class DeepFMEngine:
         lr_t = ops.adam_lr_t(self.lr, self.beta1, self.beta2, self.t)
         if not (self._plan_prefetched and self.lean_events):
             torch.cuda.current_stream().wait_event(self.ev_sorted)
-        self._prefetch_next()
+        mark = self._prefetch_mark()
         self._k("emb_pool_bwd_adam", "hbm", self.B * (28 * self.F * self.D + 40 * self.F),                # K4 + optimizer
                 lambda: ops.emb_pool_bwd_sorted_adam(self.ids, self.row_base, self.plan, self.D, self.R, self.d_concat,
                                                      self.d_logit, lr_t, self.beta1, self.beta2, self.eps, self.table,
                                                      self.m_table, self.v_table, self.lin_w, self.m_lin, self.v_lin,
                                                      concat=self.concat, sum_x=self.sum_x))
+        self._prefetch_issue(mark)
         ops.reduce_sum(self.d_logit, out=self.g_lin_bias)                       # d loss / d (first-order bias), fixed order
         if self.overlap_dw:
             torch.cuda.current_stream().wait_event(self.ev_dw)     # the dense step needs the first layer's gradient

@@ -808,11 +808,6 @@ class ShardedDeepFMEngine:
             g_rows, g_lin = self._k("emb_pack_grads", "hbm", Bm * F * (12 * D + 4),
                                     lambda sl=sl, m=m: self.ex.pack(routes[m], self.d_concat[sl], self.d_logit[sl], self.concat[sl],
                                                                     self.sum_x[sl], self.g_lin_bias))
-            if not prefetched and m == M - 1:
-                # Second half of the next batch's routing (id exchange + owner-side sort): its two small all-to-alls sit in
-                # front of the last gradient exchange instead of behind it; the split sizes it needs arrived long ago.
-                self.prefetch_route_finish()
-                prefetched = True
             if cuda:
                 ev_p = torch.cuda.Event()
                 ev_p.record()
@@ -837,6 +832,13 @@ class ShardedDeepFMEngine:
             else:
                 self._k("linear_bwd_dw_L%d" % i, "mfma", 2.0 * B * self.Ws[i].shape[0] * self.Ws[i].shape[1],
                         lambda xin=xin, dyi=dyi, i=i: p.linear_bwd_dw(xin, dyi, 1.0, self.gWs[i], self.gbs[i], workspace=self.dw_ws[i]))
+        if not prefetched:
+            # Second half of the next batch's routing (id exchange + owner-side plan: ~50 launches for two micro-batches).  Issued
+            # HERE, after the last gradient exchange / K4 and the wgrads have been handed to the GPU: in front of them (round 2)
+            # the host spent ~250 us on these launches while the communication stream sat idle (rocprofv3 on the single-GPU
+            # engine showed the same pattern: a 233 us gap in front of K4).  The split sizes it needs arrived long ago.
+            self.prefetch_route_finish()
+            prefetched = True
         # ---- dense tower: one all-reduce, then w += -(lr / W) * sum_r g_r  (mean over the global batch) ------
         if not self.ex.local:
             self._k("allreduce_dense_grads", "xgmi", self.flat_grads.numel() * 4, lambda: self.tr.allreduce(self.flat_grads))
@@ -982,8 +984,12 @@ class ShardedDCNEngine:
         d_out = d_top
         d_x0 = torch.zeros((B, ld), **f32)[:, :n_in]
         for l in range(len(self.cross_W) - 1, -1, -1):
-            d_x = torch.zeros((B, ld), **f32)[:, :n_in]
-            d_prod = p.cross_combine_bwd(x0, prods[l], d_out, self.diag, d_x0, d_x)
+            if self.diag == 0.0:         # the dgrad accumulates into the d_out buffer itself (see dcn_engine.DCNEngine)
+                d_x = d_out
+                d_prod = p.cross_combine_bwd(x0, prods[l], d_out, 0.0, d_x0, None)
+            else:
+                d_x = torch.zeros((B, ld), **f32)[:, :n_in]
+                d_prod = p.cross_combine_bwd(x0, prods[l], d_out, self.diag, d_x0, d_x)
             p.linear_bwd_dx(d_prod, self.cross_W[l], None, accumulate=True, out=d_x)
             p.linear_bwd_dw(xs[l], d_prod, 1.0, self.g_cross_W[l], self.g_cross_b[l])
             d_out = d_x

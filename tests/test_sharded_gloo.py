@@ -166,7 +166,8 @@ class OraclePrims:
     def cross_combine_bwd(x0, prod, d_out, diag_scale, d_x0_accum, d_x_accum):
         d_prod = d_out * x0
         d_x0_accum.add_(d_out * prod)
-        d_x_accum.add_(d_out + diag_scale * d_prod)
+        if d_x_accum is not None:
+            d_x_accum.add_(d_out + diag_scale * d_prod)
         return d_prod
 
     @staticmethod
