@@ -29,7 +29,7 @@ SIGNATURES = {
     "dr_lin_fields_fwd": [_p, _i64, _i32, _i32, _p, _p, _p, _p, _i64, _p],
     "dr_lin_fields_bwd": [_p, _i64, _i32, _i32, _p, _p, _p, _i64, _f32, _p, _p],
     "dr_emb_pool_bwd_sorted_adam": [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _i64, _p, _i64, _p, _p, _p, _f32, _f32,
-                                    _f32, _f32, _p, _p, _p, _p, _p, _p, _p],
+                                    _f32, _f32, _p, _p, _p, _p, _p, _p, _p, _p],
     "dr_adam_step": [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _p],
     "dr_ftrl_step": [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _p],
     "dr_linear_bwd_dw_workspace_bytes": [_i64, _i32, _i32],
@@ -55,7 +55,9 @@ SIGNATURES = {
     "dr_emb_plan_set_small_limit": [_i32],
     "dr_adam_catchup_rows": [_p, _i64, _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _f32, _f32, _f32, _f32, _p],
     "dr_emb_pool_bwd_sorted": [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _i64, _p, _i64, _p, _p, _p, _f32, _p, _p,
-                               _p, _p],
+                               _p, _p, _p],
+    "dr_emb_snapshot_sorted_rows": [_p, _p, _p, _i32, _i64, _p, _p],
+    "dr_ids_transpose_i32": [_p, _i64, _i32, _p, _p],
     "dr_linear_bwd_dx_fm": [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _i64, _i32, _i32, _p, _i64, _p],
     "dr_inbatch_softmax_workspace_bytes": [_i64],
     "dr_inbatch_softmax_fwd": [_p, _p, _i64, _i32, _p, _p, _p, _f32, _p, _p, _p, _p, _i64, _p],
@@ -86,6 +88,7 @@ SIGNATURES = {
     "dr_bf3_emb_linear_fwd": [_p, _i64, _i32, _p, _i64, _p, _i32, _p, _p, _p, _p, _i64, _i32, _p, _i64, _i64, _i32, _p, _i32, _p, _p, _p, _i64, _p],
     "dr_bf3_wgrad_workspace_bytes": [_i64, _i32, _i32],
     "dr_bf3_wgrad": [_p, _i64, _p, _i64, _i64, _i32, _i32, _f32, _p, _i64, _p, _p, _i64, _p],
+    "dr_bf3_wgrad_emb": [_p, _i64, _i32, _p, _p, _i32, _p, _p, _i64, _i32, _i32, _f32, _p, _i64, _p, _p, _i64, _p],
     "dr_bf3_gemm_tn_workspace_bytes": [_i64, _i32, _i32],
     "dr_bf3_gemm_tn": [_p, _i64, _i64, _p, _i64, _i64, _i64, _i32, _i32, _f32, _p, _i64, _p, _p, _p, _i64, _p],
     "dr_cin_fwd": [_p, _p, _i64, _i32, _i32, _i32, _p, _i32, _p, _i32, _p, _p],

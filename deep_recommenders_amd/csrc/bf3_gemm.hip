@@ -1098,7 +1098,7 @@ __global__ __launch_bounds__(512, 2) void bf3_emb_linear_kernel(RsArgs g, EmbArg
             BF3_DS_READ_B128(an[0], ra, 0); BF3_DS_READ_B128(an[1], r1, 0);
             BF3_DS_READ_B128(an[2], r2, 0); BF3_DS_READ_B128(an[3], r3, 0);
         }
-        if (gathered && c_fm) {
+        if (gathered && c_fm && e.concat != nullptr) {                     // (kernel-uniform: concat == NULL skips the stores)
             // the image position-wise (8 lanes per 128-byte line) -> concat, for the backward kernels; missing ids store zeros
             const unsigned sa = a_st + astage * A_STAGE;
             f32x4 st[4];
@@ -1303,12 +1303,17 @@ struct TnRsArgs {
     int64_t R; int32_t F; int32_t N;
     int64_t per; int32_t split;                  // reduction rows per slice (multiple of 32), number of slices
     float* partial; float* colsum;               // [split][Fp][Np], [split][Np] (colsum may be null)
+    // GATHER form (the first layer of the DeepFM / DCN tower): X is never materialised -- column c < 64 nf of reduction row r is
+    // element (c & 63) of table row row_base[c >> 6] + ids_t[c >> 6][r] (zero for a missing id), columns [64 nf, F) come from
+    // dense_pad[r][c - 64 nf]
+    const int32_t* ids_t; const int64_t* row_base; const float* table; int32_t nf; const float* dense_pad;
 };
 
 __device__ __forceinline__ void rs_split8v(const float (&v)[8], bf16x8& p0, bf16x8& p1, bf16x8& p2) {
     rs_split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), p0, p1, p2);
 }
 
+template <int GATHER>
 __global__ __launch_bounds__(512, 2) void bf3_gemm_tn_rs_kernel(TnRsArgs g) {
     constexpr int NW = 8, BMF = 32 * NW, BN = 256, NT = BN / 32;
     constexpr int B_PLANE = BN * 64;                                    // bytes: 256 n-rows x 64 bytes (32 r)
@@ -1364,6 +1369,56 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_tn_rs_kernel(TnRsArgs g) {
             }
         }
     };
+    // GATHER: where this wave's 32 columns live.  A wave covers half a field's row (32 of its 64 dims: one 128-byte line per
+    // reduction row and lane half, exactly the lines the forward's gather fetched), or the dense features, or nothing (columns
+    // past F: a valid dummy source, the outputs are never read).  Every load stays unconditional.
+    const int c0w = f0 + wave * 32;
+    const bool w_field = GATHER && c0w < 64 * g.nf;
+    const bool w_dense = GATHER && !w_field && g.dense_pad != nullptr && c0w < 64 * g.nf + 32;
+    const float* gbase = nullptr;
+    int64_t gpitch = 0;
+    const int32_t* idrow = nullptr;
+    if (GATHER) {
+        if (w_field) {
+            const int fld = c0w >> 6;
+            gbase = g.table + g.row_base[fld] * 64 + (c0w & 32) + l31;
+            gpitch = 64;
+            idrow = g.ids_t + (int64_t)fld * g.R;
+        } else if (w_dense) {
+            gbase = g.dense_pad + l31;
+            gpitch = 32;
+        } else {
+            gbase = g.table + l31;
+        }
+    }
+    int idv = 0;                                                        // this lane's id of the k-tile whose rows are fetched next
+    int xmask = 0;                                                      // validity of xa[e] (row inside the slice, id present)
+    auto load_ids = [&](int64_t r0) -> int {
+        if (!w_field) return 0;                                         // (wave-uniform)
+        const int64_t r = r0 + l31 < g.R ? r0 + l31 : g.R - 1;
+        return idrow[r];
+    };
+    auto load_gather = [&](float (&dst)[16], int ids_of_tile, int64_t r0) {
+        int vm = 0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int64_t r = r0 + 16 * hi + e;
+            const bool inr = r < r_end;
+            int64_t idx;
+            bool ok;
+            if (w_field) {                                              // lanes 0..31 hold the ids of rows r0 .. r0 + 31
+                const int id = __shfl(ids_of_tile, 16 * hi + e, 64);
+                ok = inr && id >= 0;
+                idx = id > 0 ? id : 0;
+            } else {
+                ok = inr && w_dense;
+                idx = w_dense ? (inr ? r : r_end - 1) : 0;
+            }
+            dst[e] = gbase[idx * gpitch];
+            vm |= (ok ? 1 : 0) << e;
+        }
+        xmask = vm;
+    };
     bf16x8 fa[2][3];
     bf16x8 fb[4][3];                                                    // group q uses buffer q & 3, read two groups ahead
     float cs = 0.f;
@@ -1408,7 +1463,13 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_tn_rs_kernel(TnRsArgs g) {
     // ---- prologue: B(0) into stage 0, A(0) and B(1) into registers -------------------------------------------------------------
     load_raw(yb, g.Y, g.ldy, yoff, r_begin);
     stage_b(0);
-    load_raw(xa, g.X, g.ldx, xoff, r_begin);
+    if (GATHER) {
+        idv = load_ids(r_begin);
+        load_gather(xa, idv, r_begin);
+        idv = load_ids(r_begin + BK);
+    } else {
+        load_raw(xa, g.X, g.ldx, xoff, r_begin);
+    }
     load_raw(yb, g.Y, g.ldy, yoff, r_begin + BK);                       // (all zeros when nk == 1)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     read_b(0, 0, 0);
@@ -1423,13 +1484,20 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_tn_rs_kernel(TnRsArgs g) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = xa[8 * s + j];
+                for (int j = 0; j < 8; ++j) v[j] = (!GATHER || ((xmask >> (8 * s + j)) & 1)) ? xa[8 * s + j] : 0.f;
                 rs_split8v(v, fa[s][0], fa[s][1], fa[s][2]);
             }
         }
         if (kt + 1 < nk) stage_b(stage ^ 1);
         __builtin_amdgcn_sched_barrier(0);
-        load_raw(xa, g.X, g.ldx, xoff, r_begin + (int64_t)(kt + 1) * BK);
+        if (GATHER) {
+            // (the 16 id shuffles are LDS operations: they and the loads they address stay between these two scheduling
+            // barriers, i.e. in front of every fragment read the counted lgkmcnt waits of the MFMA loop reckon with)
+            load_gather(xa, idv, r_begin + (int64_t)(kt + 1) * BK);
+            idv = load_ids(r_begin + (int64_t)(kt + 2) * BK);
+        } else {
+            load_raw(xa, g.X, g.ldx, xoff, r_begin + (int64_t)(kt + 1) * BK);
+        }
         load_raw(yb, g.Y, g.ldy, yoff, r_begin + (int64_t)(kt + 2) * BK);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1975,9 +2043,36 @@ extern "C" int dr_bf3_wgrad(const float* x, int64_t ld_x, const float* dy, int64
     tn_rs_plan(R, F, N, split, per, Fp, Np);
     float* partial = static_cast<float*>(workspace);
     float* colsum = partial + (int64_t)split * Fp * Np;
-    TnRsArgs g{x, ld_x, dy, ld_dy, R, F, N, per, split, partial, dstb != nullptr ? colsum : nullptr};
+    TnRsArgs g{x, ld_x, dy, ld_dy, R, F, N, per, split, partial, dstb != nullptr ? colsum : nullptr, nullptr, nullptr, nullptr, 0, nullptr};
     const int grid = (Fp / 256) * (Np / 256) * split;
-    hipLaunchKernelGGL(bf3_gemm_tn_rs_kernel, dim3(grid), dim3(512), 0, dr_s(stream), g);
+    hipLaunchKernelGGL(bf3_gemm_tn_rs_kernel<0>, dim3(grid), dim3(512), 0, dr_s(stream), g);
+    hipLaunchKernelGGL(bf3_tn_rs_reduce_kernel, dim3(dr_grid_for((int64_t)F * N, 256)), dim3(256), 0, dr_s(stream), partial,
+                       dstb != nullptr ? colsum : nullptr, split, F, N, Fp, Np, scale, dstW, ld_w, dstb);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+// The same wgrad for the FIRST tower layer, whose x = concat(field embeddings, dense features) is never read from a buffer: the
+// kernel gathers it from the tables (GATHER form of TnRsArgs; D = 64).  ids_t [nf][R] int32: the batch's bucket ids, field-major
+// (dr_ids_transpose_i32), -1 = missing; dense_pad [R, 32] zero-padded dense features (NULL iff F == 64 nf).  With this the forward
+// need not store `concat` at all (keras/models/ranking/deepfm.py:44-45: stack / concat become pure fiction).
+extern "C" int dr_bf3_wgrad_emb(const int32_t* ids_t, int64_t R, int32_t nf, const int64_t* row_base, const float* table, int32_t D,
+                                const float* dense_pad, const float* dy, int64_t ld_dy, int32_t F, int32_t N, float scale, float* dstW,
+                                int64_t ld_w, float* dstb, void* workspace, int64_t workspace_bytes, dr_stream_t stream) {
+    if (R <= 0 || F <= 0 || N <= 0 || nf <= 0) return DR_EINVAL;
+    if (D != 64 || F < 64 * nf || F > 64 * nf + 32) return DR_ESHAPE;
+    if (!ids_t || !row_base || !table || !dy || !dstW || !workspace || ld_dy < N || ld_w < N) return DR_EINVAL;
+    if (F > 64 * nf && !dense_pad) return DR_EINVAL;
+    if (workspace_bytes < dr_bf3_wgrad_workspace_bytes(R, F, N)) return DR_EINVAL;
+    int split, Fp, Np;
+    int64_t per;
+    tn_rs_plan(R, F, N, split, per, Fp, Np);
+    float* partial = static_cast<float*>(workspace);
+    float* colsum = partial + (int64_t)split * Fp * Np;
+    TnRsArgs g{nullptr, 0, dy, ld_dy, R, F, N, per, split, partial, dstb != nullptr ? colsum : nullptr, ids_t, row_base, table, nf,
+               F > 64 * nf ? dense_pad : nullptr};
+    const int grid = (Fp / 256) * (Np / 256) * split;
+    hipLaunchKernelGGL(bf3_gemm_tn_rs_kernel<1>, dim3(grid), dim3(512), 0, dr_s(stream), g);
     hipLaunchKernelGGL(bf3_tn_rs_reduce_kernel, dim3(dr_grid_for((int64_t)F * N, 256)), dim3(256), 0, dr_s(stream), partial,
                        dstb != nullptr ? colsum : nullptr, split, F, N, Fp, Np, scale, dstW, ld_w, dstb);
     DR_CHECK_LAUNCH();
@@ -1996,10 +2091,11 @@ extern "C" int dr_bf3_emb_linear_fwd(const int64_t* ids, int64_t M, int32_t F, c
     // the k-tile <-> (field, half row) map is built for 64-wide rows; the dense features are one k-tile; a field is one 4 GB buffer
     if (D != 64 || K > 64 * F + 32 || field_rows_max <= 0 || field_rows_max > (1 << 24)) return DR_ESHAPE;
     if (M == 0) return DR_OK;
-    if (!ids || !row_base || !table || !concat || !sum_x || !fm_logit || !out || !planes_ok(wt_planes, plane_stride, ld_planes))
+    // concat may be NULL: nothing then stores the gathered embeddings (the wgrad gathers them itself, dr_bf3_wgrad_emb)
+    if (!ids || !row_base || !table || !sum_x || !fm_logit || !out || !planes_ok(wt_planes, plane_stride, ld_planes))
         return DR_EINVAL;
     if (K > 64 * F && (!dense_pad || (reinterpret_cast<uintptr_t>(dense_pad) & 15) != 0)) return DR_EINVAL;
-    if ((reinterpret_cast<uintptr_t>(concat) & 15) != 0 || (ld_concat & 3) != 0 || ld_concat < K ||
+    if ((concat != nullptr && ((reinterpret_cast<uintptr_t>(concat) & 15) != 0 || (ld_concat & 3) != 0 || ld_concat < K)) ||
         (reinterpret_cast<uintptr_t>(table) & 15) != 0 || (reinterpret_cast<uintptr_t>(sum_x) & 15) != 0)
         return DR_EINVAL;
     if (ld_planes < (K + BK - 1) / BK * BK || ld_out < N) return DR_EINVAL;

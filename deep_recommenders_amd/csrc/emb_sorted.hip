@@ -57,7 +57,7 @@ __device__ __forceinline__ void emb_bwd_unique_body(const int bid, const int nbl
     const int nq = D >> 2;
     const bool dvalid = sub < nq;
     const int subc = dvalid ? sub : nq - 1;
-    const bool fm = concat != nullptr && sum_x != nullptr && d_fm_logit != nullptr;
+    const bool fm = sum_x != nullptr && d_fm_logit != nullptr;      // (a unique row's own value IS x: concat is never read here)
     const bool do_lin = lin_w != nullptr && (d_fm_logit != nullptr || slot_lin != nullptr) && sub == 0;
     const float* lsrc = lin_w != nullptr ? lin_w : table;                 // loaded value unused when lin_w == NULL
     const float* dlsrc = d_fm_logit != nullptr ? d_fm_logit : grad;       // idem
@@ -165,7 +165,8 @@ __device__ __forceinline__ void emb_bwd_dups_body(const int bid, const int nblk,
                                                            const float* __restrict__ sum_x,
                                                            const float* __restrict__ d_fm_logit,
                                                            const float* __restrict__ slot_lin, float scale,
-                                                           float* __restrict__ table, float* __restrict__ lin_w, AdamArgs ad) {
+                                                           float* __restrict__ table, float* __restrict__ lin_w, AdamArgs ad,
+                                                           const float* __restrict__ x_sorted) {
     // ADAM: the update is not linear in the gradient, so a row's slots must be summed completely before the one update:
     // the segment-start head walks the WHOLE segment (however long) and the aligned heads of hot rows do nothing.
     // One lane group (LPR lanes = one table row) per head.  The piece is walked in chunks of LPR sorted entries: the
@@ -179,10 +180,15 @@ __device__ __forceinline__ void emb_bwd_dups_body(const int bid, const int nblk,
     const int nq = D >> 2;
     const bool dvalid = sub < nq;
     const int subc = dvalid ? sub : nq - 1;
-    const bool fm = concat != nullptr && sum_x != nullptr && d_fm_logit != nullptr;
+    const bool fm = sum_x != nullptr && d_fm_logit != nullptr;
     const bool any_lin = d_fm_logit != nullptr || slot_lin != nullptr;
-    const float* xsrc = fm ? concat : grad;                    // values unused when !fm
-    const int64_t xld = fm ? ldc : ld;
+    // x of a slot = its row's value before this step (single-valued fields): read from `concat` when the forward stored it, else
+    // from x_sorted [L, D], the rows of the sorted list snapshotted BEFORE this launch (dr_emb_snapshot_sorted_rows) -- reading the
+    // table row itself here would race with the atomic pieces of a hot row
+    const bool x_from_snap = fm && concat == nullptr;
+    const float* xsrc = (fm && !x_from_snap) ? concat : grad;  // values unused when !fm or x_from_snap
+    const int64_t xld = (fm && !x_from_snap) ? ldc : ld;
+    const float* snap = x_from_snap ? x_sorted : grad;
     const float* sxsrc = fm ? sum_x : grad;
     const int64_t sxp = fm ? (int64_t)D : 0;
     const float* dlsrc = d_fm_logit != nullptr ? d_fm_logit : grad;
@@ -226,7 +232,8 @@ __device__ __forceinline__ void emb_bwd_dups_body(const int bid, const int nblk,
                     const int32_t p = __shfl(sp, slot * LPR + (act[u] ? t : 0), 64);
                     const int32_t b = p / F, f = p - b * F;
                     v[u] = *reinterpret_cast<const float4*>(grad + (int64_t)b * ld + f * D + subc * 4);
-                    x[u] = *reinterpret_cast<const float4*>(xsrc + (int64_t)b * xld + f * D + subc * 4);
+                    x[u] = x_from_snap ? *reinterpret_cast<const float4*>(snap + (j + (act[u] ? t : 0)) * (int64_t)D + subc * 4)
+                                       : *reinterpret_cast<const float4*>(xsrc + (int64_t)b * xld + f * D + subc * 4);
                     sxv[u] = *reinterpret_cast<const float4*>(sxsrc + (int64_t)b * sxp + subc * 4);
                     dl[u] = dlsrc[b];
                     gl[u] = slot_lin != nullptr ? slot_lin[p] : dl[u];
@@ -296,12 +303,13 @@ struct BwdSortedArgs {
     const float* grad; int64_t ld; const float* concat; int64_t ldc; const float* sum_x; const float* d_fm_logit;
     const float* slot_lin; float scale; float* table; float* lin_w; float* lin_bias;
     const uint64_t* rows; const int32_t* slots; int64_t n; const int32_t* dup_heads; const int32_t* dup_count; uint64_t num_rows;
+    const float* x_sorted;
 };
 template <int LPR, int U, bool ADAM>
 __global__ __launch_bounds__(256) void emb_bwd_sorted_kernel(BwdSortedArgs a, AdamArgs ad, int grid_d) {
     if ((int)blockIdx.x < grid_d)
         emb_bwd_dups_body<LPR, ADAM>(blockIdx.x, grid_d, a.rows, a.slots, a.n, a.dup_heads, a.dup_count, a.F, a.D, a.num_rows, a.grad,
-                                     a.ld, a.concat, a.ldc, a.sum_x, a.d_fm_logit, a.slot_lin, a.scale, a.table, a.lin_w, ad);
+                                     a.ld, a.concat, a.ldc, a.sum_x, a.d_fm_logit, a.slot_lin, a.scale, a.table, a.lin_w, ad, a.x_sorted);
     else
         emb_bwd_unique_body<LPR, U, ADAM>(blockIdx.x - grid_d, gridDim.x - grid_d, a.ids, a.flags, a.B, a.F, a.row_base, a.D, a.grad,
                                           a.ld, a.concat, a.ldc, a.sum_x, a.d_fm_logit, a.slot_lin, a.scale, a.table, a.lin_w,
@@ -315,7 +323,7 @@ static int bwd_sorted_impl(const int64_t* ids, const int64_t* row_base, const in
                            const int32_t* dup_count, int64_t B, int32_t F, int32_t D, int64_t num_rows, const float* grad,
                            int64_t ld_grad, const float* concat, int64_t ld_concat, const float* sum_x,
                            const float* d_fm_logit, const float* slot_lin_grad, float scale, float* dst_table,
-                           float* dst_lin, float* dst_bias, const AdamArgs* adam, dr_stream_t stream) {
+                           float* dst_lin, float* dst_bias, const AdamArgs* adam, const float* x_sorted, dr_stream_t stream) {
     if (B < 0 || F <= 0 || F > 64 || D < 4 || D > 256 || (D & 3) || num_rows <= 0) return DR_EINVAL;
     const int64_t n = B * F;
     if (n == 0) return DR_OK;
@@ -324,6 +332,8 @@ static int bwd_sorted_impl(const int64_t* ids, const int64_t* row_base, const in
         ld_grad < (int64_t)F * D || (ld_grad & 3))
         return DR_EINVAL;
     if (concat != nullptr && (ld_concat < (int64_t)F * D || (ld_concat & 3) || sum_x == nullptr)) return DR_EINVAL;
+    if (sum_x != nullptr && d_fm_logit == nullptr) return DR_EINVAL;
+    if (sum_x != nullptr && concat == nullptr && x_sorted == nullptr) return DR_EINVAL;     // the FM term needs x from somewhere
     int lpr = 1;
     while (lpr * 4 < D) lpr <<= 1;
     const uint64_t* rows = reinterpret_cast<const uint64_t*>(sorted_rows);
@@ -333,7 +343,8 @@ static int bwd_sorted_impl(const int64_t* ids, const int64_t* row_base, const in
     AdamArgs ad{};
     if (adam != nullptr) ad = *adam;
     const BwdSortedArgs ba{ids, unique_flags, B, F, row_base, D, grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit, slot_lin_grad,
-                           scale, dst_table, dst_lin, dst_bias, rows, sorted_slots, n, dup_heads, dup_count, (uint64_t)num_rows};
+                           scale, dst_table, dst_lin, dst_bias, rows, sorted_slots, n, dup_heads, dup_count, (uint64_t)num_rows,
+                           x_sorted};
 #define LAUNCH(L, ADAM_)                                                                                              \
     {                                                                                                                 \
         constexpr int NS_ = 64 / L;                                                                                   \
@@ -365,10 +376,43 @@ extern "C" int dr_emb_pool_bwd_sorted(const int64_t* ids, const int64_t* row_bas
                                       int32_t D, int64_t num_rows, const float* grad, int64_t ld_grad,
                                       const float* concat, int64_t ld_concat, const float* sum_x,
                                       const float* d_fm_logit, const float* slot_lin_grad, float scale,
-                                      float* dst_table, float* dst_lin, float* dst_bias, dr_stream_t stream) {
+                                      float* dst_table, float* dst_lin, float* dst_bias, const float* x_sorted,
+                                      dr_stream_t stream) {
     return bwd_sorted_impl(ids, row_base, sorted_rows, sorted_slots, unique_flags, dup_heads, dup_count, B, F, D, num_rows,
                            grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit, slot_lin_grad, scale, dst_table, dst_lin,
-                           dst_bias, nullptr, stream);
+                           dst_bias, nullptr, x_sorted, stream);
+}
+
+// x_sorted[j, :] = table[sorted_rows[j], :] for the L = dup_count[1] entries of the plan's sorted list (rows of missing ids: zeros).
+// Run BEFORE dr_emb_pool_bwd_sorted[_adam] when the forward did not store `concat`: the FM term of a slot that shares its row
+// needs the row's value from before this step, and the table itself is being updated by the time the duplicate pass reads.
+// (Uniform ids at config 3: L ~ 11 K rows, 3 MB; skewed batches: up to all B * F slots.)
+namespace {
+__global__ __launch_bounds__(256) void snapshot_sorted_rows_kernel(const uint64_t* __restrict__ rows, const int32_t* __restrict__ dup_count,
+                                                                   const float* __restrict__ table, int32_t D, uint64_t num_rows,
+                                                                   float* __restrict__ x_sorted) {
+    const int64_t L = dup_count[1];
+    const int q = D >> 2;                                                // float4 per row
+    const int64_t total = L * q, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t j = i / q;
+        const int c = (int)(i - j * q);
+        const uint64_t k = rows[j];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < num_rows) v = *reinterpret_cast<const float4*>(table + k * (uint64_t)D + c * 4);
+        *reinterpret_cast<float4*>(x_sorted + j * (int64_t)D + c * 4) = v;
+    }
+}
+}  // namespace
+
+extern "C" int dr_emb_snapshot_sorted_rows(const int64_t* sorted_rows, const int32_t* dup_count, const float* table, int32_t D,
+                                           int64_t num_rows, float* x_sorted, dr_stream_t stream) {
+    if (D < 4 || (D & 3) || num_rows <= 0) return DR_EINVAL;
+    if (!sorted_rows || !dup_count || !table || !x_sorted) return DR_EINVAL;
+    hipLaunchKernelGGL(snapshot_sorted_rows_kernel, dim3(2048), dim3(256), 0, dr_s(stream), reinterpret_cast<const uint64_t*>(sorted_rows),
+                       dup_count, table, D, (uint64_t)num_rows, x_sorted);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
 }
 
 // Fused row-wise Adam form of the sorted K4: same inputs, `grad` is the gradient of the mean
@@ -384,13 +428,13 @@ extern "C" int dr_emb_pool_bwd_sorted_adam(const int64_t* ids, const int64_t* ro
                                            const float* concat, int64_t ld_concat, const float* sum_x,
                                            const float* d_fm_logit, const float* slot_lin_grad, float lr_t, float beta1,
                                            float beta2, float eps, float* table, float* m_table, float* v_table,
-                                           float* lin_w, float* m_lin, float* v_lin, dr_stream_t stream) {
+                                           float* lin_w, float* m_lin, float* v_lin, const float* x_sorted, dr_stream_t stream) {
     if (!m_table || !v_table) return DR_EINVAL;
     if (lin_w != nullptr && (!m_lin || !v_lin)) return DR_EINVAL;
     AdamArgs ad{m_table, v_table, m_lin, v_lin, lr_t, beta1, beta2, eps};
     return bwd_sorted_impl(ids, row_base, sorted_rows, sorted_slots, unique_flags, dup_heads, dup_count, B, F, D, num_rows,
                            grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit, slot_lin_grad, 0.f, table, lin_w, nullptr,
-                           &ad, stream);
+                           &ad, x_sorted, stream);
 }
 
 // ---- TF's NON-lazy sparse Adam, evaluated lazily -----------------------------------------------------------------------------------

@@ -364,3 +364,38 @@ extern "C" int dr_vocab_lookup_bytes(const uint8_t* bytes, const int64_t* offset
     DR_CHECK_LAUNCH();
     return DR_OK;
 }
+
+// ids [B, F] int64 -> out [F][B] int32 (field-major): the row indices of one field for consecutive examples become one 128-byte
+// line per 32 examples -- what the gather form of the first-layer wgrad (dr_bf3_wgrad_emb) reads per k-tile.  -1 stays -1.
+namespace {
+__global__ __launch_bounds__(256) void ids_transpose_i32_kernel(const int64_t* __restrict__ ids, int64_t B, int32_t F,
+                                                                int32_t* __restrict__ out) {
+    __shared__ int32_t tile[64][65];
+    // a block moves 64 examples x up to 64 fields through LDS so that both sides are coalesced
+    const int64_t b0 = (int64_t)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int f0 = 0; f0 < F; f0 += 64) {
+        for (int r = ty; r < 64; r += 4) {                               // rows = examples, tx = field
+            const int64_t b = b0 + r;
+            const int f = f0 + tx;
+            tile[r][tx] = (b < B && f < F) ? (int32_t)ids[b * F + f] : -1;
+        }
+        __syncthreads();
+        for (int r = ty; r < 64; r += 4) {                               // rows = fields, tx = example
+            const int f = f0 + r;
+            const int64_t b = b0 + tx;
+            if (f < F && b < B) out[(int64_t)f * B + b] = tile[tx][r];
+        }
+        __syncthreads();
+    }
+}
+}  // namespace
+
+extern "C" int dr_ids_transpose_i32(const int64_t* ids, int64_t B, int32_t F, int32_t* out, dr_stream_t stream) {
+    if (B < 0 || F <= 0) return DR_EINVAL;
+    if (B == 0) return DR_OK;
+    if (!ids || !out) return DR_EINVAL;
+    hipLaunchKernelGGL(ids_transpose_i32_kernel, dim3((unsigned)((B + 63) / 64)), dim3(256), 0, dr_s(stream), ids, B, F, out);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}

@@ -156,6 +156,16 @@ class DeepFMEngine:
         # its own kernel.
         self.fuse_k3 = _os.environ.get("DR_FUSE_K3", "1") == "1" and D == 64 and self.Nd <= 32 and V <= (1 << 24)
         self.dense_pad = torch.zeros((B, 32), dtype=torch.float32, device=device) if (self.fuse_k3 and self.Nd) else None
+        # `concat` is never built (round 3): the fused first layer stops storing the gathered embeddings (0.44 GB written per step,
+        # ~70 us of the kernel) because nothing reads them any more -- the first layer's wgrad gathers its operand from the tables
+        # itself (dr_bf3_wgrad_emb, from field-major int32 ids), and K4's duplicate pass takes x of the few slots that share rows
+        # from a snapshot of those rows taken just before the update (dr_emb_snapshot_sorted_rows).  DR_NO_CONCAT=0: as round 2.
+        self.no_concat = (_os.environ.get("DR_NO_CONCAT", "1") == "1" and self.fuse_k3 and self.wplanes[0] is not None
+                          and self.wg_ws[0] is not None and sorted_bwd and self.acts[0] in (0, 1) and len(dnn_units) >= 1
+                          and not (self.fuse_head and len(self.Ws) == 2))
+        if self.no_concat:
+            self._ids_t = [torch.empty((F, B), dtype=torch.int32, device=device) for _ in range(2)]
+            self.x_sorted = torch.empty((B * F, D), dtype=torch.float32, device=device)
         # The slot sort of batch s + 1 next to K4 of batch s (DR_PREFETCH_PLAN=0: every step hashes and sorts its own batch).  K4 is
         # the one long kernel of the step that is HBM-bound with small blocks, i.e. that shares the machine; beside the persistent
         # GEMMs (the fused first layer occupies all 160 KB of LDS on every CU) the sort chain's ~20 small launches only advance in
@@ -184,6 +194,8 @@ class DeepFMEngine:
         # is OFF unless DR_OVERLAP_DW=1 asks for it.
         _ov = _os.environ.get("DR_OVERLAP_DW", "0")
         self.overlap_dw = _ov == "1"
+        if self.overlap_dw:
+            self.no_concat = False       # the gathering wgrad would read the tables while K4 updates them on the other stream
         self.concurrent = {}
         if self.overlap_dw:
             k4 = "emb_pool_bwd_adam" if optimizer == "adam" else "emb_pool_bwd"
@@ -238,13 +250,16 @@ class DeepFMEngine:
                 self.side.wait_event(self.ev_k4)
             self._k("next_batch: hash_bucket_i64(side stream, overlapped)", "overlap", self.B * self.F * 16,
                     lambda: ops.hash_bucket_i64(nk, self.col_buckets, out=self._ids[nxt]))
+            if self.no_concat:
+                ops.ids_transpose_i32(self._ids[nxt], out=self._ids_t[nxt])
             nd = self._next_dense
             self._pref_dense = None
             if nd is not None and self.Nd and not self.overlap_dw:
                 # the dense features of that batch too: this step's wgrad (the last reader of concat's dense columns) and forward
                 # (dense_pad) are behind us on the training stream, which the side stream has waited for
                 nd.record_stream(self.side)
-                self.concat[:, self.F * self.D:self.F * self.D + self.Nd].copy_(nd)
+                if not self.no_concat:
+                    self.concat[:, self.F * self.D:self.F * self.D + self.Nd].copy_(nd)
                 if self.dense_pad is not None:
                     self.dense_pad[:, :self.Nd].copy_(nd)
                 self._pref_dense = self._token(nd)
@@ -298,7 +313,12 @@ class DeepFMEngine:
         return out
 
     def _wgrad(self, i, x, dy, sc, dstW, dstb):
-        if self.wg_ws[i] is not None:
+        if i == 0 and self.no_concat:
+            # x = [embeddings of this batch's rows, dense features]: gathered from the tables (they are updated only by K4, later
+            # on this stream) through the field-major ids
+            ops.bf3_wgrad_emb(self._ids_t[self.cur], self.row_base, self.table, self.dense_pad, dy, sc, dstW, dstb,
+                              workspace=self.wg_ws[0])
+        elif self.wg_ws[i] is not None:
             ops.bf3_wgrad(x, dy, sc, dstW, dstb, workspace=self.wg_ws[i])
         else:
             ops.linear_bwd_dw(x, dy, sc, dstW, dstb, workspace=self.dw_ws[i])
@@ -331,6 +351,8 @@ class DeepFMEngine:
                 torch.cuda.current_stream().wait_event(self._ev_hashed[self.cur ^ 1])
             self._k("hash_bucket_i64", "hbm", B * F * 16,
                     lambda: ops.hash_bucket_i64(keys, self.col_buckets, out=self.ids))                # K1
+            if self.no_concat:
+                ops.ids_transpose_i32(self.ids, out=self._ids_t[self.cur])
         if self.sorted_bwd and self.sort_inline:
             self._k("emb_sort_slots", "hbm", B * F * 36,
                     lambda: ops.emb_sort_slots(self.ids, self.row_base, self.R, self.plan))
@@ -351,7 +373,8 @@ class DeepFMEngine:
         if self.sorted_bwd and not self.sort_inline and not self.sort_with_k3 and not prefetched:
             self._launch_sort()              # after K3: under the first GEMM and the tower tail
         if self.Nd and not (prefetched and self._pref_dense is not None and self._pref_dense == self._token(dense)):
-            self.concat[:, F * D:F * D + self.Nd].copy_(dense)                         # layout: append dense feats
+            if not self.no_concat:
+                self.concat[:, F * D:F * D + self.Nd].copy_(dense)                     # layout: append dense feats
             if self.dense_pad is not None:
                 self.dense_pad[:, :self.Nd].copy_(dense)                               # the fused kernel's own (k-tile wide) copy
         self._pref_dense = None
@@ -365,7 +388,8 @@ class DeepFMEngine:
                 # K3 + first Dense in one launch: the GEMM gathers its activation operand from the tables, writes concat and the
                 # FM terms on the way (the dense features were placed in concat above)
                 self._k("emb_linear_fwd_L0", "mfma", 2.0 * B * W.shape[0] * W.shape[1],
-                        lambda b=b: ops.bf3_emb_linear_fwd(self.ids, self.row_base, self.V, self.table, self.lin_w, self.lin_bias, self.dense_pad, self.concat,
+                        lambda b=b: ops.bf3_emb_linear_fwd(self.ids, self.row_base, self.V, self.table, self.lin_w, self.lin_bias, self.dense_pad,
+                                                           None if self.no_concat else self.concat,
                                                            self.in_dim, self.wplanes[0].wt, b, self.acts[0], self.sum_x, self.fm_logit,
                                                            self.hs[0]))
             elif self.wplanes[i] is not None:
@@ -462,11 +486,14 @@ class DeepFMEngine:
         elif self.sorted_bwd:
             if not (self._plan_prefetched and self.lean_events):
                 torch.cuda.current_stream().wait_event(self.ev_sorted)
+            if self.no_concat:     # x of the slots that share rows, before the update touches them (11 K rows for uniform ids)
+                ops.emb_snapshot_sorted_rows(self.plan, self.table, self.R, self.x_sorted)
             mark = self._prefetch_mark()
             self._k("emb_pool_bwd", "hbm", self.alg_bytes_bwd(),                                      # K4 (sorted)
                     lambda: ops.emb_pool_bwd_sorted(self.ids, self.row_base, self.plan, D, self.R, self.d_concat, self.d_logit,
-                                                    -lr, self.table, self.lin_w, self.lin_bias, concat=self.concat,
-                                                    sum_x=self.sum_x))
+                                                    -lr, self.table, self.lin_w, self.lin_bias,
+                                                    concat=None if self.no_concat else self.concat, sum_x=self.sum_x,
+                                                    x_sorted=self.x_sorted if self.no_concat else None))
             self._prefetch_issue(mark)
         else:
             self._k("emb_pool_bwd", "hbm", self.alg_bytes_bwd(),                                      # K4 (atomics)
@@ -492,12 +519,15 @@ class DeepFMEngine:
         lr_t = ops.adam_lr_t(self.lr, self.beta1, self.beta2, self.t)
         if not (self._plan_prefetched and self.lean_events):
             torch.cuda.current_stream().wait_event(self.ev_sorted)
+        if self.no_concat:
+            ops.emb_snapshot_sorted_rows(self.plan, self.table, self.R, self.x_sorted)
         mark = self._prefetch_mark()
         self._k("emb_pool_bwd_adam", "hbm", self.B * (28 * self.F * self.D + 40 * self.F),                # K4 + optimizer
                 lambda: ops.emb_pool_bwd_sorted_adam(self.ids, self.row_base, self.plan, self.D, self.R, self.d_concat,
                                                      self.d_logit, lr_t, self.beta1, self.beta2, self.eps, self.table,
                                                      self.m_table, self.v_table, self.lin_w, self.m_lin, self.v_lin,
-                                                     concat=self.concat, sum_x=self.sum_x))
+                                                     concat=None if self.no_concat else self.concat, sum_x=self.sum_x,
+                                                     x_sorted=self.x_sorted if self.no_concat else None))
         self._prefetch_issue(mark)
         ops.reduce_sum(self.d_logit, out=self.g_lin_bias)                       # d loss / d (first-order bias), fixed order
         if self.overlap_dw:

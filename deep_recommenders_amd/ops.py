@@ -469,8 +469,27 @@ def emb_plan_set_small_limit(limit):
     return int(lib().dr_emb_plan_set_small_limit(int(limit)))
 
 
+def emb_snapshot_sorted_rows(plan, table, num_rows, out):
+    """out[j, :] = table[plan.rows[j], :] for the plan's sorted list (dr_emb_snapshot_sorted_rows): the x of the slots that share
+    rows, taken before K4 updates the table -- needed when the forward did not store `concat`."""
+    assert out.is_contiguous() and out.shape[0] >= plan.n and out.shape[1] == table.shape[1]
+    check(lib().dr_emb_snapshot_sorted_rows(ptr(plan.rows), ptr(plan.dup_count), ptr(table), table.shape[1], int(num_rows), ptr(out),
+                                            stream_ptr()), "dr_emb_snapshot_sorted_rows")
+    return out
+
+
+def ids_transpose_i32(ids, out=None):
+    """ids [B, F] int64 -> [F, B] int32 (field-major), for bf3_wgrad_emb"""
+    ids = _c(ids, torch.int64)
+    B, F = ids.shape
+    if out is None:
+        out = torch.empty((F, B), dtype=torch.int32, device=ids.device)
+    check(lib().dr_ids_transpose_i32(ptr(ids), B, F, ptr(out), stream_ptr()), "dr_ids_transpose_i32")
+    return out
+
+
 def emb_pool_bwd_sorted(ids, row_base, plan, D, num_rows, grad, d_fm_logit, scale, dst_table, dst_lin=None, dst_bias=None,
-                        concat=None, sum_x=None, slot_lin_grad=None):
+                        concat=None, sum_x=None, slot_lin_grad=None, x_sorted=None):
     ids = _c(ids, torch.int64)
     B, F = ids.shape
     assert grad.stride(1) == 1
@@ -478,7 +497,7 @@ def emb_pool_bwd_sorted(ids, row_base, plan, D, num_rows, grad, d_fm_logit, scal
                                        ptr(plan.dup_heads), ptr(plan.dup_count), B, F, D, int(num_rows), ptr(grad),
                                        grad.stride(0), ptr(concat), concat.stride(0) if concat is not None else 0,
                                        ptr(sum_x), ptr(d_fm_logit), ptr(slot_lin_grad), float(scale), ptr(dst_table), ptr(dst_lin),
-                                       ptr(dst_bias),
+                                       ptr(dst_bias), ptr(x_sorted),
                                        stream_ptr()), "dr_emb_pool_bwd_sorted")
 
 
@@ -488,7 +507,7 @@ def adam_lr_t(lr, beta1, beta2, step):
 
 
 def emb_pool_bwd_sorted_adam(ids, row_base, plan, D, num_rows, grad, d_fm_logit, lr_t, beta1, beta2, eps, table, m_table,
-                             v_table, lin_w=None, m_lin=None, v_lin=None, concat=None, sum_x=None, slot_lin_grad=None):
+                             v_table, lin_w=None, m_lin=None, v_lin=None, concat=None, sum_x=None, slot_lin_grad=None, x_sorted=None):
     """Sorted K4 with a fused row-wise Adam update (see dr_emb_pool_bwd_sorted_adam in include/dr_hotpath.h)."""
     ids = _c(ids, torch.int64)
     B, F = ids.shape
@@ -498,7 +517,7 @@ def emb_pool_bwd_sorted_adam(ids, row_base, plan, D, num_rows, grad, d_fm_logit,
                                             grad.stride(0), ptr(concat), concat.stride(0) if concat is not None else 0,
                                             ptr(sum_x), ptr(d_fm_logit), ptr(slot_lin_grad), float(lr_t), float(beta1),
                                             float(beta2), float(eps), ptr(table), ptr(m_table), ptr(v_table), ptr(lin_w),
-                                            ptr(m_lin), ptr(v_lin), stream_ptr()), "dr_emb_pool_bwd_sorted_adam")
+                                            ptr(m_lin), ptr(v_lin), ptr(x_sorted), stream_ptr()), "dr_emb_pool_bwd_sorted_adam")
 
 
 def adam_catchup_rows(ids, row_base, table, m_table, v_table, lin_w, m_lin, v_lin, row_step, upto, stamp, lr, beta1=0.9,
@@ -873,10 +892,10 @@ def bf3_emb_linear_fwd(ids, row_base, field_rows_max, table, lin_w, lin_bias, de
     features or a field of more than 2^24 rows."""
     ids = _c(ids, torch.int64)
     M, F = ids.shape
-    assert concat.stride(1) == 1 and out.stride(1) == 1 and wt.cols == K and out.shape == (M, wt.rows)
+    assert (concat is None or concat.stride(1) == 1) and out.stride(1) == 1 and wt.cols == K and out.shape == (M, wt.rows)
     assert dense_pad is None or (dense_pad.shape == (M, 32) and dense_pad.is_contiguous())
     check(lib().dr_bf3_emb_linear_fwd(ptr(ids), M, F, ptr(row_base), int(field_rows_max), ptr(table), table.shape[1], ptr(lin_w), ptr(lin_bias),
-                                      ptr(dense_pad), ptr(concat), concat.stride(0), int(K), ptr(wt.buf), wt.plane_stride, wt.ld,
+                                      ptr(dense_pad), ptr(concat), concat.stride(0) if concat is not None else 0, int(K), ptr(wt.buf), wt.plane_stride, wt.ld,
                                       wt.rows, ptr(bias), int(act), ptr(sum_x), ptr(fm_logit), ptr(out), out.stride(0), stream_ptr()),
           "dr_bf3_emb_linear_fwd")
     return out
@@ -884,6 +903,21 @@ def bf3_emb_linear_fwd(ids, row_base, field_rows_max, table, lin_w, lin_bias, de
 
 def bf3_wgrad_workspace(R, F, N, device):
     return torch.empty(max(64, lib().dr_bf3_wgrad_workspace_bytes(int(R), int(F), int(N)) // 4), dtype=torch.float32, device=device)
+
+
+def bf3_wgrad_emb(ids_t, row_base, table, dense_pad, dy, scale, dstW, dstb=None, workspace=None):
+    """bf3_wgrad of the first tower layer with x gathered from the tables (dr_bf3_wgrad_emb): ids_t [nf, R] int32 field-major,
+    dense_pad [R, 32] or None; dstW [64 nf + Nd, N]."""
+    nf, R = ids_t.shape
+    F, N = dstW.shape
+    assert ids_t.dtype == torch.int32 and ids_t.is_contiguous() and dy.stride(1) == 1 and dstW.stride(1) == 1 and dy.shape == (R, N)
+    assert dense_pad is None or (dense_pad.shape == (R, 32) and dense_pad.is_contiguous())
+    if workspace is None:
+        workspace = bf3_wgrad_workspace(R, F, N, dy.device)
+    check(lib().dr_bf3_wgrad_emb(ptr(ids_t), R, nf, ptr(row_base), ptr(table), table.shape[1], ptr(dense_pad), ptr(dy), dy.stride(0),
+                                 F, N, float(scale), ptr(dstW), dstW.stride(0), ptr(dstb), ptr(workspace), workspace.numel() * 4,
+                                 stream_ptr()), "dr_bf3_wgrad_emb")
+    return dstW
 
 
 def bf3_wgrad(x, dy, scale, dstW, dstb=None, workspace=None):

@@ -69,6 +69,8 @@ int dr_hash_bucket_i64(const int64_t* keys, int64_t B, int32_t C, const uint64_t
                        int64_t* ids_out, dr_stream_t stream);
 
 /* Same for byte strings in CSR form (bytes + offsets[n+1]); "" -> id -1. One bucket count. */
+/* ids [B, F] int64 -> out [F][B] int32, field-major (what dr_bf3_wgrad_emb reads: one 128-byte line per 32 examples of a field) */
+int dr_ids_transpose_i32(const int64_t* ids, int64_t B, int32_t F, int32_t* out, dr_stream_t stream);
 int dr_hash_bucket_bytes(const uint8_t* bytes, const int64_t* offsets, int64_t n,
                          uint64_t num_buckets, int64_t* ids_out, dr_stream_t stream);
 
@@ -182,7 +184,13 @@ int dr_emb_pool_bwd_sorted(const int64_t* ids, const int64_t* row_base, const in
                            int32_t D, int64_t num_rows, const float* grad, int64_t ld_grad,
                            const float* concat, int64_t ld_concat, const float* sum_x,
                            const float* d_fm_logit, const float* slot_lin_grad, float scale,
-                           float* dst_table, float* dst_lin, float* dst_bias, dr_stream_t stream);
+                           float* dst_table, float* dst_lin, float* dst_bias, const float* x_sorted, dr_stream_t stream);
+/* The FM term (sum_x, d_fm_logit given) needs x[b, f, :] of every slot: for a slot that owns its row it is the row's own value
+ * (read by the update anyway); for slots that SHARE a row it comes from `concat` if the forward stored it, else from
+ * x_sorted [L, D] = the rows of the plan's sorted list, snapshotted by dr_emb_snapshot_sorted_rows before the update starts
+ * (round 3: the fused first layer no longer stores concat, the wgrad gathers its operand from the tables -- dr_bf3_wgrad_emb). */
+int dr_emb_snapshot_sorted_rows(const int64_t* sorted_rows, const int32_t* dup_count, const float* table, int32_t D,
+                                int64_t num_rows, float* x_sorted, dr_stream_t stream);
 
 /* SURVEY.md section 8f rank 1 -- the optimizer of the reference's own examples (tf.train.AdamOptimizer(0.01),
  * examples/train_fm_on_movielens_estimator.py:51-52; tf.keras.optimizers.Adam(), examples/train_deepfm_on_movielens_keras.py:44)
@@ -200,7 +208,7 @@ int dr_emb_pool_bwd_sorted_adam(const int64_t* ids, const int64_t* row_base, con
                                 const float* concat, int64_t ld_concat, const float* sum_x,
                                 const float* d_fm_logit, const float* slot_lin_grad, float lr_t, float beta1,
                                 float beta2, float eps, float* table, float* m_table, float* v_table,
-                                float* lin_w, float* m_lin, float* v_lin, dr_stream_t stream);
+                                float* lin_w, float* m_lin, float* v_lin, const float* x_sorted, dr_stream_t stream);
 /* Dense Adam step (same formula) over a flat parameter buffer; grad is multiplied by grad_scale first. */
 /* TF's NON-lazy sparse Adam, evaluated lazily (examples/train_fm_on_movielens_estimator.py:51-52: tf.train.AdamOptimizer decays
  * m / v of the WHOLE variable and moves every row on every step).  row_step[R] int32 (zero-initialised) counts
@@ -544,6 +552,13 @@ int64_t dr_bf3_wgrad_workspace_bytes(int64_t R, int32_t F, int32_t N);
 int dr_bf3_wgrad(const float* x, int64_t ld_x, const float* dy, int64_t ld_dy, int64_t R, int32_t F, int32_t N,
                  float scale, float* dstW, int64_t ld_w, float* dstb, void* workspace, int64_t workspace_bytes,
                  dr_stream_t stream);
+/* dr_bf3_wgrad for the FIRST tower layer, x = concat(field embeddings, dense features) gathered from the tables instead of read from
+ * a buffer (D = 64; F = in_dim in [64 nf, 64 nf + 32]): ids_t [nf][R] int32 field-major ids (dr_ids_transpose_i32, -1 = missing),
+ * dense_pad [R, 32] zero-padded dense features (NULL iff F == 64 nf).  Same workspace as dr_bf3_wgrad(R, F, N).
+ * Autodiff of the first Dense of keras/models/ranking/deepfm.py:30-34 w.r.t. its kernel, with deepfm.py:44-45's concat never built. */
+int dr_bf3_wgrad_emb(const int32_t* ids_t, int64_t R, int32_t nf, const int64_t* row_base, const float* table, int32_t D,
+                     const float* dense_pad, const float* dy, int64_t ld_dy, int32_t F, int32_t N, float scale, float* dstW,
+                     int64_t ld_w, float* dstb, void* workspace, int64_t workspace_bytes, dr_stream_t stream);
 int64_t dr_bf3_gemm_tn_workspace_bytes(int64_t R, int32_t F, int32_t N);
 int dr_bf3_gemm_tn(const void* x_planes, int64_t x_plane_stride, int64_t x_ld, const void* y_planes,
                    int64_t y_plane_stride, int64_t y_ld, int64_t R, int32_t F, int32_t N, float scale, float* dst,
