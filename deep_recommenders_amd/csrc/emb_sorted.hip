@@ -183,8 +183,8 @@ __device__ __forceinline__ void emb_bwd_dups_body(const int bid, const int nblk,
     const bool fm = sum_x != nullptr && d_fm_logit != nullptr;
     const bool any_lin = d_fm_logit != nullptr || slot_lin != nullptr;
     // x of a slot = its row's value before this step (single-valued fields): read from `concat` when the forward stored it, else
-    // from x_sorted [L, D], the rows of the sorted list snapshotted BEFORE this launch (dr_emb_snapshot_sorted_rows) -- reading the
-    // table row itself here would race with the atomic pieces of a hot row
+    // from x_sorted[i, :], the row of work-list head i snapshotted BEFORE this launch (dr_emb_snapshot_sorted_rows; every slot of
+    // a piece shares the head's row) -- reading the table row itself here would race with the atomic pieces of a hot row
     const bool x_from_snap = fm && concat == nullptr;
     const float* xsrc = (fm && !x_from_snap) ? concat : grad;  // values unused when !fm or x_from_snap
     const int64_t xld = (fm && !x_from_snap) ? ldc : ld;
@@ -210,6 +210,7 @@ __device__ __forceinline__ void emb_bwd_dups_body(const int bid, const int nblk,
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         float dls = 0.f;
         int64_t j = i;
+        const float4 xhead = *reinterpret_cast<const float4*>(snap + (x_from_snap ? i : 0) * (int64_t)D + subc * 4);
         bool done = !live || (ADAM && !seg_start);
         while (__any(!done)) {
             const int64_t jj = j + sub;
@@ -232,8 +233,8 @@ __device__ __forceinline__ void emb_bwd_dups_body(const int bid, const int nblk,
                     const int32_t p = __shfl(sp, slot * LPR + (act[u] ? t : 0), 64);
                     const int32_t b = p / F, f = p - b * F;
                     v[u] = *reinterpret_cast<const float4*>(grad + (int64_t)b * ld + f * D + subc * 4);
-                    x[u] = x_from_snap ? *reinterpret_cast<const float4*>(snap + (j + (act[u] ? t : 0)) * (int64_t)D + subc * 4)
-                                       : *reinterpret_cast<const float4*>(xsrc + (int64_t)b * xld + f * D + subc * 4);
+                    x[u] = *reinterpret_cast<const float4*>(xsrc + (int64_t)b * xld + f * D + subc * 4);
+                    if (x_from_snap) x[u] = xhead;
                     sxv[u] = *reinterpret_cast<const float4*>(sxsrc + (int64_t)b * sxp + subc * 4);
                     dl[u] = dlsrc[b];
                     gl[u] = slot_lin != nullptr ? slot_lin[p] : dl[u];
@@ -383,34 +384,36 @@ extern "C" int dr_emb_pool_bwd_sorted(const int64_t* ids, const int64_t* row_bas
                            dst_bias, nullptr, x_sorted, stream);
 }
 
-// x_sorted[j, :] = table[sorted_rows[j], :] for the L = dup_count[1] entries of the plan's sorted list (rows of missing ids: zeros).
-// Run BEFORE dr_emb_pool_bwd_sorted[_adam] when the forward did not store `concat`: the FM term of a slot that shares its row
-// needs the row's value from before this step, and the table itself is being updated by the time the duplicate pass reads.
-// (Uniform ids at config 3: L ~ 11 K rows, 3 MB; skewed batches: up to all B * F slots.)
+// x_sorted[i, :] = table[sorted_rows[i], :] for every position i on the duplicate pass's work list (dup_heads[0 .. dup_count[0])):
+// the value, before this step's update, of each row that several slots share -- one row per PIECE the pass processes, at the
+// piece's own sorted position.  Run BEFORE dr_emb_pool_bwd_sorted[_adam] when the forward did not store `concat`: the FM term of
+// such slots needs their row's old value, and the table is being updated by the time the duplicate pass reads.
+// (Uniform ids at config 3: 5.6 K rows = 1.4 MB; Zipf(1.05): 88 K rows.)  x_sorted must hold B * F rows (positions index it).
 namespace {
-__global__ __launch_bounds__(256) void snapshot_sorted_rows_kernel(const uint64_t* __restrict__ rows, const int32_t* __restrict__ dup_count,
-                                                                   const float* __restrict__ table, int32_t D, uint64_t num_rows,
-                                                                   float* __restrict__ x_sorted) {
-    const int64_t L = dup_count[1];
+__global__ __launch_bounds__(256) void snapshot_sorted_rows_kernel(const uint64_t* __restrict__ rows, const int32_t* __restrict__ dup_heads,
+                                                                   const int32_t* __restrict__ dup_count, const float* __restrict__ table,
+                                                                   int32_t D, uint64_t num_rows, float* __restrict__ x_sorted) {
+    const int64_t nh = dup_count[0];
     const int q = D >> 2;                                                // float4 per row
-    const int64_t total = L * q, stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int64_t j = i / q;
-        const int c = (int)(i - j * q);
-        const uint64_t k = rows[j];
+    const int64_t total = nh * q, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const int64_t h = t / q;
+        const int c = (int)(t - h * q);
+        const int64_t i = dup_heads[h];
+        const uint64_t k = rows[i];
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (k < num_rows) v = *reinterpret_cast<const float4*>(table + k * (uint64_t)D + c * 4);
-        *reinterpret_cast<float4*>(x_sorted + j * (int64_t)D + c * 4) = v;
+        *reinterpret_cast<float4*>(x_sorted + i * (int64_t)D + c * 4) = v;
     }
 }
 }  // namespace
 
-extern "C" int dr_emb_snapshot_sorted_rows(const int64_t* sorted_rows, const int32_t* dup_count, const float* table, int32_t D,
-                                           int64_t num_rows, float* x_sorted, dr_stream_t stream) {
+extern "C" int dr_emb_snapshot_sorted_rows(const int64_t* sorted_rows, const int32_t* dup_heads, const int32_t* dup_count,
+                                           const float* table, int32_t D, int64_t num_rows, float* x_sorted, dr_stream_t stream) {
     if (D < 4 || (D & 3) || num_rows <= 0) return DR_EINVAL;
-    if (!sorted_rows || !dup_count || !table || !x_sorted) return DR_EINVAL;
-    hipLaunchKernelGGL(snapshot_sorted_rows_kernel, dim3(2048), dim3(256), 0, dr_s(stream), reinterpret_cast<const uint64_t*>(sorted_rows),
-                       dup_count, table, D, (uint64_t)num_rows, x_sorted);
+    if (!sorted_rows || !dup_heads || !dup_count || !table || !x_sorted) return DR_EINVAL;
+    hipLaunchKernelGGL(snapshot_sorted_rows_kernel, dim3(1024), dim3(256), 0, dr_s(stream), reinterpret_cast<const uint64_t*>(sorted_rows),
+                       dup_heads, dup_count, table, D, (uint64_t)num_rows, x_sorted);
     DR_CHECK_LAUNCH();
     return DR_OK;
 }

@@ -470,11 +470,11 @@ def emb_plan_set_small_limit(limit):
 
 
 def emb_snapshot_sorted_rows(plan, table, num_rows, out):
-    """out[j, :] = table[plan.rows[j], :] for the plan's sorted list (dr_emb_snapshot_sorted_rows): the x of the slots that share
-    rows, taken before K4 updates the table -- needed when the forward did not store `concat`."""
+    """out[i, :] = table[plan.rows[i], :] for every work-list head i of the plan (dr_emb_snapshot_sorted_rows): the x of the slots
+    that share rows, taken before K4 updates the table -- needed when the forward did not store `concat`."""
     assert out.is_contiguous() and out.shape[0] >= plan.n and out.shape[1] == table.shape[1]
-    check(lib().dr_emb_snapshot_sorted_rows(ptr(plan.rows), ptr(plan.dup_count), ptr(table), table.shape[1], int(num_rows), ptr(out),
-                                            stream_ptr()), "dr_emb_snapshot_sorted_rows")
+    check(lib().dr_emb_snapshot_sorted_rows(ptr(plan.rows), ptr(plan.dup_heads), ptr(plan.dup_count), ptr(table), table.shape[1],
+                                            int(num_rows), ptr(out), stream_ptr()), "dr_emb_snapshot_sorted_rows")
     return out
 
 

@@ -187,10 +187,11 @@ int dr_emb_pool_bwd_sorted(const int64_t* ids, const int64_t* row_base, const in
                            float* dst_table, float* dst_lin, float* dst_bias, const float* x_sorted, dr_stream_t stream);
 /* The FM term (sum_x, d_fm_logit given) needs x[b, f, :] of every slot: for a slot that owns its row it is the row's own value
  * (read by the update anyway); for slots that SHARE a row it comes from `concat` if the forward stored it, else from
- * x_sorted [L, D] = the rows of the plan's sorted list, snapshotted by dr_emb_snapshot_sorted_rows before the update starts
+ * x_sorted [B * F, D], where dr_emb_snapshot_sorted_rows has placed -- before the update starts -- the row of every work-list
+ * head at the head's sorted position (one row per piece of a shared row: 5.6 K rows for uniform ids at config 3)
  * (round 3: the fused first layer no longer stores concat, the wgrad gathers its operand from the tables -- dr_bf3_wgrad_emb). */
-int dr_emb_snapshot_sorted_rows(const int64_t* sorted_rows, const int32_t* dup_count, const float* table, int32_t D,
-                                int64_t num_rows, float* x_sorted, dr_stream_t stream);
+int dr_emb_snapshot_sorted_rows(const int64_t* sorted_rows, const int32_t* dup_heads, const int32_t* dup_count,
+                                const float* table, int32_t D, int64_t num_rows, float* x_sorted, dr_stream_t stream);
 
 /* SURVEY.md section 8f rank 1 -- the optimizer of the reference's own examples (tf.train.AdamOptimizer(0.01),
  * examples/train_fm_on_movielens_estimator.py:51-52; tf.keras.optimizers.Adam(), examples/train_deepfm_on_movielens_keras.py:44)

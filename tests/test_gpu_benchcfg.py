@@ -182,6 +182,7 @@ def _run_deepfm(V, optimizer, kind, lr, steps=2):
     assert ops.get_gemm_mode() == "bf16x3"                 # bench.py's default product mode
     eng = _make_engine(V, optimizer, lr)
     assert eng.fuse_head and eng.sorted_bwd and eng.wplanes[0] is not None and eng.wg_ws[0] is not None, "not the benched orchestration"
+    assert eng.no_concat == (os.environ.get("DR_NO_CONCAT", "1") == "1")
     assert ops.linear_bwd_narrow_supported(B, 256, 32) and eng.narrow_ws[1] is not None
     batches = _batches(steps, kind, seed=1234)
     ids_list = [_oracle_ids(k, V) for k, _, _ in batches]
@@ -250,6 +251,14 @@ def test_deepfm_bench_config_full_vocab_sgd_uniform():
     free, _ = torch.cuda.mem_get_info()
     V = 10_000_000 if free > 90e9 else 1_000_000
     _run_deepfm(V, "sgd", "uniform", lr=1.0)
+
+
+def test_deepfm_bench_config_with_concat_buffer(monkeypatch):
+    """DR_NO_CONCAT=0: the round-2 data flow (the fused forward stores `concat`, the first-layer wgrad and K4's duplicate pass read
+    it) stays a supported switch -- same oracle assertions as the default (concat never built: gathering wgrad + row snapshot)."""
+    monkeypatch.setenv("DR_NO_CONCAT", "0")
+    eng, _ = _run_deepfm(1_000_000, "sgd", "uniform", lr=1.0)
+    assert not eng.no_concat
 
 
 def test_deepfm_bench_config_sgd_zipf():
