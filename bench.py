@@ -360,7 +360,8 @@ def main():
     # passes of this same command (profiles/, see `traffic_source`), only for the default configuration they were taken on
     traffic, traffic_source = {}, None
     try:
-        src = "profiles/r02_pmc_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) else "profiles/r01_pmc_traffic.json"
+        src = next(("profiles/%s_pmc_traffic.json" % r for r in ("r03", "r02", "r01")
+                    if os.path.exists(os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % r))), "profiles/r01_pmc_traffic.json")
         pmc = json.load(open(os.path.join(ROOT, src)))
         name_map = pmc.get("event_names") or {}
         default_cfg = (a.model, a.batch, a.fields, a.vocab, a.dim, a.dense, a.dnn, a.optimizer, a.gemm) == \

@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|FAILED|Error" | head -10 > gpurun_out/pytest_gpu.log
+timeout 1200 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|FAILED|Error" | head -10 > gpurun_out/pytest_gpu.log
 cat gpurun_out/pytest_gpu.log
 bash tools/collect_profiles.sh
 cd $R
@@ -15,9 +15,10 @@ timeout 200 python bench.py --preset c2 --no-cpu-baseline > gpurun_out/line_c2.l
 timeout 300 python bench.py --model dcn --no-cpu-baseline > gpurun_out/line_dcn.log 2>&1
 timeout 300 python bench.py --model dssm --no-cpu-baseline > gpurun_out/line_dssm.log 2>&1
 DR_FUSE_K3=0 DR_PREFETCH_PLAN=0 timeout 200 python bench.py --no-cpu-baseline > gpurun_out/line_unfused.log 2>&1
+DR_NO_CONCAT=0 timeout 200 python bench.py --no-cpu-baseline > gpurun_out/line_concat.log 2>&1
 DR_FORCE_SHARDED=1 timeout 200 python bench.py --no-cpu-baseline > gpurun_out/line_sharded_world1.log 2>&1
 timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-for f in default adam zipf c2 dcn dssm unfused sharded_world1; do
+for f in default adam zipf c2 dcn dssm unfused concat sharded_world1; do
   python - $f <<'PY'
 import json, sys
 try:

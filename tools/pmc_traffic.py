@@ -57,7 +57,7 @@ def main():
     event_names = {"emb_linear_fwd_L0": "bf3_emb_linear_kernel", "emb_pool_fwd": "emb_pool_fwd_sv_kernel<16,8>",
                    "emb_pool_bwd": "emb_bwd_sorted_kernel<16,4,false>", "hash_bucket_i64": "hash_bucket_i64_kernel",
                    "linear_fwd_L0": "bf3_gemm_rs_kernel<0,0>", "linear_bwd_dx_L0": "bf3_gemm_rs_kernel<0,0>",
-                   "linear_bwd_dw_L0": "bf3_gemm_tn_rs_kernel"}
+                   "linear_bwd_dw_L0": "bf3_gemm_tn_rs_kernel<1>"}
     json.dump({"_note": note, "kernels": kernels, "event_names": event_names}, open(out_path, "w"), indent=1, sort_keys=True)
     for k, v in kernels.items():
         print("%-60s %10.1f MB" % (k, v["hbm_bytes_corrected"] / 1e6))
