@@ -1376,8 +1376,11 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_tn_rs_kernel(TnRsArgs g) {
     const bool w_field = GATHER && c0w < 64 * g.nf;
     const bool w_dense = GATHER && !w_field && g.dense_pad != nullptr && c0w < 64 * g.nf + 32;
     // One raw buffer resource per wave (its field's rows / the dense features / a dummy): the address of a load is then ONE 32-bit
-    // VALU operation, id * 256 + column (a field is at most 2^24 rows = 4 GB, as in the fused forward), instead of 64-bit pointer
-    // arithmetic per lane and load -- the first version of this gather cost the kernel 53 us (342 -> 395).
+    // VALU operation, id * 256 + column (a field is below 2^24 rows = 4 GB, as in the fused forward), instead of 64-bit pointer
+    // arithmetic per lane and load.  The resource's range check does the masking: a missing id (-1) becomes offset 0xFFFFFF00 +
+    // column >= num_records and the hardware returns 0 -- no clamp, no select.  The 32 ids of a k-tile sit in the lanes so that
+    // DPP row_share:e hands every lane the id of ITS row e (lanes 0-31: rows 0-15 twice, lanes 32-63: rows 16-31 twice) -- one
+    // VALU move per load, no LDS shuffle.  (First cut: 64-bit pointers + ds_bpermute + clamp + select: +53 us on the kernel.)
     const float* gptr = g.table;
     unsigned gpitch = 0;                                                // bytes per source row
     const int32_t* idrow = nullptr;
@@ -1392,34 +1395,32 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_tn_rs_kernel(TnRsArgs g) {
             gpitch = 128;
         }
     }
-    const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gptr), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gptr), 0, (int)0xFFFFFF00u, 0x00020000);
     const unsigned gcol = (unsigned)l31 * 4u;
-    int idv = 0;                                                        // this lane's id of the k-tile whose rows are fetched next
-    int xmask = 0;                                                      // validity of xa[e] (row inside the slice, id present)
+    const int id_lane = (lane & 15) + 16 * hi;                          // the row of the k-tile whose id this lane keeps
+    int idv = 0;                                                        // ids of the k-tile whose rows are fetched next
+    int xmask = -1;                                                     // validity of xa[e] (partial k-tiles only)
     auto load_ids = [&](int64_t r0) -> int {
         if (!w_field) return 0;                                         // (wave-uniform)
-        const int64_t r = r0 + l31 < g.R ? r0 + l31 : g.R - 1;
+        const int64_t r = r0 + id_lane < g.R ? r0 + id_lane : g.R - 1;
         return idrow[r];
     };
     auto load_gather = [&](float (&dst)[16], int ids_of_tile, int64_t r0) {
-        int vm = 0;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int64_t r = r0 + 16 * hi + e;
-            const bool inr = r < r_end;
-            unsigned idx;
-            bool ok;
-            if (w_field) {                                              // lanes 0..31 hold the ids of rows r0 .. r0 + 31
-                const int id = __shfl(ids_of_tile, 16 * hi + e, 64);
-                ok = inr && id >= 0;
-                idx = (unsigned)(id > 0 ? id : 0);
-            } else {
-                ok = inr && w_dense;
-                idx = (unsigned)(inr ? r : r_end - 1);
-            }
-            dst[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grsrc, (int)(idx * gpitch + gcol), 0, 0));
-            vm |= (ok ? 1 : 0) << e;
+        const bool full = r0 + BK <= r_end;                             // (wave-uniform) all but a slice's last k-tile
+        int vm = -1;
+#define GATHER_ONE(E)                                                                                                   \
+        {                                                                                                                \
+            const int64_t r = r0 + 16 * hi + E;                                                                          \
+            unsigned idx;                                                                                                \
+            if (w_field) idx = (unsigned)__builtin_amdgcn_update_dpp(0, ids_of_tile, 0x150 + E, 0xf, 0xf, false);        \
+            else idx = (unsigned)(r < r_end ? r : r_end - 1);                                                            \
+            if (!full && !(r < r_end)) { idx = w_field ? 0x00FFFFFFu : idx; vm &= ~(1 << E); }                           \
+            dst[E] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grsrc, (int)(idx * gpitch + gcol), 0, 0)); \
         }
+        GATHER_ONE(0) GATHER_ONE(1) GATHER_ONE(2) GATHER_ONE(3) GATHER_ONE(4) GATHER_ONE(5) GATHER_ONE(6) GATHER_ONE(7)
+        GATHER_ONE(8) GATHER_ONE(9) GATHER_ONE(10) GATHER_ONE(11) GATHER_ONE(12) GATHER_ONE(13) GATHER_ONE(14) GATHER_ONE(15)
+#undef GATHER_ONE
+        if (!(w_field || w_dense)) vm = 0;                              // columns past F: zeros (their outputs are never read)
         xmask = vm;
     };
     bf16x8 fa[2][3];
@@ -1487,7 +1488,7 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_tn_rs_kernel(TnRsArgs g) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = (!GATHER || ((xmask >> (8 * s + j)) & 1)) ? xa[8 * s + j] : 0.f;
+                for (int j = 0; j < 8; ++j) v[j] = (!GATHER || xmask == -1 || ((xmask >> (8 * s + j)) & 1)) ? xa[8 * s + j] : 0.f;
                 rs_split8v(v, fa[s][0], fa[s][1], fa[s][2]);
             }
         }

@@ -162,7 +162,7 @@ class DeepFMEngine:
         # from a snapshot of those rows taken just before the update (dr_emb_snapshot_sorted_rows).  DR_NO_CONCAT=0: as round 2.
         self.no_concat = (_os.environ.get("DR_NO_CONCAT", "1") == "1" and self.fuse_k3 and self.wplanes[0] is not None
                           and self.wg_ws[0] is not None and sorted_bwd and self.acts[0] in (0, 1) and len(dnn_units) >= 1
-                          and not (self.fuse_head and len(self.Ws) == 2))
+                          and not (self.fuse_head and len(self.Ws) == 2) and V < (1 << 24) - 1)
         if self.no_concat:
             self._ids_t = [torch.empty((F, B), dtype=torch.int32, device=device) for _ in range(2)]
             self.x_sorted = torch.empty((B * F, D), dtype=torch.float32, device=device)

@@ -555,7 +555,8 @@ int dr_bf3_wgrad(const float* x, int64_t ld_x, const float* dy, int64_t ld_dy, i
                  dr_stream_t stream);
 /* dr_bf3_wgrad for the FIRST tower layer, x = concat(field embeddings, dense features) gathered from the tables instead of read from
  * a buffer (D = 64; F = in_dim in [64 nf, 64 nf + 32]): ids_t [nf][R] int32 field-major ids (dr_ids_transpose_i32, -1 = missing),
- * dense_pad [R, 32] zero-padded dense features (NULL iff F == 64 nf).  Same workspace as dr_bf3_wgrad(R, F, N).
+ * dense_pad [R, 32] zero-padded dense features (NULL iff F == 64 nf).  Same workspace as dr_bf3_wgrad(R, F, N).  Every field
+ * must have fewer than 2^24 - 1 rows (ids index a 4 GB raw buffer per field; -1 falls outside it and reads as zero).
  * Autodiff of the first Dense of keras/models/ranking/deepfm.py:30-34 w.r.t. its kernel, with deepfm.py:44-45's concat never built. */
 int dr_bf3_wgrad_emb(const int32_t* ids_t, int64_t R, int32_t nf, const int64_t* row_base, const float* table, int32_t D,
                      const float* dense_pad, const float* dy, int64_t ld_dy, int32_t F, int32_t N, float scale, float* dstW,
