@@ -140,6 +140,7 @@ class DeepFMEngine:
         self.loss = torch.zeros(1, **f32)
         self.ws = torch.empty(1024, **f32)
         self._events = None      # name -> [bound, work, [(start, end), ...]]
+        self._ev_every, self._ev_step, self._ev_live = 1, 0, False
         # ---- deterministic backward: slots sorted by table row on a side stream (depends only on ids) ----
         # Schedule experiments and their outcomes are recorded in DESIGN.md section 3 (sort started with K3 / in the backward /
         # on a high-priority stream, K4 overlapped with the first-layer wgrad, FM gradient folded into the dgrad epilogue):
@@ -270,11 +271,17 @@ class DeepFMEngine:
         self._pref = self._token(nk)
 
     # ---- per-kernel HIP events on the launch stream (bench.py's roofline numbers) ----------------------
-    def enable_kernel_events(self, on: bool):
+    def enable_kernel_events(self, on: bool, every: int = 1):
+        """Per-kernel HIP events on the launch stream.  every = n: only every n-th train_step is bracketed -- two event records per
+        kernel are two extra packets per kernel boundary, and at 12 kernels per 1.5 ms step that is no longer free (round 3: 1.56
+        ms with events on every step, 1.48 ms without, same box); bench.py samples every 4th step of the timed region."""
         self._events = {} if on else None
+        self._ev_every = max(1, int(every))
+        self._ev_step = 0
+        self._ev_live = bool(on)
 
     def _k(self, name, bound, work, fn):
-        if self._events is None:
+        if self._events is None or not self._ev_live:
             return fn()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
@@ -563,6 +570,9 @@ class DeepFMEngine:
         it; ShardedDeepFMEngine uses the same argument to route ahead): its K1 + slot sort then run beside this step's K4.
         next_dense (optional, with next_keys): that batch's dense features, placed into the input buffers at the same time."""
         self._next_keys, self._next_dense = next_keys, next_dense
+        if self._events is not None:
+            self._ev_live = (self._ev_step % self._ev_every) == 0
+            self._ev_step += 1
         self.forward(keys, dense, labels)
         self.backward_and_update()
         self._next_keys = self._next_dense = None
