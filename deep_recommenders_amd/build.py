@@ -16,8 +16,10 @@ HOST_SRC = os.path.join(HERE, "csrc_host")
 HOST_SO = os.path.join(LIBDIR, "libdr_input.so")          # host-side input boundary (include/dr_input.h), plain g++
 COLL_SRC = os.path.join(HERE, "csrc_coll")
 COLL_SO = os.path.join(LIBDIR, "libdr_collectives.so")    # exchange steps over RCCL (include/dr_collectives.h), host C++
+# -pragma-unroll-threshold: `#pragma unroll` means it (the register-split GEMM's epilogue over 2 x 8 accumulator tiles is larger than
+# the default limit; a loop-indexed accumulator array that is NOT unrolled lives in scratch memory)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
-         "-Wno-unused-function", "-Wno-unused-result"]
+         "-Wno-unused-function", "-Wno-unused-result", "-mllvm", "-pragma-unroll-threshold=131072"]
 
 
 def sources():

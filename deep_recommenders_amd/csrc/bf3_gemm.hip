@@ -534,13 +534,18 @@ __device__ __forceinline__ void rs_split8(const float4& lo, const float4& hi4, b
 
 // EPI: 0 = bias / ReLU, 1 = + ReLU' mask, 3 = accumulate (C +=), 2 = DCN cross combine, 4 = top-K filter (one epilogue per
 // instantiation: all of them unrolled over the 8 column tiles in one kernel cost 50 spilled registers)
-template <int EPI, int DBG = 0>
-__global__ __launch_bounds__(512, 2) void bf3_gemm_rs_kernel(RsArgs g) {
-    constexpr int NW = 8, BM = 32 * NW, BN = 256, NT = BN / 32, NS = 3;
+// MS: 32-row sets per wave.  1 = 8 waves x 32 rows (two waves per SIMD, 128 accumulator registers each); 2 = 4 waves x 64 rows (ONE
+// wave per SIMD with all 512 registers, 256 of them accumulators): every weight fragment read from the LDS feeds 12 MFMAs instead
+// of 6 and the ring's DMA pieces per MFMA stay the same, at the price of a single in-order instruction stream per SIMD.
+template <int EPI, int DBG = 0, int MS = 1>
+__global__ __launch_bounds__(512 / MS, MS == 1 ? 2 : 1) void bf3_gemm_rs_kernel(RsArgs g) {
+    constexpr int NW = 8 / MS, BM = 32 * MS * NW, BN = 256, NT = BN / 32, NS = 3;
     constexpr int B_PLANE = BN * 64;                                    // bytes: 256 rows x 64-byte rows (32 bf16)
     constexpr int STAGE = 3 * B_PLANE;                                  // 48 KB
-    constexpr int PW = STAGE / 1024 / NW;                               // 6 LDS-DMA pieces per wave and k-tile
-    static_assert(PW == 6, "piece schedule below assumes 6 pieces per wave and k-tile");
+    constexpr int PW = STAGE / 1024 / NW;                               // 6 MS LDS-DMA pieces per wave and k-tile
+    static_assert(PW == 6 * MS && (MS == 1 || MS == 2), "piece schedule below assumes 6 MS pieces per wave and k-tile");
+    constexpr int VM_STEP = 4 * MS + PW;                                // VMEM operations of one step (A loads + pieces)
+    constexpr int VM_WAIT_STEP = 0x0F70 | (VM_STEP & 15) | ((VM_STEP >> 4) << 14);   // s_waitcnt vmcnt(VM_STEP) (6-bit field, split)
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -555,7 +560,7 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_rs_kernel(RsArgs g) {
     // -- so every wave issues its pieces in groups 6..11, behind its own mid barrier -- and a wave has its pieces of step t + 1
     // landed before its mid barrier of step t (vmcnt(4): only this step's 4 activation loads are younger), which is the barrier
     // in front of the leading group's first read of that stage.  Bit-identical results; no gain measured (see rs_launch).
-    constexpr bool STG = (DBG & 16) != 0;
+    constexpr bool STG = (DBG & 16) != 0 && MS == 1;
     const int grp = STG ? (wave >> 2) : 0;
 
     const int tiles_n = (g.N + BN - 1) / BN;
@@ -581,7 +586,9 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_rs_kernel(RsArgs g) {
     // the buffer form is counted exactly (a register load followed by 6 pieces gets vmcnt(6)).
     const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<__bf16*>(g.B), 0, (int)min((int64_t)0x7fffffff, 3 * g.b_ps * 2), 0x00020000);
-    int bvoff[PW];                                                      // per-lane byte offset of piece i at k = 0
+    int bvoff[12];                                                      // per-lane byte offset of piece i < PW at k = 0 (arrays the
+                                                                        // lambdas capture have FIXED sizes: with a template-dependent size
+                                                                        // hipcc silently drops the kernel's host stub)
     int pb_tile = blockIdx.x, pb_kt = 0, pb_stage = 0, pb_koff = 0;     // pb_koff: byte offset along k of the next real step
     auto setup_b = [&](int tile) {
         const int n0 = (xcd_remap(tile, ntiles) % tiles_n) * BN;
@@ -618,27 +625,32 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_rs_kernel(RsArgs g) {
         }
     };
     // A: this lane's 16 floats of a k-tile
-    const float* asrc = nullptr;
+    const float* asrc[2];
     int pa_tile = blockIdx.x, pa_kt = 0;
     auto setup_a = [&](int tile) {
         const int64_t m0 = (int64_t)(xcd_remap(tile, ntiles) / tiles_n) * BM;
-        int64_t row = m0 + wave * 32 + l31;
-        row = row < g.M ? row : g.M - 1;                                // rows past the edge only feed unstored outputs
-        asrc = g.A + row * g.lda + 16 * hi;
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) {
+            int64_t row = m0 + wave * (32 * MS) + 32 * ms + l31;
+            row = row < g.M ? row : g.M - 1;                            // rows past the edge only feed unstored outputs
+            asrc[ms] = g.A + row * g.lda + 16 * hi;
+        }
     };
-    float4 an[4];                                                       // A of the NEXT step, in flight
+    float4 an[2][4];                                                    // A of the NEXT step, in flight
     const int kv4 = (g.K + 3) / 4 * 4;                                  // rows are readable up to here (lda % 4 == 0, lda >= K)
     int an_k0 = 0;                                                      // k index of an[0].x
     auto mask_a = [&]() {
         if (!ktail) return;                                             // kernel-uniform: K % 32 == 0 has nothing to zero
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = an_k0 + 4 * q;
-            an[q].x = k < g.K ? an[q].x : 0.f;
-            an[q].y = k + 1 < g.K ? an[q].y : 0.f;
-            an[q].z = k + 2 < g.K ? an[q].z : 0.f;
-            an[q].w = k + 3 < g.K ? an[q].w : 0.f;
-        }
+        for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = an_k0 + 4 * q;
+                an[ms][q].x = k < g.K ? an[ms][q].x : 0.f;
+                an[ms][q].y = k + 1 < g.K ? an[ms][q].y : 0.f;
+                an[ms][q].z = k + 2 < g.K ? an[ms][q].z : 0.f;
+                an[ms][q].w = k + 3 < g.K ? an[ms][q].w : 0.f;
+            }
     };
     auto load_a = [&](bool real) {
         // Every load unconditional (a load under a divergent branch makes hipcc's wait-count pass fall back to vmcnt(0), which
@@ -649,25 +661,33 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_rs_kernel(RsArgs g) {
         // here would wait for the loads on the spot.
         an_k0 = pa_kt * BK + 16 * hi;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int over = max(0, an_k0 + 4 * q - (kv4 - 4));
-            an[q] = *reinterpret_cast<const float4*>(asrc + 4 * q - over);
-        }
+        for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int over = max(0, an_k0 + 4 * q - (kv4 - 4));
+                an[ms][q] = *reinterpret_cast<const float4*>(asrc[ms] + 4 * q - over);
+            }
         if (!real) return;                                              // (uniform; no VMEM below)
-        if constexpr (!(DBG & 8)) asrc += BK;
+        if constexpr (!(DBG & 8)) {
+#pragma unroll
+            for (int ms = 0; ms < MS; ++ms) asrc[ms] += BK;
+        }
         if (++pa_kt == nk) {
             pa_kt = 0;
             pa_tile += gridDim.x;
             if (pa_tile < ntiles) setup_a(pa_tile);
-            else if constexpr (!(DBG & 8)) asrc -= (int64_t)nk * BK;    // end of the stream: the dummy loads re-read k-tile 0 of the
-                                                                        // last rows (pa_kt == 0, so `over` keeps them inside the row)
+            else if constexpr (!(DBG & 8)) {                            // end of the stream: the dummy loads re-read k-tile 0 of the
+#pragma unroll                                                          // last rows (pa_kt == 0, so `over` keeps them inside the row)
+                for (int ms = 0; ms < MS; ++ms) asrc[ms] -= (int64_t)nk * BK;
+            }
         }
     };
 
-    bf16x8 fa[2][3];                                                    // [k-step][plane] of the CURRENT step
+    bf16x8 fa[MS][2][3];                                                // [row set][k-step][plane] of the CURRENT step
     bf16x8 fb[4][3];                                                    // [buffer][plane]: group q uses buffer q & 3; the
                                                                         // reads run TWO groups (12 MFMAs) ahead of their use
     auto read_b = [&](int buf, int stage, int q) {                      // group q = (k-step q >> 3, column tile q & 7)
+        if constexpr (DBG & 32) return;                                 // ablation: no fragment reads (stale registers)
         const unsigned bb = b_addr[q >> 3] + stage * STAGE;
         const int nt = q & 7;
         // immediates must be literal: dispatch on the column tile
@@ -682,10 +702,11 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_rs_kernel(RsArgs g) {
 #undef RS_READ3
     };
     auto wait_b = [&](int buf, bool all) {   // group's fragments landed; `all`: every LDS read of this wave retired
+        if constexpr (DBG & 32) return;
         if (all) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[buf][0]), "+v"(fb[buf][1]), "+v"(fb[buf][2]));
         else asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fb[buf][0]), "+v"(fb[buf][1]), "+v"(fb[buf][2]));   // the next group's 3 may fly
     };
-    f32x16 acc[NT];
+    f32x16 acc[MS][NT];
     constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
 
     // ---- prologue: B steps 0 and 1, A step 0 ---------------------------------------------------------------------------------
@@ -698,7 +719,7 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_rs_kernel(RsArgs g) {
 #pragma unroll                                                          // loads on every path into the loop, as inside it
     for (int i = 0; i < PW; ++i) issue_b(i);
     if (total > 1) advance_b();
-    __builtin_amdgcn_s_waitcnt(0x0F70 | 10);                            // vmcnt(10): step 0's pieces landed
+    __builtin_amdgcn_s_waitcnt(VM_WAIT_STEP);                           // vmcnt(4 MS + PW): step 0's pieces landed
     asm volatile("s_barrier" ::: "memory");
     if (STG && grp) asm volatile("s_barrier" ::: "memory");             // the lagging group starts at the leading group's first mid barrier
     read_b(0, 0, 0);
@@ -706,14 +727,29 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_rs_kernel(RsArgs g) {
 
     int tile = blockIdx.x, kt = 0, stage = 0;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
-        for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
-    for (int step = 0; step < total; ++step) {
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[ms][t][k] = 0.f;
+    int step = 0;
+    for (; tile < ntiles; tile += gridDim.x) {
+    for (kt = 0; kt < nk; ++kt, ++step) {
         // ---- step start: A of this step -> bf16 terms (the compiler waits for the loads here), next step's A into flight ----
         mask_a();
-        rs_split8(an[0], an[1], fa[0][0], fa[0][1], fa[0][2]);
-        rs_split8(an[2], an[3], fa[1][0], fa[1][1], fa[1][2]);
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) {
+            if constexpr (DBG & 64) {                                   // ablation: no split (the loaded bits as operands)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        fa[ms][s2][pl] = __builtin_bit_cast(bf16x8, an[ms][2 * s2 + (pl & 1)]);
+            } else {
+                rs_split8(an[ms][0], an[ms][1], fa[ms][0][0], fa[ms][0][1], fa[ms][0][2]);
+                rs_split8(an[ms][2], an[ms][3], fa[ms][1][0], fa[ms][1][1], fa[ms][1][2]);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
         const bool has_a = step + 1 < total, has_b = step + 2 < total;
         load_a(has_a);
@@ -731,7 +767,7 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_rs_kernel(RsArgs g) {
             } else if (q == 14) {
                 // groups 14 and 15 are in registers and this wave is done reading stage `stage`; publish step + 1
                 wait_b(2, true);
-                __builtin_amdgcn_s_waitcnt(0x0F70 | 10);               // vmcnt(10): all but this step's 4 A loads + 6 pieces
+                __builtin_amdgcn_s_waitcnt(VM_WAIT_STEP);              // all but this step's 4 MS A loads + PW pieces
                 asm volatile("s_barrier" ::: "memory");
                 if (has_a) read_b(0, nstage, 0);
             } else {
@@ -739,29 +775,35 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_rs_kernel(RsArgs g) {
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (!(DBG & 2)) {
+                // (MS == 2: the two row sets' chains interleaved or one after the other -- fenced, or the machine scheduler re-interleaves
+                // them -- measure the same)
 #pragma unroll
                 for (int term = 0; term < 6; ++term)
-                    acc[q & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q >> 3][PA[term]], fb[q & 3][PB[term]], acc[q & 7], 0, 0, 0);
+#pragma unroll
+                    for (int ms = 0; ms < MS; ++ms)
+                        acc[ms][q & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ms][q >> 3][PA[term]], fb[q & 3][PB[term]],
+                                                                                 acc[ms][q & 7], 0, 0, 0);
             } else {
-                acc[q & 7][0] += (float)fa[q >> 3][0][0] + (float)fb[q & 3][0][0] + (float)fb[q & 3][1][0] + (float)fb[q & 3][2][0];
+                acc[0][q & 7][0] += (float)fa[0][q >> 3][0][0] + (float)fb[q & 3][0][0] + (float)fb[q & 3][1][0] + (float)fb[q & 3][2][0];
             }
             __builtin_amdgcn_sched_barrier(0);    // keeps the next group's lgkmcnt wait from being hoisted between these MFMAs
-            if (STG ? (q >= 6 && q < 6 + PW) : ((q & 1) == 1 && q < 2 * PW)) {
-                if constexpr (!(DBG & 1)) issue_b(STG ? q - 6 : q >> 1);
+            if (STG ? (q >= 6 && q < 6 + PW) : (MS == 2 ? q < PW : ((q & 1) == 1 && q < 2 * PW))) {
+                if constexpr (!(DBG & 1)) issue_b(STG ? q - 6 : (MS == 2 ? q : q >> 1));
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (has_b) advance_b();
         stage = nstage;
-        if (++kt < nk) continue;
+    }
         // ---- epilogue of an output tile: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-        kt = 0;
         {
             const int lid = xcd_remap(tile, ntiles);
             const int64_t tm0 = (int64_t)(lid / tiles_n) * BM;
             const int tn0 = (lid % tiles_n) * BN;
             const bool relu = g.act == 1;
-            const int64_t r0 = tm0 + wave * 32 + 4 * hi;
+#pragma unroll
+          for (int ms = 0; ms < MS; ++ms) {
+            const int64_t r0 = tm0 + wave * (32 * MS) + 32 * ms + 4 * hi;
             // interior tiles: every load / store of the epilogue unconditional (a memory operation under a divergent branch makes
             // hipcc wait vmcnt(0) in front of each one); edge tiles take the guarded loop
             const bool interior = tm0 + BM <= g.M && tn0 + BN <= g.N;
@@ -777,8 +819,8 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_rs_kernel(RsArgs g) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         const int col = tn0 + nt * 32 + l31;
-                        const float v = acc[nt][reg];
-                        acc[nt][reg] = 0.f;
+                        const float v = acc[ms][nt][reg];
+                        acc[ms][nt][reg] = 0.f;
                         const bool pass = rv && col < g.N && v > t;
                         const unsigned half = (unsigned)((__ballot(pass) >> (32 * hi)) & 0xffffffffull);
                         if (half != 0u) {
@@ -818,8 +860,8 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_rs_kernel(RsArgs g) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const int reg = 4 * c4 + e;
-                                const float pr = acc[nt][reg] + bj + g.diag * xv[e];
-                                acc[nt][reg] = 0.f;
+                                const float pr = acc[ms][nt][reg] + bj + g.diag * xv[e];
+                                acc[ms][nt][reg] = 0.f;
                                 if (g.prod_out != nullptr) g.prod_out[xo + (int64_t)(e + 8 * c4) * g.ldx] = pr;
                                 crow[(int64_t)(e + 8 * c4) * g.ldc] = fmaf(x0v[e], pr, xv[e]);
                             }
@@ -834,8 +876,8 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_rs_kernel(RsArgs g) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const int reg = 4 * c4 + e;
-                                float v = acc[nt][reg] + bj;
-                                acc[nt][reg] = 0.f;
+                                float v = acc[ms][nt][reg] + bj;
+                                acc[ms][nt][reg] = 0.f;
                                 v = relu ? fmaxf(v, 0.f) : v;
                                 crow[(int64_t)(e + 8 * c4) * g.ldc] = EPI == 1 ? (aux[e] > 0.f ? v : 0.f) : aux[e] + v;
                             }
@@ -843,8 +885,8 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_rs_kernel(RsArgs g) {
                     } else {
 #pragma unroll
                         for (int reg = 0; reg < 16; ++reg) {
-                            float v = acc[nt][reg] + bj;
-                            acc[nt][reg] = 0.f;
+                            float v = acc[ms][nt][reg] + bj;
+                            acc[ms][nt][reg] = 0.f;
                             crow[(int64_t)((reg & 3) + 8 * (reg >> 2)) * g.ldc] = relu ? fmaxf(v, 0.f) : v;
                         }
                     }
@@ -852,8 +894,8 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_rs_kernel(RsArgs g) {
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         const int64_t row = r0 + (reg & 3) + 8 * (reg >> 2);
-                        float v = acc[nt][reg] + bj;
-                        acc[nt][reg] = 0.f;
+                        float v = acc[ms][nt][reg] + bj;
+                        acc[ms][nt][reg] = 0.f;
                         if (!cv || row >= g.M) continue;
                         float* dst = g.C + row * g.ldc + col;
                         if constexpr (cross) {
@@ -874,14 +916,17 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_rs_kernel(RsArgs g) {
                         }
                     }
                 }
+                // MS == 2: all 256 accumulators live in AGPRs; without a fence per column tile the scheduler copies them out
+                // ahead of the stores and spills 265 registers
+                if constexpr (MS == 2) __builtin_amdgcn_sched_barrier(0);
             }
             }   // EPI != 4
+          }     // ms
             // Stores and loads share vmcnt on gfx9 and hipcc treats a mix of the two as unordered: left pending into the next
             // k-tile, the stores turn its wait for the A registers into vmcnt(0) on EVERY k-tile.  Draining here costs the
             // pipeline one refill per output tile instead.
             __builtin_amdgcn_s_waitcnt(0x0F70);
         }
-        tile += gridDim.x;
     }
     if (STG && !grp) asm volatile("s_barrier" ::: "memory");            // the leading group's extra barrier (see STG above)
 }
@@ -1845,6 +1890,32 @@ int rs_launch(const RsArgs& g, hipStream_t stream) {
     if (g.mask != nullptr && g.accumulate) return DR_EINVAL;            // (no caller needs both)
     if (g.tau != nullptr) {
         hipLaunchKernelGGL((bf3_gemm_rs_kernel<4>), dim3(grid), dim3(512), 0, stream, g);
+        DR_CHECK_LAUNCH();
+        return DR_OK;
+    }
+#ifdef DR_BF3_ABLATE
+    {   // ablations of the plain epilogue (tools/exp/rs64_bench.py): DR_BF3_RS_DBG = 32 no fragment reads, 64 no split, 96 both, 2 no MFMA
+        static const int dbg = [] { const char* e = getenv("DR_BF3_RS_DBG"); return e ? atoi(e) : 0; }();
+        static const bool ms2 = [] { const char* e = getenv("DR_BF3_RS64"); return e != nullptr && e[0] == '1'; }();
+        if (dbg != 0 && g.x0 == nullptr && g.mask == nullptr && !g.accumulate && g.tau == nullptr) {
+#define RS_ABL(D)                                                                                               \
+            if (dbg == D) {                                                                                     \
+                if (ms2) hipLaunchKernelGGL((bf3_gemm_rs_kernel<0, D, 2>), dim3(grid), dim3(256), 0, stream, g); \
+                else hipLaunchKernelGGL((bf3_gemm_rs_kernel<0, D, 1>), dim3(grid), dim3(512), 0, stream, g);     \
+                DR_CHECK_LAUNCH();                                                                              \
+                return DR_OK;                                                                                   \
+            }
+            RS_ABL(32) RS_ABL(64) RS_ABL(96) RS_ABL(2) RS_ABL(1)
+#undef RS_ABL
+        }
+    }
+#endif
+    // one 64-row wave per SIMD (MS = 2, see the kernel): DR_BF3_RS64=1
+    static const bool rs64 = [] { const char* e = getenv("DR_BF3_RS64"); return e != nullptr && e[0] == '1'; }();
+    if (rs64 && g.x0 == nullptr) {
+        if (g.mask != nullptr) hipLaunchKernelGGL((bf3_gemm_rs_kernel<1, 0, 2>), dim3(grid), dim3(256), 0, stream, g);
+        else if (g.accumulate) hipLaunchKernelGGL((bf3_gemm_rs_kernel<3, 0, 2>), dim3(grid), dim3(256), 0, stream, g);
+        else hipLaunchKernelGGL((bf3_gemm_rs_kernel<0, 0, 2>), dim3(grid), dim3(256), 0, stream, g);
         DR_CHECK_LAUNCH();
         return DR_OK;
     }

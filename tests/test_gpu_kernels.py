@@ -855,6 +855,46 @@ def test_bf3_linear_nt_matches_fp64(M, K, N):
     assert torch.equal(ops.bf3_linear_nt(xp[:, :K], wp.wt, bias=b, act=1), y)
 
 
+_RS64_SNIPPET = r"""
+import hashlib, sys, torch
+sys.path.insert(0, %r)
+from deep_recommenders_amd import ops
+h = hashlib.sha256()
+for (M, K, N) in [(1000, 300, 257), (2085, 1677, 256), (513, 32, 1677), (66000, 256, 300)]:
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    x = torch.randn((M, K), device="cuda", generator=g)
+    W = torch.randn((K, N), device="cuda", generator=g) * 0.1
+    b = torch.randn((N,), device="cuda", generator=g)
+    wp = ops.WeightPlanes(W)
+    y = ops.bf3_linear_nt(x, wp.wt, bias=b, act=1)
+    dy = torch.randn((M, N), device="cuda", generator=g) * 1e-2
+    below = torch.randn((M, K), device="cuda", generator=g)
+    dx = ops.bf3_linear_nt(dy, wp.w, mask=below)
+    acc = below.clone()
+    ops.bf3_linear_nt(dy, wp.w, accumulate=True, out=acc)
+    ref = torch.relu(x.double() @ W.double() + b.double())
+    assert ((y.double() - ref).abs().max() / ref.abs().max()).item() <= 3e-6
+    for t in (y, dx, acc):
+        h.update(t.contiguous().cpu().numpy().tobytes())
+print("DIGEST", h.hexdigest())
+"""
+
+
+def test_bf3_linear_nt_rs64_bit_identical():
+    """The register-split GEMM's 4-wave x 64-row shape (DR_BF3_RS64=1: one wave per SIMD, 256 accumulator registers; read once per
+    process) gives bit for bit what the default 8-wave x 32-row shape gives: forward, masked dgrad, accumulate; edge tiles, a
+    reduction tail, more than one tile per block."""
+    import os, subprocess, sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    out = []
+    for flag in ("0", "1"):
+        env = dict(os.environ, DR_BF3_RS64=flag)
+        r = subprocess.run([sys.executable, "-c", _RS64_SNIPPET % root], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1])
+    assert out[0] == out[1], out
+
+
 @pytest.mark.parametrize("M,F,Nd,N", [(300, 3, 0, 40), (2085, 26, 13, 256), (4096, 7, 5, 300), (257, 1, 2, 64),
                                       (70000, 2, 3, 64), (40001, 1, 0, 600)])
 def test_bf3_emb_linear_fwd_equals_pool_then_linear(M, F, Nd, N):
