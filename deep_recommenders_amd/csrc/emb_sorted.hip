@@ -10,6 +10,7 @@
 //
 // Replaces the autodiff of [TF] safe_embedding_lookup_sparse (IndexedSlices -> unsorted_segment_sum into the
 // variable) reached from optimizer.minimize (examples/train_fm_on_movielens_estimator.py:51-52, reference root).
+#include <cstdlib>
 #include "dr_common.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 #include <cstring>
@@ -166,7 +167,7 @@ __device__ __forceinline__ void emb_bwd_dups_body(const int bid, const int nblk,
                                                            const float* __restrict__ d_fm_logit,
                                                            const float* __restrict__ slot_lin, float scale,
                                                            float* __restrict__ table, float* __restrict__ lin_w, AdamArgs ad,
-                                                           const float* __restrict__ x_sorted) {
+                                                           float* x_sorted, const bool det) {
     // ADAM: the update is not linear in the gradient, so a row's slots must be summed completely before the one update:
     // the segment-start head walks the WHOLE segment (however long) and the aligned heads of hot rows do nothing.
     // One lane group (LPR lanes = one table row) per head.  The piece is walked in chunks of LPR sorted entries: the
@@ -284,6 +285,15 @@ __device__ __forceinline__ void emb_bwd_dups_body(const int bid, const int nblk,
                     *reinterpret_cast<float4*>(dst) = t;
                 }
                 if (lin_w != nullptr && any_lin && sub == 0) lin_w[k] = fmaf(scale, dls, lin_w[k]);
+            } else if (det) {
+                // a piece of a row hotter than CH slots, deterministic mode: park the piece's sum in ITS row of x_sorted (nobody
+                // else reads or writes x_sorted[i]; its snapshot was consumed above) -- emb_bwd_hot_apply_kernel, launched behind
+                // this kernel, adds a row's pieces in sorted order and updates the row (and its first-order weight) once
+                if (dvalid) *reinterpret_cast<float4*>(x_sorted + i * (int64_t)D + sub * 4) = g;
+                // the piece's first-order sum goes to the NEXT position's row, which no piece owns (positions inside a piece are
+                // not heads) -- unless the piece is a single slot, whose neighbour belongs to the next row: the apply kernel
+                // re-reads that one slot instead
+                if (any_lin && sub == 0 && j - i >= 2) x_sorted[(i + 1) * (int64_t)D] = dls;
             } else {
                 if (dvalid) {
                     unsafeAtomicAdd(dst + 0, scale * g.x); unsafeAtomicAdd(dst + 1, scale * g.y);
@@ -304,17 +314,129 @@ struct BwdSortedArgs {
     const float* grad; int64_t ld; const float* concat; int64_t ldc; const float* sum_x; const float* d_fm_logit;
     const float* slot_lin; float scale; float* table; float* lin_w; float* lin_bias;
     const uint64_t* rows; const int32_t* slots; int64_t n; const int32_t* dup_heads; const int32_t* dup_count; uint64_t num_rows;
-    const float* x_sorted;
+    float* x_sorted;
+    int det;                                     // SGD: hot rows' pieces park their sums in x_sorted (emb_bwd_hot_apply_kernel adds them)
 };
 template <int LPR, int U, bool ADAM>
 __global__ __launch_bounds__(256) void emb_bwd_sorted_kernel(BwdSortedArgs a, AdamArgs ad, int grid_d) {
     if ((int)blockIdx.x < grid_d)
         emb_bwd_dups_body<LPR, ADAM>(blockIdx.x, grid_d, a.rows, a.slots, a.n, a.dup_heads, a.dup_count, a.F, a.D, a.num_rows, a.grad,
-                                     a.ld, a.concat, a.ldc, a.sum_x, a.d_fm_logit, a.slot_lin, a.scale, a.table, a.lin_w, ad, a.x_sorted);
+                                     a.ld, a.concat, a.ldc, a.sum_x, a.d_fm_logit, a.slot_lin, a.scale, a.table, a.lin_w, ad, a.x_sorted,
+                                     a.det != 0);
     else
         emb_bwd_unique_body<LPR, U, ADAM>(blockIdx.x - grid_d, gridDim.x - grid_d, a.ids, a.flags, a.B, a.F, a.row_base, a.D, a.grad,
                                           a.ld, a.concat, a.ldc, a.sum_x, a.d_fm_logit, a.slot_lin, a.scale, a.table, a.lin_w,
                                           a.lin_bias, ad);
+}
+
+// Second half of the deterministic hot-row update (SGD with x_sorted given): for every row whose slots span more than one piece,
+// the pieces' parked sums -- x_sorted[i] of the segment start, then the CH-aligned positions behind it -- are added in a fixed
+// order, the row's first-order gradient is re-summed over its slots in a fixed order, and the row and its first-order weight
+// get ONE plain read-modify-write.  Same head list, same piece geometry as emb_bwd_dups_body.
+// Each lane screens one head (three dependent loads; uniform ids end here: no row has a second piece); a wave then takes the
+// hot segments its lanes found one at a time with all 64 lanes: the pieces are counted 64 at a time with a ballot, the NS lane
+// groups add contiguous runs of pieces (independent loads, four in flight) and are combined group 0 + 1 + 2 + ..., the
+// first-order sum strides the segment with 64 lanes and is reduced by a fixed butterfly.  (A first version walked each hot row
+// with one lane group and a loop-carried `rows[j] == k` test: 275 dependent round trips for the hottest row of a Zipf batch,
+// +300 us per step.)
+template <int LPR>
+__global__ __launch_bounds__(256) void emb_bwd_hot_apply_kernel(BwdSortedArgs a) {
+    constexpr int NS = DR_WAVE / LPR;
+    const int lane = threadIdx.x & 63, grp = lane / LPR, sub = lane % LPR;
+    const int D = a.D, F = a.F;
+    const bool dvalid = sub < (D >> 2);
+    const int subc = dvalid ? sub : (D >> 2) - 1;
+    const bool any_lin = a.lin_w != nullptr && (a.d_fm_logit != nullptr || a.slot_lin != nullptr);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nheads = a.dup_count[0], n = a.dup_count[1];
+    // 16 heads per wave and round, not 64: a wave works its hot segments off one after the other (8 - 12 dependent round trips
+    // each), and a Zipf batch has ~1 400 of them among 88 K heads -- spread thin, they run in parallel (75 -> 30 us)
+    constexpr int SCREEN = 16;
+    for (int64_t h0 = wave0 * SCREEN; h0 < nheads; h0 += nwaves * SCREEN) {      // (wave-uniform loop)
+        const int64_t h = h0 + lane;
+        int64_t my_i = 0, my_stop = 0;
+        bool hot = false;
+        if (lane < SCREEN && h < nheads) {
+            my_i = a.dup_heads[h];
+            const uint64_t k = a.rows[my_i];
+            const bool seg_start = (my_i == 0) || (a.rows[my_i - 1] != k);
+            my_stop = ((my_i % CH) == 0) ? my_i + CH : ((my_i + CH - 1) / CH + 1) * CH;
+            hot = seg_start && my_stop < n && a.rows[my_stop] == k;       // owner of a row with more than one piece
+        }
+        uint64_t todo = __ballot(hot);
+        while (todo != 0ull) {
+            const int src = __ffsll((unsigned long long)todo) - 1;
+            todo &= todo - 1ull;
+            const int64_t i = __shfl(my_i, src, 64), stop = __shfl(my_stop, src, 64);
+            const uint64_t k = a.rows[i];
+            // pieces behind the first: aligned positions stop, stop + CH, ... while they still hold k
+            int64_t np = 0;
+            for (;;) {
+                const int64_t pos = stop + (np + lane) * CH;
+                const bool ok = pos < n && a.rows[pos < n ? pos : n - 1] == k;
+                const uint64_t m = __ballot(ok);
+                const int c = m == ~0ull ? 64 : (__ffsll((unsigned long long)~m) - 1);
+                np += c;
+                if (c < 64) break;
+            }
+            // end of the segment: inside the last piece
+            const int64_t lp = stop + (np - 1) * CH;
+            int64_t e;
+            {
+                const int64_t pos = lp + lane;
+                const bool ok = lane < CH && pos < n && a.rows[pos < n ? pos : n - 1] == k;
+                const uint64_t m = __ballot(ok);
+                e = lp + (__ffsll((unsigned long long)~m) - 1);           // (CH <= 32 < 64: ~m is never 0)
+            }
+            // parked sums: piece 0 at i, piece q >= 1 at stop + (q - 1) CH; lane group grp adds pieces [grp * per, (grp + 1) * per)
+            const int64_t P = np + 1, per = (P + NS - 1) / NS;
+            const int64_t q0 = grp * per, q1 = (q0 + per < P) ? q0 + per : P;
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int64_t q = q0; q < q1; q += 4) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t qq = (q + u < q1) ? q + u : q1 - 1;
+                    const int64_t pos = qq == 0 ? i : stop + (qq - 1) * CH;
+                    v[u] = *reinterpret_cast<const float4*>(a.x_sorted + pos * (int64_t)D + subc * 4);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (q + u < q1) { g.x += v[u].x; g.y += v[u].y; g.z += v[u].z; g.w += v[u].w; }
+            }
+#pragma unroll
+            for (int o = 1; o < NS; ++o) {                                 // group 0 collects: ((g0 + g1) + g2) + ...
+                const float ox = __shfl(g.x, sub + o * LPR, 64), oy = __shfl(g.y, sub + o * LPR, 64);
+                const float oz = __shfl(g.z, sub + o * LPR, 64), ow = __shfl(g.w, sub + o * LPR, 64);
+                if (grp == 0) { g.x += ox; g.y += oy; g.z += oz; g.w += ow; }
+            }
+            if (grp == 0 && dvalid) {
+                float* dst = a.table + k * (uint64_t)D + sub * 4;
+                float4 t = *reinterpret_cast<const float4*>(dst);
+                t.x = fmaf(a.scale, g.x, t.x); t.y = fmaf(a.scale, g.y, t.y);
+                t.z = fmaf(a.scale, g.z, t.z); t.w = fmaf(a.scale, g.w, t.w);
+                *reinterpret_cast<float4*>(dst) = t;
+            }
+            if (any_lin) {
+                // first-order sums of the pieces: parked at the row behind each piece's own (single-slot last piece: recomputed)
+                float dls = 0.f;
+                for (int64_t q = lane; q < P; q += 64) {
+                    const int64_t pos = q == 0 ? i : stop + (q - 1) * CH;
+                    const bool single = q == P - 1 && e - pos < 2;
+                    float v = a.x_sorted[(single ? pos : pos + 1) * (int64_t)D];
+                    if (single) {
+                        const int32_t sp = a.slots[pos];
+                        v = a.slot_lin != nullptr ? a.slot_lin[sp] : a.d_fm_logit[sp / F];
+                    }
+                    dls += v;
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) dls += __shfl_xor(dls, off, 64);
+                if (lane == 0) a.lin_w[k] = fmaf(a.scale, dls, a.lin_w[k]);
+            }
+        }
+    }
 }
 
 }  // namespace
@@ -324,7 +446,8 @@ static int bwd_sorted_impl(const int64_t* ids, const int64_t* row_base, const in
                            const int32_t* dup_count, int64_t B, int32_t F, int32_t D, int64_t num_rows, const float* grad,
                            int64_t ld_grad, const float* concat, int64_t ld_concat, const float* sum_x,
                            const float* d_fm_logit, const float* slot_lin_grad, float scale, float* dst_table,
-                           float* dst_lin, float* dst_bias, const AdamArgs* adam, const float* x_sorted, dr_stream_t stream) {
+                           float* dst_lin, float* dst_bias, const AdamArgs* adam, float* x_sorted, dr_stream_t stream,
+                           int parts = 3) {
     if (B < 0 || F <= 0 || F > 64 || D < 4 || D > 256 || (D & 3) || num_rows <= 0) return DR_EINVAL;
     const int64_t n = B * F;
     if (n == 0) return DR_OK;
@@ -343,9 +466,12 @@ static int bwd_sorted_impl(const int64_t* ids, const int64_t* row_base, const in
                                 // blocks exit at once), skewed ids fill it
     AdamArgs ad{};
     if (adam != nullptr) ad = *adam;
+    // hot rows deterministic whenever the scratch rows exist (DR_K4_DETERMINISTIC=0: fp32 atomics as without x_sorted)
+    static const bool det_on = [] { const char* e = getenv("DR_K4_DETERMINISTIC"); return !(e != nullptr && e[0] == '0'); }();
+    const int det = (adam == nullptr && x_sorted != nullptr && det_on) ? 1 : 0;
     const BwdSortedArgs ba{ids, unique_flags, B, F, row_base, D, grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit, slot_lin_grad,
                            scale, dst_table, dst_lin, dst_bias, rows, sorted_slots, n, dup_heads, dup_count, (uint64_t)num_rows,
-                           x_sorted};
+                           x_sorted, det};
 #define LAUNCH(L, ADAM_)                                                                                              \
     {                                                                                                                 \
         constexpr int NS_ = 64 / L;                                                                                   \
@@ -355,6 +481,7 @@ static int bwd_sorted_impl(const int64_t* ids, const int64_t* row_base, const in
     }
 #define CALL(L)                                                                                                       \
     if (adam != nullptr) LAUNCH(L, true) else LAUNCH(L, false)
+    if (parts & 1)
     switch (lpr) {
         case 1: CALL(1); break;
         case 2: CALL(2); break;
@@ -368,6 +495,22 @@ static int bwd_sorted_impl(const int64_t* ids, const int64_t* row_base, const in
 #undef CALL
 #undef LAUNCH
     DR_CHECK_LAUNCH();
+    if (det && (parts & 2)) {
+        // deterministic hot rows: the pieces parked their sums in x_sorted, their owners add them up now (nothing to do when no row
+        // has more than CH slots: the kernel scans the head list and exits)
+#define HOT(L) hipLaunchKernelGGL((emb_bwd_hot_apply_kernel<L>), dim3(1024), dim3(256), 0, dr_s(stream), ba)
+        switch (lpr) {
+            case 1: HOT(1); break;
+            case 2: HOT(2); break;
+            case 4: HOT(4); break;
+            case 8: HOT(8); break;
+            case 16: HOT(16); break;
+            case 32: HOT(32); break;
+            default: HOT(64); break;
+        }
+#undef HOT
+        DR_CHECK_LAUNCH();
+    }
     return DR_OK;
 }
 
@@ -377,11 +520,28 @@ extern "C" int dr_emb_pool_bwd_sorted(const int64_t* ids, const int64_t* row_bas
                                       int32_t D, int64_t num_rows, const float* grad, int64_t ld_grad,
                                       const float* concat, int64_t ld_concat, const float* sum_x,
                                       const float* d_fm_logit, const float* slot_lin_grad, float scale,
-                                      float* dst_table, float* dst_lin, float* dst_bias, const float* x_sorted,
+                                      float* dst_table, float* dst_lin, float* dst_bias, float* x_sorted,
                                       dr_stream_t stream) {
     return bwd_sorted_impl(ids, row_base, sorted_rows, sorted_slots, unique_flags, dup_heads, dup_count, B, F, D, num_rows,
                            grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit, slot_lin_grad, scale, dst_table, dst_lin,
                            dst_bias, nullptr, x_sorted, stream);
+}
+
+// The same call in two halves, for callers that time (or overlap) them separately: parts = 1 the update kernel, parts = 2 the ordered
+// combination of hot rows' parked pieces (a no-op without x_sorted or with DR_K4_DETERMINISTIC=0), parts = 3 both = the call above.
+// A caller that runs part 1 MUST run part 2 on the same stream before anything reads the tables.
+extern "C" int dr_emb_pool_bwd_sorted_parts(const int64_t* ids, const int64_t* row_base, const int64_t* sorted_rows,
+                                            const int32_t* sorted_slots, const uint8_t* unique_flags,
+                                            const int32_t* dup_heads, const int32_t* dup_count, int64_t B, int32_t F,
+                                            int32_t D, int64_t num_rows, const float* grad, int64_t ld_grad,
+                                            const float* concat, int64_t ld_concat, const float* sum_x,
+                                            const float* d_fm_logit, const float* slot_lin_grad, float scale,
+                                            float* dst_table, float* dst_lin, float* dst_bias, float* x_sorted,
+                                            int32_t parts, dr_stream_t stream) {
+    if (parts < 1 || parts > 3) return DR_EINVAL;
+    return bwd_sorted_impl(ids, row_base, sorted_rows, sorted_slots, unique_flags, dup_heads, dup_count, B, F, D, num_rows,
+                           grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit, slot_lin_grad, scale, dst_table, dst_lin,
+                           dst_bias, nullptr, x_sorted, stream, parts);
 }
 
 // x_sorted[i, :] = table[sorted_rows[i], :] for every position i on the duplicate pass's work list (dup_heads[0 .. dup_count[0])):
@@ -431,7 +591,7 @@ extern "C" int dr_emb_pool_bwd_sorted_adam(const int64_t* ids, const int64_t* ro
                                            const float* concat, int64_t ld_concat, const float* sum_x,
                                            const float* d_fm_logit, const float* slot_lin_grad, float lr_t, float beta1,
                                            float beta2, float eps, float* table, float* m_table, float* v_table,
-                                           float* lin_w, float* m_lin, float* v_lin, const float* x_sorted, dr_stream_t stream) {
+                                           float* lin_w, float* m_lin, float* v_lin, float* x_sorted, dr_stream_t stream) {
     if (!m_table || !v_table) return DR_EINVAL;
     if (lin_w != nullptr && (!m_lin || !v_lin)) return DR_EINVAL;
     AdamArgs ad{m_table, v_table, m_lin, v_lin, lr_t, beta1, beta2, eps};

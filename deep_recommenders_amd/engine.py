@@ -496,11 +496,13 @@ class DeepFMEngine:
             if self.no_concat:     # x of the slots that share rows, before the update touches them (11 K rows for uniform ids)
                 ops.emb_snapshot_sorted_rows(self.plan, self.table, self.R, self.x_sorted)
             mark = self._prefetch_mark()
-            self._k("emb_pool_bwd", "hbm", self.alg_bytes_bwd(),                                      # K4 (sorted)
-                    lambda: ops.emb_pool_bwd_sorted(self.ids, self.row_base, self.plan, D, self.R, self.d_concat, self.d_logit,
-                                                    -lr, self.table, self.lin_w, self.lin_bias,
-                                                    concat=None if self.no_concat else self.concat, sum_x=self.sum_x,
-                                                    x_sorted=self.x_sorted if self.no_concat else None))
+            k4 = lambda parts: ops.emb_pool_bwd_sorted(self.ids, self.row_base, self.plan, D, self.R, self.d_concat, self.d_logit,
+                                                       -lr, self.table, self.lin_w, self.lin_bias,
+                                                       concat=None if self.no_concat else self.concat, sum_x=self.sum_x,
+                                                       x_sorted=self.x_sorted if self.no_concat else None, parts=parts)
+            self._k("emb_pool_bwd", "hbm", self.alg_bytes_bwd(), lambda: k4(1))                       # K4 (sorted)
+            if self.no_concat:     # rows hit > 32 times: their parked pieces added in sorted order (a scan of the head list otherwise)
+                self._k("emb_hot_rows_apply", "hbm", 0, lambda: k4(2))
             self._prefetch_issue(mark)
         else:
             self._k("emb_pool_bwd", "hbm", self.alg_bytes_bwd(),                                      # K4 (atomics)

@@ -489,16 +489,22 @@ def ids_transpose_i32(ids, out=None):
 
 
 def emb_pool_bwd_sorted(ids, row_base, plan, D, num_rows, grad, d_fm_logit, scale, dst_table, dst_lin=None, dst_bias=None,
-                        concat=None, sum_x=None, slot_lin_grad=None, x_sorted=None):
+                        concat=None, sum_x=None, slot_lin_grad=None, x_sorted=None, parts=3):
+    """K4 on the slot plan.  x_sorted ([B * F, D] scratch; with the FM term and no `concat` it must hold the snapshot of
+    emb_snapshot_sorted_rows) also makes the update of rows hit more than 32 times deterministic: it is clobbered.  parts: 1 = the
+    update kernel, 2 = the ordered combination of hot rows' parked pieces, 3 = both (dr_emb_pool_bwd_sorted[_parts])."""
     ids = _c(ids, torch.int64)
     B, F = ids.shape
     assert grad.stride(1) == 1
-    check(lib().dr_emb_pool_bwd_sorted(ptr(ids), ptr(row_base), ptr(plan.rows), ptr(plan.slots), ptr(plan.flags),
-                                       ptr(plan.dup_heads), ptr(plan.dup_count), B, F, D, int(num_rows), ptr(grad),
-                                       grad.stride(0), ptr(concat), concat.stride(0) if concat is not None else 0,
-                                       ptr(sum_x), ptr(d_fm_logit), ptr(slot_lin_grad), float(scale), ptr(dst_table), ptr(dst_lin),
-                                       ptr(dst_bias), ptr(x_sorted),
-                                       stream_ptr()), "dr_emb_pool_bwd_sorted")
+    args = (ptr(ids), ptr(row_base), ptr(plan.rows), ptr(plan.slots), ptr(plan.flags),
+            ptr(plan.dup_heads), ptr(plan.dup_count), B, F, D, int(num_rows), ptr(grad),
+            grad.stride(0), ptr(concat), concat.stride(0) if concat is not None else 0,
+            ptr(sum_x), ptr(d_fm_logit), ptr(slot_lin_grad), float(scale), ptr(dst_table), ptr(dst_lin),
+            ptr(dst_bias), ptr(x_sorted))
+    if parts == 3:
+        check(lib().dr_emb_pool_bwd_sorted(*args, stream_ptr()), "dr_emb_pool_bwd_sorted")
+    else:
+        check(lib().dr_emb_pool_bwd_sorted_parts(*args, int(parts), stream_ptr()), "dr_emb_pool_bwd_sorted_parts")
 
 
 def adam_lr_t(lr, beta1, beta2, step):

@@ -184,12 +184,28 @@ int dr_emb_pool_bwd_sorted(const int64_t* ids, const int64_t* row_base, const in
                            int32_t D, int64_t num_rows, const float* grad, int64_t ld_grad,
                            const float* concat, int64_t ld_concat, const float* sum_x,
                            const float* d_fm_logit, const float* slot_lin_grad, float scale,
-                           float* dst_table, float* dst_lin, float* dst_bias, const float* x_sorted, dr_stream_t stream);
+                           float* dst_table, float* dst_lin, float* dst_bias, float* x_sorted, dr_stream_t stream);
 /* The FM term (sum_x, d_fm_logit given) needs x[b, f, :] of every slot: for a slot that owns its row it is the row's own value
  * (read by the update anyway); for slots that SHARE a row it comes from `concat` if the forward stored it, else from
  * x_sorted [B * F, D], where dr_emb_snapshot_sorted_rows has placed -- before the update starts -- the row of every work-list
  * head at the head's sorted position (one row per piece of a shared row: 5.6 K rows for uniform ids at config 3)
- * (round 3: the fused first layer no longer stores concat, the wgrad gathers its operand from the tables -- dr_bf3_wgrad_emb). */
+ * (round 3: the fused first layer no longer stores concat, the wgrad gathers its operand from the tables -- dr_bf3_wgrad_emb).
+ * x_sorted also makes the SGD update of HOT rows (more than 32 slots of the batch, cut into pieces of 32 that run in parallel)
+ * deterministic: with x_sorted == NULL the pieces combine with fp32 atomics (order-dependent rounding); with x_sorted given each
+ * piece parks its sum in its own row of x_sorted (overwriting the snapshot it has consumed) and a second small launch inside
+ * the call adds a row's pieces in sorted order and updates the row once -- the same batch then gives the same bits, whatever
+ * the id distribution.  (The Adam variant always sums a row's slots in one lane group and never used atomics.) */
+/* dr_emb_pool_bwd_sorted in two halves (parts: 1 = the update kernel, 2 = the ordered combination of hot rows' parked pieces, 3 =
+ * both = dr_emb_pool_bwd_sorted): for callers that time or overlap the halves separately.  Part 2 must follow part 1 on the same
+ * stream before the tables are read; it is a no-op without x_sorted. */
+int dr_emb_pool_bwd_sorted_parts(const int64_t* ids, const int64_t* row_base, const int64_t* sorted_rows,
+                                 const int32_t* sorted_slots, const uint8_t* unique_flags,
+                                 const int32_t* dup_heads, const int32_t* dup_count, int64_t B, int32_t F,
+                                 int32_t D, int64_t num_rows, const float* grad, int64_t ld_grad,
+                                 const float* concat, int64_t ld_concat, const float* sum_x,
+                                 const float* d_fm_logit, const float* slot_lin_grad, float scale,
+                                 float* dst_table, float* dst_lin, float* dst_bias, float* x_sorted, int32_t parts,
+                                 dr_stream_t stream);
 int dr_emb_snapshot_sorted_rows(const int64_t* sorted_rows, const int32_t* dup_heads, const int32_t* dup_count,
                                 const float* table, int32_t D, int64_t num_rows, float* x_sorted, dr_stream_t stream);
 
@@ -209,7 +225,7 @@ int dr_emb_pool_bwd_sorted_adam(const int64_t* ids, const int64_t* row_base, con
                                 const float* concat, int64_t ld_concat, const float* sum_x,
                                 const float* d_fm_logit, const float* slot_lin_grad, float lr_t, float beta1,
                                 float beta2, float eps, float* table, float* m_table, float* v_table,
-                                float* lin_w, float* m_lin, float* v_lin, const float* x_sorted, dr_stream_t stream);
+                                float* lin_w, float* m_lin, float* v_lin, float* x_sorted, dr_stream_t stream);
 /* Dense Adam step (same formula) over a flat parameter buffer; grad is multiplied by grad_scale first. */
 /* TF's NON-lazy sparse Adam, evaluated lazily (examples/train_fm_on_movielens_estimator.py:51-52: tf.train.AdamOptimizer decays
  * m / v of the WHOLE variable and moves every row on every step).  row_step[R] int32 (zero-initialised) counts

@@ -272,12 +272,14 @@ def test_deepfm_bench_config_adam(kind):
     _run_deepfm(1_000_000, "adam", kind, lr=0.01)
 
 
-def test_deepfm_zipf_step_is_reproducible_up_to_the_hot_row_pieces():
-    """Run-to-run reproducibility of one SGD step on Zipf keys.  Everything in the step is fixed-order EXCEPT two
-    documented places: rows hit by more than 32 slots are summed in 32-slot pieces that combine with fp32 atomics
-    (csrc/emb_sorted.hip), and the first layer's bias gradient.  So: rows hit <= 32 times (and their first-order weights) must be
-    BIT-identical between two runs from identical state; hotter rows may differ by summation order only -- bounded here by
-    1e-3 of the update's scale."""
+@pytest.mark.parametrize("no_concat", ["1", "0"])
+def test_deepfm_zipf_step_is_reproducible(no_concat, monkeypatch):
+    """Run-to-run reproducibility of one SGD step on Zipf keys.  Default data flow (concat never built, K4 gets
+    the x_sorted snapshot buffer): rows hit by more than 32 slots are summed in 32-slot pieces that PARK their sums and are added in
+    sorted order by emb_bwd_hot_apply_kernel -- every table row and first-order weight must be BIT-identical between two runs from
+    identical state, hot rows included.  DR_NO_CONCAT=0 (no x_sorted): the pieces combine with fp32 atomics, so rows hit <= 32
+    times must be bit-identical and hotter rows may differ by summation order only (bounded by 1e-3 of the update's scale)."""
+    monkeypatch.setenv("DR_NO_CONCAT", no_concat)
     V = 1_000_000
     batches = _batches(1, "zipf", seed=77)
     keys, dense, labels = batches[0]
@@ -288,17 +290,23 @@ def test_deepfm_zipf_step_is_reproducible_up_to_the_hot_row_pieces():
     outs = []
     for _ in range(2):
         eng = _make_engine(V, "sgd", 1.0)
+        assert eng.no_concat == (no_concat == "1")
         t0 = eng.table[hot].clone()
+        l0 = eng.lin_w[hot].clone()
         eng.train_step(keys, dense, labels)
         torch.cuda.synchronize()
-        outs.append((eng.table[cool].clone(), eng.lin_w[cool].clone(), eng.table[hot].clone(), t0))
+        outs.append((eng.table[cool].clone(), eng.lin_w[cool].clone(), eng.table[hot].clone(), t0, eng.lin_w[hot].clone(), l0))
         del eng
         torch.cuda.empty_cache()
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), "a row hit <= 32 times is not bit-reproducible"
     upd = (outs[0][2] - outs[0][3]).abs().max().item()
-    assert upd > 0
-    # (first seen: 1.8e-7 on an update of 2.7e-3 -- a few ulps of the row's value, the re-association of 32-slot pieces)
-    assert (outs[0][2] - outs[1][2]).abs().max().item() <= 1e-3 * upd + 1e-6
+    assert upd > 0 and (outs[0][4] - outs[0][5]).abs().max().item() > 0
+    if no_concat == "1":
+        assert torch.equal(outs[0][2], outs[1][2]), "a hot row is not bit-reproducible"
+        assert torch.equal(outs[0][4], outs[1][4]), "a hot row's first-order weight is not bit-reproducible"
+    else:
+        # (first seen: 1.8e-7 on an update of 2.7e-3 -- a few ulps of the row's value, the re-association of 32-slot pieces)
+        assert (outs[0][2] - outs[1][2]).abs().max().item() <= 1e-3 * upd + 1e-6
 
 
 def test_deepfm_bench_config_overlap_on_off_agree():

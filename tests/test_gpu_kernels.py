@@ -556,6 +556,18 @@ def _emb_bwd_sorted_case(ops, D, F, V, hot, path):
     if not hot:     # no row is hit by more than 32 slots -> plain RMW everywhere -> bit-reproducible
         np.testing.assert_array_equal(outs[0][0], outs[1][0])
         np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    # with the x_sorted buffer the pieces of a hot row park their sums and are added in sorted order: bit-reproducible ALWAYS
+    # (the buffer's content is don't-care here -- no FM term -- so it starts as NaN: nothing unwritten may be read)
+    outs = []
+    for _ in range(2):
+        t_dev, l_dev, b_dev = _dev(table).clone(), _dev(lin).clone(), torch.zeros(1, device="cuda")
+        xs = torch.full((B * F, D), float("nan"), device="cuda")
+        ops.emb_pool_bwd_sorted(d_ids, d_rb, plan, D, R, _dev(grad), _dev(dl), -0.1, t_dev, l_dev, b_dev, x_sorted=xs)
+        outs.append((t_dev.cpu().numpy(), l_dev.cpu().numpy(), b_dev.item()))
+    np.testing.assert_allclose(outs[0][0], want_t, rtol=1e-5, atol=tol)
+    np.testing.assert_allclose(outs[0][1], want_l, rtol=1e-5, atol=tol)
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
 
 
 @pytest.mark.parametrize("D,F,V,hot", [(64, 26, 5000, False), (16, 7, 50, True), (12, 5, 1000, False)])
@@ -660,10 +672,14 @@ def test_linear_bwd_dx_fm_epilogue(ops):
     np.testing.assert_allclose(out[:, :K].cpu().numpy(), want, rtol=0, atol=2e-5 * (np.abs(want).max() + 1))
 
 
-def test_emb_bwd_sorted_with_fm_term_equals_atomic_kernel(ops):
+@pytest.mark.parametrize("hot", [False, True])
+def test_emb_bwd_sorted_with_fm_term_equals_atomic_kernel(ops, hot):
     rng = np.random.default_rng(23)
     B, F, D, V = 900, 9, 32, 400
     ids = rng.integers(0, V, size=(B, F))
+    if hot:
+        ids[:, 2] = 7                                   # one row shared by every example: 29 pieces of 32 slots
+        ids[::3, 5] = 11                                # and one hit 300 times
     ids[rng.random((B, F)) < 0.05] = -1
     row_base = (np.arange(F) * V).astype(np.int64)
     R = F * V
@@ -680,9 +696,23 @@ def test_emb_bwd_sorted_with_fm_term_equals_atomic_kernel(ops):
     srows, sslots, flags = plan.rows, plan.slots, plan.flags
     t2, l2, b2 = _dev(table).clone(), _dev(lin).clone(), torch.zeros(1, device="cuda")
     ops.emb_pool_bwd_sorted(d_ids, d_rb, plan, D, R, d_concat, dl, -0.2, t2, l2, b2, concat=concat, sum_x=sum_x)
-    np.testing.assert_allclose(t2.cpu().numpy(), t1.cpu().numpy(), rtol=1e-5, atol=1e-5)
-    np.testing.assert_allclose(l2.cpu().numpy(), l1.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    atol = 1e-5 * (B if hot else 1)
+    np.testing.assert_allclose(t2.cpu().numpy(), t1.cpu().numpy(), rtol=1e-5, atol=atol)
+    np.testing.assert_allclose(l2.cpu().numpy(), l1.cpu().numpy(), rtol=1e-5, atol=atol)
     assert abs(b1.item() - b2.item()) < 1e-3
+    # concat never built: x of the shared-row slots from the snapshot taken before the update; hot rows' pieces parked in the same
+    # buffer and applied in order -- same result, bit-identical run to run
+    res = []
+    for _ in range(2):
+        t3, l3, b3 = _dev(table).clone(), _dev(lin).clone(), torch.zeros(1, device="cuda")
+        xs = torch.full((B * F, D), float("nan"), device="cuda")
+        ops.emb_snapshot_sorted_rows(plan, t3, R, xs)
+        ops.emb_pool_bwd_sorted(d_ids, d_rb, plan, D, R, d_concat, dl, -0.2, t3, l3, b3, sum_x=sum_x, x_sorted=xs)
+        res.append((t3.cpu().numpy(), l3.cpu().numpy()))
+    np.testing.assert_allclose(res[0][0], t1.cpu().numpy(), rtol=1e-5, atol=atol)
+    np.testing.assert_allclose(res[0][1], l1.cpu().numpy(), rtol=1e-5, atol=atol)
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    np.testing.assert_array_equal(res[0][1], res[1][1])
 
 
 # ---------------------------------------------------------------- GEMM product modes
