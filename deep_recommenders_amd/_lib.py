@@ -58,6 +58,7 @@ SIGNATURES = {
                                _p, _p, _p],
     "dr_emb_pool_bwd_sorted_parts": [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _i64, _p, _i64, _p, _p, _p, _f32, _p, _p,
                                      _p, _p, _i32, _p],
+    "dr_emb_lin_update_unique": [_p, _p, _i64, _i32, _p, _p, _p, _f32, _p, _p],
     "dr_emb_snapshot_sorted_rows": [_p, _p, _p, _p, _i32, _i64, _p, _p],
     "dr_ids_transpose_i32": [_p, _i64, _i32, _p, _p],
     "dr_linear_bwd_dx_fm": [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _i64, _i32, _i32, _p, _i64, _p],

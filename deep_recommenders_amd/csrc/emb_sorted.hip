@@ -316,6 +316,7 @@ struct BwdSortedArgs {
     const uint64_t* rows; const int32_t* slots; int64_t n; const int32_t* dup_heads; const int32_t* dup_count; uint64_t num_rows;
     float* x_sorted;
     int det;                                     // SGD: hot rows' pieces park their sums in x_sorted (emb_bwd_hot_apply_kernel adds them)
+    int skip_unique_lin;                         // first-order weights of rows unique in the batch are updated by dr_emb_lin_update_unique
 };
 template <int LPR, int U, bool ADAM>
 __global__ __launch_bounds__(256) void emb_bwd_sorted_kernel(BwdSortedArgs a, AdamArgs ad, int grid_d) {
@@ -325,8 +326,8 @@ __global__ __launch_bounds__(256) void emb_bwd_sorted_kernel(BwdSortedArgs a, Ad
                                      a.det != 0);
     else
         emb_bwd_unique_body<LPR, U, ADAM>(blockIdx.x - grid_d, gridDim.x - grid_d, a.ids, a.flags, a.B, a.F, a.row_base, a.D, a.grad,
-                                          a.ld, a.concat, a.ldc, a.sum_x, a.d_fm_logit, a.slot_lin, a.scale, a.table, a.lin_w,
-                                          a.lin_bias, ad);
+                                          a.ld, a.concat, a.ldc, a.sum_x, a.d_fm_logit, a.slot_lin, a.scale, a.table,
+                                          a.skip_unique_lin ? nullptr : a.lin_w, a.lin_bias, ad);
 }
 
 // Second half of the deterministic hot-row update (SGD with x_sorted given): for every row whose slots span more than one piece,
@@ -471,7 +472,7 @@ static int bwd_sorted_impl(const int64_t* ids, const int64_t* row_base, const in
     const int det = (adam == nullptr && x_sorted != nullptr && det_on) ? 1 : 0;
     const BwdSortedArgs ba{ids, unique_flags, B, F, row_base, D, grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit, slot_lin_grad,
                            scale, dst_table, dst_lin, dst_bias, rows, sorted_slots, n, dup_heads, dup_count, (uint64_t)num_rows,
-                           x_sorted, det};
+                           x_sorted, det, (adam == nullptr && (parts & 4)) ? 1 : 0};
 #define LAUNCH(L, ADAM_)                                                                                              \
     {                                                                                                                 \
         constexpr int NS_ = 64 / L;                                                                                   \
@@ -530,6 +531,9 @@ extern "C" int dr_emb_pool_bwd_sorted(const int64_t* ids, const int64_t* row_bas
 // The same call in two halves, for callers that time (or overlap) them separately: parts = 1 the update kernel, parts = 2 the ordered
 // combination of hot rows' parked pieces (a no-op without x_sorted or with DR_K4_DETERMINISTIC=0), parts = 3 both = the call above.
 // A caller that runs part 1 MUST run part 2 on the same stream before anything reads the tables.
+// parts | 4: the first-order weights of rows that are UNIQUE in the batch are left alone -- the caller updates them with
+// dr_emb_lin_update_unique (same values, any stream, any time between the head's backward and the next forward): a random 4-byte
+// read-modify-write costs a 128-byte fetch, 0.27 GB of K4's 1.64 GB at config 3, and next to a GEMM it costs nothing.
 extern "C" int dr_emb_pool_bwd_sorted_parts(const int64_t* ids, const int64_t* row_base, const int64_t* sorted_rows,
                                             const int32_t* sorted_slots, const uint8_t* unique_flags,
                                             const int32_t* dup_heads, const int32_t* dup_count, int64_t B, int32_t F,
@@ -538,10 +542,45 @@ extern "C" int dr_emb_pool_bwd_sorted_parts(const int64_t* ids, const int64_t* r
                                             const float* d_fm_logit, const float* slot_lin_grad, float scale,
                                             float* dst_table, float* dst_lin, float* dst_bias, float* x_sorted,
                                             int32_t parts, dr_stream_t stream) {
-    if (parts < 1 || parts > 3) return DR_EINVAL;
+    if (parts < 1 || parts > 7 || (parts & 3) == 0) return DR_EINVAL;
     return bwd_sorted_impl(ids, row_base, sorted_rows, sorted_slots, unique_flags, dup_heads, dup_count, B, F, D, num_rows,
                            grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit, slot_lin_grad, scale, dst_table, dst_lin,
                            dst_bias, nullptr, x_sorted, stream, parts);
+}
+
+// dst_lin[row_base[f] + ids[b, f]] += scale * (slot_lin_grad ? slot_lin_grad[b, f] : d_fm_logit[b])  for every slot whose row no other
+// slot of the batch shares (unique_flags of the slot plan) -- the part of K4's first-order update that dr_emb_pool_bwd_sorted_parts
+// (parts | 4) leaves out.  One thread per slot, plain read-modify-write (a unique row has one writer): deterministic.
+namespace {
+__global__ __launch_bounds__(256) void lin_update_unique_kernel(const int64_t* __restrict__ ids, const uint8_t* __restrict__ flags,
+                                                                int64_t n, int32_t F, const int64_t* __restrict__ row_base,
+                                                                const float* __restrict__ d_fm_logit,
+                                                                const float* __restrict__ slot_lin, float scale,
+                                                                float* __restrict__ lin_w) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += stride) {
+        const int64_t id = ids[s];
+        if (id < 0 || !flags[s]) continue;
+        const int64_t b = s / F;
+        const int f = (int)(s - b * F);
+        const int64_t row = row_base[f] + id;
+        const float g = slot_lin != nullptr ? slot_lin[s] : d_fm_logit[b];
+        lin_w[row] = fmaf(scale, g, lin_w[row]);
+    }
+}
+}  // namespace
+
+extern "C" int dr_emb_lin_update_unique(const int64_t* ids, const uint8_t* unique_flags, int64_t B, int32_t F,
+                                        const int64_t* row_base, const float* d_fm_logit, const float* slot_lin_grad, float scale,
+                                        float* dst_lin, dr_stream_t stream) {
+    if (B < 0 || F <= 0 || F > 64) return DR_EINVAL;
+    if (B == 0) return DR_OK;
+    if (!ids || !unique_flags || !row_base || !dst_lin || (!d_fm_logit && !slot_lin_grad)) return DR_EINVAL;
+    const int64_t n = B * F;
+    hipLaunchKernelGGL(lin_update_unique_kernel, dim3(dr_grid_for(n, 256, 4096)), dim3(256), 0, dr_s(stream), ids, unique_flags, n, F,
+                       row_base, d_fm_logit, slot_lin_grad, scale, dst_lin);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
 }
 
 // x_sorted[i, :] = table[sorted_rows[i], :] for every position i on the duplicate pass's work list (dup_heads[0 .. dup_count[0])):

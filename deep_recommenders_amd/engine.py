@@ -186,6 +186,12 @@ class DeepFMEngine:
             self.ev_k4 = torch.cuda.Event()
             self.ev_dw_done = torch.cuda.Event()
             self.ev_planes = torch.cuda.Event()
+            self.ev_dlogit = torch.cuda.Event()
+            self.ev_lin = torch.cuda.Event()
+        # First-order weights of the rows that are unique in the batch (99.4 % of the slots for uniform ids) updated by a kernel of
+        # their own on the side stream, beside the tower tail, instead of inside K4: a random 4-byte read-modify-write fetches a
+        # 128-byte line, 0.27 GB of K4's 1.64 GB.  DR_LIN_SIDE=1 (off by default: see DESIGN.md for the A/B).
+        self.lin_side = (sorted_bwd and optimizer == "sgd" and _os.environ.get("DR_LIN_SIDE", "0") == "1")
         self._planes_pending = False
         self._planes_pending_l0 = False
         # First-layer wgrad on a second stream, concurrent with the HBM-bound K4 on the training stream.  It paid next to the
@@ -427,6 +433,15 @@ class DeepFMEngine:
     def backward_and_update(self):
         F, D, lr = self.F, self.D, self.lr
         adam = self.optimizer == "adam"
+        lin_side = self.lin_side and not adam and not self.sort_inline
+        if lin_side:
+            # d_logit is final (fused head or K11 above); the plan of this batch was produced on the side stream itself
+            self.ev_dlogit.record()
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(self.ev_dlogit)
+                self._k("emb_lin_update_unique(side stream, overlapped)", "overlap", self.B * self.F * 16,
+                        lambda: ops.emb_lin_update_unique(self.ids, self.row_base, self.plan, self.d_logit, -lr, self.lin_w))
+                self.ev_lin.record(self.side)
         sc = 1.0 if adam else -lr                         # Adam: gradients into the bucket; SGD: the step itself
         n = len(self.Ws)
         dy = self.d_logit.reshape(-1, 1)                  # d(mean loss)/d logit == pre-activation grad of Dense(1)
@@ -500,9 +515,13 @@ class DeepFMEngine:
                                                        -lr, self.table, self.lin_w, self.lin_bias,
                                                        concat=None if self.no_concat else self.concat, sum_x=self.sum_x,
                                                        x_sorted=self.x_sorted if self.no_concat else None, parts=parts)
-            self._k("emb_pool_bwd", "hbm", self.alg_bytes_bwd(), lambda: k4(1))                       # K4 (sorted)
+            sk = 4 if lin_side else 0
+            self._k("emb_pool_bwd", "hbm", self.alg_bytes_bwd() - (self.B * self.F * 8 if lin_side else 0),   # K4 (sorted)
+                    lambda: k4(1 | sk))
             if self.no_concat:     # rows hit > 32 times: their parked pieces added in sorted order (a scan of the head list otherwise)
-                self._k("emb_hot_rows_apply", "hbm", 0, lambda: k4(2))
+                self._k("emb_hot_rows_apply", "hbm", 0, lambda: k4(2 | sk))
+            if lin_side:
+                torch.cuda.current_stream().wait_event(self.ev_lin)
             self._prefetch_issue(mark)
         else:
             self._k("emb_pool_bwd", "hbm", self.alg_bytes_bwd(),                                      # K4 (atomics)

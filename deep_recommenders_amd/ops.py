@@ -507,6 +507,15 @@ def emb_pool_bwd_sorted(ids, row_base, plan, D, num_rows, grad, d_fm_logit, scal
         check(lib().dr_emb_pool_bwd_sorted_parts(*args, int(parts), stream_ptr()), "dr_emb_pool_bwd_sorted_parts")
 
 
+def emb_lin_update_unique(ids, row_base, plan, d_fm_logit, scale, dst_lin, slot_lin_grad=None):
+    """dst_lin[row] += scale * gradient for every slot whose row is unique in the batch (plan.flags): the part of K4's first-order
+    update that emb_pool_bwd_sorted(parts=... | 4) leaves out (dr_emb_lin_update_unique)."""
+    ids = _c(ids, torch.int64)
+    B, F = ids.shape
+    check(lib().dr_emb_lin_update_unique(ptr(ids), ptr(plan.flags), B, F, ptr(row_base), ptr(d_fm_logit), ptr(slot_lin_grad),
+                                         float(scale), ptr(dst_lin), stream_ptr()), "dr_emb_lin_update_unique")
+
+
 def adam_lr_t(lr, beta1, beta2, step):
     """[TF] B15: lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t), t = step counted from 1."""
     return lr * (1.0 - beta2 ** step) ** 0.5 / (1.0 - beta1 ** step)

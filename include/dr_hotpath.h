@@ -206,6 +206,12 @@ int dr_emb_pool_bwd_sorted_parts(const int64_t* ids, const int64_t* row_base, co
                                  const float* d_fm_logit, const float* slot_lin_grad, float scale,
                                  float* dst_table, float* dst_lin, float* dst_bias, float* x_sorted, int32_t parts,
                                  dr_stream_t stream);
+/* parts | 4: first-order weights of rows unique in the batch are NOT updated by the call; dr_emb_lin_update_unique applies exactly that
+ * part (dst_lin[row] += scale * gradient for every slot whose unique flag is set), on any stream between the head's backward and
+ * the next forward.  Why: a random 4-byte read-modify-write fetches a 128-byte line -- 0.27 GB of K4's 1.64 GB at config 3 -- and
+ * beside a matrix-bound GEMM that traffic is free. */
+int dr_emb_lin_update_unique(const int64_t* ids, const uint8_t* unique_flags, int64_t B, int32_t F, const int64_t* row_base,
+                             const float* d_fm_logit, const float* slot_lin_grad, float scale, float* dst_lin, dr_stream_t stream);
 int dr_emb_snapshot_sorted_rows(const int64_t* sorted_rows, const int32_t* dup_heads, const int32_t* dup_count,
                                 const float* table, int32_t D, int64_t num_rows, float* x_sorted, dr_stream_t stream);
 

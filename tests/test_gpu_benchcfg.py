@@ -261,6 +261,15 @@ def test_deepfm_bench_config_with_concat_buffer(monkeypatch):
     assert not eng.no_concat
 
 
+@pytest.mark.parametrize("kind", ["uniform", "zipf"])
+def test_deepfm_bench_config_lin_side_stream(kind, monkeypatch):
+    """DR_LIN_SIDE=1: the first-order weights of rows unique in the batch are updated by dr_emb_lin_update_unique on the side stream
+    (beside the tower tail) and K4 skips them -- same oracle assertions as the default."""
+    monkeypatch.setenv("DR_LIN_SIDE", "1")
+    eng, _ = _run_deepfm(1_000_000, "sgd", kind, lr=1.0)
+    assert eng.lin_side
+
+
 def test_deepfm_bench_config_sgd_zipf():
     """Zipf(1.05) keys (bench.py --ids zipf): most slots are duplicates, the K4 segment-sum path carries the step."""
     _run_deepfm(1_000_000, "sgd", "zipf", lr=1.0)
@@ -307,6 +316,39 @@ def test_deepfm_zipf_step_is_reproducible(no_concat, monkeypatch):
     else:
         # (first seen: 1.8e-7 on an update of 2.7e-3 -- a few ulps of the row's value, the re-association of 32-slot pieces)
         assert (outs[0][2] - outs[1][2]).abs().max().item() <= 1e-3 * upd + 1e-6
+
+
+@pytest.mark.parametrize("kind", ["uniform", "zipf"])
+def test_deepfm_three_steps_are_bit_reproducible(kind):
+    """Three SGD steps of the benched orchestration (next batch's plan prefetched beside K4, as bench.py runs it) from identical
+    state, twice: every loss and every parameter -- tables, first-order weights and bias, all Dense kernels and biases -- must come
+    out BIT-identical.  Nothing in the step combines floating-point values in an arrival order: split-K partials are reduced in
+    slice order, bias gradients by one block in a fixed order, shared rows in sorted order (hot rows included), and two streams
+    never write the same word."""
+    V = 1_000_000
+    batches = _batches(3, kind, seed=4242)
+    res = []
+    for _ in range(2):
+        eng = _make_engine(V, "sgd", 1.0)
+        assert eng.no_concat and eng.sorted_bwd
+        losses = []
+        for i, (keys, dense, labels) in enumerate(batches):
+            nk = batches[i + 1][0] if i + 1 < len(batches) else None
+            losses.append(eng.train_step(keys, dense, labels, next_keys=nk).clone())
+        torch.cuda.synchronize()
+        res.append(([l.cpu() for l in losses], eng.table.clone(), eng.lin_w.clone(), eng.lin_bias.clone(),
+                    [w.clone() for w in eng.Ws], [b.clone() for b in eng.bs]))
+        del eng
+        torch.cuda.empty_cache()
+    a, b = res
+    for la, lb in zip(a[0], b[0]):
+        assert torch.equal(la, lb), (la, lb)
+    assert torch.equal(a[1], b[1]), "embedding tables differ between two identical runs"
+    assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]), "first-order weights / bias differ"
+    for i, (wa, wb) in enumerate(zip(a[4], b[4])):
+        assert torch.equal(wa, wb), "Dense kernel %d differs" % i
+    for i, (ba, bb) in enumerate(zip(a[5], b[5])):
+        assert torch.equal(ba, bb), "Dense bias %d differs" % i
 
 
 def test_deepfm_bench_config_overlap_on_off_agree():

@@ -556,6 +556,18 @@ def _emb_bwd_sorted_case(ops, D, F, V, hot, path):
     if not hot:     # no row is hit by more than 32 slots -> plain RMW everywhere -> bit-reproducible
         np.testing.assert_array_equal(outs[0][0], outs[1][0])
         np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    # K4 without the unique rows' first-order weights (parts | 4) + dr_emb_lin_update_unique == K4: same bits on the first-order
+    # weights of unique rows (one fma each, either way), tables untouched by the split
+    t_dev, l_dev, b_dev = _dev(table).clone(), _dev(lin).clone(), torch.zeros(1, device="cuda")
+    ops.emb_pool_bwd_sorted(d_ids, d_rb, plan, D, R, _dev(grad), _dev(dl), -0.1, t_dev, l_dev, b_dev, parts=3 | 4)
+    ops.emb_lin_update_unique(d_ids, d_rb, plan, _dev(dl), -0.1, l_dev)
+    if hot:     # (no x_sorted here: a hot row's pieces meet through atomics, run-to-run rounding)
+        np.testing.assert_allclose(t_dev.cpu().numpy(), want_t, rtol=1e-5, atol=tol)
+    else:
+        np.testing.assert_array_equal(t_dev.cpu().numpy(), outs[1][0])
+    uniq_rows = (ids + row_base[None, :]).reshape(-1)[plan.flags.cpu().numpy().astype(bool) & (ids.reshape(-1) >= 0)]
+    np.testing.assert_array_equal(l_dev.cpu().numpy()[uniq_rows], outs[1][1][uniq_rows])
+    np.testing.assert_allclose(l_dev.cpu().numpy(), want_l, rtol=1e-5, atol=tol)
     # with the x_sorted buffer the pieces of a hot row park their sums and are added in sorted order: bit-reproducible ALWAYS
     # (the buffer's content is don't-care here -- no FM term -- so it starts as NaN: nothing unwritten may be read)
     outs = []
