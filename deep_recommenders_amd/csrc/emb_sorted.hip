@@ -318,8 +318,13 @@ struct BwdSortedArgs {
     int det;                                     // SGD: hot rows' pieces park their sums in x_sorted (emb_bwd_hot_apply_kernel adds them)
     int skip_unique_lin;                         // first-order weights of rows unique in the batch are updated by dr_emb_lin_update_unique
 };
+#ifndef DR_K4_MINWAVES     // (experiment hooks: tools/exp/k4_occupancy.sh builds variants with -DDR_K4_MINWAVES=n / -DDR_K4_U=n)
+#define DR_K4_LB __launch_bounds__(256)
+#else
+#define DR_K4_LB __launch_bounds__(256, DR_K4_MINWAVES)
+#endif
 template <int LPR, int U, bool ADAM>
-__global__ __launch_bounds__(256) void emb_bwd_sorted_kernel(BwdSortedArgs a, AdamArgs ad, int grid_d) {
+__global__ DR_K4_LB void emb_bwd_sorted_kernel(BwdSortedArgs a, AdamArgs ad, int grid_d) {
     if ((int)blockIdx.x < grid_d)
         emb_bwd_dups_body<LPR, ADAM>(blockIdx.x, grid_d, a.rows, a.slots, a.n, a.dup_heads, a.dup_count, a.F, a.D, a.num_rows, a.grad,
                                      a.ld, a.concat, a.ldc, a.sum_x, a.d_fm_logit, a.slot_lin, a.scale, a.table, a.lin_w, ad, a.x_sorted,
@@ -473,10 +478,15 @@ static int bwd_sorted_impl(const int64_t* ids, const int64_t* row_base, const in
     const BwdSortedArgs ba{ids, unique_flags, B, F, row_base, D, grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit, slot_lin_grad,
                            scale, dst_table, dst_lin, dst_bias, rows, sorted_slots, n, dup_heads, dup_count, (uint64_t)num_rows,
                            x_sorted, det, (adam == nullptr && (parts & 4)) ? 1 : 0};
+#ifdef DR_K4_U
+    constexpr int K4_U_OVERRIDE = DR_K4_U;
+#else
+    constexpr int K4_U_OVERRIDE = 0;
+#endif
 #define LAUNCH(L, ADAM_)                                                                                              \
     {                                                                                                                 \
         constexpr int NS_ = 64 / L;                                                                                   \
-        constexpr int U_ = NS_ >= 16 ? 2 : 4;                                                                         \
+        constexpr int U_ = K4_U_OVERRIDE > 0 ? K4_U_OVERRIDE : (NS_ >= 16 ? 2 : 4);                                   \
         hipLaunchKernelGGL((emb_bwd_sorted_kernel<L, U_, ADAM_>), dim3(grid_d + grid_u), dim3(256), 0, dr_s(stream), ba, ad,    \
                            grid_d);                                                                                   \
     }
