@@ -521,6 +521,12 @@ struct RsArgs {
     // written; a score is kept only if it beats its row's current k-th best tau[row], appended to the row's candidate list
     // cand_s / cand_c [M][cand_cap] through the cursor cand_cnt[row] (one atomic per (row, 32 columns) that has any)
     const float* tau; float* cand_s; int32_t* cand_c; int32_t* cand_cnt; int64_t cand_cap;
+    // per-slot gradient rows into an all-to-all send layout (the sharded engine's first-layer dgrad + dr_emb_pack_grads in one): column
+    // c < 64 pack_F of example m is dimension c & 63 of slot (m, c >> 6), whose destination row is pack_pos[m, c >> 6]:
+    //   C[pack_pos * 64 + (c & 63)] = acc + pack_dl[m] * (pack_sumx[m, c & 63] - xin[m, c])      (FM term iff pack_sumx != nullptr)
+    //   pack_lin[pack_pos] = pack_dl[m]                                                           (iff pack_lin != nullptr)
+    // columns >= 64 pack_F (dense features) are computed and dropped.  xin / ldx: the concatenated embeddings of the forward.
+    const int64_t* pack_pos; int32_t pack_F; const float* pack_dl; const float* pack_sumx; float* pack_lin;
 };
 
 __device__ __forceinline__ void rs_split8(const float4& lo, const float4& hi4, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
@@ -532,7 +538,8 @@ __device__ __forceinline__ void rs_split8(const float4& lo, const float4& hi4, b
     p2 = __builtin_shufflevector(a2, b2, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-// EPI: 0 = bias / ReLU, 1 = + ReLU' mask, 3 = accumulate (C +=), 2 = DCN cross combine, 4 = top-K filter (one epilogue per
+// EPI: 0 = bias / ReLU, 1 = + ReLU' mask, 3 = accumulate (C +=), 2 = DCN cross combine, 4 = top-K filter, 5 = scatter into the
+// embedding-gradient send layout (one epilogue per
 // instantiation: all of them unrolled over the 8 column tiles in one kernel cost 50 spilled registers)
 // MS: 32-row sets per wave.  1 = 8 waves x 32 rows (two waves per SIMD, 128 accumulator registers each); 2 = 4 waves x 64 rows (ONE
 // wave per SIMD with all 512 registers, 256 of them accumulators): every weight fragment read from the LDS feeds 12 MFMAs instead
@@ -836,6 +843,59 @@ __global__ __launch_bounds__(512 / MS, MS == 1 ? 2 : 1) void bf3_gemm_rs_kernel(
                                 }
                             }
                         }
+                    }
+                }
+            } else if constexpr (EPI == 5) {
+                // Every load unconditional (clamped).  The stores are under WAVE-UNIFORM conditions only: a 32-column group lies inside
+                // one field or entirely behind the embeddings (64 F and the group width are multiples of 32), and all rows of an
+                // interior row tile exist -- a store under a per-lane condition makes hipcc drain vmcnt in front of each one (the
+                // first version, with per-lane guards: 627 us for the half batch instead of 175 + 150).  A group's 32 lanes write
+                // one contiguous 128-byte piece of the destination row.
+                const bool fmterm = g.pack_sumx != nullptr;
+                const float* sxp = fmterm ? g.pack_sumx : g.pack_dl;
+                const float* xp = fmterm ? g.xin : g.pack_dl;
+                const int64_t xld = fmterm ? g.ldx : 0, sxld = fmterm ? 64 : 0;
+                const int kemb = min(64 * g.pack_F, g.N);
+                const bool rows_in = tm0 + BM <= g.M;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int cg = tn0 + nt * 32;                                       // (uniform) first column of the group
+                    if (cg >= kemb) {
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) acc[ms][nt][reg] = 0.f;
+                        continue;
+                    }
+                    const int col = cg + l31;
+                    const int f = cg >> 6, d = col & 63;
+                    const bool lin_here = (cg & 63) == 0 && g.pack_lin != nullptr;      // (uniform) the group that holds d == 0
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) {
+                        int64_t pp[4];
+                        float dlv[4], sxv[4], xv[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int64_t row = r0 + e + 8 * c4;
+                            const int64_t rc = row < g.M ? row : g.M - 1;
+                            pp[e] = g.pack_pos[rc * g.pack_F + f];
+                            dlv[e] = g.pack_dl[rc];
+                            sxv[e] = sxp[rc * sxld + (fmterm ? d : 0)];
+                            xv[e] = xp[rc * xld + (fmterm ? col : 0)];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int reg = 4 * c4 + e;
+                            float v = acc[ms][nt][reg];
+                            acc[ms][nt][reg] = 0.f;
+                            if (fmterm) v += dlv[e] * (sxv[e] - xv[e]);
+                            if (rows_in) {
+                                g.C[pp[e] * 64 + d] = v;
+                                if (lin_here) g.pack_lin[pp[e]] = dlv[e];               // 32 lanes, one address, one value
+                            } else if (r0 + e + 8 * c4 < g.M) {
+                                g.C[pp[e] * 64 + d] = v;
+                                if (lin_here) g.pack_lin[pp[e]] = dlv[e];
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);     // (four rows at a time: hoisted across groups, the loads spill 93 registers)
                     }
                 }
             } else {
@@ -1893,6 +1953,11 @@ int rs_launch(const RsArgs& g, hipStream_t stream) {
         DR_CHECK_LAUNCH();
         return DR_OK;
     }
+    if (g.pack_pos != nullptr) {
+        hipLaunchKernelGGL((bf3_gemm_rs_kernel<5>), dim3(grid), dim3(512), 0, stream, g);
+        DR_CHECK_LAUNCH();
+        return DR_OK;
+    }
 #ifdef DR_BF3_ABLATE
     {   // ablations of the plain epilogue (tools/exp/rs64_bench.py): DR_BF3_RS_DBG = 32 no fragment reads, 64 no split, 96 both, 2 no MFMA
         static const int dbg = [] { const char* e = getenv("DR_BF3_RS_DBG"); return e ? atoi(e) : 0; }();
@@ -2051,6 +2116,39 @@ extern "C" int dr_bf3_linear_nt(const float* A, int64_t lda, const void* b_plane
     RsArgs g{A, lda, static_cast<const __bf16*>(b_planes), b_plane_stride, b_ld, M, N, K, C, ldc, bias, act, mask, ld_mask, accumulate,
              nullptr, nullptr, 0, 0.f, nullptr};
     return rs_launch(g, dr_s(stream));
+}
+
+namespace {
+__global__ __launch_bounds__(256) void bf3_pack_bias_kernel(const float* dl, int64_t n, float* bias_sum) {
+    dr_block_sum_axpy(dl, n, 1.f, bias_sum);
+}
+}  // namespace
+
+// First-layer dgrad of a tower whose input is the concatenation of F 64-wide embeddings (+ dense features) fused with
+// dr_emb_pack_grads: the gradient of slot (m, f) -- sum_k dy[m][k] W[64 f + d][k] + d_fm_logit[m] (sum_x[m][d] - x[m][64 f + d]) --
+// goes straight to out_rows[pos[m, f], d], the all-to-all send layout; d_concat is never written (0.44 GB less written and 0.66 GB
+// less read per 65 536 examples than dgrad + pack).  w_planes: W as planes [3][K_in rows][b_ld] (rows = input features, as for
+// dr_bf3_linear_nt's dgrad use); N = number of input features (>= 64 F; the columns behind the embeddings are dropped).
+// out_lin (may be NULL): out_lin[pos[m, f]] = d_fm_logit[m].  bias_sum (may be NULL): += sum_m d_fm_logit[m], fixed order.
+// sum_x == NULL: no FM term (x / ld_x unused).  pos must be a permutation of the slots, as for dr_emb_pack_grads.
+extern "C" int dr_bf3_linear_nt_pack(const float* dy, int64_t ld_dy, const void* w_planes, int64_t plane_stride, int64_t b_ld, int64_t M,
+                                     int32_t N, int32_t K, const int64_t* pos, int32_t F, const float* d_fm_logit, const float* sum_x,
+                                     const float* x, int64_t ld_x, float* out_rows, float* out_lin, float* bias_sum,
+                                     dr_stream_t stream) {
+    if (M < 0 || N <= 0 || K <= 0 || F <= 0 || (int64_t)F * 64 > N) return DR_EINVAL;
+    if (M == 0) return DR_OK;
+    if (!dy || !pos || !d_fm_logit || !out_rows || !planes_ok(w_planes, plane_stride, b_ld)) return DR_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(dy) & 15) != 0 || (ld_dy & 3) != 0 || ld_dy < K || b_ld < (K + BK - 1) / BK * BK) return DR_EINVAL;
+    if (sum_x != nullptr && (x == nullptr || ld_x < (int64_t)F * 64)) return DR_EINVAL;
+    RsArgs g{dy, ld_dy, static_cast<const __bf16*>(w_planes), plane_stride, b_ld, M, N, K, out_rows, 0, nullptr, 0, nullptr, 0, 0,
+             nullptr, x, ld_x, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, 0, pos, F, d_fm_logit, sum_x, out_lin};
+    const int rc = rs_launch(g, dr_s(stream));
+    if (rc != DR_OK) return rc;
+    if (bias_sum != nullptr) {
+        hipLaunchKernelGGL(bf3_pack_bias_kernel, dim3(1), dim3(256), 0, dr_s(stream), d_fm_logit, M, bias_sum);
+        DR_CHECK_LAUNCH();
+    }
+    return DR_OK;
 }
 
 // internal (C++ linkage, used by retrieval.hip): the top-K scan's scores = a @ B^T on the register-split kernel -- a [M, K] fp32

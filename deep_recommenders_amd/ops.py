@@ -884,6 +884,21 @@ def bf3_linear_nt(a, b: Planes, bias=None, act=0, mask=None, accumulate=False, o
     return out
 
 
+def bf3_linear_nt_pack(dy, w: Planes, pos, d_fm_logit, out_rows, out_lin=None, bias_sum=None, sum_x=None, x=None):
+    """First-layer dgrad + emb_pack_grads in one launch (dr_bf3_linear_nt_pack): out_rows[pos[m, f], :] = (dy @ W^T)[m, 64 f : 64 f + 64]
+    + d_fm_logit[m] * (sum_x[m] - x[m, 64 f : 64 f + 64]); out_lin[pos[m, f]] = d_fm_logit[m]; bias_sum += sum(d_fm_logit).
+    w: the layer's W as planes (rows = input features).  D is 64."""
+    dy = _rowmajor_ld4(dy)
+    M, K = dy.shape
+    pos = _c(pos, torch.int64)
+    F = pos.shape[1]
+    assert w.cols == K and w.rows >= 64 * F and out_rows.is_contiguous() and out_rows.shape[1] == 64
+    check(lib().dr_bf3_linear_nt_pack(ptr(dy), dy.stride(0), ptr(w.buf), w.plane_stride, w.ld, M, w.rows, K, ptr(pos), F,
+                                      ptr(d_fm_logit), ptr(sum_x), ptr(x), x.stride(0) if x is not None else 0, ptr(out_rows),
+                                      ptr(out_lin), ptr(bias_sum), stream_ptr()), "dr_bf3_linear_nt_pack")
+    return out_rows
+
+
 def bf3_cross_fwd(x0, x, wt: Planes, b=None, diag_scale=0.0, want_prod=False, prod=None):
     """DCN cross layer on pre-split weights (wt = W^T planes): out = x0 * (x @ W + b + diag * x) + x; (out, prod) as cross_fwd."""
     M, Dm = x.shape

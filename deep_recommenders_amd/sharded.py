@@ -380,8 +380,8 @@ class ShardedEmbeddingExchange:
         return self.pool(route, got_rows, got_lin, lin_bias, ld_concat, concat=concat, sum_x=sum_x, fm_logit=fm_logit)
 
     # ---- step 8 -------------------------------------------------------------------------------------------------
-    def pack(self, route, d_concat, d_fm_logit, concat, sum_x, g_bias=None):
-        """requesting side: per-slot gradients into the send layout (local, HBM-bound)"""
+    def pack_buffers(self, route):
+        """the send-layout buffers the per-slot gradients of `route` go to (rows [n, D], first-order [n] or None)"""
         r = route
         if self.local:                       # straight into the buffers the owner-side K4 reads (nothing travels)
             sl = self._slots[r.slot]
@@ -390,7 +390,12 @@ class ShardedEmbeddingExchange:
         else:
             g_rows = torch.empty((r.n, self.D), dtype=torch.float32, device=r.pos.device)
             g_lin = torch.empty(r.n, dtype=torch.float32, device=r.pos.device) if r.has_lin else None
-        self.p.emb_pack_grads(r.pos, self.D, d_concat, concat, sum_x, d_fm_logit, g_rows, g_lin, g_bias)
+        return g_rows, g_lin
+
+    def pack(self, route, d_concat, d_fm_logit, concat, sum_x, g_bias=None):
+        """requesting side: per-slot gradients into the send layout (local, HBM-bound)"""
+        g_rows, g_lin = self.pack_buffers(route)
+        self.p.emb_pack_grads(route.pos, self.D, d_concat, concat, sum_x, d_fm_logit, g_rows, g_lin, g_bias)
         return g_rows, g_lin
 
     def exchange_and_apply(self, route, g_rows, g_lin, scale, table_local, lin_local, adam=None):
@@ -568,6 +573,11 @@ class ShardedDeepFMEngine:
         self.fuse_k3 = (use_planes and _os.environ.get("DR_FUSE_K3", "1") == "1" and D == 64 and self.Nd <= 32
                         and self.wplanes[0] is not None and B * F <= (1 << 24) and self.acts[0] in (0, 1))
         self.dense_pad = torch.zeros((B, 32), **f32) if (self.fuse_k3 and self.Nd) else None
+        # first-layer dgrad and the gradient pack in one launch (dr_bf3_linear_nt_pack): d_concat is never written.  Needs the
+        # layer's weight planes, D == 64 and single-valued fields (one slot per (example, field)).  OFF unless DR_FUSE_PACK=1:
+        # measured slower (400 us against 173 + 143 per half batch -- the MFMA accumulator layout gives a lane one column of
+        # 16 rows, so the epilogue scatters with 4-byte stores and loads where the pack kernel moves float4s).
+        self.fuse_pack = (use_planes and _os.environ.get("DR_FUSE_PACK", "0") == "1" and D == 64 and num_fields <= 64)
         # streams for the later micro-batches' fused first layers (see train_step); DR_FWD_STREAMS=0: all on the training stream
         self.fwd_streams = ([torch.cuda.Stream(device=device) for _ in range(max(0, min(mb - 1, 3)))]
                             if (self.fuse_k3 and _os.environ.get("DR_FWD_STREAMS", "1") == "1") else [])
@@ -782,6 +792,7 @@ class ShardedDeepFMEngine:
             if self.fuse_head:
                 top = n_layers - 2
                 dy = self.dhs[-1][sl]
+            fuse_pack = self.fuse_pack and self.wplanes[0] is not None and not self.narrow[0] and top >= 0
             for i in range(top, -1, -1):
                 if i > 0:
                     dx = self.dhs[i - 1][sl]
@@ -789,6 +800,16 @@ class ShardedDeepFMEngine:
                 else:
                     dx = self.d_concat[sl, :self.in_dim]
                     rs = None
+                if i == 0 and fuse_pack:
+                    # the gradient of every slot straight into the send layout (dgrad epilogue = dr_emb_pack_grads)
+                    g_rows, g_lin = self.ex.pack_buffers(routes[m])
+                    self._k("linear_bwd_dx_L0", "mfma", 2.0 * Bm * self.Ws[0].shape[0] * self.Ws[0].shape[1],
+                            lambda dy=dy, sl=sl, m=m, g_rows=g_rows, g_lin=g_lin: ops.bf3_linear_nt_pack(
+                                dy, self.wplanes[0].w, routes[m].pos, self.d_logit[sl], g_rows, g_lin, self.g_lin_bias,
+                                sum_x=self.sum_x[sl], x=self.concat[sl]))
+                    if m == 0:
+                        dw_todo.append(i)
+                    continue
                 if self.narrow[i]:
                     self._k("linear_bwd_narrow_L%d" % i, "hbm", 4.0 * Bm * (2 * self.Ws[i].shape[0] + self.Ws[i].shape[1]),
                             lambda dy=dy, i=i, dx=dx, sl=sl: p.linear_bwd_narrow(self.hs[i - 1][sl], dy, self.Ws[i], 1.0, self.gWs[i],
@@ -805,9 +826,10 @@ class ShardedDeepFMEngine:
                         dw_todo.append(i)
                 dy = dx
             # ---- step 8: pack (local), then C3 + owner-side sorted update on the communication stream ------------------
-            g_rows, g_lin = self._k("emb_pack_grads", "hbm", Bm * F * (12 * D + 4),
-                                    lambda sl=sl, m=m: self.ex.pack(routes[m], self.d_concat[sl], self.d_logit[sl], self.concat[sl],
-                                                                    self.sum_x[sl], self.g_lin_bias))
+            if not fuse_pack:
+                g_rows, g_lin = self._k("emb_pack_grads", "hbm", Bm * F * (12 * D + 4),
+                                        lambda sl=sl, m=m: self.ex.pack(routes[m], self.d_concat[sl], self.d_logit[sl], self.concat[sl],
+                                                                        self.sum_x[sl], self.g_lin_bias))
             if cuda:
                 ev_p = torch.cuda.Event()
                 ev_p.record()

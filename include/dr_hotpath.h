@@ -545,6 +545,15 @@ int dr_bf3_gemm_nt(const void* a_planes, int64_t a_plane_stride, int64_t a_ld, c
 int dr_bf3_linear_nt(const float* A, int64_t lda, const void* b_planes, int64_t b_plane_stride, int64_t b_ld, int64_t M,
                      int32_t N, int32_t K, const float* bias, int32_t act, const float* mask, int64_t ld_mask,
                      int32_t accumulate, float* C, int64_t ldc, dr_stream_t stream);
+/* The sharded engine's first-layer dgrad and dr_emb_pack_grads in ONE launch (round 3): the gradient of slot (m, f) of F 64-wide
+ * embeddings -- sum_k dy[m][k] W[64 f + d][k] + d_fm_logit[m] (sum_x[m][d] - x[m][64 f + d]) -- is written straight to
+ * out_rows[pos[m, f], d], the all-to-all send layout (autodiff of keras/models/ranking/deepfm.py:44-45 + fm.py:23-37 of the
+ * reference into the gradient exchange); d_concat never exists.  w_planes: W as planes [3][N rows][b_ld] (N = input features
+ * >= 64 F; columns behind the embeddings are dropped).  out_lin (may be NULL)[pos[m, f]] = d_fm_logit[m]; bias_sum (may be NULL)
+ * += sum_m d_fm_logit[m] in a fixed order; sum_x == NULL: no FM term.  pos: a permutation of the M F slots. */
+int dr_bf3_linear_nt_pack(const float* dy, int64_t ld_dy, const void* w_planes, int64_t plane_stride, int64_t b_ld, int64_t M,
+                          int32_t N, int32_t K, const int64_t* pos, int32_t F, const float* d_fm_logit, const float* sum_x,
+                          const float* x, int64_t ld_x, float* out_rows, float* out_lin, float* bias_sum, dr_stream_t stream);
 /* DCN cross layer forward (dr_cross_fwd's math, keras/models/ranking/dcn.py:81-88) on pre-split weights: wt_planes = W^T as
  * planes [3][Dm][ld_planes] (dr_bf3_split with transpose = 1).  x0, x, out, prod_out share leading dimension ld. */
 int dr_bf3_cross_fwd(const float* x0, const float* x, int64_t ld, const void* wt_planes, int64_t plane_stride,

@@ -897,6 +897,42 @@ def test_bf3_linear_nt_matches_fp64(M, K, N):
     assert torch.equal(ops.bf3_linear_nt(xp[:, :K], wp.wt, bias=b, act=1), y)
 
 
+@pytest.mark.parametrize("M,F,Nd,K,fm", [(300, 3, 0, 40, True), (2085, 26, 13, 256, True), (4096, 7, 5, 64, False), (513, 1, 2, 256, True)])
+def test_bf3_linear_nt_pack_equals_dgrad_then_pack(M, F, Nd, K, fm):
+    """dr_bf3_linear_nt_pack (first-layer dgrad + dr_emb_pack_grads in one launch) == dr_bf3_linear_nt followed by dr_emb_pack_grads:
+    every slot's gradient row at its permuted destination, the first-order copies, the bias sum.  Same accumulators, same FM
+    expression; the one fused multiply-add the compiler may form differently bounds the difference at an ulp of the terms."""
+    from deep_recommenders_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + F)
+    N = 64 * F + Nd
+    dy = torch.randn((M, K), device="cuda", generator=g) * 1e-2
+    W = torch.randn((N, K), device="cuda", generator=g) * 0.1          # first layer [in = N, out = K]
+    wp = ops.WeightPlanes(W)
+    pos = torch.randperm(M * F, device="cuda", generator=g).reshape(M, F)
+    dl = torch.randn((M,), device="cuda", generator=g)
+    ldc = (N + 3) // 4 * 4
+    concat = torch.randn((M, ldc), device="cuda", generator=g)
+    sum_x = concat[:, :64 * F].reshape(M, F, 64).sum(1).contiguous()
+    # reference: two kernels
+    d_concat = torch.zeros((M, ldc), device="cuda")
+    ops.bf3_linear_nt(dy, wp.w, out=d_concat[:, :N])
+    rows0 = torch.full((M * F, 64), float("nan"), device="cuda")
+    lin0 = torch.full((M * F,), float("nan"), device="cuda")
+    b0 = torch.zeros(1, device="cuda")
+    ops.emb_pack_grads(pos, 64, d_concat, concat if fm else None, sum_x if fm else None, dl, rows0, lin0, b0)
+    # fused
+    rows1 = torch.full((M * F, 64), float("nan"), device="cuda")
+    lin1 = torch.full((M * F,), float("nan"), device="cuda")
+    b1 = torch.zeros(1, device="cuda")
+    ops.bf3_linear_nt_pack(dy, wp.w, pos, dl, rows1, lin1, b1, sum_x=sum_x if fm else None, x=concat if fm else None)
+    assert not torch.isnan(rows1).any() and not torch.isnan(lin1).any()          # a permutation: every destination written
+    assert torch.equal(lin1, lin0) and torch.equal(b1, b0)
+    scale = (rows0.abs().max().item() + 1e-30)
+    assert (rows1 - rows0).abs().max().item() <= 2e-7 * scale + 1e-7 * (dl.abs().max().item() * concat.abs().max().item())
+    if not fm:
+        assert torch.equal(rows1, rows0)
+
+
 _RS64_SNIPPET = r"""
 import hashlib, sys, torch
 sys.path.insert(0, %r)
