@@ -8,6 +8,10 @@ timeout 1200 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|FAIL
 cat gpurun_out/pytest_gpu.log
 bash tools/collect_profiles.sh
 cd $R
+# SQ counters (wave-cycle split, MFMA busy cycles, LDS activity) of the default kernels and of the 64-row-wave GEMM shape
+bash tools/collect_sq_pmc.sh > /dev/null 2>&1; cp gpurun_out/pmc_sq_summary.txt gpurun_out/pmc_sq_summary_default.txt
+DR_BF3_RS64=1 bash tools/collect_sq_pmc.sh > /dev/null 2>&1; cp gpurun_out/pmc_sq_summary.txt gpurun_out/pmc_sq_summary_rs64.txt
+cd $R
 timeout 400 python bench.py > gpurun_out/line_default.log 2>&1
 timeout 200 python bench.py --optimizer adam --no-cpu-baseline > gpurun_out/line_adam.log 2>&1
 timeout 200 python bench.py --ids zipf --no-cpu-baseline > gpurun_out/line_zipf.log 2>&1
