@@ -544,13 +544,17 @@ __device__ __forceinline__ void rs_split8(const float4& lo, const float4& hi4, b
 // MS: 32-row sets per wave.  1 = 8 waves x 32 rows (two waves per SIMD, 128 accumulator registers each); 2 = 4 waves x 64 rows (ONE
 // wave per SIMD with all 512 registers, 256 of them accumulators): every weight fragment read from the LDS feeds 12 MFMAs instead
 // of 6 and the ring's DMA pieces per MFMA stay the same, at the price of a single in-order instruction stream per SIMD.
-template <int EPI, int DBG = 0, int MS = 1>
-__global__ __launch_bounds__(512 / MS, MS == 1 ? 2 : 1) void bf3_gemm_rs_kernel(RsArgs g) {
-    constexpr int NW = 8 / MS, BM = 32 * MS * NW, BN = 256, NT = BN / 32, NS = 3;
+// CS: column split of the tile between waves.  CS = 2 (with MS = 2): 8 waves again, wave w owns rows 64 (w & 3) .. + 63 and column tiles
+// 4 (w >> 2) .. + 3 -- the same 128 accumulator registers as the default and two waves per SIMD, but half the fragment reads per
+// MFMA; the price is that each activation row is loaded and split by two waves (w and w + 4: one SIMD, one L1).
+template <int EPI, int DBG = 0, int MS = 1, int CS = 1>
+__global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_kernel(RsArgs g) {
+    constexpr int NW = 8 * CS / MS, RGW = NW / CS, BM = 32 * MS * RGW, BN = 256, NT = BN / 32, NTW = NT / CS, NS = 3;
+    static_assert(CS == 1 || (CS == 2 && MS == 2), "column split only with 64-row waves");
     constexpr int B_PLANE = BN * 64;                                    // bytes: 256 rows x 64-byte rows (32 bf16)
     constexpr int STAGE = 3 * B_PLANE;                                  // 48 KB
     constexpr int PW = STAGE / 1024 / NW;                               // 6 MS LDS-DMA pieces per wave and k-tile
-    static_assert(PW == 6 * MS && (MS == 1 || MS == 2), "piece schedule below assumes 6 MS pieces per wave and k-tile");
+    static_assert(PW * NW == 48 && (MS == 1 || MS == 2), "piece schedule below assumes 48 / NW pieces per wave and k-tile");
     constexpr int VM_STEP = 4 * MS + PW;                                // VMEM operations of one step (A loads + pieces)
     constexpr int VM_WAIT_STEP = 0x0F70 | (VM_STEP & 15) | ((VM_STEP >> 4) << 14);   // s_waitcnt vmcnt(VM_STEP) (6-bit field, split)
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE];
@@ -568,6 +572,8 @@ __global__ __launch_bounds__(512 / MS, MS == 1 ? 2 : 1) void bf3_gemm_rs_kernel(
     // landed before its mid barrier of step t (vmcnt(4): only this step's 4 activation loads are younger), which is the barrier
     // in front of the leading group's first read of that stage.  Bit-identical results; no gain measured (see rs_launch).
     constexpr bool STG = (DBG & 16) != 0 && MS == 1;
+    const int rgi = CS == 1 ? wave : (wave & (RGW - 1));               // row group / column half of this wave
+    const int chi = CS == 1 ? 0 : (wave / RGW);
     const int grp = STG ? (wave >> 2) : 0;
 
     const int tiles_n = (g.N + BN - 1) / BN;
@@ -584,7 +590,7 @@ __global__ __launch_bounds__(512 / MS, MS == 1 ? 2 : 1) void bf3_gemm_rs_kernel(
     const int sw = (l31 >> 2) & 3;
     unsigned b_addr[2];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) b_addr[s] = lds0 + l31 * 64 + (((2 * hi + s) ^ sw) << 4);
+    for (int s = 0; s < 2; ++s) b_addr[s] = lds0 + l31 * 64 + (((2 * hi + s) ^ sw) << 4) + chi * (NTW * 2048);
 
     // ---- producer state: the block's stream of steps (tile, k-tile), shared by the B pieces and the A loads -----------------
     // B: piece j = wave + 8 i of a stage: plane j / 16, rows 16 (j % 16) .. + 15, lane -> (row, 16-byte chunk).
@@ -638,7 +644,7 @@ __global__ __launch_bounds__(512 / MS, MS == 1 ? 2 : 1) void bf3_gemm_rs_kernel(
         const int64_t m0 = (int64_t)(xcd_remap(tile, ntiles) / tiles_n) * BM;
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms) {
-            int64_t row = m0 + wave * (32 * MS) + 32 * ms + l31;
+            int64_t row = m0 + rgi * (32 * MS) + 32 * ms + l31;
             row = row < g.M ? row : g.M - 1;                            // rows past the edge only feed unstored outputs
             asrc[ms] = g.A + row * g.lda + 16 * hi;
         }
@@ -693,10 +699,11 @@ __global__ __launch_bounds__(512 / MS, MS == 1 ? 2 : 1) void bf3_gemm_rs_kernel(
     bf16x8 fa[MS][2][3];                                                // [row set][k-step][plane] of the CURRENT step
     bf16x8 fb[4][3];                                                    // [buffer][plane]: group q uses buffer q & 3; the
                                                                         // reads run TWO groups (12 MFMAs) ahead of their use
-    auto read_b = [&](int buf, int stage, int q) {                      // group q = (k-step q >> 3, column tile q & 7)
+                                                                        // (CS == 2: buffers 0 / 1, ONE group = 12 MFMAs ahead)
+    auto read_b = [&](int buf, int stage, int q) {                      // group q = (k-step q / NTW, column tile q % NTW)
         if constexpr (DBG & 32) return;                                 // ablation: no fragment reads (stale registers)
-        const unsigned bb = b_addr[q >> 3] + stage * STAGE;
-        const int nt = q & 7;
+        const unsigned bb = b_addr[q / NTW] + stage * STAGE;
+        const int nt = q % NTW;
         // immediates must be literal: dispatch on the column tile
 #define RS_READ3(NTI)                                                        \
         BF3_DS_READ_B128(fb[buf][0], bb, 0 * B_PLANE + NTI * 2048);          \
@@ -713,7 +720,7 @@ __global__ __launch_bounds__(512 / MS, MS == 1 ? 2 : 1) void bf3_gemm_rs_kernel(
         if (all) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[buf][0]), "+v"(fb[buf][1]), "+v"(fb[buf][2]));
         else asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fb[buf][0]), "+v"(fb[buf][1]), "+v"(fb[buf][2]));   // the next group's 3 may fly
     };
-    f32x16 acc[MS][NT];
+    f32x16 acc[MS][NTW];
     constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
 
     // ---- prologue: B steps 0 and 1, A step 0 ---------------------------------------------------------------------------------
@@ -730,13 +737,13 @@ __global__ __launch_bounds__(512 / MS, MS == 1 ? 2 : 1) void bf3_gemm_rs_kernel(
     asm volatile("s_barrier" ::: "memory");
     if (STG && grp) asm volatile("s_barrier" ::: "memory");             // the lagging group starts at the leading group's first mid barrier
     read_b(0, 0, 0);
-    read_b(1, 0, 1);
+    if constexpr (CS == 1) read_b(1, 0, 1);
 
     int tile = blockIdx.x, kt = 0, stage = 0;
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NTW; ++t)
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[ms][t][k] = 0.f;
     int step = 0;
@@ -762,6 +769,33 @@ __global__ __launch_bounds__(512 / MS, MS == 1 ? 2 : 1) void bf3_gemm_rs_kernel(
         load_a(has_a);
         __builtin_amdgcn_sched_barrier(0);
         const int nstage = stage == NS - 1 ? 0 : stage + 1;
+        if constexpr (CS == 2) {
+#pragma unroll
+            for (int q = 0; q < 2 * NTW; ++q) {
+                // this group's three fragments were issued a whole group (12 MFMAs) ago
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[q & 1][0]), "+v"(fb[q & 1][1]), "+v"(fb[q & 1][2]));
+                if (q + 1 < 2 * NTW) {
+                    read_b((q + 1) & 1, stage, q + 1);
+                } else {
+                    // this wave is done reading stage `stage`; publish step + 1
+                    __builtin_amdgcn_s_waitcnt(VM_WAIT_STEP);
+                    asm volatile("s_barrier" ::: "memory");
+                    if (has_a) read_b(0, nstage, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int term = 0; term < 6; ++term)
+#pragma unroll
+                    for (int ms = 0; ms < MS; ++ms)
+                        acc[ms][q % NTW] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ms][q / NTW][PA[term]], fb[q & 1][PB[term]],
+                                                                                   acc[ms][q % NTW], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (q < PW) {
+                    if constexpr (!(DBG & 1)) issue_b(q);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             if (STG && q == 6) {
@@ -799,6 +833,7 @@ __global__ __launch_bounds__(512 / MS, MS == 1 ? 2 : 1) void bf3_gemm_rs_kernel(
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        }   // CS == 1
         if (has_b) advance_b();
         stage = nstage;
     }
@@ -810,7 +845,8 @@ __global__ __launch_bounds__(512 / MS, MS == 1 ? 2 : 1) void bf3_gemm_rs_kernel(
             const bool relu = g.act == 1;
 #pragma unroll
           for (int ms = 0; ms < MS; ++ms) {
-            const int64_t r0 = tm0 + wave * (32 * MS) + 32 * ms + 4 * hi;
+            const int64_t r0 = tm0 + rgi * (32 * MS) + 32 * ms + 4 * hi;
+            const int cb0 = tn0 + chi * (NTW * 32);                     // first column of this wave's column tiles
             // interior tiles: every load / store of the epilogue unconditional (a memory operation under a divergent branch makes
             // hipcc wait vmcnt(0) in front of each one); edge tiles take the guarded loop
             const bool interior = tm0 + BM <= g.M && tn0 + BN <= g.N;
@@ -824,8 +860,8 @@ __global__ __launch_bounds__(512 / MS, MS == 1 ? 2 : 1) void bf3_gemm_rs_kernel(
                     const bool rv = row < g.M;
                     const float t = g.tau[rv ? row : g.M - 1];
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        const int col = tn0 + nt * 32 + l31;
+                    for (int nt = 0; nt < NTW; ++nt) {
+                        const int col = cb0 + nt * 32 + l31;
                         const float v = acc[ms][nt][reg];
                         acc[ms][nt][reg] = 0.f;
                         const bool pass = rv && col < g.N && v > t;
@@ -858,8 +894,8 @@ __global__ __launch_bounds__(512 / MS, MS == 1 ? 2 : 1) void bf3_gemm_rs_kernel(
                 const int kemb = min(64 * g.pack_F, g.N);
                 const bool rows_in = tm0 + BM <= g.M;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const int cg = tn0 + nt * 32;                                       // (uniform) first column of the group
+                for (int nt = 0; nt < NTW; ++nt) {
+                    const int cg = cb0 + nt * 32;                                       // (uniform) first column of the group
                     if (cg >= kemb) {
 #pragma unroll
                         for (int reg = 0; reg < 16; ++reg) acc[ms][nt][reg] = 0.f;
@@ -900,8 +936,8 @@ __global__ __launch_bounds__(512 / MS, MS == 1 ? 2 : 1) void bf3_gemm_rs_kernel(
                 }
             } else {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int col = tn0 + nt * 32 + l31;
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int col = cb0 + nt * 32 + l31;
                 const bool cv = col < g.N;
                 float bj = g.bias != nullptr ? g.bias[cv ? col : g.N - 1] : 0.f;
                 asm volatile("" : "+v"(bj));      // consume the load on every path (see bf3_gemm_nt_pipe_kernel)
@@ -1977,6 +2013,14 @@ int rs_launch(const RsArgs& g, hipStream_t stream) {
 #endif
     // one 64-row wave per SIMD (MS = 2, see the kernel): DR_BF3_RS64=1
     static const bool rs64 = [] { const char* e = getenv("DR_BF3_RS64"); return e != nullptr && e[0] == '1'; }();
+    static const bool rs64x2 = [] { const char* e = getenv("DR_BF3_RS64"); return e != nullptr && e[0] == '2'; }();
+    if (rs64x2 && g.x0 == nullptr) {                                    // 8 waves x (64 rows x 128 columns): DR_BF3_RS64=2
+        if (g.mask != nullptr) hipLaunchKernelGGL((bf3_gemm_rs_kernel<1, 0, 2, 2>), dim3(grid), dim3(512), 0, stream, g);
+        else if (g.accumulate) hipLaunchKernelGGL((bf3_gemm_rs_kernel<3, 0, 2, 2>), dim3(grid), dim3(512), 0, stream, g);
+        else hipLaunchKernelGGL((bf3_gemm_rs_kernel<0, 0, 2, 2>), dim3(grid), dim3(512), 0, stream, g);
+        DR_CHECK_LAUNCH();
+        return DR_OK;
+    }
     if (rs64 && g.x0 == nullptr) {
         if (g.mask != nullptr) hipLaunchKernelGGL((bf3_gemm_rs_kernel<1, 0, 2>), dim3(grid), dim3(256), 0, stream, g);
         else if (g.accumulate) hipLaunchKernelGGL((bf3_gemm_rs_kernel<3, 0, 2>), dim3(grid), dim3(256), 0, stream, g);

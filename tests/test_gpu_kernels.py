@@ -965,12 +965,12 @@ def test_bf3_linear_nt_rs64_bit_identical():
     import os, subprocess, sys
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
     out = []
-    for flag in ("0", "1"):
+    for flag in ("0", "1", "2"):      # 2: 8 waves x (64 rows x 128 columns), the column-split shape
         env = dict(os.environ, DR_BF3_RS64=flag)
         r = subprocess.run([sys.executable, "-c", _RS64_SNIPPET % root], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         out.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1])
-    assert out[0] == out[1], out
+    assert out[0] == out[1] == out[2], out
 
 
 @pytest.mark.parametrize("M,F,Nd,N", [(300, 3, 0, 40), (2085, 26, 13, 256), (4096, 7, 5, 300), (257, 1, 2, 64),
