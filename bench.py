@@ -338,6 +338,22 @@ def main():
     ms = dt / a.steps * 1e3
     value = a.batch * world * a.steps / dt
 
+    # the slot plan K4 needs, ALONE on the idle chip (after the timed region): what it would add to K4 if it did not run beside the
+    # previous step's K4 -- the overlapped event time in `overlapped_side_stream` is stretched by that sharing
+    plan_alone_us = None
+    if a.model == "deepfm" and not sharded and getattr(eng, "sorted_bwd", False) and hasattr(eng, "plan"):
+        from deep_recommenders_amd import ops as _ops
+        torch.cuda.synchronize()
+        for _ in range(3):
+            _ops.emb_sort_slots(eng.ids, eng.row_base, eng.R, plan=eng.plan)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            _ops.emb_sort_slots(eng.ids, eng.row_base, eng.R, plan=eng.plan)
+        e1.record()
+        torch.cuda.synchronize()
+        plan_alone_us = e0.elapsed_time(e1) / 10 * 1e3
+
     kernels = eng.kernel_event_summary() if prof is not None else {}
     pairs = eng.concurrent_pair_summary() if (prof is not None and hasattr(eng, "concurrent_pair_summary")) else []
     if prof is not None:
@@ -450,6 +466,10 @@ def main():
                 pu = plan[0]["event_us_while_overlapped"]
                 roofline["plan_event_us_while_overlapped"] = pu
                 roofline["frac_with_plan_charged"] = round(roofline["achieved"] * roofline["avg_us"] / (roofline["avg_us"] + pu) / roofline["peak"], 4)
+            if plan_alone_us is not None and roofline["kernel"].startswith("emb_pool_bwd"):
+                roofline["plan_alone_us"] = round(plan_alone_us, 2)
+                roofline["frac_with_plan_alone_charged"] = round(
+                    roofline["achieved"] * roofline["avg_us"] / (roofline["avg_us"] + plan_alone_us) / roofline["peak"], 4)
         if mfma_rows:
             roofline_mfma = dict(mfma_rows[0])
     if roofline is not None:
