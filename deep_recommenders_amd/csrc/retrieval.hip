@@ -9,6 +9,7 @@
 // (2 entries per lane, k <= 128).  Only elements strictly greater than the current k-th score enter the list
 // (expected k*ln(N/k) insertions per row over the whole corpus), insertion = one rank count (wave sum) + a
 // lane shift (__shfl_up).  Ties resolve to the lower candidate index, as tf.math.top_k does.
+#include <cstdlib>
 #include "dr_common.h"
 #include "topk_list.h"
 #include <math.h>
@@ -227,8 +228,13 @@ extern "C" int dr_topk_select(const float* scores, int64_t ld, int64_t Bq, int64
 static int64_t topk_hdr_bytes(int64_t Bq) { return (Bq * 8 + 255) / 256 * 256; }
 
 // corpus chunk of the scan: ~256 MB of [Bq, chunk] scores (1024 output tiles of the register-split GEMM at Bq = 8192: 4 per CU)
+static int64_t topk_env(const char* name, int64_t dflt) {
+    const char* e = getenv(name);
+    return e != nullptr && e[0] != 0 ? atoll(e) : dflt;
+}
 static int64_t topk_chunk_for(int64_t Bq, int64_t N) {
-    int64_t chunk = (int64_t)(256ll << 20) / (Bq > 0 ? Bq * 4 : 4);
+    static const int64_t first_bytes = topk_env("DR_TOPK_FIRST_MB", 256) << 20;     // (experiment knob)
+    int64_t chunk = first_bytes / (Bq > 0 ? Bq * 4 : 4);
     chunk = chunk / 256 * 256;
     if (chunk < 256) chunk = 256;
     if (chunk > N) chunk = (N + 3) / 4 * 4;
@@ -240,10 +246,25 @@ static int64_t topk_chunk_for(int64_t Bq, int64_t N) {
 constexpr int TOPK_PLANES_MAX_D = 512;
 static int64_t topk_planes_bytes(int64_t chunk) { return ((3 * ((chunk + 31) / 32 * 32) * TOPK_PLANES_MAX_D * 2) + 255) / 256 * 256; }
 
+// chunk of the FILTERED part of the scan (everything behind the dense first chunk): four times as long -- a launch of the
+// register-split kernel then walks 16 tiles per block instead of 4 (one pipeline fill and drain per launch, one selection pass and
+// one split per chunk: 122 -> 32 rounds over a 1 M corpus).  The candidate lists' capacity stays "one slot per scanned column"
+// (cannot overflow, whatever the corpus order), so the workspace grows with it: 2.1 GB at Bq = 8192.
+constexpr int TOPK_SCAN_MULT = 4;
+static int64_t topk_scan_for(int64_t chunk, int64_t N) {
+    if (N <= chunk) return chunk;
+    int64_t rest = (N - chunk + 255) / 256 * 256;
+    static const int64_t scan_cols = topk_env("DR_TOPK_SCAN_COLS", 0);              // (experiment knob) 0: TOPK_SCAN_MULT x chunk
+    int64_t scan = scan_cols > 0 ? (scan_cols + 255) / 256 * 256 : chunk * TOPK_SCAN_MULT;
+    if (scan > rest) scan = rest;
+    return scan < chunk ? chunk : scan;
+}
+
 extern "C" int64_t dr_topk_workspace_bytes(int64_t Bq, int64_t N, int32_t k) {
     (void)k;
     const int64_t chunk = topk_chunk_for(Bq, N);
-    return topk_hdr_bytes(Bq) + Bq * chunk * 8 + topk_planes_bytes(chunk);
+    const int64_t scan = topk_scan_for(chunk, N);
+    return topk_hdr_bytes(Bq) + Bq * scan * 8 + topk_planes_bytes(scan);
 }
 
 int dr_scores_nt_filter(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t M, int32_t N, int32_t D,
@@ -283,22 +304,25 @@ extern "C" int dr_topk_mips(const float* q, int64_t Bq, const float* cand, int64
     // bit-exactly whichever chunk they sit in (the lower-index rule of tf.math.top_k depends on it).  Round 2 scanned with the
     // generic 128 x 128 kernel: 95 us per 4096-item chunk, 0.21 of the bf16x3 ceiling (24 ms per 8192 queries x 1 M items).
     int64_t chunk = topk_chunk_for(Bq, N);
-    const bool rs_scan = dr_get_gemm_mode() == DR_GEMM_BF16X3 && (D % 4) == 0 && D <= TOPK_PLANES_MAX_D && N > 0 &&
-                         (reinterpret_cast<uintptr_t>(q) & 15) == 0 &&
-                         workspace_bytes >= hdr + Bq * chunk * 8 + topk_planes_bytes(chunk);
+    int64_t scan = topk_scan_for(chunk, N);                                   // length of the filtered chunks (>= chunk)
+    const bool rs_ok = dr_get_gemm_mode() == DR_GEMM_BF16X3 && (D % 4) == 0 && D <= TOPK_PLANES_MAX_D && N > 0 &&
+                       (reinterpret_cast<uintptr_t>(q) & 15) == 0;
+    if (rs_ok && workspace_bytes < hdr + Bq * scan * 8 + topk_planes_bytes(scan)) scan = chunk;   // a round-2 sized workspace
+    const bool rs_scan = rs_ok && workspace_bytes >= hdr + Bq * scan * 8 + topk_planes_bytes(scan);
     if (!rs_scan) {
         chunk = (workspace_bytes - hdr) / (Bq * 8);
         chunk = chunk >= 128 ? chunk / 128 * 128 : chunk / 4 * 4;
+        scan = chunk;
     }
     if (chunk < 4 && N > 0) return DR_EINVAL;
     char* wsb = reinterpret_cast<char*>(workspace);
     int32_t* cnt = reinterpret_cast<int32_t*>(wsb);
     float* tau = reinterpret_cast<float*>(wsb + Bq * 4);
     float* dense = reinterpret_cast<float*>(wsb + hdr);                       // [Bq, chunk] scores (chunk 0)
-    float* cand_s = dense;                                                    // [Bq, chunk] candidate scores (later chunks)
-    int32_t* cand_c = reinterpret_cast<int32_t*>(wsb + hdr + Bq * chunk * 4); // [Bq, chunk] candidate columns
-    void* planes = wsb + hdr + Bq * chunk * 8;
-    const int64_t p_rows = (chunk + 31) / 32 * 32, p_ld = ((int64_t)D + 31) / 32 * 32, p_ps = p_rows * p_ld;
+    float* cand_s = dense;                                                    // [Bq, scan] candidate scores (later chunks)
+    int32_t* cand_c = reinterpret_cast<int32_t*>(wsb + hdr + Bq * scan * 4);  // [Bq, scan] candidate columns
+    void* planes = wsb + hdr + Bq * scan * 8;
+    const int64_t p_rows = (scan + 31) / 32 * 32, p_ld = ((int64_t)D + 31) / 32 * 32, p_ps = p_rows * p_ld;
     if (rs_scan && (D % 32) != 0)      // the reduction padding of the planes must be zero (the kernel multiplies it)
         if (hipMemsetAsync(planes, 0, (size_t)(3 * p_ps * 2), dr_s(stream)) != hipSuccess) return DR_ELAUNCH;
     const unsigned sel_grid = (unsigned)((Bq + 3) / 4);
@@ -307,8 +331,9 @@ extern "C" int dr_topk_mips(const float* q, int64_t Bq, const float* cand, int64
                            Bq * k);
     }
     int first = init;
-    for (int64_t c0 = 0; c0 < N; c0 += chunk) {
-        const int64_t nc = N - c0 < chunk ? N - c0 : chunk;
+    for (int64_t c0 = 0; c0 < N; c0 += (c0 == 0 ? chunk : scan)) {
+        const int64_t len = c0 == 0 ? chunk : scan;
+        const int64_t nc = N - c0 < len ? N - c0 : len;
         if (rs_scan) {
             int rc = dr_bf3_split(cand + c0 * D, D, nc, D, planes, p_ps, p_ld, 0, 0, 0, stream);
             if (rc != DR_OK) return rc;
@@ -321,10 +346,10 @@ extern "C" int dr_topk_mips(const float* q, int64_t Bq, const float* cand, int64
             hipLaunchKernelGGL(topk_select_kernel, dim3(sel_grid), dim3(256), 0, dr_s(stream), dense, chunk, Bq, nc, k,
                                index_base, first, out_scores, out_index, (const int32_t*)nullptr, (int32_t*)nullptr, tau);
         } else {
-            int rc = rs_scan ? dr_bf3_scores_filter(q, D, planes, p_ps, p_ld, Bq, (int32_t)nc, D, tau, cand_s, cand_c, cnt, chunk, stream)
-                             : dr_scores_nt_filter(q, D, cand + c0 * D, D, Bq, (int32_t)nc, D, tau, cand_s, cand_c, cnt, chunk, stream);
+            int rc = rs_scan ? dr_bf3_scores_filter(q, D, planes, p_ps, p_ld, Bq, (int32_t)nc, D, tau, cand_s, cand_c, cnt, scan, stream)
+                             : dr_scores_nt_filter(q, D, cand + c0 * D, D, Bq, (int32_t)nc, D, tau, cand_s, cand_c, cnt, scan, stream);
             if (rc != DR_OK) return rc;
-            hipLaunchKernelGGL(topk_select_kernel, dim3(sel_grid), dim3(256), 0, dr_s(stream), cand_s, chunk, Bq, nc, k,
+            hipLaunchKernelGGL(topk_select_kernel, dim3(sel_grid), dim3(256), 0, dr_s(stream), cand_s, scan, Bq, nc, k,
                                index_base + c0, 0, out_scores, out_index, cand_c, cnt, tau);
         }
         first = 0;
