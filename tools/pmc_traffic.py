@@ -56,7 +56,7 @@ def main():
     # instantiation: their traffic is then the average of the two; names absent from the profile are dropped by bench.py)
     event_names = {"emb_linear_fwd_L0": "bf3_emb_linear_kernel", "emb_pool_fwd": "emb_pool_fwd_sv_kernel<16,8>",
                    "emb_pool_bwd": "emb_bwd_sorted_kernel<16,4,false>", "hash_bucket_i64": "hash_bucket_i64_kernel",
-                   "linear_fwd_L0": "bf3_gemm_rs_kernel<0,0,1>", "linear_bwd_dx_L0": "bf3_gemm_rs_kernel<0,0,1>",
+                   "linear_fwd_L0": "bf3_gemm_rs_kernel<0,0,1,1>", "linear_bwd_dx_L0": "bf3_gemm_rs_kernel<0,0,1,1>",
                    "linear_bwd_dw_L0": "bf3_gemm_tn_rs_kernel<1>"}
     json.dump({"_note": note, "kernels": kernels, "event_names": event_names}, open(out_path, "w"), indent=1, sort_keys=True)
     for k, v in kernels.items():
