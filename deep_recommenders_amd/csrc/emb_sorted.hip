@@ -211,7 +211,10 @@ __device__ __forceinline__ void emb_bwd_dups_body(const int bid, const int nblk,
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         float dls = 0.f;
         int64_t j = i;
-        const float4 xhead = *reinterpret_cast<const float4*>(snap + (x_from_snap ? i : 0) * (int64_t)D + subc * 4);
+        // det: no piece of a hot row writes the row inside this kernel (the pieces are parked) and a row with ONE piece is read here,
+        // by its only writer, before that writer's store -- so x comes straight from the table and no snapshot is needed
+        const float4 xhead = (x_from_snap && det) ? *reinterpret_cast<const float4*>(table + k * (uint64_t)D + subc * 4)
+                                                  : *reinterpret_cast<const float4*>(snap + (x_from_snap ? i : 0) * (int64_t)D + subc * 4);
         bool done = !live || (ADAM && !seg_start);
         while (__any(!done)) {
             const int64_t jj = j + sub;

@@ -192,6 +192,7 @@ class DeepFMEngine:
         # their own on the side stream, beside the tower tail, instead of inside K4: a random 4-byte read-modify-write fetches a
         # 128-byte line, 0.27 GB of K4's 1.64 GB.  DR_LIN_SIDE=1 (off by default: see DESIGN.md for the A/B).
         self.lin_side = (sorted_bwd and optimizer == "sgd" and _os.environ.get("DR_LIN_SIDE", "0") == "1")
+        self._k4_det = _os.environ.get("DR_K4_DETERMINISTIC", "1") != "0"      # (read once per process by the library as well)
         self._planes_pending = False
         self._planes_pending_l0 = False
         # First-layer wgrad on a second stream, concurrent with the HBM-bound K4 on the training stream.  It paid next to the
@@ -508,7 +509,9 @@ class DeepFMEngine:
         elif self.sorted_bwd:
             if not (self._plan_prefetched and self.lean_events):
                 torch.cuda.current_stream().wait_event(self.ev_sorted)
-            if self.no_concat:     # x of the slots that share rows, before the update touches them (11 K rows for uniform ids)
+            if self.no_concat and not self._k4_det:
+                # x of the slots that share rows, before the atomic pieces of hot rows touch them (DR_K4_DETERMINISTIC=0 only: the
+                # deterministic update reads x from the table itself -- no row is written before its reader has it)
                 ops.emb_snapshot_sorted_rows(self.plan, self.table, self.R, self.x_sorted)
             mark = self._prefetch_mark()
             k4 = lambda parts: ops.emb_pool_bwd_sorted(self.ids, self.row_base, self.plan, D, self.R, self.d_concat, self.d_logit,

@@ -190,6 +190,8 @@ int dr_emb_pool_bwd_sorted(const int64_t* ids, const int64_t* row_base, const in
  * x_sorted [B * F, D], where dr_emb_snapshot_sorted_rows has placed -- before the update starts -- the row of every work-list
  * head at the head's sorted position (one row per piece of a shared row: 5.6 K rows for uniform ids at config 3)
  * (round 3: the fused first layer no longer stores concat, the wgrad gathers its operand from the tables -- dr_bf3_wgrad_emb).
+ * (With the deterministic SGD update below the snapshot is not needed: x is then read from the table inside the update -- no row
+ * is written before its reader has it.  The Adam variant and DR_K4_DETERMINISTIC=0 still read the snapshot.)
  * x_sorted also makes the SGD update of HOT rows (more than 32 slots of the batch, cut into pieces of 32 that run in parallel)
  * deterministic: with x_sorted == NULL the pieces combine with fp32 atomics (order-dependent rounding); with x_sorted given each
  * piece parks its sum in its own row of x_sorted (overwriting the snapshot it has consumed) and a second small launch inside
