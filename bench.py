@@ -353,6 +353,24 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         plan_alone_us = e0.elapsed_time(e1) / 10 * 1e3
+    # ... and K4 itself alone (same batch, its plan just rebuilt above; parts = 1: the update kernel only).  In the step its event
+    # time includes what sharing the chip with the next batch's hash + plan costs it, which varies from run to run; this is the
+    # kernel by itself.  (It applies the last batch's update ten more times -- after the timed region and the loss read-out.)
+    k4_alone_us = None
+    if plan_alone_us is not None and a.optimizer == "sgd" and getattr(eng, "d_concat", None) is not None:
+        k4 = lambda: _ops.emb_pool_bwd_sorted(eng.ids, eng.row_base, eng.plan, eng.D, eng.R, eng.d_concat, eng.d_logit, -eng.lr,
+                                              eng.table, eng.lin_w, eng.lin_bias,
+                                              concat=None if eng.no_concat else eng.concat, sum_x=eng.sum_x,
+                                              x_sorted=eng.x_sorted if eng.no_concat else None, parts=1)
+        for _ in range(3):
+            k4()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            k4()
+        e1.record()
+        torch.cuda.synchronize()
+        k4_alone_us = e0.elapsed_time(e1) / 10 * 1e3
 
     kernels = eng.kernel_event_summary() if prof is not None else {}
     pairs = eng.concurrent_pair_summary() if (prof is not None and hasattr(eng, "concurrent_pair_summary")) else []
@@ -466,6 +484,9 @@ def main():
                 pu = plan[0]["event_us_while_overlapped"]
                 roofline["plan_event_us_while_overlapped"] = pu
                 roofline["frac_with_plan_charged"] = round(roofline["achieved"] * roofline["avg_us"] / (roofline["avg_us"] + pu) / roofline["peak"], 4)
+            if k4_alone_us is not None and roofline["kernel"] == "emb_pool_bwd":
+                roofline["kernel_alone_us"] = round(k4_alone_us, 2)
+                roofline["frac_kernel_alone"] = round(roofline["achieved"] * roofline["avg_us"] / k4_alone_us / roofline["peak"], 4)
             if plan_alone_us is not None and roofline["kernel"].startswith("emb_pool_bwd"):
                 roofline["plan_alone_us"] = round(plan_alone_us, 2)
                 roofline["frac_with_plan_alone_charged"] = round(
