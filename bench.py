@@ -2,8 +2,13 @@
 """Headline benchmark: examples/sec of one DeepFM training step (Criteo-shaped synthetic, BASELINE.json
 configs[2]: 26 sparse + 13 dense, 10 M vocab per field, dim 64, batch 65 536 per GPU) on N MI355X GPUs.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched under
-torch.distributed.run, one rank per GPU.  Rank 0 prints ONE JSON line.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`.  For N > 1 it runs one rank per GPU over RCCL: either the
+caller wraps it (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N`;
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) or, when WORLD_SIZE is not set, bench.py starts the N ranks
+itself (same launcher, a free port on 127.0.0.1) after checking that N devices are visible.  Rank 0 prints ONE JSON line.
+`--launch-check`: rendezvous + one small exchange per collective, no training (runs on CPU over gloo: the launch path's unit
+test).  `--share-device`: all ranks on cuda:0 with host-staged collectives -- verification of the N > 1 data path on a 1-GPU
+box, never a measurement.
 
 A "step" = hash -> fused gather+pool+FM forward -> DNN forward -> sigmoid-CE -> DNN backward ->
 scatter-add backward, with the SGD update fused into the wgrad / scatter kernels (no work skipped).
@@ -13,6 +18,7 @@ import argparse
 import json
 import os
 import re
+import subprocess
 import sys
 import time
 
@@ -71,6 +77,12 @@ def parse():
     ap.add_argument("--towers", type=str, default="256,128", help="dssm: tower widths (last = embedding dim of the retrieval space)")
     ap.add_argument("--topk", type=int, default=100, help="dssm: k of the FactorizedTopK metric pass")
     ap.add_argument("--pool", type=int, default=8, help="number of distinct synthetic batches cycled through")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="start / join the N ranks, run one small exchange per collective through the engine's transport, print one JSON "
+                         "line; no model, no timing (gloo on a box without GPUs)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="N > 1 ranks all on cuda:0, collectives staged through the host over gloo (sharded.HostStagedTransport): checks "
+                         "the N > 1 data path with the real kernels on a 1-GPU box; the printed rate is NOT a measurement")
     a = ap.parse_args()
     if a.preset == "c2":
         a.fields, a.vocab, a.dim, a.dense, a.batch = 7, 10_000, 16, 0, 4096
@@ -214,6 +226,7 @@ def cpu_baseline(a, dnn_units):
     # 2.5 K examples/s on "256 cores", one tenth of what 8 threads of a small box reach) -- probe a few counts with two calls each
     # and keep the best; `cores` reports the threads actually used.
     best_nt, best_t = ncores, None
+    probe = {}
     for nt in sorted({min(ncores, c) for c in (8, 16, 32, 64, ncores)}):
         torch.set_num_threads(nt)
         train()
@@ -221,36 +234,115 @@ def cpu_baseline(a, dnn_units):
         train()
         train()
         dt = time.perf_counter() - t0
+        probe[str(nt)] = round(2 * B / dt, 1)
         if best_t is None or dt < best_t:
             best_nt, best_t = nt, dt
     torch.set_num_threads(best_nt)
     full, n1 = _median_rate(train, B, 5, 10, 10.0)
     fwd, n2 = _median_rate(fwd_only, B, 5, 20, 8.0)
     return {"value": full, "unit": "examples/sec", "cores": best_nt, "kind": "port", "forward_only_value": fwd, "host_logical_cpus": ncores,
+            "thread_probe_examples_per_sec": probe,      # two training calls per thread count; `cores` is the winner
             "sample": "median of %d DeepFM SGD steps (and %d forward-only passes) of batch %d on torch-CPU (oracle/torch_ref.py), 5 warm-up "
                       "calls each (BASELINE.md section 2: 5 + 20; the training leg stops at its 10 s cap); torch threads = %d, the best of a "
                       "probe over {8, 16, 32, 64, %d}; tables scaled to V=%d rows/field (%.1f GB); ids pre-hashed; DeepFM tower also for "
                       "--model dcn" % (n1, n2, B, best_nt, ncores, V, F * V * D * 4 / 1e9)}
 
 
+def _visible_gpus():
+    try:
+        return torch.cuda.device_count() if torch.cuda.is_available() else 0
+    except Exception:
+        return 0
+
+
+def _device_count_message(need, have):
+    return ("bench.py --gpus %d: %d GPU(s) visible on this node (torch.cuda.device_count()), %d needed -- one rank per GPU.  "
+            "Use --gpus <= %d, or --share-device to push the N > 1 data path through ONE GPU (verification only)."
+            % (need, have, need, max(have, 1)))
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks ourselves (torch.distributed.run, one process per
+    GPU, rendezvous on a free port of 127.0.0.1 -- the container hostname may not resolve) and exit with the launcher's status."""
+    have = _visible_gpus()
+    if not a.share_device and not (a.launch_check and have == 0) and have < a.gpus:
+        raise SystemExit(_device_count_message(a.gpus, have))
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % a.gpus, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    env["DR_BENCH_SELF_LAUNCHED"] = "1"
+    print("[bench] starting %d ranks: %s" % (a.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def launch_check(a, world, rank, device, dist, transport):
+    """One small instance of every collective the sharded engines issue, through the transport they would use; rank 0 prints the line."""
+    ok = {}
+    t = torch.full((4,), float(rank + 1), device=device)
+    transport.allreduce(t)
+    ok["allreduce"] = bool(abs(float(t[0]) - world * (world + 1) / 2) < 1e-6)
+    send = (torch.arange(world * 3, device=device, dtype=torch.int64) + 100 * rank).view(world * 3, 1).contiguous()
+    recv = torch.empty_like(send)
+    transport.alltoall(recv, send, [3] * world, [3] * world)
+    want = torch.cat([torch.arange(rank * 3, rank * 3 + 3, dtype=torch.int64) + 100 * r for r in range(world)])
+    ok["alltoall"] = bool(torch.equal(recv.view(-1).cpu(), want))
+    g = torch.empty((world * 2,), device=device)
+    transport.allgather(g, torch.full((2,), float(rank), device=device))
+    ok["allgather"] = bool(torch.equal(g.view(world, 2)[:, 0].cpu(), torch.arange(world, dtype=torch.float32)))
+    seen = [None] * world
+    dist.all_gather_object(seen, {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device": str(device),
+                                  "pid": os.getpid(), "ok": ok})
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": dist.get_world_size(), "backend": dist.get_backend(), "gpus_visible": _visible_gpus(),
+                          "self_launched": os.environ.get("DR_BENCH_SELF_LAUNCHED") == "1", "transport": type(transport).__name__,
+                          "ranks": seen, "all_ok": all(all(r["ok"].values()) for r in seen)}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        self_launch(a)                  # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus %d needs a torch.distributed.run launch with %d ranks" % (a.gpus, a.gpus))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    dnn_units = [int(x) for x in a.dnn.split(",") if x]
-    from deep_recommenders_amd import ops as dr_ops
-    dr_ops.set_gemm_mode(a.gemm)
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: the launcher's --nproc-per-node must equal --gpus" % (a.gpus, world))
+    have = _visible_gpus()
+    cpu_only = a.launch_check and have == 0
+    if a.share_device:
+        local_rank = 0
+    if not cpu_only and local_rank >= have:
+        raise SystemExit(_device_count_message(a.gpus, have))
+    device = torch.device("cpu") if cpu_only else torch.device("cuda", local_rank)
+    if not cpu_only:
+        torch.cuda.set_device(local_rank)
     dist = None
+    transport = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        from deep_recommenders_amd import sharded as _sh
+        if cpu_only or a.share_device:
+            dist.init_process_group("gloo")
+            transport = _sh.TorchDistTransport() if cpu_only else _sh.HostStagedTransport()
+        else:
+            dist.init_process_group("nccl", device_id=device)
+            transport = _sh.default_transport(world, rank)
+    if a.launch_check:
+        if dist is None:
+            print(json.dumps({"launch_check": True, "n_gpus": 1, "gpus_visible": have, "note": "one rank: nothing to rendezvous"}), flush=True)
+            return
+        return launch_check(a, world, rank, device, dist, transport)
+    dnn_units = [int(x) for x in a.dnn.split(",") if x]
+    from deep_recommenders_amd import ops as dr_ops
+    dr_ops.set_gemm_mode(a.gemm)
 
     force_sharded = os.environ.get("DR_FORCE_SHARDED", "0") == "1"      # exercise the N>1 code path on one GPU
     if world == 1 and force_sharded:
@@ -264,7 +356,8 @@ def main():
         towers = [int(x) for x in a.towers.split(",") if x]
         if sharded:
             from deep_recommenders_amd.sharded_retrieval import ShardedTwoTowerEngine
-            eng = ShardedTwoTowerEngine(a.users, a.items, a.dim, towers, a.batch, lr=a.lr, k=a.topk, device=device, world=world, rank=rank)
+            eng = ShardedTwoTowerEngine(a.users, a.items, a.dim, towers, a.batch, lr=a.lr, k=a.topk, device=device, world=world, rank=rank,
+                                        transport=transport)
         else:
             from deep_recommenders_amd.two_tower_engine import TwoTowerEngine
             eng = TwoTowerEngine(a.users, a.items, a.dim, towers, a.batch, lr=a.lr, k=a.topk, device=device)
@@ -279,7 +372,7 @@ def main():
             if sharded:
                 from deep_recommenders_amd.sharded import ShardedDCNEngine
                 eng = ShardedDCNEngine(a.fields, a.vocab, a.dim, 3, dnn_units, a.batch, num_dense=a.dense, lr=a.lr, device=device,
-                                       world=world, rank=rank)
+                                       world=world, rank=rank, transport=transport)
             else:
                 from deep_recommenders_amd.dcn_engine import DCNEngine
                 eng = DCNEngine(a.fields, a.vocab, a.dim, 3, dnn_units, a.batch, num_dense=a.dense, lr=a.lr, device=device)
@@ -290,7 +383,7 @@ def main():
         else:
             from deep_recommenders_amd.sharded import ShardedDeepFMEngine
             eng = ShardedDeepFMEngine(a.fields, a.vocab, a.dim, dnn_units, a.batch, num_dense=a.dense, lr=a.lr,
-                                      device=device, world=world, rank=rank, micro_batches=a.micro_batches,
+                                      device=device, world=world, rank=rank, micro_batches=a.micro_batches, transport=transport,
                                       **({"optimizer": a.optimizer} if a.optimizer != "sgd" else {}))
         batches = synth_batches(a, device, rank)
         nb = len(batches)
@@ -331,7 +424,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if a.share_device else device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     loss = float(eng.loss.item())
@@ -374,6 +467,12 @@ def main():
 
     kernels = eng.kernel_event_summary() if prof is not None else {}
     pairs = eng.concurrent_pair_summary() if (prof is not None and hasattr(eng, "concurrent_pair_summary")) else []
+    exchange = None
+    if prof is not None and hasattr(eng, "exchange_report"):
+        exchange = eng.exchange_report(a.steps)                  # (before the events are dropped below)
+        exchange["ranks_in_process_group"] = dist.get_world_size() if dist is not None else 1
+        exchange["gpus_visible"] = have
+        exchange["backend"] = dist.get_backend() if dist is not None else None
     if prof is not None:
         eng.enable_kernel_events(False)
     if a.model == "dssm":
@@ -401,8 +500,9 @@ def main():
     # HBM traffic per launch from the PMC counters: NOT measured in this run -- replayed from the committed rocprofv3 --pmc
     # passes of this same command (profiles/, see `traffic_source`), only for the default configuration they were taken on
     traffic, traffic_source = {}, None
+    traffic_note = "HBM counters need the profiler (rocprofv3 --pmc passes of this command, tools/collect_profiles.sh); not collected inside bench.py"
     try:
-        src = next(("profiles/%s_pmc_traffic.json" % r for r in ("r03", "r02", "r01")
+        src = next(("profiles/%s_pmc_traffic.json" % r for r in ("r04", "r03", "r02", "r01")
                     if os.path.exists(os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % r))), "profiles/r01_pmc_traffic.json")
         pmc = json.load(open(os.path.join(ROOT, src)))
         name_map = pmc.get("event_names") or {}
@@ -411,8 +511,12 @@ def main():
         if default_cfg and world == 1 and not force_sharded:
             traffic = {ev: int(pmc["kernels"][k]["hbm_bytes_corrected"]) for ev, k in name_map.items() if k in pmc["kernels"]}
             traffic_source = src + " (static: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run)"
-    except Exception:
+        else:
+            traffic_note = ("the committed PMC passes (%s) were taken on the default configuration (deepfm, B 65536, 26 x 10 M x 64, DNN 256,32, sgd, "
+                            "bf16x3, one GPU); this run differs, so no traffic figure applies" % src)
+    except Exception as e:
         traffic = {}
+        traffic_note = "no committed PMC file readable (%r)" % (e,)
     roof_all = []
     comm_phases = {}
     overlapped = {}
@@ -420,6 +524,8 @@ def main():
         sec = k["ms"] * 1e-3
         if k["bound"] == "xgmi":      # exchange phases (all-to-all / all-reduce + their local halves): reported apart
             comm_phases[name] = {"avg_us": round(k["ms"] * 1e3, 2), "bytes_per_rank": k.get("alg_bytes"), "launches": k["n"]}
+            continue
+        if k["bound"] == "stall":     # training-stream waits on exchange events: reported in `exchange`
             continue
         if k["bound"] == "overlap":   # side-stream work hidden under the main stream: its event time is stretched by the sharing
             overlapped[name] = {"event_us_while_overlapped": round(k["ms"] * 1e3, 2), "launches": k["n"], "alg_bytes": k.get("alg_bytes")}
@@ -437,11 +543,20 @@ def main():
         if k["bound"] == "mfma":
             row["peak_basis"] = ("dense bf16 MFMA peak 2500 TFLOP/s / 6 products per fp32 product" if on_bf16
                                  else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)")
-            row["frac_of_f32_mfma_peak"] = round(ach / MFMA_F32_PEAK_TF, 4)
         if name == "emb_linear_fwd_L0":      # K3 fused into the first layer's GEMM: priced on the MFMA side, its HBM side stated too
-            alg = eng.alg_bytes_fwd() + 4.0 * a.batch * int(dnn_units[0]) if hasattr(eng, "alg_bytes_fwd") else None
-            row["note"] = ("K3 (gather + concat + first-order + FM) runs inside this GEMM: besides the flops it moves K3's algorithmic "
-                           "bytes + the layer output%s" % (" = %.0f MB -> %.0f GB/s, %.3f of the HBM peak" % (alg / 1e6, alg / sec / 1e9, alg / sec / 1e9 / HBM_PEAK_GBS) if alg else ""))
+            # bytes this kernel MUST move: ids + table rows + first-order weights + dense features in, layer output + sum_x + fm_logit
+            # out (+ the gathered embeddings only when `concat` is still stored, DR_NO_CONCAT=0).  SURVEY section 8(d)'s K3 figure
+            # (8FD + 12F + 8 per example) includes the 4FD concat WRITE, which the no-concat kernel does not perform: kept beside it,
+            # labelled, not used for the fraction.
+            Fq, Dq, N0 = a.fields, a.dim, int(dnn_units[0]) if dnn_units else 1
+            stores_concat = not getattr(eng, "no_concat", False)
+            must = a.batch * (8 * Fq + 4 * Fq * Dq + 4 * Fq + 4 * a.dense + 4 * N0 + 4 * Dq + 4 + (4 * Fq * Dq if stores_concat else 0))
+            sv = eng.alg_bytes_fwd() if hasattr(eng, "alg_bytes_fwd") else None
+            row["hbm_side"] = {"bytes_that_must_move": int(must), "GBps": round(must / sec / 1e9, 1), "frac_of_hbm_peak": round(must / sec / 1e9 / HBM_PEAK_GBS, 4),
+                               "concat_stored": stores_concat,
+                               "survey_8d_k3_bytes_plus_output": int(sv + 4.0 * a.batch * N0) if sv else None,
+                               "note": "K3 (gather + first-order + FM) runs inside this GEMM; the fraction is on the bytes the kernel must move, "
+                                       "the section-8(d) figure beside it still counts a concat write this kernel no longer does"}
         if k.get("note"):
             row["note"] = k["note"]
         if k.get("concurrent_with"):
@@ -493,8 +608,36 @@ def main():
                     roofline["achieved"] * roofline["avg_us"] / (roofline["avg_us"] + plan_alone_us) / roofline["peak"], 4)
         if mfma_rows:
             roofline_mfma = dict(mfma_rows[0])
+    # measured device-to-device copy ceiling next to the spec peak: hipMemcpyDtoD of 1 GiB, read + write bytes
+    copy_gbs = None
+    try:
+        if world == 1 or not a.share_device:
+            src_c = torch.empty(1 << 28, dtype=torch.float32, device=device)
+            dst_c = torch.empty_like(src_c)
+            src_c.zero_()
+            for _ in range(2):
+                dst_c.copy_(src_c)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                dst_c.copy_(src_c)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbs = 2.0 * src_c.numel() * 4 / (e0.elapsed_time(e1) / 5 * 1e-3) / 1e9
+            del src_c, dst_c
+    except Exception:
+        copy_gbs = None
     if roofline is not None:
         roofline["traffic_source"] = traffic_source
+        if traffic_source is None:
+            roofline["traffic_note"] = traffic_note
+        roofline["peak_basis"] = roofline.get("peak_basis") or "HBM3E spec peak 8.0 TB/s (MI355X_MICROARCH.md)"
+        if copy_gbs is not None and roofline.get("unit") == "GB/s":
+            roofline["measured_copy_ceiling_GBps"] = round(copy_gbs, 1)      # 1 GiB hipMemcpyDtoD on this box, read + write bytes
+            roofline["frac_of_measured_copy_ceiling"] = round(roofline["achieved"] / copy_gbs, 4)
+        roofline["event_scope"] = ("HIP events on the launch stream around each kernel, every %d-th step of the timed region; an event pair also "
+                                   "spans cross-stream waits queued in front of the kernel, so it reads 3-10 %% above rocprofv3's kernel-only "
+                                   "duration (profiles/)" % ev_every)
 
     if rank == 0:
         opt_s = "SGD" if a.optimizer == "sgd" else "Adam (row-wise on the tables)"
@@ -523,7 +666,7 @@ def main():
                                                        "; item table and corpus row-sharded over %d GPUs" % world if sharded else ""))
         out = {
             "metric": metric,
-            "value": round(value, 1), "unit": "examples/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "value": round(value, 1), "unit": "examples/sec", "n_gpus": dist.get_world_size() if (dist is not None and world > 1) else 1, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong" if a.global_batch else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload,
@@ -541,6 +684,10 @@ def main():
         out.update(extra)
         if comm_phases:
             out["exchange_phases"] = comm_phases
+        if exchange is not None:
+            out["exchange"] = exchange
+        if a.share_device:
+            out["NOT_A_MEASUREMENT"] = "--share-device: all ranks on cuda:0, collectives staged through the host over gloo (data-path check only)"
         if overlapped:
             out["overlapped_side_stream"] = overlapped
         if world == 1 and not a.no_cpu_baseline:

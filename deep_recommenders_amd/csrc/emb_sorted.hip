@@ -19,6 +19,33 @@ namespace {
 
 constexpr int CH = 32;   // a lane group sums at most CH consecutive sorted slots (bounds hot-row serialisation)
 
+// Nontemporal 16-byte accesses for the three streams of the unique-row pass: the gradient (read once), the table rows (read once,
+// written once, both lines of a row fully overwritten by the lane group) -- nothing of it is reused inside the kernel, and with the
+// default policy those 1.3 GB of lines wash through the L2 / Infinity Cache next to the 4-byte first-order weights, whose
+// read-modify-write is the one access that wants to find its line still cached.  Measured at config 3 (tools/exp/k4_ladder.py, round
+// 4, same tensors in one process): 331 us default policy -> 316 nt row loads only -> 281 us nt on all three.  DR_K4_NT=0 at
+// compile time restores the default policy (A/B builds).
+#ifndef DR_K4_NT
+#define DR_K4_NT 1
+#endif
+typedef float dr_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_stream(const float* p) {
+#if DR_K4_NT
+    const dr_f4v v = __builtin_nontemporal_load(reinterpret_cast<const dr_f4v*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const float4*>(p);
+#endif
+}
+__device__ __forceinline__ void st4_stream(float* p, const float4 v) {
+#if DR_K4_NT
+    const dr_f4v w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<dr_f4v*>(p));
+#else
+    *reinterpret_cast<float4*>(p) = v;
+#endif
+}
+
 // Fast path: streams the gradient in example order (coalesced), one wave per example; every slot whose row is
 // unique in the batch gets ONE plain 16-byte-per-lane load / fma / store of its table row.  No atomics.
 // Branch-free load phase (see emb_pool_fwd_sv_kernel in emb_pool.hip for why): every load of the
@@ -104,15 +131,18 @@ __device__ __forceinline__ void emb_bwd_unique_body(const int bid, const int nbl
                 row[u] = __shfl(my_row, fc, 64);
                 if (f >= F) row[u] = -1;
                 const int64_t rc = row[u] >= 0 ? row[u] : 0;
-                g[u] = *reinterpret_cast<const float4*>(grow + fc * D + subc * 4);
-                t[u] = *reinterpret_cast<const float4*>(table + rc * D + subc * 4);
-                lw[u] = lsrc[rc];
+                // (without a first-order table the dummy loads below read ONE address: indexed by the row they were a random
+                // 4-byte gather over the first gigabyte of `table` -- a line fetch per slot for nothing, 273 vs 236 us; round 4)
+                const int64_t lc = lin_w != nullptr ? rc : 0;
+                g[u] = ld4_stream(grow + fc * D + subc * 4);
+                t[u] = ld4_stream(table + rc * D + subc * 4);
+                lw[u] = lsrc[lc];
                 gl[u] = slot_lin != nullptr ? slot_lin[b * F + fc] : dl;
                 if (ADAM) {
-                    mt[u] = *reinterpret_cast<const float4*>(ad.m + rc * D + subc * 4);
-                    vt[u] = *reinterpret_cast<const float4*>(ad.v + rc * D + subc * 4);
-                    ml[u] = mlsrc[rc];
-                    vl[u] = vlsrc[rc];
+                    mt[u] = ld4_stream(ad.m + rc * D + subc * 4);
+                    vt[u] = ld4_stream(ad.v + rc * D + subc * 4);
+                    ml[u] = mlsrc[(ad.m_lin != nullptr) ? rc : 0];
+                    vl[u] = vlsrc[(ad.v_lin != nullptr) ? rc : 0];
                 }
             }
 #pragma unroll
@@ -134,10 +164,10 @@ __device__ __forceinline__ void emb_bwd_unique_body(const int bid, const int nbl
                 }
                 if (row[u] >= 0) {
                     if (dvalid) {
-                        *reinterpret_cast<float4*>(table + row[u] * D + sub * 4) = r;
+                        st4_stream(table + row[u] * D + sub * 4, r);
                         if (ADAM) {
-                            *reinterpret_cast<float4*>(ad.m + row[u] * D + sub * 4) = mt[u];
-                            *reinterpret_cast<float4*>(ad.v + row[u] * D + sub * 4) = vt[u];
+                            st4_stream(ad.m + row[u] * D + sub * 4, mt[u]);
+                            st4_stream(ad.v + row[u] * D + sub * 4, vt[u]);
                         }
                     }
                     if (do_lin) {

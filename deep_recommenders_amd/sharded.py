@@ -145,10 +145,12 @@ class CApiTransport:
     def alltoall(self, out, inp, out_splits=None, in_splits=None):
         assert out.is_contiguous() and inp.is_contiguous() and out.dtype == inp.dtype
         L, W = self._C.lib(), self.world
-        row = inp.element_size() * (inp[0].numel() if inp.dim() > 1 else 1)          # bytes per leading-dimension element
+        row = inp.element_size() * math.prod(inp.shape[1:])          # bytes per leading-dimension element (no indexing: a rank may send nothing)
         if out_splits is None:
             per = inp.shape[0] // W
             in_splits = out_splits = [per] * W
+        if not any(in_splits) and not any(out_splits):
+            return out
         arr = self._ct.c_int64 * W
         self._C.check(L.dr_coll_alltoallv(self._comm, inp.data_ptr(), arr(*in_splits), out.data_ptr(), arr(*out_splits), row,
                                           self._stream()), "dr_coll_alltoallv")
@@ -235,7 +237,14 @@ class ShardedEmbeddingExchange:
         self._slots = [dict(cap=0, rows_pad=None, g_pad=None, gl_pad=None, plan=None, ids=None) for _ in range(self.SLOTS)]
         self._next_slot = 0
 
-    def _a2a(self, out, inp, out_splits, in_splits):
+    # bench.py's exchange report: when set, called as phase_timer(tag, bytes_sent_by_this_rank, fn) around every data-path collective
+    # (tags "a2a_ids" = C1, "a2a_rows" = C2, "a2a_grads" = C3) -- the engines bracket fn with HIP events
+    phase_timer = None
+
+    def _a2a(self, out, inp, out_splits, in_splits, tag=None):
+        if self.phase_timer is not None and tag is not None:
+            nbytes = inp.numel() * inp.element_size()
+            return self.phase_timer(tag, nbytes, lambda: self.tr.alltoall(out, inp, out_splits, in_splits))
         return self.tr.alltoall(out, inp, out_splits, in_splits)
 
     def _ensure_capacity(self, sl, n_recv, device):
@@ -325,7 +334,7 @@ class ShardedEmbeddingExchange:
                 r.n_pad = self._ensure_capacity(sl, r.n_recv, r.pos.device)
                 rows_pad = sl["rows_pad"][:r.n_pad]
                 rows_pad[r.n_recv:].fill_(-1)
-                self._a2a(rows_pad[:r.n_recv], r._send_rows, r.recv_splits, r.send_splits)      # C1
+                self._a2a(rows_pad[:r.n_recv], r._send_rows, r.recv_splits, r.send_splits, tag="a2a_ids")      # C1
             else:
                 rows_pad = sl["rows_pad"][:r.n_pad]
             if self._cuda:
@@ -356,7 +365,7 @@ class ShardedEmbeddingExchange:
         if self.local:
             return rows_buf, lin_buf                                                   # the gather output IS the receive buffer
         got_rows = torch.empty((r.n, self.D), dtype=torch.float32, device=recv_rows.device)
-        self._a2a(got_rows, rows_buf, r.send_splits, r.recv_splits)                   # C2
+        self._a2a(got_rows, rows_buf, r.send_splits, r.recv_splits, tag="a2a_rows")   # C2
         got_lin = None
         if lin_local is not None:
             got_lin = torch.empty(r.n, dtype=torch.float32, device=recv_rows.device)
@@ -412,7 +421,7 @@ class ShardedEmbeddingExchange:
             if g_lin is not None:
                 g_lin.record_stream(cur)
         if not self.local:
-            self._a2a(g_pad[:r.n_recv], g_rows, r.recv_splits, r.send_splits)         # C3
+            self._a2a(g_pad[:r.n_recv], g_rows, r.recv_splits, r.send_splits, tag="a2a_grads")         # C3
             if r.has_lin:
                 self._a2a(gl_pad[:r.n_recv], g_lin, r.recv_splits, r.send_splits)
         if self._cuda:
@@ -589,12 +598,26 @@ class ShardedDeepFMEngine:
     # ---- per-phase HIP events (same contract as engine.DeepFMEngine) -------------------------------------------
     def enable_kernel_events(self, on: bool):
         self._events = {} if (on and self._cuda) else None
+        # the collectives themselves (C1 / C2 / C3), apart from the local kernels of their phases: bench.py's per-link rates
+        self.ex.phase_timer = (lambda tag, nbytes, fn: self._k(tag, "xgmi", nbytes, fn)) if self._events is not None else None
+
+    def _stall(self, name, stream, event):
+        """stream.wait_event(event), bracketed (when events are on) by two records on `stream`: their distance is the time the
+        stream sat idle waiting for the exchange -- the EXPOSED, non-overlapped part of the communication (bench.py sums them)."""
+        if self._events is None:
+            stream.wait_event(event)
+            return
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(stream)
+        stream.wait_event(event)
+        e.record(stream)
+        self._events.setdefault(name, ["stall", 0, []])[2].append((s, e))
 
     # Phases that get HIP events in bench.py.  The sharded step issues ~3x the launches of the single-GPU step (two
     # micro-batches, exchanges, routing) and its host thread is the scarcer resource: two event records around every small
     # kernel were enough to leave ~30 us bubbles between kernels, so only the coarse phases are bracketed.
     _TIMED = ("emb_fetch", "emb_pool_fwd", "emb_linear_fwd_L0", "linear_fwd_L0", "linear_bwd_dx_L0", "linear_bwd_dw_L0", "emb_pack_grads",
-              "emb_grads", "allreduce_dense_grads", "emb_route")
+              "emb_grads", "allreduce_dense_grads", "emb_route", "a2a_", "stall_")
 
     def _k(self, name, bound, work, fn):
         if self._events is None or not name.startswith(self._TIMED):
@@ -616,6 +639,30 @@ class ShardedDeepFMEngine:
             key = "alg_bytes" if bound in ("hbm", "xgmi") else "alg_flops"
             out[name] = {"bound": bound, "ms": ms, "n": len(evs), key: work}
         return out
+
+    def exchange_report(self, steps):
+        """What bench.py prints for an N-rank run: per collective the bytes this rank sent, its mean duration and the rate per xGMI link
+        (a rank's all-to-all payload leaves over world - 1 links, (world - 1) / world of it); `exposed_us_per_step` = time the training
+        stream sat idle waiting for rows / for the last owner-side update (the part of the exchange that no compute hid)."""
+        ks = self.kernel_event_summary()
+        W = self.world
+        rep = {"world": W, "micro_batches": self.mb, "transport": type(self.tr).__name__, "collectives": {}, "exposed_us_per_step": None}
+        for tag, what in (("a2a_ids", "C1 row ids to their owners"), ("a2a_rows", "C2 embedding rows back"), ("a2a_grads", "C3 row gradients to their owners"),
+                          ("allreduce_dense_grads", "C4 dense-tower gradients")):
+            k = ks.get(tag)
+            if k is None:
+                continue
+            sec = k["ms"] * 1e-3
+            sent = float(k["alg_bytes"])
+            on_wire = sent * (W - 1) / W if tag != "allreduce_dense_grads" else 2.0 * sent * (W - 1) / W      # ring all-reduce: 2 (W-1)/W
+            rep["collectives"][tag] = {"what": what, "bytes_sent_per_rank": int(sent), "avg_us": round(k["ms"] * 1e3, 2), "calls": k["n"],
+                                       "GBps_per_rank": round(on_wire / sec / 1e9, 2) if sec > 0 else None,
+                                       "GBps_per_link": round(on_wire / max(W - 1, 1) / sec / 1e9, 2) if (sec > 0 and W > 1) else None}
+        stalls = [k for n, k in ks.items() if n.startswith("stall_")]
+        if stalls and steps:
+            rep["exposed_us_per_step"] = round(sum(k["ms"] * k["n"] for k in stalls) * 1e3 / steps, 2)
+            rep["exposed_parts_us_per_step"] = {n: round(k["ms"] * k["n"] * 1e3 / steps, 2) for n, k in ks.items() if n.startswith("stall_")}
+        return rep
 
     def _mb_slices(self):
         Bm = self.B // self.mb
@@ -749,7 +796,7 @@ class ShardedDeepFMEngine:
         for m, sl in enumerate(slices):
             # ---- step 6 + tower forward + loss ----------------------------------------------------------------------
             if cuda:
-                main.wait_event(ev_rows[m])
+                self._stall("stall_rows(training stream waits for C2)", main, ev_rows[m])
                 if ev_fwd[m] is not None:
                     main.wait_event(ev_fwd[m])
             if not fused_l0:
@@ -875,7 +922,7 @@ class ShardedDeepFMEngine:
         if adam and self.fuse_head:
             self.loss.mul_(W)          # loss_parts were normalised by the global batch: report the rank's mean like the SGD mode
         if cuda:
-            main.wait_event(ev_last_apply)                 # the step ends when every owner has applied its updates
+            self._stall("stall_apply(training stream waits for C3 + owner-side update)", main, ev_last_apply)   # the step ends when every owner has applied its updates
             ev = torch.cuda.Event()
             ev.record()
             self._done.append(ev)
