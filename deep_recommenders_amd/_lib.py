@@ -104,6 +104,7 @@ SIGNATURES = {
     "dr_dropout_fwd": [_p, _i64, _i64, _i32, _f32, _u64, _p, _i64, _p, _p],
     "dr_dropout_bwd": [_p, _i64, _p, _i64, _i32, _f32, _p, _i64, _p],
     "dr_reduce_sum": [_p, _i64, _i32, _f32, _i32, _p, _p, _p],
+    "dr_clock_stamp": [_p, _p],
     "dr_version": [],
     "dr_set_gemm_mode": [_i32],
     "dr_get_gemm_mode": [],

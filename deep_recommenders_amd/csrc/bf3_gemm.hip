@@ -27,6 +27,17 @@
 //       of a ds_read_b128 lane group fall on 16 distinct 16-byte slots of the 256-byte bank row (conflict-free)
 //   TN: per plane [32 r][cols] = 256/512-byte rows; chunk c of row r sits at c ^ ((r & 3) << 2) -> the 4 rows x 64 bytes a
 //       32-lane half of ds_read_b64_tr_b16 touches fall on 4 distinct 64-byte quarters of the bank row
+// Cache-policy experiments (round 4): streams that are read / written ONCE marked nontemporal so that they do not wash the weight
+// planes (and, in K4, the first-order lines) out of the L2 / Infinity Cache.  0 = default policy; aux 2 = nt.
+#ifndef DR_NT_FWD_GATHER
+#define DR_NT_FWD_GATHER 1
+#endif
+#ifndef DR_NT_WGRAD_GATHER
+#define DR_NT_WGRAD_GATHER 0
+#endif
+#ifndef DR_NT_DGRAD_STORE
+#define DR_NT_DGRAD_STORE 0
+#endif
 #include "dr_common.h"
 #include "bf3_split.h"
 #include <cstdlib>
@@ -983,7 +994,8 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
                         for (int reg = 0; reg < 16; ++reg) {
                             float v = acc[ms][nt][reg] + bj;
                             acc[ms][nt][reg] = 0.f;
-                            crow[(int64_t)((reg & 3) + 8 * (reg >> 2)) * g.ldc] = relu ? fmaxf(v, 0.f) : v;
+                            if (DR_NT_DGRAD_STORE && EPI == 0) __builtin_nontemporal_store(relu ? fmaxf(v, 0.f) : v, &crow[(int64_t)((reg & 3) + 8 * (reg >> 2)) * g.ldc]);
+                            else crow[(int64_t)((reg & 3) + 8 * (reg >> 2)) * g.ldc] = relu ? fmaxf(v, 0.f) : v;
                         }
                     }
                 } else {
@@ -1151,7 +1163,7 @@ __global__ __launch_bounds__(512, 2) void bf3_emb_linear_kernel(RsArgs g, EmbArg
             // (one DMA with a selected resource, not one under each arm of a branch: with the branch hipcc's wait for anything
             // older than these DMAs comes out as vmcnt(0))
             __builtin_amdgcn_struct_ptr_buffer_load_lds(dense ? drsrc : trsrc, (lds_ptr_t)dst, 16, idx,
-                                                        gchunk * 16 + (dense ? 0 : (kt & 1) * 128), 0, 0, 0);
+                                                        gchunk * 16 + (dense ? 0 : (kt & 1) * 128), 0, 0, DR_NT_FWD_GATHER ? 2 : 0);
         }
         return m4;
     };
@@ -1340,7 +1352,7 @@ __global__ __launch_bounds__(512, 2) void bf3_emb_linear_kernel(RsArgs g, EmbArg
                         const int idx = dense ? grow_row(m02, i) : max(idg_use[i], 0);
                         unsigned char* dst = smem + A_BASE + astage * A_STAGE + wave * A_WAVE + i * 1024;
                         __builtin_amdgcn_struct_ptr_buffer_load_lds(dense ? drsrc : trsrc, (lds_ptr_t)dst, 16, idx,
-                                                                    gchunk * 16 + (dense ? 0 : (kt2 & 1) * 128), 0, 0, 0);
+                                                                    gchunk * 16 + (dense ? 0 : (kt2 & 1) * 128), 0, 0, DR_NT_FWD_GATHER ? 2 : 0);
                     }
                     m4q = (m4q >> 4) | (m4 << 4);
                 }
@@ -1556,7 +1568,7 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_tn_rs_kernel(TnRsArgs g) {
             if (w_field) idx = (unsigned)__builtin_amdgcn_update_dpp(0, ids_of_tile, 0x150 + E, 0xf, 0xf, false);        \
             else idx = (unsigned)(r < r_end ? r : r_end - 1);                                                            \
             if (!full && !(r < r_end)) { idx = w_field ? 0x00FFFFFFu : idx; vm &= ~(1 << E); }                           \
-            dst[E] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grsrc, (int)(idx * gpitch + gcol), 0, 0)); \
+            dst[E] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grsrc, (int)(idx * gpitch + gcol), 0, DR_NT_WGRAD_GATHER ? 2 : 0)); \
         }
         GATHER_ONE(0) GATHER_ONE(1) GATHER_ONE(2) GATHER_ONE(3) GATHER_ONE(4) GATHER_ONE(5) GATHER_ONE(6) GATHER_ONE(7)
         GATHER_ONE(8) GATHER_ONE(9) GATHER_ONE(10) GATHER_ONE(11) GATHER_ONE(12) GATHER_ONE(13) GATHER_ONE(14) GATHER_ONE(15)

@@ -11,6 +11,29 @@
 
 namespace {
 
+// The owner-side gather and the requester-side pack move every byte exactly once (random rows in, packed rows out; gradient rows in,
+// permuted rows out): all their 16-byte accesses are nontemporal, like K4's (emb_sorted.hip; round 4).  DR_SHARD_NT=0: default policy.
+#ifndef DR_SHARD_NT
+#define DR_SHARD_NT 1
+#endif
+typedef float sh_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_once(const float* p) {
+#if DR_SHARD_NT
+    const sh_f4v v = __builtin_nontemporal_load(reinterpret_cast<const sh_f4v*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const float4*>(p);
+#endif
+}
+__device__ __forceinline__ void st4_once(float* p, const float4 v) {
+#if DR_SHARD_NT
+    const sh_f4v w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<sh_f4v*>(p));
+#else
+    *reinterpret_cast<float4*>(p) = v;
+#endif
+}
+
 constexpr int MAXW = 16;           // max world size for the bucketing kernels
 constexpr int SLOTS_PER_THREAD = 8;
 constexpr int CHUNK = 256 * SLOTS_PER_THREAD;
@@ -169,15 +192,15 @@ __global__ __launch_bounds__(256) void rows_gather_kernel(const int64_t* __restr
             const int64_t r = rows[ic[u]];
             present[u] = r >= 0;
             const int64_t rc = present[u] ? r : 0;
-            v[u] = *reinterpret_cast<const float4*>(table + rc * D + subc * 4);
-            lw[u] = lsrc[rc];
+            v[u] = ld4_once(table + rc * D + subc * 4);
+            lw[u] = lsrc[lin_w != nullptr ? rc : 0];           // (no first-order table: ONE dummy address, not a random gather)
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const float4 x = present[u] ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
             if (out_lin == nullptr) ldst[ic[u] * lpitch + subc * 4] = x.x;      // dummy (same value the row store writes)
             else ldst[ic[u]] = (present[u] && lin_w != nullptr) ? lw[u] : 0.f;
-            *reinterpret_cast<float4*>(out + ic[u] * D + subc * 4) = x;
+            st4_once(out + ic[u] * D + subc * 4, x);
         }
     }
 }
@@ -255,8 +278,8 @@ __global__ __launch_bounds__(256) void pack_grads_kernel(const int64_t* __restri
                     const int fl = f < Fg ? f : Fg - 1;                   // field within the group (lane that holds its pos)
                     const int fc = fg + fl;
                     p[u] = __shfl(my_pos, fl, 64);
-                    g[u] = *reinterpret_cast<const float4*>(d_concat + b * ld + fc * D + subc * 4);
-                    x[u] = *reinterpret_cast<const float4*>(xsrc + b * xld + fc * D + subc * 4);
+                    g[u] = ld4_once(d_concat + b * ld + fc * D + subc * 4);
+                    x[u] = ld4_once(xsrc + b * xld + fc * D + subc * 4);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -266,7 +289,7 @@ __global__ __launch_bounds__(256) void pack_grads_kernel(const int64_t* __restri
                         v.z += dl * (sx.z - x[u].z); v.w += dl * (sx.w - x[u].w);
                     }
                     if (out_lin != nullptr) ldst[p[u]] = dl;
-                    *reinterpret_cast<float4*>(out_rows + p[u] * D + subc * 4) = v;
+                    st4_once(out_rows + p[u] * D + subc * 4, v);
                 }
             }
             my_pos = next_pos;

@@ -1097,3 +1097,10 @@ def reduce_sum(x, squared=False, alpha=1.0, out=None, accumulate=False):
     check(lib().dr_reduce_sum(ptr(x), x.numel(), int(bool(squared)), float(alpha), int(bool(accumulate)), ptr(out), ptr(ws),
                               stream_ptr()), "dr_reduce_sum")
     return out
+
+
+def clock_stamp(buf, index):
+    """buf[index] (int64 device tensor) = the device wall clock (100 MHz ticks) when the current stream reaches this point
+    (dr_clock_stamp: a one-thread kernel; measurement plumbing for bench.py's exposed-wait report)."""
+    assert buf.dtype == torch.int64 and buf.is_contiguous() and 0 <= index < buf.numel()
+    check(lib().dr_clock_stamp(buf.data_ptr() + 8 * int(index), stream_ptr()), "dr_clock_stamp")

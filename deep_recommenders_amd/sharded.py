@@ -591,6 +591,7 @@ class ShardedDeepFMEngine:
         self.fwd_streams = ([torch.cuda.Stream(device=device) for _ in range(max(0, min(mb - 1, 3)))]
                             if (self.fuse_k3 and _os.environ.get("DR_FWD_STREAMS", "1") == "1") else [])
         self._events = None
+        self._stamps = None
         self._route = None
         self._done = []
         self._comm_synced = False
@@ -598,26 +599,49 @@ class ShardedDeepFMEngine:
     # ---- per-phase HIP events (same contract as engine.DeepFMEngine) -------------------------------------------
     def enable_kernel_events(self, on: bool):
         self._events = {} if (on and self._cuda) else None
+        self._stamps = None
         # the collectives themselves (C1 / C2 / C3), apart from the local kernels of their phases: bench.py's per-link rates
         self.ex.phase_timer = (lambda tag, nbytes, fn: self._k(tag, "xgmi", nbytes, fn)) if self._events is not None else None
 
     def _stall(self, name, stream, event):
-        """stream.wait_event(event), bracketed (when events are on) by two records on `stream`: their distance is the time the
-        stream sat idle waiting for the exchange -- the EXPOSED, non-overlapped part of the communication (bench.py sums them)."""
-        if self._events is None:
+        """stream.wait_event(event); when events are on, bracketed by two device clock stamps on `stream` (ops.clock_stamp: one-thread
+        kernels writing the 100 MHz wall clock): their distance is the time the stream sat idle waiting for the exchange -- the
+        EXPOSED, non-overlapped part of the communication (bench.py sums them).  Not HIP timing events: two event records around a
+        cross-stream wait, four waits per step, stretched the step from 1.93 to 4.1 ms (round 4)."""
+        if self._events is None or not self._cuda:
             stream.wait_event(event)
             return
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record(stream)
-        stream.wait_event(event)
-        e.record(stream)
-        self._events.setdefault(name, ["stall", 0, []])[2].append((s, e))
+        if self._stamps is None:
+            self._stamps = torch.zeros(1 << 16, dtype=torch.int64, device=self.dev)
+            self._stamp_n, self._stamp_names = 0, []
+        i = self._stamp_n
+        if i + 2 > self._stamps.numel():
+            stream.wait_event(event)
+            return
+        with torch.cuda.stream(stream):
+            ops.clock_stamp(self._stamps, i)
+            stream.wait_event(event)
+            ops.clock_stamp(self._stamps, i + 1)
+        self._stamp_n = i + 2
+        self._stamp_names.append(name)
+
+    def stall_summary(self):
+        """name -> (total microseconds the stream waited there, number of waits) since events were enabled"""
+        if getattr(self, "_stamps", None) is None or not self._stamp_n:
+            return {}
+        torch.cuda.synchronize()
+        t = self._stamps[:self._stamp_n].cpu().view(-1, 2)
+        out = {}
+        for nm, (a, b) in zip(self._stamp_names, t.tolist()):
+            tot, n = out.get(nm, (0.0, 0))
+            out[nm] = (tot + max(0, b - a) * 0.01, n + 1)          # 100 MHz ticks -> microseconds
+        return out
 
     # Phases that get HIP events in bench.py.  The sharded step issues ~3x the launches of the single-GPU step (two
     # micro-batches, exchanges, routing) and its host thread is the scarcer resource: two event records around every small
     # kernel were enough to leave ~30 us bubbles between kernels, so only the coarse phases are bracketed.
     _TIMED = ("emb_fetch", "emb_pool_fwd", "emb_linear_fwd_L0", "linear_fwd_L0", "linear_bwd_dx_L0", "linear_bwd_dw_L0", "emb_pack_grads",
-              "emb_grads", "allreduce_dense_grads", "emb_route", "a2a_", "stall_")
+              "emb_grads", "allreduce_dense_grads", "emb_route", "a2a_")
 
     def _k(self, name, bound, work, fn):
         if self._events is None or not name.startswith(self._TIMED):
@@ -658,10 +682,12 @@ class ShardedDeepFMEngine:
             rep["collectives"][tag] = {"what": what, "bytes_sent_per_rank": int(sent), "avg_us": round(k["ms"] * 1e3, 2), "calls": k["n"],
                                        "GBps_per_rank": round(on_wire / sec / 1e9, 2) if sec > 0 else None,
                                        "GBps_per_link": round(on_wire / max(W - 1, 1) / sec / 1e9, 2) if (sec > 0 and W > 1) else None}
-        stalls = [k for n, k in ks.items() if n.startswith("stall_")]
+        stalls = self.stall_summary()
         if stalls and steps:
-            rep["exposed_us_per_step"] = round(sum(k["ms"] * k["n"] for k in stalls) * 1e3 / steps, 2)
-            rep["exposed_parts_us_per_step"] = {n: round(k["ms"] * k["n"] * 1e3 / steps, 2) for n, k in ks.items() if n.startswith("stall_")}
+            rep["exposed_us_per_step"] = round(sum(t for t, _ in stalls.values()) / steps, 2)
+            rep["exposed_parts_us_per_step"] = {n: round(t / steps, 2) for n, (t, _) in stalls.items()}
+            rep["exposed_note"] = ("time the training stream sat idle at its waits for the exchange (device clock stamps around each wait; "
+                                   "the stamp kernels' own launch boundaries, ~2 us per wait, are included)")
         return rep
 
     def _mb_slices(self):

@@ -645,6 +645,11 @@ int dr_dropout_bwd(const float* dy, int64_t ld_dy, const uint8_t* mask, int64_t 
 int dr_reduce_sum(const float* x, int64_t n, int32_t squared, float alpha, int32_t accumulate, float* out,
                   float* workspace, dr_stream_t stream);
 
+/* dr_clock_stamp: dst[0] = the device's constant-rate wall clock (100 MHz ticks) when a one-thread kernel reaches the head of
+ * `stream`.  Measurement plumbing with no reference counterpart: bench.py brackets the sharded step's cross-stream waits with two
+ * stamps to report the EXPOSED part of the exchange (HIP timing events around a wait serialise the step). */
+int dr_clock_stamp(uint64_t* dst, dr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
