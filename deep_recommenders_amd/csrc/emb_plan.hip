@@ -103,7 +103,10 @@ __global__ __launch_bounds__(256) void radix_make_keys_kernel(const int64_t* __r
     const int32_t stride = gridDim.x * blockDim.x;
     for (int32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
         const int64_t id = ids[p];
-        const uint64_t row = id >= 0 ? (uint64_t)(row_base[p % F] + id) : sentinel;   // missing ids sort to the end
+        // missing ids sort to the end -- and so does an id beyond the slab (sentinel == num_rows): shifted into the composite key it
+        // would wrap and alias a valid row, which K4 would then update
+        const uint64_t r0 = id >= 0 ? (uint64_t)(row_base[p % F] + id) : sentinel;
+        const uint64_t row = r0 < sentinel ? r0 : sentinel;
         if (GATED) {
             keys[p] = row;
             vals[p] = (uint32_t)p;

@@ -26,11 +26,16 @@ __device__ __forceinline__ float4 f4fma2(float4 a, float4 acc) {
     return make_float4(fmaf(a.x, a.x, acc.x), fmaf(a.y, a.y, acc.y), fmaf(a.z, a.z, acc.z), fmaf(a.w, a.w, acc.w));
 }
 // streaming (non-temporal) 16-byte store: the pooled rows are consumed much later by the GEMM, from HBM
+typedef float ep_f4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void f4store_nt(float* p, float4 v) {
-    __builtin_nontemporal_store(v.x, p);
-    __builtin_nontemporal_store(v.y, p + 1);
-    __builtin_nontemporal_store(v.z, p + 2);
-    __builtin_nontemporal_store(v.w, p + 3);
+    const ep_f4v w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<ep_f4v*>(p));
+}
+// ... and the table rows are read once: nontemporal too, so that they do not wash the first-order lines out of the caches (round 4,
+// the same finding as K4's: emb_sorted.hip)
+__device__ __forceinline__ float4 f4load_nt(const float* p) {
+    const ep_f4v v = __builtin_nontemporal_load(reinterpret_cast<const ep_f4v*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ float4 f4shfl_xor(float4 v, int m) {
     return make_float4(__shfl_xor(v.x, m, 64), __shfl_xor(v.y, m, 64), __shfl_xor(v.z, m, 64), __shfl_xor(v.w, m, 64));
@@ -91,8 +96,8 @@ __global__ __launch_bounds__(256) void emb_pool_fwd_sv_kernel(
                 present[u] = r >= 0;
                 counted[u] = f < F && dvalid;
                 const int64_t rc = present[u] ? r : 0;
-                v[u] = *reinterpret_cast<const float4*>(table + rc * D + subc * 4);
-                lw[u] = lsrc[rc];
+                v[u] = f4load_nt(table + rc * D + subc * 4);
+                lw[u] = lsrc[lin_w != nullptr ? rc : 0];      // (no first-order table: one dummy address, not a random gather)
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {

@@ -228,6 +228,7 @@ extern "C" int dr_topk_select(const float* scores, int64_t ld, int64_t Bq, int64
 static int64_t topk_hdr_bytes(int64_t Bq) { return (Bq * 8 + 255) / 256 * 256; }
 
 // corpus chunk of the scan: ~256 MB of [Bq, chunk] scores (1024 output tiles of the register-split GEMM at Bq = 8192: 4 per CU)
+constexpr int64_t TOPK_MAX_COLS = 32768;      // longest chunk of the scan (dense first chunk and filtered chunks alike)
 static int64_t topk_env(const char* name, int64_t dflt) {
     const char* e = getenv(name);
     return e != nullptr && e[0] != 0 ? atoll(e) : dflt;
@@ -237,6 +238,9 @@ static int64_t topk_chunk_for(int64_t Bq, int64_t N) {
     int64_t chunk = first_bytes / (Bq > 0 ? Bq * 4 : 4);
     chunk = chunk / 256 * 256;
     if (chunk < 256) chunk = 256;
+    // bounded in COLUMNS too, whatever Bq: a small query batch over a large corpus (serving) used to get a chunk of 256 MB / (4 Bq)
+    // columns and planes / candidate lists sized for it -- 8.5 GB of workspace at Bq = 128, N = 10 M
+    if (chunk > TOPK_MAX_COLS) chunk = TOPK_MAX_COLS;
     if (chunk > N) chunk = (N + 3) / 4 * 4;
     if (chunk < 4) chunk = 4;
     return chunk;
@@ -256,6 +260,7 @@ static int64_t topk_scan_for(int64_t chunk, int64_t N) {
     int64_t rest = (N - chunk + 255) / 256 * 256;
     static const int64_t scan_cols = topk_env("DR_TOPK_SCAN_COLS", 0);              // (experiment knob) 0: TOPK_SCAN_MULT x chunk
     int64_t scan = scan_cols > 0 ? (scan_cols + 255) / 256 * 256 : chunk * TOPK_SCAN_MULT;
+    if (scan > TOPK_MAX_COLS && scan_cols <= 0) scan = TOPK_MAX_COLS;
     if (scan > rest) scan = rest;
     return scan < chunk ? chunk : scan;
 }

@@ -192,9 +192,11 @@ class DeepFMEngine:
         # their own on the side stream, beside the tower tail, instead of inside K4: a random 4-byte read-modify-write fetches a
         # 128-byte line, 0.27 GB of K4's 1.64 GB.  DR_LIN_SIDE=1 (off by default: see DESIGN.md for the A/B).
         self.lin_side = (sorted_bwd and optimizer == "sgd" and _os.environ.get("DR_LIN_SIDE", "0") == "1")
-        self._k4_det = _os.environ.get("DR_K4_DETERMINISTIC", "1") != "0"      # (read once per process by the library as well)
+        # (the library reads the same variable once per process, with the same rule: off iff the value STARTS with '0')
+        self._k4_det = not _os.environ.get("DR_K4_DETERMINISTIC", "1").startswith("0")
         self._planes_pending = False
         self._planes_pending_l0 = False
+        self._in_train_step = False
         # First-layer wgrad on a second stream, concurrent with the HBM-bound K4 on the training stream.  It paid next to the
         # in-kernel-split wgrad (2 blocks / CU, matrix pipe ~35 % busy: 1.91 -> 1.84 ms / step); next to the register-split wgrad
         # (one 512-thread block per CU holding all its registers and 96 KB of LDS) the two kernels only time-slice the CUs: the
@@ -374,6 +376,12 @@ class DeepFMEngine:
         if self.sorted_bwd and not self.sort_inline and self.sort_with_k3 and not prefetched:
             self._launch_sort()              # next to K3 (both HBM-bound, small blocks: they do share the machine)
         if self.adam_tf:
+            # (the catch-up stamps the looked-up rows with step t + 1 BEFORE that step's update exists: a forward that is not followed
+            # by backward_and_update -- predict, a second forward -- would leave rows marked as updated and silently diverge from
+            # TF's dense Adam)
+            if not self._in_train_step:
+                raise RuntimeError("optimizer='adam_tf': forward() is only valid inside train_step() (it stamps the looked-up rows "
+                                   "with the step that backward_and_update is about to apply)")
             # rows this batch looks up: replay the decay-only steps they missed (through step t - 1), stamp them t
             self._k("adam_catchup_rows", "hbm", 0,
                     lambda: ops.adam_catchup_rows(self.ids, self.row_base, self.table, self.m_table, self.v_table, self.lin_w, self.m_lin,
@@ -597,8 +605,12 @@ class DeepFMEngine:
         if self._events is not None:
             self._ev_live = (self._ev_step % self._ev_every) == 0
             self._ev_step += 1
-        self.forward(keys, dense, labels)
-        self.backward_and_update()
+        self._in_train_step = True
+        try:
+            self.forward(keys, dense, labels)
+            self.backward_and_update()
+        finally:
+            self._in_train_step = False
         self._next_keys = self._next_dense = None
         return self.loss
 

@@ -590,6 +590,8 @@ class ShardedDeepFMEngine:
         # streams for the later micro-batches' fused first layers (see train_step); DR_FWD_STREAMS=0: all on the training stream
         self.fwd_streams = ([torch.cuda.Stream(device=device) for _ in range(max(0, min(mb - 1, 3)))]
                             if (self.fuse_k3 and _os.environ.get("DR_FWD_STREAMS", "1") == "1") else [])
+        self.k4_first = _os.environ.get("DR_SH_K4_FIRST", "0") == "1"
+        self.wgrad_split = _os.environ.get("DR_SH_WGRAD_SPLIT", "0") == "1"
         self._events = None
         self._stamps = None
         self._route = None
@@ -906,6 +908,19 @@ class ShardedDeepFMEngine:
             if cuda:
                 ev_p = torch.cuda.Event()
                 ev_p.record()
+                if self.wgrad_split:
+                    # this micro-batch's share of the wide layers' wgrads right here (dW accumulates over the micro-batches): the
+                    # exchange + owner-side K4 of micro-batch m then run beside a HALF-length wgrad, and the last K4 -- which the
+                    # next step's first row fetch waits for -- beside wgrad(M - 1) only, not beside the whole batch's
+                    for i in (dw_todo if m > 0 else list(dw_todo)):
+                        xin = x_in[sl] if i == 0 else self.hs[i - 1][sl]
+                        dyi = self.dhs[i][sl] if i < n_layers - 1 else self.d_logit[sl].reshape(-1, 1)
+                        if self.wg_ws[i] is not None:
+                            self._k("linear_bwd_dw_L%d" % i, "mfma", 2.0 * Bm * self.Ws[i].shape[0] * self.Ws[i].shape[1],
+                                    lambda xin=xin, dyi=dyi, i=i: ops.bf3_wgrad(xin, dyi, 1.0, self.gWs[i], self.gbs[i], workspace=self.wg_ws[i]))
+                        else:
+                            self._k("linear_bwd_dw_L%d" % i, "mfma", 2.0 * Bm * self.Ws[i].shape[0] * self.Ws[i].shape[1],
+                                    lambda xin=xin, dyi=dyi, i=i: p.linear_bwd_dw(xin, dyi, 1.0, self.gWs[i], self.gbs[i], workspace=self.dw_ws[i]))
                 with torch.cuda.stream(self.comm):
                     self.comm.wait_event(ev_p)
                     self._k("emb_grads(a2a+sorted K4)", "xgmi", Bm * F * (4 * D + 4),
@@ -916,9 +931,17 @@ class ShardedDeepFMEngine:
                         ev_last_apply.record()
             else:
                 self.ex.exchange_and_apply(routes[m], g_rows, g_lin, -self.lr / W, self.table, self.lin_w, adam=adam_args)
-        # ---- wgrads over the WHOLE rank batch (activations of all micro-batches are contiguous): under the last exchange --
+        # ---- wgrads over the WHOLE rank batch (activations of all micro-batches are contiguous) --------------------------------
+        # DR_SH_K4_FIRST=1 (measured, not adopted): the wgrad WAITS for the last owner-side update.  A persistent GEMM block owns its
+        # CU, so the last K4 crawls beside the wgrad (469 us instead of 170, rocprofv3 timeline of the world-1 step) and the next
+        # step's row fetches -- which must see that update -- queue behind it: K4 -> gather -> forward is a serial 180 us hole on
+        # the training stream.  With K4 first the NEXT step's fetches run beside the wgrad and both forwards find their rows
+        # waiting (322 us for the pair instead of 436) -- but the wgrad stretches by as much beside the gathers (309 -> 413 us) and
+        # the last K4 is fully exposed: 1.97 ms against 1.94 (same call, alternating, three rounds).
+        if cuda and self.k4_first and ev_last_apply is not None:
+            self._stall("stall_apply(training stream waits for C3 + owner-side update)", main, ev_last_apply)
         dys[0] = self.dhs[0] if n_layers > 1 else self.d_logit.reshape(-1, 1)
-        for i in dw_todo:
+        for i in ([] if (cuda and self.wgrad_split) else dw_todo):
             xin = x_in if i == 0 else self.hs[i - 1]
             dyi = self.dhs[i] if i < n_layers - 1 else self.d_logit.reshape(-1, 1)
             if self.wg_ws[i] is not None:
@@ -948,7 +971,8 @@ class ShardedDeepFMEngine:
         if adam and self.fuse_head:
             self.loss.mul_(W)          # loss_parts were normalised by the global batch: report the rank's mean like the SGD mode
         if cuda:
-            self._stall("stall_apply(training stream waits for C3 + owner-side update)", main, ev_last_apply)   # the step ends when every owner has applied its updates
+            if not self.k4_first:
+                self._stall("stall_apply(training stream waits for C3 + owner-side update)", main, ev_last_apply)   # the step ends when every owner has applied its updates
             ev = torch.cuda.Event()
             ev.record()
             self._done.append(ev)
