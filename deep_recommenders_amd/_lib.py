@@ -46,10 +46,13 @@ SIGNATURES = {
     "dr_bce_prob_fwd_bwd": [_p, _p, _i64, _i32, _p, _p, _p, _p],
     "dr_shard_bucket_workspace_bytes": [_i64, _i32],
     "dr_shard_bucket_ids": [_p, _i64, _i32, _i64, _i32, _p, _p, _p, _p, _p],
+    "dr_shard_bucket_ids_dedup": [_p, _p, _i64, _i32, _i64, _i32, _p, _p, _p, _p, _p],
+    "dr_shard_dedup_slots": [_p, _p, _p, _i64, _i64, _p, _p],
     "dr_rows_gather": [_p, _i64, _p, _i32, _p, _p, _p, _p],
     "dr_rows_scatter_add": [_p, _i64, _p, _i32, _p, _f32, _p, _p, _p],
     "dr_axpy": [_i64, _f32, _p, _p, _p],
     "dr_emb_pack_grads": [_p, _i64, _i32, _i32, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p],
+    "dr_emb_pack_grads_dedup": [_p, _p, _i64, _i32, _i32, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p],
     "dr_emb_sort_workspace_bytes": [_i64],
     "dr_emb_sort_slots": [_p, _i64, _i32, _p, _i64, _p, _p, _p, _p, _p, _p, _i64, _p],
     "dr_emb_plan_set_small_limit": [_i32],

@@ -49,7 +49,9 @@ __device__ __forceinline__ void slot_route(int64_t id, int64_t p, int32_t C, int
     }
 }
 
-__global__ __launch_bounds__(256) void bucket_hist_kernel(const int64_t* __restrict__ ids, int64_t n, int32_t C,
+// rep (may be NULL): the slot plan's representative of every slot's row (dr_shard_dedup_slots); a slot that is not its own
+// representative gets NO send slot -- its row travels once, with the representative -- and its pos is copied from it afterwards.
+__global__ __launch_bounds__(256) void bucket_hist_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ rep, int64_t n, int32_t C,
                                                           int64_t rps, int32_t world, int64_t* __restrict__ block_hist) {
     __shared__ int hist[MAXW];
     if (threadIdx.x < MAXW) hist[threadIdx.x] = 0;
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(256) void bucket_hist_kernel(const int64_t* __restr
     const int64_t base = (int64_t)blockIdx.x * CHUNK + (int64_t)threadIdx.x * SLOTS_PER_THREAD;
     for (int j = 0; j < SLOTS_PER_THREAD; ++j) {
         const int64_t p = base + j;
-        if (p < n) {
+        if (p < n && (rep == nullptr || rep[p] == p)) {
             int o; int64_t lr;
             slot_route(ids[p], p, C, rps, world, o, lr);
             atomicAdd(&hist[o], 1);
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256) void bucket_scan_kernel(int64_t* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256) void bucket_scatter_kernel(const int64_t* __restrict__ ids, int64_t n, int32_t C,
+__global__ __launch_bounds__(256) void bucket_scatter_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ rep, int64_t n, int32_t C,
                                                              int64_t rps, int32_t world,
                                                              const int64_t* __restrict__ block_off,
                                                              int64_t* __restrict__ send_rows,
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(const int64_t* __re
     for (int j = 0; j < SLOTS_PER_THREAD; ++j) {
         const int64_t p = base + j;
         owner[j] = -1;
-        if (p < n) {
+        if (p < n && (rep == nullptr || rep[p] == p)) {
             slot_route(ids[p], p, C, rps, world, owner[j], lrow[j]);
 #pragma unroll
             for (int w = 0; w < MAXW; ++w) local[w] += (owner[j] == w) ? 1 : 0;
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(const int64_t* __re
 #pragma unroll
     for (int j = 0; j < SLOTS_PER_THREAD; ++j) {
         const int64_t p = base + j;
-        if (p < n) {
+        if (p < n && owner[j] >= 0) {
             const int o = owner[j];
             int before = 0;
 #pragma unroll
@@ -159,6 +161,40 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(const int64_t* __re
             send_rows[dst] = lrow[j];
             pos[p] = dst;
         }
+    }
+}
+
+// ---- requester-side de-duplication (round 4) ----------------------------------------------------------------------------------
+// [TF] safe_embedding_lookup_sparse looks every DISTINCT id up once (`unique` inside embedding_lookup_sparse, reached from
+// keras/models/ranking/fm.py:57-61 of the reference); the exchange can do the same: a row several slots of a micro-batch share
+// travels once each way.  The representative of a row = its lowest slot.  Built from the slot plan of the micro-batch's ids
+// (dr_emb_sort_slots over global rows f * V + id): the plan's sorted arrays hold the slots of shared rows grouped by row, slots
+// ascending inside a row -- the segment start is found by binary search (lower bound of the row), no scan needed.
+__global__ __launch_bounds__(256) void dedup_fill_kernel(int64_t* __restrict__ rep, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) rep[p] = p;
+}
+__global__ __launch_bounds__(256) void dedup_rep_kernel(const uint64_t* __restrict__ rows, const int32_t* __restrict__ slots,
+                                                        const int32_t* __restrict__ dup_count, uint64_t num_rows,
+                                                        int64_t* __restrict__ rep) {
+    const int64_t L = dup_count[1];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < L; j += stride) {
+        const uint64_t k = rows[j];
+        if (k >= num_rows) continue;                       // missing ids (radix path: sentinel at the end) keep their own slot
+        int64_t lo = 0, hi = j;                            // first index whose row is k
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (rows[mid] < k) lo = mid + 1; else hi = mid;
+        }
+        rep[slots[j]] = slots[lo];
+    }
+}
+__global__ __launch_bounds__(256) void dedup_pos_kernel(const int64_t* __restrict__ rep, int64_t n, int64_t* __restrict__ pos) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+        const int64_t r = rep[p];
+        if (r != p) pos[p] = pos[r];                       // (representatives are written by bucket_scatter_kernel of the same call, earlier in stream order)
     }
 }
 
@@ -232,14 +268,14 @@ __global__ __launch_bounds__(256) void rows_scatter_add_kernel(const int64_t* __
 // send layout (pos is a permutation of 0..n-1: every destination written exactly once — no zero fill, no atomics).
 //   out_rows[pos[b,f], :] = d_concat[b, f*D:(f+1)*D] + d_fm_logit[b] * (sum_x[b,:] - concat[b, f*D:(f+1)*D])
 //   out_lin[pos[b,f]]     = d_fm_logit[b]
-template <int LPR, int U>
+template <int LPR, int U, bool DEDUP>
 __global__ __launch_bounds__(256) void pack_grads_kernel(const int64_t* __restrict__ pos, int64_t B, int32_t F, int32_t D,
                                                          const float* __restrict__ d_concat, int64_t ld,
                                                          const float* __restrict__ concat, int64_t ldc,
                                                          const float* __restrict__ sum_x,
                                                          const float* __restrict__ d_fm_logit,
                                                          float* __restrict__ out_rows, float* __restrict__ out_lin,
-                                                         float* __restrict__ bias_sum) {
+                                                         float* __restrict__ bias_sum, const uint8_t* __restrict__ uniq) {
     // One wave per example; branch-free loop body (see emb_pool.hip): slots past the last field repeat field F-1 (same
     // destination, same value), lanes past D/4 repeat the last float4; the example's F positions are read once,
     // coalesced, and broadcast with shuffles; the next example's positions are prefetched.
@@ -262,10 +298,15 @@ __global__ __launch_bounds__(256) void pack_grads_kernel(const int64_t* __restri
         const int Fg = F - fg < 64 ? F - fg : 64;
         const int lanec = fg + (lane < Fg ? lane : Fg - 1);
         int64_t my_pos = pos[w0 * F + lanec];
+        // de-duplicated exchange (uniq != NULL): slots that share a row share a destination (zero-filled by the caller); they add
+        // their gradients with fp32 atomics, slots whose row is unique in the micro-batch store as before.  The flag rides in
+        // bit 62 of the position.
+        if (DEDUP && !uniq[w0 * F + lanec]) my_pos |= (int64_t)1 << 62;
         float dl = dlsrc[w0];
         for (int64_t b = w0; b < B; b += nw) {
             const int64_t bn = b + nw < B ? b + nw : b;
-            const int64_t next_pos = pos[bn * F + lanec];
+            int64_t next_pos = pos[bn * F + lanec];
+            if (DEDUP && !uniq[bn * F + lanec]) next_pos |= (int64_t)1 << 62;
             const float next_dl = dlsrc[bn];
             if (d_fm_logit == nullptr) dl = 0.f;
             const float4 sx = *reinterpret_cast<const float4*>(sxsrc + b * sxp + subc * 4);
@@ -288,8 +329,18 @@ __global__ __launch_bounds__(256) void pack_grads_kernel(const int64_t* __restri
                         v.x += dl * (sx.x - x[u].x); v.y += dl * (sx.y - x[u].y);
                         v.z += dl * (sx.z - x[u].z); v.w += dl * (sx.w - x[u].w);
                     }
-                    if (out_lin != nullptr) ldst[p[u]] = dl;
-                    st4_once(out_rows + p[u] * D + subc * 4, v);
+                    const bool shared = DEDUP && ((p[u] >> 62) & 1);
+                    const int64_t pp = DEDUP ? (p[u] & ~((int64_t)1 << 62)) : p[u];
+                    if (!shared) {
+                        if (out_lin != nullptr) ldst[pp] = dl;
+                        st4_once(out_rows + pp * D + subc * 4, v);
+                    } else if (f0 + u * NS + slot < Fg) {                  // (a padded slot repeats field Fg - 1: add it once)
+                        if (out_lin != nullptr && sub == 0) unsafeAtomicAdd(out_lin + pp, dl);
+                        if (sub < nq) {
+                            float* q = out_rows + pp * D + sub * 4;
+                            unsafeAtomicAdd(q + 0, v.x); unsafeAtomicAdd(q + 1, v.y); unsafeAtomicAdd(q + 2, v.z); unsafeAtomicAdd(q + 3, v.w);
+                        }
+                    }
                 }
             }
             my_pos = next_pos;
@@ -317,9 +368,8 @@ extern "C" int64_t dr_shard_bucket_workspace_bytes(int64_t n, int32_t world) {
     return (nblk * world + 16) * (int64_t)sizeof(int64_t);
 }
 
-extern "C" int dr_shard_bucket_ids(const int64_t* ids, int64_t n, int32_t C, int64_t rows_per_shard, int32_t world,
-                                   int64_t* counts, int64_t* send_rows, int64_t* pos, int64_t* workspace,
-                                   dr_stream_t stream) {
+static int bucket_ids_impl(const int64_t* ids, const int64_t* rep, int64_t n, int32_t C, int64_t rows_per_shard, int32_t world,
+                           int64_t* counts, int64_t* send_rows, int64_t* pos, int64_t* workspace, dr_stream_t stream) {
     if (n < 0 || C <= 0 || world <= 0 || world > MAXW || rows_per_shard <= 0) return DR_EINVAL;
     if (!counts) return DR_EINVAL;
     if (n == 0) {
@@ -327,11 +377,44 @@ extern "C" int dr_shard_bucket_ids(const int64_t* ids, int64_t n, int32_t C, int
     }
     if (!ids || !send_rows || !pos || !workspace) return DR_EINVAL;
     const int nblk = (int)((n + CHUNK - 1) / CHUNK);
-    hipLaunchKernelGGL(bucket_hist_kernel, dim3(nblk), dim3(256), 0, dr_s(stream), ids, n, C, rows_per_shard, world,
+    hipLaunchKernelGGL(bucket_hist_kernel, dim3(nblk), dim3(256), 0, dr_s(stream), ids, rep, n, C, rows_per_shard, world,
                        workspace);
     hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(256), 0, dr_s(stream), workspace, (int64_t)nblk, world, counts);
-    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nblk), dim3(256), 0, dr_s(stream), ids, n, C, rows_per_shard, world,
+    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(nblk), dim3(256), 0, dr_s(stream), ids, rep, n, C, rows_per_shard, world,
                        workspace, send_rows, pos);
+    if (rep != nullptr)
+        hipLaunchKernelGGL(dedup_pos_kernel, dim3(dr_grid_for(n, 256)), dim3(256), 0, dr_s(stream), rep, n, pos);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+extern "C" int dr_shard_bucket_ids(const int64_t* ids, int64_t n, int32_t C, int64_t rows_per_shard, int32_t world,
+                                   int64_t* counts, int64_t* send_rows, int64_t* pos, int64_t* workspace,
+                                   dr_stream_t stream) {
+    return bucket_ids_impl(ids, nullptr, n, C, rows_per_shard, world, counts, send_rows, pos, workspace, stream);
+}
+
+// The same with the representative map of dr_shard_dedup_slots: only slots that are their own representative get a send slot
+// (counts then sum to the number of DISTINCT rows of the micro-batch, missing ids included one by one); pos[p] of every other slot =
+// pos of its representative.
+extern "C" int dr_shard_bucket_ids_dedup(const int64_t* ids, const int64_t* rep, int64_t n, int32_t C, int64_t rows_per_shard,
+                                         int32_t world, int64_t* counts, int64_t* send_rows, int64_t* pos, int64_t* workspace,
+                                         dr_stream_t stream) {
+    if (!rep) return DR_EINVAL;
+    return bucket_ids_impl(ids, rep, n, C, rows_per_shard, world, counts, send_rows, pos, workspace, stream);
+}
+
+// rep[p] = lowest slot of the micro-batch that looks up the same row as slot p (p itself for a row no other slot shares, and for a
+// missing id), from the slot plan of the micro-batch's ids (dr_emb_sort_slots over the global rows row_base[f] + id; num_rows as
+// given there).
+extern "C" int dr_shard_dedup_slots(const int64_t* sorted_rows, const int32_t* sorted_slots, const int32_t* dup_count, int64_t n,
+                                    int64_t num_rows, int64_t* rep, dr_stream_t stream) {
+    if (n < 0 || num_rows <= 0) return DR_EINVAL;
+    if (n == 0) return DR_OK;
+    if (!sorted_rows || !sorted_slots || !dup_count || !rep) return DR_EINVAL;
+    hipLaunchKernelGGL(dedup_fill_kernel, dim3(dr_grid_for(n, 256)), dim3(256), 0, dr_s(stream), rep, n);
+    hipLaunchKernelGGL(dedup_rep_kernel, dim3(dr_grid_for(n, 256)), dim3(256), 0, dr_s(stream),
+                       reinterpret_cast<const uint64_t*>(sorted_rows), sorted_slots, dup_count, (uint64_t)num_rows, rep);
     DR_CHECK_LAUNCH();
     return DR_OK;
 }
@@ -386,18 +469,43 @@ extern "C" int dr_axpy(int64_t n, float alpha, const float* x, float* y, dr_stre
     return DR_OK;
 }
 
-extern "C" int dr_emb_pack_grads(const int64_t* pos, int64_t B, int32_t F, int32_t D, const float* d_concat, int64_t ld_dconcat,
-                                 const float* concat, int64_t ld_concat, const float* sum_x, const float* d_fm_logit,
-                                 float* out_rows, float* out_lin, float* bias_sum, dr_stream_t stream) {
+static int pack_grads_impl(const int64_t* pos, const uint8_t* uniq, int64_t B, int32_t F, int32_t D, const float* d_concat, int64_t ld_dconcat,
+                           const float* concat, int64_t ld_concat, const float* sum_x, const float* d_fm_logit,
+                           float* out_rows, float* out_lin, float* bias_sum, dr_stream_t stream) {
     if (B < 0 || F <= 0 || D < 4 || D > 256 || (D & 3)) return DR_EINVAL;
     if (B == 0) return DR_OK;
     if (!pos || !d_concat || !out_rows || ld_dconcat < (int64_t)F * D || (ld_dconcat & 3)) return DR_EINVAL;
     if (concat != nullptr && (ld_concat < (int64_t)F * D || (ld_concat & 3))) return DR_EINVAL;
     const int lpr = lpr_for_d(D);
     const int grid = dr_grid_for(B, 4, 8192);
-#define CALL(L) hipLaunchKernelGGL((pack_grads_kernel<L, (64 / L >= 16 ? 2 : 4)>), dim3(grid), dim3(256), 0, dr_s(stream), pos, B, F, D, d_concat, ld_dconcat, concat, ld_concat, sum_x, d_fm_logit, out_rows, out_lin, bias_sum)
+#define CALL(L)                                                                                                                       \
+    if (uniq != nullptr)                                                                                                              \
+        hipLaunchKernelGGL((pack_grads_kernel<L, (64 / L >= 16 ? 2 : 4), true>), dim3(grid), dim3(256), 0, dr_s(stream), pos, B, F, D, \
+                           d_concat, ld_dconcat, concat, ld_concat, sum_x, d_fm_logit, out_rows, out_lin, bias_sum, uniq);             \
+    else                                                                                                                              \
+        hipLaunchKernelGGL((pack_grads_kernel<L, (64 / L >= 16 ? 2 : 4), false>), dim3(grid), dim3(256), 0, dr_s(stream), pos, B, F, D, \
+                           d_concat, ld_dconcat, concat, ld_concat, sum_x, d_fm_logit, out_rows, out_lin, bias_sum, uniq)
     DR_LPR_SWITCH(lpr, CALL)
 #undef CALL
     DR_CHECK_LAUNCH();
     return DR_OK;
+}
+
+extern "C" int dr_emb_pack_grads(const int64_t* pos, int64_t B, int32_t F, int32_t D, const float* d_concat, int64_t ld_dconcat,
+                                 const float* concat, int64_t ld_concat, const float* sum_x, const float* d_fm_logit,
+                                 float* out_rows, float* out_lin, float* bias_sum, dr_stream_t stream) {
+    return pack_grads_impl(pos, nullptr, B, F, D, d_concat, ld_dconcat, concat, ld_concat, sum_x, d_fm_logit, out_rows, out_lin, bias_sum,
+                           stream);
+}
+
+// De-duplicated form: pos maps several slots to one destination (dr_shard_bucket_ids_dedup); unique_flags [B * F] = the slot plan's
+// flags of the same micro-batch.  Slots whose row is unique store, the others ADD (fp32 atomics: the order in which a shared row's
+// slots arrive is not fixed) -- out_rows / out_lin must be zero where shared rows land (the caller zero-fills the buffers).
+extern "C" int dr_emb_pack_grads_dedup(const int64_t* pos, const uint8_t* unique_flags, int64_t B, int32_t F, int32_t D,
+                                       const float* d_concat, int64_t ld_dconcat, const float* concat, int64_t ld_concat,
+                                       const float* sum_x, const float* d_fm_logit, float* out_rows, float* out_lin, float* bias_sum,
+                                       dr_stream_t stream) {
+    if (!unique_flags) return DR_EINVAL;
+    return pack_grads_impl(pos, unique_flags, B, F, D, d_concat, ld_dconcat, concat, ld_concat, sum_x, d_fm_logit, out_rows, out_lin,
+                           bias_sum, stream);
 }

@@ -383,7 +383,19 @@ def bce_prob_fwd_bwd(prob, labels, mode, want_grad=True, workspace=None):
 # ----------------------------------------------------------------------------------------------
 # row-sharded tables: bucketing + owner-side gather / scatter, dense axpy
 # ----------------------------------------------------------------------------------------------
-def shard_bucket_ids(ids, rows_per_shard, world, counts=None, send_rows=None, pos=None, workspace=None):
+def shard_dedup_slots(ids, row_base, num_rows, plan, out=None):
+    """(rep, unique_flags) of a micro-batch: rep[p] int64 = the lowest slot that looks up the same row as slot p (dr_shard_dedup_slots
+    over `plan` = emb_sort_slots(ids, row_base, num_rows)); unique_flags = the plan's per-slot flags (row shared by no other slot)."""
+    B, F = ids.shape
+    n = B * F
+    if out is None or out.numel() < n:
+        out = torch.empty(n, dtype=torch.int64, device=ids.device)
+    check(lib().dr_shard_dedup_slots(ptr(plan.rows), ptr(plan.slots), ptr(plan.dup_count), n, int(num_rows), ptr(out), stream_ptr()),
+          "dr_shard_dedup_slots")
+    return out, plan.flags
+
+
+def shard_bucket_ids(ids, rows_per_shard, world, counts=None, send_rows=None, pos=None, workspace=None, rep=None):
     ids = _c(ids, torch.int64)
     B, C = ids.shape
     n = B * C
@@ -397,6 +409,10 @@ def shard_bucket_ids(ids, rows_per_shard, world, counts=None, send_rows=None, po
     if workspace is None:
         nbytes = lib().dr_shard_bucket_workspace_bytes(n, world)
         workspace = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
+    if rep is not None:
+        check(lib().dr_shard_bucket_ids_dedup(ptr(ids), ptr(rep), n, C, int(rows_per_shard), int(world), ptr(counts), ptr(send_rows),
+                                              ptr(pos), ptr(workspace), stream_ptr()), "dr_shard_bucket_ids_dedup")
+        return counts, send_rows, pos
     check(lib().dr_shard_bucket_ids(ptr(ids), n, C, int(rows_per_shard), int(world), ptr(counts), ptr(send_rows),
                                     ptr(pos), ptr(workspace), stream_ptr()), "dr_shard_bucket_ids")
     return counts, send_rows, pos
@@ -790,9 +806,14 @@ def softmax_ce_rows_bwd(logits, labels, inv_temperature, sample_weight, d_loss, 
     return out
 
 
-def emb_pack_grads(pos, D, d_concat, concat, sum_x, d_fm_logit, out_rows, out_lin=None, bias_sum=None):
+def emb_pack_grads(pos, D, d_concat, concat, sum_x, d_fm_logit, out_rows, out_lin=None, bias_sum=None, unique_flags=None):
     pos = _c(pos, torch.int64)
     B, F = pos.shape
+    if unique_flags is not None:          # de-duplicated exchange: several slots per destination, shared rows accumulate (zero-filled buffers)
+        check(lib().dr_emb_pack_grads_dedup(ptr(pos), ptr(unique_flags), B, F, D, ptr(d_concat), d_concat.stride(0), ptr(concat),
+                                            concat.stride(0) if concat is not None else 0, ptr(sum_x), ptr(d_fm_logit), ptr(out_rows),
+                                            ptr(out_lin), ptr(bias_sum), stream_ptr()), "dr_emb_pack_grads_dedup")
+        return
     check(lib().dr_emb_pack_grads(ptr(pos), B, F, D, ptr(d_concat), d_concat.stride(0), ptr(concat),
                                   concat.stride(0) if concat is not None else 0, ptr(sum_x), ptr(d_fm_logit), ptr(out_rows),
                                   ptr(out_lin), ptr(bias_sum), stream_ptr()), "dr_emb_pack_grads")

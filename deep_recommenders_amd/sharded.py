@@ -37,6 +37,7 @@ class HipPrims:
     """The product implementation: every primitive is a launch of a hand-written gfx950 kernel."""
     hash_bucket_i64 = staticmethod(ops.hash_bucket_i64)
     shard_bucket_ids = staticmethod(ops.shard_bucket_ids)
+    shard_dedup_slots = staticmethod(ops.shard_dedup_slots)
     rows_gather = staticmethod(ops.rows_gather)
     rows_scatter_add = staticmethod(ops.rows_scatter_add)
     emb_pool_fwd = staticmethod(ops.emb_pool_fwd)
@@ -187,8 +188,8 @@ class Route:
     """Everything about one batch that depends only on its keys: where each slot's row lives, how many rows travel to /
     from each rank, the owner-side list of requested rows and its sort plan.  Built by ShardedEmbeddingExchange.route()
     on a dedicated stream, possibly one step ahead of its use."""
-    __slots__ = ("pos", "send_splits", "recv_splits", "n", "n_recv", "n_pad", "slot", "ready", "sorted", "key", "has_lin",
-                 "_send_rows", "_counts_host", "_counts_ev", "_finished")
+    __slots__ = ("pos", "send_splits", "recv_splits", "n", "n_send", "n_recv", "n_pad", "slot", "ready", "sorted", "key", "has_lin",
+                 "uniq", "_send_rows", "_counts_host", "_counts_ev", "_finished")
 
 
 class ShardedEmbeddingExchange:
@@ -209,8 +210,15 @@ class ShardedEmbeddingExchange:
     SLOTS = 4       # routes in flight: (micro-batches per step = 2) x (the step being trained + the prefetched one)
 
     def __init__(self, num_fields, vocab_per_field, dim, world, rank, device, prims=None, group=None, transport=None,
-                 alias_world1=True):
+                 alias_world1=True, dedup=None):
         self.F, self.V, self.D = num_fields, vocab_per_field, dim
+        # Requester-side de-duplication (DR_SH_DEDUP=1 / dedup=True; round 4): a row that several slots of a micro-batch look up
+        # travels ONCE each way -- what [TF] safe_embedding_lookup_sparse's `unique` does inside the lookup (reached from
+        # keras/models/ranking/fm.py:57-61 of the reference).  Uniform ids over 10 M rows: nothing to save (99.8 % of a micro-batch's
+        # slots are distinct rows); Zipf(1.05) keys: 1.6 x fewer bytes on the wire, for a slot plan + a representative map per
+        # micro-batch on the routing stream and fp32 atomics in the pack for the shared rows (their summation order is then not fixed).
+        import os as _os
+        self.dedup = (_os.environ.get("DR_SH_DEDUP", "0") == "1") if dedup is None else bool(dedup)
         self.world, self.rank, self.dev = world, rank, device
         self.rows_per_shard = (vocab_per_field + world - 1) // world
         self.local_rows = num_fields * self.rows_per_shard
@@ -221,7 +229,8 @@ class ShardedEmbeddingExchange:
         # list, the gather output is the receive buffer, the packed gradients are written where the owner-side K4 reads them) and
         # no collective is issued -- RCCL used to copy 2 x 443 MB to itself per step.  alias_world1=False keeps the
         # collectives (a group of one), which is how the tests push the N > 1 code through RCCL on a single GPU.
-        self.local = world == 1 and alias_world1 and (prims is None or prims is HipPrims)
+        self.local = world == 1 and alias_world1 and (prims is None or prims is HipPrims) and not self.dedup
+        self._field_base = torch.arange(num_fields, dtype=torch.int64, device=device) * vocab_per_field
         self._zero_base = torch.zeros(num_fields, dtype=torch.int64, device=device)
         self._zero_base_g = torch.zeros(self.GROUP, dtype=torch.int64, device=device)
         self._col_start = torch.arange(num_fields + 1, dtype=torch.int32, device=device)
@@ -234,7 +243,8 @@ class ShardedEmbeddingExchange:
     def set_slots(self, n):
         """Number of routes that may be in flight (2 x micro-batches per step)."""
         self.SLOTS = int(n)
-        self._slots = [dict(cap=0, rows_pad=None, g_pad=None, gl_pad=None, plan=None, ids=None) for _ in range(self.SLOTS)]
+        self._slots = [dict(cap=0, rows_pad=None, g_pad=None, gl_pad=None, plan=None, ids=None, req_plan=None, rep=None)
+                       for _ in range(self.SLOTS)]
         self._next_slot = 0
 
     # bench.py's exchange report: when set, called as phase_timer(tag, bytes_sent_by_this_rank, fn) around every data-path collective
@@ -297,10 +307,21 @@ class ShardedEmbeddingExchange:
                 rows_pad[r.n:].fill_(-1)
                 _, send_rows, pos = self.p.shard_bucket_ids(ids, self.rows_per_shard, W, send_rows=rows_pad[:r.n])
                 r.send_splits = r.recv_splits = [r.n]
+                r.n_send, r.uniq = r.n, None
                 r._counts_host = r._counts_ev = None
                 r.pos, r._send_rows = pos, None
                 return r
-            counts, send_rows, pos = self.p.shard_bucket_ids(ids, self.rows_per_shard, W)
+            r.uniq = None
+            if self.dedup:
+                # slot plan of THIS micro-batch's ids over the global rows f * V + id (the kernels K4's plan uses), then every
+                # slot's representative = the lowest slot looking up the same row; only representatives get a send slot
+                if sl["req_plan"] is None and hasattr(self.p, "new_sort_plan"):
+                    sl["req_plan"] = self.p.new_sort_plan(r.n, ids.device)
+                sl["req_plan"] = self.p.emb_sort_slots(ids, self._field_base, self.F * self.V, sl["req_plan"])
+                sl["rep"], r.uniq = self.p.shard_dedup_slots(ids, self._field_base, self.F * self.V, sl["req_plan"], out=sl["rep"])
+                counts, send_rows, pos = self.p.shard_bucket_ids(ids, self.rows_per_shard, W, rep=sl["rep"])
+            else:
+                counts, send_rows, pos = self.p.shard_bucket_ids(ids, self.rows_per_shard, W)
             recv_counts = torch.empty_like(counts)
             self.tr.alltoall(recv_counts, counts)                                         # split sizes
             both = torch.stack([counts, recv_counts])
@@ -328,13 +349,14 @@ class ShardedEmbeddingExchange:
             r.send_splits = [int(v) for v in r._counts_host[0].tolist()]
             r.recv_splits = [int(v) for v in r._counts_host[1].tolist()]
             r.n_recv = sum(r.recv_splits)
+            r.n_send = sum(r.send_splits)                   # == r.n unless de-duplicated
         ctx = torch.cuda.stream(self._rs) if self._cuda else _NullCtx()
         with ctx:
             if not self.local:
                 r.n_pad = self._ensure_capacity(sl, r.n_recv, r.pos.device)
                 rows_pad = sl["rows_pad"][:r.n_pad]
                 rows_pad[r.n_recv:].fill_(-1)
-                self._a2a(rows_pad[:r.n_recv], r._send_rows, r.recv_splits, r.send_splits, tag="a2a_ids")      # C1
+                self._a2a(rows_pad[:r.n_recv], r._send_rows[:r.n_send], r.recv_splits, r.send_splits, tag="a2a_ids")      # C1
             else:
                 rows_pad = sl["rows_pad"][:r.n_pad]
             if self._cuda:
@@ -364,11 +386,11 @@ class ShardedEmbeddingExchange:
         r.has_lin = lin_local is not None
         if self.local:
             return rows_buf, lin_buf                                                   # the gather output IS the receive buffer
-        got_rows = torch.empty((r.n, self.D), dtype=torch.float32, device=recv_rows.device)
+        got_rows = torch.empty((r.n_send, self.D), dtype=torch.float32, device=recv_rows.device)
         self._a2a(got_rows, rows_buf, r.send_splits, r.recv_splits, tag="a2a_rows")   # C2
         got_lin = None
         if lin_local is not None:
-            got_lin = torch.empty(r.n, dtype=torch.float32, device=recv_rows.device)
+            got_lin = torch.empty(r.n_send, dtype=torch.float32, device=recv_rows.device)
             self._a2a(got_lin, lin_buf, r.send_splits, r.recv_splits)
         r.has_lin = lin_local is not None
         return got_rows, got_lin
@@ -396,6 +418,9 @@ class ShardedEmbeddingExchange:
             sl = self._slots[r.slot]
             g_rows = sl["g_pad"][:r.n]
             g_lin = sl["gl_pad"][:r.n] if r.has_lin else None
+        elif r.uniq is not None:             # de-duplicated: shared rows are ACCUMULATED by the pack, so they start from zero
+            g_rows = torch.zeros((r.n_send, self.D), dtype=torch.float32, device=r.pos.device)
+            g_lin = torch.zeros(r.n_send, dtype=torch.float32, device=r.pos.device) if r.has_lin else None
         else:
             g_rows = torch.empty((r.n, self.D), dtype=torch.float32, device=r.pos.device)
             g_lin = torch.empty(r.n, dtype=torch.float32, device=r.pos.device) if r.has_lin else None
@@ -404,7 +429,10 @@ class ShardedEmbeddingExchange:
     def pack(self, route, d_concat, d_fm_logit, concat, sum_x, g_bias=None):
         """requesting side: per-slot gradients into the send layout (local, HBM-bound)"""
         g_rows, g_lin = self.pack_buffers(route)
-        self.p.emb_pack_grads(route.pos, self.D, d_concat, concat, sum_x, d_fm_logit, g_rows, g_lin, g_bias)
+        if route.uniq is not None:
+            self.p.emb_pack_grads(route.pos, self.D, d_concat, concat, sum_x, d_fm_logit, g_rows, g_lin, g_bias, unique_flags=route.uniq)
+        else:
+            self.p.emb_pack_grads(route.pos, self.D, d_concat, concat, sum_x, d_fm_logit, g_rows, g_lin, g_bias)
         return g_rows, g_lin
 
     def exchange_and_apply(self, route, g_rows, g_lin, scale, table_local, lin_local, adam=None):
@@ -456,7 +484,7 @@ class ShardedDeepFMEngine:
     def __init__(self, num_fields, vocab_per_field, dim, dnn_units: Sequence[int], batch, num_dense=0, lr=0.01,
                  device="cuda", world=None, rank=None, seed=42, prims=None, group=None, lin_init_std=0.0,
                  init_tables=None, micro_batches=None, optimizer="sgd", beta1=0.9, beta2=0.999, eps=1e-8, transport=None,
-                 alias_world1=True):
+                 alias_world1=True, dedup=None):
         assert optimizer in ("sgd", "adam")
         self.optimizer, self.beta1, self.beta2, self.eps, self.t = optimizer, beta1, beta2, eps, 0
         self.world = world if world is not None else dist.get_world_size(group)
@@ -466,7 +494,7 @@ class ShardedDeepFMEngine:
         self.p = prims if prims is not None else HipPrims
         F, V, D, B, W = self.F, self.V, self.D, self.B, self.world
         self.ex = ShardedEmbeddingExchange(F, V, D, W, self.rank, device, self.p, group, transport=transport,
-                                           alias_world1=alias_world1)
+                                           alias_world1=alias_world1, dedup=dedup)
         self.tr = self.ex.tr
         rps = self.ex.rows_per_shard
         g = torch.Generator(device=device)
@@ -586,7 +614,8 @@ class ShardedDeepFMEngine:
         # layer's weight planes, D == 64 and single-valued fields (one slot per (example, field)).  OFF unless DR_FUSE_PACK=1:
         # measured slower (400 us against 173 + 143 per half batch -- the MFMA accumulator layout gives a lane one column of
         # 16 rows, so the epilogue scatters with 4-byte stores and loads where the pack kernel moves float4s).
-        self.fuse_pack = (use_planes and _os.environ.get("DR_FUSE_PACK", "0") == "1" and D == 64 and num_fields <= 64)
+        self.fuse_pack = (use_planes and _os.environ.get("DR_FUSE_PACK", "0") == "1" and D == 64 and num_fields <= 64
+                          and not self.ex.dedup)
         # streams for the later micro-batches' fused first layers (see train_step); DR_FWD_STREAMS=0: all on the training stream
         self.fwd_streams = ([torch.cuda.Stream(device=device) for _ in range(max(0, min(mb - 1, 3)))]
                             if (self.fuse_k3 and _os.environ.get("DR_FWD_STREAMS", "1") == "1") else [])
@@ -672,7 +701,8 @@ class ShardedDeepFMEngine:
         stream sat idle waiting for rows / for the last owner-side update (the part of the exchange that no compute hid)."""
         ks = self.kernel_event_summary()
         W = self.world
-        rep = {"world": W, "micro_batches": self.mb, "transport": type(self.tr).__name__, "collectives": {}, "exposed_us_per_step": None}
+        rep = {"world": W, "micro_batches": self.mb, "transport": type(self.tr).__name__, "dedup_before_exchange": bool(self.ex.dedup),
+               "collectives": {}, "exposed_us_per_step": None}
         for tag, what in (("a2a_ids", "C1 row ids to their owners"), ("a2a_rows", "C2 embedding rows back"), ("a2a_grads", "C3 row gradients to their owners"),
                           ("allreduce_dense_grads", "C4 dense-tower gradients")):
             k = ks.get(tag)

@@ -494,6 +494,17 @@ int64_t dr_shard_bucket_workspace_bytes(int64_t n, int32_t world);
 int dr_shard_bucket_ids(const int64_t* ids, int64_t n, int32_t C, int64_t rows_per_shard, int32_t world,
                         int64_t* counts, int64_t* send_rows, int64_t* pos, int64_t* workspace,
                         dr_stream_t stream);
+/* Requester-side de-duplication of the exchange (round 4): what [TF] safe_embedding_lookup_sparse's `unique` does inside the lookup
+ * reached from keras/models/ranking/fm.py:57-61 -- a row that several slots of a micro-batch look up travels once each way.
+ * dr_shard_dedup_slots: rep[p] = the lowest slot looking up the same row as slot p (p itself for an unshared row or a missing id), from
+ *   the slot plan of the micro-batch's ids (dr_emb_sort_slots over the global rows row_base[f] + id, with the same num_rows).
+ * dr_shard_bucket_ids_dedup: dr_shard_bucket_ids in which only the representatives get a send slot (counts sum to the number of
+ *   distinct rows) and pos[p] = pos[rep[p]] for every other slot.  Integer, bit-exact. */
+int dr_shard_dedup_slots(const int64_t* sorted_rows, const int32_t* sorted_slots, const int32_t* dup_count, int64_t n,
+                         int64_t num_rows, int64_t* rep, dr_stream_t stream);
+int dr_shard_bucket_ids_dedup(const int64_t* ids, const int64_t* rep, int64_t n, int32_t C, int64_t rows_per_shard,
+                              int32_t world, int64_t* counts, int64_t* send_rows, int64_t* pos, int64_t* workspace,
+                              dr_stream_t stream);
 int dr_rows_gather(const int64_t* rows, int64_t n, const float* table, int32_t D, const float* lin_w,
                    float* out_rows, float* out_lin, dr_stream_t stream);
 int dr_rows_scatter_add(const int64_t* rows, int64_t n, const float* grads, int32_t D,
@@ -509,6 +520,12 @@ int dr_emb_pack_grads(const int64_t* pos, int64_t B, int32_t F, int32_t D, const
                       int64_t ld_dconcat, const float* concat, int64_t ld_concat, const float* sum_x,
                       const float* d_fm_logit, float* out_rows, float* out_lin, float* bias_sum,
                       dr_stream_t stream);
+/* the same for a de-duplicated exchange: pos maps the slots of a shared row to ONE destination; unique_flags [B * F] (the slot plan's
+ * flags of the micro-batch) says which slots own their row -- those store, the others ADD with fp32 atomics (their order is not
+ * fixed).  out_rows / out_lin must be zero-filled by the caller. */
+int dr_emb_pack_grads_dedup(const int64_t* pos, const uint8_t* unique_flags, int64_t B, int32_t F, int32_t D, const float* d_concat,
+                            int64_t ld_dconcat, const float* concat, int64_t ld_concat, const float* sum_x,
+                            const float* d_fm_logit, float* out_rows, float* out_lin, float* bias_sum, dr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K7p  first (wide) tower layer on PRE-SPLIT operands -- the "planes" form of the bf16x3 product mode.

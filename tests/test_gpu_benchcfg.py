@@ -376,12 +376,12 @@ def test_deepfm_bench_config_overlap_on_off_agree():
         _assert_update(name + " (overlap off vs on)", b0, a1, a0, rel=1e-4, outliers=1e-4)
 
 
-@pytest.mark.parametrize("Bd,V", [(8192, 200_000), (65536, 1_000_000)])
+@pytest.mark.parametrize("Bd,V", [(8192, 200_000), (65536, 10_000_000)])
 def test_dcn_bench_config_matches_oracle(Bd, V):
     """bench.py --model dcn (BASELINE config 4): Din = 26 * 64 + 13 = 1677, 3 full-rank cross layers, MLP [1024, 512, 256],
-    fused SGD.  Batch 8192 keeps the host side short; batch 65 536 is the configuration's own (the benched size had no
-    oracle test) with the compact-table trick of the DeepFM tests -- the oracle trains the rows the batch touches (V does not
-    enter the arithmetic; the 10 M-row slab is exercised by test_deepfm_bench_config_full_vocab_sgd_uniform).
+    fused SGD.  Batch 8192 keeps the host side short; batch 65 536 over the full 26 x 10 M-row slab (66.6 GB) is the configuration
+    bench.py --model dcn times (the oracle test ran at V = 1 M), with the compact-table trick of the DeepFM tests --
+    the touched rows are gathered to the host and the oracle trains that compact table.
     Oracle in float64 (T.cross / dense layers under autograd), as in test_gpu_models.py."""
     from deep_recommenders_amd.dcn_engine import DCNEngine
     lr = 1.0

@@ -437,6 +437,66 @@ def test_shard_bucket_ids_bit_exact(ops, world):
     np.testing.assert_array_equal(pos.cpu().numpy().reshape(-1), want_pos)
 
 
+@pytest.mark.parametrize("V,path", [(50_000, "claim"), (300, "radix")])
+def test_shard_dedup_bucketing_and_pack(ops, V, path):
+    """Requester-side de-duplication (dr_shard_dedup_slots / dr_shard_bucket_ids_dedup / dr_emb_pack_grads_dedup): the lowest slot of
+    every row is its representative (bit-exact against NumPy), only representatives get a send slot, every slot's position points at
+    its row's place, and the pack sums the gradients of the slots that share a row.  V = 300: nearly every slot shares its row (the
+    plan's radix path, every slot in the sorted arrays); V = 50 000: mostly unique rows (the claim path: only the shared-row slots)."""
+    rng = np.random.default_rng(21)
+    B, F, D, world = 2048, 6, 64, 4
+    ids = rng.integers(0, V, size=(B, F))
+    ids[rng.random((B, F)) < 0.01] = -1
+    base = np.arange(F, dtype=np.int64) * V
+    ids_d, base_d = _dev(ids), _dev(base)
+    plan = ops.emb_sort_slots(ids_d, base_d, F * V)
+    rep, flags = ops.shard_dedup_slots(ids_d, base_d, F * V, plan)
+    flat = ids.reshape(-1)
+    rows = np.where(flat >= 0, flat + np.tile(base, B), -1 - np.arange(flat.size))
+    uniq, first, cnt = np.unique(rows, return_index=True, return_counts=True)
+    idx = np.searchsorted(uniq, rows)
+    np.testing.assert_array_equal(rep.cpu().numpy(), first[idx])
+    want_flags = np.where(flat >= 0, cnt[idx] == 1, flags.cpu().numpy()[:flat.size] != 0)      # (a missing id's flag is not consumed)
+    np.testing.assert_array_equal(flags.cpu().numpy()[:flat.size][flat >= 0] != 0, want_flags[flat >= 0])
+    rps = (V + world - 1) // world
+    counts, send_rows, pos = ops.shard_bucket_ids(ids_d, rps, world, rep=rep)
+    p = np.arange(flat.size)
+    is_rep = first[idx] == p
+    owner = np.where(flat >= 0, flat % world, p % world)
+    local = np.where(flat >= 0, (p % F) * rps + flat // world, -1)
+    keep = p[is_rep]
+    order = keep[np.argsort(owner[keep], kind="stable")]
+    want_pos = np.full(flat.size, -1, dtype=np.int64)
+    want_pos[order] = np.arange(order.size)
+    want_pos = want_pos[first[idx]]
+    np.testing.assert_array_equal(counts.cpu().numpy(), np.bincount(owner[keep], minlength=world))
+    n_send = order.size
+    np.testing.assert_array_equal(send_rows.cpu().numpy()[:n_send], local[order])
+    np.testing.assert_array_equal(pos.cpu().numpy().reshape(-1), want_pos)
+    assert n_send < flat.size
+    # pack: shared rows accumulate
+    ld = F * D + 4
+    d_concat = rng.standard_normal((B, ld)).astype(np.float32)
+    concat = rng.standard_normal((B, ld)).astype(np.float32)
+    sum_x = rng.standard_normal((B, D)).astype(np.float32)
+    dl = rng.standard_normal(B).astype(np.float32)
+    out = torch.zeros((n_send, D), device="cuda")
+    out_lin = torch.zeros(n_send, device="cuda")
+    bias = torch.zeros(1, device="cuda")
+    ops.emb_pack_grads(pos, D, _dev(d_concat), _dev(concat), _dev(sum_x), _dev(dl), out, out_lin, bias, unique_flags=flags)
+    want = np.zeros((n_send, D))
+    want_lin = np.zeros(n_send)
+    for f in range(F):
+        g = d_concat[:, f * D:(f + 1) * D].astype(np.float64) + dl[:, None].astype(np.float64) * (sum_x.astype(np.float64) - concat[:, f * D:(f + 1) * D])
+        np.add.at(want, want_pos.reshape(B, F)[:, f], g)
+        np.add.at(want_lin, want_pos.reshape(B, F)[:, f], dl.astype(np.float64))
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(out_lin.cpu().numpy(), want_lin, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(float(bias[0]), float(dl.astype(np.float64).sum()), rtol=1e-5, atol=1e-4)
+    if path == "claim":
+        assert plan.sorted_len() < B * F                   # only the shared-row slots were sorted
+
+
 def test_rows_gather_scatter_axpy(ops):
     rng = np.random.default_rng(14)
     R, D, n = 1000, 64, 5003

@@ -27,6 +27,10 @@ SMALL = dict(F=6, V=3001, D=16, B=768, Nd=3, units=[32, 16], lr=0.05, key_max=10
 FUSED = dict(F=5, V=2003, D=64, B=4096, Nd=3, units=[128, 16], lr=0.05, key_max=10**14, steps=2, expect_fused_l0=True)
 
 
+# the de-duplicated exchange on a problem where most slots share their row (500 ids per field, 2048 examples per micro-batch)
+DEDUP = dict(F=5, V=503, D=64, B=4096, Nd=3, units=[128, 16], lr=0.05, key_max=10**14, steps=2, expect_fused_l0=True, dedup=True)
+
+
 def _assert_close(name, got, want, before=None, rel=2e-3):
     """parameters after N steps: |got - want| <= rel * |want - before| + a few ulp + 1e-3 rms(update) for all but 1e-4 of the
     elements (ReLU ties, see tests/test_gpu_benchcfg.py::_assert_update); without `before`: plain allclose."""
@@ -46,9 +50,9 @@ def _assert_close(name, got, want, before=None, rel=2e-3):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("cfg_name,micro_batches", [("SMALL", 2), ("FUSED", 2), ("FUSED", 1)])
+@pytest.mark.parametrize("cfg_name,micro_batches", [("SMALL", 2), ("FUSED", 2), ("FUSED", 1), ("DEDUP", 2)])
 def test_two_ranks_one_gpu_deepfm_sgd_equals_oracle(tmp_path, cfg_name, micro_batches):
-    cfg = dict(SMALL if cfg_name == "SMALL" else FUSED)
+    cfg = dict({"SMALL": SMALL, "FUSED": FUSED, "DEDUP": DEDUP}[cfg_name])
     world = 2
     res = SG._spawn(SG._worker, (micro_batches, "sgd", None, True, cfg), tmp_path, timeout=500)
     Ws0, bs0 = res[0][6], res[0][7]

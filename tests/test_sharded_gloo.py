@@ -29,18 +29,49 @@ class OraclePrims:
         return res
 
     @staticmethod
-    def shard_bucket_ids(ids, rows_per_shard, world):
+    def shard_bucket_ids(ids, rows_per_shard, world, rep=None):
         B, C = ids.shape
         flat = ids.reshape(-1).numpy()
         p = np.arange(flat.size)
         owner = np.where(flat >= 0, flat % world, p % world)
         local = np.where(flat >= 0, (p % C) * rows_per_shard + flat // world, -1)
-        order = np.argsort(owner, kind="stable")
-        pos = np.empty_like(order)
+        if rep is None:
+            order = np.argsort(owner, kind="stable")
+            pos = np.empty_like(order)
+            pos[order] = np.arange(order.size)
+            counts = np.bincount(owner, minlength=world).astype(np.int64)
+            return torch.from_numpy(counts), torch.from_numpy(local[order].astype(np.int64)), \
+                torch.from_numpy(pos.astype(np.int64)).reshape(B, C)
+        # de-duplicated: only the representatives get a send slot, every other slot shares its representative's position
+        rep = rep.numpy()
+        is_rep = rep == p
+        keep = p[is_rep]
+        order = keep[np.argsort(owner[keep], kind="stable")]
+        pos = np.full(flat.size, -1, dtype=np.int64)
         pos[order] = np.arange(order.size)
-        counts = np.bincount(owner, minlength=world).astype(np.int64)
-        return torch.from_numpy(counts), torch.from_numpy(local[order].astype(np.int64)), \
-            torch.from_numpy(pos.astype(np.int64)).reshape(B, C)
+        pos = pos[rep]
+        counts = np.bincount(owner[keep], minlength=world).astype(np.int64)
+        send = np.full(flat.size, -7, dtype=np.int64)          # (entries past the distinct rows are never sent)
+        send[:order.size] = local[order]
+        return torch.from_numpy(counts), torch.from_numpy(send), torch.from_numpy(pos).reshape(B, C)
+
+    @staticmethod
+    def new_sort_plan(n, device):
+        return "oracle-plan"
+
+    @staticmethod
+    def shard_dedup_slots(ids, row_base, num_rows, plan, out=None):
+        """rep[p] = lowest slot with the same (field, id); missing ids keep their own slot; flags = 1 iff no other slot shares the row"""
+        B, F = ids.shape
+        rows = (ids + row_base[None, :]).reshape(-1).numpy()
+        miss = ids.reshape(-1).numpy() < 0
+        p = np.arange(rows.size)
+        key = np.where(miss, -1 - p, rows)                       # every missing slot is its own key
+        uniq, first, cnt = np.unique(key, return_index=True, return_counts=True)
+        idx = np.searchsorted(uniq, key)
+        rep = first[idx]
+        flags = (cnt[idx] == 1).astype(np.uint8)
+        return torch.from_numpy(rep.astype(np.int64)), torch.from_numpy(flags)
 
     @staticmethod
     def rows_gather(rows, table, lin_w=None):
@@ -88,12 +119,17 @@ class OraclePrims:
             dst_bias += scale * d_fm.sum()
 
     @staticmethod
-    def emb_pack_grads(pos, D, d_concat, concat, sum_x, d_fm, out_rows, out_lin=None, bias_sum=None):
+    def emb_pack_grads(pos, D, d_concat, concat, sum_x, d_fm, out_rows, out_lin=None, bias_sum=None, unique_flags=None):
         B, F = pos.shape
         for f in range(F):
             g = d_concat[:, f * D:(f + 1) * D]
             if d_fm is not None:
                 g = g + d_fm[:, None] * (sum_x - concat[:, f * D:(f + 1) * D])
+            if unique_flags is not None:                     # de-duplicated: slots of a shared row accumulate (zero-filled buffers)
+                out_rows.index_add_(0, pos[:, f], g)
+                if out_lin is not None:
+                    out_lin.index_add_(0, pos[:, f], d_fm)
+                continue
             out_rows[pos[:, f]] = g
             if out_lin is not None:
                 out_lin[pos[:, f]] = d_fm
@@ -276,7 +312,8 @@ def _worker(rank, world, port, outdir, micro_batches, optimizer="sgd", units=Non
         dev = kw["device"]
         eng = ShardedDeepFMEngine(c["F"], c["V"], c["D"], units or c["units"], c["B"], num_dense=c["Nd"], lr=c["lr"],
                                   world=world, rank=rank, seed=5, init_tables=(table, lin),
-                                  micro_batches=micro_batches, optimizer=optimizer, **kw)
+                                  micro_batches=micro_batches, optimizer=optimizer, dedup=bool(c.get("dedup", False)), **kw)
+        assert eng.ex.dedup == bool(c.get("dedup", False))
         assert eng.mb == (1 if (optimizer == "adam" or not eng.fuse_head) else micro_batches)
         assert eng.fuse_head == (units is None)         # the [16, 40] tower of the unfused-head test cannot take the fused head
         if gpu and c.get("expect_fused_l0") is not None:
@@ -382,6 +419,62 @@ def test_two_rank_sharded_steps_equal_single_process_oracle(tmp_path, micro_batc
             np.testing.assert_allclose(Ws_r[i].numpy(), Wc[i].numpy(), rtol=2e-5, atol=2e-6)
             np.testing.assert_allclose(bs_r[i].numpy(), bc[i].numpy(), rtol=2e-5, atol=2e-6)
         np.testing.assert_allclose(bias_r.numpy(), bias.numpy(), rtol=2e-5, atol=2e-7)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("micro_batches,optimizer", [(1, "sgd"), (2, "sgd"), (1, "adam")])
+def test_two_rank_sharded_dedup_exchange_equals_single_process_oracle(tmp_path, micro_batches, optimizer):
+    """Requester-side de-duplication (dedup=True; [TF] `unique` inside the lookup, keras/models/ranking/fm.py:57-61): rows that several
+    slots of a micro-batch share travel once each way and their gradients are summed before they are sent.  Same assertion as the plain
+    exchange -- the result equals the single-process oracle on the global batches -- on a problem where sharing is the rule (24
+    examples x 4 fields over 37 ids per field), and the wire really carries fewer rows."""
+    world = 2
+    cfg = dict(CFG, dedup=True)
+    res = _spawn(_worker, (micro_batches, optimizer, None, False, cfg), tmp_path)
+    Ws0, bs0 = res[0][6], res[0][7]
+    losses, tab, li, bias, Wc, bc = _reference_deepfm(cfg, Ws0, bs0, optimizer)
+    for t, lo in enumerate(losses):
+        assert abs(0.5 * (res[0][0][t] + res[1][0][t]) - lo) < 2e-6
+    tol = dict(rtol=2e-5, atol=2e-6) if optimizer == "sgd" else dict(rtol=0, atol=2e-3 * cfg["lr"])
+    for r in range(world):
+        _, tab_r, lin_r, Ws_r, bs_r, bias_r, _, _ = res[r]
+        for got, want in _shard_views(cfg, world, r, tab_r, lin_r, tab, li):
+            np.testing.assert_allclose(got.numpy(), want.numpy(), **tol)
+        for i in range(len(Wc)):
+            np.testing.assert_allclose(Ws_r[i].numpy(), Wc[i].numpy(), **tol)
+
+
+def test_dedup_bucketing_sends_each_distinct_row_once():
+    """The representative map and the de-duplicated bucketing of the oracle-backed primitives (the HIP kernels are checked against
+    exactly these in tests/test_gpu_kernels.py): counts sum to the number of distinct rows (+ one slot per missing id), every slot's
+    position points at its row, representatives are the lowest slots."""
+    g = torch.Generator().manual_seed(4)
+    B, F, V, world = 40, 3, 11, 2
+    ids = torch.randint(0, V, (B, F), generator=g)
+    ids[2, 1] = -1
+    ids[7, 1] = -1
+    base = torch.arange(F) * V
+    rep, flags = OraclePrims.shard_dedup_slots(ids, base, F * V, None)
+    flat = (ids + base[None, :]).reshape(-1)
+    for p_ in range(B * F):
+        r = int(rep[p_])
+        if ids.reshape(-1)[p_] < 0:
+            assert r == p_ and flags[p_] == 1
+            continue
+        assert r <= p_ and flat[r] == flat[p_] and not bool((flat[:r] == flat[p_]).any())
+        assert bool(flags[p_]) == (int((flat == flat[p_]).sum()) == 1)
+    rps = (V + world - 1) // world
+    counts, send, pos = OraclePrims.shard_bucket_ids(ids, rps, world, rep=rep)
+    n_distinct = len(set(flat[ids.reshape(-1) >= 0].tolist())) + 2
+    assert int(counts.sum()) == n_distinct
+    cflat, pflat = ids.reshape(-1), pos.reshape(-1)
+    for p_ in range(B * F):
+        want = -1 if cflat[p_] < 0 else (p_ % F) * rps + int(cflat[p_]) // world
+        assert int(send[pflat[p_]]) == want
+    owner_of_pos = np.repeat(np.arange(world), counts.numpy())
+    for p_ in range(B * F):
+        if cflat[p_] >= 0:
+            assert owner_of_pos[pflat[p_]] == int(cflat[p_]) % world
 
 
 @pytest.mark.timeout(300)

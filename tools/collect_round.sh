@@ -16,8 +16,8 @@ timeout 400 python bench.py > gpurun_out/line_default.log 2>&1
 timeout 200 python bench.py --optimizer adam --no-cpu-baseline > gpurun_out/line_adam.log 2>&1
 timeout 200 python bench.py --ids zipf --no-cpu-baseline > gpurun_out/line_zipf.log 2>&1
 timeout 200 python bench.py --preset c2 --no-cpu-baseline > gpurun_out/line_c2.log 2>&1
-timeout 300 python bench.py --model dcn --no-cpu-baseline > gpurun_out/line_dcn.log 2>&1
-timeout 300 python bench.py --model dssm --no-cpu-baseline > gpurun_out/line_dssm.log 2>&1
+timeout 400 python bench.py --model dcn > gpurun_out/line_dcn.log 2>&1
+timeout 400 python bench.py --model dssm > gpurun_out/line_dssm.log 2>&1
 DR_FUSE_K3=0 DR_PREFETCH_PLAN=0 timeout 200 python bench.py --no-cpu-baseline > gpurun_out/line_unfused.log 2>&1
 DR_NO_CONCAT=0 timeout 200 python bench.py --no-cpu-baseline > gpurun_out/line_concat.log 2>&1
 DR_FORCE_SHARDED=1 timeout 200 python bench.py --no-cpu-baseline > gpurun_out/line_sharded_world1.log 2>&1
