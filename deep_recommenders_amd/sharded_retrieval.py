@@ -179,6 +179,18 @@ class ShardedTwoTowerEngine:
         self.loss = torch.zeros(1, **f32)
         self.corpus = None
         self._cuda = torch.device(device).type == "cuda"
+        # The two towers are independent until the score matrix, and every one of their kernels is small (64 - 128 blocks on 256
+        # CUs): the candidate side (row exchange + tower forward; dc all-reduce, tower backward, gradient exchange + owner-side
+        # update) CAN run on a second stream beside the query side, as in two_tower_engine.TwoTowerEngine (DR_TT_STREAMS=1; round 4).
+        # Built, parity-tested on two ranks, measured at world 1 and left OFF: 2.30 ms per step against 2.25 on one stream (same
+        # call, alternating) -- this step is bound by the host (two routes with a blocking split-size read each, ~120 small
+        # launches), not by the device, so a second stream only adds fork / join packets.  Collectives are ISSUED in one fixed order
+        # on every rank (candidate side first), whatever stream carries them.
+        import os as _os
+        self.two_streams = self._cuda and _os.environ.get("DR_TT_STREAMS", "0") == "1"
+        if self.two_streams:
+            self.side = torch.cuda.Stream(device=device)
+            self.ev_fork, self.ev_c = torch.cuda.Event(), torch.cuda.Event()
 
     def enable_kernel_events(self, on):       # bench.py contract; the sharded step reports no per-kernel rows
         pass
@@ -197,6 +209,21 @@ class ShardedTwoTowerEngine:
         return r, emb
 
     def embeddings(self, user_keys, item_ids):
+        if self.two_streams:
+            main = torch.cuda.current_stream()
+            self.ev_fork.record(main)
+            item_ids.record_stream(self.side)
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(self.ev_fork)
+                ri, i = self._embed(self.ex_i, item_ids, self.item_table, False)
+                c = self.c_tower.forward(self.p, i) if self.c_tower.Ws else i
+                self.ev_c.record(self.side)
+            ru, u = self._embed(self.ex_u, user_keys, self.user_table, True)
+            q = self.q_tower.forward(self.p, u) if self.q_tower.Ws else u
+            main.wait_event(self.ev_c)
+            for t in [i, c] + list(getattr(self.c_tower, "xs", [])):
+                t.record_stream(main)
+            return ru, ri, q, c
         ru, u = self._embed(self.ex_u, user_keys, self.user_table, True)
         ri, i = self._embed(self.ex_i, item_ids, self.item_table, False)
         q = self.q_tower.forward(self.p, u) if self.q_tower.Ws else u
@@ -226,20 +253,40 @@ class ShardedTwoTowerEngine:
         else:
             dq = torch.empty((B, _pad4(self.out_dim)), dtype=torch.float32, device=q.device)[:, :self.out_dim]
             p.linear_fwd(G, c_all, None, 0, out=dq)                                    # dq = G c_all
-        dc_all = torch.zeros((W * B, _pad4(self.out_dim)), dtype=torch.float32, device=q.device)[:, :self.out_dim]
-        p.linear_bwd_dw(G, q, 1.0, dc_all)                                             # this rank's part of G^T q
-        dc_buf = dc_all if dc_all.is_contiguous() else dc_all.contiguous()
-        self.tr.allreduce(dc_buf)                                                      # candidates' gradients from every rank's queries
-        dc = dc_buf[self.rank * B:(self.rank + 1) * B]
+        def cand_side():
+            dc_all = torch.zeros((W * B, _pad4(self.out_dim)), dtype=torch.float32, device=q.device)[:, :self.out_dim]
+            p.linear_bwd_dw(G, q, 1.0, dc_all)                                         # this rank's part of G^T q
+            dc_buf = dc_all if dc_all.is_contiguous() else dc_all.contiguous()
+            self.tr.allreduce(dc_buf)                                                  # candidates' gradients from every rank's queries
+            dc = dc_buf[self.rank * B:(self.rank + 1) * B]
+            d_i = self.c_tower.backward(p, dc) if self.c_tower.Ws else dc
+            d_i = d_i if d_i.stride(1) == 1 else d_i.contiguous()
+            g_rows, _ = self.ex_i.pack(ri, d_i, None, None, None)
+            self.ex_i.exchange_and_apply(ri, g_rows, None, -lr, self.item_table, None)  # C3 + K4 (item rows)
+            return dc_buf
+
         self.flat_grads.zero_()
-        d_u = self.q_tower.backward(p, dq) if self.q_tower.Ws else dq
-        d_i = self.c_tower.backward(p, dc) if self.c_tower.Ws else dc
+        if self.two_streams:
+            # candidate side of the backward on the second stream; the two towers' gradients live in disjoint parts of the bucket
+            main = torch.cuda.current_stream()
+            self.ev_fork.record(main)
+            for t in (G, q):
+                t.record_stream(self.side)
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(self.ev_fork)
+                keep = cand_side()
+                self.ev_c.record(self.side)
+            d_u = self.q_tower.backward(p, dq) if self.q_tower.Ws else dq
+            main.wait_event(self.ev_c)
+            keep.record_stream(main)
+        else:
+            d_u = self.q_tower.backward(p, dq) if self.q_tower.Ws else dq
+            cand_side()
         self.tr.allreduce(self.flat_grads)                                             # C4
         p.axpy(-lr, self.flat_grads, self.flat_params)
-        for ex, r, d_emb, table in ((self.ex_u, ru, d_u, self.user_table), (self.ex_i, ri, d_i, self.item_table)):
-            d_emb = d_emb if d_emb.stride(1) == 1 else d_emb.contiguous()
-            g_rows, _ = ex.pack(r, d_emb, None, None, None)
-            ex.exchange_and_apply(r, g_rows, None, -lr, table, None)                    # C3 + K4
+        d_u = d_u if d_u.stride(1) == 1 else d_u.contiguous()
+        g_rows, _ = self.ex_u.pack(ru, d_u, None, None, None)
+        self.ex_u.exchange_and_apply(ru, g_rows, None, -lr, self.user_table, None)      # C3 + K4 (user rows)
         return self.loss
 
     # ---- corpus index + metric pass -------------------------------------------------------------------------------------------
