@@ -454,7 +454,8 @@ def main():
         k4 = lambda: _ops.emb_pool_bwd_sorted(eng.ids, eng.row_base, eng.plan, eng.D, eng.R, eng.d_concat, eng.d_logit, -eng.lr,
                                               eng.table, eng.lin_w, eng.lin_bias,
                                               concat=None if eng.no_concat else eng.concat, sum_x=eng.sum_x,
-                                              x_sorted=eng.x_sorted if eng.no_concat else None, parts=1)
+                                              x_sorted=eng.x_sorted if eng.no_concat else None, parts=1,
+                                              lin_old_t=getattr(eng, "lin_old_t", None) if getattr(eng, "_lin_old_valid", False) else None)
         for _ in range(3):
             k4()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -61,6 +61,8 @@ SIGNATURES = {
                                _p, _p, _p],
     "dr_emb_pool_bwd_sorted_parts": [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _i64, _p, _i64, _p, _p, _p, _f32, _p, _p,
                                      _p, _p, _i32, _p],
+    "dr_emb_pool_bwd_sorted_ex": [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _i64, _p, _i64, _p, _p, _p, _f32, _p, _p,
+                                  _p, _p, _p, _i32, _p],
     "dr_emb_lin_update_unique": [_p, _p, _i64, _i32, _p, _p, _p, _f32, _p, _p],
     "dr_emb_snapshot_sorted_rows": [_p, _p, _p, _p, _i32, _i64, _p, _p],
     "dr_ids_transpose_i32": [_p, _i64, _i32, _p, _p],
@@ -93,6 +95,8 @@ SIGNATURES = {
     "dr_linear_fwd_splitk_workspace_bytes": [_i64, _i32, _i32],
     "dr_linear_fwd_splitk": [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _i64, _p, _i64, _p],
     "dr_bf3_emb_linear_fwd": [_p, _i64, _i32, _p, _i64, _p, _i32, _p, _p, _p, _p, _i64, _i32, _p, _i64, _i64, _i32, _p, _i32, _p, _p, _p, _i64, _p],
+    "dr_bf3_emb_linear_fwd_lv": [_p, _i64, _i32, _p, _i64, _p, _i32, _p, _p, _p, _p, _i64, _i32, _p, _i64, _i64, _i32, _p, _i32, _p, _p, _p, _i64,
+                                 _p, _p],
     "dr_bf3_wgrad_workspace_bytes": [_i64, _i32, _i32],
     "dr_bf3_wgrad": [_p, _i64, _p, _i64, _i64, _i32, _i32, _f32, _p, _i64, _p, _p, _i64, _p],
     "dr_bf3_wgrad_emb": [_p, _i64, _i32, _p, _p, _i32, _p, _p, _i64, _i32, _i32, _f32, _p, _i64, _p, _p, _i64, _p],

@@ -1075,6 +1075,8 @@ struct EmbArgs {
     const float* dense_pad;                      // [M, 32] dense features, zero-padded (null when K == 64 F)
     float* concat; int64_t ld_concat;            // out: [M, ld], columns [0, 64 F)
     float* sum_x; float* fm_logit;               // out: [M, 64], [M]
+    float* lin_vals;                             // out (may be null): [F, M] field-major, the first-order weight every slot read -- K4
+                                                 // then only WRITES lin_w[row] (one line operation per slot instead of two; round 4)
 };
 
 __device__ __forceinline__ int sload_i32(const void* base, int byte_off) {      // scalar load of a wave-uniform word, on the spot
@@ -1285,6 +1287,12 @@ __global__ __launch_bounds__(512, 2) void bf3_emb_linear_kernel(RsArgs g, EmbArg
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { S0[4 * q] += an[q][0]; S0[4 * q + 1] += an[q][1]; S0[4 * q + 2] += an[q][2]; S0[4 * q + 3] += an[q][3]; }
                 lin += (hi == 0 && !mo_cur && has_lw) ? lwn : 0.f;
+                if (e.lin_vals != nullptr) {                                // (kernel-uniform)
+                    // lanes l and l + 32 hold the same row's weight: both store it (same address, same value) -- no divergent
+                    // branch around a memory operation; asm for the reason given at the concat stores above
+                    float* lv = e.lin_vals + (int64_t)(kt >> 1) * g.M + min(m0c + wave * 32 + l31, (int)g.M - 1);
+                    asm volatile("global_store_dword %0, %1, off" :: "v"(lv), "v"(lwn) : "memory");
+                }
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { S1[4 * q] += an[q][0]; S1[4 * q + 1] += an[q][1]; S1[4 * q + 2] += an[q][2]; S1[4 * q + 3] += an[q][3]; }
@@ -2311,11 +2319,11 @@ extern "C" int dr_bf3_wgrad_emb(const int32_t* ids_t, int64_t R, int32_t nf, con
 // Fused K3 + first Dense layer (see bf3_emb_linear_kernel): h[m][n] = act(sum_k x[m][k] W[k][n] + bias[n]) with
 // x = concat(field embeddings of ids[m], dense features = dense_pad[m, : K - 64 F]); also writes concat[:, : 64 F],
 // sum_x [M, 64] and fm_logit [M] = lin_bias + sum_f lin_w[row] + 0.5 sum_d ((sum_f x_fd)^2 - sum_f x_fd^2).
-extern "C" int dr_bf3_emb_linear_fwd(const int64_t* ids, int64_t M, int32_t F, const int64_t* row_base, int64_t field_rows_max,
-                                     const float* table, int32_t D, const float* lin_w, const float* lin_bias, const float* dense_pad, float* concat,
-                                     int64_t ld_concat, int32_t K, const void* wt_planes, int64_t plane_stride, int64_t ld_planes, int32_t N,
-                                     const float* bias, int32_t act, float* sum_x, float* fm_logit, float* out, int64_t ld_out,
-                                     dr_stream_t stream) {
+static int emb_linear_fwd_impl(const int64_t* ids, int64_t M, int32_t F, const int64_t* row_base, int64_t field_rows_max,
+                               const float* table, int32_t D, const float* lin_w, const float* lin_bias, const float* dense_pad, float* concat,
+                               int64_t ld_concat, int32_t K, const void* wt_planes, int64_t plane_stride, int64_t ld_planes, int32_t N,
+                               const float* bias, int32_t act, float* sum_x, float* fm_logit, float* out, int64_t ld_out,
+                               float* lin_vals_t, dr_stream_t stream) {
     if (M < 0 || M > 0x7fffff00 || F <= 0 || N <= 0 || K < 64 * F || act < 0 || act > 1) return DR_EINVAL;
     // the k-tile <-> (field, half row) map is built for 64-wide rows; the dense features are one k-tile; a field is one 4 GB buffer
     if (D != 64 || K > 64 * F + 32 || field_rows_max <= 0 || field_rows_max > (1 << 24)) return DR_ESHAPE;
@@ -2330,11 +2338,33 @@ extern "C" int dr_bf3_emb_linear_fwd(const int64_t* ids, int64_t M, int32_t F, c
     if (ld_planes < (K + BK - 1) / BK * BK || ld_out < N) return DR_EINVAL;
     RsArgs g{nullptr, 0, static_cast<const __bf16*>(wt_planes), plane_stride, ld_planes, M, N, K, out, ld_out, bias, act, nullptr, 0, 0,
              nullptr, nullptr, 0, 0.f, nullptr};
-    EmbArgs e{ids, F, row_base, table, lin_w, lin_bias, K > 64 * F ? dense_pad : nullptr, concat, ld_concat, sum_x, fm_logit};
+    EmbArgs e{ids, F, row_base, table, lin_w, lin_bias, K > 64 * F ? dense_pad : nullptr, concat, ld_concat, sum_x, fm_logit,
+              lin_w != nullptr ? lin_vals_t : nullptr};
     const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
     if (tiles > 0x7fffffff) return DR_EINVAL;
     const int grid = (int)(tiles < 256 ? tiles : 256);
     hipLaunchKernelGGL(bf3_emb_linear_kernel, dim3(grid), dim3(512), 0, dr_s(stream), g, e);
     DR_CHECK_LAUNCH();
     return DR_OK;
+}
+
+extern "C" int dr_bf3_emb_linear_fwd(const int64_t* ids, int64_t M, int32_t F, const int64_t* row_base, int64_t field_rows_max,
+                                     const float* table, int32_t D, const float* lin_w, const float* lin_bias, const float* dense_pad, float* concat,
+                                     int64_t ld_concat, int32_t K, const void* wt_planes, int64_t plane_stride, int64_t ld_planes, int32_t N,
+                                     const float* bias, int32_t act, float* sum_x, float* fm_logit, float* out, int64_t ld_out,
+                                     dr_stream_t stream) {
+    return emb_linear_fwd_impl(ids, M, F, row_base, field_rows_max, table, D, lin_w, lin_bias, dense_pad, concat, ld_concat, K, wt_planes,
+                               plane_stride, ld_planes, N, bias, act, sum_x, fm_logit, out, ld_out, nullptr, stream);
+}
+
+// The same, also saving the first-order weight of every slot as it was read: lin_vals_t [F, M] field-major (lin_vals_t[f * M + m] =
+// lin_w[row_base[f] + ids[m, f]]; undefined for a missing id).  dr_emb_pool_bwd_sorted_ex takes it as `lin_old_t`: the backward then
+// updates a unique row's first-order weight with ONE write instead of a read-modify-write of a line it would have to fetch again.
+extern "C" int dr_bf3_emb_linear_fwd_lv(const int64_t* ids, int64_t M, int32_t F, const int64_t* row_base, int64_t field_rows_max,
+                                        const float* table, int32_t D, const float* lin_w, const float* lin_bias, const float* dense_pad,
+                                        float* concat, int64_t ld_concat, int32_t K, const void* wt_planes, int64_t plane_stride,
+                                        int64_t ld_planes, int32_t N, const float* bias, int32_t act, float* sum_x, float* fm_logit,
+                                        float* out, int64_t ld_out, float* lin_vals_t, dr_stream_t stream) {
+    return emb_linear_fwd_impl(ids, M, F, row_base, field_rows_max, table, D, lin_w, lin_bias, dense_pad, concat, ld_concat, K, wt_planes,
+                               plane_stride, ld_planes, N, bias, act, sum_x, fm_logit, out, ld_out, lin_vals_t, stream);
 }

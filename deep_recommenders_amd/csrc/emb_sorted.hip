@@ -79,11 +79,17 @@ __device__ __forceinline__ void emb_bwd_unique_body(const int bid, const int nbl
                                                               const float* __restrict__ d_fm_logit,
                                                               const float* __restrict__ slot_lin, float scale,
                                                               float* __restrict__ table, float* __restrict__ lin_w,
-                                                              float* __restrict__ lin_bias, AdamArgs ad) {
+                                                              float* __restrict__ lin_bias, AdamArgs ad,
+                                                              const float* __restrict__ lin_old_t) {
     constexpr int NS = DR_WAVE / LPR;
     const int lane = threadIdx.x & 63, slot = lane / LPR, sub = lane % LPR;
     const int nq = D >> 2;
     const bool dvalid = sub < nq;
+    // lin_old_t [F, B] (may be NULL; SGD only): the first-order weight every slot READ in the forward (dr_bf3_emb_linear_fwd_lv).  A
+    // unique row's weight has not changed since, so its update is one WRITE of old + scale * g -- not a read-modify-write whose line
+    // has to come back from HBM first.  K4 is bound by 128-byte line operations (8 per slot with the RMW: gradient 2, row 2 + 2,
+    // first-order 1 + 1): this removes one of them (measured: 281 -> 264 us, tools/exp/k4_ladder.py LINW).
+    const bool lold = !ADAM && lin_old_t != nullptr && lin_w != nullptr;
     const int subc = dvalid ? sub : nq - 1;
     const bool fm = sum_x != nullptr && d_fm_logit != nullptr;      // (a unique row's own value IS x: concat is never read here)
     const bool do_lin = lin_w != nullptr && (d_fm_logit != nullptr || slot_lin != nullptr) && sub == 0;
@@ -104,17 +110,22 @@ __device__ __forceinline__ void emb_bwd_unique_body(const int bid, const int nbl
     const int64_t my_base = row_base[lanec];
     int64_t my_row;
     float dl;
+    const float* losrc = lold ? lin_old_t + (int64_t)lanec * B : dlsrc;     // (dummy source when there is no saved weight)
+    const int64_t lo_mul = lold ? 1 : 0;
+    float my_lo;
     {
         const int64_t id = ids[wave0 * F + lanec];
         const uint8_t fl = flags[wave0 * F + lanec];
         my_row = (lane < F && id >= 0 && fl) ? my_base + id : -1;
         dl = dlsrc[wave0];
+        my_lo = losrc[wave0 * lo_mul];
     }
     for (int64_t b = wave0; b < B; b += nwaves) {
         const int64_t bn = b + nwaves, bnc = bn < B ? bn : b;
         const int64_t next_id = ids[bnc * F + lanec];                    // prefetch, consumed at the loop bottom
         const uint8_t next_fl = flags[bnc * F + lanec];
         const float next_dl = dlsrc[bnc];
+        const float next_lo = losrc[bnc * lo_mul];
         if (d_fm_logit == nullptr) dl = 0.f;
         const float* grow = grad + b * ld;
         const float4 sx = *reinterpret_cast<const float4*>(sxsrc + b * sx_pitch + subc * 4);
@@ -133,10 +144,12 @@ __device__ __forceinline__ void emb_bwd_unique_body(const int bid, const int nbl
                 const int64_t rc = row[u] >= 0 ? row[u] : 0;
                 // (without a first-order table the dummy loads below read ONE address: indexed by the row they were a random
                 // 4-byte gather over the first gigabyte of `table` -- a line fetch per slot for nothing, 273 vs 236 us; round 4)
-                const int64_t lc = lin_w != nullptr ? rc : 0;
+                const int64_t lc = (lin_w != nullptr && !lold) ? rc : 0;
                 g[u] = ld4_stream(grow + fc * D + subc * 4);
                 t[u] = ld4_stream(table + rc * D + subc * 4);
                 lw[u] = lsrc[lc];
+                const float lo_u = __shfl(my_lo, fc, 64);
+                if (lold) lw[u] = lo_u;
                 gl[u] = slot_lin != nullptr ? slot_lin[b * F + fc] : dl;
                 if (ADAM) {
                     mt[u] = ld4_stream(ad.m + rc * D + subc * 4);
@@ -179,6 +192,7 @@ __device__ __forceinline__ void emb_bwd_unique_body(const int bid, const int nbl
         }
         my_row = (bn < B && lane < F && next_id >= 0 && next_fl) ? my_base + next_id : -1;
         dl = next_dl;
+        my_lo = next_lo;
     }
 }
 
@@ -350,6 +364,7 @@ struct BwdSortedArgs {
     float* x_sorted;
     int det;                                     // SGD: hot rows' pieces park their sums in x_sorted (emb_bwd_hot_apply_kernel adds them)
     int skip_unique_lin;                         // first-order weights of rows unique in the batch are updated by dr_emb_lin_update_unique
+    const float* lin_old_t;                      // [F, B] first-order weights as the forward read them (may be NULL)
 };
 #ifndef DR_K4_MINWAVES     // (experiment hooks: tools/exp/k4_occupancy.sh builds variants with -DDR_K4_MINWAVES=n / -DDR_K4_U=n)
 #define DR_K4_LB __launch_bounds__(256)
@@ -365,7 +380,7 @@ __global__ DR_K4_LB void emb_bwd_sorted_kernel(BwdSortedArgs a, AdamArgs ad, int
     else
         emb_bwd_unique_body<LPR, U, ADAM>(blockIdx.x - grid_d, gridDim.x - grid_d, a.ids, a.flags, a.B, a.F, a.row_base, a.D, a.grad,
                                           a.ld, a.concat, a.ldc, a.sum_x, a.d_fm_logit, a.slot_lin, a.scale, a.table,
-                                          a.skip_unique_lin ? nullptr : a.lin_w, a.lin_bias, ad);
+                                          a.skip_unique_lin ? nullptr : a.lin_w, a.lin_bias, ad, a.lin_old_t);
 }
 
 // Second half of the deterministic hot-row update (SGD with x_sorted given): for every row whose slots span more than one piece,
@@ -486,7 +501,7 @@ static int bwd_sorted_impl(const int64_t* ids, const int64_t* row_base, const in
                            int64_t ld_grad, const float* concat, int64_t ld_concat, const float* sum_x,
                            const float* d_fm_logit, const float* slot_lin_grad, float scale, float* dst_table,
                            float* dst_lin, float* dst_bias, const AdamArgs* adam, float* x_sorted, dr_stream_t stream,
-                           int parts = 3) {
+                           int parts = 3, const float* lin_old_t = nullptr) {
     if (B < 0 || F <= 0 || F > 64 || D < 4 || D > 256 || (D & 3) || num_rows <= 0) return DR_EINVAL;
     const int64_t n = B * F;
     if (n == 0) return DR_OK;
@@ -510,7 +525,8 @@ static int bwd_sorted_impl(const int64_t* ids, const int64_t* row_base, const in
     const int det = (adam == nullptr && x_sorted != nullptr && det_on) ? 1 : 0;
     const BwdSortedArgs ba{ids, unique_flags, B, F, row_base, D, grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit, slot_lin_grad,
                            scale, dst_table, dst_lin, dst_bias, rows, sorted_slots, n, dup_heads, dup_count, (uint64_t)num_rows,
-                           x_sorted, det, (adam == nullptr && (parts & 4)) ? 1 : 0};
+                           x_sorted, det, (adam == nullptr && (parts & 4)) ? 1 : 0,
+                           (adam == nullptr && slot_lin_grad == nullptr) ? lin_old_t : nullptr};
 #ifdef DR_K4_U
     constexpr int K4_U_OVERRIDE = DR_K4_U;
 #else
@@ -589,6 +605,23 @@ extern "C" int dr_emb_pool_bwd_sorted_parts(const int64_t* ids, const int64_t* r
     return bwd_sorted_impl(ids, row_base, sorted_rows, sorted_slots, unique_flags, dup_heads, dup_count, B, F, D, num_rows,
                            grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit, slot_lin_grad, scale, dst_table, dst_lin,
                            dst_bias, nullptr, x_sorted, stream, parts);
+}
+
+// dr_emb_pool_bwd_sorted_parts with `lin_old_t` [F, B] (field-major; may be NULL = as above): the first-order weight every slot read in
+// the forward of THIS step (dr_bf3_emb_linear_fwd_lv).  Rows unique in the batch then get dst_lin[row] = lin_old + scale * g as ONE
+// write -- valid only if nothing has written dst_lin since that forward.  Shared rows are summed and updated as before.
+extern "C" int dr_emb_pool_bwd_sorted_ex(const int64_t* ids, const int64_t* row_base, const int64_t* sorted_rows,
+                                         const int32_t* sorted_slots, const uint8_t* unique_flags,
+                                         const int32_t* dup_heads, const int32_t* dup_count, int64_t B, int32_t F,
+                                         int32_t D, int64_t num_rows, const float* grad, int64_t ld_grad,
+                                         const float* concat, int64_t ld_concat, const float* sum_x,
+                                         const float* d_fm_logit, const float* slot_lin_grad, float scale,
+                                         float* dst_table, float* dst_lin, float* dst_bias, float* x_sorted,
+                                         const float* lin_old_t, int32_t parts, dr_stream_t stream) {
+    if (parts < 1 || parts > 7 || (parts & 3) == 0) return DR_EINVAL;
+    return bwd_sorted_impl(ids, row_base, sorted_rows, sorted_slots, unique_flags, dup_heads, dup_count, B, F, D, num_rows,
+                           grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit, slot_lin_grad, scale, dst_table, dst_lin,
+                           dst_bias, nullptr, x_sorted, stream, parts, lin_old_t);
 }
 
 // dst_lin[row_base[f] + ids[b, f]] += scale * (slot_lin_grad ? slot_lin_grad[b, f] : d_fm_logit[b])  for every slot whose row no other

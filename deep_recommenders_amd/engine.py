@@ -167,6 +167,12 @@ class DeepFMEngine:
         if self.no_concat:
             self._ids_t = [torch.empty((F, B), dtype=torch.int32, device=device) for _ in range(2)]
             self.x_sorted = torch.empty((B * F, D), dtype=torch.float32, device=device)
+        # The fused forward saves the first-order weight every slot read ([F, B], 6.8 MB at config 3); K4 then WRITES a unique row's
+        # new weight (old + step) instead of read-modify-writing a line it would have to fetch from HBM again: K4 is bound by
+        # 128-byte line operations, 8 per slot, and this removes one (round 4; DR_K4_LINOLD=0: the read-modify-write).
+        self.lin_old_t = (torch.empty((F, B), dtype=torch.float32, device=device)
+                          if (_os.environ.get("DR_K4_LINOLD", "1") == "1" and self.fuse_k3 and sorted_bwd and optimizer == "sgd") else None)
+        self._lin_old_valid = False
         # The slot sort of batch s + 1 next to K4 of batch s (DR_PREFETCH_PLAN=0: every step hashes and sorts its own batch).  K4 is
         # the one long kernel of the step that is HBM-bound with small blocks, i.e. that shares the machine; beside the persistent
         # GEMMs (the fused first layer occupies all 160 KB of LDS on every CU) the sort chain's ~20 small launches only advance in
@@ -403,6 +409,7 @@ class DeepFMEngine:
         x = self.concat[:, :self.in_dim]
         head = self.fuse_head and labels is not None
         nl = len(self.Ws)
+        self._lin_old_valid = False
         for i, (W, b) in enumerate(zip(self.Ws, self.bs)):                             # K7
             if head and i == nl - 2:
                 break
@@ -413,7 +420,8 @@ class DeepFMEngine:
                         lambda b=b: ops.bf3_emb_linear_fwd(self.ids, self.row_base, self.V, self.table, self.lin_w, self.lin_bias, self.dense_pad,
                                                            None if self.no_concat else self.concat,
                                                            self.in_dim, self.wplanes[0].wt, b, self.acts[0], self.sum_x, self.fm_logit,
-                                                           self.hs[0]))
+                                                           self.hs[0], lin_vals_t=self.lin_old_t))
+                self._lin_old_valid = self.lin_old_t is not None
             elif self.wplanes[i] is not None:
                 self._k("linear_fwd_L%d" % i, "mfma", 2.0 * B * W.shape[0] * W.shape[1],
                         lambda x=x, b=b, i=i: ops.bf3_linear_nt(x, self.wplanes[i].wt, bias=b, act=self.acts[i], out=self.hs[i]))
@@ -525,7 +533,8 @@ class DeepFMEngine:
             k4 = lambda parts: ops.emb_pool_bwd_sorted(self.ids, self.row_base, self.plan, D, self.R, self.d_concat, self.d_logit,
                                                        -lr, self.table, self.lin_w, self.lin_bias,
                                                        concat=None if self.no_concat else self.concat, sum_x=self.sum_x,
-                                                       x_sorted=self.x_sorted if self.no_concat else None, parts=parts)
+                                                       x_sorted=self.x_sorted if self.no_concat else None, parts=parts,
+                                                       lin_old_t=self.lin_old_t if (self._lin_old_valid and not lin_side) else None)
             sk = 4 if lin_side else 0
             self._k("emb_pool_bwd", "hbm", self.alg_bytes_bwd() - (self.B * self.F * 8 if lin_side else 0),   # K4 (sorted)
                     lambda: k4(1 | sk))

@@ -505,7 +505,7 @@ def ids_transpose_i32(ids, out=None):
 
 
 def emb_pool_bwd_sorted(ids, row_base, plan, D, num_rows, grad, d_fm_logit, scale, dst_table, dst_lin=None, dst_bias=None,
-                        concat=None, sum_x=None, slot_lin_grad=None, x_sorted=None, parts=3):
+                        concat=None, sum_x=None, slot_lin_grad=None, x_sorted=None, parts=3, lin_old_t=None):
     """K4 on the slot plan.  x_sorted ([B * F, D] scratch; with the FM term and no `concat` it must hold the snapshot of
     emb_snapshot_sorted_rows) also makes the update of rows hit more than 32 times deterministic: it is clobbered.  parts: 1 = the
     update kernel, 2 = the ordered combination of hot rows' parked pieces, 3 = both (dr_emb_pool_bwd_sorted[_parts])."""
@@ -517,7 +517,10 @@ def emb_pool_bwd_sorted(ids, row_base, plan, D, num_rows, grad, d_fm_logit, scal
             grad.stride(0), ptr(concat), concat.stride(0) if concat is not None else 0,
             ptr(sum_x), ptr(d_fm_logit), ptr(slot_lin_grad), float(scale), ptr(dst_table), ptr(dst_lin),
             ptr(dst_bias), ptr(x_sorted))
-    if parts == 3:
+    if lin_old_t is not None:       # first-order weights as this step's forward read them, [F, B]: unique rows get one write, no RMW
+        assert lin_old_t.shape == (F, B) and lin_old_t.is_contiguous() and lin_old_t.dtype == torch.float32
+        check(lib().dr_emb_pool_bwd_sorted_ex(*args, ptr(lin_old_t), int(parts), stream_ptr()), "dr_emb_pool_bwd_sorted_ex")
+    elif parts == 3:
         check(lib().dr_emb_pool_bwd_sorted(*args, stream_ptr()), "dr_emb_pool_bwd_sorted")
     else:
         check(lib().dr_emb_pool_bwd_sorted_parts(*args, int(parts), stream_ptr()), "dr_emb_pool_bwd_sorted_parts")
@@ -935,7 +938,8 @@ def bf3_cross_fwd(x0, x, wt: Planes, b=None, diag_scale=0.0, want_prod=False, pr
     return out, prod
 
 
-def bf3_emb_linear_fwd(ids, row_base, field_rows_max, table, lin_w, lin_bias, dense_pad, concat, K, wt: Planes, bias, act, sum_x, fm_logit, out):
+def bf3_emb_linear_fwd(ids, row_base, field_rows_max, table, lin_w, lin_bias, dense_pad, concat, K, wt: Planes, bias, act, sum_x, fm_logit, out,
+                       lin_vals_t=None):
     """K3 + first Dense in one launch (dr_bf3_emb_linear_fwd): gathers the field embeddings of ids [M, F] from table [R, 64] as the
     GEMM's activation operand, writes them to concat[:, :64 F], the FM terms to sum_x / fm_logit, and
     out = act([embeddings, dense_pad[:, :K - 64 F]] @ W + bias).  dense_pad: [M, 32] zero-padded dense features (None iff
@@ -945,6 +949,13 @@ def bf3_emb_linear_fwd(ids, row_base, field_rows_max, table, lin_w, lin_bias, de
     M, F = ids.shape
     assert (concat is None or concat.stride(1) == 1) and out.stride(1) == 1 and wt.cols == K and out.shape == (M, wt.rows)
     assert dense_pad is None or (dense_pad.shape == (M, 32) and dense_pad.is_contiguous())
+    if lin_vals_t is not None:      # also save every slot's first-order weight, field-major [F, M] (emb_pool_bwd_sorted's lin_old_t)
+        assert lin_vals_t.shape == (F, M) and lin_vals_t.is_contiguous() and lin_vals_t.dtype == torch.float32
+        check(lib().dr_bf3_emb_linear_fwd_lv(ptr(ids), M, F, ptr(row_base), int(field_rows_max), ptr(table), table.shape[1], ptr(lin_w), ptr(lin_bias),
+                                             ptr(dense_pad), ptr(concat), concat.stride(0) if concat is not None else 0, int(K), ptr(wt.buf),
+                                             wt.plane_stride, wt.ld, wt.rows, ptr(bias), int(act), ptr(sum_x), ptr(fm_logit), ptr(out), out.stride(0),
+                                             ptr(lin_vals_t), stream_ptr()), "dr_bf3_emb_linear_fwd_lv")
+        return out
     check(lib().dr_bf3_emb_linear_fwd(ptr(ids), M, F, ptr(row_base), int(field_rows_max), ptr(table), table.shape[1], ptr(lin_w), ptr(lin_bias),
                                       ptr(dense_pad), ptr(concat), concat.stride(0) if concat is not None else 0, int(K), ptr(wt.buf), wt.plane_stride, wt.ld,
                                       wt.rows, ptr(bias), int(act), ptr(sum_x), ptr(fm_logit), ptr(out), out.stride(0), stream_ptr()),

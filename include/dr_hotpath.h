@@ -214,6 +214,18 @@ int dr_emb_pool_bwd_sorted_parts(const int64_t* ids, const int64_t* row_base, co
  * beside a matrix-bound GEMM that traffic is free. */
 int dr_emb_lin_update_unique(const int64_t* ids, const uint8_t* unique_flags, int64_t B, int32_t F, const int64_t* row_base,
                              const float* d_fm_logit, const float* slot_lin_grad, float scale, float* dst_lin, dr_stream_t stream);
+/* dr_emb_pool_bwd_sorted_parts with lin_old_t [F, B] (field-major, may be NULL): the first-order weights as the forward of THIS step
+ * read them (dr_bf3_emb_linear_fwd_lv).  A row unique in the batch then gets dst_lin[row] = lin_old + scale * g as ONE write instead
+ * of a read-modify-write (K4 is bound by 128-byte line operations; this removes one of eight per slot).  Valid only if nothing
+ * wrote dst_lin since that forward; ignored with slot_lin_grad. */
+int dr_emb_pool_bwd_sorted_ex(const int64_t* ids, const int64_t* row_base, const int64_t* sorted_rows,
+                              const int32_t* sorted_slots, const uint8_t* unique_flags,
+                              const int32_t* dup_heads, const int32_t* dup_count, int64_t B, int32_t F,
+                              int32_t D, int64_t num_rows, const float* grad, int64_t ld_grad,
+                              const float* concat, int64_t ld_concat, const float* sum_x,
+                              const float* d_fm_logit, const float* slot_lin_grad, float scale,
+                              float* dst_table, float* dst_lin, float* dst_bias, float* x_sorted,
+                              const float* lin_old_t, int32_t parts, dr_stream_t stream);
 int dr_emb_snapshot_sorted_rows(const int64_t* sorted_rows, const int32_t* dup_heads, const int32_t* dup_count,
                                 const float* table, int32_t D, int64_t num_rows, float* x_sorted, dr_stream_t stream);
 
@@ -599,6 +611,14 @@ int dr_bf3_emb_linear_fwd(const int64_t* ids, int64_t M, int32_t F, const int64_
                           int64_t ld_concat, int32_t K, const void* wt_planes, int64_t plane_stride, int64_t ld_planes, int32_t N,
                           const float* bias, int32_t act, float* sum_x, float* fm_logit, float* out, int64_t ld_out,
                           dr_stream_t stream);
+/* dr_bf3_emb_linear_fwd that also saves the first-order weight of every slot as it was read: lin_vals_t [F, M] field-major,
+ * lin_vals_t[f * M + m] = lin_w[row_base[f] + ids[m, f]] (undefined for a missing id; ignored when lin_w == NULL).  Handed to
+ * dr_emb_pool_bwd_sorted_ex as `lin_old_t`, it turns the first-order update of a row that is unique in the batch into ONE write. */
+int dr_bf3_emb_linear_fwd_lv(const int64_t* ids, int64_t M, int32_t F, const int64_t* row_base, int64_t field_rows_max,
+                             const float* table, int32_t D, const float* lin_w, const float* lin_bias, const float* dense_pad, float* concat,
+                             int64_t ld_concat, int32_t K, const void* wt_planes, int64_t plane_stride, int64_t ld_planes, int32_t N,
+                             const float* bias, int32_t act, float* sum_x, float* fm_logit, float* out, int64_t ld_out,
+                             float* lin_vals_t, dr_stream_t stream);
 int64_t dr_bf3_wgrad_workspace_bytes(int64_t R, int32_t F, int32_t N);
 int dr_bf3_wgrad(const float* x, int64_t ld_x, const float* dy, int64_t ld_dy, int64_t R, int32_t F, int32_t N,
                  float scale, float* dstW, int64_t ld_w, float* dstb, void* workspace, int64_t workspace_bytes,
