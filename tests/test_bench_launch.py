@@ -56,6 +56,26 @@ def test_gpus2_without_launcher_spawns_two_ranks_and_prints_one_line():
     assert "starting 2 ranks" in err and "--master-addr 127.0.0.1" in err
 
 
+@pytest.mark.timeout(300)
+def test_wrapped_by_the_drivers_launcher_line():
+    """The driver's own form for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` -- bench.py must NOT spawn again, and rank 0 prints the one line."""
+    if not _no_gpu():
+        pytest.skip("CPU form of the check (gloo)")
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), BENCH, "--gpus", "2", "--launch-check"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = _json_lines(p.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["self_launched"] is False and lines[0]["all_ok"] is True
+    assert "starting 2 ranks" not in p.stderr
+
+
 @pytest.mark.timeout(120)
 def test_gpus2_on_a_box_without_enough_gpus_names_the_device_count():
     import torch
