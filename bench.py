@@ -407,10 +407,11 @@ def main():
         prof = None
     ev_every = 1
     if prof is not None:
-        # the single-GPU DeepFM engine brackets every 4th step of the timed region (steps 0, 4, 8, ...): two event records per kernel
-        # on EVERY step cost ~5 % of a 1.5 ms step (round 3: 1.56 vs 1.48 ms); the per-kernel averages are over those launches
+        # the DeepFM engines bracket every 4th step of the timed region (steps 0, 4, 8, ...): two event records per kernel
+        # on EVERY step cost ~5 % of a 1.5 ms step (round 3: 1.56 vs 1.48 ms; sharded engine, round 4: 2.05 vs 1.94 ms); the per-kernel
+        # averages are over those launches
         try:
-            ev_every = 4 if (a.model == "deepfm" and not sharded and a.steps >= 8) else 1
+            ev_every = 4 if (a.model == "deepfm" and a.steps >= 8) else 1
             eng.enable_kernel_events(True, every=ev_every)
         except TypeError:
             ev_every = 1

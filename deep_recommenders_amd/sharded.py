@@ -619,6 +619,7 @@ class ShardedDeepFMEngine:
         # streams for the later micro-batches' fused first layers (see train_step); DR_FWD_STREAMS=0: all on the training stream
         self.fwd_streams = ([torch.cuda.Stream(device=device) for _ in range(max(0, min(mb - 1, 3)))]
                             if (self.fuse_k3 and _os.environ.get("DR_FWD_STREAMS", "1") == "1") else [])
+        self._ev_every, self._ev_step, self._ev_live = 1, 0, False
         self.k4_first = _os.environ.get("DR_SH_K4_FIRST", "0") == "1"
         self.wgrad_split = _os.environ.get("DR_SH_WGRAD_SPLIT", "0") == "1"
         self._events = None
@@ -628,8 +629,11 @@ class ShardedDeepFMEngine:
         self._comm_synced = False
 
     # ---- per-phase HIP events (same contract as engine.DeepFMEngine) -------------------------------------------
-    def enable_kernel_events(self, on: bool):
+    def enable_kernel_events(self, on: bool, every: int = 1):
+        """Per-phase HIP events / clock stamps.  every = n: only every n-th train_step is bracketed (the bracketing costs ~6 % of the
+        world-1 step: 2.05 vs 1.94 ms); kernel_event_summary / exchange_report average over the bracketed steps."""
         self._events = {} if (on and self._cuda) else None
+        self._ev_every, self._ev_step, self._ev_live = max(1, int(every)), 0, bool(on)
         self._stamps = None
         # the collectives themselves (C1 / C2 / C3), apart from the local kernels of their phases: bench.py's per-link rates
         self.ex.phase_timer = (lambda tag, nbytes, fn: self._k(tag, "xgmi", nbytes, fn)) if self._events is not None else None
@@ -639,7 +643,7 @@ class ShardedDeepFMEngine:
         kernels writing the 100 MHz wall clock): their distance is the time the stream sat idle waiting for the exchange -- the
         EXPOSED, non-overlapped part of the communication (bench.py sums them).  Not HIP timing events: two event records around a
         cross-stream wait, four waits per step, stretched the step from 1.93 to 4.1 ms (round 4)."""
-        if self._events is None or not self._cuda:
+        if self._events is None or not self._cuda or not self._ev_live:
             stream.wait_event(event)
             return
         if self._stamps is None:
@@ -675,7 +679,7 @@ class ShardedDeepFMEngine:
               "emb_grads", "allreduce_dense_grads", "emb_route", "a2a_")
 
     def _k(self, name, bound, work, fn):
-        if self._events is None or not name.startswith(self._TIMED):
+        if self._events is None or not self._ev_live or not name.startswith(self._TIMED):
             return fn()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
@@ -715,6 +719,8 @@ class ShardedDeepFMEngine:
                                        "GBps_per_rank": round(on_wire / sec / 1e9, 2) if sec > 0 else None,
                                        "GBps_per_link": round(on_wire / max(W - 1, 1) / sec / 1e9, 2) if (sec > 0 and W > 1) else None}
         stalls = self.stall_summary()
+        if self._events is not None and self._ev_every > 1:
+            steps = (steps + self._ev_every - 1) // self._ev_every          # bracketed steps only
         if stalls and steps:
             rep["exposed_us_per_step"] = round(sum(t for t, _ in stalls.values()) / steps, 2)
             rep["exposed_parts_us_per_step"] = {n: round(t / steps, 2) for n, (t, _) in stalls.items()}
@@ -764,6 +770,9 @@ class ShardedDeepFMEngine:
         p, F, D, W, B, M = self.p, self.F, self.D, self.world, self.B, self.mb
         Bm = B // M
         cuda = self._cuda
+        if self._events is not None:
+            self._ev_live = (self._ev_step % self._ev_every) == 0
+            self._ev_step += 1
         for wp in self.wplanes:          # weights written from outside since the last refresh (load / copy_ / broadcast): re-split
             if wp is not None:
                 wp.ensure_fresh()
