@@ -46,6 +46,101 @@ __global__ __launch_bounds__(256) void ivf_pack_kernel(const float* __restrict__
     }
 }
 
+
+// ---- list build: stable counting sort of the N vectors by their coarse assignment (round 4: torch.argsort / bincount / cumsum until
+// then -- the `index.add(candidates)` half of faiss' IVF build, factorized_top_k.py:374-391).  Stable = inside a list the vectors keep
+// their input order, so equal scores tie on the lower candidate number exactly as the exact search does.
+//   pass 1  per block (IVB_CHUNK consecutive vectors): LDS histogram of its list ids -> block_hist[list][block]
+//   pass 2  ONE block: exclusive scan over (list-major, block-minor); list_start[l] = start of (l, block 0)
+//   pass 3  per block again, 256 vectors a round: rank inside the round by comparing against the earlier keys of the round (LDS),
+//           plus what earlier rounds of the block placed in the same list (LDS counters), plus the block's scanned offset
+constexpr int IVB_CHUNK = 2048;          // vectors per block
+constexpr int IVB_MAXLIST = 8192;        // list ids an LDS histogram holds (32 KB)
+
+__global__ __launch_bounds__(256) void ivf_build_hist_kernel(const int64_t* __restrict__ assign, int64_t N, int32_t nlist,
+                                                             int32_t nblk, int64_t* __restrict__ block_hist) {
+    __shared__ int hist[IVB_MAXLIST];
+    for (int l = threadIdx.x; l < nlist; l += 256) hist[l] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * IVB_CHUNK;
+    for (int j = threadIdx.x; j < IVB_CHUNK; j += 256) {
+        const int64_t i = base + j;
+        if (i < N) {
+            const int64_t a = assign[i];
+            if (a >= 0 && a < nlist) atomicAdd(&hist[(int)a], 1);
+        }
+    }
+    __syncthreads();
+    for (int l = threadIdx.x; l < nlist; l += 256) block_hist[(int64_t)l * nblk + blockIdx.x] = hist[l];
+}
+
+__global__ __launch_bounds__(256) void ivf_build_scan_kernel(int64_t* __restrict__ block_hist, int64_t total, int32_t nlist, int32_t nblk,
+                                                             int64_t* __restrict__ list_start) {
+    __shared__ int64_t part[256];
+    __shared__ int64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    // 8 consecutive entries per thread and round: 2048 entries per round
+    for (int64_t base = 0; base < total; base += 2048) {
+        int64_t v[8], sum = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t i = base + (int64_t)threadIdx.x * 8 + j;
+            v[j] = i < total ? block_hist[i] : 0;
+            sum += v[j];
+        }
+        part[threadIdx.x] = sum;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const int64_t t = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+            __syncthreads();
+            part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        int64_t run = carry + part[threadIdx.x] - sum;                  // exclusive prefix of this thread's 8 entries
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t i = base + (int64_t)threadIdx.x * 8 + j;
+            if (i < total) {
+                block_hist[i] = run;
+                if (i % nblk == 0) list_start[i / nblk] = run;
+            }
+            run += v[j];
+        }
+        __syncthreads();
+        if (threadIdx.x == 255) carry += part[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) list_start[nlist] = carry;
+}
+
+__global__ __launch_bounds__(256) void ivf_build_scatter_kernel(const int64_t* __restrict__ assign, int64_t N, int32_t nlist, int32_t nblk,
+                                                                const int64_t* __restrict__ block_off, int64_t* __restrict__ order) {
+    __shared__ int placed[IVB_MAXLIST];          // vectors of this block already placed in each list (earlier rounds)
+    __shared__ int keys[256];
+    for (int l = threadIdx.x; l < nlist; l += 256) placed[l] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * IVB_CHUNK;
+    for (int r = 0; r < IVB_CHUNK / 256; ++r) {
+        const int64_t i = base + r * 256 + threadIdx.x;
+        int key = -1;
+        if (i < N) {
+            const int64_t a = assign[i];
+            if (a >= 0 && a < nlist) key = (int)a;
+        }
+        keys[threadIdx.x] = key;
+        __syncthreads();
+        int rank = 0;
+        if (key >= 0) {
+            for (int t = 0; t < (int)threadIdx.x; ++t) rank += keys[t] == key ? 1 : 0;
+            order[block_off[(int64_t)key * nblk + blockIdx.x] + placed[key] + rank] = i;
+        }
+        __syncthreads();
+        if (key >= 0) atomicAdd(&placed[key], 1);
+        __syncthreads();
+    }
+}
+
 template <int DU>
 __global__ __launch_bounds__(256) void ivf_scan_kernel(const float* __restrict__ q, int64_t Bq, int32_t D,
                                                        const int64_t* __restrict__ probes, int32_t nprobe,
@@ -108,6 +203,30 @@ extern "C" int dr_ivf_scan(const float* q, int64_t Bq, int32_t D, const int64_t*
     const unsigned grid = (unsigned)((Bq + 3) / 4);
     hipLaunchKernelGGL((ivf_scan_kernel<8>), dim3(grid), dim3(256), 4 * D * sizeof(float), dr_s(stream), q, Bq, D, probes, nprobe,
                        blk_off, packed, packed_ids, k, out_scores, out_index);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+extern "C" int64_t dr_ivf_build_workspace_bytes(int64_t N, int32_t nlist) {
+    const int64_t nblk = (N + IVB_CHUNK - 1) / IVB_CHUNK;
+    return (nblk > 0 ? nblk : 1) * (int64_t)(nlist > 0 ? nlist : 1) * (int64_t)sizeof(int64_t);
+}
+
+// Groups the N vectors by coarse list: order[list_start[l] .. list_start[l + 1]) = the vectors assigned to list l, ascending (stable);
+// an assignment outside [0, nlist) drops its vector.  workspace: dr_ivf_build_workspace_bytes(N, nlist).  nlist <= 8192.
+extern "C" int dr_ivf_build_lists(const int64_t* assign, int64_t N, int32_t nlist, int64_t* order, int64_t* list_start, void* workspace,
+                                  int64_t workspace_bytes, dr_stream_t stream) {
+    if (N < 0 || nlist <= 0 || nlist > IVB_MAXLIST) return DR_EINVAL;
+    if (!list_start) return DR_EINVAL;
+    if (N == 0) return hipMemsetAsync(list_start, 0, sizeof(int64_t) * (nlist + 1), dr_s(stream)) == hipSuccess ? DR_OK : DR_ELAUNCH;
+    if (!assign || !order || !workspace || workspace_bytes < dr_ivf_build_workspace_bytes(N, nlist)) return DR_EINVAL;
+    const int64_t nblk64 = (N + IVB_CHUNK - 1) / IVB_CHUNK;
+    if (nblk64 > 0x7fffffff) return DR_EINVAL;
+    const int nblk = (int)nblk64;
+    int64_t* bh = static_cast<int64_t*>(workspace);
+    hipLaunchKernelGGL(ivf_build_hist_kernel, dim3(nblk), dim3(256), 0, dr_s(stream), assign, N, nlist, nblk, bh);
+    hipLaunchKernelGGL(ivf_build_scan_kernel, dim3(1), dim3(256), 0, dr_s(stream), bh, (int64_t)nblk * nlist, nlist, nblk, list_start);
+    hipLaunchKernelGGL(ivf_build_scatter_kernel, dim3(nblk), dim3(256), 0, dr_s(stream), assign, N, nlist, nblk, bh, order);
     DR_CHECK_LAUNCH();
     return DR_OK;
 }

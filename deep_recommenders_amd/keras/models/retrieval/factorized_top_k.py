@@ -207,7 +207,8 @@ class Faiss(TopK):
             a = self._assign(cand, centroids)
             sums = torch.zeros((self._nlist, D), dtype=torch.float32, device=cand.device)
             ops.rows_scatter_add(a, cand, None, 1.0, sums, None)
-            counts = torch.bincount(a, minlength=self._nlist).to(torch.float32).reshape(-1, 1)
+            _, ls = ops.ivf_build_lists(a, self._nlist)
+            counts = (ls[1:] - ls[:-1]).to(torch.float32).reshape(-1, 1)
             centroids = torch.where(counts > 0, sums / counts.clamp(min=1.0), centroids)     # an empty cluster keeps its centroid
         return centroids
 
@@ -231,9 +232,7 @@ class Faiss(TopK):
         self._centroids = self._train(cand).contiguous()
         assign = self._assign(cand, self._centroids)
         self._assignments = assign
-        order = torch.argsort(assign, stable=True)
-        list_start = torch.zeros(self._nlist + 1, dtype=torch.int64, device=cand.device)
-        list_start[1:] = torch.cumsum(torch.bincount(assign, minlength=self._nlist), 0)
+        order, list_start = ops.ivf_build_lists(assign, self._nlist)            # stable counting sort by list (dr_ivf_build_lists)
         self._packed, self._packed_ids, self._blk_off = ops.ivf_pack(cand, order, list_start, ids)
         return self
 

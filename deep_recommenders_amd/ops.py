@@ -684,6 +684,20 @@ def topk_mips(q, cand, k, index_base=0, init=True, state=None, workspace=None):
     return state
 
 
+def ivf_build_lists(assign, nlist):
+    """(order [N] int64, list_start [nlist + 1] int64): the vectors grouped by coarse list, input order kept inside a list
+    (dr_ivf_build_lists: stable counting sort on the device)."""
+    assign = _c(assign, torch.int64)
+    N = assign.numel()
+    order = torch.empty(max(N, 1), dtype=torch.int64, device=assign.device)[:N]
+    list_start = torch.empty(int(nlist) + 1, dtype=torch.int64, device=assign.device)
+    nb = lib().dr_ivf_build_workspace_bytes(N, int(nlist))
+    ws = torch.empty(max(1, nb // 8), dtype=torch.int64, device=assign.device)
+    check(lib().dr_ivf_build_lists(ptr(assign), N, int(nlist), ptr(order), ptr(list_start), ptr(ws), ws.numel() * 8, stream_ptr()),
+          "dr_ivf_build_lists")
+    return order, list_start
+
+
 def ivf_pack(cand, order, list_start, ids=None):
     """IVF-Flat storage: lists padded to 64-vector blocks, each block dimension-major.  -> (packed, packed_ids, blk_off)"""
     cand = _c(cand, torch.float32)

@@ -447,6 +447,13 @@ int dr_topk_mips(const float* q, int64_t Bq, const float* cand, int64_t N, int32
  *                over those lists, top k (score descending, ties by identifier ascending); slots that find fewer than k
  *                vectors keep score -inf / index -1 (faiss returns -1 labels there too).
  * ---------------------------------------------------------------------------------------- */
+/* dr_ivf_build_lists (round 4): the grouping half of `index.add` (factorized_top_k.py:374-391) -- a STABLE counting sort of the N
+ * vectors by their coarse assignment: order[list_start[l] .. list_start[l+1]) = the vectors of list l in input order (so equal scores
+ * tie on the lower candidate number, as in the exact search); an assignment outside [0, nlist) drops its vector.  nlist <= 8192;
+ * workspace >= dr_ivf_build_workspace_bytes(N, nlist).  Integer, bit-exact. */
+int64_t dr_ivf_build_workspace_bytes(int64_t N, int32_t nlist);
+int dr_ivf_build_lists(const int64_t* assign, int64_t N, int32_t nlist, int64_t* order, int64_t* list_start, void* workspace,
+                       int64_t workspace_bytes, dr_stream_t stream);
 int dr_ivf_pack(const float* cand, int64_t N, int32_t D, const int64_t* order, const int64_t* list_start,
                 const int64_t* blk_off, int32_t nlist, int64_t total_blocks, const int64_t* ids, float* packed,
                 int64_t* packed_ids, dr_stream_t stream);

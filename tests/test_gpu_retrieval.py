@@ -81,6 +81,24 @@ def test_topk_mips_matches_oracle_large_and_ties():
         ops.topk_mips(torch.tensor(q).cuda(), torch.tensor(cand[:5]).cuda(), 10)
 
 
+@pytest.mark.parametrize("N,nlist", [(100_003, 1024), (5000, 1), (70_000, 8192), (300, 7)])
+def test_ivf_build_lists_is_a_stable_counting_sort(N, nlist):
+    """dr_ivf_build_lists == np.argsort(assign, kind="stable") + the list boundaries (bit-exact); assignments outside [0, nlist) drop
+    their vector (the grouping half of faiss' index.add, keras/models/retrieval/factorized_top_k.py:374-391 of the reference)."""
+    from deep_recommenders_amd import ops
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, nlist, size=N)
+    if N > 1000:
+        a[rng.integers(0, N, size=17)] = -1
+        a[rng.integers(0, N, size=5)] = nlist
+    order, ls = ops.ivf_build_lists(torch.from_numpy(a).cuda(), nlist)
+    ok = (a >= 0) & (a < nlist)
+    want_order = np.argsort(np.where(ok, a, nlist), kind="stable")[:int(ok.sum())]
+    want_ls = np.concatenate([[0], np.cumsum(np.bincount(a[ok], minlength=nlist))])
+    np.testing.assert_array_equal(ls.cpu().numpy(), want_ls)
+    np.testing.assert_array_equal(order.cpu().numpy()[:int(ok.sum())], want_order)
+
+
 def test_faiss_ivf_flat_index():
     """the `Faiss` (IVF-Flat, inner product) index.  Pinned like the reference pins it
     (tests/keras/test_factorized_top_k.py:36-130): exact top-k with nlist=1 on 100 items, save/load self-consistency; plus
