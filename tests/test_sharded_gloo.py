@@ -275,17 +275,18 @@ NSTEPS = 2
 
 
 def _global_problem(cfg=None):
-    """`steps` global batches of 2 * B examples (rank r trains on rows [r*B, (r+1)*B) of each)."""
+    """`steps` global batches of world * B examples (rank r trains on rows [r*B, (r+1)*B) of each); world = cfg["world"], default 2."""
     g = torch.Generator().manual_seed(123)
     c = cfg or CFG
+    Wn = c.get("world", 2)
     table = torch.randn((c["F"] * c["V"], c["D"]), generator=g) * 0.3
     lin = torch.randn(c["F"] * c["V"], generator=g) * 0.1
     batches = []
     for _ in range(c.get("steps", NSTEPS)):
-        keys = torch.randint(0, c.get("key_max", 10**9), (2 * c["B"], c["F"]), generator=g)
+        keys = torch.randint(0, c.get("key_max", 10**9), (Wn * c["B"], c["F"]), generator=g)
         keys[3, 1] = -1                            # a missing id travels through the exchange as a zero row
-        dense = torch.rand((2 * c["B"], c["Nd"]), generator=g)
-        labels = (torch.rand(2 * c["B"], generator=g) < 0.3).float()
+        dense = torch.rand((Wn * c["B"], c["Nd"]), generator=g)
+        labels = (torch.rand(Wn * c["B"], generator=g) < 0.3).float()
         batches.append((keys, dense, labels))
     return table, lin, batches
 
@@ -442,6 +443,29 @@ def test_two_rank_sharded_dedup_exchange_equals_single_process_oracle(tmp_path, 
             np.testing.assert_allclose(got.numpy(), want.numpy(), **tol)
         for i in range(len(Wc)):
             np.testing.assert_allclose(Ws_r[i].numpy(), Wc[i].numpy(), **tol)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("dedup", [False, True])
+def test_four_rank_sharded_steps_equal_single_process_oracle(tmp_path, dedup):
+    """The same assertion on FOUR ranks (every earlier multi-process test has world 2): owner = id % 4, uneven split sizes in every
+    all-to-all, ranks 2 and 3 as both requesters and owners, two micro-batches with prefetched routes; with and without the
+    de-duplicated exchange."""
+    world = 4
+    cfg = dict(CFG, world=world, dedup=dedup)
+    res = _spawn(_worker, (2, "sgd", None, False, cfg), tmp_path, world=world)
+    Ws0, bs0 = res[0][6], res[0][7]
+    losses, tab, li, bias, Wc, bc = _reference_deepfm(cfg, Ws0, bs0, "sgd")
+    for t, lo in enumerate(losses):
+        assert abs(sum(res[r][0][t] for r in range(world)) / world - lo) < 2e-6
+    for r in range(world):
+        _, tab_r, lin_r, Ws_r, bs_r, bias_r, _, _ = res[r]
+        for got, want in _shard_views(cfg, world, r, tab_r, lin_r, tab, li):
+            np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=2e-5, atol=2e-6)
+        for i in range(len(Wc)):
+            np.testing.assert_allclose(Ws_r[i].numpy(), Wc[i].numpy(), rtol=2e-5, atol=2e-6)
+            np.testing.assert_allclose(bs_r[i].numpy(), bc[i].numpy(), rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(bias_r.numpy(), bias.numpy(), rtol=2e-5, atol=2e-7)
 
 
 def test_dedup_bucketing_sends_each_distinct_row_once():
