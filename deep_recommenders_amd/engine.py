@@ -178,6 +178,10 @@ class DeepFMEngine:
         # GEMMs (the fused first layer occupies all 160 KB of LDS on every CU) the sort chain's ~20 small launches only advance in
         # the gaps: 1.2 ms instead of 0.17, and K4 waited 74 us for it (round 2, rocprofv3: K4 305 us, its event 379 us).
         self.prefetch_plan = _os.environ.get("DR_PREFETCH_PLAN", "1") == "1"
+        # DR_PREFETCH_EARLY=1 (experiment, round 4): the next batch's hash + slot plan start at the BEGINNING of this step (beside the
+        # GEMMs, where they crawl but have a whole step of slack) instead of beside K4, which then has HBM to itself; the next batch's
+        # dense features are still placed after this step's wgrad.
+        self.prefetch_early = _os.environ.get("DR_PREFETCH_EARLY", "0") == "1"
         # Fewer cross-stream packets in front of K4 (rocprofv3 showed a 31 us gap there against 11 - 13 us between the other
         # dependent kernels): the side chain is ordered behind the plane refresh instead of an event of its own, and the wait for
         # a PREFETCHED plan -- long complete by then -- sits in front of the first-layer wgrad.  DR_LEAN_EVENTS=0: as before.
@@ -194,6 +198,9 @@ class DeepFMEngine:
             self.ev_planes = torch.cuda.Event()
             self.ev_dlogit = torch.cuda.Event()
             self.ev_lin = torch.cuda.Event()
+            self.ev_fwd0 = torch.cuda.Event()
+            self._ev_dense = [torch.cuda.Event(), torch.cuda.Event()]
+            self._dense_by_event = False
         # First-order weights of the rows that are unique in the batch (99.4 % of the slots for uniform ids) updated by a kernel of
         # their own on the side stream, beside the tower tail, instead of inside K4: a random 4-byte read-modify-write fetches a
         # 128-byte line, 0.27 GB of K4's 1.64 GB.  DR_LIN_SIDE=1 (off by default: see DESIGN.md for the A/B).
@@ -203,6 +210,7 @@ class DeepFMEngine:
         self._planes_pending = False
         self._planes_pending_l0 = False
         self._in_train_step = False
+        self._early_issued = False
         # First-layer wgrad on a second stream, concurrent with the HBM-bound K4 on the training stream.  It paid next to the
         # in-kernel-split wgrad (2 blocks / CU, matrix pipe ~35 % busy: 1.91 -> 1.84 ms / step); next to the register-split wgrad
         # (one 512-thread block per CU holding all its registers and 96 KB of LDS) the two kernels only time-slice the CUs: the
@@ -261,13 +269,16 @@ class DeepFMEngine:
         nk = self._next_keys
         nxt = self.cur ^ 1
         nk.record_stream(self.side)
+        early_done = self._early_issued
+        self._early_issued = False
         with torch.cuda.stream(self.side):
             if not ordered:
                 self.side.wait_event(self.ev_k4)
-            self._k("next_batch: hash_bucket_i64(side stream, overlapped)", "overlap", self.B * self.F * 16,
-                    lambda: ops.hash_bucket_i64(nk, self.col_buckets, out=self._ids[nxt]))
-            if self.no_concat:
-                ops.ids_transpose_i32(self._ids[nxt], out=self._ids_t[nxt])
+            if not early_done:
+                self._k("next_batch: hash_bucket_i64(side stream, overlapped)", "overlap", self.B * self.F * 16,
+                        lambda: ops.hash_bucket_i64(nk, self.col_buckets, out=self._ids[nxt]))
+                if self.no_concat:
+                    ops.ids_transpose_i32(self._ids[nxt], out=self._ids_t[nxt])
             nd = self._next_dense
             self._pref_dense = None
             if nd is not None and self.Nd and not self.overlap_dw:
@@ -279,11 +290,37 @@ class DeepFMEngine:
                 if self.dense_pad is not None:
                     self.dense_pad[:, :self.Nd].copy_(nd)
                 self._pref_dense = self._token(nd)
-            self._ev_hashed[nxt].record(self.side)          # what the next forward waits for: ids (+ dense features) in place
+            if early_done:
+                self._ev_dense[nxt].record(self.side)       # ids and plan were issued at the start of the step: only the dense features here
+                self._dense_by_event = True
+            else:
+                self._dense_by_event = False
+                self._ev_hashed[nxt].record(self.side)          # what the next forward waits for: ids (+ dense features) in place
+                self._k("next_batch: emb_sort_slots(side stream, overlapped)", "overlap", self.B * self.F * 36,
+                        lambda: ops.emb_sort_slots(self._ids[nxt], self.row_base, self.R, self._plans[nxt]))
+                self._ev_sorted[nxt].record(self.side)
+        self._pref = self._token(nk)
+
+    def _prefetch_early(self):
+        """DR_PREFETCH_EARLY=1: hash + field-major ids + slot plan of the NEXT batch, issued at the start of this step's forward."""
+        nk = self._next_keys
+        self._early_issued = False
+        if nk is None or not (self.prefetch_early and self.sorted_bwd and not self.sort_inline and self.prefetch_plan):
+            return
+        nxt = self.cur ^ 1
+        self.ev_fwd0.record()                   # behind the previous step's K4 (the last user of buffer `nxt`)
+        nk.record_stream(self.side)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.ev_fwd0)
+            self._k("next_batch: hash_bucket_i64(side stream, overlapped)", "overlap", self.B * self.F * 16,
+                    lambda: ops.hash_bucket_i64(nk, self.col_buckets, out=self._ids[nxt]))
+            if self.no_concat:
+                ops.ids_transpose_i32(self._ids[nxt], out=self._ids_t[nxt])
+            self._ev_hashed[nxt].record(self.side)
             self._k("next_batch: emb_sort_slots(side stream, overlapped)", "overlap", self.B * self.F * 36,
                     lambda: ops.emb_sort_slots(self._ids[nxt], self.row_base, self.R, self._plans[nxt]))
             self._ev_sorted[nxt].record(self.side)
-        self._pref = self._token(nk)
+        self._early_issued = True
 
     # ---- per-kernel HIP events on the launch stream (bench.py's roofline numbers) ----------------------
     def enable_kernel_events(self, on: bool, every: int = 1):
@@ -366,6 +403,8 @@ class DeepFMEngine:
             # K1 + the slot sort of this batch ran beside the previous step's K4
             self.cur ^= 1
             torch.cuda.current_stream().wait_event(self._ev_hashed[self.cur])
+            if getattr(self, "_dense_by_event", False):
+                torch.cuda.current_stream().wait_event(self._ev_dense[self.cur])
         else:
             if pref_tok is not None:
                 # a prefetch was issued for OTHER keys and is discarded: its side-stream copy of that batch's dense features into
@@ -375,6 +414,8 @@ class DeepFMEngine:
                     lambda: ops.hash_bucket_i64(keys, self.col_buckets, out=self.ids))                # K1
             if self.no_concat:
                 ops.ids_transpose_i32(self.ids, out=self._ids_t[self.cur])
+        if self._in_train_step:
+            self._prefetch_early()
         if self.sorted_bwd and self.sort_inline:
             self._k("emb_sort_slots", "hbm", B * F * 36,
                     lambda: ops.emb_sort_slots(self.ids, self.row_base, self.R, self.plan))
