@@ -38,6 +38,9 @@ SIGNATURES = {
     "dr_tower_head_fwd_bwd": [_p, _i64, _p, _i64, _p, _i64, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _p, _i32, _f32, _p, _i64, _p,
                               _p, _i64, _p, _p, _p, _i64, _p, _p, _i64, _p],
     "dr_linear_bwd_narrow": [_p, _i64, _p, _i64, _p, _i64, _i64, _i32, _i32, _i32, _f32, _p, _i64, _p, _p, _i64, _p, _i64, _p],
+    "dr_linear_bwd_narrow_parts": [_p, _i64, _p, _i64, _p, _i64, _i64, _i32, _i32, _i32, _f32, _p, _i64, _p, _p, _i64, _p, _i64, _i32, _p],
+    "dr_tower_head_fwd_bwd_parts": [_p, _i64, _p, _i64, _p, _i64, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _p, _i32, _f32, _p, _i64, _p,
+                                    _p, _i64, _p, _p, _p, _i64, _p, _p, _i64, _i32, _p],
     "dr_cross_fwd": [_p, _p, _i64, _p, _i64, _p, _f32, _i64, _i32, _p, _p, _p],
     "dr_cross_combine_bwd": [_p, _p, _p, _i64, _i32, _i64, _f32, _p, _p, _p, _p],
     "dr_bce_fwd_bwd": [_p, _p, _i64, _p, _i64, _i32, _p, _p, _p, _p, _p],
@@ -100,6 +103,7 @@ SIGNATURES = {
     "dr_bf3_wgrad_workspace_bytes": [_i64, _i32, _i32],
     "dr_bf3_wgrad": [_p, _i64, _p, _i64, _i64, _i32, _i32, _f32, _p, _i64, _p, _p, _i64, _p],
     "dr_bf3_wgrad_emb": [_p, _i64, _i32, _p, _p, _i32, _p, _p, _i64, _i32, _i32, _f32, _p, _i64, _p, _p, _i64, _p],
+    "dr_bf3_wgrad_emb_parts": [_p, _i64, _i32, _p, _p, _i32, _p, _p, _i64, _i32, _i32, _f32, _p, _i64, _p, _p, _i64, _i32, _p],
     "dr_bf3_gemm_tn_workspace_bytes": [_i64, _i32, _i32],
     "dr_bf3_gemm_tn": [_p, _i64, _i64, _p, _i64, _i64, _i64, _i32, _i32, _f32, _p, _i64, _p, _p, _p, _i64, _p],
     "dr_cin_fwd": [_p, _p, _i64, _i32, _i32, _i32, _p, _i32, _p, _i32, _p, _p],

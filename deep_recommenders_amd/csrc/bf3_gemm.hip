@@ -2293,9 +2293,9 @@ extern "C" int dr_bf3_wgrad(const float* x, int64_t ld_x, const float* dy, int64
 // kernel gathers it from the tables (GATHER form of TnRsArgs; D = 64).  ids_t [nf][R] int32: the batch's bucket ids, field-major
 // (dr_ids_transpose_i32), -1 = missing; dense_pad [R, 32] zero-padded dense features (NULL iff F == 64 nf).  With this the forward
 // need not store `concat` at all (keras/models/ranking/deepfm.py:44-45: stack / concat become pure fiction).
-extern "C" int dr_bf3_wgrad_emb(const int32_t* ids_t, int64_t R, int32_t nf, const int64_t* row_base, const float* table, int32_t D,
-                                const float* dense_pad, const float* dy, int64_t ld_dy, int32_t F, int32_t N, float scale, float* dstW,
-                                int64_t ld_w, float* dstb, void* workspace, int64_t workspace_bytes, dr_stream_t stream) {
+static int wgrad_emb_impl(const int32_t* ids_t, int64_t R, int32_t nf, const int64_t* row_base, const float* table, int32_t D,
+                          const float* dense_pad, const float* dy, int64_t ld_dy, int32_t F, int32_t N, float scale, float* dstW,
+                          int64_t ld_w, float* dstb, void* workspace, int64_t workspace_bytes, int32_t parts, dr_stream_t stream) {
     if (R <= 0 || F <= 0 || N <= 0 || nf <= 0) return DR_EINVAL;
     if (D != 64 || F < 64 * nf || F > 64 * nf + 32) return DR_ESHAPE;
     if (!ids_t || !row_base || !table || !dy || !dstW || !workspace || ld_dy < N || ld_w < N) return DR_EINVAL;
@@ -2309,11 +2309,31 @@ extern "C" int dr_bf3_wgrad_emb(const int32_t* ids_t, int64_t R, int32_t nf, con
     TnRsArgs g{nullptr, 0, dy, ld_dy, R, F, N, per, split, partial, dstb != nullptr ? colsum : nullptr, ids_t, row_base, table, nf,
                F > 64 * nf ? dense_pad : nullptr};
     const int grid = (Fp / 256) * (Np / 256) * split;
-    hipLaunchKernelGGL(bf3_gemm_tn_rs_kernel<1>, dim3(grid), dim3(512), 0, dr_s(stream), g);
-    hipLaunchKernelGGL(bf3_tn_rs_reduce_kernel, dim3(dr_grid_for((int64_t)F * N, 256)), dim3(256), 0, dr_s(stream), partial,
-                       dstb != nullptr ? colsum : nullptr, split, F, N, Fp, Np, scale, dstW, ld_w, dstb);
+    if (parts & 1) hipLaunchKernelGGL(bf3_gemm_tn_rs_kernel<1>, dim3(grid), dim3(512), 0, dr_s(stream), g);
+    if (parts & 2)
+        hipLaunchKernelGGL(bf3_tn_rs_reduce_kernel, dim3(dr_grid_for((int64_t)F * N, 256)), dim3(256), 0, dr_s(stream), partial,
+                           dstb != nullptr ? colsum : nullptr, split, F, N, Fp, Np, scale, dstW, ld_w, dstb);
     DR_CHECK_LAUNCH();
     return DR_OK;
+}
+
+extern "C" int dr_bf3_wgrad_emb(const int32_t* ids_t, int64_t R, int32_t nf, const int64_t* row_base, const float* table, int32_t D,
+                                const float* dense_pad, const float* dy, int64_t ld_dy, int32_t F, int32_t N, float scale, float* dstW,
+                                int64_t ld_w, float* dstb, void* workspace, int64_t workspace_bytes, dr_stream_t stream) {
+    return wgrad_emb_impl(ids_t, R, nf, row_base, table, D, dense_pad, dy, ld_dy, F, N, scale, dstW, ld_w, dstb, workspace, workspace_bytes,
+                          3, stream);
+}
+
+// In two halves: parts = 1 the split-K GEMM into the workspace, parts = 2 the fixed-order reduce that applies it (dstW += scale * sum,
+// dstb likewise), 3 = both.  Part 2 may run on another stream (the engine puts it in front of the weight-plane refresh, which lives
+// there already); it must finish before anything reads dstW / dstb and before the next part 1 over the same workspace.
+extern "C" int dr_bf3_wgrad_emb_parts(const int32_t* ids_t, int64_t R, int32_t nf, const int64_t* row_base, const float* table, int32_t D,
+                                      const float* dense_pad, const float* dy, int64_t ld_dy, int32_t F, int32_t N, float scale,
+                                      float* dstW, int64_t ld_w, float* dstb, void* workspace, int64_t workspace_bytes, int32_t parts,
+                                      dr_stream_t stream) {
+    if (parts < 1 || parts > 3) return DR_EINVAL;
+    return wgrad_emb_impl(ids_t, R, nf, row_base, table, D, dense_pad, dy, ld_dy, F, N, scale, dstW, ld_w, dstb, workspace, workspace_bytes,
+                          parts, stream);
 }
 
 // Fused K3 + first Dense layer (see bf3_emb_linear_kernel): h[m][n] = act(sum_k x[m][k] W[k][n] + bias[n]) with

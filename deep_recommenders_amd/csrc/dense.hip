@@ -992,12 +992,12 @@ extern "C" int64_t dr_tower_head_workspace_bytes(int64_t M) {
     return (tiles > 0 ? tiles : 1) * HEAD_PART * (int64_t)sizeof(float);
 }
 
-extern "C" int dr_tower_head_fwd_bwd(const float* x, int64_t ld_x, const float* W1, int64_t ld_w1, const float* b1,
-                                     int64_t M, int64_t n_total, int32_t K, int32_t H, int32_t act, const float* w2,
-                                     int64_t ld_w2, const float* b2, const float* extra_logit, const float* labels,
-                                     int32_t loss_mode, float scale, float* dst_w2, int64_t ld_dst_w2, float* dst_b2,
-                                     float* h_out, int64_t ld_h, float* prob, float* d_logit, float* d_h, int64_t ld_dh,
-                                     float* loss_out, void* workspace, int64_t workspace_bytes, dr_stream_t stream) {
+static int tower_head_impl(const float* x, int64_t ld_x, const float* W1, int64_t ld_w1, const float* b1,
+                           int64_t M, int64_t n_total, int32_t K, int32_t H, int32_t act, const float* w2,
+                           int64_t ld_w2, const float* b2, const float* extra_logit, const float* labels,
+                           int32_t loss_mode, float scale, float* dst_w2, int64_t ld_dst_w2, float* dst_b2,
+                           float* h_out, int64_t ld_h, float* prob, float* d_logit, float* d_h, int64_t ld_dh,
+                           float* loss_out, void* workspace, int64_t workspace_bytes, int32_t parts, dr_stream_t stream) {
     if (M <= 0 || K <= 0 || H <= 0) return DR_EINVAL;
     if (H > 32) return DR_ESHAPE;
     if (!x || !W1 || !w2 || !labels || !workspace || loss_mode < 0 || loss_mode > 2) return DR_EINVAL;
@@ -1012,13 +1012,43 @@ extern "C" int dr_tower_head_fwd_bwd(const float* x, int64_t ld_x, const float* 
     g.prob = prob; g.d_logit = d_logit; g.d_h = d_h; g.ld_dh = ld_dh;
     g.head_partial = static_cast<float*>(workspace);
     g.split = 1;
-    int rc = launch<true, false, EPI_HEAD>(g, dr_s(stream));
-    if (rc != DR_OK) return rc;
-    const int nblocks = (int)((M + BM - 1) / BM);
-    hipLaunchKernelGGL(head_finish_kernel, dim3(1), dim3(256), 0, dr_s(stream), g.head_partial, nblocks, H, scale, g.inv_n,
-                       dst_w2, ld_dst_w2, dst_b2, loss_out);
+    if (parts & 1) {
+        int rc = launch<true, false, EPI_HEAD>(g, dr_s(stream));
+        if (rc != DR_OK) return rc;
+    }
+    if (parts & 2) {
+        const int nblocks = (int)((M + BM - 1) / BM);
+        hipLaunchKernelGGL(head_finish_kernel, dim3(1), dim3(256), 0, dr_s(stream), g.head_partial, nblocks, H, scale, g.inv_n,
+                           dst_w2, ld_dst_w2, dst_b2, loss_out);
+    }
     DR_CHECK_LAUNCH();
     return DR_OK;
+}
+
+extern "C" int dr_tower_head_fwd_bwd(const float* x, int64_t ld_x, const float* W1, int64_t ld_w1, const float* b1,
+                                     int64_t M, int64_t n_total, int32_t K, int32_t H, int32_t act, const float* w2,
+                                     int64_t ld_w2, const float* b2, const float* extra_logit, const float* labels,
+                                     int32_t loss_mode, float scale, float* dst_w2, int64_t ld_dst_w2, float* dst_b2,
+                                     float* h_out, int64_t ld_h, float* prob, float* d_logit, float* d_h, int64_t ld_dh,
+                                     float* loss_out, void* workspace, int64_t workspace_bytes, dr_stream_t stream) {
+    return tower_head_impl(x, ld_x, W1, ld_w1, b1, M, n_total, K, H, act, w2, ld_w2, b2, extra_logit, labels, loss_mode, scale, dst_w2,
+                           ld_dst_w2, dst_b2, h_out, ld_h, prob, d_logit, d_h, ld_dh, loss_out, workspace, workspace_bytes, 3, stream);
+}
+
+// The same call in two halves (parts = 1: the GEMM + head kernel -- prob, d_logit, d_h and the per-block partials; parts = 2: the small
+// finish kernel that sums the partials into dst_w2 / dst_b2 / loss_out; 3 = both = the call above).  Nothing the rest of the step
+// reads comes out of part 2, so a caller may run it on another stream (it must finish before the NEXT call's part 1: w2 / b2 and the
+// workspace).  Round 4: the three small reduce kernels of the step off the training stream.
+extern "C" int dr_tower_head_fwd_bwd_parts(const float* x, int64_t ld_x, const float* W1, int64_t ld_w1, const float* b1,
+                                           int64_t M, int64_t n_total, int32_t K, int32_t H, int32_t act, const float* w2,
+                                           int64_t ld_w2, const float* b2, const float* extra_logit, const float* labels,
+                                           int32_t loss_mode, float scale, float* dst_w2, int64_t ld_dst_w2, float* dst_b2,
+                                           float* h_out, int64_t ld_h, float* prob, float* d_logit, float* d_h, int64_t ld_dh,
+                                           float* loss_out, void* workspace, int64_t workspace_bytes, int32_t parts,
+                                           dr_stream_t stream) {
+    if (parts < 1 || parts > 3) return DR_EINVAL;
+    return tower_head_impl(x, ld_x, W1, ld_w1, b1, M, n_total, K, H, act, w2, ld_w2, b2, extra_logit, labels, loss_mode, scale, dst_w2,
+                           ld_dst_w2, dst_b2, h_out, ld_h, prob, d_logit, d_h, ld_dh, loss_out, workspace, workspace_bytes, parts, stream);
 }
 
 extern "C" int dr_linear_fwd(const float* x, int64_t ld_x, const float* W, int64_t ld_w, const float* b, int64_t M,

@@ -224,10 +224,10 @@ extern "C" int64_t dr_linear_bwd_narrow_workspace_bytes(int64_t M, int32_t K, in
 
 // Returns DR_ESHAPE when the shape is outside the fused kernel's domain (the caller then uses dr_linear_bwd_dx +
 // dr_linear_bwd_dw): needs N <= 32, K in {128, 256, 512}, M a positive multiple of 32, 4*KT-byte aligned rows.
-extern "C" int dr_linear_bwd_narrow(const float* x, int64_t ld_x, const float* dy, int64_t ld_dy, const float* W,
-                                    int64_t ld_w, int64_t M, int32_t K, int32_t N, int32_t relu_mask, float scale,
-                                    float* dstW, int64_t ld_dstw, float* dstb, float* dx, int64_t ld_dx, void* workspace,
-                                    int64_t workspace_bytes, dr_stream_t stream) {
+static int bwd_narrow_impl(const float* x, int64_t ld_x, const float* dy, int64_t ld_dy, const float* W,
+                           int64_t ld_w, int64_t M, int32_t K, int32_t N, int32_t relu_mask, float scale,
+                           float* dstW, int64_t ld_dstw, float* dstb, float* dx, int64_t ld_dx, void* workspace,
+                           int64_t workspace_bytes, int32_t parts, dr_stream_t stream) {
     if (M <= 0 || K <= 0 || N <= 0) return DR_EINVAL;
     if (!x || !dy || !W || !dstW || !dx || !workspace) return DR_EINVAL;
     if (N > 32 || (K != 128 && K != 256 && K != 512) || (M % TT_ROWS) != 0) return DR_ESHAPE;
@@ -243,12 +243,35 @@ extern "C" int dr_linear_bwd_narrow(const float* x, int64_t ld_x, const float* d
 #define TT_CALL(KT)                                                                                                     \
     hipLaunchKernelGGL((linear_bwd_narrow_kernel<KT>), dim3(grid), dim3(256), 0, dr_s(stream), x, ld_x, dy, ld_dy, W,   \
                        ld_w, M, K, N, relu_mask, dx, ld_dx, partial)
-    if (kt == 1) TT_CALL(1);
-    else if (kt == 2) TT_CALL(2);
-    else TT_CALL(4);
+    if (parts & 1) {
+        if (kt == 1) TT_CALL(1);
+        else if (kt == 2) TT_CALL(2);
+        else TT_CALL(4);
+    }
 #undef TT_CALL
-    hipLaunchKernelGGL(linear_bwd_narrow_reduce_kernel, dim3(K + 1), dim3(256), 0, dr_s(stream), partial, grid, K, N, scale,
-                       dstW, ld_dstw, dstb);
+    if (parts & 2)
+        hipLaunchKernelGGL(linear_bwd_narrow_reduce_kernel, dim3(K + 1), dim3(256), 0, dr_s(stream), partial, grid, K, N, scale,
+                           dstW, ld_dstw, dstb);
     DR_CHECK_LAUNCH();
     return DR_OK;
+}
+
+extern "C" int dr_linear_bwd_narrow(const float* x, int64_t ld_x, const float* dy, int64_t ld_dy, const float* W,
+                                    int64_t ld_w, int64_t M, int32_t K, int32_t N, int32_t relu_mask, float scale,
+                                    float* dstW, int64_t ld_dstw, float* dstb, float* dx, int64_t ld_dx, void* workspace,
+                                    int64_t workspace_bytes, dr_stream_t stream) {
+    return bwd_narrow_impl(x, ld_x, dy, ld_dy, W, ld_w, M, K, N, relu_mask, scale, dstW, ld_dstw, dstb, dx, ld_dx, workspace,
+                           workspace_bytes, 3, stream);
+}
+
+// In two halves: parts = 1 the one-pass kernel (dx and the per-block partials of dW / db), parts = 2 the reduce that applies them
+// (dstW += scale * sum, dstb likewise), 3 = both.  Part 2 may run on another stream; it must finish before anything reads dstW / dstb
+// and before the next part 1 over the same workspace.
+extern "C" int dr_linear_bwd_narrow_parts(const float* x, int64_t ld_x, const float* dy, int64_t ld_dy, const float* W,
+                                          int64_t ld_w, int64_t M, int32_t K, int32_t N, int32_t relu_mask, float scale,
+                                          float* dstW, int64_t ld_dstw, float* dstb, float* dx, int64_t ld_dx, void* workspace,
+                                          int64_t workspace_bytes, int32_t parts, dr_stream_t stream) {
+    if (parts < 1 || parts > 3) return DR_EINVAL;
+    return bwd_narrow_impl(x, ld_x, dy, ld_dy, W, ld_w, M, K, N, relu_mask, scale, dstW, ld_dstw, dstb, dx, ld_dx, workspace,
+                           workspace_bytes, parts, stream);
 }

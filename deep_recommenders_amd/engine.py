@@ -199,6 +199,8 @@ class DeepFMEngine:
             self.ev_dlogit = torch.cuda.Event()
             self.ev_lin = torch.cuda.Event()
             self.ev_fwd0 = torch.cuda.Event()
+            self.ev_part1 = torch.cuda.Event()
+            self.ev_small = torch.cuda.Event()
             self._ev_dense = [torch.cuda.Event(), torch.cuda.Event()]
             self._dense_by_event = False
         # First-order weights of the rows that are unique in the batch (99.4 % of the slots for uniform ids) updated by a kernel of
@@ -207,6 +209,15 @@ class DeepFMEngine:
         self.lin_side = (sorted_bwd and optimizer == "sgd" and _os.environ.get("DR_LIN_SIDE", "0") == "1")
         # (the library reads the same variable once per process, with the same rule: off iff the value STARTS with '0')
         self._k4_det = not _os.environ.get("DR_K4_DETERMINISTIC", "1").startswith("0")
+        # The step's three small reduce kernels -- the fused head's finish (partials -> Dense(1) step + loss), the narrow backward's
+        # reduce (partials -> its weight step) and the first-layer wgrad's split-K reduce -- on the SIDE stream (round 4;
+        # DR_REDUCE_SIDE=0: on the training stream as before).  Nothing in the rest of the step reads what they write; on the training
+        # stream each cost its own 6 - 19 us plus a dependent-launch boundary (a build that skips them: 1.408 -> 1.37 ms).  SGD only
+        # (Adam's dense step consumes the gradient bucket they fill).
+        _rs = _os.environ.get("DR_REDUCE_SIDE", "0")
+        self.reduce_side = (sorted_bwd and optimizer == "sgd" and _rs in ("1", "2") and _os.environ.get("DR_SORT_INLINE", "0") != "1")
+        self.reduce_side_wgrad = self.reduce_side and _rs == "1"          # "2": the head's and the narrow backward's only
+        self._small_pending = False
         self._planes_pending = False
         self._planes_pending_l0 = False
         self._in_train_step = False
@@ -371,12 +382,26 @@ class DeepFMEngine:
             out.append({"kernels": [a, b], "joint_us": tot / n * 1e3})
         return out
 
+    def _wgrad_reduce_deferred(self, i):
+        """layer 0's gathering wgrad with its reduce on the side stream, in front of the plane refresh that lives there already"""
+        return (self.reduce_side_wgrad and i == 0 and self.no_concat and self.wplanes[0] is not None and not self.sort_inline
+                and not self.overlap_dw)
+
+    def _side_part2(self, fn):
+        """second half of a two-part call on the side stream, behind the first half (just launched on the training stream)"""
+        self.ev_part1.record()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.ev_part1)
+            fn()
+            self.ev_small.record(self.side)
+        self._small_pending = True
+
     def _wgrad(self, i, x, dy, sc, dstW, dstb):
         if i == 0 and self.no_concat:
             # x = [embeddings of this batch's rows, dense features]: gathered from the tables (they are updated only by K4, later
             # on this stream) through the field-major ids
             ops.bf3_wgrad_emb(self._ids_t[self.cur], self.row_base, self.table, self.dense_pad, dy, sc, dstW, dstb,
-                              workspace=self.wg_ws[0])
+                              workspace=self.wg_ws[0], parts=1 if self._wgrad_reduce_deferred(i) else 3)
         elif self.wg_ws[i] is not None:
             ops.bf3_wgrad(x, dy, sc, dstW, dstb, workspace=self.wg_ws[i])
         else:
@@ -474,13 +499,18 @@ class DeepFMEngine:
         if head:
             # K7 tail + K11: Dense(H<=32, relu), Dense(1), + FM logit, loss, d_logit, d_h and the Dense(1) SGD step
             W1, W2 = self.Ws[-2], self.Ws[-1]
-            self._k("tower_head_fwd_bwd", "hbm", 4.0 * B * (W1.shape[0] + W1.shape[1] + 4),
-                    lambda x=x, W1=W1, W2=W2: ops.tower_head_fwd_bwd(
-                        x, W1, self.bs[-2], W2, self.bs[-1], self.fm_logit, labels, loss_mode,
-                        1.0 if self.optimizer == "adam" else -self.lr, act=1,
-                        prob=self.prob, d_logit=self.d_logit, d_h=self.dhs[-1], loss=self.loss, workspace=self.head_ws,
-                        dst_W2=self.gWs[-1] if self.optimizer == "adam" else "inplace",
-                        dst_b2=self.gbs[-1] if self.optimizer == "adam" else "inplace"))
+            def head(parts, x=x, W1=W1, W2=W2):
+                return ops.tower_head_fwd_bwd(
+                    x, W1, self.bs[-2], W2, self.bs[-1], self.fm_logit, labels, loss_mode,
+                    1.0 if self.optimizer == "adam" else -self.lr, act=1,
+                    prob=self.prob, d_logit=self.d_logit, d_h=self.dhs[-1], loss=self.loss, workspace=self.head_ws,
+                    dst_W2=self.gWs[-1] if self.optimizer == "adam" else "inplace",
+                    dst_b2=self.gbs[-1] if self.optimizer == "adam" else "inplace", parts=parts)
+            if self.reduce_side and self._in_train_step:
+                self._k("tower_head_fwd_bwd", "hbm", 4.0 * B * (W1.shape[0] + W1.shape[1] + 4), lambda: head(1))
+                self._side_part2(lambda: head(2))
+            else:
+                self._k("tower_head_fwd_bwd", "hbm", 4.0 * B * (W1.shape[0] + W1.shape[1] + 4), lambda: head(3))
             return self.prob
         if labels is None:
             labels = self.prob   # dummy, loss ignored
@@ -519,9 +549,13 @@ class DeepFMEngine:
                 dx = self.d_concat[:, :self.in_dim]
                 rs = None
             if i > 0 and self.fuse_narrow and self.narrow_ws[i] is not None:
-                self._k("linear_bwd_narrow_L%d" % i, "hbm", 4.0 * self.B * (2 * W.shape[0] + W.shape[1]),
-                        lambda x=x, dy=dy, W=W, dx=dx, i=i, dstW=dstW, dstb=dstb: ops.linear_bwd_narrow(
-                            x, dy, W, sc, dstW, dstb, dx, relu_mask=True, workspace=self.narrow_ws[i]))
+                def narrow(parts, x=x, dy=dy, W=W, dx=dx, i=i, dstW=dstW, dstb=dstb):
+                    return ops.linear_bwd_narrow(x, dy, W, sc, dstW, dstb, dx, relu_mask=True, workspace=self.narrow_ws[i], parts=parts)
+                if self.reduce_side and self._in_train_step:
+                    self._k("linear_bwd_narrow_L%d" % i, "hbm", 4.0 * self.B * (2 * W.shape[0] + W.shape[1]), lambda: narrow(1))
+                    self._side_part2(lambda: narrow(2))
+                else:
+                    self._k("linear_bwd_narrow_L%d" % i, "hbm", 4.0 * self.B * (2 * W.shape[0] + W.shape[1]), lambda: narrow(3))
                 dy = dx
                 continue
             # dx first (uses the pre-update W), then the wgrad (with the fused SGD step unless Adam)
@@ -554,6 +588,10 @@ class DeepFMEngine:
                     self.ev_dw_done.record()
                     with torch.cuda.stream(self.side):
                         self.side.wait_event(self.ev_dw_done)
+                        if self._wgrad_reduce_deferred(i):
+                            # the split-K reduce (+ fused SGD step) of the GEMM just launched: nothing on the training stream reads W
+                            ops.bf3_wgrad_emb(self._ids_t[self.cur], self.row_base, self.table, self.dense_pad, dy, sc, dstW, dstb,
+                                              workspace=self.wg_ws[0], parts=2)
                         self.wplanes[i].refresh()
                         self.ev_planes.record(self.side)
                     self._planes_pending = True
@@ -588,6 +626,11 @@ class DeepFMEngine:
             self._k("emb_pool_bwd", "hbm", self.alg_bytes_bwd(),                                      # K4 (atomics)
                     lambda: ops.emb_pool_bwd(self.ids, F, self.col_start, self.row_base, D, self.d_concat, self.concat,
                                              self.sum_x, self.d_logit, -lr, self.table, self.lin_w, self.lin_bias))
+        if self._small_pending:
+            # the head's finish / narrow reduce ran on the side stream: whoever reads the loss or the small layers' weights next does
+            # so on this stream (they finished long ago -- the wait is free)
+            torch.cuda.current_stream().wait_event(self.ev_small)
+            self._small_pending = False
         if self.overlap_dw and not adam:
             torch.cuda.current_stream().wait_event(self.ev_dw)     # next step's forward reads the updated first layer
 

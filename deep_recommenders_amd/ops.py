@@ -239,7 +239,7 @@ def linear_bwd_narrow_workspace(M, K, N, device):
                        dtype=torch.float32, device=device)
 
 
-def linear_bwd_narrow(x, dy, W, scale, dstW, dstb, dx, relu_mask=True, workspace=None):
+def linear_bwd_narrow(x, dy, W, scale, dstW, dstb, dx, relu_mask=True, workspace=None, parts=3):
     """One pass over x: dx = (dy @ W^T) * (x > 0 if relu_mask); dstW += scale * x^T dy; dstb += scale * colsum(dy).
     dx uses the pre-update W even when dstW is W.  Raises RuntimeError(DR_ESHAPE) outside the kernel's domain."""
     M, K = x.shape
@@ -248,6 +248,12 @@ def linear_bwd_narrow(x, dy, W, scale, dstW, dstb, dx, relu_mask=True, workspace
     assert W.shape == (K, N) and dstW.shape == (K, N) and dx.shape == (M, K)
     if workspace is None:
         workspace = linear_bwd_narrow_workspace(M, K, N, x.device)
+    if parts != 3:          # 1: the one-pass kernel, 2: the reduce that applies the partials (may run on another stream)
+        check(lib().dr_linear_bwd_narrow_parts(ptr(x), x.stride(0), ptr(dy), dy.stride(0), ptr(W), W.stride(0), M, K, N,
+                                               1 if relu_mask else 0, float(scale), ptr(dstW), dstW.stride(0), ptr(dstb), ptr(dx),
+                                               dx.stride(0), ptr(workspace), workspace.numel() * 4, int(parts), stream_ptr()),
+              "dr_linear_bwd_narrow_parts")
+        return dx
     check(lib().dr_linear_bwd_narrow(ptr(x), x.stride(0), ptr(dy), dy.stride(0), ptr(W), W.stride(0), M, K, N,
                                      1 if relu_mask else 0, float(scale), ptr(dstW), dstW.stride(0), ptr(dstb), ptr(dx),
                                      dx.stride(0), ptr(workspace), workspace.numel() * 4, stream_ptr()),
@@ -260,7 +266,7 @@ def tower_head_workspace(M, device):
 
 
 def tower_head_fwd_bwd(x, W1, b1, W2, b2, extra_logit, labels, loss_mode, scale, act=1, h_out=None, prob=None, d_logit=None,
-                       d_h=None, loss=None, workspace=None, dst_W2="inplace", dst_b2="inplace", n_total=0):
+                       d_h=None, loss=None, workspace=None, dst_W2="inplace", dst_b2="inplace", n_total=0, parts=3):
     """Last hidden layer (H <= 32) + Dense(1) + extra logit + BCE loss + the Dense(1) backward, fused.
     W2: [H, 1] (any row stride).  dst_W2 / dst_b2 += scale * gradient: by default the parameters themselves (fused SGD,
     scale = -lr); pass gradient buffers with scale = 1 for data-parallel training, or None to skip.  n_total: size of
@@ -280,6 +286,14 @@ def tower_head_fwd_bwd(x, W1, b1, W2, b2, extra_logit, labels, loss_mode, scale,
     loss = loss if loss is not None else torch.empty(1, dtype=torch.float32, device=dev)
     if workspace is None:
         workspace = tower_head_workspace(M, dev)
+    if parts != 3:          # 1: GEMM + head kernel, 2: the finish kernel (partials -> dst_W2 / dst_b2 / loss; may run on another stream)
+        check(lib().dr_tower_head_fwd_bwd_parts(ptr(x), x.stride(0), ptr(W1), W1.stride(0), ptr(b1), M, int(n_total), K, H, int(act), ptr(W2),
+                                                W2.stride(0), ptr(b2), ptr(extra_logit), ptr(labels), int(loss_mode), float(scale),
+                                                ptr(dst_W2), dst_W2.stride(0) if dst_W2 is not None else 0, ptr(dst_b2),
+                                                ptr(h_out), h_out.stride(0) if h_out is not None else 0, ptr(prob), ptr(d_logit),
+                                                ptr(d_h), d_h.stride(0), ptr(loss), ptr(workspace), workspace.numel() * 4, int(parts),
+                                                stream_ptr()), "dr_tower_head_fwd_bwd_parts")
+        return loss, prob, d_logit, d_h
     check(lib().dr_tower_head_fwd_bwd(ptr(x), x.stride(0), ptr(W1), W1.stride(0), ptr(b1), M, int(n_total), K, H, int(act), ptr(W2),
                                       W2.stride(0), ptr(b2), ptr(extra_logit), ptr(labels), int(loss_mode), float(scale),
                                       ptr(dst_W2), dst_W2.stride(0) if dst_W2 is not None else 0, ptr(dst_b2),
@@ -981,7 +995,7 @@ def bf3_wgrad_workspace(R, F, N, device):
     return torch.empty(max(64, lib().dr_bf3_wgrad_workspace_bytes(int(R), int(F), int(N)) // 4), dtype=torch.float32, device=device)
 
 
-def bf3_wgrad_emb(ids_t, row_base, table, dense_pad, dy, scale, dstW, dstb=None, workspace=None):
+def bf3_wgrad_emb(ids_t, row_base, table, dense_pad, dy, scale, dstW, dstb=None, workspace=None, parts=3):
     """bf3_wgrad of the first tower layer with x gathered from the tables (dr_bf3_wgrad_emb): ids_t [nf, R] int32 field-major,
     dense_pad [R, 32] or None; dstW [64 nf + Nd, N]."""
     nf, R = ids_t.shape
@@ -990,6 +1004,11 @@ def bf3_wgrad_emb(ids_t, row_base, table, dense_pad, dy, scale, dstW, dstb=None,
     assert dense_pad is None or (dense_pad.shape == (R, 32) and dense_pad.is_contiguous())
     if workspace is None:
         workspace = bf3_wgrad_workspace(R, F, N, dy.device)
+    if parts != 3:          # 1: the split-K GEMM into the workspace, 2: the reduce that applies it (may run on another stream)
+        check(lib().dr_bf3_wgrad_emb_parts(ptr(ids_t), R, nf, ptr(row_base), ptr(table), table.shape[1], ptr(dense_pad), ptr(dy), dy.stride(0),
+                                           F, N, float(scale), ptr(dstW), dstW.stride(0), ptr(dstb), ptr(workspace), workspace.numel() * 4,
+                                           int(parts), stream_ptr()), "dr_bf3_wgrad_emb_parts")
+        return dstW
     check(lib().dr_bf3_wgrad_emb(ptr(ids_t), R, nf, ptr(row_base), ptr(table), table.shape[1], ptr(dense_pad), ptr(dy), dy.stride(0),
                                  F, N, float(scale), ptr(dstW), dstW.stride(0), ptr(dstb), ptr(workspace), workspace.numel() * 4,
                                  stream_ptr()), "dr_bf3_wgrad_emb")

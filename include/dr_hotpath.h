@@ -356,6 +356,20 @@ int dr_tower_head_fwd_bwd(const float* x, int64_t ld_x, const float* W1, int64_t
                           int64_t ld_w2, const float* b2, const float* extra_logit, const float* labels,
                           int32_t loss_mode, float scale, float* dst_w2, int64_t ld_dst_w2, float* dst_b2, float* h_out, int64_t ld_h, float* prob, float* d_logit, float* d_h, int64_t ld_dh,
                           float* loss_out, void* workspace, int64_t workspace_bytes, dr_stream_t stream);
+/* dr_linear_bwd_narrow / dr_tower_head_fwd_bwd in two halves (round 4): parts = 1 the main kernel (everything the rest of the step
+ * reads: dx; prob, d_logit, d_h), parts = 2 the small reduce that applies the per-block partials to the weights (and writes the
+ * loss), 3 = both.  Part 2 may run on ANOTHER stream -- the engine keeps the three reduce kernels of a step off its training stream;
+ * it must finish before anything reads the updated weights and before the next part 1 over the same workspace. */
+int dr_linear_bwd_narrow_parts(const float* x, int64_t ld_x, const float* dy, int64_t ld_dy, const float* W,
+                               int64_t ld_w, int64_t M, int32_t K, int32_t N, int32_t relu_mask, float scale,
+                               float* dstW, int64_t ld_dstw, float* dstb, float* dx, int64_t ld_dx,
+                               void* workspace, int64_t workspace_bytes, int32_t parts, dr_stream_t stream);
+int dr_tower_head_fwd_bwd_parts(const float* x, int64_t ld_x, const float* W1, int64_t ld_w1, const float* b1,
+                                int64_t M, int64_t n_total, int32_t K, int32_t H, int32_t act, const float* w2,
+                                int64_t ld_w2, const float* b2, const float* extra_logit, const float* labels,
+                                int32_t loss_mode, float scale, float* dst_w2, int64_t ld_dst_w2, float* dst_b2, float* h_out, int64_t ld_h,
+                                float* prob, float* d_logit, float* d_h, int64_t ld_dh, float* loss_out, void* workspace,
+                                int64_t workspace_bytes, int32_t parts, dr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K8  DCN cross layer (keras/models/ranking/dcn.py:70-88):
@@ -638,6 +652,11 @@ int dr_bf3_wgrad(const float* x, int64_t ld_x, const float* dy, int64_t ld_dy, i
 int dr_bf3_wgrad_emb(const int32_t* ids_t, int64_t R, int32_t nf, const int64_t* row_base, const float* table, int32_t D,
                      const float* dense_pad, const float* dy, int64_t ld_dy, int32_t F, int32_t N, float scale, float* dstW,
                      int64_t ld_w, float* dstb, void* workspace, int64_t workspace_bytes, dr_stream_t stream);
+/* ... in two halves like dr_linear_bwd_narrow_parts: parts = 1 the split-K GEMM into the workspace, 2 the fixed-order reduce that
+ * applies it to dstW / dstb, 3 = both */
+int dr_bf3_wgrad_emb_parts(const int32_t* ids_t, int64_t R, int32_t nf, const int64_t* row_base, const float* table, int32_t D,
+                           const float* dense_pad, const float* dy, int64_t ld_dy, int32_t F, int32_t N, float scale, float* dstW,
+                           int64_t ld_w, float* dstb, void* workspace, int64_t workspace_bytes, int32_t parts, dr_stream_t stream);
 int64_t dr_bf3_gemm_tn_workspace_bytes(int64_t R, int32_t F, int32_t N);
 int dr_bf3_gemm_tn(const void* x_planes, int64_t x_plane_stride, int64_t x_ld, const void* y_planes,
                    int64_t y_plane_stride, int64_t y_ld, int64_t R, int32_t F, int32_t N, float scale, float* dst,

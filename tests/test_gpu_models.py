@@ -340,6 +340,39 @@ def test_engine_next_batch_prefetch_is_bit_identical(optimizer, D, V):
     assert engs[0].loss.item() == engs[1].loss.item()
 
 
+@pytest.mark.parametrize("switch,value", [("DR_REDUCE_SIDE", "1"), ("DR_REDUCE_SIDE", "2"), ("DR_PREFETCH_EARLY", "1")])
+def test_engine_schedule_switches_are_bit_identical(switch, value, monkeypatch):
+    """Round 4's measured-and-rejected schedules stay correct: the step's small reduce kernels on the side stream
+    (dr_tower_head_fwd_bwd_parts / dr_linear_bwd_narrow_parts / dr_bf3_wgrad_emb_parts: the two halves of each call on two streams),
+    and the next batch's hash + plan issued at the start of the step.  Same kernels, same arithmetic order: parameters and losses
+    must be bit-identical to the default schedule over prefetched steps (D = 64: fused first layer, gathering wgrad, planes)."""
+    from deep_recommenders_amd.engine import DeepFMEngine
+    F, B, Nd, D, V = 4, 2304, 3, 64, 3000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(12)
+    batches = [(torch.randint(0, 10**12, (B, F), device="cuda", generator=g), torch.rand((B, Nd), device="cuda", generator=g),
+                (torch.rand(B, device="cuda", generator=g) < 0.3).float()) for _ in range(3)]
+
+    def run():
+        eng = DeepFMEngine(F, V, D, [256, 16], B, num_dense=Nd, lr=0.05, seed=3, lin_init_std=0.1)
+        losses = []
+        for n in range(5):
+            k, d, l = batches[n % 3]
+            nk, nd = batches[(n + 1) % 3][0], batches[(n + 1) % 3][1]
+            losses.append(float(eng.train_step(k, d, l, next_keys=nk, next_dense=nd).item()))
+        torch.cuda.synchronize()
+        return eng, losses
+    base, l0 = run()
+    monkeypatch.setenv(switch, value)
+    alt, l1 = run()
+    if switch == "DR_REDUCE_SIDE":
+        assert alt.reduce_side and alt.reduce_side_wgrad == (value == "1")
+    else:
+        assert alt.prefetch_early
+    assert l0 == l1
+    assert torch.equal(base.table, alt.table) and torch.equal(base.lin_w, alt.lin_w) and torch.equal(base.flat_params, alt.flat_params)
+
+
 def test_engine_train_step_matches_oracle():
     """The fused engine step (what bench.py times) against the host restatement: loss and updated weights."""
     from deep_recommenders_amd.engine import DeepFMEngine
