@@ -30,6 +30,8 @@ SIGNATURES = {
     "dr_lin_fields_bwd": [_p, _i64, _i32, _i32, _p, _p, _p, _i64, _f32, _p, _p],
     "dr_emb_pool_bwd_sorted_adam": [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _i64, _p, _i64, _p, _p, _p, _f32, _f32,
                                     _f32, _f32, _p, _p, _p, _p, _p, _p, _p, _p],
+    "dr_emb_pool_bwd_sorted_adam_ex": [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _i64, _p, _i64, _p, _p, _p, _f32, _f32,
+                                    _f32, _f32, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "dr_adam_step": [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _p],
     "dr_ftrl_step": [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _p],
     "dr_linear_bwd_dw_workspace_bytes": [_i64, _i32, _i32],

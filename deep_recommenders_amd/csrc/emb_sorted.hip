@@ -60,6 +60,9 @@ __device__ __forceinline__ void st4_stream(float* p, const float4 v) {
 struct AdamArgs {
     float* m; float* v;            // [R, D]
     float* m_lin; float* v_lin;    // [R] (may be null when there is no first-order table)
+    int64_t lin_stride;            // 1: two arrays; 2: v_lin == m_lin + 1 -- the two moments of a row interleaved in ONE [R, 2] array, so
+                                   // that a row's first-order state is one line operation to read and one to write instead of two each
+                                   // (K4 is bound by line operations, DESIGN.md section 3 "Round 4")
     float lr_t, b1, b2, eps;
 };
 
@@ -89,7 +92,7 @@ __device__ __forceinline__ void emb_bwd_unique_body(const int bid, const int nbl
     // unique row's weight has not changed since, so its update is one WRITE of old + scale * g -- not a read-modify-write whose line
     // has to come back from HBM first.  K4 is bound by 128-byte line operations (8 per slot with the RMW: gradient 2, row 2 + 2,
     // first-order 1 + 1): this removes one of them (measured: 281 -> 264 us, tools/exp/k4_ladder.py LINW).
-    const bool lold = !ADAM && lin_old_t != nullptr && lin_w != nullptr;
+    const bool lold = lin_old_t != nullptr && lin_w != nullptr;
     const int subc = dvalid ? sub : nq - 1;
     const bool fm = sum_x != nullptr && d_fm_logit != nullptr;      // (a unique row's own value IS x: concat is never read here)
     const bool do_lin = lin_w != nullptr && (d_fm_logit != nullptr || slot_lin != nullptr) && sub == 0;
@@ -154,8 +157,8 @@ __device__ __forceinline__ void emb_bwd_unique_body(const int bid, const int nbl
                 if (ADAM) {
                     mt[u] = ld4_stream(ad.m + rc * D + subc * 4);
                     vt[u] = ld4_stream(ad.v + rc * D + subc * 4);
-                    ml[u] = mlsrc[(ad.m_lin != nullptr) ? rc : 0];
-                    vl[u] = vlsrc[(ad.v_lin != nullptr) ? rc : 0];
+                    ml[u] = mlsrc[(ad.m_lin != nullptr) ? rc * ad.lin_stride : 0];
+                    vl[u] = vlsrc[(ad.v_lin != nullptr) ? rc * ad.lin_stride : 0];
                 }
             }
 #pragma unroll
@@ -185,7 +188,7 @@ __device__ __forceinline__ void emb_bwd_unique_body(const int bid, const int nbl
                     }
                     if (do_lin) {
                         lin_w[row[u]] = nl;
-                        if (ADAM && ad.m_lin != nullptr) { ad.m_lin[row[u]] = ml[u]; ad.v_lin[row[u]] = vl[u]; }
+                        if (ADAM && ad.m_lin != nullptr) { ad.m_lin[row[u] * ad.lin_stride] = ml[u]; ad.v_lin[row[u] * ad.lin_stride] = vl[u]; }
                     }
                 }
             }
@@ -318,9 +321,9 @@ __device__ __forceinline__ void emb_bwd_dups_body(const int bid, const int nblk,
                     *reinterpret_cast<float4*>(ad.v + k * (uint64_t)D + sub * 4) = vt;
                 }
                 if (lin_w != nullptr && any_lin && sub == 0) {
-                    float ml = ad.m_lin != nullptr ? ad.m_lin[k] : 0.f, vl = ad.v_lin != nullptr ? ad.v_lin[k] : 0.f;
+                    float ml = ad.m_lin != nullptr ? ad.m_lin[k * ad.lin_stride] : 0.f, vl = ad.v_lin != nullptr ? ad.v_lin[k * ad.lin_stride] : 0.f;
                     lin_w[k] += adam_elem(dls, ml, vl, ad);
-                    if (ad.m_lin != nullptr) { ad.m_lin[k] = ml; ad.v_lin[k] = vl; }
+                    if (ad.m_lin != nullptr) { ad.m_lin[k * ad.lin_stride] = ml; ad.v_lin[k * ad.lin_stride] = vl; }
                 }
             }
         } else if (live) {
@@ -526,7 +529,7 @@ static int bwd_sorted_impl(const int64_t* ids, const int64_t* row_base, const in
     const BwdSortedArgs ba{ids, unique_flags, B, F, row_base, D, grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit, slot_lin_grad,
                            scale, dst_table, dst_lin, dst_bias, rows, sorted_slots, n, dup_heads, dup_count, (uint64_t)num_rows,
                            x_sorted, det, (adam == nullptr && (parts & 4)) ? 1 : 0,
-                           (adam == nullptr && slot_lin_grad == nullptr) ? lin_old_t : nullptr};
+                           slot_lin_grad == nullptr ? lin_old_t : nullptr};
 #ifdef DR_K4_U
     constexpr int K4_U_OVERRIDE = DR_K4_U;
 #else
@@ -709,10 +712,30 @@ extern "C" int dr_emb_pool_bwd_sorted_adam(const int64_t* ids, const int64_t* ro
                                            float* lin_w, float* m_lin, float* v_lin, float* x_sorted, dr_stream_t stream) {
     if (!m_table || !v_table) return DR_EINVAL;
     if (lin_w != nullptr && (!m_lin || !v_lin)) return DR_EINVAL;
-    AdamArgs ad{m_table, v_table, m_lin, v_lin, lr_t, beta1, beta2, eps};
+    // m_lin / v_lin as the two columns of one [R, 2] array (v_lin == m_lin + 1): row stride 2
+    AdamArgs ad{m_table, v_table, m_lin, v_lin, (m_lin != nullptr && v_lin == m_lin + 1) ? 2 : 1, lr_t, beta1, beta2, eps};
     return bwd_sorted_impl(ids, row_base, sorted_rows, sorted_slots, unique_flags, dup_heads, dup_count, B, F, D, num_rows,
                            grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit, slot_lin_grad, 0.f, table, lin_w, nullptr,
                            &ad, x_sorted, stream);
+}
+
+// ... with lin_old_t [F, B] (may be NULL) as in dr_emb_pool_bwd_sorted_ex: the first-order weight of a row unique in the batch is
+// written from the value the forward of this step saved instead of being read again.
+extern "C" int dr_emb_pool_bwd_sorted_adam_ex(const int64_t* ids, const int64_t* row_base, const int64_t* sorted_rows,
+                                              const int32_t* sorted_slots, const uint8_t* unique_flags,
+                                              const int32_t* dup_heads, const int32_t* dup_count, int64_t B, int32_t F,
+                                              int32_t D, int64_t num_rows, const float* grad, int64_t ld_grad,
+                                              const float* concat, int64_t ld_concat, const float* sum_x,
+                                              const float* d_fm_logit, const float* slot_lin_grad, float lr_t, float beta1,
+                                              float beta2, float eps, float* table, float* m_table, float* v_table,
+                                              float* lin_w, float* m_lin, float* v_lin, float* x_sorted, const float* lin_old_t,
+                                              dr_stream_t stream) {
+    if (!m_table || !v_table) return DR_EINVAL;
+    if (lin_w != nullptr && (!m_lin || !v_lin)) return DR_EINVAL;
+    AdamArgs ad{m_table, v_table, m_lin, v_lin, (m_lin != nullptr && v_lin == m_lin + 1) ? 2 : 1, lr_t, beta1, beta2, eps};
+    return bwd_sorted_impl(ids, row_base, sorted_rows, sorted_slots, unique_flags, dup_heads, dup_count, B, F, D, num_rows,
+                           grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit, slot_lin_grad, 0.f, table, lin_w, nullptr,
+                           &ad, x_sorted, stream, 3, lin_old_t);
 }
 
 // ---- TF's NON-lazy sparse Adam, evaluated lazily -----------------------------------------------------------------------------------
@@ -733,7 +756,7 @@ __global__ __launch_bounds__(256) void adam_catchup_rows_kernel(const int64_t* _
                                                                 float* __restrict__ v, float* __restrict__ lin_w,
                                                                 float* __restrict__ m_lin, float* __restrict__ v_lin,
                                                                 int32_t* __restrict__ row_step, int32_t upto, int32_t stamp,
-                                                                float lr, float b1, float b2, float eps) {
+                                                                float lr, float b1, float b2, float eps, int64_t ls) {
     // one 16-lane group per slot (D <= 64: 4 floats per lane; D > 64: the group walks the row in 64-float pieces)
     const int lane = threadIdx.x & 63, sub = lane & 15;
     const int64_t groups = (int64_t)gridDim.x * (blockDim.x >> 4);
@@ -766,7 +789,7 @@ __global__ __launch_bounds__(256) void adam_catchup_rows_kernel(const int64_t* _
             // first-order weight of the row: lane 0 of the group, first piece only (rides in the .x slots of a second set)
             const bool lin_live = live && d0 == 0 && sub == 0 && lin_w != nullptr;
             float wl = 0.f, ml = 0.f, vl = 0.f;
-            if (lin_live) { wl = lin_w[row]; ml = m_lin[row]; vl = v_lin[row]; }
+            if (lin_live) { wl = lin_w[row]; ml = m_lin[row * ls]; vl = v_lin[row * ls]; }
             double p1 = pow(lb1, (double)(old + 1)), p2 = pow(lb2, (double)(old + 1));      // b^s of the first missed step
             int32_t done = 0;
             bool active = live;
@@ -808,7 +831,7 @@ __global__ __launch_bounds__(256) void adam_catchup_rows_kernel(const int64_t* _
                 *reinterpret_cast<float4*>(table + row * D + d) = w4;
                 *reinterpret_cast<float4*>(m + row * D + d) = m4;
                 *reinterpret_cast<float4*>(v + row * D + d) = v4;
-                if (lin_live) { lin_w[row] = wl; m_lin[row] = ml; v_lin[row] = vl; }
+                if (lin_live) { lin_w[row] = wl; m_lin[row * ls] = ml; v_lin[row * ls] = vl; }
             }
         }
     }
@@ -825,7 +848,8 @@ extern "C" int dr_adam_catchup_rows(const int64_t* ids, int64_t n, int32_t F, co
     if (!ids || !row_base || !table || !m_table || !v_table || !row_step) return DR_EINVAL;
     if (lin_w != nullptr && (!m_lin || !v_lin)) return DR_EINVAL;
     hipLaunchKernelGGL(adam_catchup_rows_kernel, dim3(dr_grid_for(n, 16, 8192)), dim3(256), 0, dr_s(stream), ids, n, F, row_base, D,
-                       table, m_table, v_table, lin_w, m_lin, v_lin, row_step, upto, stamp, lr, beta1, beta2, eps);
+                       table, m_table, v_table, lin_w, m_lin, v_lin, row_step, upto, stamp, lr, beta1, beta2, eps,
+                       (int64_t)((m_lin != nullptr && v_lin == m_lin + 1) ? 2 : 1));
     DR_CHECK_LAUNCH();
     return DR_OK;
 }

@@ -20,6 +20,11 @@ def _pad4(n):
     return (n + 3) // 4 * 4
 
 
+def _os_env(name, default):
+    import os
+    return os.environ.get(name, default)
+
+
 class DeepFMEngine:
     def __init__(self, num_fields: int, vocab_per_field: int, dim: int, dnn_units: Sequence[int], batch: int,
                  num_dense: int = 0, lr: float = 0.01, device="cuda", seed: int = 42, hashed: bool = True,
@@ -89,8 +94,15 @@ class DeepFMEngine:
             self.g_lin_bias = self.flat_grads[self._bias_off:self._bias_off + 1]
             self.m_table = torch.zeros_like(self.table)
             self.v_table = torch.zeros_like(self.table)
-            self.m_lin = torch.zeros_like(self.lin_w)
-            self.v_lin = torch.zeros_like(self.lin_w)
+            # first-order moments interleaved in ONE [R, 2] array (m_lin, v_lin are its two columns; the kernels see v_lin == m_lin + 1
+            # and stride by 2): a row's first-order Adam state is then one line to read and one to write instead of two each -- the
+            # fused Adam K4 is bound by line operations like the SGD one (round 4; DR_ADAM_LIN_PACKED=0: two arrays)
+            if _os_env("DR_ADAM_LIN_PACKED", "1") == "1":
+                self.mv_lin = torch.zeros((self.R, 2), dtype=torch.float32, device=device)
+                self.m_lin, self.v_lin = self.mv_lin[:, 0], self.mv_lin[:, 1]
+            else:
+                self.m_lin = torch.zeros_like(self.lin_w)
+                self.v_lin = torch.zeros_like(self.lin_w)
             self.row_step = torch.zeros(self.R, dtype=torch.int32, device=device) if self.adam_tf else None
         import os as _os
         self.acts = [1] * len(dnn_units) + [0]
@@ -171,7 +183,7 @@ class DeepFMEngine:
         # new weight (old + step) instead of read-modify-writing a line it would have to fetch from HBM again: K4 is bound by
         # 128-byte line operations, 8 per slot, and this removes one (round 4; DR_K4_LINOLD=0: the read-modify-write).
         self.lin_old_t = (torch.empty((F, B), dtype=torch.float32, device=device)
-                          if (_os.environ.get("DR_K4_LINOLD", "1") == "1" and self.fuse_k3 and sorted_bwd and optimizer == "sgd") else None)
+                          if (_os.environ.get("DR_K4_LINOLD", "1") == "1" and self.fuse_k3 and sorted_bwd) else None)
         self._lin_old_valid = False
         # The slot sort of batch s + 1 next to K4 of batch s (DR_PREFETCH_PLAN=0: every step hashes and sorts its own batch).  K4 is
         # the one long kernel of the step that is HBM-bound with small blocks, i.e. that shares the machine; beside the persistent
@@ -659,7 +671,8 @@ class DeepFMEngine:
                                                      self.d_logit, lr_t, self.beta1, self.beta2, self.eps, self.table,
                                                      self.m_table, self.v_table, self.lin_w, self.m_lin, self.v_lin,
                                                      concat=None if self.no_concat else self.concat, sum_x=self.sum_x,
-                                                     x_sorted=self.x_sorted if self.no_concat else None))
+                                                     x_sorted=self.x_sorted if self.no_concat else None,
+                                                     lin_old_t=self.lin_old_t if self._lin_old_valid else None))
         self._prefetch_issue(mark)
         ops.reduce_sum(self.d_logit, out=self.g_lin_bias)                       # d loss / d (first-order bias), fixed order
         if self.overlap_dw:

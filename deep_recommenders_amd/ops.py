@@ -555,11 +555,21 @@ def adam_lr_t(lr, beta1, beta2, step):
 
 
 def emb_pool_bwd_sorted_adam(ids, row_base, plan, D, num_rows, grad, d_fm_logit, lr_t, beta1, beta2, eps, table, m_table,
-                             v_table, lin_w=None, m_lin=None, v_lin=None, concat=None, sum_x=None, slot_lin_grad=None, x_sorted=None):
+                             v_table, lin_w=None, m_lin=None, v_lin=None, concat=None, sum_x=None, slot_lin_grad=None, x_sorted=None,
+                             lin_old_t=None):
     """Sorted K4 with a fused row-wise Adam update (see dr_emb_pool_bwd_sorted_adam in include/dr_hotpath.h)."""
     ids = _c(ids, torch.int64)
     B, F = ids.shape
     assert grad.stride(1) == 1
+    if lin_old_t is not None:
+        assert lin_old_t.shape == (F, B) and lin_old_t.is_contiguous()
+        check(lib().dr_emb_pool_bwd_sorted_adam_ex(ptr(ids), ptr(row_base), ptr(plan.rows), ptr(plan.slots), ptr(plan.flags),
+                                            ptr(plan.dup_heads), ptr(plan.dup_count), B, F, D, int(num_rows), ptr(grad),
+                                            grad.stride(0), ptr(concat), concat.stride(0) if concat is not None else 0,
+                                            ptr(sum_x), ptr(d_fm_logit), ptr(slot_lin_grad), float(lr_t), float(beta1),
+                                            float(beta2), float(eps), ptr(table), ptr(m_table), ptr(v_table), ptr(lin_w),
+                                            ptr(m_lin), ptr(v_lin), ptr(x_sorted), ptr(lin_old_t), stream_ptr()), "dr_emb_pool_bwd_sorted_adam_ex")
+        return
     check(lib().dr_emb_pool_bwd_sorted_adam(ptr(ids), ptr(row_base), ptr(plan.rows), ptr(plan.slots), ptr(plan.flags),
                                             ptr(plan.dup_heads), ptr(plan.dup_count), B, F, D, int(num_rows), ptr(grad),
                                             grad.stride(0), ptr(concat), concat.stride(0) if concat is not None else 0,

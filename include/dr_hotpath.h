@@ -238,6 +238,9 @@ int dr_emb_snapshot_sorted_rows(const int64_t* sorted_rows, const int32_t* dup_h
  * equal to TF's Adam on the first step and for rows touched on every step; TF decays m/v of the whole variable each step
  * (SURVEY App. B15), which is a full pass over the 66 GB table at config 3.  The first-order bias is a dense parameter:
  * dr_adam_step.  Deterministic (a row's slots are summed by one lane group in sorted order). */
+/* (round 4) m_lin / v_lin may be the two columns of ONE [R, 2] array -- pass v_lin == m_lin + 1 -- and are then addressed with a row
+ * stride of 2: a row's first-order moments share a cache line (one line operation to read, one to write, instead of two each).  The
+ * same convention holds for dr_adam_catchup_rows. */
 int dr_emb_pool_bwd_sorted_adam(const int64_t* ids, const int64_t* row_base, const int64_t* sorted_rows,
                                 const int32_t* sorted_slots, const uint8_t* unique_flags,
                                 const int32_t* dup_heads, const int32_t* dup_count, int64_t B, int32_t F,
@@ -246,6 +249,16 @@ int dr_emb_pool_bwd_sorted_adam(const int64_t* ids, const int64_t* row_base, con
                                 const float* d_fm_logit, const float* slot_lin_grad, float lr_t, float beta1,
                                 float beta2, float eps, float* table, float* m_table, float* v_table,
                                 float* lin_w, float* m_lin, float* v_lin, float* x_sorted, dr_stream_t stream);
+/* ... with lin_old_t as in dr_emb_pool_bwd_sorted_ex */
+int dr_emb_pool_bwd_sorted_adam_ex(const int64_t* ids, const int64_t* row_base, const int64_t* sorted_rows,
+                                const int32_t* sorted_slots, const uint8_t* unique_flags,
+                                const int32_t* dup_heads, const int32_t* dup_count, int64_t B, int32_t F,
+                                int32_t D, int64_t num_rows, const float* grad, int64_t ld_grad,
+                                const float* concat, int64_t ld_concat, const float* sum_x,
+                                const float* d_fm_logit, const float* slot_lin_grad, float lr_t, float beta1,
+                                float beta2, float eps, float* table, float* m_table, float* v_table,
+                                float* lin_w, float* m_lin, float* v_lin, float* x_sorted, const float* lin_old_t,
+                                   dr_stream_t stream);
 /* Dense Adam step (same formula) over a flat parameter buffer; grad is multiplied by grad_scale first. */
 /* TF's NON-lazy sparse Adam, evaluated lazily (examples/train_fm_on_movielens_estimator.py:51-52: tf.train.AdamOptimizer decays
  * m / v of the WHOLE variable and moves every row on every step).  row_step[R] int32 (zero-initialised) counts
