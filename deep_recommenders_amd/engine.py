@@ -193,7 +193,8 @@ class DeepFMEngine:
         # DR_PREFETCH_EARLY=1 (experiment, round 4): the next batch's hash + slot plan start at the BEGINNING of this step (beside the
         # GEMMs, where they crawl but have a whole step of slack) instead of beside K4, which then has HBM to itself; the next batch's
         # dense features are still placed after this step's wgrad.
-        self.prefetch_early = _os.environ.get("DR_PREFETCH_EARLY", "0") == "1"
+        self.prefetch_early = _os.environ.get("DR_PREFETCH_EARLY", "0") in ("1", "2")
+        self.prefetch_after_fwd = _os.environ.get("DR_PREFETCH_EARLY", "0") == "2"      # "2": behind the first GEMM, beside the tower tail
         # Fewer cross-stream packets in front of K4 (rocprofv3 showed a 31 us gap there against 11 - 13 us between the other
         # dependent kernels): the side chain is ordered behind the plane refresh instead of an event of its own, and the wait for
         # a PREFETCHED plan -- long complete by then -- sits in front of the first-layer wgrad.  DR_LEAN_EVENTS=0: as before.
@@ -451,7 +452,7 @@ class DeepFMEngine:
                     lambda: ops.hash_bucket_i64(keys, self.col_buckets, out=self.ids))                # K1
             if self.no_concat:
                 ops.ids_transpose_i32(self.ids, out=self._ids_t[self.cur])
-        if self._in_train_step:
+        if self._in_train_step and not self.prefetch_after_fwd:
             self._prefetch_early()
         if self.sorted_bwd and self.sort_inline:
             self._k("emb_sort_slots", "hbm", B * F * 36,
@@ -500,6 +501,8 @@ class DeepFMEngine:
                                                            self.in_dim, self.wplanes[0].wt, b, self.acts[0], self.sum_x, self.fm_logit,
                                                            self.hs[0], lin_vals_t=self.lin_old_t))
                 self._lin_old_valid = self.lin_old_t is not None
+                if self._in_train_step and self.prefetch_after_fwd:
+                    self._prefetch_early()
             elif self.wplanes[i] is not None:
                 self._k("linear_fwd_L%d" % i, "mfma", 2.0 * B * W.shape[0] * W.shape[1],
                         lambda x=x, b=b, i=i: ops.bf3_linear_nt(x, self.wplanes[i].wt, bias=b, act=self.acts[i], out=self.hs[i]))
