@@ -40,6 +40,10 @@ MFMA_F32_PEAK_TF = 157.3  # dense fp32 MFMA peak (same guide)
 # peak (2.5 PFLOP/s, same guide) divided by six
 MFMA_BF16_PEAK_TF = 2500.0
 MFMA_BF16X3_PEAK_TF = MFMA_BF16_PEAK_TF / 6.0
+# the first layer's three GEMMs of the DeepFM engine run in the "f16x2" operand mode by default (round 4): two fp16 terms per value,
+# THREE v_mfma_f32_32x32x16_f16 products per fp32 product (the fp16 pipe has the bf16 pipe's dense rate)
+MFMA_F16X2_PEAK_TF = MFMA_BF16_PEAK_TF / 3.0
+H2_KERNELS = ("emb_linear_fwd_L0", "linear_bwd_dx_L0", "linear_bwd_dw_L0")
 
 
 def parse():
@@ -456,7 +460,8 @@ def main():
                                               eng.table, eng.lin_w, eng.lin_bias,
                                               concat=None if eng.no_concat else eng.concat, sum_x=eng.sum_x,
                                               x_sorted=eng.x_sorted if eng.no_concat else None, parts=1,
-                                              lin_old_t=getattr(eng, "lin_old_t", None) if getattr(eng, "_lin_old_valid", False) else None)
+                                              lin_old_t=getattr(eng, "lin_old_t", None) if getattr(eng, "_lin_old_valid", False) else None,
+                                              table_amax=getattr(eng, "tab_amax", None) if getattr(eng, "h2", False) else None)
         for _ in range(3):
             k4()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -538,13 +543,17 @@ def main():
             # the wide-tile GEMMs run on the bf16 pipe in the default mode (6 products per fp32 product); the narrow-tile
             # and fused-tail kernels always use the fp32 MFMA
             on_bf16 = a.gemm == "bf16x3" and re.match(r"^(linear|emb_linear|cross|[qc]_tower)_(fwd|bwd_dx|bwd_dw)_L\d+$", name) is not None
-            ach, peak, unit = k["alg_flops"] / sec / 1e12, (MFMA_BF16X3_PEAK_TF if on_bf16 else MFMA_F32_PEAK_TF), "TFLOP/s"
+            on_h2 = on_bf16 and bool(getattr(eng, "h2", False)) and name in H2_KERNELS
+            ach, peak, unit = k["alg_flops"] / sec / 1e12, (MFMA_F16X2_PEAK_TF if on_h2 else MFMA_BF16X3_PEAK_TF if on_bf16 else MFMA_F32_PEAK_TF), "TFLOP/s"
         row = {"kernel": name, "bound": k["bound"], "achieved": round(ach, 2), "peak": round(peak, 1), "unit": unit,
                "frac": round(ach / peak, 4), "traffic": traffic.get(name), "avg_us": round(k["ms"] * 1e3, 2),
                "launches": k["n"]}
         if k["bound"] == "mfma":
-            row["peak_basis"] = ("dense bf16 MFMA peak 2500 TFLOP/s / 6 products per fp32 product" if on_bf16
+            row["peak_basis"] = ("dense fp16 MFMA peak 2500 TFLOP/s / 3 products per fp32 product (f16x2 operand mode)" if on_h2
+                                 else "dense bf16 MFMA peak 2500 TFLOP/s / 6 products per fp32 product" if on_bf16
                                  else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)")
+            if on_h2:     # continuity with rounds 2-3, which priced these kernels against the six-product ceiling
+                row["frac_of_bf16x3_ceiling"] = round(ach / MFMA_BF16X3_PEAK_TF, 4)
         if name == "emb_linear_fwd_L0":      # K3 fused into the first layer's GEMM: priced on the MFMA side, its HBM side stated too
             # bytes this kernel MUST move: ids + table rows + first-order weights + dense features in, layer output + sum_x + fm_logit
             # out (+ the gathered embeddings only when `concat` is still stored, DR_NO_CONCAT=0).  SURVEY section 8(d)'s K3 figure
@@ -576,7 +585,9 @@ def main():
             if k["bound"] == "hbm":
                 ideal_us += k["alg_bytes"] / (HBM_PEAK_GBS * 1e9) * 1e6
             else:
-                ideal_us += k["alg_flops"] / ((MFMA_BF16X3_PEAK_TF if a.gemm == "bf16x3" else MFMA_F32_PEAK_TF) * 1e12) * 1e6
+                pk = MFMA_F16X2_PEAK_TF if (a.gemm == "bf16x3" and getattr(eng, "h2", False) and nm_ in H2_KERNELS) else \
+                    (MFMA_BF16X3_PEAK_TF if a.gemm == "bf16x3" else MFMA_F32_PEAK_TF)
+                ideal_us += k["alg_flops"] / (pk * 1e12) * 1e6
         roof_pairs.append({"kernels": pr["kernels"], "joint_us": round(pr["joint_us"], 2), "roofline_sum_us": round(ideal_us, 2),
                            "frac": round(ideal_us / pr["joint_us"], 4)})
     solo = [r for r in roof_all if "concurrent_with" not in r]
@@ -672,7 +683,11 @@ def main():
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong" if a.global_batch else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload,
-                       "gemm_products": ("fp32 in / fp32 accumulate; products = 6 bf16 MFMA products of exact 3-way bf16 splits (error vs fp64 <= native fp32 MFMA, tests/test_gpu_kernels.py)"
+                       "gemm_products": (("fp32 in / fp32 accumulate; first layer's three GEMMs: 3 fp16 MFMA products of two-term fp16 splits of x * 2^k, "
+                                          "k per tensor from its amax record (f16x2 mode; error vs fp64 <= the bf16x3 mode's, tests/test_gpu_h2_gemm.py); "
+                                          "other wide GEMMs: 6 bf16 MFMA products of exact 3-way bf16 splits")
+                                         if (a.gemm == "bf16x3" and getattr(eng, "h2", False)) else
+                                         "fp32 in / fp32 accumulate; products = 6 bf16 MFMA products of exact 3-way bf16 splits (error vs fp64 <= native fp32 MFMA, tests/test_gpu_kernels.py)"
                                          if a.gemm == "bf16x3" else "native v_mfma_f32_32x32x2_f32"),
                        "global_batch": a.batch * world, "parallelism": par, "final_loss": round(loss, 6),
                        "per_kernel_events": prof is not None, "per_kernel_events_every_n_steps": ev_every if prof is not None else None},

@@ -31,7 +31,7 @@ SIGNATURES = {
     "dr_emb_pool_bwd_sorted_adam": [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _i64, _p, _i64, _p, _p, _p, _f32, _f32,
                                     _f32, _f32, _p, _p, _p, _p, _p, _p, _p, _p],
     "dr_emb_pool_bwd_sorted_adam_ex": [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _i64, _p, _i64, _p, _p, _p, _f32, _f32,
-                                    _f32, _f32, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+                                    _f32, _f32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "dr_adam_step": [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _p],
     "dr_ftrl_step": [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _p],
     "dr_linear_bwd_dw_workspace_bytes": [_i64, _i32, _i32],
@@ -41,6 +41,7 @@ SIGNATURES = {
                               _p, _i64, _p, _p, _p, _i64, _p, _p, _i64, _p],
     "dr_linear_bwd_narrow": [_p, _i64, _p, _i64, _p, _i64, _i64, _i32, _i32, _i32, _f32, _p, _i64, _p, _p, _i64, _p, _i64, _p],
     "dr_linear_bwd_narrow_parts": [_p, _i64, _p, _i64, _p, _i64, _i64, _i32, _i32, _i32, _f32, _p, _i64, _p, _p, _i64, _p, _i64, _i32, _p],
+    "dr_linear_bwd_narrow_amax": [_p, _i64, _p, _i64, _p, _i64, _i64, _i32, _i32, _i32, _f32, _p, _i64, _p, _p, _i64, _p, _i64, _i32, _p, _p],
     "dr_tower_head_fwd_bwd_parts": [_p, _i64, _p, _i64, _p, _i64, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _p, _i32, _f32, _p, _i64, _p,
                                     _p, _i64, _p, _p, _p, _i64, _p, _p, _i64, _i32, _p],
     "dr_cross_fwd": [_p, _p, _i64, _p, _i64, _p, _f32, _i64, _i32, _p, _p, _p],
@@ -67,7 +68,7 @@ SIGNATURES = {
     "dr_emb_pool_bwd_sorted_parts": [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _i64, _p, _i64, _p, _p, _p, _f32, _p, _p,
                                      _p, _p, _i32, _p],
     "dr_emb_pool_bwd_sorted_ex": [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _i64, _p, _i64, _p, _p, _p, _f32, _p, _p,
-                                  _p, _p, _p, _i32, _p],
+                                  _p, _p, _p, _i32, _p, _p],
     "dr_emb_lin_update_unique": [_p, _p, _i64, _i32, _p, _p, _p, _f32, _p, _p],
     "dr_emb_snapshot_sorted_rows": [_p, _p, _p, _p, _i32, _i64, _p, _p],
     "dr_ids_transpose_i32": [_p, _i64, _i32, _p, _p],
@@ -108,6 +109,13 @@ SIGNATURES = {
     "dr_bf3_wgrad_emb_parts": [_p, _i64, _i32, _p, _p, _i32, _p, _p, _i64, _i32, _i32, _f32, _p, _i64, _p, _p, _i64, _i32, _p],
     "dr_bf3_gemm_tn_workspace_bytes": [_i64, _i32, _i32],
     "dr_bf3_gemm_tn": [_p, _i64, _i64, _p, _i64, _i64, _i64, _i32, _i32, _f32, _p, _i64, _p, _p, _p, _i64, _p],
+    "dr_h2_amax": [_p, _i64, _i64, _i32, _p, _i32, _p],
+    "dr_h2_split": [_p, _i64, _i64, _i32, _p, _i64, _i64, _i64, _i64, _i32, _p, _p],
+    "dr_h2_linear_nt": [_p, _i64, _p, _p, _i64, _i64, _p, _i64, _i32, _i32, _p, _i32, _p, _i64, _i32, _p, _i64, _p],
+    "dr_h2_emb_linear_fwd": [_p, _i64, _i32, _p, _i64, _p, _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _p, _i64, _i64, _p, _i32, _p, _i32,
+                             _p, _p, _p, _i64, _p, _p],
+    "dr_h2_wgrad": [_p, _i64, _p, _p, _i64, _p, _i64, _i32, _i32, _f32, _p, _i64, _p, _p, _i64, _p],
+    "dr_h2_wgrad_emb": [_p, _i64, _i32, _p, _p, _i32, _p, _p, _p, _p, _i64, _p, _i32, _i32, _f32, _p, _i64, _p, _p, _i64, _i32, _p],
     "dr_cin_fwd": [_p, _p, _i64, _i32, _i32, _i32, _p, _i32, _p, _i32, _p, _p],
     "dr_cin_bwd": [_p, _p, _i64, _i32, _i32, _i32, _p, _i32, _i32, _p, _p, _p, _p, _p, _p, _p],
     "dr_din_concat_fwd": [_p, _p, _i64, _i32, _i32, _p, _i64, _p],

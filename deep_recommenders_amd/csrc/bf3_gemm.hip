@@ -538,7 +538,43 @@ struct RsArgs {
     //   pack_lin[pack_pos] = pack_dl[m]                                                           (iff pack_lin != nullptr)
     // columns >= 64 pack_F (dense features) are computed and dropped.  xin / ldx: the concatenated embeddings of the forward.
     const int64_t* pack_pos; int32_t pack_F; const float* pack_dl; const float* pack_sumx; float* pack_lin;
+    // f16x2 mode (H2 kernels only): the amax records of A and of the tensor B's two planes were split from
+    const uint32_t* a_amax; const uint32_t* b_amax;
 };
+
+// ---------------------------------------------------------------------------------------------------------------------
+// "f16x2" operand mode (H2 = 1 in the register-split kernels; round 4): every fp32 value, multiplied by a power-of-two scale s of
+// its TENSOR, is carried as two fp16 terms  x s = h + l,  h = f16_rn(x s),  l = f16_rn(x s - h)  (22 significant bits; the
+// subtraction is exact), and a product is formed as  h_a l_b + l_a h_b + h_a h_b  -- THREE MFMAs (v_mfma_f32_32x32x16_f16, same
+// shape and rate as the bf16 one) where the bf16x3 mode needs six; the dropped l_a l_b is below 2^-22 |ab|.  fp16 has 5 exponent
+// bits, hence the scale: s = 2^(140 - e) with e the biased exponent of the tensor's largest magnitude (an `amax record`: one
+// uint32 holding max |x| as float bits, maintained by the tensor's PRODUCER with atomicMax -- dr_h2_amax, K4, the tower tail --
+// or an upper bound of it), so that |x s| < 2^14: a factor 4 below fp16's largest finite value (a bound that is stale by less
+// than that cannot overflow; beyond it FP16_OVFL, set at kernel entry, clamps instead of producing inf).  Elements more than
+// 2^-17 below the tensor's largest carry fewer than 22 bits in l (subnormal); their absolute error is 2^-39 of the largest.
+// The epilogue multiplies the accumulator by 1 / (s_a s_b) -- exact.  Accuracy against fp64: tests/test_gpu_h2_gemm.py.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void h2_scale_of(uint32_t amax_bits, float& s, float& inv) {
+    int e = (int)((amax_bits >> 23) & 0xffu);                           // max |x| < 2^(e - 126)
+    e = e < 20 ? 20 : (e > 250 ? 250 : e);                              // (all-zero / denormal tensors: any scale works)
+    s = __uint_as_float((uint32_t)(267 - e) << 23);                     // 2^(140 - e)
+    inv = __uint_as_float((uint32_t)(e - 13) << 23);                    // 2^(e - 140)
+}
+__device__ __forceinline__ void h2_mode_on() { __builtin_amdgcn_s_setreg(1 | (23 << 6), 1); }   // MODE.FP16_OVFL: clamp, no inf
+
+__device__ __forceinline__ void h2_split8(const float4& lo, const float4& hi4, float s, bf16x8& p0, bf16x8& p1) {
+    const f32x8 v = f32x8{lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w} * s;
+    const f16x8 h = __builtin_convertvector(v, f16x8);
+    const f32x8 r = v - __builtin_convertvector(h, f32x8);
+    const f16x8 l = __builtin_convertvector(r, f16x8);
+    p0 = __builtin_bit_cast(bf16x8, h);
+    p1 = __builtin_bit_cast(bf16x8, l);
+}
+__device__ __forceinline__ f32x16 h2_mfma(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
 
 __device__ __forceinline__ void rs_split8(const float4& lo, const float4& hi4, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
     bf16x4 a0, a1, a2, b0, b1, b2;
@@ -558,14 +594,18 @@ __device__ __forceinline__ void rs_split8(const float4& lo, const float4& hi4, b
 // CS: column split of the tile between waves.  CS = 2 (with MS = 2): 8 waves again, wave w owns rows 64 (w & 3) .. + 63 and column tiles
 // 4 (w >> 2) .. + 3 -- the same 128 accumulator registers as the default and two waves per SIMD, but half the fragment reads per
 // MFMA; the price is that each activation row is loaded and split by two waves (w and w + 4: one SIMD, one L1).
-template <int EPI, int DBG = 0, int MS = 1, int CS = 1>
+// H2: the f16x2 operand mode (see h2_split8 above): B holds TWO fp16 planes (32 KB stages, 4 pieces per wave and k-tile), three MFMAs
+// per fragment pair.
+template <int EPI, int DBG = 0, int MS = 1, int CS = 1, int H2 = 0>
 __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_kernel(RsArgs g) {
     constexpr int NW = 8 * CS / MS, RGW = NW / CS, BM = 32 * MS * RGW, BN = 256, NT = BN / 32, NTW = NT / CS, NS = 3;
     static_assert(CS == 1 || (CS == 2 && MS == 2), "column split only with 64-row waves");
-    constexpr int B_PLANE = BN * 64;                                    // bytes: 256 rows x 64-byte rows (32 bf16)
-    constexpr int STAGE = 3 * B_PLANE;                                  // 48 KB
-    constexpr int PW = STAGE / 1024 / NW;                               // 6 MS LDS-DMA pieces per wave and k-tile
-    static_assert(PW * NW == 48 && (MS == 1 || MS == 2), "piece schedule below assumes 48 / NW pieces per wave and k-tile");
+    static_assert(!H2 || (MS == 1 && CS == 1 && (EPI == 0 || EPI == 1 || EPI == 3)), "f16x2: default shape, plain epilogues");
+    constexpr int NPL = H2 ? 2 : 3;                                     // operand planes
+    constexpr int B_PLANE = BN * 64;                                    // bytes: 256 rows x 64-byte rows (32 bf16 / fp16)
+    constexpr int STAGE = NPL * B_PLANE;                                // 48 KB (32 KB)
+    constexpr int PW = STAGE / 1024 / NW;                               // 6 MS (4) LDS-DMA pieces per wave and k-tile
+    static_assert(PW * NW == 16 * NPL && (MS == 1 || MS == 2), "piece schedule below assumes 16 NPL / NW pieces per wave and k-tile");
     constexpr int VM_STEP = 4 * MS + PW;                                // VMEM operations of one step (A loads + pieces)
     constexpr int VM_WAIT_STEP = 0x0F70 | (VM_STEP & 15) | ((VM_STEP >> 4) << 14);   // s_waitcnt vmcnt(VM_STEP) (6-bit field, split)
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE];
@@ -609,7 +649,15 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
     // treats the FLAT-encoded form as "may touch LDS through flat" and from then on waits vmcnt(0) for every VMEM result,
     // the buffer form is counted exactly (a register load followed by 6 pieces gets vmcnt(6)).
     const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<__bf16*>(g.B), 0, (int)min((int64_t)0x7fffffff, 3 * g.b_ps * 2), 0x00020000);
+        const_cast<__bf16*>(g.B), 0, (int)min((int64_t)0x7fffffff, NPL * g.b_ps * 2), 0x00020000);
+    float h2_sa = 1.f, h2_out = 1.f;                                    // H2: A's scale, 1 / (s_a s_b)
+    if constexpr (H2) {
+        float ia, sb, ib;
+        h2_scale_of(g.a_amax[0], h2_sa, ia);
+        h2_scale_of(g.b_amax[0], sb, ib);
+        h2_out = ia * ib;
+        h2_mode_on();
+    }
     int bvoff[12];                                                      // per-lane byte offset of piece i < PW at k = 0 (arrays the
                                                                         // lambdas capture have FIXED sizes: with a template-dependent size
                                                                         // hipcc silently drops the kernel's host stub)
@@ -719,7 +767,7 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
 #define RS_READ3(NTI)                                                        \
         BF3_DS_READ_B128(fb[buf][0], bb, 0 * B_PLANE + NTI * 2048);          \
         BF3_DS_READ_B128(fb[buf][1], bb, 1 * B_PLANE + NTI * 2048);          \
-        BF3_DS_READ_B128(fb[buf][2], bb, 2 * B_PLANE + NTI * 2048);
+        if constexpr (!(DBG & 256) && !H2) BF3_DS_READ_B128(fb[buf][2], bb, 2 * B_PLANE + NTI * 2048);
         switch (nt) {
             case 0: RS_READ3(0) break; case 1: RS_READ3(1) break; case 2: RS_READ3(2) break; case 3: RS_READ3(3) break;
             case 4: RS_READ3(4) break; case 5: RS_READ3(5) break; case 6: RS_READ3(6) break; default: RS_READ3(7) break;
@@ -728,7 +776,13 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
     };
     auto wait_b = [&](int buf, bool all) {   // group's fragments landed; `all`: every LDS read of this wave retired
         if constexpr (DBG & 32) return;
+        if constexpr (H2) {
+            if (all) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[buf][0]), "+v"(fb[buf][1]));
+            else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fb[buf][0]), "+v"(fb[buf][1]));   // the next group's 2 may fly
+            return;
+        }
         if (all) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[buf][0]), "+v"(fb[buf][1]), "+v"(fb[buf][2]));
+        else if constexpr (DBG & 256) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fb[buf][0]), "+v"(fb[buf][1]), "+v"(fb[buf][2]));
         else asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fb[buf][0]), "+v"(fb[buf][1]), "+v"(fb[buf][2]));   // the next group's 3 may fly
     };
     f32x16 acc[MS][NTW];
@@ -770,6 +824,9 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl)
                         fa[ms][s2][pl] = __builtin_bit_cast(bf16x8, an[ms][2 * s2 + (pl & 1)]);
+            } else if constexpr (H2) {
+                h2_split8(an[ms][0], an[ms][1], h2_sa, fa[ms][0][0], fa[ms][0][1]);
+                h2_split8(an[ms][2], an[ms][3], h2_sa, fa[ms][1][0], fa[ms][1][1]);
             } else {
                 rs_split8(an[ms][0], an[ms][1], fa[ms][0][0], fa[ms][0][1], fa[ms][0][2]);
                 rs_split8(an[ms][2], an[ms][3], fa[ms][1][0], fa[ms][1][1], fa[ms][1][2]);
@@ -826,11 +883,17 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
                 if (has_a) read_b(1, nstage, 1);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!(DBG & 2)) {
+            if constexpr (H2) {
+                // smallest terms first: h_a l_b, l_a h_b, h_a h_b
+                acc[0][q & 7] = h2_mfma(fa[0][q >> 3][0], fb[q & 3][1], acc[0][q & 7]);
+                acc[0][q & 7] = h2_mfma(fa[0][q >> 3][1], fb[q & 3][0], acc[0][q & 7]);
+                acc[0][q & 7] = h2_mfma(fa[0][q >> 3][0], fb[q & 3][0], acc[0][q & 7]);
+            } else if constexpr (!(DBG & 2)) {
                 // (MS == 2: the two row sets' chains interleaved or one after the other -- fenced, or the machine scheduler re-interleaves
                 // them -- measure the same)
+                // (DBG & 128, ablation only: THREE products per fragment pair -- what a two-plane fp16 split would issue)
 #pragma unroll
-                for (int term = 0; term < 6; ++term)
+                for (int term = (DBG & 128) ? 3 : 0; term < 6; ++term)
 #pragma unroll
                     for (int ms = 0; ms < MS; ++ms)
                         acc[ms][q & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ms][q >> 3][PA[term]], fb[q & 3][PB[term]],
@@ -983,7 +1046,7 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const int reg = 4 * c4 + e;
-                                float v = acc[ms][nt][reg] + bj;
+                                float v = H2 ? fmaf(acc[ms][nt][reg], h2_out, bj) : acc[ms][nt][reg] + bj;
                                 acc[ms][nt][reg] = 0.f;
                                 v = relu ? fmaxf(v, 0.f) : v;
                                 crow[(int64_t)(e + 8 * c4) * g.ldc] = EPI == 1 ? (aux[e] > 0.f ? v : 0.f) : aux[e] + v;
@@ -992,7 +1055,7 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
                     } else {
 #pragma unroll
                         for (int reg = 0; reg < 16; ++reg) {
-                            float v = acc[ms][nt][reg] + bj;
+                            float v = H2 ? fmaf(acc[ms][nt][reg], h2_out, bj) : acc[ms][nt][reg] + bj;
                             acc[ms][nt][reg] = 0.f;
                             if (DR_NT_DGRAD_STORE && EPI == 0) __builtin_nontemporal_store(relu ? fmaxf(v, 0.f) : v, &crow[(int64_t)((reg & 3) + 8 * (reg >> 2)) * g.ldc]);
                             else crow[(int64_t)((reg & 3) + 8 * (reg >> 2)) * g.ldc] = relu ? fmaxf(v, 0.f) : v;
@@ -1002,7 +1065,7 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         const int64_t row = r0 + (reg & 3) + 8 * (reg >> 2);
-                        float v = acc[ms][nt][reg] + bj;
+                        float v = H2 ? fmaf(acc[ms][nt][reg], h2_out, bj) : acc[ms][nt][reg] + bj;
                         acc[ms][nt][reg] = 0.f;
                         if (!cv || row >= g.M) continue;
                         float* dst = g.C + row * g.ldc + col;
@@ -1077,6 +1140,7 @@ struct EmbArgs {
     float* sum_x; float* fm_logit;               // out: [M, 64], [M]
     float* lin_vals;                             // out (may be null): [F, M] field-major, the first-order weight every slot read -- K4
                                                  // then only WRITES lin_w[row] (one line operation per slot instead of two; round 4)
+    const uint32_t* dense_amax;                  // f16x2 mode: amax record of dense_pad (null: none); the table's is RsArgs::a_amax
 };
 
 __device__ __forceinline__ int sload_i32(const void* base, int byte_off) {      // scalar load of a wave-uniform word, on the spot
@@ -1085,14 +1149,18 @@ __device__ __forceinline__ int sload_i32(const void* base, int byte_off) {      
     return v;
 }
 
+// H2: the f16x2 operand mode (h2_split8): two fp16 weight planes (32 KB stages, 4 pieces per wave and k-tile), three MFMAs per
+// fragment pair; the activation scale comes from the larger of the table's and the dense features' amax records.
+template <int H2>
 __global__ __launch_bounds__(512, 2) void bf3_emb_linear_kernel(RsArgs g, EmbArgs e) {
     constexpr int NW = 8, BM = 32 * NW, BN = 256, NT = BN / 32, NS = 2;
-    constexpr int B_PLANE = BN * 64;                                    // bytes: 256 rows x 64-byte rows (32 bf16)
-    constexpr int STAGE = 3 * B_PLANE;                                  // 48 KB
-    constexpr int PW = STAGE / 1024 / NW;                               // 6 LDS-DMA pieces per wave and k-tile
+    constexpr int NPL = H2 ? 2 : 3;
+    constexpr int B_PLANE = BN * 64;                                    // bytes: 256 rows x 64-byte rows (32 bf16 / fp16)
+    constexpr int STAGE = NPL * B_PLANE;                                // 48 KB (32 KB)
+    constexpr int PW = STAGE / 1024 / NW;                               // 6 (4) LDS-DMA pieces per wave and k-tile
     constexpr int A_WAVE = 32 * 128, A_STAGE = NW * A_WAVE;             // 4 KB per wave, 32 KB per stage
     constexpr int A_BASE = NS * STAGE;
-    static_assert(PW == 6, "piece schedule below assumes 6 pieces per wave and k-tile");
+    static_assert(PW == 2 * NPL, "piece schedule below assumes 2 pieces per plane, wave and k-tile");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE + 2 * A_STAGE];
     typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -1121,7 +1189,15 @@ __global__ __launch_bounds__(512, 2) void bf3_emb_linear_kernel(RsArgs g, EmbArg
     const unsigned a_st = lds0 + A_BASE + wave * A_WAVE + lane * 16;                                    // position 64 i + lane
 
     const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<__bf16*>(g.B), 0, (int)min((int64_t)0x7fffffff, 3 * g.b_ps * 2), 0x00020000);
+        const_cast<__bf16*>(g.B), 0, (int)min((int64_t)0x7fffffff, NPL * g.b_ps * 2), 0x00020000);
+    float h2_sa = 1.f, h2_out = 1.f;                                    // H2: the activations' scale, 1 / (s_a s_b)
+    if constexpr (H2) {
+        float ia, sb, ib;
+        h2_scale_of(max(g.a_amax[0], e.dense_amax != nullptr ? e.dense_amax[0] : 0u), h2_sa, ia);
+        h2_scale_of(g.b_amax[0], sb, ib);
+        h2_out = ia * ib;
+        h2_mode_on();
+    }
     // (the table resource is built per FIELD, base = its first row: a buffer offset -- index x stride included -- is 32 bits
     // wide, so one resource reaches 4 GB = 2^24 rows; a resource over the whole 66 GB slab wraps, measured)
     const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -1195,7 +1271,7 @@ __global__ __launch_bounds__(512, 2) void bf3_emb_linear_kernel(RsArgs g, EmbArg
 #define RS_READ3(NTI)                                                        \
         BF3_DS_READ_B128(fb[buf][0], bb, 0 * B_PLANE + NTI * 2048);          \
         BF3_DS_READ_B128(fb[buf][1], bb, 1 * B_PLANE + NTI * 2048);          \
-        BF3_DS_READ_B128(fb[buf][2], bb, 2 * B_PLANE + NTI * 2048);
+        if constexpr (!H2) BF3_DS_READ_B128(fb[buf][2], bb, 2 * B_PLANE + NTI * 2048);
         switch (nt) {
             case 0: RS_READ3(0) break; case 1: RS_READ3(1) break; case 2: RS_READ3(2) break; case 3: RS_READ3(3) break;
             case 4: RS_READ3(4) break; case 5: RS_READ3(5) break; case 6: RS_READ3(6) break; default: RS_READ3(7) break;
@@ -1203,7 +1279,8 @@ __global__ __launch_bounds__(512, 2) void bf3_emb_linear_kernel(RsArgs g, EmbArg
 #undef RS_READ3
     };
     auto wait_b = [&](int buf) {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[buf][0]), "+v"(fb[buf][1]), "+v"(fb[buf][2]));
+        if constexpr (H2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[buf][0]), "+v"(fb[buf][1]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[buf][0]), "+v"(fb[buf][1]), "+v"(fb[buf][2]));
     };
     f32x16 acc[NT];
     constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
@@ -1276,6 +1353,9 @@ __global__ __launch_bounds__(512, 2) void bf3_emb_linear_kernel(RsArgs g, EmbArg
             }
         }
         // ("memory": the gather DMA that refills this A stage further down must not be moved above these reads)
+        if constexpr (H2)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(an[0]), "+v"(an[1]), "+v"(an[2]), "+v"(an[3]), "+v"(fb[0][0]), "+v"(fb[0][1]) :: "memory");
+        else
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(an[0]), "+v"(an[1]), "+v"(an[2]), "+v"(an[3]), "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2])
                      :: "memory");
         if (gathered && mo_cur) {
@@ -1304,8 +1384,13 @@ __global__ __launch_bounds__(512, 2) void bf3_emb_linear_kernel(RsArgs g, EmbArg
         {
             const float4 a0 = make_float4(an[0][0], an[0][1], an[0][2], an[0][3]), a1 = make_float4(an[1][0], an[1][1], an[1][2], an[1][3]);
             const float4 a2 = make_float4(an[2][0], an[2][1], an[2][2], an[2][3]), a3 = make_float4(an[3][0], an[3][1], an[3][2], an[3][3]);
-            rs_split8(a0, a1, fa[0][0], fa[0][1], fa[0][2]);
-            rs_split8(a2, a3, fa[1][0], fa[1][1], fa[1][2]);
+            if constexpr (H2) {
+                h2_split8(a0, a1, h2_sa, fa[0][0], fa[0][1]);
+                h2_split8(a2, a3, h2_sa, fa[1][0], fa[1][1]);
+            } else {
+                rs_split8(a0, a1, fa[0][0], fa[0][1], fa[0][2]);
+                rs_split8(a2, a3, fa[1][0], fa[1][1], fa[1][2]);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         const int nstage = stage ^ 1;
@@ -1324,9 +1409,15 @@ __global__ __launch_bounds__(512, 2) void bf3_emb_linear_kernel(RsArgs g, EmbArg
                 if (step + 1 < total) read_b(0, nstage, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (H2) {
+                acc[q & 7] = h2_mfma(fa[q >> 3][0], fb[q & 1][1], acc[q & 7]);
+                acc[q & 7] = h2_mfma(fa[q >> 3][1], fb[q & 1][0], acc[q & 7]);
+                acc[q & 7] = h2_mfma(fa[q >> 3][0], fb[q & 1][0], acc[q & 7]);
+            } else {
 #pragma unroll
             for (int term = 0; term < 6; ++term)
                 acc[q & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q >> 3][PA[term]], fb[q & 1][PB[term]], acc[q & 7], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);    // keeps the next group's lgkmcnt wait from being hoisted between these MFMAs
             if (q < PW) {
                 issue_b(q, kt1, n01, nstage);                           // weight pieces of step + 1 (a dummy re-fetch at the end of the stream)
@@ -1395,7 +1486,7 @@ __global__ __launch_bounds__(512, 2) void bf3_emb_linear_kernel(RsArgs g, EmbArg
                     float* crow = g.C + r0 * g.ldc + col;
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
-                        float v = acc[nt][reg] + bj;
+                        float v = H2 ? fmaf(acc[nt][reg], h2_out, bj) : acc[nt][reg] + bj;
                         acc[nt][reg] = 0.f;
                         crow[(int64_t)((reg & 3) + 8 * (reg >> 2)) * g.ldc] = relu ? fmaxf(v, 0.f) : v;
                     }
@@ -1403,7 +1494,7 @@ __global__ __launch_bounds__(512, 2) void bf3_emb_linear_kernel(RsArgs g, EmbArg
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         const int64_t row = r0 + (reg & 3) + 8 * (reg >> 2);
-                        float v = acc[nt][reg] + bj;
+                        float v = H2 ? fmaf(acc[nt][reg], h2_out, bj) : acc[nt][reg] + bj;
                         acc[nt][reg] = 0.f;
                         if (!cv || row >= g.M) continue;
                         g.C[row * g.ldc + col] = relu ? fmaxf(v, 0.f) : v;
@@ -1468,17 +1559,26 @@ struct TnRsArgs {
     // element (c & 63) of table row row_base[c >> 6] + ids_t[c >> 6][r] (zero for a missing id), columns [64 nf, F) come from
     // dense_pad[r][c - 64 nf]
     const int32_t* ids_t; const int64_t* row_base; const float* table; int32_t nf; const float* dense_pad;
+    // f16x2 mode: amax records of x (GATHER: the table's; x2 = the dense features', may be null) and of dy
+    const uint32_t* x_amax; const uint32_t* x2_amax; const uint32_t* y_amax;
 };
 
 __device__ __forceinline__ void rs_split8v(const float (&v)[8], bf16x8& p0, bf16x8& p1, bf16x8& p2) {
     rs_split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), p0, p1, p2);
 }
 
-template <int GATHER>
+__device__ __forceinline__ void h2_split8v(const float (&v)[8], float s, bf16x8& p0, bf16x8& p1) {
+    h2_split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), s, p0, p1);
+}
+
+// H2: the f16x2 operand mode (h2_split8): both operands split into two fp16 terms with their tensors' scales; the partials carry
+// s_x s_y and the reduce kernel divides it out.
+template <int GATHER, int H2 = 0>
 __global__ __launch_bounds__(512, 2) void bf3_gemm_tn_rs_kernel(TnRsArgs g) {
     constexpr int NW = 8, BMF = 32 * NW, BN = 256, NT = BN / 32;
+    constexpr int NPL = H2 ? 2 : 3;
     constexpr int B_PLANE = BN * 64;                                    // bytes: 256 n-rows x 64 bytes (32 r)
-    constexpr int STAGE = 3 * B_PLANE;                                  // 48 KB
+    constexpr int STAGE = NPL * B_PLANE;                                // 48 KB (32 KB)
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1495,6 +1595,13 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_tn_rs_kernel(TnRsArgs g) {
     if (r_end > g.R) r_end = g.R;
     const int nk = (int)((r_end - r_begin + BK - 1) / BK);              // >= 1 by construction of split
     const bool want_cs = g.colsum != nullptr && f0 == 0;
+    float h2_sx = 1.f, h2_sy = 1.f;
+    if constexpr (H2) {
+        float inv;
+        h2_scale_of(max(g.x_amax[0], g.x2_amax != nullptr ? g.x2_amax[0] : 0u), h2_sx, inv);
+        h2_scale_of(g.y_amax[0], h2_sy, inv);
+        h2_mode_on();
+    }
 
     // this lane's columns (clamped: columns past the edge only feed outputs nobody reads)
     const int fcol = min(f0 + wave * 32 + l31, g.F - 1);
@@ -1594,11 +1701,12 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_tn_rs_kernel(TnRsArgs g) {
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) { v[j] = yb[8 * s + j]; cs += v[j]; }
-            rs_split8v(v, p0, p1, p2);
+            if constexpr (H2) h2_split8v(v, h2_sy, p0, p1);
+            else rs_split8v(v, p0, p1, p2);
             unsigned char* w = wrow + stage * STAGE + (((2 * hi + s) ^ sw) << 4);
             *reinterpret_cast<bf16x8*>(w) = p0;
             *reinterpret_cast<bf16x8*>(w + B_PLANE) = p1;
-            *reinterpret_cast<bf16x8*>(w + 2 * B_PLANE) = p2;
+            if constexpr (!H2) *reinterpret_cast<bf16x8*>(w + 2 * B_PLANE) = p2;
         }
     };
     auto read_b = [&](int buf, int stage, int q) {
@@ -1607,7 +1715,7 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_tn_rs_kernel(TnRsArgs g) {
 #define RS_READ3(NTI)                                                        \
         BF3_DS_READ_B128(fb[buf][0], bb, 0 * B_PLANE + NTI * 2048);          \
         BF3_DS_READ_B128(fb[buf][1], bb, 1 * B_PLANE + NTI * 2048);          \
-        BF3_DS_READ_B128(fb[buf][2], bb, 2 * B_PLANE + NTI * 2048);
+        if constexpr (!H2) BF3_DS_READ_B128(fb[buf][2], bb, 2 * B_PLANE + NTI * 2048);
         switch (nt) {
             case 0: RS_READ3(0) break; case 1: RS_READ3(1) break; case 2: RS_READ3(2) break; case 3: RS_READ3(3) break;
             case 4: RS_READ3(4) break; case 5: RS_READ3(5) break; case 6: RS_READ3(6) break; default: RS_READ3(7) break;
@@ -1615,6 +1723,11 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_tn_rs_kernel(TnRsArgs g) {
 #undef RS_READ3
     };
     auto wait_b = [&](int buf, bool all) {
+        if constexpr (H2) {
+            if (all) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[buf][0]), "+v"(fb[buf][1]));
+            else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fb[buf][0]), "+v"(fb[buf][1]));
+            return;
+        }
         if (all) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[buf][0]), "+v"(fb[buf][1]), "+v"(fb[buf][2]));
         else asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fb[buf][0]), "+v"(fb[buf][1]), "+v"(fb[buf][2]));
     };
@@ -1650,7 +1763,8 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_tn_rs_kernel(TnRsArgs g) {
             for (int s = 0; s < 2; ++s) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = (!GATHER || xmask == -1 || ((xmask >> (8 * s + j)) & 1)) ? xa[8 * s + j] : 0.f;
-                rs_split8v(v, fa[s][0], fa[s][1], fa[s][2]);
+                if constexpr (H2) h2_split8v(v, h2_sx, fa[s][0], fa[s][1]);
+                else rs_split8v(v, fa[s][0], fa[s][1], fa[s][2]);
             }
         }
         if (kt + 1 < nk) stage_b(stage ^ 1);
@@ -1680,9 +1794,15 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_tn_rs_kernel(TnRsArgs g) {
                 if (kt + 1 < nk) read_b(1, stage ^ 1, 1);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (H2) {
+                acc[q & 7] = h2_mfma(fa[q >> 3][0], fb[q & 3][1], acc[q & 7]);
+                acc[q & 7] = h2_mfma(fa[q >> 3][1], fb[q & 3][0], acc[q & 7]);
+                acc[q & 7] = h2_mfma(fa[q >> 3][0], fb[q & 3][0], acc[q & 7]);
+            } else {
 #pragma unroll
             for (int term = 0; term < 6; ++term)
                 acc[q & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q >> 3][PA[term]], fb[q & 3][PB[term]], acc[q & 7], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -1702,9 +1822,18 @@ __global__ __launch_bounds__(512, 2) void bf3_gemm_tn_rs_kernel(TnRsArgs g) {
 __global__ __launch_bounds__(256) void bf3_tn_rs_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ colsum,
                                                                int32_t split, int32_t F, int32_t N, int32_t Fp, int32_t Np,
                                                                float scale, float* __restrict__ dst, int64_t ld,
-                                                               float* __restrict__ dstb) {
+                                                               float* __restrict__ dstb, const uint32_t* __restrict__ x_amax = nullptr,
+                                                               const uint32_t* __restrict__ x2_amax = nullptr,
+                                                               const uint32_t* __restrict__ y_amax = nullptr) {
     const int64_t total = (int64_t)F * N, stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t ps = (int64_t)Fp * Np;
+    float wscale = scale;                                               // f16x2 partials carry s_x s_y (powers of two: exact)
+    if (x_amax != nullptr) {
+        float sx, ix, sy, iy;
+        h2_scale_of(max(x_amax[0], x2_amax != nullptr ? x2_amax[0] : 0u), sx, ix);
+        h2_scale_of(y_amax[0], sy, iy);
+        wscale = scale * (ix * iy);
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const int64_t f = i / N;
         const int n = (int)(i - f * N);
@@ -1716,7 +1845,7 @@ __global__ __launch_bounds__(256) void bf3_tn_rs_reduce_kernel(const float* __re
             acc = (((acc + v0) + v1) + v2) + v3;
         }
         for (; s < split; ++s) acc += p[s * ps];
-        dst[f * ld + n] = fmaf(scale, acc, dst[f * ld + n]);
+        dst[f * ld + n] = fmaf(wscale, acc, dst[f * ld + n]);
     }
     if (blockIdx.x == 0 && colsum != nullptr && dstb != nullptr)
         for (int n = threadIdx.x; n < N; n += blockDim.x) {
@@ -1983,6 +2112,58 @@ __global__ __launch_bounds__(256) void bf3_split_kernel(const float* __restrict_
     }
 }
 
+// ---- f16x2 mode: amax records and the weight split ---------------------------------------------------------------------------
+// amax[0] = max(amax[0], max |src|) as float bits (non-negative floats order like their bit patterns; a NaN lands above inf)
+__global__ __launch_bounds__(256) void h2_amax_kernel(const float* __restrict__ src, int64_t ld, int64_t R, int32_t C,
+                                                      uint32_t* __restrict__ amax) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    uint32_t m = 0u;
+    if ((C & 3) == 0 && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const int cq = C >> 2;
+        const int64_t total = R * cq;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+            const int64_t r = i / cq;
+            const float4 v = *reinterpret_cast<const float4*>(src + r * ld + (i - r * cq) * 4);
+            m = max(max(m, __float_as_uint(fabsf(v.x))), max(__float_as_uint(fabsf(v.y)), max(__float_as_uint(fabsf(v.z)), __float_as_uint(fabsf(v.w)))));
+        }
+    } else {
+        const int64_t total = R * C;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+            const int64_t r = i / C;
+            m = max(m, __float_as_uint(fabsf(src[r * ld + (i - r * C)])));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    __shared__ uint32_t wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+        if (m != 0u) atomicMax(amax, m);
+    }
+}
+
+// fp32 [R][C] * s -> two fp16 planes; planes[p][r0 + r][c0 + c] (transpose = 0) or planes[p][r0 + c][c0 + r] (transpose = 1); s from the record
+__global__ __launch_bounds__(256) void h2_split_kernel(const float* __restrict__ src, int64_t ld_src, int64_t R, int32_t C,
+                                                       _Float16* __restrict__ planes, int64_t ps, int64_t ldp, int64_t r0,
+                                                       int64_t c0, int32_t transpose, const uint32_t* __restrict__ amax) {
+    float sc, inv;
+    h2_scale_of(amax[0], sc, inv);
+    h2_mode_on();
+    const int64_t total = R * C, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        // consecutive threads: consecutive DESTINATION elements (2-byte stores coalesce; the source is small and cached)
+        int64_t r, c, off;
+        if (!transpose) { r = i / C; c = i - r * C; off = (r0 + r) * ldp + c0 + c; }
+        else { c = i / R; r = i - c * R; off = (r0 + c) * ldp + c0 + r; }
+        const float v = src[r * ld_src + c] * sc;
+        const _Float16 h = (_Float16)v;
+        planes[off] = h;
+        planes[ps + off] = (_Float16)(v - (float)h);
+    }
+}
+
 // planes -> fp32 (tests, debugging): dst[r][c] = (p2 + p1) + p0
 __global__ __launch_bounds__(256) void bf3_join_kernel(const __bf16* __restrict__ planes, int64_t ps, int64_t ldp, int64_t R,
                                                        int32_t C, float* __restrict__ dst, int64_t ld_dst) {
@@ -2004,6 +2185,14 @@ int rs_launch(const RsArgs& g, hipStream_t stream) {
     // buys nothing -- so it is opt-in (DR_BF3_STAGGER=1)
     static const bool stg = [] { const char* e = getenv("DR_BF3_STAGGER"); return e != nullptr && e[0] == '1'; }();
     if (g.mask != nullptr && g.accumulate) return DR_EINVAL;            // (no caller needs both)
+    if (g.a_amax != nullptr) {                                          // f16x2 operand mode
+        if (g.b_amax == nullptr || g.tau != nullptr || g.pack_pos != nullptr || g.x0 != nullptr) return DR_EINVAL;
+        if (g.mask != nullptr) hipLaunchKernelGGL((bf3_gemm_rs_kernel<1, 0, 1, 1, 1>), dim3(grid), dim3(512), 0, stream, g);
+        else if (g.accumulate) hipLaunchKernelGGL((bf3_gemm_rs_kernel<3, 0, 1, 1, 1>), dim3(grid), dim3(512), 0, stream, g);
+        else hipLaunchKernelGGL((bf3_gemm_rs_kernel<0, 0, 1, 1, 1>), dim3(grid), dim3(512), 0, stream, g);
+        DR_CHECK_LAUNCH();
+        return DR_OK;
+    }
     if (g.tau != nullptr) {
         hipLaunchKernelGGL((bf3_gemm_rs_kernel<4>), dim3(grid), dim3(512), 0, stream, g);
         DR_CHECK_LAUNCH();
@@ -2026,7 +2215,7 @@ int rs_launch(const RsArgs& g, hipStream_t stream) {
                 DR_CHECK_LAUNCH();                                                                              \
                 return DR_OK;                                                                                   \
             }
-            RS_ABL(32) RS_ABL(64) RS_ABL(96) RS_ABL(2) RS_ABL(1)
+            RS_ABL(32) RS_ABL(64) RS_ABL(96) RS_ABL(2) RS_ABL(1) RS_ABL(128) RS_ABL(384) RS_ABL(448)
 #undef RS_ABL
         }
     }
@@ -2183,6 +2372,51 @@ extern "C" int dr_bf3_linear_nt(const float* A, int64_t lda, const void* b_plane
 }
 
 namespace {
+// ---- f16x2 operand mode (see h2_split8): amax records, the weight split, forward / dgrad on fp32 activations -----------------------
+// amax[0] = max(reset ? 0 : amax[0], max |src[r][c]|) as float bits.  The record of a GEMM operand must be >= its true largest
+// magnitude when the GEMM runs (a producer may keep a running maximum instead of an exact one).
+extern "C" int dr_h2_amax(const float* src, int64_t ld, int64_t R, int32_t C, uint32_t* amax, int32_t reset, dr_stream_t stream) {
+    if (R < 0 || C < 0 || ld < C || !amax) return DR_EINVAL;
+    if (reset && hipMemsetAsync(amax, 0, sizeof(uint32_t), dr_s(stream)) != hipSuccess) return DR_ELAUNCH;
+    if (R == 0 || C == 0) return DR_OK;
+    if (!src) return DR_EINVAL;
+    hipLaunchKernelGGL(h2_amax_kernel, dim3(dr_grid_for(R * ((C + 3) / 4), 256)), dim3(256), 0, dr_s(stream), src, ld, R, C, amax);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+// Two fp16 planes of src * s(amax) -- the layout of dr_bf3_split with two planes instead of three.  The GEMMs that read the planes
+// are handed the same record (unchanged since the split).
+extern "C" int dr_h2_split(const float* src, int64_t ld_src, int64_t R, int32_t C, void* planes, int64_t plane_stride,
+                           int64_t ld_planes, int64_t row_offset, int64_t col_offset, int32_t transpose, const uint32_t* amax,
+                           dr_stream_t stream) {
+    if (R < 0 || C < 0 || ld_src < C || row_offset < 0 || col_offset < 0 || ld_planes <= 0 || plane_stride <= 0 || !amax) return DR_EINVAL;
+    if (R == 0 || C == 0) return DR_OK;
+    if (!src || !planes) return DR_EINVAL;
+    if (!transpose && col_offset + C > ld_planes) return DR_EINVAL;
+    if (transpose && col_offset + R > ld_planes) return DR_EINVAL;
+    hipLaunchKernelGGL(h2_split_kernel, dim3(dr_grid_for(R * (int64_t)C, 256)), dim3(256), 0, dr_s(stream), src, ld_src, R, C,
+                       static_cast<_Float16*>(planes), plane_stride, ld_planes, row_offset, col_offset, transpose, amax);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+// dr_bf3_linear_nt in the f16x2 mode: b_planes = two fp16 planes (dr_h2_split with b_amax), A fp32 with the record a_amax.
+extern "C" int dr_h2_linear_nt(const float* A, int64_t lda, const uint32_t* a_amax, const void* b_planes, int64_t b_plane_stride,
+                               int64_t b_ld, const uint32_t* b_amax, int64_t M, int32_t N, int32_t K, const float* bias, int32_t act,
+                               const float* mask, int64_t ld_mask, int32_t accumulate, float* C, int64_t ldc, dr_stream_t stream) {
+    if (M < 0 || N <= 0 || K <= 0 || act < 0 || act > 1 || !a_amax || !b_amax) return DR_EINVAL;
+    if (M == 0) return DR_OK;
+    if (!A || !C || !planes_ok(b_planes, b_plane_stride, b_ld)) return DR_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(A) & 15) != 0 || (lda & 3) != 0 || lda < K) return DR_EINVAL;
+    if (b_ld < (K + BK - 1) / BK * BK || ldc < N || (mask != nullptr && ld_mask < N)) return DR_EINVAL;
+    RsArgs g{A, lda, static_cast<const __bf16*>(b_planes), b_plane_stride, b_ld, M, N, K, C, ldc, bias, act, mask, ld_mask, accumulate,
+             nullptr, nullptr, 0, 0.f, nullptr};
+    g.a_amax = a_amax;
+    g.b_amax = b_amax;
+    return rs_launch(g, dr_s(stream));
+}
+
 __global__ __launch_bounds__(256) void bf3_pack_bias_kernel(const float* dl, int64_t n, float* bias_sum) {
     dr_block_sum_axpy(dl, n, 1.f, bias_sum);
 }
@@ -2269,9 +2503,9 @@ extern "C" int64_t dr_bf3_wgrad_workspace_bytes(int64_t R, int32_t F, int32_t N)
 
 // dstW[f][n] += scale * sum_r x[r][f] dy[r][n];  dstb[n] += scale * sum_r dy[r][n] (dstb may be NULL).  x [R, F], dy [R, N] fp32
 // row-major; the bf16x3 product mode, deterministic (fixed-order reduce over the reduction slices).
-extern "C" int dr_bf3_wgrad(const float* x, int64_t ld_x, const float* dy, int64_t ld_dy, int64_t R, int32_t F, int32_t N,
-                            float scale, float* dstW, int64_t ld_w, float* dstb, void* workspace, int64_t workspace_bytes,
-                            dr_stream_t stream) {
+static int wgrad_impl(const float* x, int64_t ld_x, const float* dy, int64_t ld_dy, int64_t R, int32_t F, int32_t N,
+                      float scale, float* dstW, int64_t ld_w, float* dstb, void* workspace, int64_t workspace_bytes,
+                      dr_stream_t stream, const uint32_t* x_amax = nullptr, const uint32_t* dy_amax = nullptr) {
     if (R <= 0 || F <= 0 || N <= 0) return DR_EINVAL;
     if (!x || !dy || !dstW || !workspace || ld_x < F || ld_dy < N || ld_w < N) return DR_EINVAL;
     if (workspace_bytes < dr_bf3_wgrad_workspace_bytes(R, F, N)) return DR_EINVAL;
@@ -2280,13 +2514,31 @@ extern "C" int dr_bf3_wgrad(const float* x, int64_t ld_x, const float* dy, int64
     tn_rs_plan(R, F, N, split, per, Fp, Np);
     float* partial = static_cast<float*>(workspace);
     float* colsum = partial + (int64_t)split * Fp * Np;
-    TnRsArgs g{x, ld_x, dy, ld_dy, R, F, N, per, split, partial, dstb != nullptr ? colsum : nullptr, nullptr, nullptr, nullptr, 0, nullptr};
+    TnRsArgs g{x, ld_x, dy, ld_dy, R, F, N, per, split, partial, dstb != nullptr ? colsum : nullptr, nullptr, nullptr, nullptr, 0, nullptr,
+               x_amax, nullptr, dy_amax};
     const int grid = (Fp / 256) * (Np / 256) * split;
-    hipLaunchKernelGGL(bf3_gemm_tn_rs_kernel<0>, dim3(grid), dim3(512), 0, dr_s(stream), g);
+    if (x_amax != nullptr) hipLaunchKernelGGL((bf3_gemm_tn_rs_kernel<0, 1>), dim3(grid), dim3(512), 0, dr_s(stream), g);
+    else hipLaunchKernelGGL((bf3_gemm_tn_rs_kernel<0, 0>), dim3(grid), dim3(512), 0, dr_s(stream), g);
     hipLaunchKernelGGL(bf3_tn_rs_reduce_kernel, dim3(dr_grid_for((int64_t)F * N, 256)), dim3(256), 0, dr_s(stream), partial,
-                       dstb != nullptr ? colsum : nullptr, split, F, N, Fp, Np, scale, dstW, ld_w, dstb);
+                       dstb != nullptr ? colsum : nullptr, split, F, N, Fp, Np, scale, dstW, ld_w, dstb, x_amax,
+                       static_cast<const uint32_t*>(nullptr), dy_amax);
     DR_CHECK_LAUNCH();
     return DR_OK;
+}
+
+extern "C" int dr_bf3_wgrad(const float* x, int64_t ld_x, const float* dy, int64_t ld_dy, int64_t R, int32_t F, int32_t N,
+                            float scale, float* dstW, int64_t ld_w, float* dstb, void* workspace, int64_t workspace_bytes,
+                            dr_stream_t stream) {
+    return wgrad_impl(x, ld_x, dy, ld_dy, R, F, N, scale, dstW, ld_w, dstb, workspace, workspace_bytes, stream);
+}
+
+// dr_bf3_wgrad in the f16x2 operand mode (h2_split8): x_amax / dy_amax are the operands' amax records (dr_h2_amax, or a producer's).
+// Same workspace, same fixed-order reduce.
+extern "C" int dr_h2_wgrad(const float* x, int64_t ld_x, const uint32_t* x_amax, const float* dy, int64_t ld_dy, const uint32_t* dy_amax,
+                           int64_t R, int32_t F, int32_t N, float scale, float* dstW, int64_t ld_w, float* dstb, void* workspace,
+                           int64_t workspace_bytes, dr_stream_t stream) {
+    if (!x_amax || !dy_amax) return DR_EINVAL;
+    return wgrad_impl(x, ld_x, dy, ld_dy, R, F, N, scale, dstW, ld_w, dstb, workspace, workspace_bytes, stream, x_amax, dy_amax);
 }
 
 // The same wgrad for the FIRST tower layer, whose x = concat(field embeddings, dense features) is never read from a buffer: the
@@ -2295,8 +2547,10 @@ extern "C" int dr_bf3_wgrad(const float* x, int64_t ld_x, const float* dy, int64
 // need not store `concat` at all (keras/models/ranking/deepfm.py:44-45: stack / concat become pure fiction).
 static int wgrad_emb_impl(const int32_t* ids_t, int64_t R, int32_t nf, const int64_t* row_base, const float* table, int32_t D,
                           const float* dense_pad, const float* dy, int64_t ld_dy, int32_t F, int32_t N, float scale, float* dstW,
-                          int64_t ld_w, float* dstb, void* workspace, int64_t workspace_bytes, int32_t parts, dr_stream_t stream) {
+                          int64_t ld_w, float* dstb, void* workspace, int64_t workspace_bytes, int32_t parts, dr_stream_t stream,
+                          const uint32_t* table_amax = nullptr, const uint32_t* dense_amax = nullptr, const uint32_t* dy_amax = nullptr) {
     if (R <= 0 || F <= 0 || N <= 0 || nf <= 0) return DR_EINVAL;
+    if (table_amax != nullptr && (!dy_amax || (F > 64 * nf && !dense_amax))) return DR_EINVAL;
     if (D != 64 || F < 64 * nf || F > 64 * nf + 32) return DR_ESHAPE;
     if (!ids_t || !row_base || !table || !dy || !dstW || !workspace || ld_dy < N || ld_w < N) return DR_EINVAL;
     if (F > 64 * nf && !dense_pad) return DR_EINVAL;
@@ -2307,12 +2561,16 @@ static int wgrad_emb_impl(const int32_t* ids_t, int64_t R, int32_t nf, const int
     float* partial = static_cast<float*>(workspace);
     float* colsum = partial + (int64_t)split * Fp * Np;
     TnRsArgs g{nullptr, 0, dy, ld_dy, R, F, N, per, split, partial, dstb != nullptr ? colsum : nullptr, ids_t, row_base, table, nf,
-               F > 64 * nf ? dense_pad : nullptr};
+               F > 64 * nf ? dense_pad : nullptr, table_amax, F > 64 * nf ? dense_amax : nullptr, dy_amax};
     const int grid = (Fp / 256) * (Np / 256) * split;
-    if (parts & 1) hipLaunchKernelGGL(bf3_gemm_tn_rs_kernel<1>, dim3(grid), dim3(512), 0, dr_s(stream), g);
+    if (parts & 1) {
+        if (table_amax != nullptr) hipLaunchKernelGGL((bf3_gemm_tn_rs_kernel<1, 1>), dim3(grid), dim3(512), 0, dr_s(stream), g);
+        else hipLaunchKernelGGL((bf3_gemm_tn_rs_kernel<1, 0>), dim3(grid), dim3(512), 0, dr_s(stream), g);
+    }
     if (parts & 2)
         hipLaunchKernelGGL(bf3_tn_rs_reduce_kernel, dim3(dr_grid_for((int64_t)F * N, 256)), dim3(256), 0, dr_s(stream), partial,
-                           dstb != nullptr ? colsum : nullptr, split, F, N, Fp, Np, scale, dstW, ld_w, dstb);
+                           dstb != nullptr ? colsum : nullptr, split, F, N, Fp, Np, scale, dstW, ld_w, dstb, table_amax,
+                           F > 64 * nf ? dense_amax : static_cast<const uint32_t*>(nullptr), dy_amax);
     DR_CHECK_LAUNCH();
     return DR_OK;
 }
@@ -2336,6 +2594,17 @@ extern "C" int dr_bf3_wgrad_emb_parts(const int32_t* ids_t, int64_t R, int32_t n
                           parts, stream);
 }
 
+// dr_bf3_wgrad_emb_parts in the f16x2 operand mode: table_amax as in dr_h2_emb_linear_fwd, dense_amax the record of dense_pad (required
+// iff F > 64 nf), dy_amax the record of dy.  The records must be the same for part 1 and part 2 of one product.
+extern "C" int dr_h2_wgrad_emb(const int32_t* ids_t, int64_t R, int32_t nf, const int64_t* row_base, const float* table, int32_t D,
+                               const uint32_t* table_amax, const float* dense_pad, const uint32_t* dense_amax, const float* dy, int64_t ld_dy,
+                               const uint32_t* dy_amax, int32_t F, int32_t N, float scale, float* dstW, int64_t ld_w, float* dstb,
+                               void* workspace, int64_t workspace_bytes, int32_t parts, dr_stream_t stream) {
+    if (parts < 1 || parts > 3 || !table_amax || !dy_amax) return DR_EINVAL;
+    return wgrad_emb_impl(ids_t, R, nf, row_base, table, D, dense_pad, dy, ld_dy, F, N, scale, dstW, ld_w, dstb, workspace, workspace_bytes,
+                          parts, stream, table_amax, dense_amax, dy_amax);
+}
+
 // Fused K3 + first Dense layer (see bf3_emb_linear_kernel): h[m][n] = act(sum_k x[m][k] W[k][n] + bias[n]) with
 // x = concat(field embeddings of ids[m], dense features = dense_pad[m, : K - 64 F]); also writes concat[:, : 64 F],
 // sum_x [M, 64] and fm_logit [M] = lin_bias + sum_f lin_w[row] + 0.5 sum_d ((sum_f x_fd)^2 - sum_f x_fd^2).
@@ -2343,7 +2612,8 @@ static int emb_linear_fwd_impl(const int64_t* ids, int64_t M, int32_t F, const i
                                const float* table, int32_t D, const float* lin_w, const float* lin_bias, const float* dense_pad, float* concat,
                                int64_t ld_concat, int32_t K, const void* wt_planes, int64_t plane_stride, int64_t ld_planes, int32_t N,
                                const float* bias, int32_t act, float* sum_x, float* fm_logit, float* out, int64_t ld_out,
-                               float* lin_vals_t, dr_stream_t stream) {
+                               float* lin_vals_t, dr_stream_t stream, const uint32_t* table_amax = nullptr,
+                               const uint32_t* dense_amax = nullptr, const uint32_t* w_amax = nullptr) {
     if (M < 0 || M > 0x7fffff00 || F <= 0 || N <= 0 || K < 64 * F || act < 0 || act > 1) return DR_EINVAL;
     // the k-tile <-> (field, half row) map is built for 64-wide rows; the dense features are one k-tile; a field is one 4 GB buffer
     if (D != 64 || K > 64 * F + 32 || field_rows_max <= 0 || field_rows_max > (1 << 24)) return DR_ESHAPE;
@@ -2359,11 +2629,18 @@ static int emb_linear_fwd_impl(const int64_t* ids, int64_t M, int32_t F, const i
     RsArgs g{nullptr, 0, static_cast<const __bf16*>(wt_planes), plane_stride, ld_planes, M, N, K, out, ld_out, bias, act, nullptr, 0, 0,
              nullptr, nullptr, 0, 0.f, nullptr};
     EmbArgs e{ids, F, row_base, table, lin_w, lin_bias, K > 64 * F ? dense_pad : nullptr, concat, ld_concat, sum_x, fm_logit,
-              lin_w != nullptr ? lin_vals_t : nullptr};
+              lin_w != nullptr ? lin_vals_t : nullptr, K > 64 * F ? dense_amax : nullptr};
     const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
     if (tiles > 0x7fffffff) return DR_EINVAL;
     const int grid = (int)(tiles < 256 ? tiles : 256);
-    hipLaunchKernelGGL(bf3_emb_linear_kernel, dim3(grid), dim3(512), 0, dr_s(stream), g, e);
+    if (table_amax != nullptr) {                                        // f16x2 operand mode
+        if (!w_amax || (K > 64 * F && !dense_amax)) return DR_EINVAL;
+        g.a_amax = table_amax;
+        g.b_amax = w_amax;
+        hipLaunchKernelGGL(bf3_emb_linear_kernel<1>, dim3(grid), dim3(512), 0, dr_s(stream), g, e);
+    } else {
+        hipLaunchKernelGGL(bf3_emb_linear_kernel<0>, dim3(grid), dim3(512), 0, dr_s(stream), g, e);
+    }
     DR_CHECK_LAUNCH();
     return DR_OK;
 }
@@ -2387,4 +2664,19 @@ extern "C" int dr_bf3_emb_linear_fwd_lv(const int64_t* ids, int64_t M, int32_t F
                                         float* out, int64_t ld_out, float* lin_vals_t, dr_stream_t stream) {
     return emb_linear_fwd_impl(ids, M, F, row_base, field_rows_max, table, D, lin_w, lin_bias, dense_pad, concat, ld_concat, K, wt_planes,
                                plane_stride, ld_planes, N, bias, act, sum_x, fm_logit, out, ld_out, lin_vals_t, stream);
+}
+
+// dr_bf3_emb_linear_fwd_lv in the f16x2 operand mode: wt_planes = two fp16 planes (dr_h2_split with w_amax); table_amax >= the largest
+// magnitude in `table` (the engine keeps it as a running maximum: dr_h2_amax over the table once, K4 afterwards); dense_amax = the
+// record of dense_pad (required iff K > 64 F).  lin_vals_t may be NULL.
+extern "C" int dr_h2_emb_linear_fwd(const int64_t* ids, int64_t M, int32_t F, const int64_t* row_base, int64_t field_rows_max,
+                                    const float* table, int32_t D, const uint32_t* table_amax, const float* lin_w, const float* lin_bias,
+                                    const float* dense_pad, const uint32_t* dense_amax, float* concat, int64_t ld_concat, int32_t K,
+                                    const void* wt_planes, int64_t plane_stride, int64_t ld_planes, const uint32_t* w_amax, int32_t N,
+                                    const float* bias, int32_t act, float* sum_x, float* fm_logit, float* out, int64_t ld_out,
+                                    float* lin_vals_t, dr_stream_t stream) {
+    if (!table_amax || !w_amax) return DR_EINVAL;
+    return emb_linear_fwd_impl(ids, M, F, row_base, field_rows_max, table, D, lin_w, lin_bias, dense_pad, concat, ld_concat, K, wt_planes,
+                               plane_stride, ld_planes, N, bias, act, sum_x, fm_logit, out, ld_out, lin_vals_t, stream, table_amax,
+                               dense_amax, w_amax);
 }

@@ -72,6 +72,19 @@ __device__ __forceinline__ float adam_elem(float g, float& m, float& v, const Ad
     return -a.lr_t * m / (sqrtf(v) + a.eps);
 }
 
+// Running amax record of the table (round 4; include/dr_hotpath.h "f16x2 operand mode"): amax[0] = max(amax[0], |every value this
+// kernel writes into dst_table|) as float bits -- the GEMMs that take table rows as an fp16-split operand derive their scale from it.
+// One load per wave and an atomic only where it would raise the record (after the first few waves of the first step: never).
+__device__ __forceinline__ float amax4(float mx, const float4& r) {
+    return fmaxf(fmaxf(mx, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
+}
+__device__ __forceinline__ void amax_commit(uint32_t* __restrict__ rec, float mx) {
+    uint32_t m = __float_as_uint(mx);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(rec, m);
+}
+
 template <int LPR, int U, bool ADAM>
 __device__ __forceinline__ void emb_bwd_unique_body(const int bid, const int nblk, const int64_t* __restrict__ ids,
                                                               const uint8_t* __restrict__ flags, int64_t B, int32_t F,
@@ -83,8 +96,9 @@ __device__ __forceinline__ void emb_bwd_unique_body(const int bid, const int nbl
                                                               const float* __restrict__ slot_lin, float scale,
                                                               float* __restrict__ table, float* __restrict__ lin_w,
                                                               float* __restrict__ lin_bias, AdamArgs ad,
-                                                              const float* __restrict__ lin_old_t) {
+                                                              const float* __restrict__ lin_old_t, uint32_t* __restrict__ amax) {
     constexpr int NS = DR_WAVE / LPR;
+    float wmax = 0.f;
     const int lane = threadIdx.x & 63, slot = lane / LPR, sub = lane % LPR;
     const int nq = D >> 2;
     const bool dvalid = sub < nq;
@@ -180,6 +194,7 @@ __device__ __forceinline__ void emb_bwd_unique_body(const int bid, const int nbl
                 }
                 if (row[u] >= 0) {
                     if (dvalid) {
+                        wmax = amax4(wmax, r);
                         st4_stream(table + row[u] * D + sub * 4, r);
                         if (ADAM) {
                             st4_stream(ad.m + row[u] * D + sub * 4, mt[u]);
@@ -197,6 +212,7 @@ __device__ __forceinline__ void emb_bwd_unique_body(const int bid, const int nbl
         dl = next_dl;
         my_lo = next_lo;
     }
+    if (amax != nullptr) amax_commit(amax, wmax);
 }
 
 // Duplicate path: rows touched by >= 2 slots.  One lane group per segment head sums the slot gradients in sorted
@@ -214,7 +230,8 @@ __device__ __forceinline__ void emb_bwd_dups_body(const int bid, const int nblk,
                                                            const float* __restrict__ d_fm_logit,
                                                            const float* __restrict__ slot_lin, float scale,
                                                            float* __restrict__ table, float* __restrict__ lin_w, AdamArgs ad,
-                                                           float* x_sorted, const bool det) {
+                                                           float* x_sorted, const bool det, uint32_t* __restrict__ amax) {
+    float wmax = 0.f;
     // ADAM: the update is not linear in the gradient, so a row's slots must be summed completely before the one update:
     // the segment-start head walks the WHOLE segment (however long) and the aligned heads of hot rows do nothing.
     // One lane group (LPR lanes = one table row) per head.  The piece is walked in chunks of LPR sorted entries: the
@@ -316,6 +333,7 @@ __device__ __forceinline__ void emb_bwd_dups_body(const int bid, const int nblk,
                     float4 vt = *reinterpret_cast<const float4*>(ad.v + k * (uint64_t)D + sub * 4);
                     t.x += adam_elem(g.x, mt.x, vt.x, ad); t.y += adam_elem(g.y, mt.y, vt.y, ad);
                     t.z += adam_elem(g.z, mt.z, vt.z, ad); t.w += adam_elem(g.w, mt.w, vt.w, ad);
+                    wmax = amax4(wmax, t);
                     *reinterpret_cast<float4*>(dst) = t;
                     *reinterpret_cast<float4*>(ad.m + k * (uint64_t)D + sub * 4) = mt;
                     *reinterpret_cast<float4*>(ad.v + k * (uint64_t)D + sub * 4) = vt;
@@ -332,6 +350,7 @@ __device__ __forceinline__ void emb_bwd_dups_body(const int bid, const int nblk,
                     float4 t = *reinterpret_cast<const float4*>(dst);
                     t.x = fmaf(scale, g.x, t.x); t.y = fmaf(scale, g.y, t.y);
                     t.z = fmaf(scale, g.z, t.z); t.w = fmaf(scale, g.w, t.w);
+                    wmax = amax4(wmax, t);
                     *reinterpret_cast<float4*>(dst) = t;
                 }
                 if (lin_w != nullptr && any_lin && sub == 0) lin_w[k] = fmaf(scale, dls, lin_w[k]);
@@ -345,7 +364,13 @@ __device__ __forceinline__ void emb_bwd_dups_body(const int bid, const int nblk,
                 // re-reads that one slot instead
                 if (any_lin && sub == 0 && j - i >= 2) x_sorted[(i + 1) * (int64_t)D] = dls;
             } else {
-                if (dvalid) {
+                if (dvalid && amax != nullptr) {
+                    // (every piece reports old + its own sum; the piece the memory system applies last reports the row's final value)
+                    float4 o;
+                    o.x = unsafeAtomicAdd(dst + 0, scale * g.x) + scale * g.x; o.y = unsafeAtomicAdd(dst + 1, scale * g.y) + scale * g.y;
+                    o.z = unsafeAtomicAdd(dst + 2, scale * g.z) + scale * g.z; o.w = unsafeAtomicAdd(dst + 3, scale * g.w) + scale * g.w;
+                    wmax = amax4(wmax, o);
+                } else if (dvalid) {
                     unsafeAtomicAdd(dst + 0, scale * g.x); unsafeAtomicAdd(dst + 1, scale * g.y);
                     unsafeAtomicAdd(dst + 2, scale * g.z); unsafeAtomicAdd(dst + 3, scale * g.w);
                 }
@@ -353,6 +378,7 @@ __device__ __forceinline__ void emb_bwd_dups_body(const int bid, const int nblk,
             }
         }
     }
+    if (amax != nullptr) amax_commit(amax, wmax);
 }
 
 // K4 in ONE launch: the first `grid_d` blocks walk the duplicate segments, the rest stream the examples and update the rows
@@ -368,6 +394,7 @@ struct BwdSortedArgs {
     int det;                                     // SGD: hot rows' pieces park their sums in x_sorted (emb_bwd_hot_apply_kernel adds them)
     int skip_unique_lin;                         // first-order weights of rows unique in the batch are updated by dr_emb_lin_update_unique
     const float* lin_old_t;                      // [F, B] first-order weights as the forward read them (may be NULL)
+    uint32_t* amax;                              // running amax record of dst_table (may be NULL)
 };
 #ifndef DR_K4_MINWAVES     // (experiment hooks: tools/exp/k4_occupancy.sh builds variants with -DDR_K4_MINWAVES=n / -DDR_K4_U=n)
 #define DR_K4_LB __launch_bounds__(256)
@@ -379,11 +406,11 @@ __global__ DR_K4_LB void emb_bwd_sorted_kernel(BwdSortedArgs a, AdamArgs ad, int
     if ((int)blockIdx.x < grid_d)
         emb_bwd_dups_body<LPR, ADAM>(blockIdx.x, grid_d, a.rows, a.slots, a.n, a.dup_heads, a.dup_count, a.F, a.D, a.num_rows, a.grad,
                                      a.ld, a.concat, a.ldc, a.sum_x, a.d_fm_logit, a.slot_lin, a.scale, a.table, a.lin_w, ad, a.x_sorted,
-                                     a.det != 0);
+                                     a.det != 0, a.amax);
     else
         emb_bwd_unique_body<LPR, U, ADAM>(blockIdx.x - grid_d, gridDim.x - grid_d, a.ids, a.flags, a.B, a.F, a.row_base, a.D, a.grad,
                                           a.ld, a.concat, a.ldc, a.sum_x, a.d_fm_logit, a.slot_lin, a.scale, a.table,
-                                          a.skip_unique_lin ? nullptr : a.lin_w, a.lin_bias, ad, a.lin_old_t);
+                                          a.skip_unique_lin ? nullptr : a.lin_w, a.lin_bias, ad, a.lin_old_t, a.amax);
 }
 
 // Second half of the deterministic hot-row update (SGD with x_sorted given): for every row whose slots span more than one piece,
@@ -407,6 +434,7 @@ __global__ __launch_bounds__(256) void emb_bwd_hot_apply_kernel(BwdSortedArgs a)
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nheads = a.dup_count[0], n = a.dup_count[1];
+    float wmax = 0.f;
     // 16 heads per wave and round, not 64: a wave works its hot segments off one after the other (8 - 12 dependent round trips
     // each), and a Zipf batch has ~1 400 of them among 88 K heads -- spread thin, they run in parallel (75 -> 30 us)
     constexpr int SCREEN = 16;
@@ -473,6 +501,7 @@ __global__ __launch_bounds__(256) void emb_bwd_hot_apply_kernel(BwdSortedArgs a)
                 float4 t = *reinterpret_cast<const float4*>(dst);
                 t.x = fmaf(a.scale, g.x, t.x); t.y = fmaf(a.scale, g.y, t.y);
                 t.z = fmaf(a.scale, g.z, t.z); t.w = fmaf(a.scale, g.w, t.w);
+                wmax = amax4(wmax, t);
                 *reinterpret_cast<float4*>(dst) = t;
             }
             if (any_lin) {
@@ -494,6 +523,7 @@ __global__ __launch_bounds__(256) void emb_bwd_hot_apply_kernel(BwdSortedArgs a)
             }
         }
     }
+    if (a.amax != nullptr) amax_commit(a.amax, wmax);
 }
 
 }  // namespace
@@ -504,7 +534,7 @@ static int bwd_sorted_impl(const int64_t* ids, const int64_t* row_base, const in
                            int64_t ld_grad, const float* concat, int64_t ld_concat, const float* sum_x,
                            const float* d_fm_logit, const float* slot_lin_grad, float scale, float* dst_table,
                            float* dst_lin, float* dst_bias, const AdamArgs* adam, float* x_sorted, dr_stream_t stream,
-                           int parts = 3, const float* lin_old_t = nullptr) {
+                           int parts = 3, const float* lin_old_t = nullptr, uint32_t* table_amax = nullptr) {
     if (B < 0 || F <= 0 || F > 64 || D < 4 || D > 256 || (D & 3) || num_rows <= 0) return DR_EINVAL;
     const int64_t n = B * F;
     if (n == 0) return DR_OK;
@@ -529,7 +559,7 @@ static int bwd_sorted_impl(const int64_t* ids, const int64_t* row_base, const in
     const BwdSortedArgs ba{ids, unique_flags, B, F, row_base, D, grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit, slot_lin_grad,
                            scale, dst_table, dst_lin, dst_bias, rows, sorted_slots, n, dup_heads, dup_count, (uint64_t)num_rows,
                            x_sorted, det, (adam == nullptr && (parts & 4)) ? 1 : 0,
-                           slot_lin_grad == nullptr ? lin_old_t : nullptr};
+                           slot_lin_grad == nullptr ? lin_old_t : nullptr, table_amax};
 #ifdef DR_K4_U
     constexpr int K4_U_OVERRIDE = DR_K4_U;
 #else
@@ -613,6 +643,8 @@ extern "C" int dr_emb_pool_bwd_sorted_parts(const int64_t* ids, const int64_t* r
 // dr_emb_pool_bwd_sorted_parts with `lin_old_t` [F, B] (field-major; may be NULL = as above): the first-order weight every slot read in
 // the forward of THIS step (dr_bf3_emb_linear_fwd_lv).  Rows unique in the batch then get dst_lin[row] = lin_old + scale * g as ONE
 // write -- valid only if nothing has written dst_lin since that forward.  Shared rows are summed and updated as before.
+// table_amax (may be NULL): running amax record of dst_table -- raised to the largest |value| this call writes into the table (the
+// f16x2 GEMMs, dr_h2_emb_linear_fwd / dr_h2_wgrad_emb, scale the table rows by it).
 extern "C" int dr_emb_pool_bwd_sorted_ex(const int64_t* ids, const int64_t* row_base, const int64_t* sorted_rows,
                                          const int32_t* sorted_slots, const uint8_t* unique_flags,
                                          const int32_t* dup_heads, const int32_t* dup_count, int64_t B, int32_t F,
@@ -620,11 +652,11 @@ extern "C" int dr_emb_pool_bwd_sorted_ex(const int64_t* ids, const int64_t* row_
                                          const float* concat, int64_t ld_concat, const float* sum_x,
                                          const float* d_fm_logit, const float* slot_lin_grad, float scale,
                                          float* dst_table, float* dst_lin, float* dst_bias, float* x_sorted,
-                                         const float* lin_old_t, int32_t parts, dr_stream_t stream) {
+                                         const float* lin_old_t, int32_t parts, uint32_t* table_amax, dr_stream_t stream) {
     if (parts < 1 || parts > 7 || (parts & 3) == 0) return DR_EINVAL;
     return bwd_sorted_impl(ids, row_base, sorted_rows, sorted_slots, unique_flags, dup_heads, dup_count, B, F, D, num_rows,
                            grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit, slot_lin_grad, scale, dst_table, dst_lin,
-                           dst_bias, nullptr, x_sorted, stream, parts, lin_old_t);
+                           dst_bias, nullptr, x_sorted, stream, parts, lin_old_t, table_amax);
 }
 
 // dst_lin[row_base[f] + ids[b, f]] += scale * (slot_lin_grad ? slot_lin_grad[b, f] : d_fm_logit[b])  for every slot whose row no other
@@ -720,7 +752,7 @@ extern "C" int dr_emb_pool_bwd_sorted_adam(const int64_t* ids, const int64_t* ro
 }
 
 // ... with lin_old_t [F, B] (may be NULL) as in dr_emb_pool_bwd_sorted_ex: the first-order weight of a row unique in the batch is
-// written from the value the forward of this step saved instead of being read again.
+// written from the value the forward of this step saved instead of being read again.  table_amax (may be NULL): as above.
 extern "C" int dr_emb_pool_bwd_sorted_adam_ex(const int64_t* ids, const int64_t* row_base, const int64_t* sorted_rows,
                                               const int32_t* sorted_slots, const uint8_t* unique_flags,
                                               const int32_t* dup_heads, const int32_t* dup_count, int64_t B, int32_t F,
@@ -729,13 +761,13 @@ extern "C" int dr_emb_pool_bwd_sorted_adam_ex(const int64_t* ids, const int64_t*
                                               const float* d_fm_logit, const float* slot_lin_grad, float lr_t, float beta1,
                                               float beta2, float eps, float* table, float* m_table, float* v_table,
                                               float* lin_w, float* m_lin, float* v_lin, float* x_sorted, const float* lin_old_t,
-                                              dr_stream_t stream) {
+                                              uint32_t* table_amax, dr_stream_t stream) {
     if (!m_table || !v_table) return DR_EINVAL;
     if (lin_w != nullptr && (!m_lin || !v_lin)) return DR_EINVAL;
     AdamArgs ad{m_table, v_table, m_lin, v_lin, (m_lin != nullptr && v_lin == m_lin + 1) ? 2 : 1, lr_t, beta1, beta2, eps};
     return bwd_sorted_impl(ids, row_base, sorted_rows, sorted_slots, unique_flags, dup_heads, dup_count, B, F, D, num_rows,
                            grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit, slot_lin_grad, 0.f, table, lin_w, nullptr,
-                           &ad, x_sorted, stream, 3, lin_old_t);
+                           &ad, x_sorted, stream, 3, lin_old_t, table_amax);
 }
 
 // ---- TF's NON-lazy sparse Adam, evaluated lazily -----------------------------------------------------------------------------------

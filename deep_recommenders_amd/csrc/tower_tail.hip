@@ -54,9 +54,11 @@ __global__ __launch_bounds__(256, 2) void linear_bwd_narrow_kernel(const float* 
                                                                    const float* __restrict__ W, int64_t ldw, int64_t M,
                                                                    int32_t K, int32_t N, int32_t relu_mask,
                                                                    float* __restrict__ dx, int64_t lddx,
-                                                                   float* __restrict__ partial) {
+                                                                   float* __restrict__ partial, uint32_t* __restrict__ dx_amax) {
     typedef typename VecT<KT>::type vec_t;
     __shared__ float dys[2][TT_ROWS * TT_P];
+    __shared__ uint32_t amax_w[4];
+    float dx_max = 0.f;                                       // largest |dx| this lane stored (dx_amax != NULL: the f16x2 GEMMs' record)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
     const int col0 = wave * 32 * KT + KT * c;                 // first of this lane's KT columns
@@ -147,6 +149,7 @@ __global__ __launch_bounds__(256, 2) void linear_bwd_narrow_kernel(const float* 
             for (int j = 0; j < 16; ++j) {
                 float v = acc[j];
                 if (relu_mask && !(vget<KT>(xv[j], t) > 0.f)) v = 0.f;
+                dx_max = fmaxf(dx_max, fabsf(v));
                 vset<KT>(xv[j], t, v);
             }
         }
@@ -175,6 +178,17 @@ __global__ __launch_bounds__(256, 2) void linear_bwd_narrow_kernel(const float* 
             pp[(int64_t)k * 32 + c] = live * accw[t][j];
         }
     if (wave == 0 && h == 0) pp[(int64_t)K * 32 + c] = live * bias_acc;
+    if (dx_amax != nullptr) {                                 // (kernel-uniform) one atomic per block, and only if it would raise the record
+        uint32_t m = live_block ? __float_as_uint(dx_max) : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+        if (lane == 0) amax_w[wave] = m;
+        __syncthreads();
+        if (tid == 0) {
+            m = max(max(amax_w[0], amax_w[1]), max(amax_w[2], amax_w[3]));
+            if (m > __hip_atomic_load(dx_amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dx_amax, m);
+        }
+    }
 }
 
 // dstW[k][n] += scale * sum_p partial[p][k][n] ; k == K -> dstb[n].  One block per k, fixed summation order.
@@ -227,7 +241,7 @@ extern "C" int64_t dr_linear_bwd_narrow_workspace_bytes(int64_t M, int32_t K, in
 static int bwd_narrow_impl(const float* x, int64_t ld_x, const float* dy, int64_t ld_dy, const float* W,
                            int64_t ld_w, int64_t M, int32_t K, int32_t N, int32_t relu_mask, float scale,
                            float* dstW, int64_t ld_dstw, float* dstb, float* dx, int64_t ld_dx, void* workspace,
-                           int64_t workspace_bytes, int32_t parts, dr_stream_t stream) {
+                           int64_t workspace_bytes, int32_t parts, dr_stream_t stream, uint32_t* dx_amax = nullptr) {
     if (M <= 0 || K <= 0 || N <= 0) return DR_EINVAL;
     if (!x || !dy || !W || !dstW || !dx || !workspace) return DR_EINVAL;
     if (N > 32 || (K != 128 && K != 256 && K != 512) || (M % TT_ROWS) != 0) return DR_ESHAPE;
@@ -242,8 +256,9 @@ static int bwd_narrow_impl(const float* x, int64_t ld_x, const float* dy, int64_
     float* partial = static_cast<float*>(workspace);
 #define TT_CALL(KT)                                                                                                     \
     hipLaunchKernelGGL((linear_bwd_narrow_kernel<KT>), dim3(grid), dim3(256), 0, dr_s(stream), x, ld_x, dy, ld_dy, W,   \
-                       ld_w, M, K, N, relu_mask, dx, ld_dx, partial)
+                       ld_w, M, K, N, relu_mask, dx, ld_dx, partial, dx_amax)
     if (parts & 1) {
+        if (dx_amax != nullptr && hipMemsetAsync(dx_amax, 0, sizeof(uint32_t), dr_s(stream)) != hipSuccess) return DR_ELAUNCH;
         if (kt == 1) TT_CALL(1);
         else if (kt == 2) TT_CALL(2);
         else TT_CALL(4);
@@ -274,4 +289,15 @@ extern "C" int dr_linear_bwd_narrow_parts(const float* x, int64_t ld_x, const fl
     if (parts < 1 || parts > 3) return DR_EINVAL;
     return bwd_narrow_impl(x, ld_x, dy, ld_dy, W, ld_w, M, K, N, relu_mask, scale, dstW, ld_dstw, dstb, dx, ld_dx, workspace,
                            workspace_bytes, parts, stream);
+}
+
+// dr_linear_bwd_narrow_parts that also leaves max |dx| (float bits) in dx_amax[0] -- the amax record the f16x2 GEMMs (dr_h2_linear_nt,
+// dr_h2_wgrad_emb) want for dx as their operand; the record is reset and rebuilt by part 1.
+extern "C" int dr_linear_bwd_narrow_amax(const float* x, int64_t ld_x, const float* dy, int64_t ld_dy, const float* W,
+                                         int64_t ld_w, int64_t M, int32_t K, int32_t N, int32_t relu_mask, float scale,
+                                         float* dstW, int64_t ld_dstw, float* dstb, float* dx, int64_t ld_dx, void* workspace,
+                                         int64_t workspace_bytes, int32_t parts, uint32_t* dx_amax, dr_stream_t stream) {
+    if (parts < 1 || parts > 3 || !dx_amax) return DR_EINVAL;
+    return bwd_narrow_impl(x, ld_x, dy, ld_dy, W, ld_w, M, K, N, relu_mask, scale, dstW, ld_dstw, dstb, dx, ld_dx, workspace,
+                           workspace_bytes, parts, stream, dx_amax);
 }

@@ -185,6 +185,22 @@ class DeepFMEngine:
         self.lin_old_t = (torch.empty((F, B), dtype=torch.float32, device=device)
                           if (_os.environ.get("DR_K4_LINOLD", "1") == "1" and self.fuse_k3 and sorted_bwd) else None)
         self._lin_old_valid = False
+        # The first layer's three GEMMs in the "f16x2" operand mode (round 4; include/dr_hotpath.h dr_h2_*): every operand value as
+        # two fp16 terms of x * s, three matrix instructions per fragment pair instead of the bf16x3 mode's six -- fused forward
+        # 302 -> 220 us, dgrad 308 -> 209, gathering wgrad 374 -> 299 (tools/exp/h2_check.py), errors against fp64 at or below the
+        # bf16x3 mode's.  The power-of-two scales come from amax records kept on the device: the table's is a running maximum (one
+        # pass over the table here, K4 raises it with every value it writes), the dense features' is rebuilt whenever dense_pad is
+        # written, d h0's comes out of the narrow backward that produces it, W's out of the plane refresh.
+        # DR_GEMM_SPLIT=bf16x3 restores the six-product mode.  Needs the fused first layer, the gathering wgrad and the sorted K4;
+        # "adam_tf" (whose catch-up kernel also writes table rows) stays on bf16x3.
+        self.h2 = (_os.environ.get("DR_GEMM_SPLIT", "f16x2") == "f16x2" and self.no_concat and self.wplanes[0] is not None
+                   and not self.adam_tf and _os.environ.get("DR_OVERLAP_DW", "0") != "1")
+        if self.h2:
+            self.wplanes[0] = ops.H2WeightPlanes(self.Ws[0])
+            self.tab_amax = ops.h2_amax(self.table)
+            self._tab_ver = self.table._version
+            self.dense_amax = ops.h2_record(device) if self.dense_pad is not None else None
+            self.dh0_amax = ops.h2_record(device)
         # The slot sort of batch s + 1 next to K4 of batch s (DR_PREFETCH_PLAN=0: every step hashes and sorts its own batch).  K4 is
         # the one long kernel of the step that is HBM-bound with small blocks, i.e. that shares the machine; beside the persistent
         # GEMMs (the fused first layer occupies all 160 KB of LDS on every CU) the sort chain's ~20 small launches only advance in
@@ -313,6 +329,8 @@ class DeepFMEngine:
                     self.concat[:, self.F * self.D:self.F * self.D + self.Nd].copy_(nd)
                 if self.dense_pad is not None:
                     self.dense_pad[:, :self.Nd].copy_(nd)
+                    if self.h2:
+                        ops.h2_amax(self.dense_pad, self.dense_amax)
                 self._pref_dense = self._token(nd)
             if early_done:
                 self._ev_dense[nxt].record(self.side)       # ids and plan were issued at the start of the step: only the dense features here
@@ -410,7 +428,10 @@ class DeepFMEngine:
         self._small_pending = True
 
     def _wgrad(self, i, x, dy, sc, dstW, dstb):
-        if i == 0 and self.no_concat:
+        if i == 0 and self.h2:
+            ops.h2_wgrad_emb(self._ids_t[self.cur], self.row_base, self.table, self.tab_amax, self.dense_pad, self.dense_amax, dy,
+                             self.dh0_amax, sc, dstW, dstb, workspace=self.wg_ws[0], parts=1 if self._wgrad_reduce_deferred(i) else 3)
+        elif i == 0 and self.no_concat:
             # x = [embeddings of this batch's rows, dense features]: gathered from the tables (they are updated only by K4, later
             # on this stream) through the field-major ids
             ops.bf3_wgrad_emb(self._ids_t[self.cur], self.row_base, self.table, self.dense_pad, dy, sc, dstW, dstb,
@@ -433,6 +454,11 @@ class DeepFMEngine:
         for wp in self.wplanes:          # weights written from outside since the last refresh (load / copy_ / fill_): re-split
             if wp is not None:
                 wp.ensure_fresh()
+        if self.h2 and self.table._version != self._tab_ver:
+            # the table was written from outside (checkpoint restore, copy_ / fill_ in a test): rebuild its amax record.  K4's own
+            # writes go through raw pointers and keep the record themselves.
+            ops.h2_amax(self.table, self.tab_amax)
+            self._tab_ver = self.table._version
         pref_tok = self._pref
         prefetched = pref_tok is not None and pref_tok == self._token(keys)
         self._pref = None
@@ -484,6 +510,8 @@ class DeepFMEngine:
                 self.concat[:, F * D:F * D + self.Nd].copy_(dense)                     # layout: append dense feats
             if self.dense_pad is not None:
                 self.dense_pad[:, :self.Nd].copy_(dense)                               # the fused kernel's own (k-tile wide) copy
+                if self.h2:
+                    ops.h2_amax(self.dense_pad, self.dense_amax)
         self._pref_dense = None
         x = self.concat[:, :self.in_dim]
         head = self.fuse_head and labels is not None
@@ -495,7 +523,13 @@ class DeepFMEngine:
             if i == 0 and fused_l0:
                 # K3 + first Dense in one launch: the GEMM gathers its activation operand from the tables, writes concat and the
                 # FM terms on the way (the dense features were placed in concat above)
-                self._k("emb_linear_fwd_L0", "mfma", 2.0 * B * W.shape[0] * W.shape[1],
+                if self.h2:
+                    self._k("emb_linear_fwd_L0", "mfma", 2.0 * B * W.shape[0] * W.shape[1],
+                            lambda b=b: ops.h2_emb_linear_fwd(self.ids, self.row_base, self.V, self.table, self.tab_amax, self.lin_w, self.lin_bias,
+                                                              self.dense_pad, self.dense_amax, None, self.in_dim, self.wplanes[0].wt, b,
+                                                              self.acts[0], self.sum_x, self.fm_logit, self.hs[0], lin_vals_t=self.lin_old_t))
+                else:
+                  self._k("emb_linear_fwd_L0", "mfma", 2.0 * B * W.shape[0] * W.shape[1],
                         lambda b=b: ops.bf3_emb_linear_fwd(self.ids, self.row_base, self.V, self.table, self.lin_w, self.lin_bias, self.dense_pad,
                                                            None if self.no_concat else self.concat,
                                                            self.in_dim, self.wplanes[0].wt, b, self.acts[0], self.sum_x, self.fm_logit,
@@ -565,7 +599,8 @@ class DeepFMEngine:
                 rs = None
             if i > 0 and self.fuse_narrow and self.narrow_ws[i] is not None:
                 def narrow(parts, x=x, dy=dy, W=W, dx=dx, i=i, dstW=dstW, dstb=dstb):
-                    return ops.linear_bwd_narrow(x, dy, W, sc, dstW, dstb, dx, relu_mask=True, workspace=self.narrow_ws[i], parts=parts)
+                    return ops.linear_bwd_narrow(x, dy, W, sc, dstW, dstb, dx, relu_mask=True, workspace=self.narrow_ws[i], parts=parts,
+                                                 dx_amax=self.dh0_amax if (i == 1 and self.h2 and (parts & 1)) else None)
                 if self.reduce_side and self._in_train_step:
                     self._k("linear_bwd_narrow_L%d" % i, "hbm", 4.0 * self.B * (2 * W.shape[0] + W.shape[1]), lambda: narrow(1))
                     self._side_part2(lambda: narrow(2))
@@ -574,7 +609,12 @@ class DeepFMEngine:
                 dy = dx
                 continue
             # dx first (uses the pre-update W), then the wgrad (with the fused SGD step unless Adam)
-            if self.wplanes[i] is not None:
+            if i == 0 and self.h2:
+                if not (n > 1 and self.fuse_narrow and self.narrow_ws[1] is not None):
+                    ops.h2_amax(dy, self.dh0_amax)       # (layer 1's backward was not the narrow kernel that leaves the record)
+                self._k("linear_bwd_dx_L%d" % i, "mfma", fl,
+                        lambda dy=dy, rs=rs, dx=dx, i=i: ops.h2_linear_nt(dy, self.dh0_amax, self.wplanes[i].w, mask=rs, out=dx))
+            elif self.wplanes[i] is not None:
                 self._k("linear_bwd_dx_L%d" % i, "mfma", fl,
                         lambda dy=dy, rs=rs, dx=dx, i=i: ops.bf3_linear_nt(dy, self.wplanes[i].w, mask=rs, out=dx))
             else:
@@ -603,7 +643,10 @@ class DeepFMEngine:
                     self.ev_dw_done.record()
                     with torch.cuda.stream(self.side):
                         self.side.wait_event(self.ev_dw_done)
-                        if self._wgrad_reduce_deferred(i):
+                        if self._wgrad_reduce_deferred(i) and self.h2:
+                            ops.h2_wgrad_emb(self._ids_t[self.cur], self.row_base, self.table, self.tab_amax, self.dense_pad, self.dense_amax,
+                                             dy, self.dh0_amax, sc, dstW, dstb, workspace=self.wg_ws[0], parts=2)
+                        elif self._wgrad_reduce_deferred(i):
                             # the split-K reduce (+ fused SGD step) of the GEMM just launched: nothing on the training stream reads W
                             ops.bf3_wgrad_emb(self._ids_t[self.cur], self.row_base, self.table, self.dense_pad, dy, sc, dstW, dstb,
                                               workspace=self.wg_ws[0], parts=2)
@@ -628,7 +671,8 @@ class DeepFMEngine:
                                                        -lr, self.table, self.lin_w, self.lin_bias,
                                                        concat=None if self.no_concat else self.concat, sum_x=self.sum_x,
                                                        x_sorted=self.x_sorted if self.no_concat else None, parts=parts,
-                                                       lin_old_t=self.lin_old_t if (self._lin_old_valid and not lin_side) else None)
+                                                       lin_old_t=self.lin_old_t if (self._lin_old_valid and not lin_side) else None,
+                                                       table_amax=self.tab_amax if self.h2 else None)
             sk = 4 if lin_side else 0
             self._k("emb_pool_bwd", "hbm", self.alg_bytes_bwd() - (self.B * self.F * 8 if lin_side else 0),   # K4 (sorted)
                     lambda: k4(1 | sk))
@@ -675,7 +719,8 @@ class DeepFMEngine:
                                                      self.m_table, self.v_table, self.lin_w, self.m_lin, self.v_lin,
                                                      concat=None if self.no_concat else self.concat, sum_x=self.sum_x,
                                                      x_sorted=self.x_sorted if self.no_concat else None,
-                                                     lin_old_t=self.lin_old_t if self._lin_old_valid else None))
+                                                     lin_old_t=self.lin_old_t if self._lin_old_valid else None,
+                                                     table_amax=self.tab_amax if self.h2 else None))
         self._prefetch_issue(mark)
         ops.reduce_sum(self.d_logit, out=self.g_lin_bias)                       # d loss / d (first-order bias), fixed order
         if self.overlap_dw:

@@ -239,7 +239,7 @@ def linear_bwd_narrow_workspace(M, K, N, device):
                        dtype=torch.float32, device=device)
 
 
-def linear_bwd_narrow(x, dy, W, scale, dstW, dstb, dx, relu_mask=True, workspace=None, parts=3):
+def linear_bwd_narrow(x, dy, W, scale, dstW, dstb, dx, relu_mask=True, workspace=None, parts=3, dx_amax=None):
     """One pass over x: dx = (dy @ W^T) * (x > 0 if relu_mask); dstW += scale * x^T dy; dstb += scale * colsum(dy).
     dx uses the pre-update W even when dstW is W.  Raises RuntimeError(DR_ESHAPE) outside the kernel's domain."""
     M, K = x.shape
@@ -248,6 +248,12 @@ def linear_bwd_narrow(x, dy, W, scale, dstW, dstb, dx, relu_mask=True, workspace
     assert W.shape == (K, N) and dstW.shape == (K, N) and dx.shape == (M, K)
     if workspace is None:
         workspace = linear_bwd_narrow_workspace(M, K, N, x.device)
+    if dx_amax is not None:  # also leave max |dx| in the record (the f16x2 GEMMs that take dx as an operand want it)
+        check(lib().dr_linear_bwd_narrow_amax(ptr(x), x.stride(0), ptr(dy), dy.stride(0), ptr(W), W.stride(0), M, K, N,
+                                              1 if relu_mask else 0, float(scale), ptr(dstW), dstW.stride(0), ptr(dstb), ptr(dx),
+                                              dx.stride(0), ptr(workspace), workspace.numel() * 4, int(parts), ptr(dx_amax), stream_ptr()),
+              "dr_linear_bwd_narrow_amax")
+        return dx
     if parts != 3:          # 1: the one-pass kernel, 2: the reduce that applies the partials (may run on another stream)
         check(lib().dr_linear_bwd_narrow_parts(ptr(x), x.stride(0), ptr(dy), dy.stride(0), ptr(W), W.stride(0), M, K, N,
                                                1 if relu_mask else 0, float(scale), ptr(dstW), dstW.stride(0), ptr(dstb), ptr(dx),
@@ -519,7 +525,7 @@ def ids_transpose_i32(ids, out=None):
 
 
 def emb_pool_bwd_sorted(ids, row_base, plan, D, num_rows, grad, d_fm_logit, scale, dst_table, dst_lin=None, dst_bias=None,
-                        concat=None, sum_x=None, slot_lin_grad=None, x_sorted=None, parts=3, lin_old_t=None):
+                        concat=None, sum_x=None, slot_lin_grad=None, x_sorted=None, parts=3, lin_old_t=None, table_amax=None):
     """K4 on the slot plan.  x_sorted ([B * F, D] scratch; with the FM term and no `concat` it must hold the snapshot of
     emb_snapshot_sorted_rows) also makes the update of rows hit more than 32 times deterministic: it is clobbered.  parts: 1 = the
     update kernel, 2 = the ordered combination of hot rows' parked pieces, 3 = both (dr_emb_pool_bwd_sorted[_parts])."""
@@ -531,9 +537,11 @@ def emb_pool_bwd_sorted(ids, row_base, plan, D, num_rows, grad, d_fm_logit, scal
             grad.stride(0), ptr(concat), concat.stride(0) if concat is not None else 0,
             ptr(sum_x), ptr(d_fm_logit), ptr(slot_lin_grad), float(scale), ptr(dst_table), ptr(dst_lin),
             ptr(dst_bias), ptr(x_sorted))
-    if lin_old_t is not None:       # first-order weights as this step's forward read them, [F, B]: unique rows get one write, no RMW
-        assert lin_old_t.shape == (F, B) and lin_old_t.is_contiguous() and lin_old_t.dtype == torch.float32
-        check(lib().dr_emb_pool_bwd_sorted_ex(*args, ptr(lin_old_t), int(parts), stream_ptr()), "dr_emb_pool_bwd_sorted_ex")
+    if lin_old_t is not None or table_amax is not None:
+        # lin_old_t: first-order weights as this step's forward read them, [F, B]: unique rows get one write, no RMW
+        # table_amax: running amax record of dst_table (ops.h2_record), raised to the largest magnitude written
+        assert lin_old_t is None or (lin_old_t.shape == (F, B) and lin_old_t.is_contiguous() and lin_old_t.dtype == torch.float32)
+        check(lib().dr_emb_pool_bwd_sorted_ex(*args, ptr(lin_old_t), int(parts), ptr(table_amax), stream_ptr()), "dr_emb_pool_bwd_sorted_ex")
     elif parts == 3:
         check(lib().dr_emb_pool_bwd_sorted(*args, stream_ptr()), "dr_emb_pool_bwd_sorted")
     else:
@@ -556,19 +564,19 @@ def adam_lr_t(lr, beta1, beta2, step):
 
 def emb_pool_bwd_sorted_adam(ids, row_base, plan, D, num_rows, grad, d_fm_logit, lr_t, beta1, beta2, eps, table, m_table,
                              v_table, lin_w=None, m_lin=None, v_lin=None, concat=None, sum_x=None, slot_lin_grad=None, x_sorted=None,
-                             lin_old_t=None):
+                             lin_old_t=None, table_amax=None):
     """Sorted K4 with a fused row-wise Adam update (see dr_emb_pool_bwd_sorted_adam in include/dr_hotpath.h)."""
     ids = _c(ids, torch.int64)
     B, F = ids.shape
     assert grad.stride(1) == 1
-    if lin_old_t is not None:
-        assert lin_old_t.shape == (F, B) and lin_old_t.is_contiguous()
+    if lin_old_t is not None or table_amax is not None:
+        assert lin_old_t is None or (lin_old_t.shape == (F, B) and lin_old_t.is_contiguous())
         check(lib().dr_emb_pool_bwd_sorted_adam_ex(ptr(ids), ptr(row_base), ptr(plan.rows), ptr(plan.slots), ptr(plan.flags),
                                             ptr(plan.dup_heads), ptr(plan.dup_count), B, F, D, int(num_rows), ptr(grad),
                                             grad.stride(0), ptr(concat), concat.stride(0) if concat is not None else 0,
                                             ptr(sum_x), ptr(d_fm_logit), ptr(slot_lin_grad), float(lr_t), float(beta1),
                                             float(beta2), float(eps), ptr(table), ptr(m_table), ptr(v_table), ptr(lin_w),
-                                            ptr(m_lin), ptr(v_lin), ptr(x_sorted), ptr(lin_old_t), stream_ptr()), "dr_emb_pool_bwd_sorted_adam_ex")
+                                            ptr(m_lin), ptr(v_lin), ptr(x_sorted), ptr(lin_old_t), ptr(table_amax), stream_ptr()), "dr_emb_pool_bwd_sorted_adam_ex")
         return
     check(lib().dr_emb_pool_bwd_sorted_adam(ptr(ids), ptr(row_base), ptr(plan.rows), ptr(plan.slots), ptr(plan.flags),
                                             ptr(plan.dup_heads), ptr(plan.dup_count), B, F, D, int(num_rows), ptr(grad),
@@ -1057,6 +1065,137 @@ class WeightPlanes:
         """Planes are SHADOW copies: forward / dgrad read them, not W.  The engines refresh them after their own (kernel-side)
         updates; a write to W from outside -- checkpoint restore, W.copy_ / fill_ in a test, a broadcast -- bumps torch's version
         counter of the parameter buffer, which is what this checks at the top of every step (host compare, no launch)."""
+        if self.W._version != self._ver:
+            self.refresh()
+
+
+# ---- "f16x2" operand mode of the first tower layer's GEMMs (dr_h2_*, include/dr_hotpath.h) -------------------------------------------
+def h2_record(device):
+    """An amax record: one uint32 (held as int32) with max |x| of a tensor as float bits; 0 = nothing seen yet."""
+    return torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def h2_amax(src, amax=None, reset=True):
+    """amax = max(0 if reset else amax, max |src|) as float bits (dr_h2_amax); src fp32 [R, C] with unit inner stride (or 1-D)."""
+    if src.dim() == 1:
+        src = src.view(1, -1)
+    assert src.dim() == 2 and src.stride(1) == 1 and src.dtype == torch.float32
+    if amax is None:
+        amax = h2_record(src.device)
+    R, C = src.shape
+    check(lib().dr_h2_amax(ptr(src), src.stride(0) if R > 1 else max(C, 1), R, C, ptr(amax), 1 if reset else 0, stream_ptr()), "dr_h2_amax")
+    return amax
+
+
+def h2_amax_value(amax):
+    """The record as a float (host sync; tests and diagnostics)."""
+    return float(amax.view(torch.float32).item())
+
+
+class H2Planes:
+    """planes[2][rows_alloc][ld] fp16 in HBM: the two terms of W * s, s from the record `amax` (shared by the W and W^T planes of one
+    weight).  Same padding rules as Planes."""
+
+    def __init__(self, rows, cols, device, amax=None):
+        self.rows, self.cols = int(rows), int(cols)
+        self.rows_alloc = (self.rows + 31) // 32 * 32
+        self.ld = (self.cols + 31) // 32 * 32
+        self.buf = torch.zeros((2, self.rows_alloc, self.ld), dtype=torch.float16, device=device)
+        self.amax = amax if amax is not None else h2_record(device)
+
+    @property
+    def plane_stride(self):
+        return self.rows_alloc * self.ld
+
+
+def h2_split(src, planes: H2Planes, row_offset=0, col_offset=0, transpose=False):
+    """fp32 [R, C] * s(planes.amax) -> two fp16 planes (layout of bf3_split).  planes.amax must already cover src (h2_amax)."""
+    assert src.dim() == 2 and src.stride(1) == 1 and src.dtype == torch.float32
+    R, C = src.shape
+    check(lib().dr_h2_split(ptr(src), src.stride(0), R, C, ptr(planes.buf), planes.plane_stride, planes.ld, row_offset, col_offset,
+                            1 if transpose else 0, ptr(planes.amax), stream_ptr()), "dr_h2_split")
+    return planes
+
+
+def h2_linear_nt(a, a_amax, b: H2Planes, bias=None, act=0, mask=None, accumulate=False, out=None):
+    """bf3_linear_nt in the f16x2 mode: a fp32 [M, K] with its amax record, b the weights as H2Planes."""
+    a = _rowmajor_ld4(a)
+    M, K = a.shape
+    if a.stride(0) % 4 or a.data_ptr() % 16:
+        buf = torch.zeros((M, _pad4(K)), dtype=torch.float32, device=a.device)
+        buf[:, :K].copy_(a)
+        a = buf[:, :K]
+    N = b.rows
+    assert b.cols == K, "weights' planes must have the reduction length as columns"
+    if out is None:
+        assert not accumulate
+        out = torch.empty((M, _pad4(N)), dtype=torch.float32, device=a.device)[:, :N]
+    assert out.shape == (M, N) and out.stride(1) == 1
+    check(lib().dr_h2_linear_nt(ptr(a), a.stride(0), ptr(a_amax), ptr(b.buf), b.plane_stride, b.ld, ptr(b.amax), M, N, K, ptr(bias), int(act),
+                                ptr(mask), mask.stride(0) if mask is not None else 0, int(bool(accumulate)), ptr(out), out.stride(0),
+                                stream_ptr()), "dr_h2_linear_nt")
+    return out
+
+
+def h2_emb_linear_fwd(ids, row_base, field_rows_max, table, table_amax, lin_w, lin_bias, dense_pad, dense_amax, concat, K, wt: H2Planes, bias, act,
+                      sum_x, fm_logit, out, lin_vals_t=None):
+    """bf3_emb_linear_fwd in the f16x2 mode (dr_h2_emb_linear_fwd): table_amax >= max |table|, dense_amax the record of dense_pad."""
+    ids = _c(ids, torch.int64)
+    M, F = ids.shape
+    assert (concat is None or concat.stride(1) == 1) and out.stride(1) == 1 and wt.cols == K and out.shape == (M, wt.rows)
+    assert dense_pad is None or (dense_pad.shape == (M, 32) and dense_pad.is_contiguous())
+    assert lin_vals_t is None or (lin_vals_t.shape == (F, M) and lin_vals_t.is_contiguous() and lin_vals_t.dtype == torch.float32)
+    check(lib().dr_h2_emb_linear_fwd(ptr(ids), M, F, ptr(row_base), int(field_rows_max), ptr(table), table.shape[1], ptr(table_amax), ptr(lin_w),
+                                     ptr(lin_bias), ptr(dense_pad), ptr(dense_amax), ptr(concat), concat.stride(0) if concat is not None else 0,
+                                     int(K), ptr(wt.buf), wt.plane_stride, wt.ld, ptr(wt.amax), wt.rows, ptr(bias), int(act), ptr(sum_x),
+                                     ptr(fm_logit), ptr(out), out.stride(0), ptr(lin_vals_t), stream_ptr()), "dr_h2_emb_linear_fwd")
+    return out
+
+
+def h2_wgrad(x, x_amax, dy, dy_amax, scale, dstW, dstb=None, workspace=None):
+    """bf3_wgrad in the f16x2 mode."""
+    R, F = x.shape
+    N = dy.shape[1]
+    assert x.stride(1) == 1 and dy.stride(1) == 1 and dstW.shape == (F, N) and dstW.stride(1) == 1 and dy.shape[0] == R
+    if workspace is None:
+        workspace = bf3_wgrad_workspace(R, F, N, x.device)
+    check(lib().dr_h2_wgrad(ptr(x), x.stride(0), ptr(x_amax), ptr(dy), dy.stride(0), ptr(dy_amax), R, F, N, float(scale), ptr(dstW),
+                            dstW.stride(0), ptr(dstb), ptr(workspace), workspace.numel() * 4, stream_ptr()), "dr_h2_wgrad")
+    return dstW
+
+
+def h2_wgrad_emb(ids_t, row_base, table, table_amax, dense_pad, dense_amax, dy, dy_amax, scale, dstW, dstb=None, workspace=None, parts=3):
+    """bf3_wgrad_emb in the f16x2 mode."""
+    nf, R = ids_t.shape
+    F, N = dstW.shape
+    assert ids_t.dtype == torch.int32 and ids_t.is_contiguous() and dy.stride(1) == 1 and dstW.stride(1) == 1 and dy.shape == (R, N)
+    assert dense_pad is None or (dense_pad.shape == (R, 32) and dense_pad.is_contiguous())
+    if workspace is None:
+        workspace = bf3_wgrad_workspace(R, F, N, dy.device)
+    check(lib().dr_h2_wgrad_emb(ptr(ids_t), R, nf, ptr(row_base), ptr(table), table.shape[1], ptr(table_amax), ptr(dense_pad), ptr(dense_amax),
+                                ptr(dy), dy.stride(0), ptr(dy_amax), F, N, float(scale), ptr(dstW), dstW.stride(0), ptr(dstb), ptr(workspace),
+                                workspace.numel() * 4, int(parts), stream_ptr()), "dr_h2_wgrad_emb")
+    return dstW
+
+
+class H2WeightPlanes:
+    """WeightPlanes in the f16x2 mode: W^T and W as two fp16 planes each, one amax record; refresh() = dr_h2_amax + two dr_h2_split."""
+
+    def __init__(self, W):
+        K, N = W.shape
+        self.W = W
+        self.amax = h2_record(W.device)
+        self.wt = H2Planes(N, K, W.device, self.amax)
+        self.w = H2Planes(K, N, W.device, self.amax)
+        self.refresh()
+
+    def refresh(self):
+        h2_amax(self.W, self.amax, reset=True)
+        h2_split(self.W, self.wt, transpose=True)
+        h2_split(self.W, self.w)
+        self._ver = self.W._version
+
+    def ensure_fresh(self):
         if self.W._version != self._ver:
             self.refresh()
 

@@ -225,7 +225,7 @@ int dr_emb_pool_bwd_sorted_ex(const int64_t* ids, const int64_t* row_base, const
                               const float* concat, int64_t ld_concat, const float* sum_x,
                               const float* d_fm_logit, const float* slot_lin_grad, float scale,
                               float* dst_table, float* dst_lin, float* dst_bias, float* x_sorted,
-                              const float* lin_old_t, int32_t parts, dr_stream_t stream);
+                              const float* lin_old_t, int32_t parts, uint32_t* table_amax, dr_stream_t stream);
 int dr_emb_snapshot_sorted_rows(const int64_t* sorted_rows, const int32_t* dup_heads, const int32_t* dup_count,
                                 const float* table, int32_t D, int64_t num_rows, float* x_sorted, dr_stream_t stream);
 
@@ -257,8 +257,7 @@ int dr_emb_pool_bwd_sorted_adam_ex(const int64_t* ids, const int64_t* row_base, 
                                 const float* concat, int64_t ld_concat, const float* sum_x,
                                 const float* d_fm_logit, const float* slot_lin_grad, float lr_t, float beta1,
                                 float beta2, float eps, float* table, float* m_table, float* v_table,
-                                float* lin_w, float* m_lin, float* v_lin, float* x_sorted, const float* lin_old_t,
-                                   dr_stream_t stream);
+                                float* lin_w, float* m_lin, float* v_lin, float* x_sorted, const float* lin_old_t, uint32_t* table_amax, dr_stream_t stream);
 /* Dense Adam step (same formula) over a flat parameter buffer; grad is multiplied by grad_scale first. */
 /* TF's NON-lazy sparse Adam, evaluated lazily (examples/train_fm_on_movielens_estimator.py:51-52: tf.train.AdamOptimizer decays
  * m / v of the WHOLE variable and moves every row on every step).  row_step[R] int32 (zero-initialised) counts
@@ -377,6 +376,12 @@ int dr_linear_bwd_narrow_parts(const float* x, int64_t ld_x, const float* dy, in
                                int64_t ld_w, int64_t M, int32_t K, int32_t N, int32_t relu_mask, float scale,
                                float* dstW, int64_t ld_dstw, float* dstb, float* dx, int64_t ld_dx,
                                void* workspace, int64_t workspace_bytes, int32_t parts, dr_stream_t stream);
+/* ... that also leaves max |dx| as float bits in dx_amax[0] (reset and rebuilt by part 1): the amax record of dx for the f16x2 GEMMs
+ * (dr_h2_linear_nt / dr_h2_wgrad_emb below) */
+int dr_linear_bwd_narrow_amax(const float* x, int64_t ld_x, const float* dy, int64_t ld_dy, const float* W, int64_t ld_w, int64_t M,
+                              int32_t K, int32_t N, int32_t relu_mask, float scale, float* dstW, int64_t ld_dstw, float* dstb, float* dx,
+                              int64_t ld_dx, void* workspace, int64_t workspace_bytes, int32_t parts, uint32_t* dx_amax,
+                              dr_stream_t stream);
 int dr_tower_head_fwd_bwd_parts(const float* x, int64_t ld_x, const float* W1, int64_t ld_w1, const float* b1,
                                 int64_t M, int64_t n_total, int32_t K, int32_t H, int32_t act, const float* w2,
                                 int64_t ld_w2, const float* b2, const float* extra_logit, const float* labels,
@@ -675,6 +680,37 @@ int dr_bf3_gemm_tn(const void* x_planes, int64_t x_plane_stride, int64_t x_ld, c
                    int64_t y_plane_stride, int64_t y_ld, int64_t R, int32_t F, int32_t N, float scale, float* dst,
                    int64_t ld_dst, const float* y_colsum, float* dstb, void* workspace, int64_t workspace_bytes,
                    dr_stream_t stream);
+
+/* ---- "f16x2" operand mode of the first tower layer's three GEMMs (round 4) ---------------------------------------------------------
+ * The same products as dr_bf3_emb_linear_fwd_lv / dr_bf3_linear_nt / dr_bf3_wgrad(_emb) (keras/models/ranking/deepfm.py:30-34 of the
+ * reference and its autodiff; fp32 in, fp32 accumulate, fp32 out) with every operand value carried as TWO fp16 terms of x * s (22
+ * significant bits) and a product formed from THREE matrix instructions instead of the bf16x3 mode's six.  s is a power of two per
+ * TENSOR, derived inside the kernels from the tensor's `amax record`: one uint32 in device memory holding max |x| as float bits (or an
+ * upper bound of it).  Records are written by dr_h2_amax or maintained by the tensor's producer (dr_emb_pool_bwd_sorted_ex and
+ * dr_emb_pool_bwd_sorted_adam_ex keep the table's as a running maximum); a record that is too SMALL by a factor of 4 or more
+ * saturates values instead of producing inf (still wrong: keep it an upper bound).  Accuracy: tests/test_gpu_h2_gemm.py.
+ * Errors as the bf3 calls, plus DR_EINVAL for a missing record. */
+int dr_h2_amax(const float* src, int64_t ld, int64_t R, int32_t C, uint32_t* amax, int32_t reset, dr_stream_t stream);
+/* two fp16 planes of src * s(amax), laid out like dr_bf3_split's three (same arguments) */
+int dr_h2_split(const float* src, int64_t ld_src, int64_t R, int32_t C, void* planes, int64_t plane_stride, int64_t ld_planes,
+                int64_t row_offset, int64_t col_offset, int32_t transpose, const uint32_t* amax, dr_stream_t stream);
+int dr_h2_linear_nt(const float* A, int64_t lda, const uint32_t* a_amax, const void* b_planes, int64_t b_plane_stride, int64_t b_ld,
+                    const uint32_t* b_amax, int64_t M, int32_t N, int32_t K, const float* bias, int32_t act, const float* mask,
+                    int64_t ld_mask, int32_t accumulate, float* C, int64_t ldc, dr_stream_t stream);
+/* dense_amax: the record of dense_pad, required iff K > 64 F; lin_vals_t may be NULL */
+int dr_h2_emb_linear_fwd(const int64_t* ids, int64_t M, int32_t F, const int64_t* row_base, int64_t field_rows_max, const float* table,
+                         int32_t D, const uint32_t* table_amax, const float* lin_w, const float* lin_bias, const float* dense_pad,
+                         const uint32_t* dense_amax, float* concat, int64_t ld_concat, int32_t K, const void* wt_planes,
+                         int64_t plane_stride, int64_t ld_planes, const uint32_t* w_amax, int32_t N, const float* bias, int32_t act,
+                         float* sum_x, float* fm_logit, float* out, int64_t ld_out, float* lin_vals_t, dr_stream_t stream);
+int dr_h2_wgrad(const float* x, int64_t ld_x, const uint32_t* x_amax, const float* dy, int64_t ld_dy, const uint32_t* dy_amax, int64_t R,
+                int32_t F, int32_t N, float scale, float* dstW, int64_t ld_w, float* dstb, void* workspace, int64_t workspace_bytes,
+                dr_stream_t stream);
+int dr_h2_wgrad_emb(const int32_t* ids_t, int64_t R, int32_t nf, const int64_t* row_base, const float* table, int32_t D,
+                    const uint32_t* table_amax, const float* dense_pad, const uint32_t* dense_amax, const float* dy, int64_t ld_dy,
+                    const uint32_t* dy_amax, int32_t F, int32_t N, float scale, float* dstW, int64_t ld_w, float* dstb, void* workspace,
+                    int64_t workspace_bytes, int32_t parts, dr_stream_t stream);
+
 
 /* ------------------------------------------------------------------------------------------
  * CIN  Compressed Interaction Network layer of xDeepFM (keras/models/ranking/xdeepfm.py:71-96):
