@@ -543,7 +543,7 @@ def main():
             # the wide-tile GEMMs run on the bf16 pipe in the default mode (6 products per fp32 product); the narrow-tile
             # and fused-tail kernels always use the fp32 MFMA
             on_bf16 = a.gemm == "bf16x3" and re.match(r"^(linear|emb_linear|cross|[qc]_tower)_(fwd|bwd_dx|bwd_dw)_L\d+$", name) is not None
-            on_h2 = on_bf16 and bool(getattr(eng, "h2", False)) and name in H2_KERNELS
+            on_h2 = on_bf16 and bool(getattr(eng, "h2", False)) and (name in H2_KERNELS or bool(getattr(eng, "h2_all_wide", False)))
             ach, peak, unit = k["alg_flops"] / sec / 1e12, (MFMA_F16X2_PEAK_TF if on_h2 else MFMA_BF16X3_PEAK_TF if on_bf16 else MFMA_F32_PEAK_TF), "TFLOP/s"
         row = {"kernel": name, "bound": k["bound"], "achieved": round(ach, 2), "peak": round(peak, 1), "unit": unit,
                "frac": round(ach / peak, 4), "traffic": traffic.get(name), "avg_us": round(k["ms"] * 1e3, 2),

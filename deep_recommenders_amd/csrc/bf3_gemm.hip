@@ -540,6 +540,7 @@ struct RsArgs {
     const int64_t* pack_pos; int32_t pack_F; const float* pack_dl; const float* pack_sumx; float* pack_lin;
     // f16x2 mode (H2 kernels only): the amax records of A and of the tensor B's two planes were split from
     const uint32_t* a_amax; const uint32_t* b_amax;
+    uint32_t* c_amax;                            // (H2, may be null) out: raised to max |value stored into C| -- the record of the NEXT GEMM's operand
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -600,7 +601,7 @@ template <int EPI, int DBG = 0, int MS = 1, int CS = 1, int H2 = 0>
 __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_kernel(RsArgs g) {
     constexpr int NW = 8 * CS / MS, RGW = NW / CS, BM = 32 * MS * RGW, BN = 256, NT = BN / 32, NTW = NT / CS, NS = 3;
     static_assert(CS == 1 || (CS == 2 && MS == 2), "column split only with 64-row waves");
-    static_assert(!H2 || (MS == 1 && CS == 1 && (EPI == 0 || EPI == 1 || EPI == 3)), "f16x2: default shape, plain epilogues");
+    static_assert(!H2 || (CS == 1 && EPI != 5), "f16x2: no column split, no pack epilogue");
     constexpr int NPL = H2 ? 2 : 3;                                     // operand planes
     constexpr int B_PLANE = BN * 64;                                    // bytes: 256 rows x 64-byte rows (32 bf16 / fp16)
     constexpr int STAGE = NPL * B_PLANE;                                // 48 KB (32 KB)
@@ -651,6 +652,7 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
     const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<__bf16*>(g.B), 0, (int)min((int64_t)0x7fffffff, NPL * g.b_ps * 2), 0x00020000);
     float h2_sa = 1.f, h2_out = 1.f;                                    // H2: A's scale, 1 / (s_a s_b)
+    float cmax = 0.f;                                                   // H2: largest |value| this lane stored into C
     if constexpr (H2) {
         float ia, sb, ib;
         h2_scale_of(g.a_amax[0], h2_sa, ia);
@@ -824,7 +826,7 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl)
                         fa[ms][s2][pl] = __builtin_bit_cast(bf16x8, an[ms][2 * s2 + (pl & 1)]);
-            } else if constexpr (H2) {
+            } else if constexpr (H2 != 0) {
                 h2_split8(an[ms][0], an[ms][1], h2_sa, fa[ms][0][0], fa[ms][0][1]);
                 h2_split8(an[ms][2], an[ms][3], h2_sa, fa[ms][1][0], fa[ms][1][1]);
             } else {
@@ -883,11 +885,14 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
                 if (has_a) read_b(1, nstage, 1);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (H2) {
+            if constexpr (H2 && !(DBG & 2)) {
                 // smallest terms first: h_a l_b, l_a h_b, h_a h_b
-                acc[0][q & 7] = h2_mfma(fa[0][q >> 3][0], fb[q & 3][1], acc[0][q & 7]);
-                acc[0][q & 7] = h2_mfma(fa[0][q >> 3][1], fb[q & 3][0], acc[0][q & 7]);
-                acc[0][q & 7] = h2_mfma(fa[0][q >> 3][0], fb[q & 3][0], acc[0][q & 7]);
+                constexpr int HA[3] = {0, 1, 0}, HB[3] = {1, 0, 0};
+#pragma unroll
+                for (int term = 0; term < 3; ++term)
+#pragma unroll
+                    for (int ms = 0; ms < MS; ++ms)
+                        acc[ms][q & 7] = h2_mfma(fa[ms][q >> 3][HA[term]], fb[q & 3][HB[term]], acc[ms][q & 7]);
             } else if constexpr (!(DBG & 2)) {
                 // (MS == 2: the two row sets' chains interleaved or one after the other -- fenced, or the machine scheduler re-interleaves
                 // them -- measure the same)
@@ -899,7 +904,7 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
                         acc[ms][q & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ms][q >> 3][PA[term]], fb[q & 3][PB[term]],
                                                                                  acc[ms][q & 7], 0, 0, 0);
             } else {
-                acc[0][q & 7][0] += (float)fa[0][q >> 3][0][0] + (float)fb[q & 3][0][0] + (float)fb[q & 3][1][0] + (float)fb[q & 3][2][0];
+                acc[0][q & 7][0] += (float)fa[0][q >> 3][0][0] + (float)fb[q & 3][0][0] + (float)fb[q & 3][1][0] + (H2 ? 0.f : (float)fb[q & 3][2][0]);
             }
             __builtin_amdgcn_sched_barrier(0);    // keeps the next group's lgkmcnt wait from being hoisted between these MFMAs
             if (STG ? (q >= 6 && q < 6 + PW) : (MS == 2 ? q < PW : ((q & 1) == 1 && q < 2 * PW))) {
@@ -936,7 +941,7 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
 #pragma unroll
                     for (int nt = 0; nt < NTW; ++nt) {
                         const int col = cb0 + nt * 32 + l31;
-                        const float v = acc[ms][nt][reg];
+                        const float v = H2 ? acc[ms][nt][reg] * h2_out : acc[ms][nt][reg];
                         acc[ms][nt][reg] = 0.f;
                         const bool pass = rv && col < g.N && v > t;
                         const unsigned half = (unsigned)((__ballot(pass) >> (32 * hi)) & 0xffffffffull);
@@ -1030,10 +1035,12 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const int reg = 4 * c4 + e;
-                                const float pr = acc[ms][nt][reg] + bj + g.diag * xv[e];
+                                const float pr = (H2 ? fmaf(acc[ms][nt][reg], h2_out, bj) : acc[ms][nt][reg] + bj) + g.diag * xv[e];
                                 acc[ms][nt][reg] = 0.f;
                                 if (g.prod_out != nullptr) g.prod_out[xo + (int64_t)(e + 8 * c4) * g.ldx] = pr;
-                                crow[(int64_t)(e + 8 * c4) * g.ldc] = fmaf(x0v[e], pr, xv[e]);
+                                const float o = fmaf(x0v[e], pr, xv[e]);
+                                if constexpr (H2) cmax = fmaxf(cmax, fabsf(o));
+                                crow[(int64_t)(e + 8 * c4) * g.ldc] = o;
                             }
                         }
                     } else if constexpr (EPI == 1 || EPI == 3) {
@@ -1049,7 +1056,9 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
                                 float v = H2 ? fmaf(acc[ms][nt][reg], h2_out, bj) : acc[ms][nt][reg] + bj;
                                 acc[ms][nt][reg] = 0.f;
                                 v = relu ? fmaxf(v, 0.f) : v;
-                                crow[(int64_t)(e + 8 * c4) * g.ldc] = EPI == 1 ? (aux[e] > 0.f ? v : 0.f) : aux[e] + v;
+                                const float o = EPI == 1 ? (aux[e] > 0.f ? v : 0.f) : aux[e] + v;
+                                if constexpr (H2) cmax = fmaxf(cmax, fabsf(o));
+                                crow[(int64_t)(e + 8 * c4) * g.ldc] = o;
                             }
                         }
                     } else {
@@ -1057,6 +1066,7 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
                         for (int reg = 0; reg < 16; ++reg) {
                             float v = H2 ? fmaf(acc[ms][nt][reg], h2_out, bj) : acc[ms][nt][reg] + bj;
                             acc[ms][nt][reg] = 0.f;
+                            if constexpr (H2) cmax = fmaxf(cmax, relu ? fmaxf(v, 0.f) : fabsf(v));
                             if (DR_NT_DGRAD_STORE && EPI == 0) __builtin_nontemporal_store(relu ? fmaxf(v, 0.f) : v, &crow[(int64_t)((reg & 3) + 8 * (reg >> 2)) * g.ldc]);
                             else crow[(int64_t)((reg & 3) + 8 * (reg >> 2)) * g.ldc] = relu ? fmaxf(v, 0.f) : v;
                         }
@@ -1073,18 +1083,19 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
                             const float xv = g.xin[row * g.ldx + col];
                             const float pr = v + g.diag * xv;
                             if (g.prod_out != nullptr) g.prod_out[row * g.ldx + col] = pr;
-                            *dst = fmaf(g.x0[row * g.ldx + col], pr, xv);
+                            const float o = fmaf(g.x0[row * g.ldx + col], pr, xv);
+                            if constexpr (H2) cmax = fmaxf(cmax, fabsf(o));
+                            *dst = o;
                             continue;
                         }
                         v = relu ? fmaxf(v, 0.f) : v;
                         if constexpr (EPI == 1) {
                             if (!(g.mask[row * g.ld_mask + col] > 0.f)) v = 0.f;
-                            *dst = v;
                         } else if constexpr (EPI == 3) {
-                            *dst = *dst + v;
-                        } else {
-                            *dst = v;
+                            v = *dst + v;
                         }
+                        if constexpr (H2) cmax = fmaxf(cmax, fabsf(v));
+                        *dst = v;
                     }
                 }
                 // MS == 2: all 256 accumulators live in AGPRs; without a fence per column tile the scheduler copies them out
@@ -1100,6 +1111,14 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
         }
     }
     if (STG && !grp) asm volatile("s_barrier" ::: "memory");            // the leading group's extra barrier (see STG above)
+    if constexpr (H2 && EPI != 4) {
+        if (g.c_amax != nullptr) {                                      // (kernel-uniform) one load per wave, an atomic only if it raises the record
+            uint32_t m = __float_as_uint(cmax);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+            if (lane == 0 && m > __hip_atomic_load(g.c_amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(g.c_amax, m);
+        }
+    }
 }
 
 // =====================================================================================================================
@@ -2116,21 +2135,29 @@ __global__ __launch_bounds__(256) void bf3_split_kernel(const float* __restrict_
 // amax[0] = max(amax[0], max |src|) as float bits (non-negative floats order like their bit patterns; a NaN lands above inf)
 __global__ __launch_bounds__(256) void h2_amax_kernel(const float* __restrict__ src, int64_t ld, int64_t R, int32_t C,
                                                       uint32_t* __restrict__ amax) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     uint32_t m = 0u;
-    if ((C & 3) == 0 && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
-        const int cq = C >> 2;
-        const int64_t total = R * cq;
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-            const int64_t r = i / cq;
-            const float4 v = *reinterpret_cast<const float4*>(src + r * ld + (i - r * cq) * 4);
-            m = max(max(m, __float_as_uint(fabsf(v.x))), max(__float_as_uint(fabsf(v.y)), max(__float_as_uint(fabsf(v.z)), __float_as_uint(fabsf(v.w)))));
+    const bool al16 = (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+    auto take4 = [&](const float4& v) {
+        m = max(max(m, __float_as_uint(fabsf(v.x))), max(__float_as_uint(fabsf(v.y)), max(__float_as_uint(fabsf(v.z)), __float_as_uint(fabsf(v.w)))));
+    };
+    if (ld == C || R == 1) {                                            // contiguous: one flat stream, four 16-byte loads in flight
+        const int64_t n = R * (int64_t)C, nv = al16 ? (n >> 2) : 0;
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+        int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        for (; i + 3 * stride < nv; i += 4 * stride) {
+            const float4 v0 = s4[i], v1 = s4[i + stride], v2 = s4[i + 2 * stride], v3 = s4[i + 3 * stride];
+            take4(v0); take4(v1); take4(v2); take4(v3);
         }
-    } else {
-        const int64_t total = R * C;
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-            const int64_t r = i / C;
-            m = max(m, __float_as_uint(fabsf(src[r * ld + (i - r * C)])));
+        for (; i < nv; i += stride) take4(s4[i]);
+        for (int64_t j = (nv << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) m = max(m, __float_as_uint(fabsf(src[j])));
+    } else {                                                            // padded rows: a block per row (and stride)
+        const bool vec = al16 && (ld & 3) == 0;
+        const int cv = vec ? (C >> 2) : 0;
+        for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+            const float* row = src + r * ld;
+            for (int c = threadIdx.x; c < cv; c += blockDim.x) take4(reinterpret_cast<const float4*>(row)[c]);
+            for (int c = (cv << 2) + threadIdx.x; c < C; c += blockDim.x) m = max(m, __float_as_uint(fabsf(row[c])));
         }
     }
 #pragma unroll
@@ -2140,7 +2167,7 @@ __global__ __launch_bounds__(256) void h2_amax_kernel(const float* __restrict__ 
     __syncthreads();
     if (threadIdx.x == 0) {
         m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
-        if (m != 0u) atomicMax(amax, m);
+        if (m > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax, m);
     }
 }
 
@@ -2152,6 +2179,23 @@ __global__ __launch_bounds__(256) void h2_split_kernel(const float* __restrict__
     h2_scale_of(amax[0], sc, inv);
     h2_mode_on();
     const int64_t total = R * C, stride = (int64_t)gridDim.x * blockDim.x;
+    if (!transpose && (C & 3) == 0 && (ldp & 3) == 0 && (c0 & 3) == 0 && (ld_src & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(planes) & 7) == 0 && (ps & 3) == 0 && total < (int64_t)0x7fffffff) {
+        // four columns per thread: one 16-byte load, one 8-byte store per plane (the top-K scan splits the whole corpus through here)
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const unsigned cq = (unsigned)C >> 2, tq = (unsigned)(total >> 2);
+        for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < tq; i += (unsigned)stride) {
+            const unsigned r = i / cq, c = (i - r * cq) << 2;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + (int64_t)r * ld_src + c) * sc;
+            const f16x4 h = __builtin_convertvector(v, f16x4);
+            const f16x4 l = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), f16x4);
+            const int64_t off = (r0 + r) * ldp + c0 + c;
+            *reinterpret_cast<f16x4*>(planes + off) = h;
+            *reinterpret_cast<f16x4*>(planes + ps + off) = l;
+        }
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         // consecutive threads: consecutive DESTINATION elements (2-byte stores coalesce; the source is small and cached)
         int64_t r, c, off;
@@ -2186,7 +2230,35 @@ int rs_launch(const RsArgs& g, hipStream_t stream) {
     static const bool stg = [] { const char* e = getenv("DR_BF3_STAGGER"); return e != nullptr && e[0] == '1'; }();
     if (g.mask != nullptr && g.accumulate) return DR_EINVAL;            // (no caller needs both)
     if (g.a_amax != nullptr) {                                          // f16x2 operand mode
-        if (g.b_amax == nullptr || g.tau != nullptr || g.pack_pos != nullptr || g.x0 != nullptr) return DR_EINVAL;
+        if (g.b_amax == nullptr || g.pack_pos != nullptr) return DR_EINVAL;
+        if (g.c_amax != nullptr && hipMemsetAsync(g.c_amax, 0, sizeof(uint32_t), stream) != hipSuccess) return DR_ELAUNCH;
+        if (g.tau != nullptr) {
+            hipLaunchKernelGGL((bf3_gemm_rs_kernel<4, 0, 1, 1, 1>), dim3(grid), dim3(512), 0, stream, g);
+            DR_CHECK_LAUNCH();
+            return DR_OK;
+        }
+        if (g.x0 != nullptr) {
+            hipLaunchKernelGGL((bf3_gemm_rs_kernel<2, 0, 1, 1, 1>), dim3(grid), dim3(512), 0, stream, g);
+            DR_CHECK_LAUNCH();
+            return DR_OK;
+        }
+#ifdef DR_BF3_ABLATE
+        {   // tools/exp/h2_ablate.py: DR_BF3_RS_DBG = 32 no fragment reads, 64 no split, 96 both, 2 no MFMA; DR_BF3_RS64=1: 4 waves x 64 rows
+            static const int dbg = [] { const char* e = getenv("DR_BF3_RS_DBG"); return e ? atoi(e) : 0; }();
+            static const bool ms2 = [] { const char* e = getenv("DR_BF3_RS64"); return e != nullptr && e[0] == '1'; }();
+            if (g.mask == nullptr && !g.accumulate) {
+#define RS_ABL2(D)                                                                                                    \
+                if (dbg == D) {                                                                                       \
+                    if (ms2) hipLaunchKernelGGL((bf3_gemm_rs_kernel<0, D, 2, 1, 1>), dim3(grid), dim3(256), 0, stream, g); \
+                    else hipLaunchKernelGGL((bf3_gemm_rs_kernel<0, D, 1, 1, 1>), dim3(grid), dim3(512), 0, stream, g);     \
+                    DR_CHECK_LAUNCH();                                                                                \
+                    return DR_OK;                                                                                     \
+                }
+                RS_ABL2(0) RS_ABL2(32) RS_ABL2(64) RS_ABL2(96) RS_ABL2(2) RS_ABL2(1)
+#undef RS_ABL2
+            }
+        }
+#endif
         if (g.mask != nullptr) hipLaunchKernelGGL((bf3_gemm_rs_kernel<1, 0, 1, 1, 1>), dim3(grid), dim3(512), 0, stream, g);
         else if (g.accumulate) hipLaunchKernelGGL((bf3_gemm_rs_kernel<3, 0, 1, 1, 1>), dim3(grid), dim3(512), 0, stream, g);
         else hipLaunchKernelGGL((bf3_gemm_rs_kernel<0, 0, 1, 1, 1>), dim3(grid), dim3(512), 0, stream, g);
@@ -2371,7 +2443,6 @@ extern "C" int dr_bf3_linear_nt(const float* A, int64_t lda, const void* b_plane
     return rs_launch(g, dr_s(stream));
 }
 
-namespace {
 // ---- f16x2 operand mode (see h2_split8): amax records, the weight split, forward / dgrad on fp32 activations -----------------------
 // amax[0] = max(reset ? 0 : amax[0], max |src[r][c]|) as float bits.  The record of a GEMM operand must be >= its true largest
 // magnitude when the GEMM runs (a producer may keep a running maximum instead of an exact one).
@@ -2380,7 +2451,8 @@ extern "C" int dr_h2_amax(const float* src, int64_t ld, int64_t R, int32_t C, ui
     if (reset && hipMemsetAsync(amax, 0, sizeof(uint32_t), dr_s(stream)) != hipSuccess) return DR_ELAUNCH;
     if (R == 0 || C == 0) return DR_OK;
     if (!src) return DR_EINVAL;
-    hipLaunchKernelGGL(h2_amax_kernel, dim3(dr_grid_for(R * ((C + 3) / 4), 256)), dim3(256), 0, dr_s(stream), src, ld, R, C, amax);
+    const int grid = (ld == C || R == 1) ? dr_grid_for(R * ((C + 3) / 4), 256 * 4) : (int)(R < 4096 ? R : 4096);
+    hipLaunchKernelGGL(h2_amax_kernel, dim3(grid), dim3(256), 0, dr_s(stream), src, ld, R, C, amax);
     DR_CHECK_LAUNCH();
     return DR_OK;
 }
@@ -2402,9 +2474,11 @@ extern "C" int dr_h2_split(const float* src, int64_t ld_src, int64_t R, int32_t 
 }
 
 // dr_bf3_linear_nt in the f16x2 mode: b_planes = two fp16 planes (dr_h2_split with b_amax), A fp32 with the record a_amax.
+// c_amax (may be NULL): reset, then raised to max |value stored into C| -- the record the next GEMM wants for C as ITS operand.
 extern "C" int dr_h2_linear_nt(const float* A, int64_t lda, const uint32_t* a_amax, const void* b_planes, int64_t b_plane_stride,
                                int64_t b_ld, const uint32_t* b_amax, int64_t M, int32_t N, int32_t K, const float* bias, int32_t act,
-                               const float* mask, int64_t ld_mask, int32_t accumulate, float* C, int64_t ldc, dr_stream_t stream) {
+                               const float* mask, int64_t ld_mask, int32_t accumulate, float* C, int64_t ldc, uint32_t* c_amax,
+                               dr_stream_t stream) {
     if (M < 0 || N <= 0 || K <= 0 || act < 0 || act > 1 || !a_amax || !b_amax) return DR_EINVAL;
     if (M == 0) return DR_OK;
     if (!A || !C || !planes_ok(b_planes, b_plane_stride, b_ld)) return DR_EINVAL;
@@ -2414,9 +2488,44 @@ extern "C" int dr_h2_linear_nt(const float* A, int64_t lda, const uint32_t* a_am
              nullptr, nullptr, 0, 0.f, nullptr};
     g.a_amax = a_amax;
     g.b_amax = b_amax;
+    g.c_amax = c_amax;
     return rs_launch(g, dr_s(stream));
 }
 
+// dr_bf3_cross_fwd in the f16x2 mode (DCN cross layer, keras/models/ranking/dcn.py:81-88): x_amax the record of x (the GEMM's
+// activation operand), wt_planes two fp16 planes of W^T with w_amax; out_amax (may be NULL) receives the record of `out`, which is
+// the next cross layer's x.
+extern "C" int dr_h2_cross_fwd(const float* x0, const float* x, int64_t ld, const uint32_t* x_amax, const void* wt_planes,
+                               int64_t plane_stride, int64_t ld_planes, const uint32_t* w_amax, const float* b, float diag_scale,
+                               int64_t M, int32_t Dm, float* out, float* prod_out, uint32_t* out_amax, dr_stream_t stream) {
+    if (M < 0 || Dm <= 0 || diag_scale < 0.f || !x_amax || !w_amax) return DR_EINVAL;
+    if (M == 0) return DR_OK;
+    if (!x0 || !x || !out || !planes_ok(wt_planes, plane_stride, ld_planes)) return DR_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) != 0 || (ld & 3) != 0 || ld < Dm || ld_planes < (Dm + BK - 1) / BK * BK) return DR_EINVAL;
+    RsArgs g{x, ld, static_cast<const __bf16*>(wt_planes), plane_stride, ld_planes, M, Dm, Dm, out, ld, b, 0, nullptr, 0, 0,
+             x0, x, ld, diag_scale, prod_out};
+    g.a_amax = x_amax;
+    g.b_amax = w_amax;
+    g.c_amax = out_amax;
+    return rs_launch(g, dr_s(stream));
+}
+
+// dr_bf3_scores_filter in the f16x2 mode (retrieval.hip's top-K scan)
+int dr_h2_scores_filter(const float* a, int64_t lda, const uint32_t* a_amax, const void* b_planes, int64_t b_plane_stride, int64_t b_ld,
+                        const uint32_t* b_amax, int64_t M, int32_t N, int32_t K, const float* tau, float* cand_s, int32_t* cand_c,
+                        int32_t* cand_cnt, int64_t cand_cap, dr_stream_t stream) {
+    if (M < 0 || N <= 0 || K <= 0 || cand_cap <= 0 || !a_amax || !b_amax) return DR_EINVAL;
+    if (M == 0) return DR_OK;
+    if (!a || !tau || !cand_s || !cand_c || !cand_cnt || !planes_ok(b_planes, b_plane_stride, b_ld)) return DR_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(a) & 15) != 0 || (lda & 3) != 0 || lda < K || b_ld < (K + BK - 1) / BK * BK) return DR_EINVAL;
+    RsArgs g{a, lda, static_cast<const __bf16*>(b_planes), b_plane_stride, b_ld, M, N, K, nullptr, 0, nullptr, 0, nullptr, 0, 0,
+             nullptr, nullptr, 0, 0.f, nullptr, tau, cand_s, cand_c, cand_cnt, cand_cap};
+    g.a_amax = a_amax;
+    g.b_amax = b_amax;
+    return rs_launch(g, dr_s(stream));
+}
+
+namespace {
 __global__ __launch_bounds__(256) void bf3_pack_bias_kernel(const float* dl, int64_t n, float* bias_sum) {
     dr_block_sum_axpy(dl, n, 1.f, bias_sum);
 }

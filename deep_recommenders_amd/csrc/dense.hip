@@ -818,9 +818,11 @@ __global__ __launch_bounds__(256) void cross_combine_bwd_kernel(const float* __r
                                                                 const float* __restrict__ prod,
                                                                 const float* __restrict__ d_out, int64_t M, int32_t Dm,
                                                                 int64_t ld, float diag, float* __restrict__ d_prod,
-                                                                float* __restrict__ d_x0, float* __restrict__ d_x) {
+                                                                float* __restrict__ d_x0, float* __restrict__ d_x,
+                                                                uint32_t* __restrict__ dp_amax) {
     const int64_t n = M * Dm;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    float mx = 0.f;                                           // (dp_amax != NULL: the record of d_prod for the f16x2 GEMMs that read it)
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const int64_t r = i / Dm;
         const int c = (int)(i - r * Dm);
@@ -828,8 +830,15 @@ __global__ __launch_bounds__(256) void cross_combine_bwd_kernel(const float* __r
         const float go = d_out[o];
         const float dp = go * x0[o];
         d_prod[o] = dp;
+        mx = fmaxf(mx, fabsf(dp));
         if (d_x0 != nullptr) d_x0[o] += go * prod[o];
         if (d_x != nullptr) d_x[o] += go + diag * dp;
+    }
+    if (dp_amax != nullptr) {
+        uint32_t m = __float_as_uint(mx);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+        if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(dp_amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dp_amax, m);
     }
 }
 
@@ -1251,7 +1260,22 @@ extern "C" int dr_cross_combine_bwd(const float* x0, const float* prod, const fl
     if (M == 0) return DR_OK;
     if (!x0 || !prod || !d_out || !d_prod || ld < Dm) return DR_EINVAL;
     hipLaunchKernelGGL(cross_combine_bwd_kernel, dim3(dr_grid_for(M * Dm, 256)), dim3(256), 0, dr_s(stream), x0, prod,
-                       d_out, M, Dm, ld, diag_scale, d_prod, d_x0_accum, d_x_accum);
+                       d_out, M, Dm, ld, diag_scale, d_prod, d_x0_accum, d_x_accum, static_cast<uint32_t*>(nullptr));
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+// ... that also leaves max |d_prod| (float bits) in d_prod_amax[0] (reset first): the amax record of d_prod for the f16x2 GEMMs that
+// take it as an operand (dr_h2_linear_nt, dr_h2_wgrad)
+extern "C" int dr_cross_combine_bwd_amax(const float* x0, const float* prod, const float* d_out, int64_t M, int32_t Dm,
+                                         int64_t ld, float diag_scale, float* d_prod, float* d_x0_accum, float* d_x_accum,
+                                         uint32_t* d_prod_amax, dr_stream_t stream) {
+    if (M < 0 || Dm <= 0 || !d_prod_amax) return DR_EINVAL;
+    if (hipMemsetAsync(d_prod_amax, 0, sizeof(uint32_t), dr_s(stream)) != hipSuccess) return DR_ELAUNCH;
+    if (M == 0) return DR_OK;
+    if (!x0 || !prod || !d_out || !d_prod || ld < Dm) return DR_EINVAL;
+    hipLaunchKernelGGL(cross_combine_bwd_kernel, dim3(dr_grid_for(M * Dm, 256)), dim3(256), 0, dr_s(stream), x0, prod,
+                       d_out, M, Dm, ld, diag_scale, d_prod, d_x0_accum, d_x_accum, d_prod_amax);
     DR_CHECK_LAUNCH();
     return DR_OK;
 }

@@ -225,7 +225,8 @@ extern "C" int dr_topk_select(const float* scores, int64_t ld, int64_t Bq, int64
 
 // workspace = [append cursors Bq x i32][tau Bq x f32] (256-B aligned) + Bq x chunk x 8 B, used as a dense score matrix
 // [Bq, chunk] for the first chunk and as candidate lists (scores + columns, capacity = chunk: cannot overflow) afterwards
-static int64_t topk_hdr_bytes(int64_t Bq) { return (Bq * 8 + 255) / 256 * 256; }
+// (+ two amax records behind tau: the queries' and the corpus', for the f16x2 scan)
+static int64_t topk_hdr_bytes(int64_t Bq) { return (Bq * 8 + 8 + 255) / 256 * 256; }
 
 // corpus chunk of the scan: ~256 MB of [Bq, chunk] scores (1024 output tiles of the register-split GEMM at Bq = 8192: 4 per CU)
 constexpr int64_t TOPK_MAX_COLS = 32768;      // longest chunk of the scan (dense first chunk and filtered chunks alike)
@@ -284,6 +285,17 @@ extern "C" int dr_bf3_linear_nt(const float* A, int64_t lda, const void* b_plane
                                 int32_t N, int32_t K, const float* bias, int32_t act, const float* mask, int64_t ld_mask,
                                 int32_t accumulate, float* C, int64_t ldc, dr_stream_t stream);
 extern "C" int32_t dr_get_gemm_mode(void);
+// the same three in the f16x2 operand mode (bf3_gemm.hip; include/dr_hotpath.h "f16x2 operand mode")
+int dr_h2_scores_filter(const float* a, int64_t lda, const uint32_t* a_amax, const void* b_planes, int64_t b_plane_stride, int64_t b_ld,
+                        const uint32_t* b_amax, int64_t M, int32_t N, int32_t K, const float* tau, float* cand_s, int32_t* cand_c,
+                        int32_t* cand_cnt, int64_t cand_cap, dr_stream_t stream);
+extern "C" int dr_h2_amax(const float* src, int64_t ld, int64_t R, int32_t C, uint32_t* amax, int32_t reset, dr_stream_t stream);
+extern "C" int dr_h2_split(const float* src, int64_t ld_src, int64_t R, int32_t C, void* planes, int64_t plane_stride, int64_t ld_planes,
+                           int64_t row_offset, int64_t col_offset, int32_t transpose, const uint32_t* amax, dr_stream_t stream);
+extern "C" int dr_h2_linear_nt(const float* A, int64_t lda, const uint32_t* a_amax, const void* b_planes, int64_t b_plane_stride,
+                               int64_t b_ld, const uint32_t* b_amax, int64_t M, int32_t N, int32_t K, const float* bias, int32_t act,
+                               const float* mask, int64_t ld_mask, int32_t accumulate, float* C, int64_t ldc, uint32_t* c_amax,
+                               dr_stream_t stream);
 
 __global__ __launch_bounds__(256) void zero_i32_kernel(int32_t* __restrict__ p, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -327,6 +339,18 @@ extern "C" int dr_topk_mips(const float* q, int64_t Bq, const float* cand, int64
     float* cand_s = dense;                                                    // [Bq, scan] candidate scores (later chunks)
     int32_t* cand_c = reinterpret_cast<int32_t*>(wsb + hdr + Bq * scan * 4);  // [Bq, scan] candidate columns
     void* planes = wsb + hdr + Bq * scan * 8;
+    // f16x2 operand mode of the scan (round 4; DR_GEMM_SPLIT=bf16x3 restores the six-product scan): queries and corpus as two fp16 terms
+    // of x * 2^k, three matrix instructions per fragment pair.  ONE scale for the whole corpus (a pass over it: 0.1 ms per million
+    // 128-wide items) and one for the queries, so that equal candidates still tie bit-exactly whichever chunk they sit in.
+    static const bool h2_env = [] { const char* e = getenv("DR_GEMM_SPLIT"); return !(e != nullptr && e[0] == 'b'); }();
+    const bool h2 = rs_scan && h2_env;
+    uint32_t* rec_q = reinterpret_cast<uint32_t*>(wsb + Bq * 8);
+    uint32_t* rec_c = rec_q + 1;
+    if (h2) {
+        int rc = dr_h2_amax(q, D, Bq, D, rec_q, 1, stream);
+        if (rc == DR_OK) rc = dr_h2_amax(cand, D, N, D, rec_c, 1, stream);
+        if (rc != DR_OK) return rc;
+    }
     const int64_t p_rows = (scan + 31) / 32 * 32, p_ld = ((int64_t)D + 31) / 32 * 32, p_ps = p_rows * p_ld;
     if (rs_scan && (D % 32) != 0)      // the reduction padding of the planes must be zero (the kernel multiplies it)
         if (hipMemsetAsync(planes, 0, (size_t)(3 * p_ps * 2), dr_s(stream)) != hipSuccess) return DR_ELAUNCH;
@@ -340,18 +364,22 @@ extern "C" int dr_topk_mips(const float* q, int64_t Bq, const float* cand, int64
         const int64_t len = c0 == 0 ? chunk : scan;
         const int64_t nc = N - c0 < len ? N - c0 : len;
         if (rs_scan) {
-            int rc = dr_bf3_split(cand + c0 * D, D, nc, D, planes, p_ps, p_ld, 0, 0, 0, stream);
+            int rc = h2 ? dr_h2_split(cand + c0 * D, D, nc, D, planes, p_ps, p_ld, 0, 0, 0, rec_c, stream)
+                        : dr_bf3_split(cand + c0 * D, D, nc, D, planes, p_ps, p_ld, 0, 0, 0, stream);
             if (rc != DR_OK) return rc;
         }
         if (c0 == 0) {
-            int rc = rs_scan ? dr_bf3_linear_nt(q, D, planes, p_ps, p_ld, Bq, (int32_t)nc, D, nullptr, 0, nullptr, 0, 0, dense, chunk, stream)
+            int rc = h2 ? dr_h2_linear_nt(q, D, rec_q, planes, p_ps, p_ld, rec_c, Bq, (int32_t)nc, D, nullptr, 0, nullptr, 0, 0, dense, chunk,
+                                          nullptr, stream)
+                     : rs_scan ? dr_bf3_linear_nt(q, D, planes, p_ps, p_ld, Bq, (int32_t)nc, D, nullptr, 0, nullptr, 0, 0, dense, chunk, stream)
                              : dr_scores_nt(q, D, cand, D, Bq, (int32_t)nc, D, dense, chunk, stream);
             if (rc != DR_OK) return rc;
             if (N > chunk) hipLaunchKernelGGL(zero_i32_kernel, dim3(dr_grid_for(Bq, 256)), dim3(256), 0, dr_s(stream), cnt, Bq);
             hipLaunchKernelGGL(topk_select_kernel, dim3(sel_grid), dim3(256), 0, dr_s(stream), dense, chunk, Bq, nc, k,
                                index_base, first, out_scores, out_index, (const int32_t*)nullptr, (int32_t*)nullptr, tau);
         } else {
-            int rc = rs_scan ? dr_bf3_scores_filter(q, D, planes, p_ps, p_ld, Bq, (int32_t)nc, D, tau, cand_s, cand_c, cnt, scan, stream)
+            int rc = h2 ? dr_h2_scores_filter(q, D, rec_q, planes, p_ps, p_ld, rec_c, Bq, (int32_t)nc, D, tau, cand_s, cand_c, cnt, scan, stream)
+                     : rs_scan ? dr_bf3_scores_filter(q, D, planes, p_ps, p_ld, Bq, (int32_t)nc, D, tau, cand_s, cand_c, cnt, scan, stream)
                              : dr_scores_nt_filter(q, D, cand + c0 * D, D, Bq, (int32_t)nc, D, tau, cand_s, cand_c, cnt, scan, stream);
             if (rc != DR_OK) return rc;
             hipLaunchKernelGGL(topk_select_kernel, dim3(sel_grid), dim3(256), 0, dr_s(stream), cand_s, scan, Bq, nc, k,

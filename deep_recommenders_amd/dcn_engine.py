@@ -56,10 +56,23 @@ class DCNEngine:
         # forward / dgrad GEMMs on pre-split weights (see DeepFMEngine); DR_PLANES=0: the in-kernel-split GEMMs
         import os as _os
         on = _os.environ.get("DR_PLANES", "1") == "1"
-        self.cross_planes = [ops.WeightPlanes(W) if on and ops.planes_worthwhile(B, self.in_dim, self.in_dim) else None
+        # "f16x2" operand mode of every wide GEMM (round 4; see DeepFMEngine / include/dr_hotpath.h dr_h2_*): three matrix
+        # instructions per fragment pair instead of six.  Every GEMM's activation operand needs its amax record: x0's is built by
+        # one dr_h2_amax pass, every later operand's comes out of the kernel that PRODUCES it (the GEMM epilogues' c_amax, the cross
+        # combine backward's d_prod_amax).  DR_GEMM_SPLIT=bf16x3 restores the six-product mode.
+        self.h2 = on and _os.environ.get("DR_GEMM_SPLIT", "f16x2") == "f16x2" and ops.planes_worthwhile(B, self.in_dim, self.in_dim)
+        self.h2_all_wide = self.h2                               # (bench.py: every planes GEMM of this engine is priced as f16x2)
+        WP = ops.H2WeightPlanes if self.h2 else ops.WeightPlanes
+        self.cross_planes = [WP(W) if on and ops.planes_worthwhile(B, self.in_dim, self.in_dim) else None
                              for W in self.cross_W]
-        self.wplanes = [ops.WeightPlanes(W) if on and u > 1 and ops.planes_worthwhile(B, W.shape[0], W.shape[1]) else None
+        self.wplanes = [WP(W) if on and u > 1 and ops.planes_worthwhile(B, W.shape[0], W.shape[1]) else None
                         for W, u in zip(self.Ws, units)]
+        if self.h2:
+            rec = lambda: ops.h2_record(device)
+            self.x_amax = [rec() for _ in range(num_cross + 1)]          # x_0 .. x_L
+            self.h_amax = [rec() for _ in units]                         # MLP activations h_i
+            self.dh_amax = [rec() for _ in units]                        # their gradients (dy of layer i)
+            self.dp_amax = rec()                                         # d_prod of the cross layer being differentiated
         self.row_base = torch.arange(F, device=device, dtype=torch.int64) * V
         self.col_buckets = torch.full((F,), V, dtype=torch.int64, device=device)
         self.ids = torch.empty((B, F), dtype=torch.int64, device=device)
@@ -132,10 +145,17 @@ class DCNEngine:
         if self.Nd:
             self.x0[:, F * D:F * D + self.Nd].copy_(dense)
         x0 = self.x0[:, :n_in]
+        h2 = self.h2
+        if h2:
+            self._k("h2_amax_x0", "hbm", 4.0 * B * n_in, lambda: ops.h2_amax(x0, self.x_amax[0]))
         xs, prods = [x0], []
         fl_c = 2.0 * B * n_in * n_in
         for l, (W, b) in enumerate(zip(self.cross_W, self.cross_b)):
-            if self.cross_planes[l] is not None:
+            if h2:
+                out, prod = self._k("cross_fwd_L%d" % l, "mfma", fl_c,
+                                    lambda x=xs[-1], b=b, l=l: ops.h2_cross_fwd(x0, x, self.x_amax[l], self.cross_planes[l].wt, b, self.diag,
+                                                                                want_prod=True, out_amax=self.x_amax[l + 1]))
+            elif self.cross_planes[l] is not None:
                 out, prod = self._k("cross_fwd_L%d" % l, "mfma", fl_c,
                                     lambda x=xs[-1], b=b, l=l: ops.bf3_cross_fwd(x0, x, self.cross_planes[l].wt, b, self.diag, want_prod=True))
             else:
@@ -144,7 +164,18 @@ class DCNEngine:
             xs.append(out)
             prods.append(prod)
         x = xs[-1]
+        xam = self.x_amax[-1] if h2 else None                 # record of the current MLP input (None: not known)
         for i, (W, b) in enumerate(zip(self.Ws, self.bs)):
+            if h2 and self.wplanes[i] is not None:
+                if xam is None:
+                    xam = ops.h2_amax(x, self.h_amax[i - 1])
+                self._k("linear_fwd_L%d" % i, "mfma", 2.0 * B * W.shape[0] * W.shape[1],
+                        lambda x=x, b=b, i=i, xam=xam: ops.h2_linear_nt(x, xam, self.wplanes[i].wt, bias=b, act=self.acts[i], out=self.hs[i],
+                                                                        out_amax=self.h_amax[i]))
+                xam = self.h_amax[i]
+                x = self.hs[i]
+                continue
+            xam = None
             if self.wplanes[i] is not None:
                 self._k("linear_fwd_L%d" % i, "mfma", 2.0 * B * W.shape[0] * W.shape[1],
                         lambda x=x, b=b, i=i: ops.bf3_linear_nt(x, self.wplanes[i].wt, bias=b, act=self.acts[i], out=self.hs[i]))
@@ -156,6 +187,7 @@ class DCNEngine:
                         out=(self.prob, self.d_logit, self.loss))
         # ---- backward: MLP ---------------------------------------------------------------------------------------------
         dy = self.d_logit.reshape(-1, 1)
+        dyam = None                                           # record of dy (None: not known, built by a pass when a GEMM wants it)
         for i in range(len(self.Ws) - 1, -1, -1):
             xin = xs[-1] if i == 0 else self.hs[i - 1]
             W = self.Ws[i]
@@ -164,6 +196,21 @@ class DCNEngine:
                 dx, rs = self.dhs[i - 1], (self.hs[i - 1] if self.acts[i - 1] else None)
             else:
                 dx, rs = self.d_top[:, :n_in], None
+            if h2 and self.wplanes[i] is not None:
+                if dyam is None:
+                    dyam = ops.h2_amax(dy, self.dh_amax[i])
+                xinam = self.x_amax[-1] if i == 0 else self.h_amax[i - 1]
+                dxam = self.dh_amax[i - 1] if i > 0 else None
+                self._k("linear_bwd_dx_L%d" % i, "mfma", fl,
+                        lambda dy=dy, rs=rs, dx=dx, i=i, dyam=dyam, dxam=dxam: ops.h2_linear_nt(dy, dyam, self.wplanes[i].w, mask=rs, out=dx,
+                                                                                                out_amax=dxam))
+                self._k("linear_bwd_dw_L%d" % i, "mfma", fl,
+                        lambda xin=xin, dy=dy, W=W, i=i, dyam=dyam, xinam=xinam: ops.h2_wgrad(xin, xinam, dy, dyam, -lr, W, self.bs[i],
+                                                                                              workspace=self.wg_ws[i]))
+                self.wplanes[i].refresh()
+                dy, dyam = dx, dxam
+                continue
+            dyam = None
             if self.wplanes[i] is not None:
                 self._k("linear_bwd_dx_L%d" % i, "mfma", fl,
                         lambda dy=dy, rs=rs, dx=dx, i=i: ops.bf3_linear_nt(dy, self.wplanes[i].w, mask=rs, out=dx))
@@ -188,11 +235,22 @@ class DCNEngine:
                 # combine kernel) -- no zero-filled d_x, no read-modify-write of it in the combine pass: -1.3 GB per layer
                 d_x = d_out
                 d_prod = self._k("cross_combine_bwd_L%d" % l, "hbm", 6.0 * 4 * B * n_in,
-                                 lambda l=l, d_out=d_out: ops.cross_combine_bwd(x0, prods[l], d_out, 0.0, d_x0, None))
+                                 lambda l=l, d_out=d_out: ops.cross_combine_bwd(x0, prods[l], d_out, 0.0, d_x0, None,
+                                                                                d_prod_amax=self.dp_amax if h2 else None))
             else:
                 d_x = torch.zeros((B, self.ld), dtype=torch.float32, device=d_out.device)[:, :n_in]
                 d_prod = self._k("cross_combine_bwd_L%d" % l, "hbm", 6.0 * 4 * B * n_in,
-                                 lambda l=l, d_out=d_out, d_x=d_x: ops.cross_combine_bwd(x0, prods[l], d_out, self.diag, d_x0, d_x))
+                                 lambda l=l, d_out=d_out, d_x=d_x: ops.cross_combine_bwd(x0, prods[l], d_out, self.diag, d_x0, d_x,
+                                                                                         d_prod_amax=self.dp_amax if h2 else None))
+            if h2:
+                self._k("cross_bwd_dx_L%d" % l, "mfma", fl_c,
+                        lambda d_prod=d_prod, l=l, d_x=d_x: ops.h2_linear_nt(d_prod, self.dp_amax, self.cross_planes[l].w, accumulate=True, out=d_x))
+                self._k("cross_bwd_dw_L%d" % l, "mfma", fl_c,
+                        lambda l=l, d_prod=d_prod, W=W: ops.h2_wgrad(xs[l], self.x_amax[l], d_prod, self.dp_amax, -lr, W, self.cross_b[l],
+                                                                     workspace=self.cross_wg_ws))
+                self.cross_planes[l].refresh()
+                d_out = d_x
+                continue
             if self.cross_planes[l] is not None:
                 self._k("cross_bwd_dx_L%d" % l, "mfma", fl_c,
                         lambda d_prod=d_prod, l=l, d_x=d_x: ops.bf3_linear_nt(d_prod, self.cross_planes[l].w, accumulate=True, out=d_x))

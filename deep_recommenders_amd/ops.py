@@ -332,12 +332,16 @@ def cross_fwd(x0, x, W, b, diag_scale=0.0, want_prod=False, prod=None):
     return out, prod
 
 
-def cross_combine_bwd(x0, prod, d_out, diag_scale, d_x0_accum, d_x_accum):
+def cross_combine_bwd(x0, prod, d_out, diag_scale, d_x0_accum, d_x_accum, d_prod_amax=None):
     M, Dm = d_out.shape
     ld = d_out.stride(0)
     for t in (x0, prod, d_x0_accum, d_x_accum):
         assert t is None or t.stride(0) == ld, "cross tensors must share one leading dimension"
     d_prod = torch.empty((M, ld), dtype=torch.float32, device=d_out.device)[:, :Dm]
+    if d_prod_amax is not None:     # also the amax record of d_prod (operand of the cross layer's f16x2 dgrad / wgrad)
+        check(lib().dr_cross_combine_bwd_amax(ptr(x0), ptr(prod), ptr(d_out), M, Dm, ld, float(diag_scale), ptr(d_prod),
+                                              ptr(d_x0_accum), ptr(d_x_accum), ptr(d_prod_amax), stream_ptr()), "dr_cross_combine_bwd_amax")
+        return d_prod
     check(lib().dr_cross_combine_bwd(ptr(x0), ptr(prod), ptr(d_out), M, Dm, ld, float(diag_scale), ptr(d_prod),
                                      ptr(d_x0_accum), ptr(d_x_accum), stream_ptr()), "dr_cross_combine_bwd")
     return d_prod
@@ -1117,8 +1121,9 @@ def h2_split(src, planes: H2Planes, row_offset=0, col_offset=0, transpose=False)
     return planes
 
 
-def h2_linear_nt(a, a_amax, b: H2Planes, bias=None, act=0, mask=None, accumulate=False, out=None):
-    """bf3_linear_nt in the f16x2 mode: a fp32 [M, K] with its amax record, b the weights as H2Planes."""
+def h2_linear_nt(a, a_amax, b: H2Planes, bias=None, act=0, mask=None, accumulate=False, out=None, out_amax=None):
+    """bf3_linear_nt in the f16x2 mode: a fp32 [M, K] with its amax record, b the weights as H2Planes.  out_amax (a record, optional)
+    receives max |out|: what the next GEMM needs to take `out` as ITS operand."""
     a = _rowmajor_ld4(a)
     M, K = a.shape
     if a.stride(0) % 4 or a.data_ptr() % 16:
@@ -1133,8 +1138,23 @@ def h2_linear_nt(a, a_amax, b: H2Planes, bias=None, act=0, mask=None, accumulate
     assert out.shape == (M, N) and out.stride(1) == 1
     check(lib().dr_h2_linear_nt(ptr(a), a.stride(0), ptr(a_amax), ptr(b.buf), b.plane_stride, b.ld, ptr(b.amax), M, N, K, ptr(bias), int(act),
                                 ptr(mask), mask.stride(0) if mask is not None else 0, int(bool(accumulate)), ptr(out), out.stride(0),
-                                stream_ptr()), "dr_h2_linear_nt")
+                                ptr(out_amax), stream_ptr()), "dr_h2_linear_nt")
     return out
+
+
+def h2_cross_fwd(x0, x, x_amax, wt: H2Planes, b=None, diag_scale=0.0, want_prod=False, prod=None, out_amax=None):
+    """bf3_cross_fwd in the f16x2 mode (x_amax: the record of x; out_amax: receives the record of out)."""
+    M, Dm = x.shape
+    assert x0.shape == x.shape and x0.stride(0) == x.stride(0) and wt.rows == Dm and wt.cols == Dm
+    ld = x.stride(0)
+    out = torch.empty((M, ld), dtype=torch.float32, device=x.device)[:, :Dm]
+    if want_prod and prod is None:
+        prod = torch.empty((M, ld), dtype=torch.float32, device=x.device)[:, :Dm]
+    if prod is not None:
+        assert prod.stride(0) == ld
+    check(lib().dr_h2_cross_fwd(ptr(x0), ptr(x), ld, ptr(x_amax), ptr(wt.buf), wt.plane_stride, wt.ld, ptr(wt.amax), ptr(b), float(diag_scale),
+                                M, Dm, ptr(out), ptr(prod), ptr(out_amax), stream_ptr()), "dr_h2_cross_fwd")
+    return out, prod
 
 
 def h2_emb_linear_fwd(ids, row_base, field_rows_max, table, table_amax, lin_w, lin_bias, dense_pad, dense_amax, concat, K, wt: H2Planes, bias, act,

@@ -696,7 +696,14 @@ int dr_h2_split(const float* src, int64_t ld_src, int64_t R, int32_t C, void* pl
                 int64_t row_offset, int64_t col_offset, int32_t transpose, const uint32_t* amax, dr_stream_t stream);
 int dr_h2_linear_nt(const float* A, int64_t lda, const uint32_t* a_amax, const void* b_planes, int64_t b_plane_stride, int64_t b_ld,
                     const uint32_t* b_amax, int64_t M, int32_t N, int32_t K, const float* bias, int32_t act, const float* mask,
-                    int64_t ld_mask, int32_t accumulate, float* C, int64_t ldc, dr_stream_t stream);
+                    int64_t ld_mask, int32_t accumulate, float* C, int64_t ldc, uint32_t* c_amax, dr_stream_t stream);
+/* c_amax / out_amax (may be NULL): reset, then raised to max |value stored into C / out| -- the record of the NEXT GEMM's operand */
+int dr_h2_cross_fwd(const float* x0, const float* x, int64_t ld, const uint32_t* x_amax, const void* wt_planes, int64_t plane_stride,
+                    int64_t ld_planes, const uint32_t* w_amax, const float* b, float diag_scale, int64_t M, int32_t Dm, float* out,
+                    float* prod_out, uint32_t* out_amax, dr_stream_t stream);
+/* dr_cross_combine_bwd that also leaves the record of d_prod (the operand of the cross layer's dgrad and wgrad) */
+int dr_cross_combine_bwd_amax(const float* x0, const float* prod, const float* d_out, int64_t M, int32_t Dm, int64_t ld, float diag_scale,
+                              float* d_prod, float* d_x0_accum, float* d_x_accum, uint32_t* d_prod_amax, dr_stream_t stream);
 /* dense_amax: the record of dense_pad, required iff K > 64 F; lin_vals_t may be NULL */
 int dr_h2_emb_linear_fwd(const int64_t* ids, int64_t M, int32_t F, const int64_t* row_base, int64_t field_rows_max, const float* table,
                          int32_t D, const uint32_t* table_amax, const float* lin_w, const float* lin_bias, const float* dense_pad,

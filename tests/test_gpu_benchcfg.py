@@ -76,7 +76,7 @@ def _assert_update(name, before, after, want_after, rel=2e-3, outliers=1e-4):
     bad = err > tol
     frac = float(bad.mean())
     assert frac <= outliers, "%s: %.2e of %d elements off (allowed %.0e); worst |err| %.3e at update %.3e (rms update %.3e)" % (
-        name, frac, bad.size, float(err[bad].max()), float(np.abs(d_cpu)[bad].max()), rms)
+        name, frac, bad.size, outliers, float(err[bad].max()), float(np.abs(d_cpu)[bad].max()), rms)
     if bad.any():
         assert bool((err[bad] <= 0.5 * np.abs(d_cpu)[bad] + 2 * rms).all()), "%s: an outlier is not ReLU-tie sized: |err| %.3e (rms %.3e)" % (
             name, float(err[bad].max()), rms)
@@ -211,7 +211,12 @@ def _run_deepfm(V, optimizer, kind, lr, steps=2):
         _assert_update("first-order weights", orc.lin0.numpy(), got_l, orc.lin.numpy())
         _assert_update("first-order bias", orc.bias0.numpy(), eng.lin_bias.cpu().numpy(), orc.bias.numpy())
         for j in range(len(orc.Ws)):
-            _assert_update("W%d" % j, orc.Ws0[j].numpy(), eng.Ws[j].cpu().numpy(), orc.Ws[j].numpy())
+            # W0: ONE ReLU tie in the 32-unit layer (an example whose pre-activation there is within rounding of zero) switches that
+            # example's whole d h0 row, i.e. all 256 columns of W0's 13 dense-feature rows (x ~ 1): 3328 of its 429 312 elements, 0.8 %,
+            # each by ~1e-3 of the rms update.  Which examples tie depends on the last bits of h0, so on the product mode (the f16x2
+            # mode hit one with this seed where the bf16x3 mode hit none; tools/exp/h2_engine_diff.py, h2_flips.py: both modes flip 1 - 3
+            # of the 16.7 M first-layer units against fp64).  Two such ties are allowed; every outlier stays bounded below.
+            _assert_update("W%d" % j, orc.Ws0[j].numpy(), eng.Ws[j].cpu().numpy(), orc.Ws[j].numpy(), outliers=2e-2 if j == 0 else 1e-4)
             _assert_update("b%d" % j, orc.bs0[j].numpy(), eng.bs[j].cpu().numpy(), orc.bs[j].numpy())
     else:
         _assert_close_adam("table rows", got_t, orc.table.numpy(), lr, 3e-3)
@@ -425,7 +430,11 @@ def test_dcn_bench_config_matches_oracle(Bd, V):
     gt = torch.zeros((len(U), D), dtype=dd).index_add_(0, cidx.reshape(-1), grads[0].reshape(-1, D))
     # K = 1677-long fp32 reductions feeding three stacked cross layers: the device gradient carries ~1e-6 * sqrt(K) relative
     # round-off per layer; 1e-2 of each update (+ the ulp / rms floor) still catches any missing term
-    _assert_update("table rows", t0.numpy(), eng.table[Ud].cpu().numpy(), (t0.to(dd) - lr * gt).float().numpy(), rel=1e-2)
+    # (outliers: an example with ONE ReLU tie in the MLP -- a pre-activation within rounding of zero among its 1792 hidden units --
+    # gets a different d x row, i.e. all 26 x 64 = 1664 table elements it touches: 1.2e-4 of the elements at batch 8192.  Which
+    # examples tie depends on the product mode's last bits (0 with bf16x3 and 2 with f16x2 at this seed; both modes flip 1 - 3 of
+    # 16.7 M units against fp64, tools/exp/h2_flips.py).  Up to eight such examples; each outlier stays bounded by _assert_update.)
+    _assert_update("table rows", t0.numpy(), eng.table[Ud].cpu().numpy(), (t0.to(dd) - lr * gt).float().numpy(), rel=1e-2, outliers=1e-3)
     n = 3
     for j in range(n):
         _assert_update("cross W%d" % j, cW0[j].numpy(), eng.cross_W[j].cpu().numpy(), (cW0[j].to(dd) - lr * grads[1 + j]).float().numpy(), rel=1e-2)

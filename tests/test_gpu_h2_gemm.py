@@ -309,3 +309,82 @@ def test_engine_f16x2_step_tracks_the_bf16x3_step(optimizer, monkeypatch):
     monkeypatch.delenv("DR_GEMM_SPLIT")
     again, l2b = run()
     assert l2b == l2 and torch.equal(again.table, h2.table) and torch.equal(again.flat_params, h2.flat_params)
+
+
+def test_h2_gemm_epilogues_leave_the_amax_record_of_what_they_store(ops):
+    """out_amax of dr_h2_linear_nt / dr_h2_cross_fwd and d_prod_amax of dr_cross_combine_bwd_amax: exactly max |stored value| as float
+    bits (reset by the call) -- a chain of GEMMs hands each output to the next as an operand without a pass over it."""
+    g = torch.Generator(device="cuda").manual_seed(21)
+    for (M, K, N) in ((1000, 83, 40), (4100, 300, 520)):
+        a = torch.randn((M, (K + 3) // 4 * 4), device="cuda", generator=g)[:, :K]
+        W = torch.randn((K, N), device="cuda", generator=g) * 0.1
+        b = torch.randn((N,), device="cuda", generator=g)
+        mask = torch.randn((M, N), device="cuda", generator=g)
+        wp, am = ops.H2WeightPlanes(W), ops.h2_amax(a)
+        rec = ops.h2_record("cuda")
+        for kw in (dict(bias=b, act=1), dict(bias=b, mask=mask), dict()):
+            rec.fill_(0x7f000000)
+            y = ops.h2_linear_nt(a, am, wp.wt, out_amax=rec, **kw)
+            assert int(rec.item()) == _amax_bits(y), kw
+        o = torch.randn((M, N), device="cuda", generator=g)
+        ops.h2_linear_nt(a, am, wp.wt, accumulate=True, out=o, out_amax=rec)
+        assert int(rec.item()) == _amax_bits(o)
+    M, Dm = 1500, 333
+    buf0 = torch.randn((M, 336), device="cuda", generator=g)
+    buf1 = torch.randn((M, 336), device="cuda", generator=g)
+    x0, x = buf0[:, :Dm], buf1[:, :Dm]
+    W = torch.randn((Dm, Dm), device="cuda", generator=g) * 0.05
+    b = torch.randn((Dm,), device="cuda", generator=g)
+    rec = ops.h2_record("cuda")
+    out, prod = ops.h2_cross_fwd(x0, x, ops.h2_amax(x), ops.H2WeightPlanes(W).wt, b, 0.3, want_prod=True, out_amax=rec)
+    pr = x.double() @ W.double() + b.double() + 0.3 * x.double()
+    assert _rel(prod, pr) <= 3e-6 and _rel(out, x0.double() * pr + x.double()) <= 3e-6
+    o3, p3 = ops.bf3_cross_fwd(x0, x, ops.WeightPlanes(W).wt, b, 0.3, want_prod=True)
+    assert _rel(out, x0.double() * pr + x.double()) <= 1.5 * _rel(o3, x0.double() * pr + x.double()) + 1e-7
+    assert int(rec.item()) == _amax_bits(out)
+    # the reference's known answer (tests/keras/test_dcn.py:16-23)
+    x0k = torch.zeros((5, 4), device="cuda"); xk = torch.zeros((5, 4), device="cuda")
+    x0k[:, :3] = torch.tensor([0.1, 0.2, 0.3], device="cuda"); xk[:, :3] = torch.tensor([0.4, 0.5, 0.6], device="cuda")
+    ok, _ = ops.h2_cross_fwd(x0k[:, :3], xk[:, :3], ops.h2_amax(xk[:, :3]), ops.H2WeightPlanes(torch.ones((3, 3), device="cuda")).wt, torch.zeros(3, device="cuda"))
+    assert torch.allclose(ok, torch.tensor([[0.55, 0.8, 1.05]], device="cuda").repeat(5, 1), rtol=1e-6)
+    # the cross layer's backward combine
+    d_out = (torch.randn((M, 336), device="cuda", generator=g) * 1e-3)[:, :Dm]
+    dx0a, dx0b = torch.zeros((M, 336), device="cuda")[:, :Dm], torch.zeros((M, 336), device="cuda")[:, :Dm]
+    dp0 = ops.cross_combine_bwd(x0, prod, d_out, 0.0, dx0a, None)
+    rec.fill_(0x7f000000)
+    dp1 = ops.cross_combine_bwd(x0, prod, d_out, 0.0, dx0b, None, d_prod_amax=rec)
+    assert torch.equal(dp0, dp1) and torch.equal(dx0a, dx0b) and int(rec.item()) == _amax_bits(dp1)
+
+
+def test_dcn_engine_f16x2_step_tracks_the_bf16x3_step(monkeypatch):
+    """DCNEngine (config 4's stack: 3 cross layers + MLP) with every wide GEMM in the f16x2 mode against DR_GEMM_SPLIT=bf16x3: losses
+    to 1e-5 relative, parameters to fp32 noise; the records chained through the epilogues equal the tensors' true amax."""
+    from deep_recommenders_amd.dcn_engine import DCNEngine
+    F, B, Nd, D, V = 6, 4096, 5, 64, 3000
+    g = torch.Generator(device="cuda").manual_seed(12)
+    batches = [(torch.randint(0, 10**12, (B, F), device="cuda", generator=g), torch.rand((B, Nd), device="cuda", generator=g) * 4,
+                (torch.rand(B, device="cuda", generator=g) < 0.3).float()) for _ in range(3)]
+
+    def run():
+        eng = DCNEngine(F, V, D, 3, [512, 256, 128], B, num_dense=Nd, lr=0.05, seed=3)
+        losses = [float(eng.train_step(*batches[n % 3]).item()) for n in range(5)]
+        torch.cuda.synchronize()
+        return eng, losses
+    h2, l2 = run()
+    assert h2.h2 and all(isinstance(p, ops_mod().H2WeightPlanes) for p in h2.cross_planes)
+    monkeypatch.setenv("DR_GEMM_SPLIT", "bf16x3")
+    b3, l3 = run()
+    assert not b3.h2
+    for a, b in zip(l2, l3):
+        assert abs(a - b) <= 1e-5 * abs(b), (l2, l3)
+    assert (h2.table - b3.table).abs().max().item() <= 2e-5 * b3.table.abs().max().item()
+    for Wa, Wb in zip(h2.cross_W + h2.Ws, b3.cross_W + b3.Ws):
+        assert (Wa - Wb).abs().max().item() <= 2e-5 * Wb.abs().max().item()
+    assert int(h2.x_amax[0].item()) == _amax_bits(h2.x0[:, :h2.in_dim])
+    for i in range(len(h2.Ws) - 1):
+        assert int(h2.h_amax[i].item()) == _amax_bits(h2.hs[i])
+
+
+def ops_mod():
+    from deep_recommenders_amd import ops as _ops
+    return _ops
