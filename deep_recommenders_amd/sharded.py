@@ -435,7 +435,7 @@ class ShardedEmbeddingExchange:
             self.p.emb_pack_grads(route.pos, self.D, d_concat, concat, sum_x, d_fm_logit, g_rows, g_lin, g_bias)
         return g_rows, g_lin
 
-    def exchange_and_apply(self, route, g_rows, g_lin, scale, table_local, lin_local, adam=None):
+    def exchange_and_apply(self, route, g_rows, g_lin, scale, table_local, lin_local, adam=None, table_amax=None):
         """C3 + owner-side update (runs on the communication stream, overlapped with the tower).  adam = (lr_t, beta1, beta2,
         eps, m_table, v_table, m_lin, v_lin): one row-wise Adam update per touched row from the SUM of the gradients every
         rank sent for it (the gradients must already be those of the global-mean loss); otherwise dst += scale * sum."""
@@ -459,11 +459,11 @@ class ShardedEmbeddingExchange:
             self.p.emb_pool_bwd_sorted_adam(rows_pad.view(-1, G), self._zero_base_g, sl["plan"], D, self.local_rows,
                                             g_pad.view(-1, G * D), None, lr_t, b1, b2, eps, table_local, m_t, v_t,
                                             lin_local if r.has_lin else None, m_l, v_l,
-                                            slot_lin_grad=gl_pad if r.has_lin else None)
+                                            slot_lin_grad=gl_pad if r.has_lin else None, **({"table_amax": table_amax} if table_amax is not None else {}))
         else:
             self.p.emb_pool_bwd_sorted(rows_pad.view(-1, G), self._zero_base_g, sl["plan"], D, self.local_rows,
                                        g_pad.view(-1, G * D), None, scale, table_local, lin_local if r.has_lin else None, None,
-                                       slot_lin_grad=gl_pad if r.has_lin else None)
+                                       slot_lin_grad=gl_pad if r.has_lin else None, **({"table_amax": table_amax} if table_amax is not None else {}))
         if self._cuda:
             sl["free_ev"] = torch.cuda.Event()
             sl["free_ev"].record()
@@ -619,6 +619,28 @@ class ShardedDeepFMEngine:
         # streams for the later micro-batches' fused first layers (see train_step); DR_FWD_STREAMS=0: all on the training stream
         self.fwd_streams = ([torch.cuda.Stream(device=device) for _ in range(max(0, min(mb - 1, 3)))]
                             if (self.fuse_k3 and _os.environ.get("DR_FWD_STREAMS", "1") == "1") else [])
+        # The first layer's three GEMMs in the "f16x2" operand mode (round 4; see engine.DeepFMEngine / include/dr_hotpath.h dr_h2_*).  The
+        # activation scale of the forward and the wgrad comes from the amax record of the TABLES: every rank keeps a running record of
+        # its own shard (K4 raises it) and, with real peers, one 4-byte all-reduce(MAX) behind the step's last owner-side update makes
+        # it the bound for the rows any rank may receive in the next step (on the communication stream, long before those rows
+        # arrive).  d h0's record comes out of the narrow backward per micro-batch.  DR_GEMM_SPLIT=bf16x3: the six-product mode.
+        self.h2 = (self.fuse_k3 and not self.fuse_pack and _os.environ.get("DR_GEMM_SPLIT", "f16x2") == "f16x2"
+                   and not (self.fuse_head and nl - 2 == 0))
+        if self.h2:
+            self.wplanes[0] = ops.H2WeightPlanes(self.Ws[0])
+            self.tab_amax_local = ops.h2_amax(self.table)
+            # (two buffers for the global bound: the all-reduce behind step t's last update fills the one step t + 1 will read, while
+            # step t's wgrad -- whose rows were fetched before that update -- still reads the other)
+            self._tab_bufs = None if self.ex.local else [self.tab_amax_local.clone(), self.tab_amax_local.clone()]
+            self._tab_i, self._tab_swap = 0, False
+            self.tab_amax = self.tab_amax_local if self.ex.local else self._tab_bufs[0]
+            if not self.ex.local:
+                self.tr.allreduce(self.tab_amax, op=dist.ReduceOp.MAX)
+            self._tab_ver = self.table._version
+            self.dense_amax = ops.h2_record(device) if self.dense_pad is not None else None
+            self.dh0_amax = [ops.h2_record(device) for _ in range(mb)]
+            self.dh0_amax_all = ops.h2_record(device)
+            self.x_amax_all = ops.h2_record(device)
         self._ev_every, self._ev_step, self._ev_live = 1, 0, False
         self.k4_first = _os.environ.get("DR_SH_K4_FIRST", "0") == "1"
         self.wgrad_split = _os.environ.get("DR_SH_WGRAD_SPLIT", "0") == "1"
@@ -762,6 +784,14 @@ class ShardedDeepFMEngine:
             if wp is not None:
                 wp.refresh()
 
+    def _x_record(self):
+        """f16x2 mode: the record of concat = [rows this rank received, dense features] (float bits of non-negative values order like
+        integers, so the larger record is the integer maximum)"""
+        if self.dense_amax is not None:
+            torch.maximum(self.tab_amax, self.dense_amax, out=self.x_amax_all)
+        else:
+            self.x_amax_all.copy_(self.tab_amax)
+
     def train_step(self, keys, dense, labels, next_keys=None, next_keys_ready=None):
         """One step.  The rank's batch is processed as `self.mb` micro-batches that share one set of weights (all
         forwards read pre-update tables; the dense gradients are summed; the loss is the mean over world * B examples):
@@ -776,6 +806,21 @@ class ShardedDeepFMEngine:
         for wp in self.wplanes:          # weights written from outside since the last refresh (load / copy_ / broadcast): re-split
             if wp is not None:
                 wp.ensure_fresh()
+        h2 = self.h2
+        if h2 and self._tab_swap:
+            self._tab_i ^= 1
+            self.tab_amax = self._tab_bufs[self._tab_i]      # filled behind the previous step's last owner-side update
+            self._tab_swap = False
+        if h2 and self.table._version != self._tab_ver:
+            # the shard was written from outside (checkpoint restore, a test's copy_): rebuild the record (and the global bound)
+            ops.h2_amax(self.table, self.tab_amax_local)
+            if not self.ex.local:
+                if cuda:
+                    self.comm.wait_stream(torch.cuda.current_stream())
+                with (torch.cuda.stream(self.comm) if cuda else _NullCtx()):
+                    self.tab_amax.copy_(self.tab_amax_local)
+                    self.tr.allreduce(self.tab_amax, op=dist.ReduceOp.MAX)
+            self._tab_ver = self.table._version
         adam = self.optimizer == "adam"
         # SGD: gradients of the RANK-mean loss travel, the 1 / W of the global mean is folded into the step (-lr / W).
         # Adam: the update is not linear in the gradient, so the head normalises by the global batch and every gradient that
@@ -822,6 +867,8 @@ class ShardedDeepFMEngine:
             self.concat[:, F * D:F * D + self.Nd].copy_(dense)
             if self.dense_pad is not None:
                 self.dense_pad[:, :self.Nd].copy_(dense)               # the fused kernel's own (k-tile wide) copy
+                if h2:
+                    ops.h2_amax(self.dense_pad, self.dense_amax)
         n_layers = len(self.Ws)
         x_in = self.concat[:, :self.in_dim]
         dys = [None] * n_layers
@@ -837,6 +884,13 @@ class ShardedDeepFMEngine:
                 if t is not None:
                     t.record_stream(stream)
             Wt, b = self.Ws[0], self.bs[0]
+            if h2:
+                self._k("emb_linear_fwd_L0", "mfma", 2.0 * Bm * Wt.shape[0] * Wt.shape[1],
+                        lambda: ops.h2_emb_linear_fwd(
+                            routes[m].pos, self.ex._zero_base, rows_m.shape[0], rows_m, self.tab_amax, lin_m, self.lin_bias,
+                            self.dense_pad[sl] if self.dense_pad is not None else None, self.dense_amax, self.concat[sl], self.in_dim,
+                            self.wplanes[0].wt, b, self.acts[0], self.sum_x[sl], self.fm_logit[sl], self.hs[0][sl]))
+                return
             self._k("emb_linear_fwd_L0", "mfma", 2.0 * Bm * Wt.shape[0] * Wt.shape[1],
                     lambda: ops.bf3_emb_linear_fwd(
                         routes[m].pos, self.ex._zero_base, rows_m.shape[0], rows_m, lin_m, self.lin_bias,
@@ -926,11 +980,17 @@ class ShardedDeepFMEngine:
                     continue
                 if self.narrow[i]:
                     self._k("linear_bwd_narrow_L%d" % i, "hbm", 4.0 * Bm * (2 * self.Ws[i].shape[0] + self.Ws[i].shape[1]),
-                            lambda dy=dy, i=i, dx=dx, sl=sl: p.linear_bwd_narrow(self.hs[i - 1][sl], dy, self.Ws[i], 1.0, self.gWs[i],
-                                                                                self.gbs[i], dx, relu_mask=True,
-                                                                                workspace=self.narrow_ws[i]))
+                            lambda dy=dy, i=i, dx=dx, sl=sl, m=m: p.linear_bwd_narrow(self.hs[i - 1][sl], dy, self.Ws[i], 1.0, self.gWs[i],
+                                                                                     self.gbs[i], dx, relu_mask=True,
+                                                                                     workspace=self.narrow_ws[i],
+                                                                                     **({"dx_amax": self.dh0_amax[m]} if (h2 and i == 1) else {})))
                 else:
-                    if self.wplanes[i] is not None:
+                    if i == 0 and h2:
+                        if not (n_layers > 1 and self.narrow[1]):
+                            ops.h2_amax(dy, self.dh0_amax[m])        # (layer 1's backward was not the narrow kernel that leaves the record)
+                        self._k("linear_bwd_dx_L%d" % i, "mfma", 2.0 * Bm * self.Ws[i].shape[0] * self.Ws[i].shape[1],
+                                lambda dy=dy, i=i, rs=rs, dx=dx, m=m: ops.h2_linear_nt(dy, self.dh0_amax[m], self.wplanes[i].w, mask=rs, out=dx))
+                    elif self.wplanes[i] is not None:
                         self._k("linear_bwd_dx_L%d" % i, "mfma", 2.0 * Bm * self.Ws[i].shape[0] * self.Ws[i].shape[1],
                                 lambda dy=dy, i=i, rs=rs, dx=dx: ops.bf3_linear_nt(dy, self.wplanes[i].w, mask=rs, out=dx))
                     else:
@@ -954,7 +1014,12 @@ class ShardedDeepFMEngine:
                     for i in (dw_todo if m > 0 else list(dw_todo)):
                         xin = x_in[sl] if i == 0 else self.hs[i - 1][sl]
                         dyi = self.dhs[i][sl] if i < n_layers - 1 else self.d_logit[sl].reshape(-1, 1)
-                        if self.wg_ws[i] is not None:
+                        if i == 0 and h2:
+                            self._x_record()
+                            self._k("linear_bwd_dw_L%d" % i, "mfma", 2.0 * Bm * self.Ws[i].shape[0] * self.Ws[i].shape[1],
+                                    lambda xin=xin, dyi=dyi, i=i, m=m: ops.h2_wgrad(xin, self.x_amax_all, dyi, self.dh0_amax[m], 1.0, self.gWs[i],
+                                                                                    self.gbs[i], workspace=self.wg_ws[i]))
+                        elif self.wg_ws[i] is not None:
                             self._k("linear_bwd_dw_L%d" % i, "mfma", 2.0 * Bm * self.Ws[i].shape[0] * self.Ws[i].shape[1],
                                     lambda xin=xin, dyi=dyi, i=i: ops.bf3_wgrad(xin, dyi, 1.0, self.gWs[i], self.gbs[i], workspace=self.wg_ws[i]))
                         else:
@@ -964,8 +1029,16 @@ class ShardedDeepFMEngine:
                     self.comm.wait_event(ev_p)
                     self._k("emb_grads(a2a+sorted K4)", "xgmi", Bm * F * (4 * D + 4),
                             lambda m=m, g_rows=g_rows, g_lin=g_lin: self.ex.exchange_and_apply(routes[m], g_rows, g_lin, -self.lr / W,
-                                                                                               self.table, self.lin_w, adam=adam_args))
+                                                                                               self.table, self.lin_w, adam=adam_args,
+                                                                                               table_amax=self.tab_amax_local if h2 else None))
                     if m == M - 1:
+                        if h2 and not self.ex.local:
+                            # the bound for the rows ANY rank may be sent next step: max over the shards' records (4 bytes, in order
+                            # behind the last owner-side update and in front of the next step's first row fetch)
+                            nxt = self._tab_bufs[self._tab_i ^ 1]
+                            nxt.copy_(self.tab_amax_local)
+                            self.tr.allreduce(nxt, op=dist.ReduceOp.MAX)
+                            self._tab_swap = True
                         ev_last_apply = torch.cuda.Event()
                         ev_last_apply.record()
             else:
@@ -983,7 +1056,14 @@ class ShardedDeepFMEngine:
         for i in ([] if (cuda and self.wgrad_split) else dw_todo):
             xin = x_in if i == 0 else self.hs[i - 1]
             dyi = self.dhs[i] if i < n_layers - 1 else self.d_logit.reshape(-1, 1)
-            if self.wg_ws[i] is not None:
+            if i == 0 and h2:
+                # records of the whole rank batch: x = [received rows, dense features], d h0 = the micro-batches' pieces
+                self._x_record()
+                torch.amax(torch.cat(self.dh0_amax), 0, keepdim=True, out=self.dh0_amax_all)
+                self._k("linear_bwd_dw_L%d" % i, "mfma", 2.0 * B * self.Ws[i].shape[0] * self.Ws[i].shape[1],
+                        lambda xin=xin, dyi=dyi, i=i: ops.h2_wgrad(xin, self.x_amax_all, dyi, self.dh0_amax_all, 1.0, self.gWs[i], self.gbs[i],
+                                                                   workspace=self.wg_ws[i]))
+            elif self.wg_ws[i] is not None:
                 self._k("linear_bwd_dw_L%d" % i, "mfma", 2.0 * B * self.Ws[i].shape[0] * self.Ws[i].shape[1],
                         lambda xin=xin, dyi=dyi, i=i: ops.bf3_wgrad(xin, dyi, 1.0, self.gWs[i], self.gbs[i], workspace=self.wg_ws[i]))
             else:
