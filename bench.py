@@ -539,6 +539,12 @@ def main():
         if default_cfg and world == 1 and not force_sharded:
             traffic = {ev: int(pmc["kernels"][k]["hbm_bytes_corrected"]) for ev, k in name_map.items() if k in pmc["kernels"]}
             traffic_source = src + " (static: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run)"
+            if getattr(eng, "h2", False) and pmc.get("gemm_split", "bf16x3") != "f16x2":
+                # the committed passes were taken with the first layer's GEMMs in the bf16x3 mode: their byte counts (three weight planes
+                # per k-tile, not two) do not describe the f16x2 kernels this run timed.  K4 and the tail kernels are the same code.
+                for ev in H2_KERNELS:
+                    traffic.pop(ev, None)
+                traffic_source += "; the three first-layer GEMM rows carry no figure: the passes predate the f16x2 mode (profiles/README.md)"
         else:
             traffic_note = ("the committed PMC passes (%s) were taken on the default configuration (deepfm, B 65536, 26 x 10 M x 64, DNN 256,32, sgd, "
                             "bf16x3, one GPU); this run differs, so no traffic figure applies" % src)

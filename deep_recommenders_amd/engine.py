@@ -201,6 +201,8 @@ class DeepFMEngine:
             self._tab_ver = self.table._version
             self.dense_amax = ops.h2_record(device) if self.dense_pad is not None else None
             self.dh0_amax = ops.h2_record(device)
+        # (timing experiment only -- the record goes stale: K4 without the running maximum, to price the tracking)
+        self._exp_no_k4_amax = _os.environ.get("DR_EXP_K4_NO_AMAX", "0") == "1"
         # The slot sort of batch s + 1 next to K4 of batch s (DR_PREFETCH_PLAN=0: every step hashes and sorts its own batch).  K4 is
         # the one long kernel of the step that is HBM-bound with small blocks, i.e. that shares the machine; beside the persistent
         # GEMMs (the fused first layer occupies all 160 KB of LDS on every CU) the sort chain's ~20 small launches only advance in
@@ -672,7 +674,7 @@ class DeepFMEngine:
                                                        concat=None if self.no_concat else self.concat, sum_x=self.sum_x,
                                                        x_sorted=self.x_sorted if self.no_concat else None, parts=parts,
                                                        lin_old_t=self.lin_old_t if (self._lin_old_valid and not lin_side) else None,
-                                                       table_amax=self.tab_amax if self.h2 else None)
+                                                       table_amax=self.tab_amax if (self.h2 and not self._exp_no_k4_amax) else None)
             sk = 4 if lin_side else 0
             self._k("emb_pool_bwd", "hbm", self.alg_bytes_bwd() - (self.B * self.F * 8 if lin_side else 0),   # K4 (sorted)
                     lambda: k4(1 | sk))

@@ -3,14 +3,18 @@
 #   gpurun_out/prof_stats/   rocprofv3 --kernel-trace --stats of the default bench command
 #   gpurun_out/pmc_traffic.json   per-kernel HBM bytes (FETCH_SIZE / WRITE_SIZE in separate --pmc passes)
 # Copy the results into profiles/ afterwards (tools/rocpd_stats.py turns the kernel trace into a CSV summary).
+# CAUTION (round 4, 37 GPU-minutes lost): always `--output-format csv` and `timeout -s KILL`.  A rocprofv3 run WITHOUT the csv format writes a
+# rocpd database and its --stats post-processing of a few thousand launches did not finish in 35 minutes; plain `timeout` signals
+# rocprofv3 only, the profiled python keeps a pipe open and the call runs into gpurun's own limit.  Give the gpurun call a --timeout
+# that matches the work (the budget left is the default ceiling).
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $R/gpurun_out
 BENCH="python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/prof_stats_bench.log 2>&1
+timeout -s KILL 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/prof_stats_bench.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$c -- $BENCH > /dev/null 2>&1
+  timeout -s KILL 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$c -- $BENCH > /dev/null 2>&1
 done
 python $R/tools/pmc_traffic.py $R/gpurun_out/pmc_traffic.json $(find $R/gpurun_out/pmc_FETCH_SIZE $R/gpurun_out/pmc_WRITE_SIZE -name "*counter_collection.csv") > $R/gpurun_out/pmc_traffic.txt 2>&1
 STATS=$(ls -t $(find $R/gpurun_out/prof_stats -name "*kernel_stats.csv") | head -1)

@@ -1,0 +1,18 @@
+"""EXPERIMENT driver: the exact top-100 scan of config 5 alone (8192 queries x 1 M items x 128), for rocprofv3 --kernel-trace --stats."""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+import torch
+from deep_recommenders_amd import ops
+g = torch.Generator(device="cuda"); g.manual_seed(0)
+Bq, N, D, k = 8192, 1_000_000, 128, 100
+q = torch.randn((Bq, D), device="cuda", generator=g) / D ** 0.5
+c = torch.randn((N, D), device="cuda", generator=g) / D ** 0.5
+for _ in range(2):
+    s, i = ops.topk_mips(q, c, k)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(5):
+    s, i = ops.topk_mips(q, c, k)
+e1.record(); torch.cuda.synchronize()
+print("topk %.2f ms per call" % (e0.elapsed_time(e1) / 5))

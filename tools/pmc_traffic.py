@@ -54,11 +54,18 @@ def main():
             "(2*FETCH_SIZE + WRITE_SIZE) * 1024. Calibration: hash_bucket_i64_kernel reads 13.63 MB and writes 13.63 MB.")
     # bench.py event name -> profiled kernel (with DR_FUSE_K3=0 the forward and the dgrad of the first layer are the same kernel
     # instantiation: their traffic is then the average of the two; names absent from the profile are dropped by bench.py)
-    event_names = {"emb_linear_fwd_L0": "bf3_emb_linear_kernel", "emb_pool_fwd": "emb_pool_fwd_sv_kernel<16,8>",
+    # (round 4: the kernels are templates over the operand mode -- <..., 1> = f16x2, the default; the first name present wins)
+    def pick(*names):
+        return next((n for n in names if n in kernels), names[0])
+    event_names = {"emb_linear_fwd_L0": pick("bf3_emb_linear_kernel<1>", "bf3_emb_linear_kernel<0>", "bf3_emb_linear_kernel"),
+                   "emb_pool_fwd": "emb_pool_fwd_sv_kernel<16,8>",
                    "emb_pool_bwd": "emb_bwd_sorted_kernel<16,4,false>", "hash_bucket_i64": "hash_bucket_i64_kernel",
-                   "linear_fwd_L0": "bf3_gemm_rs_kernel<0,0,1,1>", "linear_bwd_dx_L0": "bf3_gemm_rs_kernel<0,0,1,1>",
-                   "linear_bwd_dw_L0": "bf3_gemm_tn_rs_kernel<1>"}
-    json.dump({"_note": note, "kernels": kernels, "event_names": event_names}, open(out_path, "w"), indent=1, sort_keys=True)
+                   "linear_fwd_L0": pick("bf3_gemm_rs_kernel<0,0,1,1,1>", "bf3_gemm_rs_kernel<0,0,1,1,0>", "bf3_gemm_rs_kernel<0,0,1,1>"),
+                   "linear_bwd_dx_L0": pick("bf3_gemm_rs_kernel<0,0,1,1,1>", "bf3_gemm_rs_kernel<0,0,1,1,0>", "bf3_gemm_rs_kernel<0,0,1,1>"),
+                   "linear_bwd_dw_L0": pick("bf3_gemm_tn_rs_kernel<1,1>", "bf3_gemm_tn_rs_kernel<1,0>", "bf3_gemm_tn_rs_kernel<1>")}
+    h2 = any(n.endswith(",1,1,1>") or n in ("bf3_emb_linear_kernel<1>", "bf3_gemm_tn_rs_kernel<1,1>") for n in event_names.values() if n in kernels)
+    json.dump({"_note": note, "kernels": kernels, "event_names": event_names, "gemm_split": "f16x2" if h2 else "bf16x3"},
+              open(out_path, "w"), indent=1, sort_keys=True)
     for k, v in kernels.items():
         print("%-60s %10.1f MB" % (k, v["hbm_bytes_corrected"] / 1e6))
 
