@@ -198,7 +198,7 @@ class DeepFMEngine:
         if self.h2:
             self.wplanes[0] = ops.H2WeightPlanes(self.Ws[0])
             self.tab_amax = ops.h2_amax(self.table)
-            self._tab_ver = self.table._version
+            self._tab_ver = (self.table.data_ptr(), self.table._version)
             self.dense_amax = ops.h2_record(device) if self.dense_pad is not None else None
             self.dh0_amax = ops.h2_record(device)
         # (timing experiment only -- the record goes stale: K4 without the running maximum, to price the tracking)
@@ -456,11 +456,11 @@ class DeepFMEngine:
         for wp in self.wplanes:          # weights written from outside since the last refresh (load / copy_ / fill_): re-split
             if wp is not None:
                 wp.ensure_fresh()
-        if self.h2 and self.table._version != self._tab_ver:
+        if self.h2 and (self.table.data_ptr(), self.table._version) != self._tab_ver:
             # the table was written from outside (checkpoint restore, copy_ / fill_ in a test): rebuild its amax record.  K4's own
             # writes go through raw pointers and keep the record themselves.
             ops.h2_amax(self.table, self.tab_amax)
-            self._tab_ver = self.table._version
+            self._tab_ver = (self.table.data_ptr(), self.table._version)
         pref_tok = self._pref
         prefetched = pref_tok is not None and pref_tok == self._token(keys)
         self._pref = None

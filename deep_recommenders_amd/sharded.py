@@ -636,7 +636,7 @@ class ShardedDeepFMEngine:
             self.tab_amax = self.tab_amax_local if self.ex.local else self._tab_bufs[0]
             if not self.ex.local:
                 self.tr.allreduce(self.tab_amax, op=dist.ReduceOp.MAX)
-            self._tab_ver = self.table._version
+            self._tab_ver = (self.table.data_ptr(), self.table._version)
             self.dense_amax = ops.h2_record(device) if self.dense_pad is not None else None
             self.dh0_amax = [ops.h2_record(device) for _ in range(mb)]
             self.dh0_amax_all = ops.h2_record(device)
@@ -811,7 +811,7 @@ class ShardedDeepFMEngine:
             self._tab_i ^= 1
             self.tab_amax = self._tab_bufs[self._tab_i]      # filled behind the previous step's last owner-side update
             self._tab_swap = False
-        if h2 and self.table._version != self._tab_ver:
+        if h2 and (self.table.data_ptr(), self.table._version) != self._tab_ver:
             # the shard was written from outside (checkpoint restore, a test's copy_): rebuild the record (and the global bound)
             ops.h2_amax(self.table, self.tab_amax_local)
             if not self.ex.local:
@@ -820,7 +820,7 @@ class ShardedDeepFMEngine:
                 with (torch.cuda.stream(self.comm) if cuda else _NullCtx()):
                     self.tab_amax.copy_(self.tab_amax_local)
                     self.tr.allreduce(self.tab_amax, op=dist.ReduceOp.MAX)
-            self._tab_ver = self.table._version
+            self._tab_ver = (self.table.data_ptr(), self.table._version)
         adam = self.optimizer == "adam"
         # SGD: gradients of the RANK-mean loss travel, the 1 / W of the global mean is folded into the step (-lr / W).
         # Adam: the update is not linear in the gradient, so the head normalises by the global batch and every gradient that
