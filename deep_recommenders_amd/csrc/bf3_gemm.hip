@@ -38,6 +38,10 @@
 #ifndef DR_NT_DGRAD_STORE
 #define DR_NT_DGRAD_STORE 0
 #endif
+// top-K filter epilogue with a per-register early reject (experiment, off: see the EPI == 4 epilogue)
+#ifndef DR_TOPK_FAST_REJECT
+#define DR_TOPK_FAST_REJECT 0
+#endif
 #include "dr_common.h"
 #include "bf3_split.h"
 #include <cstdlib>
@@ -938,6 +942,25 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
                     const int64_t row = r0 + (reg & 3) + 8 * (reg >> 2);
                     const bool rv = row < g.M;
                     const float t = g.tau[rv ? row : g.M - 1];
+#if DR_TOPK_FAST_REJECT
+                    {   // EXPERIMENT (round 4, built but NEVER RUN: the round's GPU budget ended first; tools/exp/topk_fast_reject.sh).
+                        // Once tau has warmed up almost no score passes, yet the loop below spends a compare + ballot + mask + branch on
+                        // every one of the 8 column tiles of every accumulator register (128 per wave and tile; the scan launch takes
+                        // 19.5 us per tile against ~12 us of matrix + ingest time, profiles/r04_topk_kernel_stats.csv).  One OR over the
+                        // column tiles and ONE ballot per register first; the per-column work only for a register that has a hit.
+                        const float tq = H2 ? t / h2_out : t;           // (a power-of-two factor: exact) compare the raw accumulators
+                        bool any = false;
+#pragma unroll
+                        for (int nt = 0; nt < NTW; ++nt) any = any || (cb0 + nt * 32 + l31 < g.N && acc[ms][nt][reg] > tq);
+                        if (__ballot(rv && any) == 0ull) {              // (wave-uniform)
+#pragma unroll
+                            for (int nt = 0; nt < NTW; ++nt) acc[ms][nt][reg] = 0.f;
+                            __builtin_amdgcn_sched_barrier(0);          // (registers one at a time: hoisted, the 16 thresholds and ORs spill)
+                            continue;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#endif
 #pragma unroll
                     for (int nt = 0; nt < NTW; ++nt) {
                         const int col = cb0 + nt * 32 + l31;

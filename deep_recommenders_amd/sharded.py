@@ -812,7 +812,9 @@ class ShardedDeepFMEngine:
             self.tab_amax = self._tab_bufs[self._tab_i]      # filled behind the previous step's last owner-side update
             self._tab_swap = False
         if h2 and (self.table.data_ptr(), self.table._version) != self._tab_ver:
-            # the shard was written from outside (checkpoint restore, a test's copy_): rebuild the record (and the global bound)
+            # the shard was written from outside (checkpoint restore, a test's copy_): rebuild the record (and the global bound).  The
+            # rebuild of the global bound is a collective: an outside write must happen on every rank before the same step (a restore
+            # does; a write to ONE rank's shard alone would leave the others waiting here)
             ops.h2_amax(self.table, self.tab_amax_local)
             if not self.ex.local:
                 if cuda:
