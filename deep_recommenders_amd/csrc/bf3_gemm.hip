@@ -2278,6 +2278,10 @@ int rs_launch(const RsArgs& g, hipStream_t stream) {
                     return DR_OK;                                                                                     \
                 }
                 RS_ABL2(0) RS_ABL2(32) RS_ABL2(64) RS_ABL2(96) RS_ABL2(2) RS_ABL2(1)
+                // what the no-MFMA time (131 us of the plain forward's 223) is made of -- combinations for the next GPU call:
+                // 34 = no MFMA + no fragment reads, 3 = no MFMA + no weight DMA, 10 = no MFMA + A from cache, 98 = no MFMA + no reads + no split,
+                // 35 = no MFMA + no reads + no DMA, 43 = that + A from cache (what is left: the loop, the barrier, the epilogue stores)
+                RS_ABL2(34) RS_ABL2(3) RS_ABL2(10) RS_ABL2(98) RS_ABL2(35) RS_ABL2(43)
 #undef RS_ABL2
             }
         }
