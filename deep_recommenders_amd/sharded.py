@@ -641,6 +641,18 @@ class ShardedDeepFMEngine:
             self.dh0_amax = [ops.h2_record(device) for _ in range(mb)]
             self.dh0_amax_all = ops.h2_record(device)
             self.x_amax_all = ops.h2_record(device)
+        # DR_SH_TRACK_AMAX=1 (tests): the bookkeeping of the table bound -- local running record, the all-reduce(MAX) behind the step's last
+        # owner-side update, the two-buffer swap -- WITHOUT the f16x2 kernels, so that the N > 1 control flow of the mode runs wherever
+        # the engine runs (world-size-2 gloo on CPU with the oracle-backed primitives: the record is recomputed from the shard with
+        # torch after every owner-side update instead of being raised by K4).
+        self.track_amax = self.h2 or _os.environ.get("DR_SH_TRACK_AMAX", "0") == "1"
+        if self.track_amax and not self.h2:
+            self.tab_amax_local = self._amax_of(self.table)
+            self._tab_bufs = None if self.ex.local else [self.tab_amax_local.clone(), self.tab_amax_local.clone()]
+            self._tab_i, self._tab_swap = 0, False
+            self.tab_amax = self.tab_amax_local if self.ex.local else self._tab_bufs[0]
+            if not self.ex.local:
+                self.tr.allreduce(self.tab_amax, op=dist.ReduceOp.MAX)
         self._ev_every, self._ev_step, self._ev_live = 1, 0, False
         self.k4_first = _os.environ.get("DR_SH_K4_FIRST", "0") == "1"
         self.wgrad_split = _os.environ.get("DR_SH_WGRAD_SPLIT", "0") == "1"
@@ -784,6 +796,24 @@ class ShardedDeepFMEngine:
             if wp is not None:
                 wp.refresh()
 
+    @staticmethod
+    def _amax_of(t):
+        """max |t| as float bits in an int32 [1] tensor (what dr_h2_amax leaves; torch ops: the DR_SH_TRACK_AMAX path and tests)"""
+        if t.numel() == 0:
+            return torch.zeros(1, dtype=torch.int32, device=t.device)
+        return t.detach().abs().max().to(torch.float32).reshape(1).view(torch.int32).clone()
+
+    def _publish_table_bound(self):
+        """Behind the step's last owner-side update: the bound for the rows ANY rank may be sent next step = max over the shards' records
+        (one 4-byte all-reduce, in order behind that update and in front of the next step's first row fetch), into the buffer the next
+        step will read."""
+        if not self.track_amax or self.ex.local:
+            return
+        nxt = self._tab_bufs[self._tab_i ^ 1]
+        nxt.copy_(self.tab_amax_local)
+        self.tr.allreduce(nxt, op=dist.ReduceOp.MAX)
+        self._tab_swap = True
+
     def _x_record(self):
         """f16x2 mode: the record of concat = [rows this rank received, dense features] (float bits of non-negative values order like
         integers, so the larger record is the integer maximum)"""
@@ -807,7 +837,7 @@ class ShardedDeepFMEngine:
             if wp is not None:
                 wp.ensure_fresh()
         h2 = self.h2
-        if h2 and self._tab_swap:
+        if self.track_amax and self._tab_swap:
             self._tab_i ^= 1
             self.tab_amax = self._tab_bufs[self._tab_i]      # filled behind the previous step's last owner-side update
             self._tab_swap = False
@@ -1033,18 +1063,18 @@ class ShardedDeepFMEngine:
                             lambda m=m, g_rows=g_rows, g_lin=g_lin: self.ex.exchange_and_apply(routes[m], g_rows, g_lin, -self.lr / W,
                                                                                                self.table, self.lin_w, adam=adam_args,
                                                                                                table_amax=self.tab_amax_local if h2 else None))
+                    if self.track_amax and not h2:
+                        torch.maximum(self.tab_amax_local, self._amax_of(self.table), out=self.tab_amax_local)
                     if m == M - 1:
-                        if h2 and not self.ex.local:
-                            # the bound for the rows ANY rank may be sent next step: max over the shards' records (4 bytes, in order
-                            # behind the last owner-side update and in front of the next step's first row fetch)
-                            nxt = self._tab_bufs[self._tab_i ^ 1]
-                            nxt.copy_(self.tab_amax_local)
-                            self.tr.allreduce(nxt, op=dist.ReduceOp.MAX)
-                            self._tab_swap = True
+                        self._publish_table_bound()
                         ev_last_apply = torch.cuda.Event()
                         ev_last_apply.record()
             else:
                 self.ex.exchange_and_apply(routes[m], g_rows, g_lin, -self.lr / W, self.table, self.lin_w, adam=adam_args)
+                if self.track_amax:
+                    torch.maximum(self.tab_amax_local, self._amax_of(self.table), out=self.tab_amax_local)
+                    if m == M - 1:
+                        self._publish_table_bound()
         # ---- wgrads over the WHOLE rank batch (activations of all micro-batches are contiguous) --------------------------------
         # DR_SH_K4_FIRST=1 (measured, not adopted): the wgrad WAITS for the last owner-side update.  A persistent GEMM block owns its
         # CU, so the last K4 crawls beside the wgrad (469 us instead of 170, rocprofv3 timeline of the world-1 step) and the next

@@ -646,3 +646,53 @@ def test_bucketing_oracle_matches_owner_rule():
     assert send_rows[pos[0, 0]].item() == 0 * 10 + 5 // 2
     assert send_rows[pos[0, 1]].item() == -1
     assert send_rows[pos[1, 2]].item() == 2 * 10 + 9 // 2
+
+
+def _amax_worker(rank, world, port, outdir, micro_batches):
+    """DR_SH_TRACK_AMAX=1: the table-bound bookkeeping of the f16x2 mode (sharded.py) without its kernels"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["DR_SH_TRACK_AMAX"] = "1"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from deep_recommenders_amd.sharded import ShardedDeepFMEngine
+        c = dict(CFG, lr=30.0, steps=4, world=world)            # a step size that grows the tables' range every step
+        table, lin, batches = _global_problem(c)
+        eng = ShardedDeepFMEngine(c["F"], c["V"], c["D"], c["units"], c["B"], num_dense=c["Nd"], lr=c["lr"], world=world, rank=rank, seed=5,
+                                  init_tables=(table, lin), micro_batches=micro_batches, device="cpu", prims=OraclePrims)
+        assert eng.track_amax and not eng.h2 and not eng.ex.local
+        sl = slice(rank * c["B"], (rank + 1) * c["B"])
+        local = [(k[sl].contiguous(), d[sl].contiguous(), l[sl].contiguous()) for k, d, l in batches]
+        rows = []
+
+        def true_global():
+            t = eng.table.abs().max().reshape(1).clone()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        rows.append((float(eng.tab_amax.view(torch.float32).item()), true_global(), float(eng.table.abs().max().item())))
+        for t, (k, d, l) in enumerate(local):
+            nk = local[t + 1][0] if t + 1 < len(local) else None
+            eng.train_step(k, d, l, next_keys=nk)
+            # the bound the NEXT step will read: the buffer filled behind this step's last owner-side update
+            assert eng._tab_swap
+            nxt = eng._tab_bufs[eng._tab_i ^ 1]
+            rows.append((float(nxt.view(torch.float32).item()), true_global(), float(eng.table.abs().max().item())))
+        torch.save((rank, rows), os.path.join(outdir, "rank%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("micro_batches", [1, 2])
+def test_two_rank_table_bound_of_the_f16x2_mode_is_global_and_current(tmp_path, micro_batches):
+    """The f16x2 GEMMs of the sharded engine scale the rows a rank RECEIVES by a bound over ALL shards (sharded.py: local running
+    record, one all-reduce(MAX) behind the step's last owner-side update, two buffers).  With DR_SH_TRACK_AMAX=1 that bookkeeping runs
+    on the CPU engine: after every step the bound the next step will read equals the largest magnitude in ANY rank's shard (here the
+    records are recomputed from the shards, so equality, not just >=), is the same on both ranks, and follows a growing table."""
+    res = _spawn(_amax_worker, (micro_batches,), tmp_path)
+    r0, r1 = res[0][0], res[1][0]
+    assert len(r0) == 5 and len(r1) == 5
+    for (b0, g0, l0), (b1, g1, l1) in zip(r0, r1):
+        assert b0 == b1 and g0 == g1, (r0, r1)       # one bound, on every rank
+        assert b0 == g0 == max(l0, l1), (r0, r1)     # ... the largest magnitude over both shards
+    assert r0[-1][0] > 1.5 * r0[0][0], (r0, r1)      # the tables' range did grow (1.18 -> 4.72 here), and the bound followed
