@@ -531,11 +531,11 @@ class DeepFMEngine:
                                                               self.dense_pad, self.dense_amax, None, self.in_dim, self.wplanes[0].wt, b,
                                                               self.acts[0], self.sum_x, self.fm_logit, self.hs[0], lin_vals_t=self.lin_old_t))
                 else:
-                  self._k("emb_linear_fwd_L0", "mfma", 2.0 * B * W.shape[0] * W.shape[1],
-                        lambda b=b: ops.bf3_emb_linear_fwd(self.ids, self.row_base, self.V, self.table, self.lin_w, self.lin_bias, self.dense_pad,
-                                                           None if self.no_concat else self.concat,
-                                                           self.in_dim, self.wplanes[0].wt, b, self.acts[0], self.sum_x, self.fm_logit,
-                                                           self.hs[0], lin_vals_t=self.lin_old_t))
+                    self._k("emb_linear_fwd_L0", "mfma", 2.0 * B * W.shape[0] * W.shape[1],
+                            lambda b=b: ops.bf3_emb_linear_fwd(self.ids, self.row_base, self.V, self.table, self.lin_w, self.lin_bias,
+                                                               self.dense_pad, None if self.no_concat else self.concat, self.in_dim,
+                                                               self.wplanes[0].wt, b, self.acts[0], self.sum_x, self.fm_logit, self.hs[0],
+                                                               lin_vals_t=self.lin_old_t))
                 self._lin_old_valid = self.lin_old_t is not None
                 if self._in_train_step and self.prefetch_after_fwd:
                     self._prefetch_early()
