@@ -133,6 +133,8 @@ SIGNATURES = {
     "dr_version": [],
     "dr_set_gemm_mode": [_i32],
     "dr_get_gemm_mode": [],
+    "dr_set_gemm_split": [_i32],
+    "dr_get_gemm_split": [],
 }
 _RESTYPE = {"dr_version": ctypes.c_char_p, "dr_shard_bucket_workspace_bytes": ctypes.c_int64,
             "dr_emb_sort_workspace_bytes": ctypes.c_int64, "dr_ivf_build_workspace_bytes": ctypes.c_int64,

@@ -28,6 +28,7 @@
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 #include <atomic>
 #include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -752,6 +753,13 @@ static int gemm_mode_default() {
     return DR_GEMM_BF16X3;
 }
 static std::atomic<int> g_gemm_mode{gemm_mode_default()};
+// process-wide operand split of the register-split GEMMs (dr_set_gemm_split): THE one parser of DR_GEMM_SPLIT -- f16x2 iff the
+// variable is unset or spells exactly "f16x2"; anything else is the six-product bf16x3 split
+static int gemm_split_default() {
+    const char* e = getenv("DR_GEMM_SPLIT");
+    return (e == nullptr || strcmp(e, "f16x2") == 0) ? DR_GEMM_SPLIT_F16X2 : DR_GEMM_SPLIT_BF16X3;
+}
+static std::atomic<int> g_gemm_split{gemm_split_default()};
 
 template <bool A_RC, bool B_RC, int EPI>
 int launch(GemmArgs& g, hipStream_t s) {
@@ -1387,5 +1395,12 @@ extern "C" int32_t dr_set_gemm_mode(int32_t mode) {
 }
 
 extern "C" int32_t dr_get_gemm_mode(void) { return g_gemm_mode.load(); }
+
+extern "C" int32_t dr_set_gemm_split(int32_t split) {
+    if (split != DR_GEMM_SPLIT_BF16X3 && split != DR_GEMM_SPLIT_F16X2) return DR_EINVAL;
+    return g_gemm_split.exchange(split);
+}
+
+extern "C" int32_t dr_get_gemm_split(void) { return g_gemm_split.load(); }
 
 extern "C" const char* dr_version(void) { return "deep_recommenders_amd hot path / gfx950 / f32"; }

@@ -285,6 +285,7 @@ extern "C" int dr_bf3_linear_nt(const float* A, int64_t lda, const void* b_plane
                                 int32_t N, int32_t K, const float* bias, int32_t act, const float* mask, int64_t ld_mask,
                                 int32_t accumulate, float* C, int64_t ldc, dr_stream_t stream);
 extern "C" int32_t dr_get_gemm_mode(void);
+extern "C" int32_t dr_get_gemm_split(void);
 // the same three in the f16x2 operand mode (bf3_gemm.hip; include/dr_hotpath.h "f16x2 operand mode")
 int dr_h2_scores_filter(const float* a, int64_t lda, const uint32_t* a_amax, const void* b_planes, int64_t b_plane_stride, int64_t b_ld,
                         const uint32_t* b_amax, int64_t M, int32_t N, int32_t K, const float* tau, float* cand_s, int32_t* cand_c,
@@ -342,8 +343,7 @@ extern "C" int dr_topk_mips(const float* q, int64_t Bq, const float* cand, int64
     // f16x2 operand mode of the scan (round 4; DR_GEMM_SPLIT=bf16x3 restores the six-product scan): queries and corpus as two fp16 terms
     // of x * 2^k, three matrix instructions per fragment pair.  ONE scale for the whole corpus (a pass over it: 0.1 ms per million
     // 128-wide items) and one for the queries, so that equal candidates still tie bit-exactly whichever chunk they sit in.
-    static const bool h2_env = [] { const char* e = getenv("DR_GEMM_SPLIT"); return !(e != nullptr && e[0] == 'b'); }();
-    const bool h2 = rs_scan && h2_env;
+    const bool h2 = rs_scan && dr_get_gemm_split() == DR_GEMM_SPLIT_F16X2;      // read at every call (dr_set_gemm_split)
     uint32_t* rec_q = reinterpret_cast<uint32_t*>(wsb + Bq * 8);
     uint32_t* rec_c = rec_q + 1;
     if (h2) {

@@ -59,8 +59,8 @@ class DCNEngine:
         # "f16x2" operand mode of every wide GEMM (round 4; see DeepFMEngine / include/dr_hotpath.h dr_h2_*): three matrix
         # instructions per fragment pair instead of six.  Every GEMM's activation operand needs its amax record: x0's is built by
         # one dr_h2_amax pass, every later operand's comes out of the kernel that PRODUCES it (the GEMM epilogues' c_amax, the cross
-        # combine backward's d_prod_amax).  DR_GEMM_SPLIT=bf16x3 restores the six-product mode.
-        self.h2 = on and _os.environ.get("DR_GEMM_SPLIT", "f16x2") == "f16x2" and ops.planes_worthwhile(B, self.in_dim, self.in_dim)
+        # combine backward's d_prod_amax).  ops.set_gemm_split("bf16x3") / DR_GEMM_SPLIT=bf16x3 (read once, by the library) restores the six-product mode.
+        self.h2 = on and ops.get_gemm_split() == "f16x2" and ops.planes_worthwhile(B, self.in_dim, self.in_dim)
         self.h2_all_wide = self.h2                               # (bench.py: every planes GEMM of this engine is priced as f16x2)
         WP = ops.H2WeightPlanes if self.h2 else ops.WeightPlanes
         self.cross_planes = [WP(W) if on and ops.planes_worthwhile(B, self.in_dim, self.in_dim) else None

@@ -191,9 +191,9 @@ class DeepFMEngine:
         # bf16x3 mode's.  The power-of-two scales come from amax records kept on the device: the table's is a running maximum (one
         # pass over the table here, K4 raises it with every value it writes), the dense features' is rebuilt whenever dense_pad is
         # written, d h0's comes out of the narrow backward that produces it, W's out of the plane refresh.
-        # DR_GEMM_SPLIT=bf16x3 restores the six-product mode.  Needs the fused first layer, the gathering wgrad and the sorted K4;
+        # ops.set_gemm_split("bf16x3") / DR_GEMM_SPLIT=bf16x3 (read once, by the library) restores the six-product mode.  Needs the fused first layer, the gathering wgrad and the sorted K4;
         # "adam_tf" (whose catch-up kernel also writes table rows) stays on bf16x3.
-        self.h2 = (_os.environ.get("DR_GEMM_SPLIT", "f16x2") == "f16x2" and self.no_concat and self.wplanes[0] is not None
+        self.h2 = (ops.get_gemm_split() == "f16x2" and self.no_concat and self.wplanes[0] is not None
                    and not self.adam_tf and _os.environ.get("DR_OVERLAP_DW", "0") != "1")
         if self.h2:
             self.wplanes[0] = ops.H2WeightPlanes(self.Ws[0])
@@ -247,7 +247,10 @@ class DeepFMEngine:
         # (Adam's dense step consumes the gradient bucket they fill).
         _rs = _os.environ.get("DR_REDUCE_SIDE", "0")
         self.reduce_side = (sorted_bwd and optimizer == "sgd" and _rs in ("1", "2") and _os.environ.get("DR_SORT_INLINE", "0") != "1")
-        self.reduce_side_wgrad = self.reduce_side and _rs == "1"          # "2": the head's and the narrow backward's only
+        # "2": the head's and the narrow backward's only.  The wgrad's reduce is never deferred in the f16x2 mode: its part 2 divides
+        # by the scales part 1 multiplied with, both derived from the table's amax record at launch time -- on the side stream it
+        # would run beside K4, which raises that record (a power-of-two crossing between the two parts = W0 off by 2^k)
+        self.reduce_side_wgrad = self.reduce_side and _rs == "1" and not self.h2
         self._small_pending = False
         self._planes_pending = False
         self._planes_pending_l0 = False

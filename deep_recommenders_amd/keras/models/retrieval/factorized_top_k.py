@@ -203,12 +203,16 @@ class Faiss(TopK):
         centroids = cand[torch.randperm(N, device=cand.device, generator=g)[:self._nlist]].clone()
         if self._nlist == 1:
             return cand.mean(0, keepdim=True)
+        # the cluster sizes ride along with the sums in the scatter-add's first-order channel (a ones vector as the per-row scalar):
+        # one launch per iteration; the list build -- hist + scan + scatter -- is only needed once, by index() (fp32 counts are exact
+        # to 2^24 members per cluster)
+        ones = torch.ones(N, dtype=torch.float32, device=cand.device)
         for _ in range(self._niter):
             a = self._assign(cand, centroids)
             sums = torch.zeros((self._nlist, D), dtype=torch.float32, device=cand.device)
-            ops.rows_scatter_add(a, cand, None, 1.0, sums, None)
-            _, ls = ops.ivf_build_lists(a, self._nlist)
-            counts = (ls[1:] - ls[:-1]).to(torch.float32).reshape(-1, 1)
+            counts = torch.zeros(self._nlist, dtype=torch.float32, device=cand.device)
+            ops.rows_scatter_add(a, cand, ones, 1.0, sums, counts)
+            counts = counts.reshape(-1, 1)
             centroids = torch.where(counts > 0, sums / counts.clamp(min=1.0), centroids)     # an empty cluster keeps its centroid
         return centroids
 

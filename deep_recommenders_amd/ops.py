@@ -720,11 +720,23 @@ def topk_mips(q, cand, k, index_base=0, init=True, state=None, workspace=None):
     return state
 
 
+IVF_BUILD_MAX_LISTS = 8192          # IVB_MAXLIST of csrc/ivf.hip
+
+
 def ivf_build_lists(assign, nlist):
     """(order [N] int64, list_start [nlist + 1] int64): the vectors grouped by coarse list, input order kept inside a list
     (dr_ivf_build_lists: stable counting sort on the device)."""
     assign = _c(assign, torch.int64)
     N = assign.numel()
+    if int(nlist) > IVF_BUILD_MAX_LISTS:
+        # more coarse lists than the kernel's LDS histogram holds (8192; the reference's own examples use 100): a stable sort by list
+        # through torch -- index build, not the search path
+        valid = (assign >= 0) & (assign < int(nlist))
+        key = torch.where(valid, assign, torch.full_like(assign, int(nlist)))
+        order = torch.sort(key, stable=True).indices[:int(valid.sum())]
+        list_start = torch.zeros(int(nlist) + 1, dtype=torch.int64, device=assign.device)
+        list_start[1:] = torch.cumsum(torch.bincount(assign[valid], minlength=int(nlist)), 0)
+        return order, list_start
     order = torch.empty(max(N, 1), dtype=torch.int64, device=assign.device)[:N]
     list_start = torch.empty(int(nlist) + 1, dtype=torch.int64, device=assign.device)
     nb = lib().dr_ivf_build_workspace_bytes(N, int(nlist))
@@ -889,6 +901,25 @@ def set_gemm_mode(mode):
 
 def get_gemm_mode():
     return "native" if _lib.lib().dr_get_gemm_mode() == GEMM_NATIVE_F32 else "bf16x3"
+
+
+GEMM_SPLIT_BF16X3, GEMM_SPLIT_F16X2 = 0, 1
+_GEMM_SPLITS = {"bf16x3": GEMM_SPLIT_BF16X3, "f16x2": GEMM_SPLIT_F16X2}
+
+
+def set_gemm_split(split):
+    """'f16x2' (default) or 'bf16x3': the operand split the engines (at construction) and the exact top-K scan (at every call) use
+    for their register-split GEMMs -- the library's dr_set_gemm_split, the one switch (and the one parser of DR_GEMM_SPLIT).
+    Returns the previous split's name.  Process-wide."""
+    v = _GEMM_SPLITS[split] if isinstance(split, str) else int(split)
+    prev = _lib.lib().dr_set_gemm_split(v)
+    if prev < 0:
+        raise ValueError("unknown GEMM split %r" % (split,))
+    return "f16x2" if prev == GEMM_SPLIT_F16X2 else "bf16x3"
+
+
+def get_gemm_split():
+    return "f16x2" if _lib.lib().dr_get_gemm_split() == GEMM_SPLIT_F16X2 else "bf16x3"
 
 
 # ---- K7p: first tower layer on pre-split operands ("planes": three bf16 terms per fp32 value, include/dr_hotpath.h) -------

@@ -624,7 +624,7 @@ class ShardedDeepFMEngine:
         # its own shard (K4 raises it) and, with real peers, one 4-byte all-reduce(MAX) behind the step's last owner-side update makes
         # it the bound for the rows any rank may receive in the next step (on the communication stream, long before those rows
         # arrive).  d h0's record comes out of the narrow backward per micro-batch.  DR_GEMM_SPLIT=bf16x3: the six-product mode.
-        self.h2 = (self.fuse_k3 and not self.fuse_pack and _os.environ.get("DR_GEMM_SPLIT", "f16x2") == "f16x2"
+        self.h2 = (self.fuse_k3 and not self.fuse_pack and ops.get_gemm_split() == "f16x2"
                    and not (self.fuse_head and nl - 2 == 0))
         if self.h2:
             self.wplanes[0] = ops.H2WeightPlanes(self.Ws[0])

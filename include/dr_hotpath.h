@@ -55,6 +55,20 @@ const char* dr_version(void);
 int32_t dr_set_gemm_mode(int32_t mode);
 int32_t dr_get_gemm_mode(void);
 
+/* The operand split of the register-split GEMMs under DR_GEMM_BF16X3 (the dr_bf3_* / dr_h2_* families below): how many low-precision
+ * terms carry one fp32 operand value.
+ *   DR_GEMM_SPLIT_F16X2   (default) two fp16 terms of x * 2^k, three matrix instructions per fragment pair (dr_h2_*; 22 significant
+ *                         bits per operand, whole-GEMM error against fp64 at or below the six-product split's: DESIGN.md §3)
+ *   DR_GEMM_SPLIT_BF16X3  three bf16 terms, six matrix instructions per fragment pair (dr_bf3_*)
+ * The dr_bf3_* and dr_h2_* entry points are explicit and ignore this setting; it is the ONE switch the callers that choose between
+ * them consult -- the engines of the host package at construction, and dr_topk_mips (the exact scan picks dr_h2_* or dr_bf3_*) at
+ * every call.  dr_set_gemm_split returns the previous value (DR_EINVAL for an unknown one); process-wide.  Environment override of
+ * the initial value, parsed here and nowhere else: DR_GEMM_SPLIT=f16x2 (or unset) | anything else = bf16x3. */
+#define DR_GEMM_SPLIT_BF16X3 0
+#define DR_GEMM_SPLIT_F16X2 1
+int32_t dr_set_gemm_split(int32_t split);
+int32_t dr_get_gemm_split(void);
+
 /* ------------------------------------------------------------------------------------------
  * K1  hash-bucket column:  id = int64( FarmHash::Fingerprint64(as_string(key)) mod N )
  * replaces [TF] categorical_column_with_hash_bucket ->

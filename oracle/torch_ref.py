@@ -53,11 +53,44 @@ def emb_fm_forward(table, lin_w, bias, ids, col_start, row_base):
     return concat, stack.sum(1), logit
 
 
-def dnn(x, kernels, biases):
-    """keras deepfm.py:30-34 / estimator dnn.py:17-29: relu hidden layers, linear last layer."""
-    for W, b in zip(kernels[:-1], biases[:-1]):
-        x = torch.relu(x @ W + b)
+def dnn(x, kernels, biases, relu_masks=None, ties=None, tie_eps=1e-5):
+    """keras deepfm.py:30-34 / estimator dnn.py:17-29: relu hidden layers, linear last layer.
+
+    Tie-aware comparison (relu_masks).  relu(z) has no derivative at z = 0, and two correct fp32
+    implementations of z = x W + b differ in its last bits: of the ~10^7 hidden units of a 65 536-example batch a handful have
+    |z| below that rounding, and each side picks "on" or "off" for them -- a different subgradient, an equally valid one, that
+    moves a whole row of the example's input gradient.  relu_masks[i] (bool [B, units_i], the units the IMPLEMENTATION UNDER TEST
+    treated as on in hidden layer i) makes the oracle evaluate h = z * mask instead of relu(z): the same function wherever
+    mask == (z > 0).  Every unit where they disagree is recorded in `ties` (a list, one dict per layer) and must be a tie:
+    |z_oracle| <= tie_eps * rms(z) -- the caller asserts that with check_ties(); a mask that is wrong anywhere else fails there,
+    so the mask cannot hide an error larger than the rounding of z.  relu_masks = None: plain relu."""
+    n_hidden = len(kernels) - 1
+    for i, (W, b) in enumerate(zip(kernels[:-1], biases[:-1])):
+        z = x @ W + b
+        if relu_masks is None:
+            x = torch.relu(z)
+            continue
+        m = relu_masks[i]
+        assert m.dtype == torch.bool and m.shape == z.shape and len(relu_masks) == n_hidden
+        zd = z.detach()
+        dis = m != (zd > 0)
+        if ties is not None:
+            rms = float(zd.double().pow(2).mean().sqrt())
+            worst = float(zd[dis].abs().max()) if bool(dis.any()) else 0.0
+            ties.append({"layer": i, "units": dis.numel(), "disagree": int(dis.sum()), "worst_abs_z": worst, "rms_z": rms,
+                         "examples": torch.nonzero(dis.any(1)).reshape(-1).tolist()[:64], "tie_eps": tie_eps})
+        x = z * m.to(z.dtype)
     return x @ kernels[-1] + biases[-1]
+
+
+def check_ties(ties, max_frac=1e-5):
+    """The assertion half of dnn(relu_masks=...): every unit where the device's ReLU decision differs from the oracle's is within
+    tie_eps * rms(z) of zero (the two sides' rounding of z), and there are at most max_frac of them (measured: 0 - 4 of 1.7e7)."""
+    for t in ties:
+        assert t["worst_abs_z"] <= t["tie_eps"] * t["rms_z"], "ReLU mask of layer %d is wrong at a unit with |z| = %.3e (rms z %.3e): not a tie" % (
+            t["layer"], t["worst_abs_z"], t["rms_z"])
+        assert t["disagree"] <= max(4, max_frac * t["units"]), "layer %d: %d of %d ReLU decisions differ from the oracle's" % (
+            t["layer"], t["disagree"], t["units"])
 
 
 def deepfm_logit(table, lin_w, bias, ids, col_start, row_base, kernels, biases, dense=None):

@@ -12,7 +12,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu under gpurun)")
 
 
+# Order of the GPU suite under the driver's `pytest -x`: deterministic kernel-level files first -- every §8
+# kernel row gets its evidence before any composed model runs -- then the models, the two-rank and full-size tests, and the
+# 66 GB engine-level oracle tests of bench.py's exact configurations last.  Files not listed keep their place in front (CPU tests).
+_GPU_ORDER = ["test_gpu_kernels.py", "test_gpu_h2_gemm.py", "test_gpu_retrieval.py", "test_gpu_cin_din.py", "test_gpu_edge_cases.py",
+              "test_gpu_models.py", "test_gpu_two_tower.py", "test_gpu_sharded_two_rank.py", "test_bench_launch.py",
+              "test_gpu_fullsize.py", "test_gpu_benchcfg.py"]
+
+
 def pytest_collection_modifyitems(config, items):
+    rank = {name: i + 1 for i, name in enumerate(_GPU_ORDER)}
+    items.sort(key=lambda it: rank.get(os.path.basename(str(it.fspath)), 0))       # stable: order inside a file is kept
     # GPU tests are skipped (not failed) when no device is visible, e.g. a plain `pytest tests/`.
     try:
         import torch

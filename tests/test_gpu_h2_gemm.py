@@ -297,8 +297,8 @@ def test_engine_f16x2_step_tracks_the_bf16x3_step(optimizer, monkeypatch):
         return eng, losses
     h2, l2 = run()
     assert h2.h2
-    monkeypatch.setenv("DR_GEMM_SPLIT", "bf16x3")
-    b3, l3 = run()
+    with _split("bf16x3"):
+        b3, l3 = run()
     assert not b3.h2
     for a, b in zip(l2, l3):
         assert abs(a - b) <= 1e-5 * abs(b), (l2, l3)
@@ -306,7 +306,6 @@ def test_engine_f16x2_step_tracks_the_bf16x3_step(optimizer, monkeypatch):
     assert (h2.table - b3.table).abs().max().item() <= tol * b3.table.abs().max().item()
     assert (h2.flat_params - b3.flat_params).abs().max().item() <= tol * b3.flat_params.abs().max().item()
     # the run is reproducible bit for bit (records, scales and the three-product sums are deterministic)
-    monkeypatch.delenv("DR_GEMM_SPLIT")
     again, l2b = run()
     assert l2b == l2 and torch.equal(again.table, h2.table) and torch.equal(again.flat_params, h2.flat_params)
 
@@ -372,8 +371,8 @@ def test_dcn_engine_f16x2_step_tracks_the_bf16x3_step(monkeypatch):
         return eng, losses
     h2, l2 = run()
     assert h2.h2 and all(isinstance(p, ops_mod().H2WeightPlanes) for p in h2.cross_planes)
-    monkeypatch.setenv("DR_GEMM_SPLIT", "bf16x3")
-    b3, l3 = run()
+    with _split("bf16x3"):
+        b3, l3 = run()
     assert not b3.h2
     for a, b in zip(l2, l3):
         assert abs(a - b) <= 1e-5 * abs(b), (l2, l3)
@@ -388,3 +387,49 @@ def test_dcn_engine_f16x2_step_tracks_the_bf16x3_step(monkeypatch):
 def ops_mod():
     from deep_recommenders_amd import ops as _ops
     return _ops
+
+
+class _split:
+    """`with _split("bf16x3"):` -- the library's one operand-split switch (dr_set_gemm_split) set for the block and restored after
+    it.  The engines read it at construction, the exact top-K scan at every call; an environment variable patched after the
+    library was loaded would be ignored by both."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.prev = ops_mod().set_gemm_split(self.name)
+        assert ops_mod().get_gemm_split() == self.name
+
+    def __exit__(self, *exc):
+        ops_mod().set_gemm_split(self.prev)
+
+
+def test_gemm_split_switch_is_the_librarys_and_is_read_where_documented(monkeypatch):
+    """dr_set_gemm_split / dr_get_gemm_split: one switch for the engines (read at construction) and the top-K scan (read at every
+    call).  The environment variable is parsed once, by the library, when it is loaded: patching it afterwards changes nothing."""
+    from deep_recommenders_amd.engine import DeepFMEngine
+    o = ops_mod()
+    start = o.get_gemm_split()
+    monkeypatch.setenv("DR_GEMM_SPLIT", "bf16x3" if start == "f16x2" else "f16x2")
+    assert o.get_gemm_split() == start
+    with pytest.raises((KeyError, ValueError)):
+        o.set_gemm_split("fp8x4")
+    mk = lambda: DeepFMEngine(6, 3000, 64, [256, 32], 4608, num_dense=5, lr=0.05, seed=3)
+    with _split("f16x2"):
+        assert mk().h2
+        with _split("bf16x3"):
+            assert not mk().h2
+        assert o.get_gemm_split() == "f16x2"
+        # the exact scan: the two splits give (slightly) different score bits for the same inputs, within fp32 noise of each other
+        g = torch.Generator(device="cuda").manual_seed(5)
+        q = torch.randn((256, 128), device="cuda", generator=g)
+        c = torch.randn((20000, 128), device="cuda", generator=g)
+        s_h2, i_h2 = o.topk_mips(q, c, 10)
+        with _split("bf16x3"):
+            s_b3, i_b3 = o.topk_mips(q, c, 10)
+        s_again, i_again = o.topk_mips(q, c, 10)
+        assert torch.equal(s_h2, s_again) and torch.equal(i_h2, i_again)
+        assert not torch.equal(s_h2, s_b3), "the scan did not change its product mode with the switch"
+        assert (s_h2 - s_b3).abs().max().item() <= 1e-5 * s_b3.abs().max().item()
+    assert o.get_gemm_split() == start
