@@ -491,6 +491,23 @@ def main():
         torch.cuda.synchronize()
         k4_alone_us = e0.elapsed_time(e1) / 10 * 1e3
 
+    # ... and the bare forward gather + pool kernel (K3 + K5 + K6: dr_emb_pool_fwd, what DR_FUSE_K3=0 runs) on the same batch, alone:
+    # in the default step K3 lives inside the first layer's MFMA-bound GEMM and has no HBM roofline of its own; north_star asks for
+    # the forward AND the backward fraction.  It writes concat / sum_x / fm_logit of the last batch again.
+    k3_alone_us = None
+    if plan_alone_us is not None and getattr(eng, "concat", None) is not None and hasattr(eng, "alg_bytes_fwd"):
+        k3 = lambda: _ops.emb_pool_fwd(eng.ids, eng.F, None, eng.row_base, eng.table, eng.lin_w, eng.lin_bias, ld_concat=eng.ld,
+                                       concat=eng.concat, sum_x=eng.sum_x, fm_logit=eng.fm_logit)
+        for _ in range(3):
+            k3()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            k3()
+        e1.record()
+        torch.cuda.synchronize()
+        k3_alone_us = e0.elapsed_time(e1) / 10 * 1e3
+
     kernels = eng.kernel_event_summary() if prof is not None else {}
     pairs = eng.concurrent_pair_summary() if (prof is not None and hasattr(eng, "concurrent_pair_summary")) else []
     exchange = None
@@ -530,7 +547,7 @@ def main():
     traffic, traffic_source = {}, None
     traffic_note = "HBM counters need the profiler (rocprofv3 --pmc passes of this command, tools/collect_profiles.sh); not collected inside bench.py"
     try:
-        src = next(("profiles/%s_pmc_traffic.json" % r for r in ("r04", "r03", "r02", "r01")
+        src = next(("profiles/%s_pmc_traffic.json" % r for r in ("r05", "r04", "r03", "r02", "r01")
                     if os.path.exists(os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % r))), "profiles/r01_pmc_traffic.json")
         pmc = json.load(open(os.path.join(ROOT, src)))
         name_map = pmc.get("event_names") or {}
@@ -648,22 +665,34 @@ def main():
                     roofline["achieved"] * roofline["avg_us"] / (roofline["avg_us"] + plan_alone_us) / roofline["peak"], 4)
         if mfma_rows:
             roofline_mfma = dict(mfma_rows[0])
-    # measured device-to-device copy ceiling next to the spec peak: hipMemcpyDtoD of 1 GiB, read + write bytes
+    roofline_fwd_bare = None
+    if k3_alone_us is not None:
+        fb = float(eng.alg_bytes_fwd())
+        ach = fb / (k3_alone_us * 1e-6) / 1e9
+        roofline_fwd_bare = {"kernel": "emb_pool_fwd", "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(ach / HBM_PEAK_GBS, 4), "avg_us": round(k3_alone_us, 2), "launches": 10,
+                             "alg_bytes": int(fb), "traffic": traffic.get("emb_pool_fwd"),
+                             "scope": "the bare gather + pool forward (dr_emb_pool_fwd: K3 + first-order + FM terms, concat stored; SURVEY 8(d) "
+                                      "bytes 8FD + 12F + 8 per example) on the last batch, ALONE after the timed region -- in the timed step K3 runs "
+                                      "inside emb_linear_fwd_L0 (see that row's hbm_side); DR_FUSE_K3=0 puts this kernel into the step"}
+    # measured copy ceiling next to the spec peak: the library's own streaming copy (dr_copy_nt: 16-byte
+    # nontemporal loads / stores, the guide's "float4 copy") over 1 GiB, read + write bytes.  (Rounds 1-4 timed a torch copy here,
+    # which K4 exceeded: not a ceiling.)
     copy_gbs = None
     try:
         if world == 1 or not a.share_device:
             src_c = torch.empty(1 << 28, dtype=torch.float32, device=device)
             dst_c = torch.empty_like(src_c)
             src_c.zero_()
-            for _ in range(2):
-                dst_c.copy_(src_c)
+            for _ in range(3):
+                dr_ops.copy_nt(src_c, dst_c)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(5):
-                dst_c.copy_(src_c)
+            for _ in range(10):
+                dr_ops.copy_nt(src_c, dst_c)
             e1.record()
             torch.cuda.synchronize()
-            copy_gbs = 2.0 * src_c.numel() * 4 / (e0.elapsed_time(e1) / 5 * 1e-3) / 1e9
+            copy_gbs = 2.0 * src_c.numel() * 4 / (e0.elapsed_time(e1) / 10 * 1e-3) / 1e9
             del src_c, dst_c
     except Exception:
         copy_gbs = None
@@ -673,7 +702,7 @@ def main():
             roofline["traffic_note"] = traffic_note
         roofline["peak_basis"] = roofline.get("peak_basis") or "HBM3E spec peak 8.0 TB/s (MI355X_MICROARCH.md)"
         if copy_gbs is not None and roofline.get("unit") == "GB/s":
-            roofline["measured_copy_ceiling_GBps"] = round(copy_gbs, 1)      # 1 GiB hipMemcpyDtoD on this box, read + write bytes
+            roofline["measured_copy_ceiling_GBps"] = round(copy_gbs, 1)      # dr_copy_nt over 1 GiB on this box, read + write bytes
             roofline["frac_of_measured_copy_ceiling"] = round(roofline["achieved"] / copy_gbs, 4)
         roofline["event_scope"] = (("HIP events around each phase in %d bracketed steps run after the timed region (the timed region itself carries none)" % EV_EXTRA) if events_after else
                                    "HIP events on the launch stream around each kernel, every %d-th step of the timed region; an event pair also "
@@ -717,6 +746,7 @@ def main():
                                          if (a.gemm == "bf16x3" and getattr(eng, "h2", False)) else
                                          "fp32 in / fp32 accumulate; products = 6 bf16 MFMA products of exact 3-way bf16 splits (error vs fp64 <= native fp32 MFMA, tests/test_gpu_kernels.py)"
                                          if a.gemm == "bf16x3" else "native v_mfma_f32_32x32x2_f32"),
+                       "gemm_split": dr_ops.get_gemm_split() if a.gemm == "bf16x3" else None,      # what the LIBRARY reports (dr_get_gemm_split)
                        "global_batch": a.batch * world, "parallelism": par, "final_loss": round(loss, 6),
                        "per_kernel_events": prof is not None, "per_kernel_events_every_n_steps": ev_every if prof is not None else None,
                        "per_kernel_events_in_timed_region": (prof is not None and not events_after)},
@@ -725,6 +755,10 @@ def main():
         }
         if roofline_mfma is not None:
             out["roofline_mfma"] = roofline_mfma
+        if roofline_fwd_bare is not None:
+            if copy_gbs is not None:
+                roofline_fwd_bare["frac_of_measured_copy_ceiling"] = round(roofline_fwd_bare["achieved"] / copy_gbs, 4)
+            out["roofline_fwd_bare"] = roofline_fwd_bare
         if roof_pairs:
             out["roofline_pairs"] = roof_pairs
         out.update(extra)

@@ -128,6 +128,7 @@ SIGNATURES = {
     "dr_dropout_bwd": [_p, _i64, _p, _i64, _i32, _f32, _p, _i64, _p],
     "dr_reduce_sum": [_p, _i64, _i32, _f32, _i32, _p, _p, _p],
     "dr_clock_stamp": [_p, _p],
+    "dr_copy_nt": [_p, _p, _i64, _p],
     "dr_ivf_build_workspace_bytes": [_i64, _i32],
     "dr_ivf_build_lists": [_p, _i64, _i32, _p, _p, _p, _i64, _p],
     "dr_version": [],

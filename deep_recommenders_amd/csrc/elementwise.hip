@@ -165,6 +165,39 @@ extern "C" int dr_reduce_sum(const float* x, int64_t n, int32_t squared, float a
 // around a wait turned out to serialise the sharded step (round 4: 1.93 ms -> 4.1 ms with four bracketed waits per step).
 __global__ void clock_stamp_kernel(uint64_t* __restrict__ dst) { dst[0] = wall_clock64(); }
 
+// Measurement plumbing (bench.py's `measured_copy_ceiling`): a streaming copy of 16-byte vectors with nontemporal loads and stores,
+// 4 independent vectors in flight per thread, grid = 16 blocks per CU -- the guide's "float4 copy" (6.29 TB/s read + write on MI355X).
+// What an HBM-bound kernel of this library can at best reach on THIS box; hipMemcpyDtoD / a torch copy is not a ceiling.
+typedef float copy_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void copy_nt_kernel(const copy_f4* __restrict__ src, copy_f4* __restrict__ dst, int64_t n16) {
+    const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+    for (int64_t i = ((int64_t)blockIdx.x * 4) * 256 + threadIdx.x; i < n16; i += stride) {
+        copy_f4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t j = i + u * 256;
+            v[u] = __builtin_nontemporal_load(src + (j < n16 ? j : i));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t j = i + u * 256;
+            if (j < n16) __builtin_nontemporal_store(v[u], dst + j);
+        }
+    }
+}
+
+extern "C" int dr_copy_nt(const void* src, void* dst, int64_t bytes, dr_stream_t stream) {
+    if (bytes < 0 || (bytes & 15)) return DR_EINVAL;
+    if (bytes == 0) return DR_OK;
+    if (!src || !dst || ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15)) return DR_EINVAL;
+    const int64_t n16 = bytes / 16;
+    const int64_t want = (n16 + 1023) / 1024;
+    const unsigned grid = (unsigned)(want < 4096 ? want : 4096);
+    hipLaunchKernelGGL(copy_nt_kernel, dim3(grid), dim3(256), 0, dr_s(stream), static_cast<const copy_f4*>(src), static_cast<copy_f4*>(dst), n16);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
 extern "C" int dr_clock_stamp(uint64_t* dst, dr_stream_t stream) {
     if (!dst) return DR_EINVAL;
     hipLaunchKernelGGL(clock_stamp_kernel, dim3(1), dim3(1), 0, dr_s(stream), dst);

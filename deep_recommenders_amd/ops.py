@@ -1364,6 +1364,13 @@ def reduce_sum(x, squared=False, alpha=1.0, out=None, accumulate=False):
     return out
 
 
+def copy_nt(src, dst):
+    """dst = src as a streaming 16-byte nontemporal copy (dr_copy_nt): the measured HBM ceiling bench.py reports."""
+    assert src.is_contiguous() and dst.is_contiguous() and src.numel() * src.element_size() == dst.numel() * dst.element_size()
+    check(lib().dr_copy_nt(ptr(src), ptr(dst), src.numel() * src.element_size(), stream_ptr()), "dr_copy_nt")
+    return dst
+
+
 def clock_stamp(buf, index):
     """buf[index] (int64 device tensor) = the device wall clock (100 MHz ticks) when the current stream reaches this point
     (dr_clock_stamp: a one-thread kernel; measurement plumbing for bench.py's exposed-wait report)."""

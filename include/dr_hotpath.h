@@ -783,6 +783,11 @@ int dr_reduce_sum(const float* x, int64_t n, int32_t squared, float alpha, int32
  * stamps to report the EXPOSED part of the exchange (HIP timing events around a wait serialise the step). */
 int dr_clock_stamp(uint64_t* dst, dr_stream_t stream);
 
+/* Measurement plumbing: dst[0 .. bytes) = src[0 .. bytes) as a streaming copy of 16-byte vectors with nontemporal loads / stores
+ * (bytes a multiple of 16, both pointers 16-byte aligned; DR_EINVAL otherwise).  bench.py times it over 1 GiB as the
+ * `measured_copy_ceiling` beside the 8 TB/s spec peak: read + write bytes / time is what an HBM-bound kernel can reach on that box. */
+int dr_copy_nt(const void* src, void* dst, int64_t bytes, dr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

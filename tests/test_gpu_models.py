@@ -366,7 +366,9 @@ def test_engine_schedule_switches_are_bit_identical(switch, value, monkeypatch):
     monkeypatch.setenv(switch, value)
     alt, l1 = run()
     if switch == "DR_REDUCE_SIDE":
-        assert alt.reduce_side and alt.reduce_side_wgrad == (value == "1")
+        # (the wgrad's reduce is deferred only in the bf16x3 split: in the f16x2 mode its second half would derive its scales from the
+        # table's amax record while K4 raises it on the other stream -- engine.py)
+        assert alt.reduce_side and alt.reduce_side_wgrad == (value == "1" and not alt.h2)
     else:
         assert alt.prefetch_early
     assert l0 == l1
