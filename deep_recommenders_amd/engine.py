@@ -208,11 +208,17 @@ class DeepFMEngine:
         # GEMMs (the fused first layer occupies all 160 KB of LDS on every CU) the sort chain's ~20 small launches only advance in
         # the gaps: 1.2 ms instead of 0.17, and K4 waited 74 us for it (round 2, rocprofv3: K4 305 us, its event 379 us).
         self.prefetch_plan = _os.environ.get("DR_PREFETCH_PLAN", "1") == "1"
-        # DR_PREFETCH_EARLY=1 (experiment, round 4): the next batch's hash + slot plan start at the BEGINNING of this step (beside the
+        # DR_PREFETCH_EARLY=1: the next batch's hash + slot plan start at the BEGINNING of this step (beside the
         # GEMMs, where they crawl but have a whole step of slack) instead of beside K4, which then has HBM to itself; the next batch's
         # dense features are still placed after this step's wgrad.
-        self.prefetch_early = _os.environ.get("DR_PREFETCH_EARLY", "0") in ("1", "2")
-        self.prefetch_after_fwd = _os.environ.get("DR_PREFETCH_EARLY", "0") == "2"      # "2": behind the first GEMM, beside the tower tail
+        # Round 5: ON by default.  With the f16x2 GEMMs the trade measured in round 4 (K4 -17 us, the GEMMs +14) has become neutral for the
+        # step (1.191 / 1.195 / 1.200 ms against 1.187 / 1.218 / 1.189 / 1.209, alternating, profiles/r05_ab_side_stream.log): the fused
+        # forward no longer shares the machine with the tail of the previous step's plan (251 -> 237 us), K4 runs 260 - 265 us instead of
+        # 267 - 301 (0.63 - 0.645 of the roofline instead of 0.555 - 0.627: the kernel the metric names keeps its margin over 0.60
+        # whatever the box), the wgrad and the narrow backward pay 3 us each.  DR_PREFETCH_EARLY=0: beside K4 as in rounds 2 - 4.
+        _pe = _os.environ.get("DR_PREFETCH_EARLY", "1")
+        self.prefetch_early = _pe in ("1", "2")
+        self.prefetch_after_fwd = _pe == "2"      # "2": behind the first GEMM, beside the tower tail
         # Fewer cross-stream packets in front of K4 (rocprofv3 showed a 31 us gap there against 11 - 13 us between the other
         # dependent kernels): the side chain is ordered behind the plane refresh instead of an event of its own, and the wait for
         # a PREFETCHED plan -- long complete by then -- sits in front of the first-layer wgrad.  DR_LEAN_EVENTS=0: as before.
@@ -220,6 +226,9 @@ class DeepFMEngine:
         self._plan_prefetched = False
         if sorted_bwd:
             self._plans = [ops.SortPlan(B * F, device) for _ in range(2)]
+            # (round 5, measured and rejected: this stream restricted to a subset of the CUs -- hipExtStreamCreateWithCUMask, every 4th /
+            # every 8th CU -- so that its ~25 small launches would not spread over the machine beside K4: the step went from 1.19 to
+            # 1.75 - 1.85 ms, K4 itself unchanged; profiles/r05_ab_side_stream.log)
             self.side = torch.cuda.Stream(device=device)
             self.ev_ids = torch.cuda.Event()
             self._ev_sorted = [torch.cuda.Event(), torch.cuda.Event()]

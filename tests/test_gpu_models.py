@@ -340,7 +340,7 @@ def test_engine_next_batch_prefetch_is_bit_identical(optimizer, D, V):
     assert engs[0].loss.item() == engs[1].loss.item()
 
 
-@pytest.mark.parametrize("switch,value", [("DR_REDUCE_SIDE", "1"), ("DR_REDUCE_SIDE", "2"), ("DR_PREFETCH_EARLY", "1")])
+@pytest.mark.parametrize("switch,value", [("DR_REDUCE_SIDE", "1"), ("DR_REDUCE_SIDE", "2"), ("DR_PREFETCH_EARLY", "0"), ("DR_PREFETCH_EARLY", "2")])
 def test_engine_schedule_switches_are_bit_identical(switch, value, monkeypatch):
     """Round 4's measured-and-rejected schedules stay correct: the step's small reduce kernels on the side stream
     (dr_tower_head_fwd_bwd_parts / dr_linear_bwd_narrow_parts / dr_bf3_wgrad_emb_parts: the two halves of each call on two streams),
@@ -370,7 +370,8 @@ def test_engine_schedule_switches_are_bit_identical(switch, value, monkeypatch):
         # table's amax record while K4 raises it on the other stream -- engine.py)
         assert alt.reduce_side and alt.reduce_side_wgrad == (value == "1" and not alt.h2)
     else:
-        assert alt.prefetch_early
+        assert base.prefetch_early and not base.prefetch_after_fwd          # the default since round 5: issued at the start of the step
+        assert alt.prefetch_early == (value != "0") and alt.prefetch_after_fwd == (value == "2")
     assert l0 == l1
     assert torch.equal(base.table, alt.table) and torch.equal(base.lin_w, alt.lin_w) and torch.equal(base.flat_params, alt.flat_params)
 
