@@ -1206,6 +1206,21 @@ class ShardedDCNEngine:
         self.ws = torch.empty(1024, **f32)
         self._cuda = torch.device(device).type == "cuda"
         self.mb = 1
+        # The dense half -- cross stack, MLP, loss and their backward -- is dcn_engine.DCNDense, the SAME object the single-GPU DCNEngine
+        # runs (round 5): wide GEMMs on pre-split weights in the operand split the library reports ("f16x2" by default; x0's amax record
+        # comes from a pass over the rows this rank received, so no record has to travel with the exchange), gradients accumulated
+        # into the all-reduce bucket instead of applied in place.  The generic in-kernel-split path below remains for primitives other
+        # than HipPrims (the oracle-backed ones of the gloo tests) and DR_SH_DCN_CORE=0.
+        import os as _os
+        self.core = None
+        if self._cuda and self.p is HipPrims and _os.environ.get("DR_SH_DCN_CORE", "1") == "1":
+            from .dcn_engine import DCNDense
+            self.core = DCNDense(self.cross_W, self.cross_b, self.Ws, self.bs, B, self.in_dim, ld, diag_scale, device,
+                                 grads=(self.g_cross_W, self.g_cross_b, self.gWs, self.gbs))
+            self.loss = self.core.loss
+
+    h2 = property(lambda self: bool(self.core is not None and self.core.h2))
+    h2_all_wide = property(lambda self: bool(self.core is not None and self.core.h2_all_wide))
 
     def enable_kernel_events(self, on):           # bench.py contract; the sharded DCN step reports no per-kernel rows
         pass
@@ -1224,6 +1239,12 @@ class ShardedDCNEngine:
         if self.Nd:
             self.x0[:, F * D:F * D + self.Nd].copy_(dense)
         x0 = self.x0[:, :n_in]
+        if self.core is not None:
+            # cross stack + MLP + loss + backward on the shared dense core; every weight gradient goes into the bucket
+            self.core.ensure_fresh()
+            self.flat_grads.zero_()
+            d_x0 = self.core.step(self.x0, labels, lr)
+            return self._finish_step(route, d_x0)
         # ---- forward: cross stack, MLP, loss (mean over the rank's batch; the 1 / W of the global mean is folded into the step) --
         xs, prods = [x0], []
         for Wc, bc in zip(self.cross_W, self.cross_b):
@@ -1264,6 +1285,10 @@ class ShardedDCNEngine:
             p.linear_bwd_dw(xs[l], d_prod, 1.0, self.g_cross_W[l], self.g_cross_b[l])
             d_out = d_x
         d_x0.add_(d_out)                                  # the first layer's x IS x0
+        return self._finish_step(route, d_x0)
+
+    def _finish_step(self, route, d_x0):
+        p, W, lr = self.p, self.world, self.lr
         # ---- C4: the replicated weights' gradients (asynchronous: the embedding gradients travel meanwhile) ------------------------
         work = self.tr.allreduce(self.flat_grads, async_op=True) if not self.ex.local else None
         # ---- C3: embedding-row gradients to their owners + sorted scatter with the SGD step --------------------------------------------
@@ -1272,4 +1297,6 @@ class ShardedDCNEngine:
         if work is not None:
             work.wait()
         p.axpy(-lr / W, self.flat_grads, self.flat_params)
+        if self.core is not None:
+            self.core.refresh_planes()                   # the weights just moved: their planes follow
         return self.loss

@@ -729,6 +729,47 @@ def test_sharded_engine_world1_matches_unsharded_engine(alias_world1):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("split", ["f16x2", "bf16x3"])
+def test_sharded_dcn_world1_matches_unsharded_dcn(split):
+    """ShardedDCNEngine runs the SAME dense half as DCNEngine (dcn_engine.DCNDense: pre-split weights, the library's operand split,
+    amax records chained through the epilogues), with the gradients going through the all-reduce bucket instead of being applied in
+    place: at world 1, from the same tables and weights, three steps must give the same losses and parameters -- at a shape where
+    every wide GEMM takes the register-split path (B = 4096, input width 6 * 64 + 5 = 389, MLP [256, 128])."""
+    import torch.distributed as dist
+    from deep_recommenders_amd import ops
+    from deep_recommenders_amd.dcn_engine import DCNEngine
+    from deep_recommenders_amd.sharded import ShardedDCNEngine
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    prev = ops.set_gemm_split(split)
+    try:
+        F, V, D, B, Nd, lr = 6, 3000, 64, 4096, 5, 0.05
+        ref = DCNEngine(F, V, D, 3, [256, 128], B, num_dense=Nd, lr=lr, seed=4)
+        sh = ShardedDCNEngine(F, V, D, 3, [256, 128], B, num_dense=Nd, lr=lr, device="cuda", world=1, rank=0, seed=4,
+                              init_tables=ref.table.clone())
+        assert sh.core is not None and sh.h2 == (split == "f16x2") and ref.h2 == sh.h2
+        assert all(wp is not None for wp in sh.core.cross_planes) and sh.core.wplanes[0] is not None and sh.core.wplanes[1] is not None
+        with torch.no_grad():
+            for a, b in zip(sh.cross_W + sh.cross_b + sh.Ws + sh.bs, ref.cross_W + ref.cross_b + ref.Ws + ref.bs):
+                a.copy_(b)
+        g = torch.Generator(device="cuda")
+        g.manual_seed(7)
+        for _ in range(3):
+            keys = torch.randint(0, 10**14, (B, F), device="cuda", generator=g)
+            dense = torch.rand((B, Nd), device="cuda", generator=g)
+            labels = (torch.rand(B, device="cuda", generator=g) < 0.25).float()
+            l_ref = ref.train_step(keys, dense, labels).item()
+            l_sh = sh.train_step(keys, dense, labels).item()
+            assert abs(l_ref - l_sh) <= 2e-6 * abs(l_ref), (l_ref, l_sh)
+        np.testing.assert_allclose(sh.table.cpu().numpy(), ref.table.cpu().numpy(), rtol=2e-5, atol=2e-6)
+        for a, b in zip(sh.cross_W + sh.cross_b + sh.Ws + sh.bs, ref.cross_W + ref.cross_b + ref.Ws + ref.bs):
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    finally:
+        ops.set_gemm_split(prev)
+        dist.destroy_process_group()
+
+
 def test_engine_adam_tf_equals_tf_nonlazy_sparse_adam():
     """optimizer="adam_tf": tf.train.AdamOptimizer on sparse gradients is NON-lazy -- m / v of every row decay on every step and the row
     keeps moving while m != 0 (examples/train_fm_on_movielens_estimator.py:51-52).  The engine evaluates those
