@@ -2282,6 +2282,8 @@ int rs_launch(const RsArgs& g, hipStream_t stream) {
                 // 34 = no MFMA + no fragment reads, 3 = no MFMA + no weight DMA, 10 = no MFMA + A from cache, 98 = no MFMA + no reads + no split,
                 // 35 = no MFMA + no reads + no DMA, 43 = that + A from cache (what is left: the loop, the barrier, the epilogue stores)
                 RS_ABL2(34) RS_ABL2(3) RS_ABL2(10) RS_ABL2(98) RS_ABL2(35) RS_ABL2(43)
+                // round 5: WITH the MFMAs -- 8 = A from cache (its loads re-read k-tile 0), 4 = B always k-tile 0, 12 = both, 9 = no weight DMA + A from cache, 16 = staggered wave groups
+                RS_ABL2(8) RS_ABL2(4) RS_ABL2(12) RS_ABL2(9) RS_ABL2(16)
 #undef RS_ABL2
             }
         }

@@ -86,3 +86,38 @@ def test_two_tower_metric_pass_matches_oracle():
     ws, wi = O.brute_force_top_k(q.cpu().numpy(), corpus, k=10)
     np.testing.assert_allclose(s.cpu().numpy(), ws, rtol=1e-5, atol=1e-6)
     assert (ids.cpu().numpy() == wi).mean() > 0.999
+
+
+def test_two_tower_training_step_does_not_depend_on_the_operand_split():
+    """The explicit decision of DESIGN.md section 3.2: the two-tower TRAINING step at config 5's shapes (B = 8192, towers 128 -> 256 -> 128) runs
+    the generic dr_linear_* GEMMs, whose products follow dr_set_gemm_mode -- the operand-split switch (dr_set_gemm_split, f16x2 by default)
+    governs the register-split GEMMs of the DeepFM / DCN engines and the exact top-K scan only.  From identical state under both
+    splits: the first step's tower outputs and loss are BIT-identical (every forward kernel is deterministic), and the parameters
+    after two steps agree to the run-to-run noise of the bias-gradient atomics (a different product mode would differ at 1e-7 in
+    the tower outputs already).  (The metric pass's scan IS on the switch: test_gpu_h2_gemm.py.)"""
+    from deep_recommenders_amd import ops
+    from deep_recommenders_amd.two_tower_engine import TwoTowerEngine
+    Vu, Ni, D, B = 50000, 20000, 128, 8192
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    batches = [(torch.randint(0, 10**12, (B,), device="cuda", generator=g), torch.randint(0, Ni, (B,), device="cuda", generator=g))
+               for _ in range(2)]
+    prev = ops.get_gemm_split()
+    res = []
+    try:
+        for split in ("f16x2", "bf16x3"):
+            ops.set_gemm_split(split)
+            eng = TwoTowerEngine(Vu, Ni, D, (256, 128), B, lr=1e-5, seed=5)
+            assert not hasattr(eng, "h2")
+            l1 = eng.train_step(*batches[0]).item()
+            q1, c1 = eng.q_tower.hs[-1].clone(), eng.c_tower.hs[-1].clone()
+            l2 = eng.train_step(*batches[1]).item()
+            torch.cuda.synchronize()
+            res.append((l1, q1, c1, l2, _params(eng)))
+    finally:
+        ops.set_gemm_split(prev)
+    a, b = res
+    assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert abs(a[3] - b[3]) <= 1e-6 * abs(b[3])
+    for k in a[4]:
+        np.testing.assert_allclose(a[4][k].numpy(), b[4][k].numpy(), rtol=1e-5, atol=1e-7, err_msg=k)
