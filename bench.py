@@ -740,11 +740,14 @@ def main():
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong" if a.global_batch else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload,
-                       "gemm_products": (("fp32 in / fp32 accumulate; first layer's three GEMMs: 3 fp16 MFMA products of two-term fp16 splits of x * 2^k, "
-                                          "k per tensor from its amax record (f16x2 mode; error vs fp64 <= the bf16x3 mode's, tests/test_gpu_h2_gemm.py); "
-                                          "other wide GEMMs: 6 bf16 MFMA products of exact 3-way bf16 splits")
+                       "gemm_products": (("fp32 in / fp32 accumulate; %s: 3 fp16 MFMA products of two-term fp16 splits of x * 2^k, "
+                                          "k per tensor from its amax record (f16x2 split; error vs fp64 at or below the bf16x3 split's: tests/test_gpu_h2_gemm.py, "
+                                          "profiles/r05_dcn_parity_diag.log); other GEMMs: 6 bf16 MFMA products of exact 3-way bf16 splits"
+                                          % ("every wide GEMM (cross layers, MLP layers of >= 128 outputs)" if getattr(eng, "h2_all_wide", False)
+                                             else "first layer's three GEMMs"))
                                          if (a.gemm == "bf16x3" and getattr(eng, "h2", False)) else
                                          "fp32 in / fp32 accumulate; products = 6 bf16 MFMA products of exact 3-way bf16 splits (error vs fp64 <= native fp32 MFMA, tests/test_gpu_kernels.py)"
+                                         + ("; the exact top-K scan of the metric pass follows dr_get_gemm_split (%s)" % dr_ops.get_gemm_split() if a.model == "dssm" else "")
                                          if a.gemm == "bf16x3" else "native v_mfma_f32_32x32x2_f32"),
                        "gemm_split": dr_ops.get_gemm_split() if a.gemm == "bf16x3" else None,      # what the LIBRARY reports (dr_get_gemm_split)
                        "global_batch": a.batch * world, "parallelism": par, "final_loss": round(loss, 6),

@@ -4,13 +4,14 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 mkdir -p gpurun_out
-timeout -s KILL 1200 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|FAILED|Error" | head -10 > gpurun_out/pytest_gpu.log
-cat gpurun_out/pytest_gpu.log
+# the driver's own command first (-x), then nothing is hidden: the full -rA report is kept
+timeout -s KILL 1500 python -m pytest tests -x -q -m gpu -rA 2>&1 | tail -420 > gpurun_out/pytest_gpu_full.log
+grep -E "passed|failed" gpurun_out/pytest_gpu_full.log | tail -2 | tee gpurun_out/pytest_gpu.log
+grep -E "^FAILED|^ERROR" gpurun_out/pytest_gpu_full.log | head
 bash tools/collect_profiles.sh
 cd $R
-# SQ counters (wave-cycle split, MFMA busy cycles, LDS activity) of the default kernels and of the 64-row-wave GEMM shape
+# SQ counters (wave-cycle split, MFMA busy cycles, LDS activity) of the default kernels
 bash tools/collect_sq_pmc.sh > /dev/null 2>&1; cp gpurun_out/pmc_sq_summary.txt gpurun_out/pmc_sq_summary_default.txt
-DR_BF3_RS64=1 bash tools/collect_sq_pmc.sh > /dev/null 2>&1; cp gpurun_out/pmc_sq_summary.txt gpurun_out/pmc_sq_summary_rs64.txt
 cd $R
 timeout -s KILL 400 python bench.py > gpurun_out/line_default.log 2>&1
 timeout -s KILL 200 python bench.py --optimizer adam --no-cpu-baseline > gpurun_out/line_adam.log 2>&1
@@ -21,12 +22,14 @@ timeout -s KILL 400 python bench.py --model dssm > gpurun_out/line_dssm.log 2>&1
 DR_FUSE_K3=0 DR_PREFETCH_PLAN=0 timeout -s KILL 200 python bench.py --no-cpu-baseline > gpurun_out/line_unfused.log 2>&1
 DR_NO_CONCAT=0 timeout -s KILL 200 python bench.py --no-cpu-baseline > gpurun_out/line_concat.log 2>&1
 DR_FORCE_SHARDED=1 timeout -s KILL 200 python bench.py --no-cpu-baseline > gpurun_out/line_sharded_world1.log 2>&1
+DR_FORCE_SHARDED=1 timeout -s KILL 300 python bench.py --model dcn --no-cpu-baseline > gpurun_out/line_dcn_sharded_world1.log 2>&1
+DR_PREFETCH_EARLY=0 timeout -s KILL 200 python bench.py --no-cpu-baseline > gpurun_out/line_plan_beside_k4.log 2>&1
 # the six-product mode of rounds 2-3 beside the default (f16x2) lines: default, DCN, sharded
 DR_GEMM_SPLIT=bf16x3 timeout -s KILL 200 python bench.py --no-cpu-baseline > gpurun_out/line_bf16x3.log 2>&1
 DR_GEMM_SPLIT=bf16x3 timeout -s KILL 300 python bench.py --model dcn --no-cpu-baseline > gpurun_out/line_dcn_bf16x3.log 2>&1
 DR_GEMM_SPLIT=bf16x3 DR_FORCE_SHARDED=1 timeout -s KILL 200 python bench.py --no-cpu-baseline > gpurun_out/line_sharded_world1_bf16x3.log 2>&1
 timeout -s KILL 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-for f in default adam zipf c2 dcn dssm unfused concat sharded_world1 bf16x3 dcn_bf16x3 sharded_world1_bf16x3; do
+for f in default adam zipf c2 dcn dssm unfused concat sharded_world1 dcn_sharded_world1 plan_beside_k4 bf16x3 dcn_bf16x3 sharded_world1_bf16x3; do
   python - $f <<'PY'
 import json, sys
 try:
