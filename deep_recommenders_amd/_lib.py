@@ -128,6 +128,9 @@ SIGNATURES = {
     "dr_dropout_bwd": [_p, _i64, _p, _i64, _i32, _f32, _p, _i64, _p],
     "dr_reduce_sum": [_p, _i64, _i32, _f32, _i32, _p, _p, _p],
     "dr_clock_stamp": [_p, _p],
+    "dr_tower_tail_workspace_bytes": [_i64, _i32],
+    "dr_tower_tail_fused": [_p, _i64, _p, _i64, _p, _i64, _i64, _i32, _i32, _p, _i64, _p, _p, _p, _i32, _f32, _p, _i64, _p, _p, _i64, _p,
+                            _p, _p, _p, _i64, _p, _i64, _p, _p, _i64, _i32, _p, _p],
     "dr_copy_nt": [_p, _p, _i64, _p],
     "dr_ivf_build_workspace_bytes": [_i64, _i32],
     "dr_ivf_build_lists": [_p, _i64, _i32, _p, _p, _p, _i64, _p],
@@ -138,7 +141,7 @@ SIGNATURES = {
     "dr_get_gemm_split": [],
 }
 _RESTYPE = {"dr_version": ctypes.c_char_p, "dr_shard_bucket_workspace_bytes": ctypes.c_int64,
-            "dr_emb_sort_workspace_bytes": ctypes.c_int64, "dr_ivf_build_workspace_bytes": ctypes.c_int64,
+            "dr_emb_sort_workspace_bytes": ctypes.c_int64, "dr_tower_tail_workspace_bytes": ctypes.c_int64, "dr_ivf_build_workspace_bytes": ctypes.c_int64,
             "dr_linear_bwd_dw_workspace_bytes": ctypes.c_int64,
             "dr_linear_fwd_splitk_workspace_bytes": ctypes.c_int64,
             "dr_bf3_gemm_tn_workspace_bytes": ctypes.c_int64,

@@ -44,6 +44,11 @@ template <> __device__ __forceinline__ void vset<4>(float4& v, int i, float x) {
     if (i == 0) v.x = x; else if (i == 1) v.y = x; else if (i == 2) v.z = x; else v.w = x;
 }
 
+// s_barrier behind the wave's own LDS traffic only.  __syncthreads() also waits vmcnt(0): with it every barrier of the loop below would
+// sit out the NEXT chunk's prefetch (and this chunk's dx stores) -- three times per chunk.  The hazards the barriers order are all
+// LDS ones; registers loaded from HBM are waited for by the compiler where they are used.
+__device__ __forceinline__ void tail_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ int tt_row(int j, int h) { return (j & 3) + 8 * (j >> 2) + 4 * h; }
 
 // KT = K / 128: every wave owns 32*KT columns; lane c holds the KT adjacent columns  col0 + KT*c + t  (one KT-wide
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void linear_bwd_narrow_kernel(const float* 
     load_x(xv, chunk);
 #pragma unroll
     for (int j = 0; j < 4; ++j) dys[0][sr * TT_P + sc + j] = live_block ? dyr[j] : 0.f;
-    __syncthreads();
+    tail_lds_barrier();
     int p = 0;
     for (; chunk < chunks; chunk += gridDim.x) {
         const int64_t next = chunk + gridDim.x;
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void linear_bwd_narrow_kernel(const float* 
             for (int j = 0; j < 16; ++j)
                 *reinterpret_cast<vec_t*>(base + (int64_t)tt_row(j, 0) * lddx + dx_lane) = xv[j];
         }
-        __syncthreads();
+        tail_lds_barrier();
 #pragma unroll
         for (int s = 0; s < 16; ++s) xv[s] = xn[s];
         p ^= 1;
@@ -221,6 +226,237 @@ __global__ __launch_bounds__(256) void linear_bwd_narrow_reduce_kernel(const flo
         if (k < K) dstW[(int64_t)k * ldw + n] = fmaf(scale, s, dstW[(int64_t)k * ldw + n]);
         else if (dstb != nullptr) dstb[n] = fmaf(scale, s, dstb[n]);
     }
+}
+
+// =====================================================================================================================
+// The whole tower tail in ONE pass over x = h0 (round 5): dr_tower_head_fwd_bwd followed by
+// dr_linear_bwd_narrow read the same [M, K] activations twice from HBM (67 MB each at config 3) in two latency-bound launches
+// (51 + 60 us at 0.19 / 0.29 of the HBM roofline).  Here a block walks 32-row chunks like the narrow kernel above and, per chunk,
+//   (1) stages the chunk of x through the LDS in row-major order and multiplies it with W1 on the fp32 MFMA -- every wave its
+//       K / 4 columns: lane (row m, half h) reads 16 KT consecutive floats of row m as the A operand of 16 KT
+//       v_mfma_f32_32x32x2_f32, W1's rows sit in registers as the B operand -- and the four partial [32, 32] tiles are summed
+//       through the LDS by wave 0;
+//   (2) wave 0 runs the head epilogue of dense.hip (bias, ReLU, Dense(1) as a 32-lane butterfly, + extra logit, BCE terms,
+//       d logit, d h = d logit (x) w2 * ReLU') and leaves d h in the LDS where the narrow backward expects its dy chunk;
+//   (3) all four waves run the narrow backward of the kernel above on the x values they still hold in registers.
+// x is read once, d x written once; prob / d_logit / (optionally) d_h go out as before; the Dense(1) gradient, its bias gradient
+// and the loss leave as per-block partials in dr_tower_head's layout ([block][34]), the narrow layer's as in the kernel above.
+// K in {128, 256} (the staged chunk is 32 x (K + 4) floats: 33 KB at K = 256, two blocks per CU).
+// =====================================================================================================================
+constexpr int TAIL_HEAD_PART = 34;          // == HEAD_PART of dense.hip: dw2[32], db2, loss
+
+struct TailArgs {
+    const float* x; int64_t ldx;
+    const float* W1; int64_t ldw1; const float* b1;
+    int64_t M; int32_t K; int32_t N;             // N = H <= 32
+    const float* w2; int64_t ld_w2; const float* b2;
+    const float* extra; const float* labels; int32_t loss_mode; float inv_n;
+    float* prob; float* d_logit; float* d_h; int64_t ld_dh;      // d_h may be null
+    float* dx; int64_t lddx;
+    float* partial;                              // narrow layer: [grid][(K + 1) * 32]
+    float* head_partial;                         // Dense(1) + loss: [grid][34]
+    uint32_t* dx_amax;
+};
+
+// NWV waves per block, wave w owns columns 32 w .. 32 w + 31 of x (K = 32 NWV): lane (c, h) keeps x[tt_row(s, h)][32 w + c], s < 16.
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void tower_tail_fused_kernel(TailArgs a) {
+    constexpr int K = 32 * NWV, XP = K + 4;                   // staged chunk: [32][XP] floats (pitch = 4 mod 32: b128 row reads conflict-free)
+    constexpr int RPW = 16 / NWV;                             // accumulator registers (= 2 rows each) of the head tile a wave finishes
+    __shared__ __attribute__((aligned(16))) float xs[TT_ROWS * XP];
+    __shared__ float red[NWV][TT_ROWS * TT_P];
+    __shared__ float dys[TT_ROWS * TT_P];
+    __shared__ float hsum[NWV][TAIL_HEAD_PART];
+    __shared__ uint32_t amax_w[NWV];
+    const float* __restrict__ x = a.x;
+    const int64_t ldx = a.ldx, lddx = a.lddx;
+    const int N = a.N;
+    float dx_max = 0.f;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int col0 = wave * 32 + c;                           // this lane's column (narrow-backward layout)
+    const int64_t chunks = a.M / TT_ROWS;
+
+    // B operand of the dx product (as in linear_bwd_narrow_kernel): wf[s] = W1[col0][2 s + h], zero past N
+    float wf[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int n = 2 * s + h;
+        const float v = a.W1[(int64_t)col0 * a.ldw1 + (n < N ? n : N - 1)];
+        wf[s] = n < N ? v : 0.f;
+    }
+    // B operand of the HEAD product: k-step j of this wave multiplies column cb + j (cb = 32 wave + 16 h), output column n = c
+    const int cb = wave * 32 + 16 * h;
+    float w1f[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float v = a.W1[(int64_t)(cb + j) * a.ldw1 + (c < N ? c : N - 1)];
+        w1f[j] = c < N ? v : 0.f;
+    }
+    const bool cv = c < N;
+    const float b1j = a.b1 != nullptr ? a.b1[cv ? c : N - 1] : 0.f;
+    const float w2j = cv ? a.w2[(int64_t)c * a.ld_w2] : 0.f;
+    const float b2v = a.b2 != nullptr ? a.b2[0] : 0.f;
+    float dw2_acc = 0.f, db2_acc = 0.f, loss_acc = 0.f;
+
+    f32x16 accw;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) accw[j] = 0.f;
+    float bias_acc = 0.f;
+
+    const unsigned x_lane = (unsigned)(4 * h * ldx + col0), dx_lane = (unsigned)(4 * h * lddx + col0);
+    auto load_x = [&](float (&v)[16], int64_t chunk) {
+        const float* base = x + chunk * TT_ROWS * ldx;                       // wave-uniform
+#pragma unroll
+        for (int s = 0; s < 16; ++s) v[s] = base[(int64_t)tt_row(s, 0) * ldx + x_lane];
+    };
+
+    int64_t chunk = blockIdx.x;
+    if (chunk >= chunks) chunk = chunks - 1;                  // surplus blocks redo the last chunk with zero weight, no stores
+    const bool live_block = (int64_t)blockIdx.x < chunks;
+    float xv[16], xn[16];
+    load_x(xv, chunk);
+    for (; chunk < chunks; chunk += gridDim.x) {
+        const int64_t next = chunk + gridDim.x;
+        load_x(xn, next < chunks ? next : chunk);             // prefetch (clamped)
+        // labels / extra logit of the rows this wave's share of the head epilogue covers: loaded HERE, two barriers ahead of their use
+        float labv[RPW], extv[RPW];
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int reg = wave * RPW + rr;
+            const int64_t row = chunk * TT_ROWS + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            labv[rr] = a.labels[row];
+            extv[rr] = a.extra != nullptr ? a.extra[row] : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- (1) the chunk of x, row-major, into the LDS; every wave multiplies its 32 columns with W1 -------------------------------
+#pragma unroll
+        for (int s = 0; s < 16; ++s) xs[tt_row(s, h) * XP + col0] = xv[s];
+        tail_lds_barrier();
+        {
+            f32x16 acc1;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc1[j] = 0.f;
+            const float* xr = &xs[c * XP + cb];               // row m = c, this wave-half's 16 columns
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(xr + 4 * q);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, w1f[4 * q + 0], acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, w1f[4 * q + 1], acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, w1f[4 * q + 2], acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, w1f[4 * q + 3], acc1, 0, 0, 0);
+            }
+            // this wave's partial [32 rows][32 n] -> LDS (C/D layout: column n = c, row = tt_row(reg, h))
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) red[wave][tt_row(reg, h) * TT_P + c] = acc1[reg];
+        }
+        tail_lds_barrier();
+        // ---- (2) head epilogue (dense.hip EPI_HEAD) of the rows of accumulator registers RPW wave .. + RPW - 1; d h -> dys ------------
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int reg = wave * RPW + rr;                  // (wave-uniform)
+            const int ro = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            const int64_t row = chunk * TT_ROWS + ro;
+            const int li = ro * TT_P + c;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) v += red[w][li];   // fixed order
+            v = fmaxf(v + b1j, 0.f);
+            if (!cv) v = 0.f;
+            float dot = v * w2j;
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) dot += __shfl_xor(dot, o, 64);
+            const float lg = (dot + b2v) + extv[rr];
+            float p, l, gr;
+            dr_bce_terms(lg, labv[rr], a.loss_mode, p, l, gr);
+            float gs = gr * a.inv_n;
+            if (!live_block) { l = 0.f; gs = 0.f; }
+            const float dh = !(v > 0.f) ? 0.f : gs * w2j;
+            dys[li] = dh;
+            if (live_block) {
+                if (c == 0) {
+                    if (a.prob != nullptr) a.prob[row] = p;
+                    if (a.d_logit != nullptr) a.d_logit[row] = gs;
+                }
+                if (cv && a.d_h != nullptr) a.d_h[row * a.ld_dh + c] = dh;
+            }
+            dw2_acc = fmaf(v, gs, dw2_acc);
+            if (c == 0) { db2_acc += gs; loss_acc += l; }
+        }
+        tail_lds_barrier();
+        // ---- (3) the narrow backward of this chunk (linear_bwd_narrow_kernel's body, one column per lane) ----------------------------
+        float dxa[16], dwb[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            dxa[s] = dys[c * TT_P + 2 * s + h];               // dy[m = c][n = 2 s + h]
+            dwb[s] = dys[tt_row(s, h) * TT_P + c];            // dy[m = row(s, h)][n = c]
+        }
+        if (wave == 0 && h == 0) {
+#pragma unroll 8
+            for (int r = 0; r < TT_ROWS; ++r) bias_acc += dys[r * TT_P + c];
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) accw = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[s], dwb[s], accw, 0, 0, 0);
+        {
+            f32x16 acc;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dxa[s], wf[s], acc, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                float v = acc[j];
+                if (!(xv[j] > 0.f)) v = 0.f;
+                dx_max = fmaxf(dx_max, fabsf(v));
+                xv[j] = v;
+            }
+        }
+        if (live_block) {
+            float* base = a.dx + chunk * TT_ROWS * lddx;                      // wave-uniform
+#pragma unroll
+            for (int j = 0; j < 16; ++j) base[(int64_t)tt_row(j, 0) * lddx + dx_lane] = xv[j];
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) xv[s] = xn[s];
+        // (the next iteration's first barrier -- behind its xs writes -- also orders this iteration's dys / red reads before their rewrite)
+    }
+    // ---- partial results -------------------------------------------------------------------------------------------------------------
+    float* pp = a.partial + (int64_t)blockIdx.x * (K + 1) * 32;
+    const float live = live_block ? 1.f : 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) pp[(int64_t)(wave * 32 + tt_row(j, h)) * 32 + c] = live * accw[j];   // accumulator row i <-> column 32 wave + i
+    if (wave == 0 && h == 0) pp[(int64_t)K * 32 + c] = live * bias_acc;
+    dw2_acc += __shfl_xor(dw2_acc, 32, 64);
+    db2_acc += __shfl_xor(db2_acc, 32, 64);
+    loss_acc += __shfl_xor(loss_acc, 32, 64);
+    if (h == 0) {
+        hsum[wave][c] = dw2_acc;
+        if (c == 0) { hsum[wave][32] = db2_acc; hsum[wave][33] = loss_acc; }
+    }
+    uint32_t m = live_block ? __float_as_uint(dx_max) : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    if (lane == 0) amax_w[wave] = m;
+    tail_lds_barrier();
+    if (tid < TAIL_HEAD_PART) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) sacc += hsum[w][tid];
+        a.head_partial[(int64_t)blockIdx.x * TAIL_HEAD_PART + tid] = live * sacc;
+    }
+    if (a.dx_amax != nullptr && tid == 0) {
+        uint32_t mm = 0u;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) mm = max(mm, amax_w[w]);
+        if (mm > __hip_atomic_load(a.dx_amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.dx_amax, mm);
+    }
+}
+
+int tail_grid(int64_t M, int K) {
+    const int64_t chunks = M / TT_ROWS;
+    const int64_t cap = K == 256 ? 256 : 512;                 // 8-wave blocks: one per CU; 4-wave blocks: two
+    return (int)(chunks < cap ? chunks : cap);
 }
 
 int tt_grid(int64_t M) {
@@ -300,4 +536,51 @@ extern "C" int dr_linear_bwd_narrow_amax(const float* x, int64_t ld_x, const flo
     if (parts < 1 || parts > 3 || !dx_amax) return DR_EINVAL;
     return bwd_narrow_impl(x, ld_x, dy, ld_dy, W, ld_w, M, K, N, relu_mask, scale, dstW, ld_dstw, dstb, dx, ld_dx, workspace,
                            workspace_bytes, parts, stream, dx_amax);
+}
+
+// dense.hip: sums the head's per-block partials into dst_w2 / dst_b2 / loss_out (fixed order)
+int dr_head_finish_launch(const float* partial, int32_t nblocks, int32_t H, float scale, float inv_n, float* dst_w2, int64_t ld_dst_w2,
+                          float* dst_b2, float* loss_out, hipStream_t stream);
+
+extern "C" int64_t dr_tower_tail_workspace_bytes(int64_t M, int32_t K) {
+    if (M < TT_ROWS) return 512;
+    return (int64_t)tail_grid(M, K) * ((int64_t)(K + 1) * 32 + TAIL_HEAD_PART) * (int64_t)sizeof(float);
+}
+
+// dr_tower_head_fwd_bwd (act = relu) followed by dr_linear_bwd_narrow (relu_mask = 1) of the SAME layer W1 -- the last hidden layer
+// of the tower is both the head's first factor and the narrow backward's layer -- in one pass over x (tower_tail_fused_kernel).
+extern "C" int dr_tower_tail_fused(const float* x, int64_t ld_x, const float* W1, int64_t ld_w1, const float* b1, int64_t M,
+                                   int64_t n_total, int32_t K, int32_t H, const float* w2, int64_t ld_w2, const float* b2,
+                                   const float* extra_logit, const float* labels, int32_t loss_mode, float scale, float* dst_w1,
+                                   int64_t ld_dst_w1, float* dst_b1, float* dst_w2, int64_t ld_dst_w2, float* dst_b2, float* prob,
+                                   float* d_logit, float* d_h, int64_t ld_dh, float* dx, int64_t ld_dx, float* loss_out,
+                                   void* workspace, int64_t workspace_bytes, int32_t parts, uint32_t* dx_amax, dr_stream_t stream) {
+    if (M <= 0 || K <= 0 || H <= 0 || parts < 1 || parts > 3) return DR_EINVAL;
+    if (!x || !W1 || !w2 || !labels || !dst_w1 || !dx || !workspace || loss_mode < 0 || loss_mode > 2) return DR_EINVAL;
+    if (H > 32 || (K != 128 && K != 256) || (M % TT_ROWS) != 0) return DR_ESHAPE;
+    if ((reinterpret_cast<uintptr_t>(x) & 3) || (reinterpret_cast<uintptr_t>(dx) & 3)) return DR_ESHAPE;
+    if (ld_x < K || ld_dx < K || ld_w1 < H || ld_dst_w1 < H || ld_w2 < 1 || (dst_w2 && ld_dst_w2 < 1) || (d_h && ld_dh < H)) return DR_EINVAL;
+    if (workspace_bytes < dr_tower_tail_workspace_bytes(M, K)) return DR_EINVAL;
+    const int grid = tail_grid(M, K);
+    float* partial = static_cast<float*>(workspace);
+    float* head_partial = partial + (int64_t)grid * (K + 1) * 32;
+    const float inv_n = 1.f / (float)(n_total > 0 ? n_total : M);
+    if (parts & 1) {
+        if (dx_amax != nullptr && hipMemsetAsync(dx_amax, 0, sizeof(uint32_t), dr_s(stream)) != hipSuccess) return DR_ELAUNCH;
+        TailArgs a{};
+        a.x = x; a.ldx = ld_x; a.W1 = W1; a.ldw1 = ld_w1; a.b1 = b1; a.M = M; a.K = K; a.N = H;
+        a.w2 = w2; a.ld_w2 = ld_w2; a.b2 = b2; a.extra = extra_logit; a.labels = labels; a.loss_mode = loss_mode; a.inv_n = inv_n;
+        a.prob = prob; a.d_logit = d_logit; a.d_h = d_h; a.ld_dh = ld_dh; a.dx = dx; a.lddx = ld_dx;
+        a.partial = partial; a.head_partial = head_partial; a.dx_amax = dx_amax;
+        if (K == 128) hipLaunchKernelGGL((tower_tail_fused_kernel<4>), dim3(grid), dim3(256), 0, dr_s(stream), a);
+        else hipLaunchKernelGGL((tower_tail_fused_kernel<8>), dim3(grid), dim3(512), 0, dr_s(stream), a);
+    }
+    if (parts & 2) {
+        hipLaunchKernelGGL(linear_bwd_narrow_reduce_kernel, dim3(K + 1), dim3(256), 0, dr_s(stream), partial, grid, K, H, scale,
+                           dst_w1, ld_dst_w1, dst_b1);
+        int rc = dr_head_finish_launch(head_partial, grid, H, scale, inv_n, dst_w2, ld_dst_w2, dst_b2, loss_out, dr_s(stream));
+        if (rc != DR_OK) return rc;
+    }
+    DR_CHECK_LAUNCH();
+    return DR_OK;
 }

@@ -124,9 +124,19 @@ class DeepFMEngine:
                           and self.Ws[-2].shape[1] <= 32 and self.acts[-2] == 1)
         self.head_ws = ops.tower_head_workspace(B, device) if self.fuse_head else None
         self._head_done = False
+        self._tail_done = False
         self.narrow_ws = [ops.linear_bwd_narrow_workspace(B, W.shape[0], W.shape[1], device)
                           if (i > 0 and self.acts[i - 1] and ops.linear_bwd_narrow_supported(B, W.shape[0], W.shape[1])) else None
                           for i, W in enumerate(self.Ws)]
+        # The whole tower tail in ONE pass over the activations below the last hidden layer (round 5, dr_tower_tail_fused): the fused head
+        # and the narrow backward of that SAME layer read h (67 MB at config 3) twice, in two latency-bound launches (51 + 60 us); one
+        # kernel stages each 32-row chunk through the LDS once for the head's product and keeps it in registers for the backward.
+        # Training steps only; needs the fused head, the narrow backward's shape domain (K in {128, 256}) and a ReLU layer below.
+        # DR_FUSE_TAIL=0: the two launches of rounds 1-4.
+        self.fuse_tail = (_os.environ.get("DR_FUSE_TAIL", "1") == "1" and self.fuse_head and self.fuse_narrow and nl >= 3
+                          and self.narrow_ws[nl - 2] is not None and self.acts[nl - 3] == 1
+                          and ops.tower_tail_supported(B, self.Ws[-2].shape[0], self.Ws[-2].shape[1]))
+        self.tail_ws = ops.tower_tail_workspace(B, self.Ws[-2].shape[0], device) if self.fuse_tail else None
         # ---- constant metadata ---------------------------------------------------------------------
         self.row_base = torch.arange(F, device=device, dtype=torch.int64) * V
         self.col_start = torch.arange(F + 1, device=device, dtype=torch.int32)
@@ -559,6 +569,27 @@ class DeepFMEngine:
                         lambda x=x, W=W, b=b, i=i: ops.linear_fwd(x, W, b, self.acts[i], out=self.hs[i]))
             x = self.hs[i]
         self._head_done = head
+        self._tail_done = False
+        if head and self.fuse_tail and self._in_train_step:
+            # K7 tail + K11 + the backward of the last hidden layer in one pass over x (= hs[nl - 3]): prob, loss, d_logit, d_h, the
+            # gradient for the layer below (dhs[nl - 3]) and the SGD steps (or gradients) of both layers
+            W1, W2 = self.Ws[-2], self.Ws[-1]
+            adam = self.optimizer == "adam"
+            def tail(parts, x=x, W1=W1, W2=W2):
+                return ops.tower_tail_fused(
+                    x, W1, self.bs[-2], W2, self.bs[-1], self.fm_logit, labels, loss_mode, 1.0 if adam else -self.lr, self.dhs[nl - 3],
+                    dst_W1=self.gWs[-2] if adam else "inplace", dst_b1=self.gbs[-2] if adam else "inplace",
+                    dst_W2=self.gWs[-1] if adam else "inplace", dst_b2=self.gbs[-1] if adam else "inplace",
+                    prob=self.prob, d_logit=self.d_logit, d_h=self.dhs[-1], loss=self.loss, workspace=self.tail_ws, parts=parts,
+                    dx_amax=self.dh0_amax if (self.h2 and nl - 2 == 1 and (parts & 1)) else None)
+            work = 4.0 * B * (2 * W1.shape[0] + W1.shape[1] + 4)
+            if self.reduce_side:
+                self._k("tower_tail_fused", "hbm", work, lambda: tail(1))
+                self._side_part2(lambda: tail(2))
+            else:
+                self._k("tower_tail_fused", "hbm", work, lambda: tail(3))
+            self._tail_done = True
+            return self.prob
         if head:
             # K7 tail + K11: Dense(H<=32, relu), Dense(1), + FM logit, loss, d_logit, d_h and the Dense(1) SGD step
             W1, W2 = self.Ws[-2], self.Ws[-1]
@@ -600,6 +631,9 @@ class DeepFMEngine:
         if self._head_done:                               # Dense(1) backward + its update already done by the fused head
             top = n - 2
             dy = self.dhs[-1]
+        if self._tail_done:                               # ... and the last hidden layer's by the one-pass tail
+            top = n - 3
+            dy = self.dhs[n - 3]
         for i in range(top, -1, -1):
             x = self.concat[:, :self.in_dim] if i == 0 else self.hs[i - 1]
             W = self.Ws[i]

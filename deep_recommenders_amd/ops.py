@@ -267,6 +267,41 @@ def linear_bwd_narrow(x, dy, W, scale, dstW, dstb, dx, relu_mask=True, workspace
     return dx
 
 
+def tower_tail_supported(M, K, H):
+    """Shape domain of the one-pass tower tail (dr_tower_tail_fused)."""
+    return H <= 32 and K in (128, 256) and M > 0 and M % 32 == 0
+
+
+def tower_tail_workspace(M, K, device):
+    return torch.empty(max(128, lib().dr_tower_tail_workspace_bytes(int(M), int(K)) // 4), dtype=torch.float32, device=device)
+
+
+def tower_tail_fused(x, W1, b1, W2, b2, extra_logit, labels, loss_mode, scale, dx, dst_W1="inplace", dst_b1="inplace", dst_W2="inplace",
+                     dst_b2="inplace", prob=None, d_logit=None, d_h=None, loss=None, workspace=None, n_total=0, parts=3, dx_amax=None):
+    """tower_head_fwd_bwd (relu) + linear_bwd_narrow (relu mask) of the same layer W1 in ONE pass over x (dr_tower_tail_fused).
+    dst_* += scale * gradient: the parameters themselves by default (fused SGD, scale = -lr) or gradient buffers (scale = 1).
+    Returns (loss, prob, d_logit, dx)."""
+    M, K = x.shape
+    H = W1.shape[1]
+    dev = x.device
+    dst_W1 = W1 if isinstance(dst_W1, str) else dst_W1
+    dst_b1 = b1 if isinstance(dst_b1, str) else dst_b1
+    dst_W2 = W2 if isinstance(dst_W2, str) else dst_W2
+    dst_b2 = b2 if isinstance(dst_b2, str) else dst_b2
+    assert x.stride(1) == 1 and W1.stride(1) == 1 and dst_W1.stride(1) == 1 and dx.stride(1) == 1 and W2.shape == (H, 1) and dx.shape == (M, K)
+    prob = prob if prob is not None else torch.empty(M, dtype=torch.float32, device=dev)
+    d_logit = d_logit if d_logit is not None else torch.empty(M, dtype=torch.float32, device=dev)
+    loss = loss if loss is not None else torch.empty(1, dtype=torch.float32, device=dev)
+    if workspace is None:
+        workspace = tower_tail_workspace(M, K, dev)
+    check(lib().dr_tower_tail_fused(ptr(x), x.stride(0), ptr(W1), W1.stride(0), ptr(b1), M, int(n_total), K, H, ptr(W2), W2.stride(0), ptr(b2),
+                                    ptr(extra_logit), ptr(labels), int(loss_mode), float(scale), ptr(dst_W1), dst_W1.stride(0), ptr(dst_b1),
+                                    ptr(dst_W2), dst_W2.stride(0) if dst_W2 is not None else 0, ptr(dst_b2), ptr(prob), ptr(d_logit), ptr(d_h),
+                                    d_h.stride(0) if d_h is not None else 0, ptr(dx), dx.stride(0), ptr(loss), ptr(workspace),
+                                    workspace.numel() * 4, int(parts), ptr(dx_amax), stream_ptr()), "dr_tower_tail_fused")
+    return loss, prob, d_logit, dx
+
+
 def tower_head_workspace(M, device):
     return torch.empty(max(64, lib().dr_tower_head_workspace_bytes(int(M)) // 4), dtype=torch.float32, device=device)
 

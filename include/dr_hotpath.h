@@ -382,6 +382,25 @@ int dr_tower_head_fwd_bwd(const float* x, int64_t ld_x, const float* W1, int64_t
                           int64_t ld_w2, const float* b2, const float* extra_logit, const float* labels,
                           int32_t loss_mode, float scale, float* dst_w2, int64_t ld_dst_w2, float* dst_b2, float* h_out, int64_t ld_h, float* prob, float* d_logit, float* d_h, int64_t ld_dh,
                           float* loss_out, void* workspace, int64_t workspace_bytes, dr_stream_t stream);
+/* The whole tower tail in ONE pass over x (round 5): dr_tower_head_fwd_bwd (act = relu) and dr_linear_bwd_narrow (relu_mask = 1) of the
+ * SAME layer W1 [K, H] -- in the reference's towers the last hidden layer, Dense(H <= 32, relu), is at once the head's first factor and
+ * the layer whose backward follows (keras/models/ranking/deepfm.py:30-34,41-47; estimator/models/feature_interaction/dnn.py:17-29):
+ *   h = relu(x W1 + b1); logit = h w2 + b2 + extra_logit; prob, loss, d_logit = BCE(logit, labels, loss_mode) (mean over n_total, 0 = M);
+ *   d_h = d_logit (x) w2 * (h > 0)  (written if d_h != NULL);   dx = (d_h W1^T) * (x > 0);
+ *   dst_w1 += scale * x^T d_h;  dst_b1 += scale * colsum(d_h);  dst_w2 += scale * h^T d_logit;  dst_b2 += scale * sum(d_logit).
+ * Both products use the pre-update W1 / w2 even when dst_* are the parameters themselves (scale = -lr: fused SGD); with gradient
+ * buffers scale = 1.  parts = 1: the one-pass kernel (prob, d_logit, d_h, dx, per-block partials), 2: the two fixed-order reduces that
+ * apply the partials (may run on another stream; must finish before the next part 1 over the same workspace), 3: both.  dx_amax (may
+ * be NULL): receives max |dx| as float bits (reset by part 1) -- the f16x2 GEMMs' record of dx.  Deterministic.
+ * Domain: H <= 32, K in {128, 256}, M a multiple of 32; anything else returns DR_ESHAPE (use the two calls it replaces).  Results equal those two calls' up to the summation order of the K-long dot products. */
+int64_t dr_tower_tail_workspace_bytes(int64_t M, int32_t K);
+int dr_tower_tail_fused(const float* x, int64_t ld_x, const float* W1, int64_t ld_w1, const float* b1, int64_t M, int64_t n_total,
+                        int32_t K, int32_t H, const float* w2, int64_t ld_w2, const float* b2, const float* extra_logit,
+                        const float* labels, int32_t loss_mode, float scale, float* dst_w1, int64_t ld_dst_w1, float* dst_b1,
+                        float* dst_w2, int64_t ld_dst_w2, float* dst_b2, float* prob, float* d_logit, float* d_h, int64_t ld_dh,
+                        float* dx, int64_t ld_dx, float* loss_out, void* workspace, int64_t workspace_bytes, int32_t parts,
+                        uint32_t* dx_amax, dr_stream_t stream);
+
 /* dr_linear_bwd_narrow / dr_tower_head_fwd_bwd in two halves (round 4): parts = 1 the main kernel (everything the rest of the step
  * reads: dx; prob, d_logit, d_h), parts = 2 the small reduce that applies the per-block partials to the weights (and writes the
  * loss), 3 = both.  Part 2 may run on ANOTHER stream -- the engine keeps the three reduce kernels of a step off its training stream;

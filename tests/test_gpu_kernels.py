@@ -344,6 +344,84 @@ def test_tower_head_fused(ops, M, K, H, mode):
     np.testing.assert_allclose(b2d.cpu().numpy(), b2 + scale * tb2.grad.numpy(), rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize("M,K,H,mode", [(128, 256, 32, 0), (4096, 128, 32, 1), (2048 + 32, 256, 17, 2), (65536, 256, 32, 0)])
+def test_tower_tail_fused_one_pass(ops, M, K, H, mode):
+    """dr_tower_tail_fused == dr_tower_head_fwd_bwd (relu) followed by dr_linear_bwd_narrow (relu mask) of the same layer, and both
+    == the op-by-op definition in fp64 (torch autograd): prob, loss, d_logit, d_h, dx and the four fused SGD updates.  Deterministic;
+    the amax record of dx is exact."""
+    rng = np.random.default_rng(43)
+    x = np.maximum(rng.standard_normal((M, K)), 0).astype(np.float32)        # post-ReLU activations (zeros included)
+    W1 = (rng.standard_normal((K, H)) / np.sqrt(K)).astype(np.float32)
+    b1 = (rng.standard_normal(H) * 0.1).astype(np.float32)
+    w2 = (rng.standard_normal((H, 1)) / np.sqrt(H)).astype(np.float32)
+    b2 = np.array([0.05], np.float32)
+    extra = rng.standard_normal(M).astype(np.float32)
+    z = (rng.random(M) < 0.3).astype(np.float32)
+    scale = -0.05
+    ldh = (H + 3) // 4 * 4
+
+    def params():
+        W1d = torch.zeros((K, ldh), device="cuda")[:, :H]
+        W1d.copy_(_dev(W1))
+        W2d = torch.zeros((H, 4), device="cuda")[:, :1]
+        W2d.copy_(_dev(w2))
+        return W1d, _dev(b1).clone(), W2d, _dev(b2).clone()
+    xd = _dev(x)
+    # ---- the one-pass kernel
+    W1d, b1d, W2d, b2d = params()
+    dx = torch.full((M, K), 7.0, device="cuda")
+    d_h = torch.full((M, ldh), 7.0, device="cuda")[:, :H]
+    rec = ops.h2_record("cuda")
+    rec.fill_(0x7f000000)
+    loss, prob, d_logit, _ = ops.tower_tail_fused(xd, W1d, b1d, W2d, b2d, _dev(extra), _dev(z), mode, scale, dx, d_h=d_h, dx_amax=rec)
+    # ---- the two launches it replaces
+    W1e, b1e, W2e, b2e = params()
+    dx_e = torch.empty((M, K), device="cuda")
+    loss_e, prob_e, d_logit_e, d_h_e = ops.tower_head_fwd_bwd(xd, W1e, b1e, W2e, b2e, _dev(extra), _dev(z), mode, scale)
+    ops.linear_bwd_narrow(xd, d_h_e, W1e, scale, W1e, b1e, dx_e, relu_mask=True)
+    # ---- fp64 definition
+    tx = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    tW1 = torch.tensor(W1, dtype=torch.float64, requires_grad=True)
+    tb1 = torch.tensor(b1, dtype=torch.float64, requires_grad=True)
+    tw2 = torch.tensor(w2, dtype=torch.float64, requires_grad=True)
+    tb2 = torch.tensor(b2, dtype=torch.float64, requires_grad=True)
+    pre = tx @ tW1 + tb1
+    pre.retain_grad()
+    h = torch.relu(pre)
+    logit = (h @ tw2).reshape(-1) + tb2 + torch.tensor(extra, dtype=torch.float64)
+    logit.retain_grad()
+    tz = torch.tensor(z, dtype=torch.float64)
+    lo = T.sigmoid_cross_entropy(tz, logit) if mode == 0 else (T.log_loss(tz, torch.sigmoid(logit)) if mode == 1 else T.keras_bce(tz, torch.sigmoid(logit)))
+    lo.backward()
+    want_dx = tx.grad.numpy() * (x > 0)                                       # the mask of the layer BELOW (x is post-ReLU)
+    np.testing.assert_allclose(prob.cpu().numpy(), torch.sigmoid(logit).detach().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(loss.item(), lo.item(), rtol=1e-5)
+    np.testing.assert_allclose(d_logit.cpu().numpy() * M, logit.grad.numpy() * M, rtol=0, atol=5e-5)
+    np.testing.assert_allclose(d_h.cpu().numpy() * M, pre.grad.numpy() * M, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(dx.cpu().numpy() * M, want_dx * M, rtol=0, atol=2e-4)
+    for got, p0, gr, nm in ((W1d, W1, tW1.grad, "W1"), (b1d, b1, tb1.grad, "b1"), (W2d, w2, tw2.grad, "w2"), (b2d, b2, tb2.grad, "b2")):
+        np.testing.assert_allclose(got.cpu().numpy(), p0 + scale * gr.numpy(), rtol=0, atol=3e-6, err_msg=nm)
+    # ---- against the two-launch path: same arithmetic up to the order of the K-long sums
+    np.testing.assert_allclose(prob.cpu().numpy(), prob_e.cpu().numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(loss.item(), loss_e.item(), rtol=2e-6)
+    np.testing.assert_allclose(dx.cpu().numpy() * M, dx_e.cpu().numpy() * M, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(W1d.cpu().numpy(), W1e.cpu().numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(W2d.cpu().numpy(), W2e.cpu().numpy(), rtol=0, atol=1e-6)
+    assert int(rec.item()) == int(dx.abs().max().view(torch.int32).item()), "amax record of dx"
+    assert float(d_h[:, :H].abs().max()) < 7.0 and float(dx.abs().max()) < 7.0     # every element written
+    # ---- deterministic
+    W1f, b1f, W2f, b2f = params()
+    dx2 = torch.empty((M, K), device="cuda")
+    loss2, prob2, d_logit2, _ = ops.tower_tail_fused(xd, W1f, b1f, W2f, b2f, _dev(extra), _dev(z), mode, scale, dx2)
+    assert torch.equal(dx, dx2) and torch.equal(W1d, W1f) and torch.equal(W2d, W2f) and torch.equal(b1d, b1f) and torch.equal(b2d, b2f)
+    assert torch.equal(loss, loss2) and torch.equal(prob, prob2)
+    # ---- shape contract
+    assert ops.tower_tail_supported(64, 256, 32) and not ops.tower_tail_supported(64, 512, 32) and not ops.tower_tail_supported(40, 256, 32)
+    with pytest.raises(RuntimeError, match="DR_ESHAPE"):
+        ops.tower_tail_fused(torch.zeros((64, 512), device="cuda"), torch.zeros((512, 32), device="cuda"), None, torch.zeros((32, 1), device="cuda"),
+                             None, None, torch.zeros(64, device="cuda"), 0, -0.1, torch.zeros((64, 512), device="cuda"))
+
+
 @pytest.mark.parametrize("M,K,N", [(8192, 8192, 128), (300, 5000, 40), (2048, 2049, 130)])
 def test_linear_fwd_splitk_matches_fp64_and_is_deterministic(ops, M, K, N):
     """dr_linear_fwd_splitk (the two-tower dq = G c: few output tiles, long reduction split over the grid): accumulates into y,

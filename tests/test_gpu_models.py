@@ -376,6 +376,39 @@ def test_engine_schedule_switches_are_bit_identical(switch, value, monkeypatch):
     assert torch.equal(base.table, alt.table) and torch.equal(base.lin_w, alt.lin_w) and torch.equal(base.flat_params, alt.flat_params)
 
 
+@pytest.mark.parametrize("optimizer", ["sgd", "adam"])
+def test_engine_one_pass_tail_tracks_the_two_launch_tail(optimizer, monkeypatch):
+    """dr_tower_tail_fused (the default since round 5: head + narrow backward of the last hidden layer in one pass over h) against
+    DR_FUSE_TAIL=0 (dr_tower_head_fwd_bwd + dr_linear_bwd_narrow, rounds 1-4) over prefetched steps: the same arithmetic up to the order of
+    the 256-long sums of the head's product -- losses to 1e-6 relative, parameters to fp32 noise; both paths stay under test."""
+    from deep_recommenders_amd.engine import DeepFMEngine
+    F, B, Nd, D, V = 4, 2304, 3, 64, 3000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(12)
+    batches = [(torch.randint(0, 10**12, (B, F), device="cuda", generator=g), torch.rand((B, Nd), device="cuda", generator=g),
+                (torch.rand(B, device="cuda", generator=g) < 0.3).float()) for _ in range(3)]
+
+    def run():
+        eng = DeepFMEngine(F, V, D, [256, 16], B, num_dense=Nd, lr=0.05 if optimizer == "sgd" else 0.002, seed=3, lin_init_std=0.1,
+                           optimizer=optimizer)
+        losses = []
+        for n in range(5):
+            k, d, l = batches[n % 3]
+            losses.append(float(eng.train_step(k, d, l, next_keys=batches[(n + 1) % 3][0], next_dense=batches[(n + 1) % 3][1]).item()))
+        torch.cuda.synchronize()
+        return eng, losses
+    one, l1 = run()
+    assert one.fuse_tail and one._tail_done
+    monkeypatch.setenv("DR_FUSE_TAIL", "0")
+    two, l2 = run()
+    assert not two.fuse_tail and not two._tail_done and two._head_done
+    for a, b in zip(l1, l2):
+        assert abs(a - b) <= 1e-6 * abs(b), (l1, l2)
+    tol = 2e-5 if optimizer == "sgd" else 2e-3       # (Adam divides by sqrt(v): a last-bit difference in a tiny gradient moves a whole step)
+    assert (one.table - two.table).abs().max().item() <= tol * two.table.abs().max().item()
+    assert (one.flat_params - two.flat_params).abs().max().item() <= tol * two.flat_params.abs().max().item()
+
+
 def test_engine_train_step_matches_oracle():
     """The fused engine step (what bench.py times) against the host restatement: loss and updated weights."""
     from deep_recommenders_amd.engine import DeepFMEngine
