@@ -243,6 +243,12 @@ __global__ __launch_bounds__(256) void linear_bwd_narrow_reduce_kernel(const flo
 // and the loss leave as per-block partials in dr_tower_head's layout ([block][34]), the narrow layer's as in the kernel above.
 // K in {128, 256} (the staged chunk is 32 x (K + 4) floats: 33 KB at K = 256, two blocks per CU).
 // =====================================================================================================================
+// experiment switches of the one-pass tail (tools/exp/tail_variants.sh builds one library per value; 0 = shipped):
+//   1 two blocks per CU (launch bounds 512 x 2: <= 128 VGPRs)    2 no register prefetch of the next chunk (loaded behind the dx stores)
+//   16 no head MFMAs   32 no epilogue math   64 no narrow-backward MFMAs   128 no dx stores   (16..128: timing only, wrong results)
+#ifndef DR_TAIL_DBG
+#define DR_TAIL_DBG 0
+#endif
 constexpr int TAIL_HEAD_PART = 34;          // == HEAD_PART of dense.hip: dw2[32], db2, loss
 
 struct TailArgs {
@@ -260,7 +266,7 @@ struct TailArgs {
 
 // NWV waves per block, wave w owns columns 32 w .. 32 w + 31 of x (K = 32 NWV): lane (c, h) keeps x[tt_row(s, h)][32 w + c], s < 16.
 template <int NWV>
-__global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void tower_tail_fused_kernel(TailArgs a) {
+__global__ __launch_bounds__(64 * NWV, (DR_TAIL_DBG & 1) ? 4 : 2) void tower_tail_fused_kernel(TailArgs a) {   // (HIP: second argument = min waves per SIMD)
     constexpr int K = 32 * NWV, XP = K + 4;                   // staged chunk: [32][XP] floats (pitch = 4 mod 32: b128 row reads conflict-free)
     constexpr int RPW = 16 / NWV;                             // accumulator registers (= 2 rows each) of the head tile a wave finishes
     __shared__ __attribute__((aligned(16))) float xs[TT_ROWS * XP];
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void tower_tail_fused_k
     load_x(xv, chunk);
     for (; chunk < chunks; chunk += gridDim.x) {
         const int64_t next = chunk + gridDim.x;
-        load_x(xn, next < chunks ? next : chunk);             // prefetch (clamped)
+        if constexpr (!(DR_TAIL_DBG & 2)) load_x(xn, next < chunks ? next : chunk);             // prefetch (clamped)
         // labels / extra logit of the rows this wave's share of the head epilogue covers: loaded HERE, two barriers ahead of their use
         float labv[RPW], extv[RPW];
 #pragma unroll
@@ -340,7 +346,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void tower_tail_fused_k
             for (int j = 0; j < 16; ++j) acc1[j] = 0.f;
             const float* xr = &xs[c * XP + cb];               // row m = c, this wave-half's 16 columns
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < ((DR_TAIL_DBG & 16) ? 1 : 4); ++q) {
                 const float4 v = *reinterpret_cast<const float4*>(xr + 4 * q);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, w1f[4 * q + 0], acc1, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, w1f[4 * q + 1], acc1, 0, 0, 0);
@@ -369,7 +375,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void tower_tail_fused_k
             for (int o = 1; o < 32; o <<= 1) dot += __shfl_xor(dot, o, 64);
             const float lg = (dot + b2v) + extv[rr];
             float p, l, gr;
-            dr_bce_terms(lg, labv[rr], a.loss_mode, p, l, gr);
+            if constexpr (DR_TAIL_DBG & 32) { p = lg; l = lg; gr = lg - labv[rr]; }
+            else dr_bce_terms(lg, labv[rr], a.loss_mode, p, l, gr);
             float gs = gr * a.inv_n;
             if (!live_block) { l = 0.f; gs = 0.f; }
             const float dh = !(v > 0.f) ? 0.f : gs * w2j;
@@ -397,13 +404,13 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void tower_tail_fused_k
             for (int r = 0; r < TT_ROWS; ++r) bias_acc += dys[r * TT_P + c];
         }
 #pragma unroll
-        for (int s = 0; s < 16; ++s) accw = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[s], dwb[s], accw, 0, 0, 0);
+        for (int s = 0; s < ((DR_TAIL_DBG & 64) ? 1 : 16); ++s) accw = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[s], dwb[s], accw, 0, 0, 0);
         {
             f32x16 acc;
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[j] = 0.f;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dxa[s], wf[s], acc, 0, 0, 0);
+            for (int s = 0; s < ((DR_TAIL_DBG & 64) ? 1 : 16); ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dxa[s], wf[s], acc, 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 float v = acc[j];
@@ -412,13 +419,17 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void tower_tail_fused_k
                 xv[j] = v;
             }
         }
-        if (live_block) {
+        if (live_block && (!(DR_TAIL_DBG & 128) || chunk < 0)) {
             float* base = a.dx + chunk * TT_ROWS * lddx;                      // wave-uniform
 #pragma unroll
             for (int j = 0; j < 16; ++j) base[(int64_t)tt_row(j, 0) * lddx + dx_lane] = xv[j];
         }
+        if constexpr (DR_TAIL_DBG & 2) {
+            load_x(xv, next < chunks ? next : chunk);
+        } else {
 #pragma unroll
-        for (int s = 0; s < 16; ++s) xv[s] = xn[s];
+            for (int s = 0; s < 16; ++s) xv[s] = xn[s];
+        }
         // (the next iteration's first barrier -- behind its xs writes -- also orders this iteration's dys / red reads before their rewrite)
     }
     // ---- partial results -------------------------------------------------------------------------------------------------------------
@@ -455,7 +466,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void tower_tail_fused_k
 
 int tail_grid(int64_t M, int K) {
     const int64_t chunks = M / TT_ROWS;
-    const int64_t cap = K == 256 ? 256 : 512;                 // 8-wave blocks: one per CU; 4-wave blocks: two
+    const int64_t cap = (K == 256 && !(DR_TAIL_DBG & 1)) ? 256 : 512;                 // 8-wave blocks: one per CU; 4-wave blocks: two
     return (int)(chunks < cap ? chunks : cap);
 }
 
