@@ -1004,15 +1004,6 @@ __global__ __launch_bounds__(256) void head_finish_kernel(const float* __restric
     }
 }
 
-// (tower_tail.hip: the fused tail kernel leaves the same per-block partials)
-int dr_head_finish_launch(const float* partial, int32_t nblocks, int32_t H, float scale, float inv_n, float* dst_w2, int64_t ld_dst_w2,
-                          float* dst_b2, float* loss_out, hipStream_t stream) {
-    hipLaunchKernelGGL(head_finish_kernel, dim3(1), dim3(256), 0, stream, partial, nblocks, H, scale, inv_n, dst_w2, ld_dst_w2, dst_b2,
-                       loss_out);
-    DR_CHECK_LAUNCH();
-    return DR_OK;
-}
-
 extern "C" int64_t dr_tower_head_workspace_bytes(int64_t M) {
     const int64_t tiles = (M + BM - 1) / BM;
     return (tiles > 0 ? tiles : 1) * HEAD_PART * (int64_t)sizeof(float);

@@ -464,6 +464,72 @@ __global__ __launch_bounds__(64 * NWV, (DR_TAIL_DBG & 1) ? 4 : 2) void tower_tai
     }
 }
 
+// Both fixed-order reduces of the one-pass tail in ONE launch: blocks 0 .. K apply the narrow layer's partials (as
+// linear_bwd_narrow_reduce_kernel), block K + 1 the head's (as head_finish_kernel of dense.hip: dst_w2 / dst_b2 / loss).
+__global__ __launch_bounds__(256) void tower_tail_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ head_partial,
+                                                                int32_t nparts, int32_t K, int32_t N, float scale, float inv_n,
+                                                                float* __restrict__ dstW, int64_t ldw, float* __restrict__ dstb,
+                                                                float* dst_w2, int64_t ld_w2, float* dst_b2, float* __restrict__ loss_out) {
+    __shared__ float red[8][TAIL_HEAD_PART];
+    if ((int)blockIdx.x <= K) {
+        const int k = blockIdx.x, n = threadIdx.x & 31, pg = threadIdx.x >> 5;
+        const int64_t stride = (int64_t)(K + 1) * 32;
+        const float* p = partial + (int64_t)k * 32 + n;
+        float acc = 0.f;
+        for (int q0 = pg; q0 < nparts; q0 += 8 * 8) {            // 8 loads in flight, not a chain of dependent round trips
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = q0 + 8 * u;
+                v[u] = p[(int64_t)(q < nparts ? q : q0) * stride];
+                if (q >= nparts) v[u] = 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        red[pg][n] = acc;
+        __syncthreads();
+        if (pg == 0 && n < N) {
+            float s = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) s += red[g][n];
+            if (k < K) dstW[(int64_t)k * ldw + n] = fmaf(scale, s, dstW[(int64_t)k * ldw + n]);
+            else if (dstb != nullptr) dstb[n] = fmaf(scale, s, dstb[n]);
+        }
+        return;
+    }
+    constexpr int NG = 7;
+    const int grp = threadIdx.x / TAIL_HEAD_PART, c = threadIdx.x % TAIL_HEAD_PART;
+    if (grp < NG) {
+        float acc = 0.f;
+        for (int b0 = grp; b0 < nparts; b0 += NG * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int b = b0 + u * NG;
+                v[u] = head_partial[(int64_t)(b < nparts ? b : b0) * TAIL_HEAD_PART + c];
+                if (b >= nparts) v[u] = 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        red[grp][c] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < TAIL_HEAD_PART) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int g2 = 0; g2 < NG; ++g2) sacc += red[g2][c];
+        if (c < 32) {
+            if (c < N && dst_w2 != nullptr && scale != 0.f) dst_w2[(int64_t)c * ld_w2] = fmaf(scale, sacc, dst_w2[(int64_t)c * ld_w2]);
+        } else if (c == 32) {
+            if (dst_b2 != nullptr && scale != 0.f) dst_b2[0] = fmaf(scale, sacc, dst_b2[0]);
+        } else if (loss_out != nullptr) {
+            loss_out[0] = sacc * inv_n;
+        }
+    }
+}
+
 int tail_grid(int64_t M, int K) {
     const int64_t chunks = M / TT_ROWS;
     const int64_t cap = (K == 256 && !(DR_TAIL_DBG & 1)) ? 256 : 512;                 // 8-wave blocks: one per CU; 4-wave blocks: two
@@ -549,10 +615,6 @@ extern "C" int dr_linear_bwd_narrow_amax(const float* x, int64_t ld_x, const flo
                            workspace_bytes, parts, stream, dx_amax);
 }
 
-// dense.hip: sums the head's per-block partials into dst_w2 / dst_b2 / loss_out (fixed order)
-int dr_head_finish_launch(const float* partial, int32_t nblocks, int32_t H, float scale, float inv_n, float* dst_w2, int64_t ld_dst_w2,
-                          float* dst_b2, float* loss_out, hipStream_t stream);
-
 extern "C" int64_t dr_tower_tail_workspace_bytes(int64_t M, int32_t K) {
     if (M < TT_ROWS) return 512;
     return (int64_t)tail_grid(M, K) * ((int64_t)(K + 1) * 32 + TAIL_HEAD_PART) * (int64_t)sizeof(float);
@@ -587,10 +649,8 @@ extern "C" int dr_tower_tail_fused(const float* x, int64_t ld_x, const float* W1
         else hipLaunchKernelGGL((tower_tail_fused_kernel<8>), dim3(grid), dim3(512), 0, dr_s(stream), a);
     }
     if (parts & 2) {
-        hipLaunchKernelGGL(linear_bwd_narrow_reduce_kernel, dim3(K + 1), dim3(256), 0, dr_s(stream), partial, grid, K, H, scale,
-                           dst_w1, ld_dst_w1, dst_b1);
-        int rc = dr_head_finish_launch(head_partial, grid, H, scale, inv_n, dst_w2, ld_dst_w2, dst_b2, loss_out, dr_s(stream));
-        if (rc != DR_OK) return rc;
+        hipLaunchKernelGGL(tower_tail_reduce_kernel, dim3(K + 2), dim3(256), 0, dr_s(stream), partial, head_partial, grid, K, H, scale, inv_n,
+                           dst_w1, ld_dst_w1, dst_b1, dst_w2, ld_dst_w2, dst_b2, loss_out);
     }
     DR_CHECK_LAUNCH();
     return DR_OK;
