@@ -416,7 +416,11 @@ def main():
     # exposed waits are taken from EV_EXTRA bracketed steps run after the timed region and its loss read-out (same batches, same
     # prefetch), and the line says so.  --events on: every 4th step of the timed region, as before.
     EV_EXTRA = 8
-    events_after = (prof is not None and a.events == "auto" and a.model == "deepfm" and hasattr(eng, "exchange_report"))
+    # (round 5: the two-tower step too -- ~120 small launches, bound by the host: bracketing every kernel of the timed region took the
+    # line from 1.07-1.09 to 2.75-4.0 ms on this round's boxes, profiles/r05_bench_line_dssm*.json; its per-kernel rows come from
+    # bracketed steps after the timed region as well)
+    events_after = (prof is not None and a.events == "auto" and
+                    ((a.model == "deepfm" and hasattr(eng, "exchange_report")) or a.model == "dssm"))
     ev_steps = a.steps
     if events_after:
         prof_after, prof = prof, None
@@ -448,7 +452,10 @@ def main():
     if events_after:
         prof = prof_after
         ev_every, ev_steps = 1, EV_EXTRA
-        eng.enable_kernel_events(True, every=1)
+        try:
+            eng.enable_kernel_events(True, every=1)
+        except TypeError:
+            eng.enable_kernel_events(True)
         for i in range(EV_EXTRA):
             step(a.warmup + a.steps + i)
         torch.cuda.synchronize()

@@ -51,6 +51,44 @@ def test_factorized_topk_metrics(layer):
     assert metric.result() == [0.0] * len(ks)
 
 
+@pytest.mark.parametrize("split", ["f16x2", "bf16x3"])
+def test_topk_scan_index_parity_against_fp64_brute_force(split):
+    """The register-split exact scan (dr_topk_mips: dense first chunk + filtered chunks + running lists; factorized_top_k.py:201-233) at a
+    size that takes that path (512 queries x 200 000 items x 128, k = 100), in both operand splits, against the float64 brute force
+    with the reference's tie rule (equal scores -> lower index first, [TF] B13): the reported index at every rank either IS the
+    brute force's, or the two candidates' float64 scores differ by less than the products' rounding (2e-6 of the largest score: a
+    near-tie that no fp32 scan can order); exact duplicates of a row must come out in index order; the reported scores are the
+    float64 scores of the reported indices to the same tolerance."""
+    from deep_recommenders_amd import ops
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    Bq, N, Dq, k = 512, 200_000, 128, 100
+    q = torch.randn((Bq, Dq), device="cuda", generator=g) / Dq ** 0.5
+    corpus = torch.randn((N, Dq), device="cuda", generator=g) / Dq ** 0.5
+    corpus[150_000] = corpus[77]                       # exact duplicates, one of them in a later chunk of the scan
+    corpus[40_001] = corpus[77]
+    corpus[77] *= 3.0; corpus[150_000] *= 3.0; corpus[40_001] *= 3.0       # ... and large enough to be in many rows' top-k
+    prev = ops.set_gemm_split(split)
+    try:
+        s, idx = ops.topk_mips(q, corpus, k)
+    finally:
+        ops.set_gemm_split(prev)
+    S = q.double() @ corpus.double().T                 # checker only: float64 brute force
+    order = torch.sort(S, dim=1, descending=True, stable=True)
+    want_i, want_s = order.indices[:, :k], order.values[:, :k]
+    got_s64 = torch.gather(S, 1, idx)
+    tol = 2e-6 * float(S.abs().max())
+    assert float((got_s64 - want_s).abs().max()) <= tol, "a reported candidate is not (within rounding) the brute force's at its rank"
+    assert float((s.double() - got_s64).abs().max()) <= tol
+    same = float((idx == want_i).double().mean())
+    assert same >= 0.999, same                          # near-ties are rare: almost every rank is the identical index
+    assert int((torch.sort(idx, dim=1).values[:, 1:] == torch.sort(idx, dim=1).values[:, :-1]).sum()) == 0
+    pos = {v: (idx == v).double().argmax(1) for v in (77, 40_001, 150_000)}
+    has = (idx == 77).any(1) & (idx == 40_001).any(1) & (idx == 150_000).any(1)
+    assert int(has.sum()) > 50
+    assert bool((pos[77][has] < pos[40_001][has]).all()) and bool((pos[40_001][has] < pos[150_000][has]).all())
+
+
 def test_topk_mips_matches_oracle_large_and_ties():
     from deep_recommenders_amd import ops
     rng = np.random.default_rng(5)

@@ -34,7 +34,8 @@ for f in default adam zipf c2 dcn dssm unfused concat sharded_world1 dcn_sharded
 import json, sys
 try:
     d = json.loads(open("gpurun_out/line_%s.log" % sys.argv[1]).read().strip().splitlines()[-1])
-    print(sys.argv[1], d["value"], d["ms_per_step"], d["roofline"]["kernel"], d["roofline"]["frac"], (d.get("cpu_baseline") or {}).get("value"))
+    r = d.get("roofline") or {}
+    print(sys.argv[1], d["value"], d["ms_per_step"], r.get("kernel"), r.get("frac"), (d.get("cpu_baseline") or {}).get("value"))
 except Exception as e:
     print(sys.argv[1], "FAILED", e)
 PY

@@ -62,6 +62,7 @@ def main():
                    "emb_pool_bwd": "emb_bwd_sorted_kernel<16,4,false>", "hash_bucket_i64": "hash_bucket_i64_kernel",
                    "linear_fwd_L0": pick("bf3_gemm_rs_kernel<0,0,1,1,1>", "bf3_gemm_rs_kernel<0,0,1,1,0>", "bf3_gemm_rs_kernel<0,0,1,1>"),
                    "linear_bwd_dx_L0": pick("bf3_gemm_rs_kernel<0,0,1,1,1>", "bf3_gemm_rs_kernel<0,0,1,1,0>", "bf3_gemm_rs_kernel<0,0,1,1>"),
+                   "tower_tail_fused": pick("tower_tail_fused_kernel<8>", "tower_tail_fused_kernel<4>"),
                    "linear_bwd_dw_L0": pick("bf3_gemm_tn_rs_kernel<1,1>", "bf3_gemm_tn_rs_kernel<1,0>", "bf3_gemm_tn_rs_kernel<1>")}
     h2 = any(n.endswith(",1,1,1>") or n in ("bf3_emb_linear_kernel<1>", "bf3_gemm_tn_rs_kernel<1,1>") for n in event_names.values() if n in kernels)
     json.dump({"_note": note, "kernels": kernels, "event_names": event_names, "gemm_split": "f16x2" if h2 else "bf16x3"},
