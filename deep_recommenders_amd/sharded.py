@@ -54,6 +54,8 @@ class HipPrims:
     bce_fwd_bwd = staticmethod(ops.bce_fwd_bwd)
     axpy = staticmethod(ops.axpy)
     tower_head_fwd_bwd = staticmethod(ops.tower_head_fwd_bwd)
+    tower_tail_fused = staticmethod(ops.tower_tail_fused)
+    tower_tail_supported = staticmethod(ops.tower_tail_supported)
     linear_bwd_narrow = staticmethod(ops.linear_bwd_narrow)
     linear_bwd_narrow_supported = staticmethod(ops.linear_bwd_narrow_supported)
     cross_fwd = staticmethod(ops.cross_fwd)
@@ -591,6 +593,13 @@ class ShardedDeepFMEngine:
         self.mb = mb
         self.ex.set_slots(max(4, 2 * mb))
         Bm = B // mb
+        # the tower tail of a micro-batch in ONE pass over its h (round 5: dr_tower_tail_fused, as engine.DeepFMEngine; DR_FUSE_TAIL=0: the
+        # head and the narrow backward as two launches).  HipPrims only: the oracle-backed primitives of the gloo tests have no such call.
+        import os as _os0
+        self.fuse_tail = (self._cuda and hasattr(self.p, "tower_tail_fused") and _os0.environ.get("DR_FUSE_TAIL", "1") == "1"
+                          and self.fuse_head and nl >= 3 and self.acts[nl - 3] == 1
+                          and self.p.tower_tail_supported(Bm, self.Ws[-2].shape[0], self.Ws[-2].shape[1]))
+        self.tail_ws = ops.tower_tail_workspace(Bm, self.Ws[-2].shape[0], device) if self.fuse_tail else None
         self.narrow = [hasattr(self.p, "linear_bwd_narrow") and i > 0 and self.acts[i - 1] == 1
                        and self.p.linear_bwd_narrow_supported(Bm, Wt.shape[0], Wt.shape[1]) for i, Wt in enumerate(self.Ws)]
         self.loss_parts = torch.zeros(mb, **f32)
@@ -971,7 +980,19 @@ class ShardedDeepFMEngine:
                     self._k("linear_fwd_L%d" % i, "mfma", 2.0 * Bm * Wt.shape[0] * Wt.shape[1],
                             lambda x=x, Wt=Wt, b=b, i=i, sl=sl: p.linear_fwd(x, Wt, b, self.acts[i], out=self.hs[i][sl]))
                 x = self.hs[i][sl]
-            if self.fuse_head:
+            tail_done = False
+            if self.fuse_tail:
+                # head + the backward of the last hidden layer in one pass: prob, loss part, d_logit, d_h, the gradient for the layer
+                # below (with its amax record in the f16x2 mode) and both layers' gradients into the bucket
+                nlt = n_layers
+                self._k("tower_tail_fused", "hbm", 4.0 * Bm * (2 * self.Ws[-2].shape[0] + self.Ws[-2].shape[1] + 4),
+                        lambda x=x, sl=sl, m=m: p.tower_tail_fused(
+                            x, self.Ws[-2], self.bs[-2], self.Ws[-1], self.bs[-1], self.fm_logit[sl], labels[sl], ops.LOSS_SIGMOID_CE, 1.0,
+                            self.dhs[nlt - 3][sl], dst_W1=self.gWs[-2], dst_b1=self.gbs[-2], dst_W2=self.gWs[-1], dst_b2=self.gbs[-1],
+                            prob=self.prob[sl], d_logit=self.d_logit[sl], d_h=self.dhs[-1][sl], loss=self.loss_parts[m:m + 1],
+                            workspace=self.tail_ws, n_total=n_total, dx_amax=self.dh0_amax[m] if (h2 and nlt - 2 == 1) else None))
+                tail_done = True
+            elif self.fuse_head:
                 self._k("tower_head_fwd_bwd", "hbm", 4.0 * Bm * (self.Ws[-2].shape[0] + self.Ws[-2].shape[1] + 4),
                         lambda x=x, sl=sl, m=m: p.tower_head_fwd_bwd(
                             x, self.Ws[-2], self.bs[-2], self.Ws[-1], self.bs[-1], self.fm_logit[sl], labels[sl],
@@ -992,6 +1013,9 @@ class ShardedDeepFMEngine:
             if self.fuse_head:
                 top = n_layers - 2
                 dy = self.dhs[-1][sl]
+            if tail_done:
+                top = n_layers - 3
+                dy = self.dhs[n_layers - 3][sl]
             fuse_pack = self.fuse_pack and self.wplanes[0] is not None and not self.narrow[0] and top >= 0
             for i in range(top, -1, -1):
                 if i > 0:
