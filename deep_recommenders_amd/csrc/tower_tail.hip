@@ -261,7 +261,8 @@ struct TailArgs {
     float* dx; int64_t lddx;
     float* partial;                              // narrow layer: [grid][(K + 1) * 32]
     float* head_partial;                         // Dense(1) + loss: [grid][34]
-    uint32_t* dx_amax;
+    uint32_t* dx_amax;                           // (may be null) record raised with atomicMax -- only when amax_part is null
+    uint32_t* amax_part;                         // (may be null) [grid]: every block's max |dx| as float bits, reduced by tower_tail_reduce_kernel
 };
 
 // NWV waves per block, wave w owns columns 32 w .. 32 w + 31 of x (K = 32 NWV): lane (c, h) keeps x[tt_row(s, h)][32 w + c], s < 16.
@@ -456,11 +457,12 @@ __global__ __launch_bounds__(64 * NWV, (DR_TAIL_DBG & 1) ? 4 : 2) void tower_tai
         for (int w = 0; w < NWV; ++w) sacc += hsum[w][tid];
         a.head_partial[(int64_t)blockIdx.x * TAIL_HEAD_PART + tid] = live * sacc;
     }
-    if (a.dx_amax != nullptr && tid == 0) {
+    if (tid == 0 && (a.dx_amax != nullptr || a.amax_part != nullptr)) {
         uint32_t mm = 0u;
 #pragma unroll
         for (int w = 0; w < NWV; ++w) mm = max(mm, amax_w[w]);
-        if (mm > __hip_atomic_load(a.dx_amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.dx_amax, mm);
+        if (a.amax_part != nullptr) a.amax_part[blockIdx.x] = mm;                       // reduced (and the record STORED) by the reduce launch
+        else if (mm > __hip_atomic_load(a.dx_amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.dx_amax, mm);
     }
 }
 
@@ -469,8 +471,10 @@ __global__ __launch_bounds__(64 * NWV, (DR_TAIL_DBG & 1) ? 4 : 2) void tower_tai
 __global__ __launch_bounds__(256) void tower_tail_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ head_partial,
                                                                 int32_t nparts, int32_t K, int32_t N, float scale, float inv_n,
                                                                 float* __restrict__ dstW, int64_t ldw, float* __restrict__ dstb,
-                                                                float* dst_w2, int64_t ld_w2, float* dst_b2, float* __restrict__ loss_out) {
+                                                                float* dst_w2, int64_t ld_w2, float* dst_b2, float* __restrict__ loss_out,
+                                                                const uint32_t* __restrict__ amax_part, uint32_t* __restrict__ dx_amax) {
     __shared__ float red[8][TAIL_HEAD_PART];
+    __shared__ uint32_t amx[4];
     if ((int)blockIdx.x <= K) {
         const int k = blockIdx.x, n = threadIdx.x & 31, pg = threadIdx.x >> 5;
         const int64_t stride = (int64_t)(K + 1) * 32;
@@ -515,7 +519,15 @@ __global__ __launch_bounds__(256) void tower_tail_reduce_kernel(const float* __r
         }
         red[grp][c] = acc;
     }
+    if (amax_part != nullptr) {                                         // (kernel-uniform) the record of dx: max over the blocks' maxima, STORED
+        uint32_t m = 0u;
+        for (int b = threadIdx.x; b < nparts; b += 256) m = max(m, amax_part[b]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+        if ((threadIdx.x & 63) == 0) amx[threadIdx.x >> 6] = m;
+    }
     __syncthreads();
+    if (amax_part != nullptr && threadIdx.x == 0) dx_amax[0] = max(max(amx[0], amx[1]), max(amx[2], amx[3]));
     if (threadIdx.x < TAIL_HEAD_PART) {
         float sacc = 0.f;
 #pragma unroll
@@ -617,7 +629,7 @@ extern "C" int dr_linear_bwd_narrow_amax(const float* x, int64_t ld_x, const flo
 
 extern "C" int64_t dr_tower_tail_workspace_bytes(int64_t M, int32_t K) {
     if (M < TT_ROWS) return 512;
-    return (int64_t)tail_grid(M, K) * ((int64_t)(K + 1) * 32 + TAIL_HEAD_PART) * (int64_t)sizeof(float);
+    return (int64_t)tail_grid(M, K) * ((int64_t)(K + 1) * 32 + TAIL_HEAD_PART + 1) * (int64_t)sizeof(float);
 }
 
 // dr_tower_head_fwd_bwd (act = relu) followed by dr_linear_bwd_narrow (relu_mask = 1) of the SAME layer W1 -- the last hidden layer
@@ -638,19 +650,23 @@ extern "C" int dr_tower_tail_fused(const float* x, int64_t ld_x, const float* W1
     float* partial = static_cast<float*>(workspace);
     float* head_partial = partial + (int64_t)grid * (K + 1) * 32;
     const float inv_n = 1.f / (float)(n_total > 0 ? n_total : M);
+    // the record of dx: with both parts in this call the blocks leave their maxima in the workspace and the reduce launch STORES the
+    // record -- no reset, no atomics, one launch boundary less than a memset in front of the kernel; with part 1 alone (the reduce may
+    // run on another stream, later than the record's first reader) the record is reset here and raised with atomicMax
+    uint32_t* amax_part = (dx_amax != nullptr && parts == 3) ? reinterpret_cast<uint32_t*>(head_partial + (int64_t)grid * TAIL_HEAD_PART) : nullptr;
     if (parts & 1) {
-        if (dx_amax != nullptr && hipMemsetAsync(dx_amax, 0, sizeof(uint32_t), dr_s(stream)) != hipSuccess) return DR_ELAUNCH;
+        if (dx_amax != nullptr && amax_part == nullptr && hipMemsetAsync(dx_amax, 0, sizeof(uint32_t), dr_s(stream)) != hipSuccess) return DR_ELAUNCH;
         TailArgs a{};
         a.x = x; a.ldx = ld_x; a.W1 = W1; a.ldw1 = ld_w1; a.b1 = b1; a.M = M; a.K = K; a.N = H;
         a.w2 = w2; a.ld_w2 = ld_w2; a.b2 = b2; a.extra = extra_logit; a.labels = labels; a.loss_mode = loss_mode; a.inv_n = inv_n;
         a.prob = prob; a.d_logit = d_logit; a.d_h = d_h; a.ld_dh = ld_dh; a.dx = dx; a.lddx = ld_dx;
-        a.partial = partial; a.head_partial = head_partial; a.dx_amax = dx_amax;
+        a.partial = partial; a.head_partial = head_partial; a.dx_amax = dx_amax; a.amax_part = amax_part;
         if (K == 128) hipLaunchKernelGGL((tower_tail_fused_kernel<4>), dim3(grid), dim3(256), 0, dr_s(stream), a);
         else hipLaunchKernelGGL((tower_tail_fused_kernel<8>), dim3(grid), dim3(512), 0, dr_s(stream), a);
     }
     if (parts & 2) {
         hipLaunchKernelGGL(tower_tail_reduce_kernel, dim3(K + 2), dim3(256), 0, dr_s(stream), partial, head_partial, grid, K, H, scale, inv_n,
-                           dst_w1, ld_dst_w1, dst_b1, dst_w2, ld_dst_w2, dst_b2, loss_out);
+                           dst_w1, ld_dst_w1, dst_b1, dst_w2, ld_dst_w2, dst_b2, loss_out, amax_part, dx_amax);
     }
     DR_CHECK_LAUNCH();
     return DR_OK;

@@ -391,7 +391,8 @@ int dr_tower_head_fwd_bwd(const float* x, int64_t ld_x, const float* W1, int64_t
  * Both products use the pre-update W1 / w2 even when dst_* are the parameters themselves (scale = -lr: fused SGD); with gradient
  * buffers scale = 1.  parts = 1: the one-pass kernel (prob, d_logit, d_h, dx, per-block partials), 2: the two fixed-order reduces that
  * apply the partials (may run on another stream; must finish before the next part 1 over the same workspace), 3: both.  dx_amax (may
- * be NULL): receives max |dx| as float bits (reset by part 1) -- the f16x2 GEMMs' record of dx.  Deterministic.
+ * be NULL): receives max |dx| as float bits -- the f16x2 GEMMs' record of dx (parts = 3: stored by the reduce launch, no reset needed;
+ * part 1 alone: reset and raised by the kernel, complete when part 1 is).  Deterministic.
  * Domain: H <= 32, K in {128, 256}, M a multiple of 32; anything else returns DR_ESHAPE (use the two calls it replaces).  Results equal those two calls' up to the summation order of the K-long dot products. */
 int64_t dr_tower_tail_workspace_bytes(int64_t M, int32_t K);
 int dr_tower_tail_fused(const float* x, int64_t ld_x, const float* W1, int64_t ld_w1, const float* b1, int64_t M, int64_t n_total,
