@@ -49,8 +49,11 @@ H2_KERNELS = ("emb_linear_fwd_L0", "linear_bwd_dx_L0", "linear_bwd_dw_L0")
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    # defaults (round 5: 100 / 20, were 20 / 5): the chip needs ~20 steps to reach its steady state -- with 5 warm-up steps the first timed
+    # steps run the three GEMMs 5-8 % slow (clock / power ramp; profiles/r05_steps_warmup.log: 1.185-1.205 ms at 20 / 5 against 1.148 at
+    # 100 / 20 and 1.140-1.145 at 400 / 20, same box) -- and a 24 ms timed region is short for a wall-clock measurement.  120 steps = 0.14 s.
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=65536, help="per-GPU batch (weak scaling)")
     ap.add_argument("--fields", type=int, default=26)
     ap.add_argument("--vocab", type=int, default=10_000_000)
