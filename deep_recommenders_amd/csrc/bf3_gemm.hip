@@ -601,17 +601,25 @@ __device__ __forceinline__ void rs_split8(const float4& lo, const float4& hi4, b
 // MFMA; the price is that each activation row is loaded and split by two waves (w and w + 4: one SIMD, one L1).
 // H2: the f16x2 operand mode (see h2_split8 above): B holds TWO fp16 planes (32 KB stages, 4 pieces per wave and k-tile), three MFMAs
 // per fragment pair.
-template <int EPI, int DBG = 0, int MS = 1, int CS = 1, int H2 = 0>
+// AR (round 5; H2 only): RESIDENT activation operand for short reductions, K == 32 AR (AR = 4: the top-K scan's K = 128).  A block
+// keeps ONE row tile for all of its output tiles (block b: row tile b % tiles_m, column tiles b / tiles_m + j * (grid / tiles_m); the
+// launcher makes grid a multiple of tiles_m), loads and splits its 32 K floats per lane ONCE into 16 AR registers and the step
+// loop carries no activation loads, no split and no wait for them: only the weight ring, the fragment reads and the MFMAs.  The
+// products and their order are those of the streaming kernel -- bit-identical results (the scan's dense first chunk, which runs
+// the streaming kernel, must tie exactly with the filtered chunks).
+template <int EPI, int DBG = 0, int MS = 1, int CS = 1, int H2 = 0, int AR = 0>
 __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_kernel(RsArgs g) {
     constexpr int NW = 8 * CS / MS, RGW = NW / CS, BM = 32 * MS * RGW, BN = 256, NT = BN / 32, NTW = NT / CS, NS = 3;
     static_assert(CS == 1 || (CS == 2 && MS == 2), "column split only with 64-row waves");
     static_assert(!H2 || (CS == 1 && EPI != 5), "f16x2: no column split, no pack epilogue");
+    static_assert(AR == 0 || (H2 && MS == 1 && CS == 1 && DBG == 0), "resident activations: f16x2, 8 waves x 32 rows");
     constexpr int NPL = H2 ? 2 : 3;                                     // operand planes
     constexpr int B_PLANE = BN * 64;                                    // bytes: 256 rows x 64-byte rows (32 bf16 / fp16)
     constexpr int STAGE = NPL * B_PLANE;                                // 48 KB (32 KB)
     constexpr int PW = STAGE / 1024 / NW;                               // 6 MS (4) LDS-DMA pieces per wave and k-tile
     static_assert(PW * NW == 16 * NPL && (MS == 1 || MS == 2), "piece schedule below assumes 16 NPL / NW pieces per wave and k-tile");
-    constexpr int VM_STEP = 4 * MS + PW;                                // VMEM operations of one step (A loads + pieces)
+    constexpr int KT_UNROLL = AR ? AR : 1;                              // (AR: the k-tile loop is unrolled, see there)
+    constexpr int VM_STEP = (AR ? 0 : 4 * MS) + PW;                     // VMEM operations of one step (A loads + pieces)
     constexpr int VM_WAIT_STEP = 0x0F70 | (VM_STEP & 15) | ((VM_STEP >> 4) << 14);   // s_waitcnt vmcnt(VM_STEP) (6-bit field, split)
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE];
 
@@ -637,8 +645,17 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
     const int ntiles = tiles_m * tiles_n;
     const int nk = (g.K + BK - 1) / BK;
     const bool ktail = (g.K % BK) != 0;
-    if ((int)blockIdx.x >= ntiles) return;
-    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    // the block's tiles: `tile` = blockIdx.x + j gridDim.x, j < my_tiles; lid_of(tile) = its logical id (row tile * tiles_n + column tile)
+    const int ar_npg = AR ? (int)gridDim.x / tiles_m : 1;               // AR: column tiles are dealt round-robin to the grid / tiles_m blocks of a row tile
+    const int ar_n0 = AR ? (int)blockIdx.x / tiles_m : 0;
+    const int my_tiles = AR ? (ar_n0 < tiles_n ? (tiles_n - ar_n0 + ar_npg - 1) / ar_npg : 0)
+                            : ((int)blockIdx.x < ntiles ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0);
+    if (my_tiles <= 0) return;
+    const int tile_end = (int)blockIdx.x + my_tiles * (int)gridDim.x;
+    auto lid_of = [&](int tile) {
+        if constexpr (AR != 0) return ((int)blockIdx.x % tiles_m) * tiles_n + ar_n0 + ((tile - (int)blockIdx.x) / (int)gridDim.x) * ar_npg;
+        else return xcd_remap(tile, ntiles);
+    };
     const int total = my_tiles * nk;                                    // steps of this block
 
     // B fragment read addresses (stage 0, plane 0, column tile 0), one per k-step: row = 32 nt + l31, chunk 2 hi + s swizzled
@@ -669,7 +686,7 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
                                                                         // hipcc silently drops the kernel's host stub)
     int pb_tile = blockIdx.x, pb_kt = 0, pb_stage = 0, pb_koff = 0;     // pb_koff: byte offset along k of the next real step
     auto setup_b = [&](int tile) {
-        const int n0 = (xcd_remap(tile, ntiles) % tiles_n) * BN;
+        const int n0 = (lid_of(tile) % tiles_n) * BN;
 #pragma unroll
         for (int i = 0; i < PW; ++i) {
             const int j = wave + NW * i;
@@ -694,7 +711,7 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
         if (++pb_kt == nk) {
             pb_kt = 0;
             pb_tile += gridDim.x;
-            if (pb_tile < ntiles) {
+            if (pb_tile < tile_end) {
                 setup_b(pb_tile);
                 pb_koff = 0;
             } else {
@@ -706,7 +723,7 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
     const float* asrc[2];
     int pa_tile = blockIdx.x, pa_kt = 0;
     auto setup_a = [&](int tile) {
-        const int64_t m0 = (int64_t)(xcd_remap(tile, ntiles) / tiles_n) * BM;
+        const int64_t m0 = (int64_t)(lid_of(tile) / tiles_n) * BM;
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms) {
             int64_t row = m0 + rgi * (32 * MS) + 32 * ms + l31;
@@ -753,7 +770,7 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
         if (++pa_kt == nk) {
             pa_kt = 0;
             pa_tile += gridDim.x;
-            if (pa_tile < ntiles) setup_a(pa_tile);
+            if (pa_tile < tile_end) setup_a(pa_tile);
             else if constexpr (!(DBG & 8)) {                            // end of the stream: the dummy loads re-read k-tile 0 of the
 #pragma unroll                                                          // last rows (pa_kt == 0, so `over` keeps them inside the row)
                 for (int ms = 0; ms < MS; ++ms) asrc[ms] -= (int64_t)nk * BK;
@@ -797,10 +814,22 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
     // ---- prologue: B steps 0 and 1, A step 0 ---------------------------------------------------------------------------------
     setup_b(pb_tile);
     setup_a(pa_tile);
+    bf16x8 fa_res[AR ? AR : 1][2][2];                                   // AR: [k-tile][k-step][plane] of the block's row tile
+    if constexpr (AR != 0) {                                            // ... loaded and split here, before any weight piece is in flight
+#pragma unroll
+        for (int t = 0; t < (AR ? AR : 1); ++t) {
+            float4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(asrc[0] + t * BK + 4 * q);
+            h2_split8(v[0], v[1], h2_sa, fa_res[t][0][0], fa_res[t][0][1]);
+            h2_split8(v[2], v[3], h2_sa, fa_res[t][1][0], fa_res[t][1][1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int i = 0; i < PW; ++i) issue_b(i);
     advance_b();
-    load_a(true);                                                       // BEFORE step 1's pieces: 6 VMEM operations follow the A
+    if constexpr (AR == 0) load_a(true);                                // BEFORE step 1's pieces: 6 VMEM operations follow the A
 #pragma unroll                                                          // loads on every path into the loop, as inside it
     for (int i = 0; i < PW; ++i) issue_b(i);
     if (total > 1) advance_b();
@@ -818,9 +847,22 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[ms][t][k] = 0.f;
     int step = 0;
-    for (; tile < ntiles; tile += gridDim.x) {
-    for (kt = 0; kt < nk; ++kt, ++step) {
+    for (; tile < tile_end; tile += gridDim.x) {
+    // (AR: the k-tiles unrolled, so that each step names its resident registers directly -- fa is an alias then, not a copy)
+#pragma unroll KT_UNROLL
+    for (kt = 0; kt < (AR ? AR : nk); ++kt, ++step) {
         // ---- step start: A of this step -> bf16 terms (the compiler waits for the loads here), next step's A into flight ----
+        if constexpr (AR != 0) {                                        // resident: this k-tile's terms out of the block's registers
+#define RS_AR_PICK(KT)                                                                                     \
+            if constexpr (KT < (AR ? AR : 1)) {                                                            \
+                if (kt == KT) {                                                                            \
+                    fa[0][0][0] = fa_res[KT][0][0]; fa[0][0][1] = fa_res[KT][0][1];                        \
+                    fa[0][1][0] = fa_res[KT][1][0]; fa[0][1][1] = fa_res[KT][1][1];                        \
+                }                                                                                          \
+            }
+            RS_AR_PICK(0) RS_AR_PICK(1) RS_AR_PICK(2) RS_AR_PICK(3)
+#undef RS_AR_PICK
+        } else {
         mask_a();
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms) {
@@ -838,9 +880,10 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
                 rs_split8(an[ms][2], an[ms][3], fa[ms][1][0], fa[ms][1][1], fa[ms][1][2]);
             }
         }
+        }   // !AR
         __builtin_amdgcn_sched_barrier(0);
         const bool has_a = step + 1 < total, has_b = step + 2 < total;
-        load_a(has_a);
+        if constexpr (AR == 0) load_a(has_a);
         __builtin_amdgcn_sched_barrier(0);
         const int nstage = stage == NS - 1 ? 0 : stage + 1;
         if constexpr (CS == 2) {
@@ -922,7 +965,7 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
     }
         // ---- epilogue of an output tile: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
         {
-            const int lid = xcd_remap(tile, ntiles);
+            const int lid = lid_of(tile);
             const int64_t tm0 = (int64_t)(lid / tiles_n) * BM;
             const int tn0 = (lid % tiles_n) * BN;
             const bool relu = g.act == 1;
@@ -2256,6 +2299,17 @@ int rs_launch(const RsArgs& g, hipStream_t stream) {
         if (g.b_amax == nullptr || g.pack_pos != nullptr) return DR_EINVAL;
         if (g.c_amax != nullptr && hipMemsetAsync(g.c_amax, 0, sizeof(uint32_t), stream) != hipSuccess) return DR_ELAUNCH;
         if (g.tau != nullptr) {
+            // the scan's reduction is short (K = the embedding width): resident activations (AR, see the kernel) when K is 128 or 64
+            // and the row tiles divide into the grid; DR_TOPK_RESIDENT=0: the streaming kernel (A/B, tools/exp/topk_xlane.sh)
+            static const bool resident = [] { const char* e = getenv("DR_TOPK_RESIDENT"); return e == nullptr || e[0] != '0'; }();
+            const int tiles_m = (int)((g.M + 255) / 256);
+            if (resident && (g.K == 128 || g.K == 64) && tiles_m <= 256) {
+                const int ar_grid = 256 / tiles_m * tiles_m;
+                if (g.K == 128) hipLaunchKernelGGL((bf3_gemm_rs_kernel<4, 0, 1, 1, 1, 4>), dim3(ar_grid), dim3(512), 0, stream, g);
+                else hipLaunchKernelGGL((bf3_gemm_rs_kernel<4, 0, 1, 1, 1, 2>), dim3(ar_grid), dim3(512), 0, stream, g);
+                DR_CHECK_LAUNCH();
+                return DR_OK;
+            }
             hipLaunchKernelGGL((bf3_gemm_rs_kernel<4, 0, 1, 1, 1>), dim3(grid), dim3(512), 0, stream, g);
             DR_CHECK_LAUNCH();
             return DR_OK;

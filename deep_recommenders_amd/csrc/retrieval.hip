@@ -27,6 +27,7 @@ using drtk::shfl_up_i64;
 // Candidate-list mode (cols != NULL): row `row` holds min(cnt[row], ld) entries (score, column) in ARBITRARY order (the
 // filtering GEMM epilogue appends them with atomics); the list's index tie-break makes the result independent of arrival
 // order.  On exit the kernel optionally publishes tau[row] (k-th best, -inf while the list is not full) and clears cnt[row].
+template <bool CAND>                                       // CAND: candidate-list mode (cols != NULL)
 __global__ __launch_bounds__(256) void topk_select_kernel(const float* __restrict__ scores, int64_t ld, int64_t Bq,
                                                           int64_t n, int32_t k, int64_t index_base, int32_t init,
                                                           float* __restrict__ out_s, int64_t* __restrict__ out_i,
@@ -39,16 +40,40 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const float* __restric
     L.init(k, lane);
     if (!init) L.load(out_s + row * k, out_i + row * k);
     const float* srow = scores + row * ld;
-    const int32_t* crow = cols != nullptr ? cols + row * ld : nullptr;
+    const int32_t* crow = CAND ? cols + row * ld : nullptr;
     if (cnt != nullptr) {
         const int64_t have = cnt[row];
         n = have < ld ? have : ld;
     }
-    for (int64_t j0 = 0; j0 < n; j0 += 64) {
-        const int64_t j = j0 + lane;
-        const float v = j < n ? srow[j] : -INFINITY;
-        const int64_t myidx = index_base + (crow != nullptr ? (int64_t)(j < n ? crow[j] : 0) : j);
-        L.offer(v, myidx, j < n);
+    // SEL_U x 64 entries per round, the NEXT round's loads issued before this round's insertions (an insertion is a chain of
+    // dependent cross-lane steps: a wave that waited for one 256-byte load per 64 entries, as first written, spent the dense first
+    // chunk -- 8192 entries per row -- waiting for 128 memory round trips).  Entries are offered in index order, as before.
+    constexpr int SEL_U = 4;
+    float nv[SEL_U];
+    int32_t nc[SEL_U];
+    auto fetch = [&](int64_t j0) {                            // (n > 0 here; loads past the end re-read the last entry)
+#pragma unroll
+        for (int u = 0; u < SEL_U; ++u) {
+            const int64_t j = j0 + 64 * u + lane;
+            const int64_t jj = j < n ? j : n - 1;
+            nv[u] = srow[jj];
+            if constexpr (CAND) nc[u] = crow[jj];
+            else nc[u] = 0;
+        }
+    };
+    if (n > 0) fetch(0);
+    for (int64_t j0 = 0; j0 < n; j0 += 64 * SEL_U) {
+        float v[SEL_U];
+        int32_t c[SEL_U];
+#pragma unroll
+        for (int u = 0; u < SEL_U; ++u) { v[u] = nv[u]; c[u] = nc[u]; }
+        if (j0 + 64 * SEL_U < n) fetch(j0 + 64 * SEL_U);
+#pragma unroll
+        for (int u = 0; u < SEL_U; ++u) {
+            const int64_t j = j0 + 64 * u + lane;
+            if (j0 + 64 * u >= n) break;                      // (wave-uniform)
+            L.offer(v[u], index_base + (CAND ? (int64_t)c[u] : j), j < n);
+        }
     }
     L.store(out_s + row * k, out_i + row * k);
     if (lane == 0) {
@@ -217,7 +242,7 @@ extern "C" int dr_topk_select(const float* scores, int64_t ld, int64_t Bq, int64
     if (Bq < 0 || n < 0 || k <= 0 || k > KMAX || ld < n) return DR_EINVAL;
     if (Bq == 0) return DR_OK;
     if (!out_scores || !out_index || (n > 0 && !scores)) return DR_EINVAL;
-    hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)((Bq + 3) / 4)), dim3(256), 0, dr_s(stream), scores, ld, Bq, n, k,
+    hipLaunchKernelGGL(topk_select_kernel<false>, dim3((unsigned)((Bq + 3) / 4)), dim3(256), 0, dr_s(stream), scores, ld, Bq, n, k,
                        index_base, init, out_scores, out_index, (const int32_t*)nullptr, (int32_t*)nullptr, (float*)nullptr);
     DR_CHECK_LAUNCH();
     return DR_OK;
@@ -375,14 +400,14 @@ extern "C" int dr_topk_mips(const float* q, int64_t Bq, const float* cand, int64
                              : dr_scores_nt(q, D, cand, D, Bq, (int32_t)nc, D, dense, chunk, stream);
             if (rc != DR_OK) return rc;
             if (N > chunk) hipLaunchKernelGGL(zero_i32_kernel, dim3(dr_grid_for(Bq, 256)), dim3(256), 0, dr_s(stream), cnt, Bq);
-            hipLaunchKernelGGL(topk_select_kernel, dim3(sel_grid), dim3(256), 0, dr_s(stream), dense, chunk, Bq, nc, k,
+            hipLaunchKernelGGL(topk_select_kernel<false>, dim3(sel_grid), dim3(256), 0, dr_s(stream), dense, chunk, Bq, nc, k,
                                index_base, first, out_scores, out_index, (const int32_t*)nullptr, (int32_t*)nullptr, tau);
         } else {
             int rc = h2 ? dr_h2_scores_filter(q, D, rec_q, planes, p_ps, p_ld, rec_c, Bq, (int32_t)nc, D, tau, cand_s, cand_c, cnt, scan, stream)
                      : rs_scan ? dr_bf3_scores_filter(q, D, planes, p_ps, p_ld, Bq, (int32_t)nc, D, tau, cand_s, cand_c, cnt, scan, stream)
                              : dr_scores_nt_filter(q, D, cand + c0 * D, D, Bq, (int32_t)nc, D, tau, cand_s, cand_c, cnt, scan, stream);
             if (rc != DR_OK) return rc;
-            hipLaunchKernelGGL(topk_select_kernel, dim3(sel_grid), dim3(256), 0, dr_s(stream), cand_s, scan, Bq, nc, k,
+            hipLaunchKernelGGL(topk_select_kernel<true>, dim3(sel_grid), dim3(256), 0, dr_s(stream), cand_s, scan, Bq, nc, k,
                                index_base + c0, 0, out_scores, out_index, cand_c, cnt, tau);
         }
         first = 0;

@@ -121,6 +121,35 @@ def test_topk_mips_matches_oracle_large_and_ties():
         ops.topk_mips(torch.tensor(q).cuda(), torch.tensor(cand[:5]).cuda(), 10)
 
 
+@pytest.mark.parametrize("split", ["f16x2", "bf16x3"])
+def test_topk_ties_at_the_kth_boundary_do_not_depend_on_arrival_order(split):
+    """tf.math.top_k's rule (equal scores -> lower index first, [TF] B13) AT THE k-TH BOUNDARY of the filtered scan: 40 exact copies of
+    one item, scattered over the later chunks of the corpus, outscore everything else for every query, and k = 10 -- the answer is the 10
+    copies with the lowest indices, in index order, for every row.  The filtering epilogue appends a chunk's survivors to a row's
+    candidate list with atomics (arbitrary order), so the list's gate has to be the TOTAL order (score, then index): with a gate on
+    the score alone, a copy that arrives after the list has filled with later copies is refused although it precedes them."""
+    from deep_recommenders_amd import ops
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    Bq, N, D, k = 512, 200_000, 128, 10
+    q = 0.1 * torch.randn((Bq, D), device="cuda", generator=g)
+    q[:, 0] = 1.0
+    c = torch.randn((N, D), device="cuda", generator=g) / D ** 0.5
+    u = torch.zeros(D, device="cuda")
+    u[0] = 10.0
+    copies = [40_000 + 3989 * t for t in range(40)]                    # 40 000 .. 195 571: behind the dense first chunk, several chunks
+    c[copies] = u
+    prev = ops.set_gemm_split(split)
+    try:
+        for _ in range(3):                                              # (the arrival order differs from run to run)
+            s, i = ops.topk_mips(q, c, k)
+            got = i.cpu().numpy()
+            assert (got == np.asarray(copies[:k])[None, :]).all(), got[(got != np.asarray(copies[:k])[None, :]).any(1)][:4]
+            assert bool((s == 10.0).all())
+    finally:
+        ops.set_gemm_split(prev)
+
+
 @pytest.mark.parametrize("N,nlist", [(100_003, 1024), (5000, 1), (70_000, 8192), (300, 7)])
 def test_ivf_build_lists_is_a_stable_counting_sort(N, nlist):
     """dr_ivf_build_lists == np.argsort(assign, kind="stable") + the list boundaries (bit-exact); assignments outside [0, nlist) drop

@@ -15,4 +15,6 @@ e0.record()
 for _ in range(5):
     s, i = ops.topk_mips(q, c, k)
 e1.record(); torch.cuda.synchronize()
-print("topk %.2f ms per call" % (e0.elapsed_time(e1) / 5))
+# a fingerprint of the result (A/B runs of two libraries must print the same one) + the IVF scan, which shares the list code
+fp = (int(i.sum().item()) * 1000003 + int(s.double().sum().item() * 1e6)) & 0xFFFFFFFFFFFF
+print("topk %.2f ms per call   result fingerprint %012x" % (e0.elapsed_time(e1) / 5, fp))
