@@ -38,10 +38,6 @@
 #ifndef DR_NT_DGRAD_STORE
 #define DR_NT_DGRAD_STORE 0
 #endif
-// top-K filter epilogue with a per-register early reject (experiment, off: see the EPI == 4 epilogue)
-#ifndef DR_TOPK_FAST_REJECT
-#define DR_TOPK_FAST_REJECT 0
-#endif
 #include "dr_common.h"
 #include "bf3_split.h"
 #include <cstdlib>
@@ -926,7 +922,7 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
                 // groups 14 and 15 are in registers and this wave is done reading stage `stage`; publish step + 1
                 wait_b(2, true);
                 __builtin_amdgcn_s_waitcnt(VM_WAIT_STEP);              // all but this step's 4 MS A loads + PW pieces
-                asm volatile("s_barrier" ::: "memory");
+                if constexpr (!(DBG & 512)) asm volatile("s_barrier" ::: "memory");   // (DBG 512, ablation: what the step's rendezvous costs -- racy garbage)
                 if (has_a) read_b(0, nstage, 0);
             } else {
                 if (has_a) read_b(1, nstage, 1);
@@ -979,52 +975,78 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
             constexpr bool cross = EPI == 2;
             if constexpr (EPI == 4) {
                 // top-K filter: nothing is stored unless a score beats its row's threshold -- rare once tau has warmed up (expected
-                // k / items_seen of a chunk), so the tile's epilogue is 128 compares + ballots and a handful of appends
+                // k / items_seen of a chunk), plentiful in the first filtered chunks (~400 per row right behind the dense chunk).
+                // Written in round 2 as "per (register, column tile): ballot, one atomic by the first survivor, wait for its result,
+                // store" -- up to 128 dependent atomic round trips per wave and tile, each behind the previous one's stores (the first
+                // filtered chunk took 858 us against 316 us in steady state).  Now: (0) the 16 thresholds of the lane's rows loaded
+                // together; (1) a counting pass -- the survivors of each row of this half-wave, summed over the 8 column tiles with
+                // scalar popcounts; (2) ONE atomic instruction for the tile: lane r < 16 of each half reserves row r's slots;
+                // (3) a storing pass that recomputes the masks (compares are cheap, keeping 128 masks is not).  Stores are
+                // unconditional inside a wave-uniform branch: lanes without a survivor repeat the first survivor's store (same address,
+                // same data) -- a memory operation under a divergent branch would make hipcc drain vmcnt in front of each one.
+                // Which slot of its row's list a candidate lands in is arbitrary, as before (the list's order is total: topk_list.h).
+                // lane r < 16 of a half stands for row r of that half: its threshold here, its survivor count and its list slots below
+                const int64_t lrow = r0 + (l31 & 3) + 8 * ((l31 >> 2) & 3);
+                float tlane = g.tau[lrow < g.M ? lrow : g.M - 1];
+                // compared with the RAW accumulators (f16x2: the threshold in accumulator units -- a power-of-two factor, exact): the
+                // scaled scores are formed only where one is stored
+                if constexpr (H2) tlane = tlane / h2_out;
+                if (!(lrow < g.M)) tlane = INFINITY;                    // rows past the edge: nothing passes
+                int mycnt = 0;                                          // lane r < 16 of a half: survivors of row r of that half
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
-                    const int64_t row = r0 + (reg & 3) + 8 * (reg >> 2);
-                    const bool rv = row < g.M;
-                    const float t = g.tau[rv ? row : g.M - 1];
-#if DR_TOPK_FAST_REJECT
-                    {   // EXPERIMENT (round 4, built but NEVER RUN: the round's GPU budget ended first; tools/exp/topk_fast_reject.sh).
-                        // Once tau has warmed up almost no score passes, yet the loop below spends a compare + ballot + mask + branch on
-                        // every one of the 8 column tiles of every accumulator register (128 per wave and tile; the scan launch takes
-                        // 19.5 us per tile against ~12 us of matrix + ingest time, profiles/r04_topk_kernel_stats.csv).  One OR over the
-                        // column tiles and ONE ballot per register first; the per-column work only for a register that has a hit.
-                        const float tq = H2 ? t / h2_out : t;           // (a power-of-two factor: exact) compare the raw accumulators
-                        bool any = false;
+                    int c_lo = 0, c_hi = 0;                             // (scalar)
+                    const float tq = __shfl(tlane, 32 * hi + reg, 64);
 #pragma unroll
-                        for (int nt = 0; nt < NTW; ++nt) any = any || (cb0 + nt * 32 + l31 < g.N && acc[ms][nt][reg] > tq);
-                        if (__ballot(rv && any) == 0ull) {              // (wave-uniform)
+                    for (int nt = 0; nt < NTW; ++nt) {
+                        const unsigned long long b = __ballot(cb0 + nt * 32 + l31 < g.N && acc[ms][nt][reg] > tq);
+                        c_lo += __popc((unsigned)b);
+                        c_hi += __popc((unsigned)(b >> 32));
+                    }
+                    if (l31 == reg) mycnt = hi ? c_hi : c_lo;
+                    __builtin_amdgcn_sched_barrier(0);                  // one register at a time (hoisted, the 128 scaled scores spill)
+                }
+                if (__ballot(mycnt > 0) != 0ull) {                      // (wave-uniform)
+                    int mybase = 0;
+                    if (mycnt > 0) mybase = atomicAdd(g.cand_cnt + lrow, mycnt);     // (only lanes l31 < 16 count)
 #pragma unroll
-                            for (int nt = 0; nt < NTW; ++nt) acc[ms][nt][reg] = 0.f;
-                            __builtin_amdgcn_sched_barrier(0);          // (registers one at a time: hoisted, the 16 thresholds and ORs spill)
-                            continue;
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int64_t row = r0 + (reg & 3) + 8 * (reg >> 2);
+                        int run = __shfl(mybase, 32 * hi + reg, 64);    // next free slot of this half's row
+                        const float tq = __shfl(tlane, 32 * hi + reg, 64);
+#pragma unroll
+                        for (int nt = 0; nt < NTW; ++nt) {
+                            const int col = cb0 + nt * 32 + l31;
+                            float raw = acc[ms][nt][reg];
+                            asm volatile("" : "+v"(raw));               // opaque: else the counting pass's 128 compare results are kept (spilled) for reuse
+                            acc[ms][nt][reg] = 0.f;
+                            const bool pass = col < g.N && raw > tq;
+                            const unsigned long long b = __ballot(pass);
+                            if (b == 0ull) continue;                    // (wave-uniform)
+                            const float v = H2 ? raw * h2_out : raw;
+                            const unsigned half = (unsigned)(b >> (32 * hi));
+                            const int pos = run + __popc(half & ((1u << l31) - 1u));
+                            run += __popc(half);
+                            const bool ok = pass && pos < g.cand_cap;
+                            const unsigned long long okb = __ballot(ok);
+                            if (okb == 0ull) continue;
+                            const int first = __ffsll((long long)okb) - 1;   // (wave-uniform) the survivor the idle lanes repeat
+                            int64_t dst = row * g.cand_cap + pos;
+                            const int d_lo = __builtin_amdgcn_readlane((int)(dst & 0xffffffffll), first);
+                            const int d_hi = __builtin_amdgcn_readlane((int)(dst >> 32), first);
+                            const float v1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), first));
+                            const int c1 = __builtin_amdgcn_readlane(col, first);
+                            if (!ok) dst = ((int64_t)d_hi << 32) | (uint32_t)d_lo;
+                            g.cand_s[dst] = ok ? v : v1;
+                            g.cand_c[dst] = ok ? col : c1;
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
-#endif
+                } else {
 #pragma unroll
-                    for (int nt = 0; nt < NTW; ++nt) {
-                        const int col = cb0 + nt * 32 + l31;
-                        const float v = H2 ? acc[ms][nt][reg] * h2_out : acc[ms][nt][reg];
-                        acc[ms][nt][reg] = 0.f;
-                        const bool pass = rv && col < g.N && v > t;
-                        const unsigned half = (unsigned)((__ballot(pass) >> (32 * hi)) & 0xffffffffull);
-                        if (half != 0u) {
-                            const int leader = 32 * hi + __ffs((int)half) - 1;
-                            int base = 0;
-                            if (lane == leader) base = atomicAdd(g.cand_cnt + row, __popc(half));
-                            base = __shfl(base, leader, 64);
-                            if (pass) {
-                                const int64_t pos = base + __popc(half & ((1u << l31) - 1u));
-                                if (pos < g.cand_cap) {
-                                    g.cand_s[row * g.cand_cap + pos] = v;
-                                    g.cand_c[row * g.cand_cap + pos] = col;
-                                }
-                            }
-                        }
-                    }
+                    for (int reg = 0; reg < 16; ++reg)
+#pragma unroll
+                        for (int nt = 0; nt < NTW; ++nt) acc[ms][nt][reg] = 0.f;
                 }
             } else if constexpr (EPI == 5) {
                 // Every load unconditional (clamped).  The stores are under WAVE-UNIFORM conditions only: a 32-column group lies inside
@@ -2338,6 +2360,8 @@ int rs_launch(const RsArgs& g, hipStream_t stream) {
                 RS_ABL2(34) RS_ABL2(3) RS_ABL2(10) RS_ABL2(98) RS_ABL2(35) RS_ABL2(43)
                 // round 5: WITH the MFMAs -- 8 = A from cache (its loads re-read k-tile 0), 4 = B always k-tile 0, 12 = both, 9 = no weight DMA + A from cache, 16 = staggered wave groups
                 RS_ABL2(8) RS_ABL2(4) RS_ABL2(12) RS_ABL2(9) RS_ABL2(16)
+                // 512 = no per-step barrier; 544 = that + no fragment reads; 521 = that + A from cache + no weight DMA
+                RS_ABL2(512) RS_ABL2(544) RS_ABL2(521)
 #undef RS_ABL2
             }
         }
