@@ -80,6 +80,9 @@ SIGNATURES = {
     "dr_topk_select": [_p, _i64, _i64, _i64, _i32, _i64, _i32, _p, _p, _p],
     "dr_topk_workspace_bytes": [_i64, _i64, _i32],
     "dr_topk_mips": [_p, _i64, _p, _i64, _i32, _i32, _i64, _i32, _p, _p, _p, _i64, _p],
+    "dr_topk_index_bytes": [_i64, _i32],
+    "dr_topk_index_build": [_p, _i64, _i32, _p, _i64, _p],
+    "dr_topk_mips_indexed": [_p, _i64, _p, _p, _i64, _i32, _i32, _i64, _i32, _p, _p, _p, _i64, _p],
     "dr_ivf_pack": [_p, _i64, _i32, _p, _p, _p, _i32, _i64, _p, _p, _p, _p],
     "dr_ivf_scan": [_p, _i64, _i32, _p, _i32, _p, _p, _p, _i32, _p, _p, _p],
     "dr_topk_merge": [_p, _p, _i32, _p, _p, _i32, _i64, _i32, _p, _p, _p],
@@ -148,7 +151,8 @@ _RESTYPE = {"dr_version": ctypes.c_char_p, "dr_shard_bucket_workspace_bytes": ct
             "dr_bf3_wgrad_workspace_bytes": ctypes.c_int64,
             "dr_linear_bwd_narrow_workspace_bytes": ctypes.c_int64,
             "dr_tower_head_workspace_bytes": ctypes.c_int64,
-            "dr_inbatch_softmax_workspace_bytes": ctypes.c_int64, "dr_topk_workspace_bytes": ctypes.c_int64}
+            "dr_inbatch_softmax_workspace_bytes": ctypes.c_int64, "dr_topk_workspace_bytes": ctypes.c_int64,
+            "dr_topk_index_bytes": ctypes.c_int64}
 
 DR_OK, DR_EINVAL, DR_ELAUNCH, DR_ESHAPE = 0, -1, -2, -3
 _ERR = {DR_EINVAL: "DR_EINVAL (bad argument)", DR_ELAUNCH: "DR_ELAUNCH (HIP launch error)",

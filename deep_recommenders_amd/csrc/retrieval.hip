@@ -27,7 +27,7 @@ using drtk::shfl_up_i64;
 // Candidate-list mode (cols != NULL): row `row` holds min(cnt[row], ld) entries (score, column) in ARBITRARY order (the
 // filtering GEMM epilogue appends them with atomics); the list's index tie-break makes the result independent of arrival
 // order.  On exit the kernel optionally publishes tau[row] (k-th best, -inf while the list is not full) and clears cnt[row].
-template <bool CAND>                                       // CAND: candidate-list mode (cols != NULL)
+template <bool CAND, typename IT = int64_t>                // CAND: candidate-list mode (cols != NULL); IT: index type inside the list (topk_list.h)
 __global__ __launch_bounds__(256) void topk_select_kernel(const float* __restrict__ scores, int64_t ld, int64_t Bq,
                                                           int64_t n, int32_t k, int64_t index_base, int32_t init,
                                                           float* __restrict__ out_s, int64_t* __restrict__ out_i,
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const float* __restric
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= Bq) return;
-    drtk::List L;
+    drtk::ListT<IT> L;
     L.init(k, lane);
     if (!init) L.load(out_s + row * k, out_i + row * k);
     const float* srow = scores + row * ld;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const float* __restric
         for (int u = 0; u < SEL_U; ++u) {
             const int64_t j = j0 + 64 * u + lane;
             if (j0 + 64 * u >= n) break;                      // (wave-uniform)
-            L.offer(v[u], index_base + (CAND ? (int64_t)c[u] : j), j < n);
+            L.offer(v[u], (IT)(index_base + (CAND ? (int64_t)c[u] : j)), j < n);
         }
     }
     L.store(out_s + row * k, out_i + row * k);
@@ -242,7 +242,7 @@ extern "C" int dr_topk_select(const float* scores, int64_t ld, int64_t Bq, int64
     if (Bq < 0 || n < 0 || k <= 0 || k > KMAX || ld < n) return DR_EINVAL;
     if (Bq == 0) return DR_OK;
     if (!out_scores || !out_index || (n > 0 && !scores)) return DR_EINVAL;
-    hipLaunchKernelGGL(topk_select_kernel<false>, dim3((unsigned)((Bq + 3) / 4)), dim3(256), 0, dr_s(stream), scores, ld, Bq, n, k,
+    hipLaunchKernelGGL((topk_select_kernel<false, int64_t>), dim3((unsigned)((Bq + 3) / 4)), dim3(256), 0, dr_s(stream), scores, ld, Bq, n, k,
                        index_base, init, out_scores, out_index, (const int32_t*)nullptr, (int32_t*)nullptr, (float*)nullptr);
     DR_CHECK_LAUNCH();
     return DR_OK;
@@ -254,7 +254,7 @@ extern "C" int dr_topk_select(const float* scores, int64_t ld, int64_t Bq, int64
 static int64_t topk_hdr_bytes(int64_t Bq) { return (Bq * 8 + 8 + 255) / 256 * 256; }
 
 // corpus chunk of the scan: ~256 MB of [Bq, chunk] scores (1024 output tiles of the register-split GEMM at Bq = 8192: 4 per CU)
-constexpr int64_t TOPK_MAX_COLS = 32768;      // longest chunk of the scan (dense first chunk and filtered chunks alike)
+constexpr int64_t TOPK_MAX_COLS = 32768;      // longest dense first chunk (the filtered chunks: TOPK_MAX_SCAN)
 static int64_t topk_env(const char* name, int64_t dflt) {
     const char* e = getenv(name);
     return e != nullptr && e[0] != 0 ? atoll(e) : dflt;
@@ -280,13 +280,18 @@ static int64_t topk_planes_bytes(int64_t chunk) { return ((3 * ((chunk + 31) / 3
 // register-split kernel then walks 16 tiles per block instead of 4 (one pipeline fill and drain per launch, one selection pass and
 // one split per chunk: 122 -> 32 rounds over a 1 M corpus).  The candidate lists' capacity stays "one slot per scanned column"
 // (cannot overflow, whatever the corpus order), so the workspace grows with it: 2.1 GB at Bq = 8192.
-constexpr int TOPK_SCAN_MULT = 4;
+// Round 5: eight times, up to 65 536 columns (4.3 GB of lists at Bq = 8192): with the insertions and the filter's appends cheaper, a
+// chunk's fixed costs -- launch, pipeline fill, one selection pass -- outweigh the candidates a staler threshold lets through
+// (8192 x 1 M x 128: 11.2 ms at 32 768, 10.9 at 65 536, 10.8 at 131 072; `profiles/r05_topk.log`).  The dense first chunk keeps its
+// own bound (TOPK_MAX_COLS): its selection runs one wavefront per query over the whole chunk.
+constexpr int TOPK_SCAN_MULT = 8;
+constexpr int64_t TOPK_MAX_SCAN = 65536;
 static int64_t topk_scan_for(int64_t chunk, int64_t N) {
     if (N <= chunk) return chunk;
     int64_t rest = (N - chunk + 255) / 256 * 256;
     static const int64_t scan_cols = topk_env("DR_TOPK_SCAN_COLS", 0);              // (experiment knob) 0: TOPK_SCAN_MULT x chunk
     int64_t scan = scan_cols > 0 ? (scan_cols + 255) / 256 * 256 : chunk * TOPK_SCAN_MULT;
-    if (scan > TOPK_MAX_COLS && scan_cols <= 0) scan = TOPK_MAX_COLS;
+    if (scan > TOPK_MAX_SCAN && scan_cols <= 0) scan = TOPK_MAX_SCAN;
     if (scan > rest) scan = rest;
     return scan < chunk ? chunk : scan;
 }
@@ -333,9 +338,17 @@ __global__ __launch_bounds__(256) void zero_i32_kernel(int32_t* __restrict__ p, 
 // only if it beats its row's current k-th best, into a per-row candidate list that the selection kernel then folds in.
 // After a few chunks almost nothing passes (expected k / items_seen of a chunk), so neither the [Bq, chunk] score
 // matrix nor its re-read exist any more.
-extern "C" int dr_topk_mips(const float* q, int64_t Bq, const float* cand, int64_t N, int32_t D, int32_t k,
-                            int64_t index_base, int32_t init, float* out_scores, int64_t* out_index, float* workspace,
-                            int64_t workspace_bytes, dr_stream_t stream) {
+// `index` (may be null): a corpus pre-split by dr_topk_index_build -- [256-byte header: the corpus' amax record][2 fp16 planes of
+// roundup(N, 32) x roundup(D, 32)].  Used when the scan runs in the f16x2 split: the per-call pass over the corpus for its record and
+// the per-chunk split disappear (0.36 ms of an 11.1 ms pass at 8192 x 1 M x 128); the planes and the record are the ones the call would
+// have made, so the result is the same bit for bit.  Any other mode ignores it and reads `cand`.
+constexpr int64_t TOPK_INDEX_HDR = 256;
+static int64_t topk_index_rows(int64_t N) { return (N + 31) / 32 * 32; }
+static int64_t topk_index_ld(int32_t D) { return ((int64_t)D + 31) / 32 * 32; }
+
+static int topk_mips_impl(const float* q, int64_t Bq, const float* cand, const void* index, int64_t N, int32_t D, int32_t k,
+                          int64_t index_base, int32_t init, float* out_scores, int64_t* out_index, float* workspace,
+                          int64_t workspace_bytes, dr_stream_t stream) {
     if (Bq < 0 || N < 0 || D < 4 || k <= 0 || k > KMAX) return DR_EINVAL;
     if (Bq == 0) return DR_OK;
     if (!q || !out_scores || !out_index || !workspace || (N > 0 && !cand)) return DR_EINVAL;
@@ -370,16 +383,21 @@ extern "C" int dr_topk_mips(const float* q, int64_t Bq, const float* cand, int64
     // 128-wide items) and one for the queries, so that equal candidates still tie bit-exactly whichever chunk they sit in.
     const bool h2 = rs_scan && dr_get_gemm_split() == DR_GEMM_SPLIT_F16X2;      // read at every call (dr_set_gemm_split)
     uint32_t* rec_q = reinterpret_cast<uint32_t*>(wsb + Bq * 8);
-    uint32_t* rec_c = rec_q + 1;
+    const uint32_t* rec_c = rec_q + 1;
+    const bool pre = h2 && index != nullptr;                                    // the corpus' planes and record come with the index
     if (h2) {
         int rc = dr_h2_amax(q, D, Bq, D, rec_q, 1, stream);
-        if (rc == DR_OK) rc = dr_h2_amax(cand, D, N, D, rec_c, 1, stream);
+        if (rc == DR_OK && !pre) rc = dr_h2_amax(cand, D, N, D, rec_q + 1, 1, stream);
         if (rc != DR_OK) return rc;
+        if (pre) rec_c = const_cast<uint32_t*>(static_cast<const uint32_t*>(index));
     }
-    const int64_t p_rows = (scan + 31) / 32 * 32, p_ld = ((int64_t)D + 31) / 32 * 32, p_ps = p_rows * p_ld;
-    if (rs_scan && (D % 32) != 0)      // the reduction padding of the planes must be zero (the kernel multiplies it)
+    const int64_t p_rows = pre ? topk_index_rows(N) : (scan + 31) / 32 * 32, p_ld = ((int64_t)D + 31) / 32 * 32, p_ps = p_rows * p_ld;
+    if (rs_scan && !pre && (D % 32) != 0)      // the reduction padding of the planes must be zero (the kernel multiplies it)
         if (hipMemsetAsync(planes, 0, (size_t)(3 * p_ps * 2), dr_s(stream)) != hipSuccess) return DR_ELAUNCH;
     const unsigned sel_grid = (unsigned)((Bq + 3) / 4);
+    // a search that starts here (init) only ever holds indices of [index_base, index_base + N): when they fit, the lists carry 32-bit
+    // indices (half the cross-lane traffic of an insertion); a continued search (Streaming's later batches) may hold anything
+    const bool idx32 = init != 0 && index_base >= 0 && index_base + N <= (int64_t)0x7fffffff;
     if (N == 0 && init) {
         hipLaunchKernelGGL(fill_topk_kernel, dim3(dr_grid_for(Bq * k, 256)), dim3(256), 0, dr_s(stream), out_scores, out_index,
                            Bq * k);
@@ -388,7 +406,9 @@ extern "C" int dr_topk_mips(const float* q, int64_t Bq, const float* cand, int64
     for (int64_t c0 = 0; c0 < N; c0 += (c0 == 0 ? chunk : scan)) {
         const int64_t len = c0 == 0 ? chunk : scan;
         const int64_t nc = N - c0 < len ? N - c0 : len;
-        if (rs_scan) {
+        if (pre) {                                                              // this chunk's rows of the index' planes
+            planes = const_cast<char*>(static_cast<const char*>(index)) + TOPK_INDEX_HDR + c0 * p_ld * 2;
+        } else if (rs_scan) {
             int rc = h2 ? dr_h2_split(cand + c0 * D, D, nc, D, planes, p_ps, p_ld, 0, 0, 0, rec_c, stream)
                         : dr_bf3_split(cand + c0 * D, D, nc, D, planes, p_ps, p_ld, 0, 0, 0, stream);
             if (rc != DR_OK) return rc;
@@ -400,20 +420,64 @@ extern "C" int dr_topk_mips(const float* q, int64_t Bq, const float* cand, int64
                              : dr_scores_nt(q, D, cand, D, Bq, (int32_t)nc, D, dense, chunk, stream);
             if (rc != DR_OK) return rc;
             if (N > chunk) hipLaunchKernelGGL(zero_i32_kernel, dim3(dr_grid_for(Bq, 256)), dim3(256), 0, dr_s(stream), cnt, Bq);
-            hipLaunchKernelGGL(topk_select_kernel<false>, dim3(sel_grid), dim3(256), 0, dr_s(stream), dense, chunk, Bq, nc, k,
-                               index_base, first, out_scores, out_index, (const int32_t*)nullptr, (int32_t*)nullptr, tau);
+            if (idx32) hipLaunchKernelGGL((topk_select_kernel<false, int32_t>), dim3(sel_grid), dim3(256), 0, dr_s(stream), dense, chunk, Bq, nc, k,
+                                          index_base, first, out_scores, out_index, (const int32_t*)nullptr, (int32_t*)nullptr, tau);
+            else hipLaunchKernelGGL((topk_select_kernel<false, int64_t>), dim3(sel_grid), dim3(256), 0, dr_s(stream), dense, chunk, Bq, nc, k,
+                                    index_base, first, out_scores, out_index, (const int32_t*)nullptr, (int32_t*)nullptr, tau);
         } else {
             int rc = h2 ? dr_h2_scores_filter(q, D, rec_q, planes, p_ps, p_ld, rec_c, Bq, (int32_t)nc, D, tau, cand_s, cand_c, cnt, scan, stream)
                      : rs_scan ? dr_bf3_scores_filter(q, D, planes, p_ps, p_ld, Bq, (int32_t)nc, D, tau, cand_s, cand_c, cnt, scan, stream)
                              : dr_scores_nt_filter(q, D, cand + c0 * D, D, Bq, (int32_t)nc, D, tau, cand_s, cand_c, cnt, scan, stream);
             if (rc != DR_OK) return rc;
-            hipLaunchKernelGGL(topk_select_kernel<true>, dim3(sel_grid), dim3(256), 0, dr_s(stream), cand_s, scan, Bq, nc, k,
-                               index_base + c0, 0, out_scores, out_index, cand_c, cnt, tau);
+            if (idx32) hipLaunchKernelGGL((topk_select_kernel<true, int32_t>), dim3(sel_grid), dim3(256), 0, dr_s(stream), cand_s, scan, Bq, nc, k,
+                                          index_base + c0, 0, out_scores, out_index, cand_c, cnt, tau);
+            else hipLaunchKernelGGL((topk_select_kernel<true, int64_t>), dim3(sel_grid), dim3(256), 0, dr_s(stream), cand_s, scan, Bq, nc, k,
+                                    index_base + c0, 0, out_scores, out_index, cand_c, cnt, tau);
         }
         first = 0;
     }
     DR_CHECK_LAUNCH();
     return DR_OK;
+}
+
+extern "C" int dr_topk_mips(const float* q, int64_t Bq, const float* cand, int64_t N, int32_t D, int32_t k,
+                            int64_t index_base, int32_t init, float* out_scores, int64_t* out_index, float* workspace,
+                            int64_t workspace_bytes, dr_stream_t stream) {
+    return topk_mips_impl(q, Bq, cand, nullptr, N, D, k, index_base, init, out_scores, out_index, workspace, workspace_bytes, stream);
+}
+
+// The corpus side of BruteForce.index / Streaming's candidates (factorized_top_k.py:275-297 of the reference: candidates are handed over
+// ONCE, queries arrive many times): what the f16x2 scan derives from the corpus on every call -- its amax record and the two fp16
+// planes of corpus * 2^k -- built once.
+extern "C" int64_t dr_topk_index_bytes(int64_t N, int32_t D) {
+    if (N < 0 || D <= 0) return 0;
+    return TOPK_INDEX_HDR + 2 * topk_index_rows(N) * topk_index_ld(D) * 2;
+}
+
+extern "C" int dr_topk_index_build(const float* cand, int64_t N, int32_t D, void* index, int64_t index_bytes, dr_stream_t stream) {
+    if (N < 0 || D < 4 || (D % 4) != 0 || D > TOPK_PLANES_MAX_D) return DR_EINVAL;
+    if (!index || (N > 0 && !cand) || index_bytes < dr_topk_index_bytes(N, D)) return DR_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(index) & 255) != 0) return DR_EINVAL;
+    // header and padding (rows past N, columns past D) zero: the kernel multiplies the reduction padding
+    if (hipMemsetAsync(index, 0, (size_t)dr_topk_index_bytes(N, D), dr_s(stream)) != hipSuccess) return DR_ELAUNCH;
+    if (N == 0) return DR_OK;
+    uint32_t* rec = static_cast<uint32_t*>(index);
+    int rc = dr_h2_amax(cand, D, N, D, rec, 1, stream);
+    const int64_t ld = topk_index_ld(D), ps = topk_index_rows(N) * ld;
+    // in pieces: the split kernel's fast path indexes with 32 bits
+    const int64_t piece = (int64_t)1 << 22;
+    for (int64_t r0 = 0; r0 < N && rc == DR_OK; r0 += piece) {
+        const int64_t nr = N - r0 < piece ? N - r0 : piece;
+        rc = dr_h2_split(cand + r0 * D, D, nr, D, static_cast<char*>(index) + TOPK_INDEX_HDR, ps, ld, r0, 0, 0, rec, stream);
+    }
+    return rc;
+}
+
+extern "C" int dr_topk_mips_indexed(const float* q, int64_t Bq, const float* cand, const void* index, int64_t N, int32_t D, int32_t k,
+                                    int64_t index_base, int32_t init, float* out_scores, int64_t* out_index, float* workspace,
+                                    int64_t workspace_bytes, dr_stream_t stream) {
+    if (index == nullptr || (reinterpret_cast<uintptr_t>(index) & 255) != 0) return DR_EINVAL;
+    return topk_mips_impl(q, Bq, cand, index, N, D, k, index_base, init, out_scores, out_index, workspace, workspace_bytes, stream);
 }
 
 extern "C" int dr_topk_merge(const float* sa, const int64_t* ia, int32_t ka, const float* sb, const int64_t* ib, int32_t kb,

@@ -144,6 +144,8 @@ class BruteForce(TopK):
             ids = torch.cat([_dev(b).reshape(-1) for b in _batches(identifiers)]).to(torch.int64)
         self._candidates = cand.contiguous()
         self._identifiers = ids.contiguous()
+        # the corpus side of the scan (amax record + fp16 planes of the candidates), derived here once instead of on every call
+        self._index = ops.TopKIndex(self._candidates) if self._candidates.is_cuda else None
         return self
 
     def call(self, queries, k: Optional[int] = None, **kwargs):
@@ -154,7 +156,7 @@ class BruteForce(TopK):
         if self._query_model is not None:
             queries = self._query_model(queries)
         queries = _dev(queries, torch.float32)
-        scores, index = ops.topk_mips(queries, self._candidates, k)                # :330-332
+        scores, index = ops.topk_mips(queries, self._index if getattr(self, "_index", None) is not None else self._candidates, k)   # :330-332
         return scores, ops.gather_i64(self._identifiers, index)                    # :334
 
 

@@ -736,17 +736,52 @@ def topk_select(scores, k, index_base=0, init=True, state=None):
     return state
 
 
+class TopKIndex:
+    """The corpus side of an exact top-K index (dr_topk_index_build; BruteForce.index / Streaming's candidates of the reference:
+    candidates are handed over once, queries arrive many times): the corpus' amax record and fp16 planes, which dr_topk_mips would
+    otherwise derive from the corpus on every call.  `topk_mips(q, index, k)` takes it in place of the corpus; the result is the same
+    bit for bit.  The planes follow the corpus tensor: written in place since the build (`_version`), they are rebuilt on the next use.
+    Corpora the planes do not cover (D not a multiple of 4, D > 512, empty) keep `buf` None and take the plain path."""
+
+    def __init__(self, cand):
+        self.cand = _c(cand, torch.float32)
+        N, D = self.cand.shape
+        self.buf = None
+        if N > 0 and D % 4 == 0 and 4 <= D <= 512 and self.cand.is_cuda:
+            self.buf = torch.empty(lib().dr_topk_index_bytes(N, D) // 4, dtype=torch.float32, device=self.cand.device)
+            assert self.buf.data_ptr() % 256 == 0
+        self._ver = None
+        self.ensure_fresh()
+
+    def ensure_fresh(self):
+        if self.buf is not None and self._ver != self.cand._version:
+            N, D = self.cand.shape
+            check(lib().dr_topk_index_build(ptr(self.cand), N, D, ptr(self.buf), self.buf.numel() * 4, stream_ptr()), "dr_topk_index_build")
+            self._ver = self.cand._version
+
+    @property
+    def shape(self):
+        return self.cand.shape
+
+
 def topk_mips(q, cand, k, index_base=0, init=True, state=None, workspace=None):
+    """cand: the corpus [N, D] fp32, or a TopKIndex built from it."""
     q = _c(q, torch.float32)
-    cand = _c(cand, torch.float32)
+    index = cand if isinstance(cand, TopKIndex) else None
+    cand = index.cand if index is not None else _c(cand, torch.float32)
     Bq, D = q.shape
     N = cand.shape[0]
     if state is None:
         state = topk_state(Bq, k, q.device)
     if workspace is None:
         workspace = torch.empty(max(1, lib().dr_topk_workspace_bytes(Bq, N, int(k)) // 4), dtype=torch.float32, device=q.device)
-    rc = lib().dr_topk_mips(ptr(q), Bq, ptr(cand), N, D, int(k), int(index_base), int(bool(init)), ptr(state[0]),
-                            ptr(state[1]), ptr(workspace), workspace.numel() * 4, stream_ptr())
+    if index is not None and index.buf is not None:
+        index.ensure_fresh()
+        rc = lib().dr_topk_mips_indexed(ptr(q), Bq, ptr(cand), ptr(index.buf), N, D, int(k), int(index_base), int(bool(init)),
+                                        ptr(state[0]), ptr(state[1]), ptr(workspace), workspace.numel() * 4, stream_ptr())
+    else:
+        rc = lib().dr_topk_mips(ptr(q), Bq, ptr(cand), N, D, int(k), int(index_base), int(bool(init)), ptr(state[0]),
+                                ptr(state[1]), ptr(workspace), workspace.numel() * 4, stream_ptr())
     if rc == _lib.DR_ESHAPE:
         raise ValueError("Tried to retrieve k={k} top items, but candidate batch too small."
                          "To resolve this, 1. increase batch-size, 2. set `drop_remainder`=True, "

@@ -220,12 +220,14 @@ class TwoTowerEngine:
         """Item-tower outputs of the whole corpus (BruteForce.index over `candidates.map(item_model)`)."""
         if not self.c_tower.Ws:
             self.corpus = self.item_table
+            self._corpus_index = None
             return self.corpus
         if self.corpus is None or self.corpus.data_ptr() == self.item_table.data_ptr():
             self.corpus = torch.empty((self.Ni, self.out_dim), dtype=torch.float32, device=self.item_table.device)
         for r0 in range(0, self.Ni, chunk):
             r1 = min(self.Ni, r0 + chunk)
             self.corpus[r0:r1].copy_(self.c_tower.forward_nograd(self.item_table[r0:r1]))
+        self._corpus_index = None                # (rebuilt by the next topk: the corpus' amax record and fp16 planes, once per index)
         return self.corpus
 
     def topk(self, q, k=None):
@@ -234,7 +236,13 @@ class TwoTowerEngine:
         if self._topk_ws is None or self._topk_ws[0] != (q.shape[0], k):
             nb = ops.lib().dr_topk_workspace_bytes(q.shape[0], self.Ni, int(k))
             self._topk_ws = ((q.shape[0], k), torch.empty(max(1, nb // 4), dtype=torch.float32, device=q.device))
-        return ops.topk_mips(q, self.corpus, k, workspace=self._topk_ws[1])
+        if self.corpus.data_ptr() == self.item_table.data_ptr():
+            # no item tower: the corpus IS the live table, which the training kernels write through raw pointers (no version
+            # counter moves) -- nothing derived from it may be kept across calls
+            return ops.topk_mips(q, self.corpus, k, workspace=self._topk_ws[1])
+        if getattr(self, "_corpus_index", None) is None or self._corpus_index.cand.data_ptr() != self.corpus.data_ptr():
+            self._corpus_index = ops.TopKIndex(self.corpus)
+        return ops.topk_mips(q, self._corpus_index, k, workspace=self._topk_ws[1])
 
     def metric_step(self, user_keys, item_ids, ks=(1, 5, 10, 50, 100)):
         """FactorizedTopK.update_state for one batch: hit counts of the positive among [positive ∪ top-k] for each k in ks

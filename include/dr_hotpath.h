@@ -501,6 +501,18 @@ int64_t dr_topk_workspace_bytes(int64_t Bq, int64_t N, int32_t k);
 int dr_topk_mips(const float* q, int64_t Bq, const float* cand, int64_t N, int32_t D, int32_t k,
                  int64_t index_base, int32_t init, float* out_scores, int64_t* out_index,
                  float* workspace, int64_t workspace_bytes, dr_stream_t stream);
+/* The corpus side of an index (BruteForce.index factorized_top_k.py:275-297 / Streaming's candidates: candidates are handed over ONCE,
+ * queries arrive many times).  dr_topk_index_build derives, once, what the f16x2 scan of dr_topk_mips derives from the corpus on
+ * every call -- its amax record and the two fp16 planes of cand * 2^k -- into `index` (256-byte aligned, dr_topk_index_bytes(N, D)
+ * bytes; D a multiple of 4, <= 512).  dr_topk_mips_indexed(q, ..., cand, index, ...) is dr_topk_mips with that work skipped: same
+ * arguments, same result bit for bit (the planes and the record are the ones the call would have made); `cand` must still be the
+ * corpus the index was built from -- the scan reads it instead of the index whenever it does not run in the f16x2 split
+ * (dr_get_gemm_split) or falls back to the generic kernel.  The index must be rebuilt when the corpus changes. */
+int64_t dr_topk_index_bytes(int64_t N, int32_t D);
+int dr_topk_index_build(const float* cand, int64_t N, int32_t D, void* index, int64_t index_bytes, dr_stream_t stream);
+int dr_topk_mips_indexed(const float* q, int64_t Bq, const float* cand, const void* index, int64_t N, int32_t D, int32_t k,
+                         int64_t index_base, int32_t init, float* out_scores, int64_t* out_index,
+                         float* workspace, int64_t workspace_bytes, dr_stream_t stream);
 /* ------------------------------------------------------------------------------------------
  * SURVEY.md section 8f rank 4 -- IVF-Flat approximate top-K, the GPU counterpart of the reference's `Faiss` index
  * (keras/models/retrieval/factorized_top_k.py:337-461: faiss.IndexIVFFlat(faiss.IndexFlatIP(d), d, nlist,

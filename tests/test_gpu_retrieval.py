@@ -150,6 +150,34 @@ def test_topk_ties_at_the_kth_boundary_do_not_depend_on_arrival_order(split):
         ops.set_gemm_split(prev)
 
 
+@pytest.mark.parametrize("Bq,N,D,k", [(512, 200_000, 128, 100), (77, 5003, 20, 10), (64, 70_001, 64, 50)])
+def test_topk_index_gives_the_same_bits_and_follows_the_corpus(Bq, N, D, k):
+    """dr_topk_index_build / dr_topk_mips_indexed (BruteForce.index, factorized_top_k.py:275-297: the candidates are handed over once):
+    the scan over a pre-split corpus returns exactly what the scan over the corpus returns -- scores and indices, bit for bit, in both
+    operand splits (bf16x3 ignores the index) -- and an index whose corpus tensor was written in place is rebuilt on its next use."""
+    from deep_recommenders_amd import ops
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    q = torch.randn((Bq, D), device="cuda", generator=g) / D ** 0.5
+    corpus = torch.randn((N, D), device="cuda", generator=g) / D ** 0.5
+    corpus[N - 3] = corpus[11]                                       # a duplicate across chunks: ties must fall the same way
+    index = ops.TopKIndex(corpus)
+    assert index.buf is not None
+    for split in ("f16x2", "bf16x3"):
+        prev = ops.set_gemm_split(split)
+        try:
+            s0, i0 = ops.topk_mips(q, corpus, k)
+            s1, i1 = ops.topk_mips(q, index, k)
+        finally:
+            ops.set_gemm_split(prev)
+        assert torch.equal(s0, s1) and torch.equal(i0, i1), split
+    corpus[5] *= 50.0                                                 # in place: the planes AND the corpus' amax record are stale now
+    s0, i0 = ops.topk_mips(q, corpus, k)
+    s1, i1 = ops.topk_mips(q, index, k)
+    assert torch.equal(s0, s1) and torch.equal(i0, i1)
+    assert int((i1 == 5).sum()) > 0
+
+
 @pytest.mark.parametrize("N,nlist", [(100_003, 1024), (5000, 1), (70_000, 8192), (300, 7)])
 def test_ivf_build_lists_is_a_stable_counting_sort(N, nlist):
     """dr_ivf_build_lists == np.argsort(assign, kind="stable") + the list boundaries (bit-exact); assignments outside [0, nlist) drop

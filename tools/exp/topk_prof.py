@@ -7,6 +7,8 @@ g = torch.Generator(device="cuda"); g.manual_seed(0)
 Bq, N, D, k = 8192, 1_000_000, 128, 100
 q = torch.randn((Bq, D), device="cuda", generator=g) / D ** 0.5
 c = torch.randn((N, D), device="cuda", generator=g) / D ** 0.5
+if os.environ.get("TOPK_INDEX", "0") == "1":          # the corpus pre-split once (ops.TopKIndex), as BruteForce.index does
+    c = ops.TopKIndex(c)
 for _ in range(2):
     s, i = ops.topk_mips(q, c, k)
 torch.cuda.synchronize()
