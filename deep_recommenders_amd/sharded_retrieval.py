@@ -291,6 +291,7 @@ class ShardedTwoTowerEngine:
 
     # ---- corpus index + metric pass -------------------------------------------------------------------------------------------
     def index_corpus(self, chunk: int = 1 << 16):
+        self._corpus_index = None
         rows = self.item_table[:self.n_items_local]
         if not self.c_tower.Ws:
             self.corpus = rows
@@ -302,7 +303,15 @@ class ShardedTwoTowerEngine:
         return self.corpus
 
     def topk(self, q, k=None):
-        return sharded_topk(q, self.corpus, self.shard_item_ids, k or self.k, self.world, self.rank, self.p, self.group, self.tr)
+        corpus = self.corpus
+        if self.p is RetrievalPrims and self.c_tower.Ws:
+            # the shard's side of the scan (amax record + fp16 planes), once per index_corpus instead of once per call (ops.TopKIndex);
+            # never for the live table (no item tower): the training kernels write it without moving a version counter
+            ix = getattr(self, "_corpus_index", None)
+            if ix is None or ix.cand.data_ptr() != corpus.data_ptr():
+                ix = self._corpus_index = ops.TopKIndex(corpus)
+            corpus = ix
+        return sharded_topk(q, corpus, self.shard_item_ids, k or self.k, self.world, self.rank, self.p, self.group, self.tr)
 
     def metric_step(self, user_keys, item_ids, ks=(1, 5, 10, 50, 100)):
         assert self.corpus is not None, "The `index_corpus` method must be called first"
