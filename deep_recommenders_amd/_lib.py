@@ -100,6 +100,7 @@ SIGNATURES = {
     "dr_bf3_gemm_nt": [_p, _i64, _i64, _p, _i64, _i64, _i64, _i32, _i32, _p, _i32, _p, _i64, _p, _i64, _p],
     "dr_bf3_linear_nt": [_p, _i64, _p, _i64, _i64, _i64, _i32, _i32, _p, _i32, _p, _i64, _i32, _p, _i64, _p],
     "dr_bf3_linear_nt_pack": [_p, _i64, _p, _i64, _i64, _i64, _i32, _i32, _p, _i32, _p, _p, _p, _i64, _p, _p, _p, _p],
+    "dr_h2_linear_nt_pack": [_p, _i64, _p, _p, _i64, _i64, _p, _i64, _i32, _i32, _p, _i32, _p, _p, _p, _i64, _p, _p, _p, _p],
     "dr_bf3_cross_fwd": [_p, _p, _i64, _p, _i64, _i64, _p, _f32, _i64, _i32, _p, _p, _p],
     "dr_linear_fwd_splitk_workspace_bytes": [_i64, _i32, _i32],
     "dr_linear_fwd_splitk": [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _i64, _p, _i64, _p],

@@ -607,7 +607,7 @@ template <int EPI, int DBG = 0, int MS = 1, int CS = 1, int H2 = 0, int AR = 0>
 __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_kernel(RsArgs g) {
     constexpr int NW = 8 * CS / MS, RGW = NW / CS, BM = 32 * MS * RGW, BN = 256, NT = BN / 32, NTW = NT / CS, NS = 3;
     static_assert(CS == 1 || (CS == 2 && MS == 2), "column split only with 64-row waves");
-    static_assert(!H2 || (CS == 1 && EPI != 5), "f16x2: no column split, no pack epilogue");
+    static_assert(!H2 || CS == 1, "f16x2: no column split");
     static_assert(AR == 0 || (H2 && MS == 1 && CS == 1 && DBG == 0), "resident activations: f16x2, 8 waves x 32 rows");
     constexpr int NPL = H2 ? 2 : 3;                                     // operand planes
     constexpr int B_PLANE = BN * 64;                                    // bytes: 256 rows x 64-byte rows (32 bf16 / fp16)
@@ -617,7 +617,11 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
     constexpr int KT_UNROLL = AR ? AR : 1;                              // (AR: the k-tile loop is unrolled, see there)
     constexpr int VM_STEP = (AR ? 0 : 4 * MS) + PW;                     // VMEM operations of one step (A loads + pieces)
     constexpr int VM_WAIT_STEP = 0x0F70 | (VM_STEP & 15) | ((VM_STEP >> 4) << 14);   // s_waitcnt vmcnt(VM_STEP) (6-bit field, split)
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE];
+    // EPI 5 in the f16x2 mode stages each wave's 32 x 32 accumulator block through the LDS (row-major, pitch 36 floats) behind the ring
+    // (+ the wave's 32 x 4 destinations and 32 d_fm_logit values of the tile: registers are what this epilogue is short of)
+    constexpr int PK_PITCH = 36, PK_STG = 32 * PK_PITCH * 4, PK_WAVE = PK_STG + 32 * 4 * 4 + 32 * 4;    // 4608 + 512 + 128 bytes per wave
+    constexpr int PK_BYTES = (EPI == 5 && H2) ? NW * PK_WAVE : 0;       // 41 KB: 96 + 41 of the 160 KB
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE + PK_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1047,6 +1051,68 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
                     for (int reg = 0; reg < 16; ++reg)
 #pragma unroll
                         for (int nt = 0; nt < NTW; ++nt) acc[ms][nt][reg] = 0.f;
+                }
+            } else if constexpr (EPI == 5 && H2 != 0) {
+                // The pack epilogue, second construction (round 5; the bf16x3 one below moves 4 bytes per lane and instruction and lost to
+                // dgrad + pack by 27 %).  Each 32 x 32 accumulator block goes through a per-wave LDS buffer, row-major, and comes back
+                // as float4s with 8 lanes on one row: a row's 32 columns of a field are ONE 128-byte line of its destination row and of
+                // the x row it reads -- 16-byte loads and stores, 4 passes of 8 rows per block.  Loads unconditional (rows clamped);
+                // stores unconditional on interior row tiles (a memory operation under a per-lane condition makes hipcc drain vmcnt
+                // in front of each one); the first-order copy is written by all 8 lanes of a row (one address, one value).
+                // (the launcher admits this epilogue for interior tiles only -- M a multiple of 256 -- with the FM term present and
+                // destinations that fit 32 bits: no per-lane guards, no optional loads)
+                const int kemb = min(64 * g.pack_F, g.N);
+                float* stg = reinterpret_cast<float*>(smem + NS * STAGE + wave * PK_WAVE);
+                const int64_t rw0 = r0 - 4 * hi;                                        // the wave's first row
+                const int prow = lane >> 3, pd4 = (lane & 7) * 4;                       // storing pass: row within the 8-row group, column
+                const int f0 = cb0 >> 6;                                                // the tile's first field (4 fields per 256 columns)
+                // per tile: the wave's 32 x 4 destinations (x 64: float offsets) and its rows' d_fm_logit, through the LDS (lane -> row lane / 2,
+                // fields 2 (lane & 1) + {0, 1}; lanes < 32 -> d_fm_logit of row lane)
+                int* pk_pos = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(stg) + PK_STG);
+                float* pk_dl = reinterpret_cast<float*>(pk_pos + 128);
+                {
+                    const int64_t prw = rw0 + (lane >> 1);
+                    const int fa0 = min(f0 + 2 * (lane & 1), g.pack_F - 1), fa1 = min(f0 + 2 * (lane & 1) + 1, g.pack_F - 1);
+                    const int64_t q0 = g.pack_pos[prw * g.pack_F + fa0], q1 = g.pack_pos[prw * g.pack_F + fa1];
+                    const float dlr = g.pack_dl[rw0 + l31];
+                    pk_pos[(lane >> 1) * 4 + 2 * (lane & 1)] = (int)q0 * 64;
+                    pk_pos[(lane >> 1) * 4 + 2 * (lane & 1) + 1] = (int)q1 * 64;
+                    if (hi == 0) pk_dl[l31] = dlr;
+                }
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    const int cg = cb0 + nt * 32;                                       // (uniform) first column of the block
+                    if (cg >= kemb) {
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) acc[ms][nt][reg] = 0.f;
+                        continue;
+                    }
+                    const int fi = nt >> 1, hb = nt & 1, dbase = 32 * hb;
+                    float4 xv[4], sxv[4];
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int64_t row = rw0 + 8 * it + prow;
+                        xv[it] = *reinterpret_cast<const float4*>(g.xin + row * g.ldx + cg + pd4);
+                        sxv[it] = *reinterpret_cast<const float4*>(g.pack_sumx + row * 64 + dbase + pd4);
+                    }
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        stg[((reg & 3) + 8 * (reg >> 2) + 4 * hi) * PK_PITCH + l31] = acc[ms][nt][reg] * h2_out;
+                        acc[ms][nt][reg] = 0.f;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // (one wave, in-order LDS: written before it is read)
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        float4 v = *reinterpret_cast<const float4*>(stg + (8 * it + prow) * PK_PITCH + pd4);
+                        const int pp = pk_pos[(8 * it + prow) * 4 + fi];
+                        const float dl = pk_dl[8 * it + prow];
+                        v.x += dl * (sxv[it].x - xv[it].x); v.y += dl * (sxv[it].y - xv[it].y);
+                        v.z += dl * (sxv[it].z - xv[it].z); v.w += dl * (sxv[it].w - xv[it].w);
+                        *reinterpret_cast<float4*>(g.C + pp + dbase + pd4) = v;
+                        if (hb == 0 && g.pack_lin != nullptr) g.pack_lin[pp >> 6] = dl;            // (uniform condition; 8 lanes, one address, one value)
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // the block's reads retired before the next block's writes
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             } else if constexpr (EPI == 5) {
                 // Every load unconditional (clamped).  The stores are under WAVE-UNIFORM conditions only: a 32-column group lies inside
@@ -2318,7 +2384,12 @@ int rs_launch(const RsArgs& g, hipStream_t stream) {
     static const bool stg = [] { const char* e = getenv("DR_BF3_STAGGER"); return e != nullptr && e[0] == '1'; }();
     if (g.mask != nullptr && g.accumulate) return DR_EINVAL;            // (no caller needs both)
     if (g.a_amax != nullptr) {                                          // f16x2 operand mode
-        if (g.b_amax == nullptr || g.pack_pos != nullptr) return DR_EINVAL;
+        if (g.b_amax == nullptr) return DR_EINVAL;
+        if (g.pack_pos != nullptr) {
+            hipLaunchKernelGGL((bf3_gemm_rs_kernel<5, 0, 1, 1, 1>), dim3(grid), dim3(512), 0, stream, g);
+            DR_CHECK_LAUNCH();
+            return DR_OK;
+        }
         if (g.c_amax != nullptr && hipMemsetAsync(g.c_amax, 0, sizeof(uint32_t), stream) != hipSuccess) return DR_ELAUNCH;
         if (g.tau != nullptr) {
             // the scan's reduction is short (K = the embedding width): resident activations (AR, see the kernel) when K is 128 or 64
@@ -2656,6 +2727,35 @@ extern "C" int dr_bf3_linear_nt_pack(const float* dy, int64_t ld_dy, const void*
     if (sum_x != nullptr && (x == nullptr || ld_x < (int64_t)F * 64)) return DR_EINVAL;
     RsArgs g{dy, ld_dy, static_cast<const __bf16*>(w_planes), plane_stride, b_ld, M, N, K, out_rows, 0, nullptr, 0, nullptr, 0, 0,
              nullptr, x, ld_x, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, 0, pos, F, d_fm_logit, sum_x, out_lin};
+    const int rc = rs_launch(g, dr_s(stream));
+    if (rc != DR_OK) return rc;
+    if (bias_sum != nullptr) {
+        hipLaunchKernelGGL(bf3_pack_bias_kernel, dim3(1), dim3(256), 0, dr_s(stream), d_fm_logit, M, bias_sum);
+        DR_CHECK_LAUNCH();
+    }
+    return DR_OK;
+}
+
+// dr_bf3_linear_nt_pack in the f16x2 operand mode: dy with its amax record, the weights as two fp16 planes with theirs (dr_h2_split).
+// x / ld_x: the concatenated embeddings of the forward, rows 16-byte aligned (ld_x % 4 == 0); sum_x rows are 64 floats.
+extern "C" int dr_h2_linear_nt_pack(const float* dy, int64_t ld_dy, const uint32_t* dy_amax, const void* w_planes, int64_t plane_stride,
+                                    int64_t b_ld, const uint32_t* w_amax, int64_t M, int32_t N, int32_t K, const int64_t* pos, int32_t F,
+                                    const float* d_fm_logit, const float* sum_x, const float* x, int64_t ld_x, float* out_rows,
+                                    float* out_lin, float* bias_sum, dr_stream_t stream) {
+    if (M < 0 || N <= 0 || K <= 0 || F <= 0 || (int64_t)F * 64 > N) return DR_EINVAL;
+    if (M == 0) return DR_OK;
+    if (!dy || !dy_amax || !w_amax || !pos || !d_fm_logit || !out_rows || !planes_ok(w_planes, plane_stride, b_ld)) return DR_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(dy) & 15) != 0 || (ld_dy & 3) != 0 || ld_dy < K || b_ld < (K + BK - 1) / BK * BK) return DR_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(out_rows) & 15) != 0) return DR_EINVAL;
+    if (!sum_x || !x || ld_x < (int64_t)F * 64 || (ld_x & 3) != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0 ||
+        (reinterpret_cast<uintptr_t>(sum_x) & 15) != 0)
+        return DR_EINVAL;
+    // the epilogue's domain (see there): interior row tiles only, destinations in 32 bits.  Outside it the caller runs
+    // dr_h2_linear_nt + dr_emb_pack_grads.
+    if ((M % 256) != 0 || M * (int64_t)F >= ((int64_t)1 << 25)) return DR_ESHAPE;
+    RsArgs g{dy, ld_dy, static_cast<const __bf16*>(w_planes), plane_stride, b_ld, M, N, K, out_rows, 0, nullptr, 0, nullptr, 0, 0,
+             nullptr, x, ld_x, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, 0, pos, F, d_fm_logit, sum_x, out_lin, dy_amax, w_amax,
+             nullptr};
     const int rc = rs_launch(g, dr_s(stream));
     if (rc != DR_OK) return rc;
     if (bias_sum != nullptr) {

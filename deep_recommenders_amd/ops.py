@@ -1074,6 +1074,19 @@ def bf3_linear_nt_pack(dy, w: Planes, pos, d_fm_logit, out_rows, out_lin=None, b
     return out_rows
 
 
+def h2_linear_nt_pack(dy, dy_amax, w: "H2Planes", pos, d_fm_logit, out_rows, out_lin=None, bias_sum=None, sum_x=None, x=None):
+    """bf3_linear_nt_pack in the f16x2 operand mode (dr_h2_linear_nt_pack): dy with its amax record, w the layer's W as H2Planes."""
+    dy = _rowmajor_ld4(dy)
+    M, K = dy.shape
+    pos = _c(pos, torch.int64)
+    F = pos.shape[1]
+    assert w.cols == K and w.rows >= 64 * F and out_rows.is_contiguous() and out_rows.shape[1] == 64
+    check(lib().dr_h2_linear_nt_pack(ptr(dy), dy.stride(0), ptr(dy_amax), ptr(w.buf), w.plane_stride, w.ld, ptr(w.amax), M, w.rows, K,
+                                     ptr(pos), F, ptr(d_fm_logit), ptr(sum_x), ptr(x), x.stride(0) if x is not None else 0,
+                                     ptr(out_rows), ptr(out_lin), ptr(bias_sum), stream_ptr()), "dr_h2_linear_nt_pack")
+    return out_rows
+
+
 def bf3_cross_fwd(x0, x, wt: Planes, b=None, diag_scale=0.0, want_prod=False, prod=None):
     """DCN cross layer on pre-split weights (wt = W^T planes): out = x0 * (x @ W + b + diag * x) + x; (out, prod) as cross_fwd."""
     M, Dm = x.shape

@@ -479,6 +479,9 @@ class _NullCtx:
         return False
 
 
+_FUSE_PACK_DEFAULT = "1"      # DR_FUSE_PACK's default: on since round 5 (f16x2 epilogue through the LDS: world-1 step 1.62 -> 1.55 ms, profiles/r05_sharded_fuse_pack.log)
+
+
 class ShardedDeepFMEngine:
     """DeepFM training step with row-sharded tables; same model / loss / fused SGD as engine.DeepFMEngine.
     `batch` is the per-rank batch; the loss is the mean over the global batch (world * batch)."""
@@ -619,11 +622,12 @@ class ShardedDeepFMEngine:
         self.fuse_k3 = (use_planes and _os.environ.get("DR_FUSE_K3", "1") == "1" and D == 64 and self.Nd <= 32
                         and self.wplanes[0] is not None and B * F <= (1 << 24) and self.acts[0] in (0, 1))
         self.dense_pad = torch.zeros((B, 32), **f32) if (self.fuse_k3 and self.Nd) else None
-        # first-layer dgrad and the gradient pack in one launch (dr_bf3_linear_nt_pack): d_concat is never written.  Needs the
-        # layer's weight planes, D == 64 and single-valued fields (one slot per (example, field)).  OFF unless DR_FUSE_PACK=1:
-        # measured slower (400 us against 173 + 143 per half batch -- the MFMA accumulator layout gives a lane one column of
-        # 16 rows, so the epilogue scatters with 4-byte stores and loads where the pack kernel moves float4s).
-        self.fuse_pack = (use_planes and _os.environ.get("DR_FUSE_PACK", "0") == "1" and D == 64 and num_fields <= 64
+        # first-layer dgrad and the gradient pack in one launch (dr_h2_linear_nt_pack / dr_bf3_linear_nt_pack): d_concat is never
+        # written (- 0.44 GB written, - 0.44 GB read per 65 536 examples).  Needs the layer's weight planes, D == 64 and single-valued
+        # fields (one slot per (example, field)).  Round 4's epilogue (bf16x3: 4-byte scattered stores, a lane owning one column of
+        # 16 rows) lost to dgrad + pack (400 us against 173 + 143 per half batch); round 5's, in the f16x2 split, turns each
+        # accumulator block through the LDS and moves float4s with 8 lanes on a row.  DR_FUSE_PACK=0 / 1 (default: see _fuse_pack_default).
+        self.fuse_pack = (use_planes and _os.environ.get("DR_FUSE_PACK", _FUSE_PACK_DEFAULT) == "1" and D == 64 and num_fields <= 64
                           and not self.ex.dedup)
         # streams for the later micro-batches' fused first layers (see train_step); DR_FWD_STREAMS=0: all on the training stream
         self.fwd_streams = ([torch.cuda.Stream(device=device) for _ in range(max(0, min(mb - 1, 3)))]
@@ -633,8 +637,7 @@ class ShardedDeepFMEngine:
         # its own shard (K4 raises it) and, with real peers, one 4-byte all-reduce(MAX) behind the step's last owner-side update makes
         # it the bound for the rows any rank may receive in the next step (on the communication stream, long before those rows
         # arrive).  d h0's record comes out of the narrow backward per micro-batch.  DR_GEMM_SPLIT=bf16x3: the six-product mode.
-        self.h2 = (self.fuse_k3 and not self.fuse_pack and ops.get_gemm_split() == "f16x2"
-                   and not (self.fuse_head and nl - 2 == 0))
+        self.h2 = (self.fuse_k3 and ops.get_gemm_split() == "f16x2" and not (self.fuse_head and nl - 2 == 0))
         if self.h2:
             self.wplanes[0] = ops.H2WeightPlanes(self.Ws[0])
             self.tab_amax_local = ops.h2_amax(self.table)
@@ -1016,7 +1019,8 @@ class ShardedDeepFMEngine:
             if tail_done:
                 top = n_layers - 3
                 dy = self.dhs[n_layers - 3][sl]
-            fuse_pack = self.fuse_pack and self.wplanes[0] is not None and not self.narrow[0] and top >= 0
+            fuse_pack = (self.fuse_pack and self.wplanes[0] is not None and not self.narrow[0] and top >= 0
+                         and (not h2 or (Bm % 256 == 0 and Bm * F < (1 << 25))))
             for i in range(top, -1, -1):
                 if i > 0:
                     dx = self.dhs[i - 1][sl]
@@ -1027,10 +1031,18 @@ class ShardedDeepFMEngine:
                 if i == 0 and fuse_pack:
                     # the gradient of every slot straight into the send layout (dgrad epilogue = dr_emb_pack_grads)
                     g_rows, g_lin = self.ex.pack_buffers(routes[m])
-                    self._k("linear_bwd_dx_L0", "mfma", 2.0 * Bm * self.Ws[0].shape[0] * self.Ws[0].shape[1],
-                            lambda dy=dy, sl=sl, m=m, g_rows=g_rows, g_lin=g_lin: ops.bf3_linear_nt_pack(
-                                dy, self.wplanes[0].w, routes[m].pos, self.d_logit[sl], g_rows, g_lin, self.g_lin_bias,
-                                sum_x=self.sum_x[sl], x=self.concat[sl]))
+                    if h2:
+                        if not (n_layers > 1 and self.narrow[1]):
+                            ops.h2_amax(dy, self.dh0_amax[m])        # (layer 1's backward was not the narrow kernel that leaves the record)
+                        self._k("linear_bwd_dx_L0", "mfma", 2.0 * Bm * self.Ws[0].shape[0] * self.Ws[0].shape[1],
+                                lambda dy=dy, sl=sl, m=m, g_rows=g_rows, g_lin=g_lin: ops.h2_linear_nt_pack(
+                                    dy, self.dh0_amax[m], self.wplanes[0].w, routes[m].pos, self.d_logit[sl], g_rows, g_lin, self.g_lin_bias,
+                                    sum_x=self.sum_x[sl], x=self.concat[sl]))
+                    else:
+                        self._k("linear_bwd_dx_L0", "mfma", 2.0 * Bm * self.Ws[0].shape[0] * self.Ws[0].shape[1],
+                                lambda dy=dy, sl=sl, m=m, g_rows=g_rows, g_lin=g_lin: ops.bf3_linear_nt_pack(
+                                    dy, self.wplanes[0].w, routes[m].pos, self.d_logit[sl], g_rows, g_lin, self.g_lin_bias,
+                                    sum_x=self.sum_x[sl], x=self.concat[sl]))
                     if m == 0:
                         dw_todo.append(i)
                     continue

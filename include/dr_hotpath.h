@@ -670,6 +670,14 @@ int dr_bf3_linear_nt(const float* A, int64_t lda, const void* b_planes, int64_t 
 int dr_bf3_linear_nt_pack(const float* dy, int64_t ld_dy, const void* w_planes, int64_t plane_stride, int64_t b_ld, int64_t M,
                           int32_t N, int32_t K, const int64_t* pos, int32_t F, const float* d_fm_logit, const float* sum_x,
                           const float* x, int64_t ld_x, float* out_rows, float* out_lin, float* bias_sum, dr_stream_t stream);
+/* The same in the f16x2 operand mode (round 5): dy with its amax record, W as two fp16 planes (dr_h2_split) with theirs.  The epilogue
+ * stages each 32 x 32 accumulator block through the LDS and moves float4s with 8 lanes per row: a row's 32 columns of a field are one
+ * 128-byte line of its destination row and of the x row it reads.  x, sum_x (both required), out_rows 16-byte aligned, ld_x % 4 == 0.
+ * Domain: M a multiple of 256 and M * F < 2^25; outside it DR_ESHAPE (the caller runs dr_h2_linear_nt + dr_emb_pack_grads). */
+int dr_h2_linear_nt_pack(const float* dy, int64_t ld_dy, const uint32_t* dy_amax, const void* w_planes, int64_t plane_stride,
+                         int64_t b_ld, const uint32_t* w_amax, int64_t M, int32_t N, int32_t K, const int64_t* pos, int32_t F,
+                         const float* d_fm_logit, const float* sum_x, const float* x, int64_t ld_x, float* out_rows,
+                         float* out_lin, float* bias_sum, dr_stream_t stream);
 /* DCN cross layer forward (dr_cross_fwd's math, keras/models/ranking/dcn.py:81-88) on pre-split weights: wt_planes = W^T as
  * planes [3][Dm][ld_planes] (dr_bf3_split with transpose = 1).  x0, x, out, prod_out share leading dimension ld. */
 int dr_bf3_cross_fwd(const float* x0, const float* x, int64_t ld, const void* wt_planes, int64_t plane_stride,

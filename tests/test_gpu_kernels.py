@@ -1073,6 +1073,43 @@ def test_bf3_linear_nt_pack_equals_dgrad_then_pack(M, F, Nd, K, fm):
         assert torch.equal(rows1, rows0)
 
 
+@pytest.mark.parametrize("M,F,Nd,K", [(1024, 26, 13, 256), (512, 3, 0, 64), (2048, 7, 5, 32)])
+def test_h2_linear_nt_pack_equals_dgrad_then_pack(M, F, Nd, K):
+    """dr_h2_linear_nt_pack (round 5: the first-layer dgrad in the f16x2 split with the gradient pack as its epilogue -- accumulator
+    blocks turned through the LDS, float4 moves) == dr_h2_linear_nt followed by dr_emb_pack_grads: every slot's gradient row at its
+    permuted destination, the first-order copies, the bias sum.  Same accumulators, same FM expression up to the one fused
+    multiply-add the compiler may form differently.  Outside the epilogue's domain (M not a multiple of 256) the entry point says
+    DR_ESHAPE and the caller keeps the two launches."""
+    from deep_recommenders_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + F)
+    N = 64 * F + Nd
+    dy = torch.randn((M, K), device="cuda", generator=g) * 1e-2
+    W = torch.randn((N, K), device="cuda", generator=g) * 0.1          # first layer [in = N, out = K]
+    wp = ops.H2WeightPlanes(W)
+    dy_amax = ops.h2_amax(dy)
+    pos = torch.randperm(M * F, device="cuda", generator=g).reshape(M, F)
+    dl = torch.randn((M,), device="cuda", generator=g)
+    ldc = (N + 3) // 4 * 4
+    concat = torch.randn((M, ldc), device="cuda", generator=g)
+    sum_x = concat[:, :64 * F].reshape(M, F, 64).sum(1).contiguous()
+    d_concat = torch.zeros((M, ldc), device="cuda")
+    ops.h2_linear_nt(dy, dy_amax, wp.w, out=d_concat[:, :N])
+    rows0 = torch.full((M * F, 64), float("nan"), device="cuda")
+    lin0 = torch.full((M * F,), float("nan"), device="cuda")
+    b0 = torch.zeros(1, device="cuda")
+    ops.emb_pack_grads(pos, 64, d_concat, concat, sum_x, dl, rows0, lin0, b0)
+    rows1 = torch.full((M * F, 64), float("nan"), device="cuda")
+    lin1 = torch.full((M * F,), float("nan"), device="cuda")
+    b1 = torch.zeros(1, device="cuda")
+    ops.h2_linear_nt_pack(dy, dy_amax, wp.w, pos, dl, rows1, lin1, b1, sum_x=sum_x, x=concat)
+    assert not torch.isnan(rows1).any() and not torch.isnan(lin1).any()          # a permutation: every destination written
+    assert torch.equal(lin1, lin0) and torch.equal(b1, b0)
+    scale = (rows0.abs().max().item() + 1e-30)
+    assert (rows1 - rows0).abs().max().item() <= 2e-7 * scale + 1e-7 * (dl.abs().max().item() * concat.abs().max().item())
+    with pytest.raises(RuntimeError, match="DR_ESHAPE"):
+        ops.h2_linear_nt_pack(dy[:100], dy_amax, wp.w, pos[:100], dl[:100], rows1, lin1, b1, sum_x=sum_x[:100], x=concat[:100])
+
+
 _RS64_SNIPPET = r"""
 import hashlib, sys, torch
 sys.path.insert(0, %r)

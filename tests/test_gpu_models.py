@@ -898,6 +898,50 @@ def test_sharded_engine_through_the_cabi_exchange_library():
         tr.close()
 
 
+@pytest.mark.parametrize("split", ["f16x2", "bf16x3"])
+def test_sharded_engine_fused_pack_tracks_the_two_launch_pack(split, monkeypatch):
+    """DR_FUSE_PACK (default on since round 5: the first-layer dgrad writes every slot's gradient row straight into the send layout,
+    dr_h2_linear_nt_pack / dr_bf3_linear_nt_pack) against the dgrad + dr_emb_pack_grads pair, at a shape that takes the fused path
+    (D = 64, micro-batches of 2048 rows, DNN [256, 32]): same losses, same tables / weights after three steps up to the one fused
+    multiply-add of the FM term -- and both equal the unsharded engine."""
+    from deep_recommenders_amd import ops
+    from deep_recommenders_amd.engine import DeepFMEngine
+    from deep_recommenders_amd.sharded import ShardedDeepFMEngine
+    F, V, D, B, Nd = 5, 3000, 64, 4096, 3                     # (the wide-GEMM planes want micro-batches of >= 2048 rows)
+    prev = ops.set_gemm_split(split)
+    try:
+        ref = DeepFMEngine(F, V, D, [256, 32], B, num_dense=Nd, lr=0.05, seed=9, lin_init_std=0.1)
+        engs = {}
+        for fp in ("1", "0"):
+            monkeypatch.setenv("DR_FUSE_PACK", fp)
+            e = ShardedDeepFMEngine(F, V, D, [256, 32], B, num_dense=Nd, lr=0.05, device="cuda", world=1, rank=0, seed=9,
+                                    init_tables=(ref.table.clone(), ref.lin_w.clone()))
+            assert e.mb == 2 and e.fuse_pack == (fp == "1") and e.h2 == (split == "f16x2")
+            for a, b in zip(e.Ws, ref.Ws):
+                a.copy_(b)
+            engs[fp] = e
+        g = torch.Generator(device="cuda")
+        g.manual_seed(2)
+        batches = [(torch.randint(0, 10**14, (B, F), device="cuda", generator=g), torch.rand((B, Nd), device="cuda", generator=g),
+                    (torch.rand(B, device="cuda", generator=g) < 0.25).float()) for _ in range(3)]
+        for t, (keys, dense, labels) in enumerate(batches):
+            nk = batches[t + 1][0] if t + 1 < len(batches) else None
+            l_ref = ref.train_step(keys, dense, labels).item()
+            l1 = engs["1"].train_step(keys, dense, labels, next_keys=nk).item()
+            l0 = engs["0"].train_step(keys, dense, labels, next_keys=nk).item()
+            assert abs(l1 - l0) <= 1e-6 * abs(l0) and abs(l1 - l_ref) <= 2e-6 * abs(l_ref), (l1, l0, l_ref)
+        torch.cuda.synchronize()
+        for name in ("table", "lin_w"):
+            a, b, r = (getattr(e, name).cpu().numpy() for e in (engs["1"], engs["0"], ref))
+            np.testing.assert_allclose(a, b, rtol=2e-6, atol=2e-7, err_msg=name)
+            np.testing.assert_allclose(a, r, rtol=2e-5, atol=2e-6, err_msg=name)
+        for a, b, r in zip(engs["1"].Ws, engs["0"].Ws, ref.Ws):
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-6, atol=2e-7)
+            np.testing.assert_allclose(a.cpu().numpy(), r.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    finally:
+        ops.set_gemm_split(prev)
+
+
 def test_engine_picks_up_weights_written_from_outside():
     """The wide layers' forward / dgrad read bf16 PLANES of the weights, refreshed by the engine after its own updates.  A write to
     eng.Ws from outside (checkpoint restore, copy_) must reach them too: two engines, one constructed with the
