@@ -115,6 +115,7 @@ SIGNATURES = {
     "dr_bf3_gemm_tn": [_p, _i64, _i64, _p, _i64, _i64, _i64, _i32, _i32, _f32, _p, _i64, _p, _p, _p, _i64, _p],
     "dr_h2_amax": [_p, _i64, _i64, _i32, _p, _i32, _p],
     "dr_h2_split": [_p, _i64, _i64, _i32, _p, _i64, _i64, _i64, _i64, _i32, _p, _p],
+    "dr_h2_refresh_weight": [_p, _i64, _i64, _i32, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _p],
     "dr_h2_linear_nt": [_p, _i64, _p, _p, _i64, _i64, _p, _i64, _i32, _i32, _p, _i32, _p, _i64, _i32, _p, _i64, _p, _p],
     "dr_h2_cross_fwd": [_p, _p, _i64, _p, _p, _i64, _i64, _p, _p, _f32, _i64, _i32, _p, _p, _p, _p],
     "dr_cross_combine_bwd_amax": [_p, _p, _p, _i64, _i32, _i64, _f32, _p, _p, _p, _p, _p],

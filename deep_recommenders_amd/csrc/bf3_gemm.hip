@@ -2362,6 +2362,57 @@ __global__ __launch_bounds__(256) void h2_split_kernel(const float* __restrict__
     }
 }
 
+// ---- a weight's record and BOTH of its plane images in two launches (dr_h2_refresh_weight, round 5) -----------------------------------
+// dr_h2_amax + two dr_h2_split are four launches (a 4-byte memset, the atomicMax pass, two splits); in the sharded engine they sit on
+// the serial chain between the wgrad and the next forward, where each small launch waits its turn among the exchange's HBM-bound
+// kernels (rocprofv3: memset 47 us, amax 30, splits 16 + 6).  Here: per-block maxima with plain stores, then ONE kernel that reduces
+// them in every block (256 values), stores the record from block 0 and writes both orientations.  Same record, same planes.
+constexpr int H2_REFRESH_PARTS = 256;
+__global__ __launch_bounds__(256) void h2_amax_parts_kernel(const float* __restrict__ src, int64_t ld, int64_t R, int32_t C,
+                                                            uint32_t* __restrict__ parts) {
+    uint32_t m = 0u;
+    const int64_t total = R * (int64_t)C, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t r = i / C;
+        m = max(m, __float_as_uint(fabsf(src[r * ld + (i - r * C)])));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    __shared__ uint32_t wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) parts[blockIdx.x] = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+}
+__global__ __launch_bounds__(256) void h2_split_both_kernel(const float* __restrict__ src, int64_t ld, int64_t R, int32_t C,
+                                                            _Float16* __restrict__ w, int64_t w_ps, int64_t w_ld,
+                                                            _Float16* __restrict__ wt, int64_t wt_ps, int64_t wt_ld,
+                                                            const uint32_t* __restrict__ parts, int32_t nparts, uint32_t* __restrict__ amax) {
+    uint32_t m = (int)threadIdx.x < nparts ? parts[threadIdx.x] : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    __shared__ uint32_t wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+    if (blockIdx.x == 0 && threadIdx.x == 0) amax[0] = m;               // the record the GEMMs read (they run behind this kernel)
+    float sc, inv;
+    h2_scale_of(m, sc, inv);
+    h2_mode_on();
+    const int64_t total = R * (int64_t)C, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * total; i += stride) {
+        // consecutive threads: consecutive DESTINATION elements, first of the plain image, then of the transposed one
+        int64_t r, c, off;
+        _Float16* dst;
+        int64_t ps;
+        if (i < total) { r = i / C; c = i - r * C; off = r * w_ld + c; dst = w; ps = w_ps; }
+        else { const int64_t j = i - total; c = j / R; r = j - c * R; off = c * wt_ld + r; dst = wt; ps = wt_ps; }
+        const float v = src[r * ld + c] * sc;
+        const _Float16 h = (_Float16)v;
+        dst[off] = h;
+        dst[ps + off] = (_Float16)(v - (float)h);
+    }
+}
+
 // planes -> fp32 (tests, debugging): dst[r][c] = (p2 + p1) + p0
 __global__ __launch_bounds__(256) void bf3_join_kernel(const __bf16* __restrict__ planes, int64_t ps, int64_t ldp, int64_t R,
                                                        int32_t C, float* __restrict__ dst, int64_t ld_dst) {
@@ -2647,6 +2698,21 @@ extern "C" int dr_h2_split(const float* src, int64_t ld_src, int64_t R, int32_t 
     if (transpose && col_offset + R > ld_planes) return DR_EINVAL;
     hipLaunchKernelGGL(h2_split_kernel, dim3(dr_grid_for(R * (int64_t)C, 256)), dim3(256), 0, dr_s(stream), src, ld_src, R, C,
                        static_cast<_Float16*>(planes), plane_stride, ld_planes, row_offset, col_offset, transpose, amax);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
+// A weight W [K, N] (row stride ldw): its amax record, its planes [2][K][w_ld] and the planes of its transpose [2][N][wt_ld] -- what
+// dr_h2_amax(reset) + dr_h2_split + dr_h2_split(transpose) produce, in two launches without a memset or an atomic.  parts: 256 uint32 of scratch.
+extern "C" int dr_h2_refresh_weight(const float* W, int64_t ldw, int64_t K, int32_t N, void* w_planes, int64_t w_ps, int64_t w_ld,
+                                    void* wt_planes, int64_t wt_ps, int64_t wt_ld, uint32_t* amax, uint32_t* parts, dr_stream_t stream) {
+    if (K <= 0 || N <= 0 || ldw < N || !W || !w_planes || !wt_planes || !amax || !parts) return DR_EINVAL;
+    if (w_ld < N || wt_ld < K || w_ps <= 0 || wt_ps <= 0) return DR_EINVAL;
+    const int64_t total = K * (int64_t)N;
+    const int np = (int)(total < (int64_t)H2_REFRESH_PARTS * 256 ? (total + 255) / 256 : H2_REFRESH_PARTS);
+    hipLaunchKernelGGL(h2_amax_parts_kernel, dim3(np), dim3(256), 0, dr_s(stream), W, ldw, K, N, parts);
+    hipLaunchKernelGGL(h2_split_both_kernel, dim3(dr_grid_for(2 * total, 256, 2048)), dim3(256), 0, dr_s(stream), W, ldw, K, N,
+                       static_cast<_Float16*>(w_planes), w_ps, w_ld, static_cast<_Float16*>(wt_planes), wt_ps, wt_ld, parts, np, amax);
     DR_CHECK_LAUNCH();
     return DR_OK;
 }

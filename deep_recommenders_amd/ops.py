@@ -1321,12 +1321,18 @@ class H2WeightPlanes:
         self.amax = h2_record(W.device)
         self.wt = H2Planes(N, K, W.device, self.amax)
         self.w = H2Planes(K, N, W.device, self.amax)
+        self._parts = None
         self.refresh()
 
     def refresh(self):
-        h2_amax(self.W, self.amax, reset=True)
-        h2_split(self.W, self.wt, transpose=True)
-        h2_split(self.W, self.w)
+        # record + both images in two launches (dr_h2_refresh_weight: no memset, no atomic pass; same record, same planes as
+        # dr_h2_amax + two dr_h2_split)
+        if self._parts is None:
+            self._parts = torch.zeros(256, dtype=torch.int32, device=self.W.device)
+        K, N = self.W.shape
+        check(lib().dr_h2_refresh_weight(ptr(self.W), self.W.stride(0), K, N, ptr(self.w.buf), self.w.plane_stride, self.w.ld,
+                                         ptr(self.wt.buf), self.wt.plane_stride, self.wt.ld, ptr(self.amax), ptr(self._parts),
+                                         stream_ptr()), "dr_h2_refresh_weight")
         self._ver = self.W._version
 
     def ensure_fresh(self):

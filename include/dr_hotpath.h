@@ -748,6 +748,12 @@ int dr_h2_amax(const float* src, int64_t ld, int64_t R, int32_t C, uint32_t* ama
 /* two fp16 planes of src * s(amax), laid out like dr_bf3_split's three (same arguments) */
 int dr_h2_split(const float* src, int64_t ld_src, int64_t R, int32_t C, void* planes, int64_t plane_stride, int64_t ld_planes,
                 int64_t row_offset, int64_t col_offset, int32_t transpose, const uint32_t* amax, dr_stream_t stream);
+/* A weight's record and BOTH of its plane images in two launches (round 5): what dr_h2_amax(reset = 1) + dr_h2_split +
+ * dr_h2_split(transpose = 1) produce -- same record, same planes -- without the 4-byte memset and the atomic pass (four small launches on
+ * the serial chain between a wgrad and the next forward).  W [K, N] with row stride ldw; w_planes [2][K][w_ld], wt_planes [2][N][wt_ld];
+ * parts: 256 uint32 of scratch. */
+int dr_h2_refresh_weight(const float* W, int64_t ldw, int64_t K, int32_t N, void* w_planes, int64_t w_plane_stride, int64_t w_ld,
+                         void* wt_planes, int64_t wt_plane_stride, int64_t wt_ld, uint32_t* amax, uint32_t* parts, dr_stream_t stream);
 int dr_h2_linear_nt(const float* A, int64_t lda, const uint32_t* a_amax, const void* b_planes, int64_t b_plane_stride, int64_t b_ld,
                     const uint32_t* b_amax, int64_t M, int32_t N, int32_t K, const float* bias, int32_t act, const float* mask,
                     int64_t ld_mask, int32_t accumulate, float* C, int64_t ldc, uint32_t* c_amax, dr_stream_t stream);

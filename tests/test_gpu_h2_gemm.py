@@ -433,3 +433,23 @@ def test_gemm_split_switch_is_the_librarys_and_is_read_where_documented(monkeypa
         assert not torch.equal(s_h2, s_b3), "the scan did not change its product mode with the switch"
         assert (s_h2 - s_b3).abs().max().item() <= 1e-5 * s_b3.abs().max().item()
     assert o.get_gemm_split() == start
+
+
+@pytest.mark.parametrize("K,N,ld", [(1677, 256, 256), (1677, 1677, 1680), (300, 40, 44), (32, 32, 32)])
+def test_refresh_weight_equals_amax_then_two_splits(K, N, ld):
+    """dr_h2_refresh_weight (H2WeightPlanes.refresh since round 5: per-block maxima with plain stores, then one kernel that reduces
+    them, stores the record and writes both orientations) == dr_h2_amax(reset) + dr_h2_split + dr_h2_split(transpose): the same
+    record and the same planes, bit for bit -- also after the weight moved (a second refresh must not see anything of the first)."""
+    from deep_recommenders_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(K + N)
+    W = (torch.randn((K, ld), device="cuda", generator=g) * 0.3)[:, :N]
+    wp = ops.H2WeightPlanes(W)
+    for rep in range(2):
+        rec = ops.h2_amax(W)
+        wt = ops.h2_split(W, ops.H2Planes(N, K, W.device, rec), transpose=True)
+        w = ops.h2_split(W, ops.H2Planes(K, N, W.device, rec))
+        assert torch.equal(wp.amax, rec), (ops.h2_amax_value(wp.amax), ops.h2_amax_value(rec))
+        assert torch.equal(wp.w.buf, w.buf) and torch.equal(wp.wt.buf, wt.buf)
+        W.mul_(0.01 if rep == 0 else 1.0)                 # the largest magnitude SHRINKS: a stale record would show
+        W[K // 2, N // 3] = 3.0
+        wp.ensure_fresh()
