@@ -7,4 +7,12 @@ Package layout mirrors the reference's import paths for the hot-path classes onl
     deep_recommenders_amd.feature_column           the slice of tf.feature_column those classes consume
 All arithmetic runs in hand-written gfx950 kernels behind the C-ABI of include/dr_hotpath.h.
 """
+import os as _os
+
+# HIP maps streams onto 4 hardware queues by default; the sharded engines drive 5+ streams (training, routing, exchange, the later
+# micro-batches' forwards, RCCL's own) and two streams that share a queue run in line: 1.97 instead of 1.67 ms per step at world 1
+# (profiles/r05_sharded_step_boundary.log).  Read when the HIP runtime initialises, so it has to be in the environment before the first
+# device call; a value the user set wins.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 __version__ = "0.1.0"
