@@ -76,6 +76,7 @@ SIGNATURES = {
     "dr_inbatch_softmax_workspace_bytes": [_i64],
     "dr_inbatch_softmax_fwd": [_p, _p, _i64, _i32, _p, _p, _p, _f32, _p, _p, _p, _p, _i64, _p],
     "dr_inbatch_softmax_grad_scores": [_p, _p, _i64, _i32, _p, _p, _p, _f32, _p, _f32, _p, _i64, _p],
+    "dr_inbatch_softmax_grad_scores_ws": [_p, _p, _i64, _i32, _p, _p, _p, _f32, _p, _f32, _p, _i64, _p, _i64, _p],
     "dr_scores_nt": [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _i64, _p],
     "dr_topk_select": [_p, _i64, _i64, _i64, _i32, _i64, _i32, _p, _p, _p],
     "dr_topk_workspace_bytes": [_i64, _i64, _i32],

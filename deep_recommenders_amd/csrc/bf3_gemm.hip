@@ -541,6 +541,13 @@ struct RsArgs {
     // f16x2 mode (H2 kernels only): the amax records of A and of the tensor B's two planes were split from
     const uint32_t* a_amax; const uint32_t* b_amax;
     uint32_t* c_amax;                            // (H2, may be null) out: raised to max |value stored into C| -- the record of the NEXT GEMM's operand
+    // in-batch sampled softmax (keras/models/retrieval/sbcnm.py:120-151; H2 kernels only, round 5): the scores A B^T never leave the
+    // tile.  s_ij = (acc + (-log cand_prob[j]) [+ MIN_FLOAT where cand_ids[i] == cand_ids[j], i != j]) * inv_t
+    //   EPI 6: per (row, 256-column tile) the running max and sum-exp -> sm_part_m / sm_part_l [tile_n][M]; s_ii -> sm_pos[i]
+    //   EPI 7: C[i][j] = sm_w[i] * (exp(s_ij - sm_lse[i]) - delta_ij) * inv_t * sm_alpha      (the gradient wrt the raw scores)
+    const float* sm_cand_prob; const int64_t* sm_cand_ids; float sm_inv_t;
+    float* sm_part_m; float* sm_part_l; float* sm_pos;
+    const float* sm_lse; const float* sm_w; float sm_alpha;
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1051,6 +1058,79 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
                     for (int reg = 0; reg < 16; ++reg)
 #pragma unroll
                         for (int nt = 0; nt < NTW; ++nt) acc[ms][nt][reg] = 0.f;
+                }
+            } else if constexpr (EPI == 6 || EPI == 7) {
+                // in-batch softmax on the scores of this tile (see RsArgs).  Lane r < 16 of a half stands for row r of that half (its
+                // candidate id, lse, weight: one load each per tile, handed out by shuffles); a lane's 8 columns keep their
+                // correction and id in registers.
+                constexpr float MIN_FLOAT = -3.4028234663852886e36f;    // np.finfo(np.float32).min / 100 (sbcnm.py:10)
+                const bool ids_on = g.sm_cand_ids != nullptr;
+                const int64_t lrow = r0 + (l31 & 3) + 8 * ((l31 >> 2) & 3);
+                const int64_t lrc = lrow < g.M ? lrow : g.M - 1;
+                const int64_t rid_l = ids_on ? g.sm_cand_ids[lrc] : 0;
+                float lse_l = 0.f, w_l = 1.f;
+                if constexpr (EPI == 7) {
+                    lse_l = g.sm_lse[lrc];
+                    w_l = g.sm_w != nullptr ? g.sm_w[lrc] : 1.f;
+                }
+                float colcorr[NTW];
+                int64_t colid[NTW];
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    const int col = cb0 + nt * 32 + l31;
+                    const int cc = col < g.N ? col : g.N - 1;
+                    colcorr[nt] = g.sm_cand_prob != nullptr ? -logf(g.sm_cand_prob[cc]) : 0.f;
+                    colid[nt] = ids_on ? g.sm_cand_ids[cc] : 0;
+                }
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int64_t row = r0 + (reg & 3) + 8 * (reg >> 2);
+                    const bool rv = row < g.M;
+                    const int src = 32 * hi + reg;
+                    const int rlo = __shfl((int)(rid_l & 0xffffffffll), src, 64), rhi = __shfl((int)(rid_l >> 32), src, 64);
+                    const int64_t rid = ((int64_t)rhi << 32) | (uint32_t)rlo;
+                    float sv[NTW];
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt) {
+                        float v = fmaf(acc[ms][nt][reg], h2_out, colcorr[nt]);
+                        acc[ms][nt][reg] = 0.f;
+                        if (ids_on && rid == colid[nt] && row != cb0 + nt * 32 + l31) v += MIN_FLOAT;
+                        sv[nt] = v * g.sm_inv_t;
+                    }
+                    if constexpr (EPI == 6) {
+                        float m = -INFINITY;
+#pragma unroll
+                        for (int nt = 0; nt < NTW; ++nt)
+                            if (cb0 + nt * 32 + l31 < g.N) m = fmaxf(m, sv[nt]);
+#pragma unroll
+                        for (int o = 1; o < 32; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+                        float l = 0.f;
+#pragma unroll
+                        for (int nt = 0; nt < NTW; ++nt)
+                            if (cb0 + nt * 32 + l31 < g.N) l += (sv[nt] - m < -87.f ? 0.f : expf(sv[nt] - m));
+#pragma unroll
+                        for (int o = 1; o < 32; o <<= 1) l += __shfl_xor(l, o, 64);
+                        if (rv && l31 == 0) {
+                            const int64_t pc = tn0 / BN;
+                            g.sm_part_m[pc * g.M + row] = m;
+                            g.sm_part_l[pc * g.M + row] = l;
+                        }
+#pragma unroll
+                        for (int nt = 0; nt < NTW; ++nt)
+                            if (rv && row == cb0 + nt * 32 + l31) g.sm_pos[row] = sv[nt];
+                    } else {
+                        const float lse = __shfl(lse_l, src, 64), w = __shfl(w_l, src, 64);
+                        const float scale = w * g.sm_inv_t * g.sm_alpha;
+#pragma unroll
+                        for (int nt = 0; nt < NTW; ++nt) {
+                            const int col = cb0 + nt * 32 + l31;
+                            const float d = sv[nt] - lse;
+                            const float pr = (d < -87.f ? 0.f : expf(d)) - (row == col ? 1.f : 0.f);
+                            if (interior) g.C[row * g.ldc + col] = pr * scale;
+                            else if (rv && col < g.N) g.C[row * g.ldc + col] = pr * scale;
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);                  // one row at a time (hoisted, the exponentials' temporaries spill)
                 }
             } else if constexpr (EPI == 5 && H2 != 0) {
                 // The pack epilogue, second construction (round 5; the bf16x3 one below moves 4 bytes per lane and instruction and lost to
@@ -2441,7 +2521,14 @@ int rs_launch(const RsArgs& g, hipStream_t stream) {
             DR_CHECK_LAUNCH();
             return DR_OK;
         }
-        if (g.c_amax != nullptr && hipMemsetAsync(g.c_amax, 0, sizeof(uint32_t), stream) != hipSuccess) return DR_ELAUNCH;
+        if (g.sm_part_m != nullptr || g.sm_lse != nullptr) {
+            // in-batch softmax.  The streaming kernel: with the resident activations of AR = 4 the epilogue's per-column corrections and
+            // ids (24 registers) do not fit beside 64 resident operand registers (30 - 54 spilled, reloaded inside the step loop)
+            if (g.sm_part_m != nullptr) hipLaunchKernelGGL((bf3_gemm_rs_kernel<6, 0, 1, 1, 1>), dim3(grid), dim3(512), 0, stream, g);
+            else hipLaunchKernelGGL((bf3_gemm_rs_kernel<7, 0, 1, 1, 1>), dim3(grid), dim3(512), 0, stream, g);
+            DR_CHECK_LAUNCH();
+            return DR_OK;
+        }
         if (g.tau != nullptr) {
             // the scan's reduction is short (K = the embedding width): resident activations (AR, see the kernel) when K is 128 or 64
             // and the row tiles divide into the grid; DR_TOPK_RESIDENT=0: the streaming kernel (A/B, tools/exp/topk_xlane.sh)
@@ -2843,6 +2930,31 @@ int dr_bf3_scores_filter(const float* a, int64_t lda, const void* b_planes, int6
     if ((reinterpret_cast<uintptr_t>(a) & 15) != 0 || (lda & 3) != 0 || lda < K || b_ld < (K + BK - 1) / BK * BK) return DR_EINVAL;
     RsArgs g{a, lda, static_cast<const __bf16*>(b_planes), b_plane_stride, b_ld, M, N, K, nullptr, 0, nullptr, 0, nullptr, 0, 0,
              nullptr, nullptr, 0, 0.f, nullptr, tau, cand_s, cand_c, cand_cnt, cand_cap};
+    return rs_launch(g, dr_s(stream));
+}
+
+// internal (C++ linkage, used by dense.hip's dr_inbatch_softmax_*): the in-batch softmax's two score passes on the register-split
+// f16x2 kernel.  q [B, D] fp32 with its record, c as two fp16 planes [2][B][c_ld] with its record.
+int dr_h2_inbatch_lse(const float* q, int64_t ldq, const uint32_t* q_amax, const void* c_planes, int64_t c_ps, int64_t c_ld,
+                      const uint32_t* c_amax, int64_t B, int32_t D, const float* cand_prob, const int64_t* cand_ids, float inv_t,
+                      float* part_m, float* part_l, float* pos, dr_stream_t stream) {
+    if (B <= 0 || B > 0x7fffffff || !q || !q_amax || !c_amax || !part_m || !part_l || !pos || !planes_ok(c_planes, c_ps, c_ld)) return DR_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(q) & 15) != 0 || (ldq & 3) != 0 || ldq < D) return DR_EINVAL;
+    RsArgs g{};
+    g.A = q; g.lda = ldq; g.B = static_cast<const __bf16*>(c_planes); g.b_ps = c_ps; g.b_ld = c_ld; g.M = B; g.N = (int32_t)B; g.K = D;
+    g.a_amax = q_amax; g.b_amax = c_amax;
+    g.sm_cand_prob = cand_prob; g.sm_cand_ids = cand_ids; g.sm_inv_t = inv_t; g.sm_part_m = part_m; g.sm_part_l = part_l; g.sm_pos = pos;
+    return rs_launch(g, dr_s(stream));
+}
+int dr_h2_inbatch_smgrad(const float* q, int64_t ldq, const uint32_t* q_amax, const void* c_planes, int64_t c_ps, int64_t c_ld,
+                         const uint32_t* c_amax, int64_t B, int32_t D, const float* cand_prob, const int64_t* cand_ids, float inv_t,
+                         const float* row_lse, const float* sample_weight, float d_loss, float* G, int64_t ld_g, dr_stream_t stream) {
+    if (B <= 0 || B > 0x7fffffff || !q || !q_amax || !c_amax || !row_lse || !G || ld_g < B || !planes_ok(c_planes, c_ps, c_ld)) return DR_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(q) & 15) != 0 || (ldq & 3) != 0 || ldq < D) return DR_EINVAL;
+    RsArgs g{};
+    g.A = q; g.lda = ldq; g.B = static_cast<const __bf16*>(c_planes); g.b_ps = c_ps; g.b_ld = c_ld; g.M = B; g.N = (int32_t)B; g.K = D;
+    g.C = G; g.ldc = ld_g; g.a_amax = q_amax; g.b_amax = c_amax;
+    g.sm_cand_prob = cand_prob; g.sm_cand_ids = cand_ids; g.sm_inv_t = inv_t; g.sm_lse = row_lse; g.sm_w = sample_weight; g.sm_alpha = d_loss;
     return rs_launch(g, dr_s(stream));
 }
 

@@ -1289,6 +1289,9 @@ extern "C" int dr_cross_combine_bwd_amax(const float* x0, const float* prod, con
 }
 
 // ---- K9: in-batch sampled softmax (Retrieval.call, keras/models/retrieval/sbcnm.py:120-151 of the reference) ----------
+extern "C" int dr_inbatch_softmax_grad_scores(const float* q, const float* c, int64_t B, int32_t D, const float* cand_prob,
+                                              const int64_t* cand_ids, const float* sample_weight, float inv_temperature,
+                                              const float* row_lse, float d_loss, float* G, int64_t ld_g, dr_stream_t stream);
 __global__ __launch_bounds__(256) void lse_finalize_kernel(const float* __restrict__ part_m, const float* __restrict__ part_l,
                                                            int32_t nparts, int64_t B, const float* __restrict__ pos,
                                                            const float* __restrict__ w, float* __restrict__ row_lse,
@@ -1321,9 +1324,47 @@ __global__ __launch_bounds__(256) void sum_blocks_kernel(const float* __restrict
     if (threadIdx.x == 0) out[0] = (float)((red[0] + red[1]) + (red[2] + red[3]));
 }
 
-extern "C" int64_t dr_inbatch_softmax_workspace_bytes(int64_t B) {
+// f16x2 path of the two score passes (round 5): bf3_gemm.hip's register-split kernel with the LSE / softmax-gradient epilogues; the
+// candidates' two fp16 planes and both amax records live behind the partials in the workspace.
+int dr_h2_inbatch_lse(const float* q, int64_t ldq, const uint32_t* q_amax, const void* c_planes, int64_t c_ps, int64_t c_ld,
+                      const uint32_t* c_amax, int64_t B, int32_t D, const float* cand_prob, const int64_t* cand_ids, float inv_t,
+                      float* part_m, float* part_l, float* pos, dr_stream_t stream);
+int dr_h2_inbatch_smgrad(const float* q, int64_t ldq, const uint32_t* q_amax, const void* c_planes, int64_t c_ps, int64_t c_ld,
+                         const uint32_t* c_amax, int64_t B, int32_t D, const float* cand_prob, const int64_t* cand_ids, float inv_t,
+                         const float* row_lse, const float* sample_weight, float d_loss, float* G, int64_t ld_g, dr_stream_t stream);
+extern "C" int dr_h2_amax(const float* src, int64_t ld, int64_t R, int32_t C, uint32_t* amax, int32_t reset, dr_stream_t stream);
+extern "C" int dr_h2_split(const float* src, int64_t ld_src, int64_t R, int32_t C, void* planes, int64_t plane_stride, int64_t ld_planes,
+                           int64_t row_offset, int64_t col_offset, int32_t transpose, const uint32_t* amax, dr_stream_t stream);
+
+constexpr int IB_H2_MAX_D = 512;                        // the workspace is sized without knowing D: planes budgeted for D <= 512
+static int64_t ib_parts_floats(int64_t B) {
     const int64_t tiles_n = (B + BN - 1) / BN;
-    return (2 * tiles_n * 2 * B + 1024) * (int64_t)sizeof(float);
+    return 2 * tiles_n * 2 * B + 1024;
+}
+static int64_t ib_h2_offset_bytes(int64_t B) { return (ib_parts_floats(B) * 4 + 255) / 256 * 256; }
+static int64_t ib_h2_bytes(int64_t B) { return 256 + 2 * ((B + 31) / 32 * 32) * IB_H2_MAX_D * 2; }
+
+extern "C" int64_t dr_inbatch_softmax_workspace_bytes(int64_t B) {
+    return ib_h2_offset_bytes(B) + ib_h2_bytes(B);
+}
+
+// records + candidate planes into the workspace; returns false when the f16x2 path does not apply (the caller runs the fp32 kernel)
+static bool ib_h2_prepare(const float* q, const float* c, int64_t B, int32_t D, float* workspace, int64_t workspace_bytes, hipStream_t stream,
+                          uint32_t** rec, void** planes, int64_t* ps, int64_t* ld, int* rc) {
+    *rc = DR_OK;
+    if (dr_get_gemm_split() != DR_GEMM_SPLIT_F16X2 || workspace == nullptr || (D % 4) != 0 || D > IB_H2_MAX_D || B < 256) return false;
+    if ((reinterpret_cast<uintptr_t>(q) & 15) != 0 || (reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return false;
+    if (workspace_bytes < ib_h2_offset_bytes(B) + ib_h2_bytes(B)) return false;
+    char* base = reinterpret_cast<char*>(workspace) + ib_h2_offset_bytes(B);
+    *rec = reinterpret_cast<uint32_t*>(base);
+    *planes = base + 256;
+    *ld = ((int64_t)D + 31) / 32 * 32;
+    *ps = ((B + 31) / 32 * 32) * *ld;
+    if ((D % 32) != 0 && hipMemsetAsync(*planes, 0, (size_t)(2 * *ps * 2), stream) != hipSuccess) { *rc = DR_ELAUNCH; return true; }
+    *rc = dr_h2_amax(q, D, B, D, *rec, 1, stream);
+    if (*rc == DR_OK) *rc = dr_h2_amax(c, D, B, D, *rec + 1, 1, stream);
+    if (*rc == DR_OK) *rc = dr_h2_split(c, D, B, D, *planes, *ps, *ld, 0, 0, 0, *rec + 1, stream);
+    return true;
 }
 
 extern "C" int dr_inbatch_softmax_fwd(const float* q, const float* c, int64_t B, int32_t D, const float* cand_prob,
@@ -1338,11 +1379,24 @@ extern "C" int dr_inbatch_softmax_fwd(const float* q, const float* c, int64_t B,
     g.A = q; g.lda = D; g.B = c; g.ldb = D; g.M = B; g.N = (int32_t)B; g.R = D; g.C = nullptr; g.ldc = 0;
     g.cand_prob = cand_prob; g.cand_ids = cand_ids; g.inv_t = inv_temperature;
     g.part_m = workspace; g.part_l = workspace + (int64_t)2 * tiles_n * B; g.pos = pos_score; g.split = 1;
-    int rc = launch<true, true, EPI_LSE>(g, dr_s(stream));
+    int nparts = 2 * tiles_n;
+    uint32_t* rec = nullptr;
+    void* planes = nullptr;
+    int64_t ps = 0, ld = 0;
+    int rc = DR_OK;
+    if (ib_h2_prepare(q, c, B, D, workspace, workspace_bytes, dr_s(stream), &rec, &planes, &ps, &ld, &rc)) {
+        // the scores on the f16x2 register-split kernel (three fp16 products per fp32 product; 256-column tiles: one partial per tile)
+        if (rc == DR_OK)
+            rc = dr_h2_inbatch_lse(q, D, rec, planes, ps, ld, rec + 1, B, D, cand_prob, cand_ids, inv_temperature, g.part_m, g.part_l,
+                                   pos_score, stream);
+        nparts = (int)((B + 255) / 256);
+    } else {
+        rc = launch<true, true, EPI_LSE>(g, dr_s(stream));
+    }
     if (rc != DR_OK) return rc;
     float* block_sums = workspace + (int64_t)4 * tiles_n * B;
     const int grid = dr_grid_for(B, 256, 512);
-    hipLaunchKernelGGL(lse_finalize_kernel, dim3(grid), dim3(256), 0, dr_s(stream), g.part_m, g.part_l, 2 * tiles_n, B,
+    hipLaunchKernelGGL(lse_finalize_kernel, dim3(grid), dim3(256), 0, dr_s(stream), g.part_m, g.part_l, nparts, B,
                        pos_score, sample_weight, row_lse, block_sums);
     hipLaunchKernelGGL(sum_blocks_kernel, dim3(1), dim3(256), 0, dr_s(stream), block_sums, grid, loss_out);
     DR_CHECK_LAUNCH();
@@ -1351,6 +1405,27 @@ extern "C" int dr_inbatch_softmax_fwd(const float* q, const float* c, int64_t B,
 
 // G[i][j] = d_loss * w_i * (softmax_ij - delta_ij) * inv_t  (the gradient of the loss wrt the raw q.c^T scores);
 // the caller finishes with two plain GEMMs: dq = G @ c (dr_linear_fwd), dc = G^T @ q (dr_linear_bwd_dw).
+// ... with a workspace (dr_inbatch_softmax_workspace_bytes(B); the forward's may be reused, its contents are not needed): lets the
+// pass run on the f16x2 register-split kernel, which wants the candidates as fp16 planes.  workspace NULL / too small, or a split /
+// shape the f16x2 path does not take: the fp32 kernel, as dr_inbatch_softmax_grad_scores.
+extern "C" int dr_inbatch_softmax_grad_scores_ws(const float* q, const float* c, int64_t B, int32_t D, const float* cand_prob,
+                                                 const int64_t* cand_ids, const float* sample_weight, float inv_temperature,
+                                                 const float* row_lse, float d_loss, float* G, int64_t ld_g, float* workspace,
+                                                 int64_t workspace_bytes, dr_stream_t stream) {
+    if (B <= 0 || D < 4 || B > 0x7fffffff || ld_g < B) return DR_EINVAL;
+    if (!q || !c || !row_lse || !G) return DR_EINVAL;
+    uint32_t* rec = nullptr;
+    void* planes = nullptr;
+    int64_t ps = 0, ld = 0;
+    int rc = DR_OK;
+    if (ib_h2_prepare(q, c, B, D, workspace, workspace_bytes, dr_s(stream), &rec, &planes, &ps, &ld, &rc)) {
+        if (rc != DR_OK) return rc;
+        return dr_h2_inbatch_smgrad(q, D, rec, planes, ps, ld, rec + 1, B, D, cand_prob, cand_ids, inv_temperature, row_lse, sample_weight,
+                                    d_loss, G, ld_g, stream);
+    }
+    return dr_inbatch_softmax_grad_scores(q, c, B, D, cand_prob, cand_ids, sample_weight, inv_temperature, row_lse, d_loss, G, ld_g, stream);
+}
+
 extern "C" int dr_inbatch_softmax_grad_scores(const float* q, const float* c, int64_t B, int32_t D, const float* cand_prob,
                                               const int64_t* cand_ids, const float* sample_weight, float inv_temperature,
                                               const float* row_lse, float d_loss, float* G, int64_t ld_g,

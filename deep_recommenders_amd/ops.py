@@ -702,10 +702,15 @@ def inbatch_softmax_grad_scores(q, c, row_lse, d_loss, cand_prob=None, cand_ids=
                                 inv_temperature=1.0):
     _check_inbatch_shapes(q, c, cand_prob, cand_ids, sample_weight)
     B, D = q.shape
+    q = _c(q, torch.float32)
+    c = _c(c, torch.float32)
     G = torch.empty((B, _pad4(B)), dtype=torch.float32, device=q.device)[:, :B]
-    check(lib().dr_inbatch_softmax_grad_scores(ptr(q), ptr(c), B, D, ptr(cand_prob), ptr(cand_ids), ptr(sample_weight),
-                                               float(inv_temperature), ptr(row_lse), float(d_loss), ptr(G), G.stride(0),
-                                               stream_ptr()), "dr_inbatch_softmax_grad_scores")
+    # with a workspace the pass may run on the f16x2 register-split kernel (it needs the candidates as fp16 planes)
+    nbytes = lib().dr_inbatch_softmax_workspace_bytes(B)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=q.device)
+    check(lib().dr_inbatch_softmax_grad_scores_ws(ptr(q), ptr(c), B, D, ptr(cand_prob), ptr(cand_ids), ptr(sample_weight),
+                                                  float(inv_temperature), ptr(row_lse), float(d_loss), ptr(G), G.stride(0),
+                                                  ptr(ws), nbytes, stream_ptr()), "dr_inbatch_softmax_grad_scores_ws")
     return G
 
 

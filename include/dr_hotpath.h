@@ -481,6 +481,16 @@ int dr_inbatch_softmax_grad_scores(const float* q, const float* c, int64_t B, in
                                    const float* cand_prob, const int64_t* cand_ids,
                                    const float* sample_weight, float inv_temperature, const float* row_lse,
                                    float d_loss, float* G, int64_t ld_g, dr_stream_t stream);
+/* Round 5: in the f16x2 operand split (dr_get_gemm_split) both score passes run on the register-split kernel with the LSE /
+ * softmax-gradient epilogues (three fp16 products per fp32 product, scores never leave the tile) whenever D % 4 == 0, D <= 512,
+ * B >= 256 and the workspace (256-byte aligned, dr_inbatch_softmax_workspace_bytes) is there: it also holds the candidates' two fp16
+ * planes and both amax records.  dr_inbatch_softmax_grad_scores has no workspace and stays on the fp32 kernel;
+ * dr_inbatch_softmax_grad_scores_ws takes one (the forward's may be reused; its contents are not needed). */
+int dr_inbatch_softmax_grad_scores_ws(const float* q, const float* c, int64_t B, int32_t D,
+                                      const float* cand_prob, const int64_t* cand_ids,
+                                      const float* sample_weight, float inv_temperature, const float* row_lse,
+                                      float d_loss, float* G, int64_t ld_g, float* workspace,
+                                      int64_t workspace_bytes, dr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K10  exact top-K maximum-inner-product search (BruteForce.call factorized_top_k.py:316-334,

@@ -327,9 +327,21 @@ def test_remove_accidental_negative_and_sampling_correction():
     np.testing.assert_allclose(out, O.sampling_probability_correction(logits, p), rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("B,D", [(6, 4), (200, 32), (513, 128)])
-def test_retrieval_loss_and_gradients(B, D):
+@pytest.mark.parametrize("split", ["f16x2", "bf16x3"])
+@pytest.mark.parametrize("B,D", [(6, 4), (200, 32), (513, 128), (1024, 64), (2048, 128), (700, 20)])
+def test_retrieval_loss_and_gradients(B, D, split):
+    """(B >= 256 in the f16x2 split: both score passes on the register-split kernel with the LSE / softmax-gradient epilogues --
+    513 and 700 have edge tiles in both directions, D = 20 a padded reduction; otherwise the fp32 MFMA kernel)"""
+    from deep_recommenders_amd import ops
     from deep_recommenders_amd.keras.models.retrieval import sbcnm
+    prev = ops.set_gemm_split(split)
+    try:
+        _retrieval_loss_and_gradients(B, D, sbcnm)
+    finally:
+        ops.set_gemm_split(prev)
+
+
+def _retrieval_loss_and_gradients(B, D, sbcnm):
     rng = np.random.default_rng(8)
     q = (rng.standard_normal((B, D)) / np.sqrt(D)).astype(np.float32)
     c = (rng.standard_normal((B, D)) / np.sqrt(D)).astype(np.float32)

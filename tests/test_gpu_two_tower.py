@@ -88,13 +88,14 @@ def test_two_tower_metric_pass_matches_oracle():
     assert (ids.cpu().numpy() == wi).mean() > 0.999
 
 
-def test_two_tower_training_step_does_not_depend_on_the_operand_split():
-    """The explicit decision of DESIGN.md section 3.2: the two-tower TRAINING step at config 5's shapes (B = 8192, towers 128 -> 256 -> 128) runs
-    the generic dr_linear_* GEMMs, whose products follow dr_set_gemm_mode -- the operand-split switch (dr_set_gemm_split, f16x2 by default)
-    governs the register-split GEMMs of the DeepFM / DCN engines and the exact top-K scan only.  From identical state under both
-    splits: the first step's tower outputs and loss are BIT-identical (every forward kernel is deterministic), and the parameters
-    after two steps agree to the run-to-run noise of the bias-gradient atomics (a different product mode would differ at 1e-7 in
-    the tower outputs already).  (The metric pass's scan IS on the switch: test_gpu_h2_gemm.py.)"""
+def test_two_tower_training_step_and_the_operand_split():
+    """Where the operand-split switch (dr_set_gemm_split, f16x2 by default) reaches into the two-tower TRAINING step at config 5's shapes
+    (B = 8192, towers 128 -> 256 -> 128), and where it does not.  The towers run the generic dr_linear_* GEMMs, whose products follow
+    dr_set_gemm_mode: from identical state under both splits the first step's tower outputs are BIT-identical.  The in-batch softmax's
+    two score passes (8192 x 8192 x 128) DO follow the switch since round 5 (register-split kernel with the LSE / softmax-gradient
+    epilogues in the f16x2 split, the fp32 MFMA kernel otherwise): the losses agree to the products' rounding (1e-6 relative), the
+    parameters after two steps to the run-to-run noise of the bias-gradient atomics.  (The metric pass's scan is on the switch too:
+    test_gpu_h2_gemm.py.)"""
     from deep_recommenders_amd import ops
     from deep_recommenders_amd.two_tower_engine import TwoTowerEngine
     Vu, Ni, D, B = 50000, 20000, 128, 8192
@@ -117,7 +118,7 @@ def test_two_tower_training_step_does_not_depend_on_the_operand_split():
     finally:
         ops.set_gemm_split(prev)
     a, b = res
-    assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
-    assert abs(a[3] - b[3]) <= 1e-6 * abs(b[3])
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert abs(a[0] - b[0]) <= 2e-6 * abs(b[0]) and abs(a[3] - b[3]) <= 2e-6 * abs(b[3]), (a[0], b[0], a[3], b[3])
     for k in a[4]:
         np.testing.assert_allclose(a[4][k].numpy(), b[4][k].numpy(), rtol=1e-5, atol=1e-7, err_msg=k)
