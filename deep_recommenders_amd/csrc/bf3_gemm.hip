@@ -1062,7 +1062,8 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
             } else if constexpr (EPI == 6 || EPI == 7) {
                 // in-batch softmax on the scores of this tile (see RsArgs).  Lane r < 16 of a half stands for row r of that half (its
                 // candidate id, lse, weight: one load each per tile, handed out by shuffles); a lane's 8 columns keep their
-                // correction and id in registers.
+                // correction and id in registers.  Exponentials by v_exp_f32 (__expf: 2 ulp): the arguments carry the products' 1e-6
+                // already, and libm's expf was a third of this epilogue (128 per lane and tile).
                 constexpr float MIN_FLOAT = -3.4028234663852886e36f;    // np.finfo(np.float32).min / 100 (sbcnm.py:10)
                 const bool ids_on = g.sm_cand_ids != nullptr;
                 const int64_t lrow = r0 + (l31 & 3) + 8 * ((l31 >> 2) & 3);
@@ -1107,7 +1108,7 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
                         float l = 0.f;
 #pragma unroll
                         for (int nt = 0; nt < NTW; ++nt)
-                            if (cb0 + nt * 32 + l31 < g.N) l += (sv[nt] - m < -87.f ? 0.f : expf(sv[nt] - m));
+                            if (cb0 + nt * 32 + l31 < g.N) l += (sv[nt] - m < -87.f ? 0.f : __expf(sv[nt] - m));
 #pragma unroll
                         for (int o = 1; o < 32; o <<= 1) l += __shfl_xor(l, o, 64);
                         if (rv && l31 == 0) {
@@ -1125,7 +1126,7 @@ __global__ __launch_bounds__(512 * CS / MS, MS == CS ? 2 : 1) void bf3_gemm_rs_k
                         for (int nt = 0; nt < NTW; ++nt) {
                             const int col = cb0 + nt * 32 + l31;
                             const float d = sv[nt] - lse;
-                            const float pr = (d < -87.f ? 0.f : expf(d)) - (row == col ? 1.f : 0.f);
+                            const float pr = (d < -87.f ? 0.f : __expf(d)) - (row == col ? 1.f : 0.f);
                             if (interior) g.C[row * g.ldc + col] = pr * scale;
                             else if (rv && col < g.N) g.C[row * g.ldc + col] = pr * scale;
                         }
