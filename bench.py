@@ -774,7 +774,8 @@ def main():
                                              else "first layer's three GEMMs"))
                                          if (a.gemm == "bf16x3" and getattr(eng, "h2", False)) else
                                          "fp32 in / fp32 accumulate; products = 6 bf16 MFMA products of exact 3-way bf16 splits (error vs fp64 <= native fp32 MFMA, tests/test_gpu_kernels.py)"
-                                         + ("; the exact top-K scan of the metric pass follows dr_get_gemm_split (%s)" % dr_ops.get_gemm_split() if a.model == "dssm" else "")
+                                         + ("; the in-batch softmax's two 8192 x 8192 x 128 score passes and the exact top-K scan of the metric pass follow "
+                                            "dr_get_gemm_split (%s: 3 fp16 MFMA products of two-term fp16 splits)" % dr_ops.get_gemm_split() if a.model == "dssm" else "")
                                          if a.gemm == "bf16x3" else "native v_mfma_f32_32x32x2_f32"),
                        "gemm_split": dr_ops.get_gemm_split() if a.gemm == "bf16x3" else None,      # what the LIBRARY reports (dr_get_gemm_split)
                        "global_batch": a.batch * world, "parallelism": par, "final_loss": round(loss, 6),
