@@ -2517,6 +2517,7 @@ int rs_launch(const RsArgs& g, hipStream_t stream) {
     if (g.mask != nullptr && g.accumulate) return DR_EINVAL;            // (no caller needs both)
     if (g.a_amax != nullptr) {                                          // f16x2 operand mode
         if (g.b_amax == nullptr) return DR_EINVAL;
+        if (g.c_amax != nullptr && hipMemsetAsync(g.c_amax, 0, sizeof(uint32_t), stream) != hipSuccess) return DR_ELAUNCH;
         if (g.pack_pos != nullptr) {
             hipLaunchKernelGGL((bf3_gemm_rs_kernel<5, 0, 1, 1, 1>), dim3(grid), dim3(512), 0, stream, g);
             DR_CHECK_LAUNCH();
