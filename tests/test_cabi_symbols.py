@@ -71,3 +71,17 @@ def test_collectives_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), "libdr_collectives.so does not export %s" % n
     assert _coll_lib.lib().dr_coll_world(None) == 0 and _coll_lib.lib().dr_coll_rank(None) == -1
+
+
+def test_package_import_asks_for_eight_hardware_queues_unless_the_user_chose():
+    """HIP maps streams onto 4 hardware queues by default and the sharded engines drive more streams than that (1.97 instead of 1.67 ms per
+    step at world 1, profiles/r05_sharded_step_boundary.log): importing the package puts GPU_MAX_HW_QUEUES=8 into the environment --
+    before the HIP runtime initialises, which reads it -- and leaves a value the user set alone."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import os, sys; sys.path.insert(0, %r); import deep_recommenders_amd; print(os.environ['GPU_MAX_HW_QUEUES'])" % root
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    assert subprocess.check_output([sys.executable, "-c", code], env=env).decode().strip() == "8"
+    env["GPU_MAX_HW_QUEUES"] = "2"
+    assert subprocess.check_output([sys.executable, "-c", code], env=env).decode().strip() == "2"
