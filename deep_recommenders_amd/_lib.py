@@ -119,6 +119,7 @@ SIGNATURES = {
     "dr_h2_refresh_weight": [_p, _i64, _i64, _i32, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _p],
     "dr_h2_linear_nt": [_p, _i64, _p, _p, _i64, _i64, _p, _i64, _i32, _i32, _p, _i32, _p, _i64, _i32, _p, _i64, _p, _p],
     "dr_h2_cross_fwd": [_p, _p, _i64, _p, _p, _i64, _i64, _p, _p, _f32, _i64, _i32, _p, _p, _p, _p],
+    "dr_h2_dgrad_emb_sgd": [_p, _i64, _p, _p, _i64, _i64, _p, _i64, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _f32, _p, _i64, _p, _p],
     "dr_cross_combine_bwd_amax": [_p, _p, _p, _i64, _i32, _i64, _f32, _p, _p, _p, _p, _p],
     "dr_h2_emb_linear_fwd": [_p, _i64, _i32, _p, _i64, _p, _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _p, _i64, _i64, _p, _i32, _p, _i32,
                              _p, _p, _p, _i64, _p, _p],

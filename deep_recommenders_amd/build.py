@@ -20,6 +20,7 @@ COLL_SO = os.path.join(LIBDIR, "libdr_collectives.so")    # exchange steps over 
 # the default limit; a loop-indexed accumulator array that is NOT unrolled lives in scratch memory)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
          "-Wno-unused-function", "-Wno-unused-result", "-mllvm", "-pragma-unroll-threshold=131072"]
+FLAGS += os.environ.get("DR_HIPCC_EXTRA", "").split()     # experiment builds only (tools/exp: -DDR_OCC_ABLATE, -DDR_BF3_ABLATE ...)
 
 
 def sources():

@@ -395,6 +395,7 @@ struct BwdSortedArgs {
     int skip_unique_lin;                         // first-order weights of rows unique in the batch are updated by dr_emb_lin_update_unique
     const float* lin_old_t;                      // [F, B] first-order weights as the forward read them (may be NULL)
     uint32_t* amax;                              // running amax record of dst_table (may be NULL)
+    int dups_only;                               // parts | 8: only the rows several slots share (+ the first-order bias)
 };
 #ifndef DR_K4_MINWAVES     // (experiment hooks: tools/exp/k4_occupancy.sh builds variants with -DDR_K4_MINWAVES=n / -DDR_K4_U=n)
 #define DR_K4_LB __launch_bounds__(256)
@@ -407,7 +408,10 @@ __global__ DR_K4_LB void emb_bwd_sorted_kernel(BwdSortedArgs a, AdamArgs ad, int
         emb_bwd_dups_body<LPR, ADAM>(blockIdx.x, grid_d, a.rows, a.slots, a.n, a.dup_heads, a.dup_count, a.F, a.D, a.num_rows, a.grad,
                                      a.ld, a.concat, a.ldc, a.sum_x, a.d_fm_logit, a.slot_lin, a.scale, a.table, a.lin_w, ad, a.x_sorted,
                                      a.det != 0, a.amax);
-    else
+    else if (a.dups_only) {
+        // (parts | 8: the unique rows were updated by dr_h2_dgrad_emb_sgd; ONE extra block is launched for the first-order bias)
+        if (!ADAM && a.lin_bias != nullptr && a.d_fm_logit != nullptr) dr_block_sum_axpy(a.d_fm_logit, a.B, a.scale, a.lin_bias);
+    } else
         emb_bwd_unique_body<LPR, U, ADAM>(blockIdx.x - grid_d, gridDim.x - grid_d, a.ids, a.flags, a.B, a.F, a.row_base, a.D, a.grad,
                                           a.ld, a.concat, a.ldc, a.sum_x, a.d_fm_logit, a.slot_lin, a.scale, a.table,
                                           a.skip_unique_lin ? nullptr : a.lin_w, a.lin_bias, ad, a.lin_old_t, a.amax);
@@ -559,7 +563,7 @@ static int bwd_sorted_impl(const int64_t* ids, const int64_t* row_base, const in
     const BwdSortedArgs ba{ids, unique_flags, B, F, row_base, D, grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit, slot_lin_grad,
                            scale, dst_table, dst_lin, dst_bias, rows, sorted_slots, n, dup_heads, dup_count, (uint64_t)num_rows,
                            x_sorted, det, (adam == nullptr && (parts & 4)) ? 1 : 0,
-                           slot_lin_grad == nullptr ? lin_old_t : nullptr, table_amax};
+                           slot_lin_grad == nullptr ? lin_old_t : nullptr, table_amax, (parts & 8) ? 1 : 0};
 #ifdef DR_K4_U
     constexpr int K4_U_OVERRIDE = DR_K4_U;
 #else
@@ -569,7 +573,7 @@ static int bwd_sorted_impl(const int64_t* ids, const int64_t* row_base, const in
     {                                                                                                                 \
         constexpr int NS_ = 64 / L;                                                                                   \
         constexpr int U_ = K4_U_OVERRIDE > 0 ? K4_U_OVERRIDE : (NS_ >= 16 ? 2 : 4);                                   \
-        hipLaunchKernelGGL((emb_bwd_sorted_kernel<L, U_, ADAM_>), dim3(grid_d + grid_u), dim3(256), 0, dr_s(stream), ba, ad,    \
+        hipLaunchKernelGGL((emb_bwd_sorted_kernel<L, U_, ADAM_>), dim3(grid_d + ((parts & 8) ? 1 : grid_u)), dim3(256), 0, dr_s(stream), ba, ad,    \
                            grid_d);                                                                                   \
     }
 #define CALL(L)                                                                                                       \
@@ -653,7 +657,9 @@ extern "C" int dr_emb_pool_bwd_sorted_ex(const int64_t* ids, const int64_t* row_
                                          const float* d_fm_logit, const float* slot_lin_grad, float scale,
                                          float* dst_table, float* dst_lin, float* dst_bias, float* x_sorted,
                                          const float* lin_old_t, int32_t parts, uint32_t* table_amax, dr_stream_t stream) {
-    if (parts < 1 || parts > 7 || (parts & 3) == 0) return DR_EINVAL;
+    // parts | 8 (SGD form only): the slots whose row is unique in the batch were updated elsewhere (dr_h2_dgrad_emb_sgd) -- only the
+    // duplicate pass, the hot rows and the first-order bias run here; `grad` need hold the rows of the non-unique slots only
+    if (parts < 1 || parts > 15 || (parts & 3) == 0) return DR_EINVAL;
     return bwd_sorted_impl(ids, row_base, sorted_rows, sorted_slots, unique_flags, dup_heads, dup_count, B, F, D, num_rows,
                            grad, ld_grad, concat, ld_concat, sum_x, d_fm_logit, slot_lin_grad, scale, dst_table, dst_lin,
                            dst_bias, nullptr, x_sorted, stream, parts, lin_old_t, table_amax);

@@ -587,6 +587,23 @@ def emb_pool_bwd_sorted(ids, row_base, plan, D, num_rows, grad, d_fm_logit, scal
         check(lib().dr_emb_pool_bwd_sorted_parts(*args, int(parts), stream_ptr()), "dr_emb_pool_bwd_sorted_parts")
 
 
+def h2_dgrad_emb_sgd(dy, dy_amax, w: "H2Planes", ids_t, plan, row_base, table, lin_w, lin_old_t, sum_x, d_fm_logit, scale, d_concat,
+                     table_amax=None):
+    """First-layer dgrad + K4's unique-row pass in one launch (dr_h2_dgrad_emb_sgd): the rows of `table` (and `lin_w`) that exactly one
+    slot of the batch looked up receive their SGD update; the gradient rows of all other slots are stored to `d_concat` [M, >= 64 F]
+    for emb_pool_bwd_sorted(..., parts=... | 8).  w: the layer's kernel as H2Planes (rows = input columns, >= 64 F of them)."""
+    F, M = ids_t.shape
+    K = dy.shape[1]
+    assert dy.stride(1) == 1 and d_concat.stride(1) == 1 and table.is_contiguous() and table.shape[1] == 64 and sum_x.is_contiguous()
+    assert ids_t.dtype == torch.int32 and ids_t.is_contiguous() and dy.shape[0] == M and w.rows >= 64 * F
+    assert (lin_w is None) == (lin_old_t is None)
+    assert lin_old_t is None or (lin_old_t.shape == (F, M) and lin_old_t.is_contiguous())
+    check(lib().dr_h2_dgrad_emb_sgd(ptr(dy), dy.stride(0), ptr(dy_amax), ptr(w.buf), w.plane_stride, w.ld, ptr(w.amax), M, F, K,
+                                    ptr(ids_t), ptr(plan.flags), ptr(row_base), ptr(table), ptr(lin_w), ptr(lin_old_t), ptr(sum_x),
+                                    ptr(d_fm_logit), float(scale), ptr(d_concat), d_concat.stride(0), ptr(table_amax), stream_ptr()),
+          "dr_h2_dgrad_emb_sgd")
+
+
 def emb_lin_update_unique(ids, row_base, plan, d_fm_logit, scale, dst_lin, slot_lin_grad=None):
     """dst_lin[row] += scale * gradient for every slot whose row is unique in the batch (plan.flags): the part of K4's first-order
     update that emb_pool_bwd_sorted(parts=... | 4) leaves out (dr_emb_lin_update_unique)."""

@@ -768,6 +768,22 @@ int dr_h2_linear_nt(const float* A, int64_t lda, const uint32_t* a_amax, const v
                     const uint32_t* b_amax, int64_t M, int32_t N, int32_t K, const float* bias, int32_t act, const float* mask,
                     int64_t ld_mask, int32_t accumulate, float* C, int64_t ldc, uint32_t* c_amax, dr_stream_t stream);
 /* c_amax / out_amax (may be NULL): reset, then raised to max |value stored into C / out| -- the record of the NEXT GEMM's operand */
+/* Round 6 -- the first-layer dgrad of the DeepFM tower with K4's unique-row pass as its epilogue (csrc/h2_occ.hip; D = 64, single-valued
+ * fields, SGD):  dx[m, 64 f + d] = sum_k dy[m][k] W[64 f + d][k] is the gradient row of slot (m, f).  For every slot whose table row no other
+ * slot of the batch shares (unique_flags [M, F] of dr_emb_sort_slots; ids_t [F, M] int32 from dr_ids_transpose_i32, -1 = missing) the
+ * kernel applies K4's update on the spot --  g = dx + d_fm_logit[m] (sum_x[m] - x), table[row] = x + scale g with x the row as it stands,
+ * lin_w[row] = lin_old_t[f, m] + scale d_fm_logit[m]  -- operation for operation what dr_emb_pool_bwd_sorted_ex does with the stored
+ * gradient (bit-identical tables); the other slots' dx goes to d_concat [M, ld_dconcat] for the duplicate pass.  Follow with
+ * dr_emb_pool_bwd_sorted_ex(parts | 8) on the same stream (grad = d_concat): rows shared by several slots, hot rows, first-order
+ * bias.  The tables must not be read by anything that needs their pre-step value after this call (run the first-layer wgrad that
+ * gathers x BEFORE it).  w_planes: two fp16 planes [2][>= 64 F rows][w_ld] of the layer's kernel (dr_h2_split / dr_h2_refresh_weight's
+ * `w`), w_ld >= roundup(K, 32); lin_w / lin_old_t both NULL or both given; table_amax (may be NULL): the table's running record, raised
+ * to every value written.  Autodiff of keras/models/ranking/deepfm.py:30-34,44-45 and fm.py:23-37 w.r.t. the embedding tables. */
+int dr_h2_dgrad_emb_sgd(const float* dy, int64_t ld_dy, const uint32_t* dy_amax, const void* w_planes, int64_t w_plane_stride,
+                        int64_t w_ld, const uint32_t* w_amax, int64_t M, int32_t F, int32_t K, const int32_t* ids_t,
+                        const uint8_t* unique_flags, const int64_t* row_base, float* table, float* lin_w, const float* lin_old_t,
+                        const float* sum_x, const float* d_fm_logit, float scale, float* d_concat, int64_t ld_dconcat,
+                        uint32_t* table_amax, dr_stream_t stream);
 int dr_h2_cross_fwd(const float* x0, const float* x, int64_t ld, const uint32_t* x_amax, const void* wt_planes, int64_t plane_stride,
                     int64_t ld_planes, const uint32_t* w_amax, const float* b, float diag_scale, int64_t M, int32_t Dm, float* out,
                     float* prod_out, uint32_t* out_amax, dr_stream_t stream);
