@@ -123,17 +123,8 @@ __global__ __launch_bounds__(1024) void h2_occ_nt_kernel(RsArgs g, K4Args e) {
         // ---- per-tile addresses -----------------------------------------------------------------------------------------------
         // A through a buffer resource over the tile's rows: base = row tm0, range = up to the readable end of row M - 1, so rows
         // past the edge read zeros (they only feed unstored outputs) and no load leaves the matrix; offsets are 32 bits
-        // (descriptor built by hand and the loads issued from inline asm: hipcc's wait-count pass, which cannot count the weight pieces
-        // across the loop's uniform branches, puts vmcnt(1) / vmcnt(0) in front of the split -- i.e. waits for the pieces issued a
-        // moment ago on every k-tile; the waits for these loads are the counted ones written out below)
-        u32x4 arsrc;
-        {
-            const uint64_t base = reinterpret_cast<uint64_t>(g.A + tm0 * g.lda);
-            arsrc[0] = __builtin_amdgcn_readfirstlane((unsigned)base);
-            arsrc[1] = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32) & 0xffffu);
-            arsrc[2] = __builtin_amdgcn_readfirstlane((unsigned)min((int64_t)0x7fffffff, ((g.M - tm0 - 1) * g.lda + kv4) * 4));
-            arsrc[3] = 0x00020000u;
-        }
+        const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(g.A + tm0 * g.lda), 0, (int)min((int64_t)0x7fffffff, ((g.M - tm0 - 1) * g.lda + kv4) * 4), 0x00020000);
         const int bvoff = (int)(((int64_t)min(tn0 + brow, g.N - 1) * g.b_ld + bchunk * 8) * 2);
         auto issue_b = [&](int kt, int stage) {
             if constexpr (DBG & 1) { if (kt > 0) return; }
@@ -145,17 +136,17 @@ __global__ __launch_bounds__(1024) void h2_occ_nt_kernel(RsArgs g, K4Args e) {
         };
         f32x4 an0, an1;                                                 // A of the next k-tile, in flight
         int an_kt = 0;                                                  // ... its k-tile
+        // (compiler-visible loads on purpose.  Issued from inline asm with hand-counted waits they measured the same -- hipcc's own waits
+        // in front of the split come out as vmcnt(1) / vmcnt(0), i.e. they also wait for the weight pieces issued a moment earlier,
+        // which have landed by then anyway -- and they are UNSAFE: in an instantiation short of registers (EPI 8) the compiler
+        // spilled the destination registers of the in-flight loads, whose contents it believed valid, and reloaded stale bits)
         auto load_a = [&](int kt) {
             if constexpr (DBG & 8) kt = 0;
             an_kt = kt;
-            const int soff = kt * (BK * 4);
-            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(an0) : "v"(avoff0), "s"(arsrc), "s"(soff) : "memory");
-            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(an1) : "v"(avoff1), "s"(arsrc), "s"(soff) : "memory");
+            an0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, avoff0, kt * (BK * 4), 0));
+            an1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, avoff1, kt * (BK * 4), 0));
         };
-        auto wait_a = [&](bool pieces_behind) {                         // the two loads landed; (uniform) the two pieces issued after them may fly
-            if (pieces_behind) asm volatile("s_waitcnt vmcnt(2)" : "+v"(an0), "+v"(an1));
-            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(an0), "+v"(an1));
-        };
+        auto wait_a = [&](bool) {};
         // one of the thread's two float4s of the k-tile in flight -> the two fp16 terms -> stage's A image
         auto stage_a = [&](int which, int stage) {
             if constexpr (DBG & 64) return;
@@ -270,9 +261,7 @@ __global__ __launch_bounds__(1024) void h2_occ_nt_kernel(RsArgs g, K4Args e) {
             OCC_FENCE();
             if constexpr (DBG & 2) acc[0][0][0] += (float)ah[0][0] + (float)ah[1][0] + (float)al[0][0] + (float)al[1][0] + (float)bh[0][0] + (float)bh[1][0] + (float)bl[0][0] + (float)bl[1][0];
         }
-        // (the last k-tile's barrier was the last LDS access of the main loop: the ring is free for the epilogue; the dummy loads of the
-        // last k-tiles retire here -- their registers are the compiler's again only behind this wait)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(an0), "+v"(an1));
+        // (the last k-tile's barrier was the last LDS access of the main loop: the ring is free for the epilogue)
 #undef OCC_MMA
 #undef OCC_MMA2
 #undef OCC_RD
@@ -284,9 +273,13 @@ __global__ __launch_bounds__(1024) void h2_occ_nt_kernel(RsArgs g, K4Args e) {
         {
             const bool relu = g.act == 1;
             const bool interior = tm0 + BM <= g.M && tn0 + BN <= g.N;
+            // (the lane index laundered: everything the epilogue derives from it is recomputed here, per tile -- hoisted out of the tile
+            // loop by the compiler these values live across the main loop, whose 128 registers are spoken for, and are spilled INTO it)
+            int lane_e = lane;
+            asm volatile("" : "+v"(lane_e));
             const unsigned stg = lds0 + wave * 8192;
-            const unsigned st_wr = stg + (4 * hi) * 256 + l31 * 4;      // + ((reg & 3) + 8 (reg >> 2)) * 256 + b * 128
-            const int prow = lane >> 4, pc4 = (lane & 15) * 4;          // storing pass: row within a 4-row group, first of 4 columns
+            const unsigned st_wr = stg + (4 * (lane_e >> 5)) * 256 + (lane_e & 31) * 4;      // + ((reg & 3) + 8 (reg >> 2)) * 256 + b * 128
+            const int prow = lane_e >> 4, pc4 = (lane_e & 15) * 4;      // storing pass: row within a 4-row group, first of 4 columns
             const unsigned st_rd = stg + prow * 256 + pc4 * 4;          // + 4 it * 256
             const int col0 = tn0 + 64 * wc + pc4;
             float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -297,8 +290,44 @@ __global__ __launch_bounds__(1024) void h2_occ_nt_kernel(RsArgs g, K4Args e) {
                     bj.z = g.bias[min(col0 + 2, g.N - 1)]; bj.w = g.bias[min(col0 + 3, g.N - 1)];
                 }
             }
+            // EPI 8: the tile's buffer resources (bases made wave-uniform by hand: a resource the compiler cannot prove uniform is
+            // applied lane by lane in a waterfall loop)
+            const int k4_f = (tn0 >> 6) + wc;
+            const bool k4_on = EPI == 8 && k4_f < e.F;
+            const int k4_rows = (int)min((int64_t)BM, g.M - tm0);
+            const int k4_ldc4 = (int)(e.ld_dc * 4);
+            __amdgpu_buffer_rsrc_t k4_t, k4_dl, k4_lo, k4_sx, k4_dc, k4_lw, k4_id, k4_fl;
+            if constexpr (EPI == 8) {
+                auto mk = [&](const void* p, int64_t bytes) {
+                    const uint64_t b = reinterpret_cast<uint64_t>(p);
+                    void* q = reinterpret_cast<void*>(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
+                                                      (unsigned)__builtin_amdgcn_readfirstlane((int)b));
+                    return __builtin_amdgcn_make_buffer_rsrc(q, 0, (int)(unsigned)(bytes < 0xffffff00ll ? bytes : 0xffffff00ll), 0x00020000);
+                };
+                const int fc = k4_on ? k4_f : 0;
+                const int64_t rb = e.row_base[fc];
+                const bool has_lin = e.lin_w != nullptr;
+                k4_t = mk(e.table + rb * 64, 0xffffff00ll);             // (the field's rows: id * 256 < 4 GB - 256, i.e. < 2^24 - 1 rows per field)
+                k4_dl = mk(e.d_fm_logit + tm0, (int64_t)k4_rows * 4);
+                k4_lo = has_lin ? mk(e.lin_old_t + (int64_t)fc * g.M + tm0, (int64_t)k4_rows * 4) : k4_dl;
+                k4_sx = mk(e.sum_x + tm0 * 64, (int64_t)k4_rows * 256);
+                k4_dc = mk(e.d_concat + tm0 * e.ld_dc + 64 * fc, ((int64_t)k4_rows - 1) * e.ld_dc * 4 + 256);
+                k4_lw = has_lin ? mk(e.lin_w + rb, 0x7fffffffll) : mk(e.table, 0);      // (no first-order table: every store out of range)
+                k4_id = mk(e.ids_t + (int64_t)fc * g.M + tm0, (int64_t)k4_rows * 4);
+                k4_fl = mk(e.flags + tm0 * e.F, (int64_t)k4_rows * e.F);
+            }
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
+                // EPI 8: the pass's ids and flags, requested before the staging writes so that they are back when the rows are wanted
+                int idv[8], flv[8];
+                if constexpr (EPI == 8) {
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        const int ml = 64 * wr + 32 * a + prow + 4 * it;
+                        idv[it] = (int)__builtin_amdgcn_raw_buffer_load_b32(k4_id, ml * 4, 0, 0);
+                        flv[it] = (int)__builtin_amdgcn_raw_buffer_load_b8(k4_fl, ml * e.F + k4_f, 0, 0);
+                    }
+                }
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -316,58 +345,70 @@ __global__ __launch_bounds__(1024) void h2_occ_nt_kernel(RsArgs g, K4Args e) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (one wave, in-order LDS: written before it is read)
                 const int64_t rbase = tm0 + 64 * wr + 32 * a + prow;
                 if constexpr (EPI == 8) {
-                    const int f = (tn0 >> 6) + wc;                      // (uniform) this wave's field; past the last one: nothing to do
-                    if (f < e.F) {
-                        const int64_t rb = e.row_base[f];
-                        const bool has_lin = e.lin_w != nullptr;
-                        const float* losrc = has_lin ? e.lin_old_t + (int64_t)f * g.M : e.d_fm_logit;
+                    if (k4_on) {                                        // (uniform) this wave's field exists
+                        // Everything below is addressed through buffer resources built once per tile with 32-bit offsets relative to the
+                        // tile's first row (no 64-bit address arithmetic per lane, no address registers across the loads), and every
+                        // store is UNCONDITIONAL: a lane that must not write is given an offset past the end of its resource (and far from
+                        // 2^32, where offset + size would wrap), which the memory unit drops -- the updated table row for a unique slot, the
+                        // gradient row into d_concat for the others.
+                        const int ml0 = 64 * wr + 32 * a + prow;       // row within the tile of this lane's group 0 (+ 4 it)
+                        unsigned voff[4];
+                        bool uq[4];
+                        u32x4 t[4];
+                        // (EXPLICIT waits for everything loaded here.  hipcc counts vmcnt as if loads and stores retired in issue order; they do
+                        // not -- a register spill to scratch or a store the memory unit drops is acknowledged at once -- and with one of
+                        // those between a load and its use the counted wait the compiler inserts is satisfied early: measured, the FM term
+                        // computed from a sum_x that had not arrived)
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(idv[0]), "+v"(idv[1]), "+v"(idv[2]), "+v"(idv[3]), "+v"(idv[4]), "+v"(idv[5]), "+v"(idv[6]),
+                                     "+v"(idv[7]), "+v"(flv[0]), "+v"(flv[1]), "+v"(flv[2]), "+v"(flv[3]), "+v"(flv[4]), "+v"(flv[5]), "+v"(flv[6]), "+v"(flv[7]));
 #pragma unroll
                         for (int half = 0; half < 2; ++half) {
-                            f32x4 v[4];
-                            float4 t[4], sx[4];
-                            float dl[4], lo[4];
-                            int64_t row[4];
-                            bool uq[4];
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
                                 const int it = 4 * half + i;
-                                switch (it) {
-#define OCC_R(I) case I: OCC_DS_READ_B128(v[I & 3], st_rd, I * 1024); break;
-                                    OCC_R(0) OCC_R(1) OCC_R(2) OCC_R(3) OCC_R(4) OCC_R(5) OCC_R(6) OCC_R(7)
-#undef OCC_R
-                                }
-                                const int64_t m = rbase + 4 * it, mc = m < g.M ? m : g.M - 1;
-                                const int id = e.ids_t[(int64_t)f * g.M + mc];
-                                uq[i] = m < g.M && id >= 0 && e.flags[mc * e.F + f] != 0;
-                                row[i] = rb + max(id, 0);
-                                dl[i] = e.d_fm_logit[mc];
-                                lo[i] = losrc[mc];
-                                sx[i] = *reinterpret_cast<const float4*>(e.sum_x + mc * 64 + pc4);
+                                uq[i] = ml0 + 4 * it < k4_rows && idv[it] >= 0 && flv[it] != 0;
+                                voff[i] = (unsigned)max(idv[it], 0) * 256u + (unsigned)pc4 * 4u;
+                                t[i] = __builtin_amdgcn_raw_buffer_load_b128(k4_t, (int)voff[i], 0, 2);      // (aux 2 = nt)
                             }
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {               // (all ids first: the row loads depend on them)
-                                const f32x4 tv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(e.table + row[i] * 64 + pc4));
-                                t[i] = make_float4(tv[0], tv[1], tv[2], tv[3]);
-                            }
-                            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+                            f32x4 v[4];
+                            u32x4 sx[4];
+                            float dl[4], lo[4];
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
-                                const int64_t m = rbase + 4 * (4 * half + i);
+                                const int ml = ml0 + 4 * (4 * half + i);
+                                dl[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(k4_dl, ml * 4, 0, 0));
+                                lo[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(k4_lo, ml * 4, 0, 0));
+                                sx[i] = __builtin_amdgcn_raw_buffer_load_b128(k4_sx, ml * 256 + pc4 * 4, 0, 0);
+                            }
+                            // the group's four staged rows: reads AND their wait in one asm statement -- with the wait apart the compiler,
+                            // short of registers here, copied / spilled the destinations before the data had arrived
+                            if (half == 0)
+                                asm volatile("ds_read_b128 %0, %4 offset:0\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\t"
+                                             "ds_read_b128 %3, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+                                             : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(st_rd) : "memory");
+                            else
+                                asm volatile("ds_read_b128 %0, %4 offset:4096\n\tds_read_b128 %1, %4 offset:5120\n\tds_read_b128 %2, %4 offset:6144\n\t"
+                                             "ds_read_b128 %3, %4 offset:7168\n\ts_waitcnt lgkmcnt(0)"
+                                             : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(st_rd) : "memory");
+                            asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(sx[0]), "+v"(sx[1]), "+v"(sx[2]), "+v"(sx[3]),
+                                         "+v"(dl[0]), "+v"(dl[1]), "+v"(dl[2]), "+v"(dl[3]), "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]));
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int ml = ml0 + 4 * (4 * half + i);
+                                const f32x4 tv = __builtin_bit_cast(f32x4, t[i]), sv = __builtin_bit_cast(f32x4, sx[i]);
                                 // emb_bwd_unique_body's arithmetic (g += dl (sx - x) ; x = fma(scale, g, x))
                                 float4 gq = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
-                                gq.x += dl[i] * (sx[i].x - t[i].x); gq.y += dl[i] * (sx[i].y - t[i].y);
-                                gq.z += dl[i] * (sx[i].z - t[i].z); gq.w += dl[i] * (sx[i].w - t[i].w);
-                                float4 r = t[i];
-                                r.x = fmaf(e.scale, gq.x, r.x); r.y = fmaf(e.scale, gq.y, r.y);
-                                r.z = fmaf(e.scale, gq.z, r.z); r.w = fmaf(e.scale, gq.w, r.w);
-                                // ONE unconditional 16-byte store per lane: the updated table row (unique) or the gradient row for the
-                                // duplicate pass (shared / missing) -- address and value selected, no store under a divergent branch
-                                float* dst = uq[i] ? e.table + row[i] * 64 + pc4 : e.d_concat + (m < g.M ? m : g.M - 1) * e.ld_dc + 64 * f + pc4;
-                                const f32x4 o = uq[i] ? f32x4{r.x, r.y, r.z, r.w} : v[i];
-                                if (uq[i]) cmax = fmaxf(cmax, fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w))));
-                                if (tm0 + BM <= g.M) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(dst));
-                                else if (m < g.M) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(dst));
-                                if (has_lin && uq[i] && pc4 == 0) e.lin_w[row[i]] = fmaf(e.scale, dl[i], lo[i]);
+                                gq.x += dl[i] * (sv[0] - tv[0]); gq.y += dl[i] * (sv[1] - tv[1]);
+                                gq.z += dl[i] * (sv[2] - tv[2]); gq.w += dl[i] * (sv[3] - tv[3]);
+                                f32x4 r;
+                                r[0] = fmaf(e.scale, gq.x, tv[0]); r[1] = fmaf(e.scale, gq.y, tv[1]);
+                                r[2] = fmaf(e.scale, gq.z, tv[2]); r[3] = fmaf(e.scale, gq.w, tv[3]);
+                                if (uq[i]) cmax = fmaxf(cmax, fmaxf(fmaxf(fabsf(r[0]), fabsf(r[1])), fmaxf(fabsf(r[2]), fabsf(r[3]))));
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r), k4_t, uq[i] ? (int)voff[i] : (int)0xffffff00u, 0, 2);
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[i]), k4_dc,
+                                                                       (uq[i] || ml >= k4_rows) ? (int)0x80000000u : ml * k4_ldc4 + pc4 * 4, 0, 2);
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaf(e.scale, dl[i], lo[i])), k4_lw,
+                                                                      (uq[i] && pc4 == 0) ? (int)(voff[i] >> 6) : (int)0x80000000u, 0, 0);
                             }
                         }
                     }
