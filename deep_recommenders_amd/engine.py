@@ -206,7 +206,8 @@ class DeepFMEngine:
         self.h2 = (ops.get_gemm_split() == "f16x2" and self.no_concat and self.wplanes[0] is not None
                    and not self.adam_tf and _os.environ.get("DR_OVERLAP_DW", "0") != "1")
         if self.h2:
-            self.wplanes[0] = ops.H2WeightPlanes(self.Ws[0])
+            # (two W images: the fused dgrad + K4 of step s reads the old one while the refresh behind step s's wgrad writes the other)
+            self.wplanes[0] = ops.H2WeightPlanes(self.Ws[0], double_buffer=True)
             self.tab_amax = ops.h2_amax(self.table)
             self._tab_ver = (self.table.data_ptr(), self.table._version)
             self.dense_amax = ops.h2_record(device) if self.dense_pad is not None else None
@@ -259,6 +260,16 @@ class DeepFMEngine:
         self.lin_side = (sorted_bwd and optimizer == "sgd" and _os.environ.get("DR_LIN_SIDE", "0") == "1")
         # (the library reads the same variable once per process, with the same rule: off iff the value STARTS with '0')
         self._k4_det = not _os.environ.get("DR_K4_DETERMINISTIC", "1").startswith("0")
+        # Round 6: K4's unique-row pass as the EPILOGUE of the first layer's dgrad (dr_h2_dgrad_emb_sgd, csrc/h2_occ.hip).  The dgrad's
+        # output tile for (example m, field f) IS the gradient row of slot (m, f); the separate K4 read it back from d_concat 0.2 ms
+        # after the dgrad had written it -- 0.88 GB of the step's HBM traffic for nothing.  Fused, a slot whose table row no other slot
+        # shares gets K4's update straight from the accumulators (same operations, bit-identical tables:
+        # tests/test_gpu_fused_k4.py); the few shared rows go through d_concat and K4's duplicate pass as before.  The first-layer
+        # wgrad, which gathers x from the tables, moves IN FRONT of the dgrad.  Needs the f16x2 split, SGD, the sorted plan, no
+        # concat, D == 64 and the forward's saved first-order weights.  DR_FUSE_K4=0: dgrad, wgrad, K4 as in round 5.
+        self.fuse_k4 = (_os.environ.get("DR_FUSE_K4", "1") != "0" and self.h2 and optimizer == "sgd" and sorted_bwd and self.no_concat
+                        and D == 64 and not self.lin_side and not self.sort_inline and self.lin_old_t is not None
+                        and self.Ws[0].shape[0] >= F * D)
         # The step's three small reduce kernels -- the fused head's finish (partials -> Dense(1) step + loss), the narrow backward's
         # reduce (partials -> its weight step) and the first-layer wgrad's split-K reduce -- on the SIDE stream (round 4;
         # DR_REDUCE_SIDE=0: on the training stream as before).  Nothing in the rest of the step reads what they write; on the training
@@ -273,6 +284,7 @@ class DeepFMEngine:
         self._small_pending = False
         self._planes_pending = False
         self._planes_pending_l0 = False
+        self._k4_fused_done = False
         self._in_train_step = False
         self._early_issued = False
         # First-layer wgrad on a second stream, concurrent with the HBM-bound K4 on the training stream.  It paid next to the
@@ -656,6 +668,10 @@ class DeepFMEngine:
                     self._k("linear_bwd_narrow_L%d" % i, "hbm", 4.0 * self.B * (2 * W.shape[0] + W.shape[1]), lambda: narrow(3))
                 dy = dx
                 continue
+            if i == 0 and self.fuse_k4 and self._lin_old_valid and not adam and not self.overlap_dw:
+                self._backward_l0_fused_k4(x, dy, sc, dstW, dstb, fl)
+                dy = None
+                continue
             # dx first (uses the pre-update W), then the wgrad (with the fused SGD step unless Adam)
             if i == 0 and self.h2:
                 if not (n > 1 and self.fuse_narrow and self.narrow_ws[1] is not None):
@@ -707,6 +723,8 @@ class DeepFMEngine:
             dy = dx
         if adam:
             self._adam_finish()
+        elif self._k4_fused_done:
+            self._k4_fused_done = False
         elif self.sorted_bwd:
             if not (self._plan_prefetched and self.lean_events):
                 torch.cuda.current_stream().wait_event(self.ev_sorted)
@@ -740,6 +758,46 @@ class DeepFMEngine:
             self._small_pending = False
         if self.overlap_dw and not adam:
             torch.cuda.current_stream().wait_event(self.ev_dw)     # next step's forward reads the updated first layer
+
+    def _backward_l0_fused_k4(self, x, dy, sc, dstW, dstb, fl):
+        """First layer's backward with K4 fused into the dgrad (see fuse_k4): wgrad (gathers x from the still un-updated tables; its
+        fused SGD step moves W0 but not the planes the dgrad reads) -> dgrad + K4's unique rows -> K4's duplicate pass, hot rows and
+        first-order bias.  The plane refresh waits for the dgrad."""
+        lr = self.lr
+        torch.cuda.current_stream().wait_event(self.ev_sorted)             # the plan's flags (long complete when prefetched)
+        self._k("linear_bwd_dw_L0", "mfma", fl, lambda: self._wgrad(0, x, dy, sc, dstW, dstb))
+        # The weight just moved: its planes follow on the side stream, BESIDE the dgrad, which keeps reading the previous W image and
+        # record (H2WeightPlanes(double_buffer=True): the refresh writes the other pair) -- the next forward waits for nothing.
+        w_old = self.wplanes[0].w
+        self.ev_dw_done.record()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.ev_dw_done)
+            self.wplanes[0].refresh()
+            self.ev_planes.record(self.side)
+        self._planes_pending = True
+        self._planes_pending_l0 = True
+        # the next batch's dense features (and, unless they went out at the start of the step, its hash + plan) behind the refresh: the
+        # wgrad was the last reader of dense_pad
+        early = self._early_issued
+        mark = self._prefetch_mark()
+        if early:
+            self._prefetch_issue(mark)
+        if not self._k4_det:
+            ops.emb_snapshot_sorted_rows(self.plan, self.table, self.R, self.x_sorted)
+        tab_amax = self.tab_amax if not self._exp_no_k4_amax else None
+        # bytes this kernel must move: SURVEY 8(d)'s K4 figure minus the 4FD read of d_concat that no longer exists, plus the dgrad's dy
+        work = self.alg_bytes_bwd() - 4.0 * self.B * self.F * self.D + 4.0 * self.B * dy.shape[1]
+        self._k("emb_pool_bwd_fused_dgrad_L0", "hbm", work,
+                lambda: ops.h2_dgrad_emb_sgd(dy, self.dh0_amax, w_old, self._ids_t[self.cur], self.plan, self.row_base, self.table,
+                                             self.lin_w, self.lin_old_t, self.sum_x, self.d_logit, -lr, self.d_concat, table_amax=tab_amax))
+        k4 = lambda parts: ops.emb_pool_bwd_sorted(self.ids, self.row_base, self.plan, self.D, self.R, self.d_concat, self.d_logit, -lr,
+                                                   self.table, self.lin_w, self.lin_bias, sum_x=self.sum_x, x_sorted=self.x_sorted,
+                                                   parts=parts | 8, lin_old_t=self.lin_old_t, table_amax=tab_amax)
+        self._k("emb_pool_bwd_dups", "hbm", 0, lambda: k4(1))
+        self._k("emb_hot_rows_apply", "hbm", 0, lambda: k4(2))
+        if not early:
+            self._prefetch_issue(mark)
+        self._k4_fused_done = True
 
     def _launch_sort(self):
         """The slot sort depends only on ids and is needed only by K4: it runs on a side stream.  It is HBM-bound like K3 and,

@@ -1337,12 +1337,16 @@ def h2_wgrad_emb(ids_t, row_base, table, table_amax, dense_pad, dense_amax, dy, 
 class H2WeightPlanes:
     """WeightPlanes in the f16x2 mode: W^T and W as two fp16 planes each, one amax record; refresh() = dr_h2_amax + two dr_h2_split."""
 
-    def __init__(self, W):
+    def __init__(self, W, double_buffer=False):
+        """double_buffer: refresh() writes the W image (`w`) and the record into a SECOND buffer pair and then makes them current, so a
+        kernel still reading the previous `w` (with the previous record) may run beside the refresh -- the caller keeps the H2Planes
+        object it took before calling refresh().  `wt` is single: nothing may read it while a refresh runs."""
         K, N = W.shape
         self.W = W
         self.amax = h2_record(W.device)
         self.wt = H2Planes(N, K, W.device, self.amax)
         self.w = H2Planes(K, N, W.device, self.amax)
+        self._w_alt = H2Planes(K, N, W.device, h2_record(W.device)) if double_buffer else None
         self._parts = None
         self.refresh()
 
@@ -1352,6 +1356,10 @@ class H2WeightPlanes:
         if self._parts is None:
             self._parts = torch.zeros(256, dtype=torch.int32, device=self.W.device)
         K, N = self.W.shape
+        if self._w_alt is not None:
+            self.w, self._w_alt = self._w_alt, self.w
+            self.amax = self.w.amax
+            self.wt.amax = self.amax
         check(lib().dr_h2_refresh_weight(ptr(self.W), self.W.stride(0), K, N, ptr(self.w.buf), self.w.plane_stride, self.w.ld,
                                          ptr(self.wt.buf), self.wt.plane_stride, self.wt.ld, ptr(self.amax), ptr(self._parts),
                                          stream_ptr()), "dr_h2_refresh_weight")

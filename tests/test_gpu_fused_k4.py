@@ -107,3 +107,40 @@ def test_fused_dgrad_k4_against_fp64(ops):
     assert err <= 2e-6 * want.abs().max().item()
     wl = s["lin"][idc].double() - lr * s["dl"].double()[:, None]
     assert ((l1[idc].double() - wl).abs() * flags).max().item() <= 1e-7
+
+
+@pytest.mark.parametrize("V,zipf", [(3000, False), (200000, False), (50000, True)])
+def test_engine_with_fused_k4_is_bit_identical_to_the_three_kernel_backward(V, zipf, monkeypatch):
+    """DeepFMEngine's default step (wgrad -> dgrad + K4's unique rows -> duplicate pass) against DR_FUSE_K4=0 (dgrad -> wgrad -> K4):
+    same arithmetic in every kernel, so parameters and losses must be bit-identical over prefetched steps -- many shared rows
+    (V = 3000), mostly unique rows, and a skewed batch whose hot rows take the parked-pieces path."""
+    from deep_recommenders_amd.engine import DeepFMEngine
+    F, B, Nd, D = 5, 2304, 3, 64
+    g = torch.Generator(device="cuda")
+    g.manual_seed(21)
+    def keys():
+        if zipf:
+            u = torch.rand((B, F), device="cuda", generator=g)
+            return (1.0 / (u + 1e-4)).long()                      # heavy head: a few keys hundreds of times
+        return torch.randint(0, 10**12, (B, F), device="cuda", generator=g)
+    batches = [(keys(), torch.rand((B, Nd), device="cuda", generator=g), (torch.rand(B, device="cuda", generator=g) < 0.3).float())
+               for _ in range(3)]
+
+    def run():
+        eng = DeepFMEngine(F, V, D, [256, 16], B, num_dense=Nd, lr=0.05, seed=3, lin_init_std=0.1)
+        losses = []
+        for n in range(5):
+            k, d, l = batches[n % 3]
+            nk, nd = batches[(n + 1) % 3][0], batches[(n + 1) % 3][1]
+            losses.append(float(eng.train_step(k, d, l, next_keys=nk, next_dense=nd).item()))
+        torch.cuda.synchronize()
+        return eng, losses
+    fused, l1 = run()
+    assert fused.fuse_k4 and fused.h2
+    monkeypatch.setenv("DR_FUSE_K4", "0")
+    plain, l0 = run()
+    assert not plain.fuse_k4
+    assert l1 == l0
+    assert torch.equal(fused.table, plain.table) and torch.equal(fused.lin_w, plain.lin_w) and torch.equal(fused.lin_bias, plain.lin_bias)
+    assert torch.equal(fused.flat_params, plain.flat_params)
+    assert torch.equal(fused.tab_amax, plain.tab_amax)
