@@ -46,6 +46,15 @@ MFMA_F16X2_PEAK_TF = MFMA_BF16_PEAK_TF / 3.0
 H2_KERNELS = ("emb_linear_fwd_L0", "linear_bwd_dx_L0", "linear_bwd_dw_L0")
 
 
+def _lib_sha256():
+    try:
+        import hashlib
+        p = os.path.join(ROOT, "deep_recommenders_amd", "lib", "libdr_hotpath.so")
+        return hashlib.sha256(open(p, "rb").read()).hexdigest()
+    except Exception:
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -574,15 +583,22 @@ def main():
     traffic, traffic_source = {}, None
     traffic_note = "HBM counters need the profiler (rocprofv3 --pmc passes of this command, tools/collect_profiles.sh); not collected inside bench.py"
     try:
-        src = next(("profiles/%s_pmc_traffic.json" % r for r in ("r05", "r04", "r03", "r02", "r01")
+        src = next(("profiles/%s_pmc_traffic.json" % r for r in ("r06", "r05", "r04", "r03", "r02", "r01")
                     if os.path.exists(os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % r))), "profiles/r01_pmc_traffic.json")
         pmc = json.load(open(os.path.join(ROOT, src)))
         name_map = pmc.get("event_names") or {}
+        # the static figures describe the LIBRARY they were collected on (tools/collect_profiles.sh records its sha256): a kernel change
+        # that doubled the traffic must not keep printing the old number -- a different library gets no figure
+        lib_sha = _lib_sha256()
+        if pmc.get("lib_sha256") and lib_sha and pmc["lib_sha256"] != lib_sha:
+            raise RuntimeError("collected on libdr_hotpath.so %s..., this run loads %s...: re-collect with tools/collect_profiles.sh"
+                               % (pmc["lib_sha256"][:12], lib_sha[:12]))
         default_cfg = (a.model, a.batch, a.fields, a.vocab, a.dim, a.dense, a.dnn, a.optimizer, a.gemm) == \
             ("deepfm", 65536, 26, 10_000_000, 64, 13, "256,32", "sgd", "bf16x3")
         if default_cfg and world == 1 and not force_sharded:
             traffic = {ev: int(pmc["kernels"][k]["hbm_bytes_corrected"]) for ev, k in name_map.items() if k in pmc["kernels"]}
-            traffic_source = src + " (static: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run)"
+            traffic_source = src + (" (static: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command by tools/collect_profiles.sh, "
+                                    "not this run; collected on the library this run loads: sha256 %s)" % (lib_sha or "?")[:400])
             if getattr(eng, "h2", False) and pmc.get("gemm_split", "bf16x3") != "f16x2":
                 # the committed passes were taken with the first layer's GEMMs in the bf16x3 mode: their byte counts (three weight planes
                 # per k-tile, not two) do not describe the f16x2 kernels this run timed.  K4 and the tail kernels are the same code.
@@ -594,7 +610,7 @@ def main():
                             "bf16x3, one GPU); this run differs, so no traffic figure applies" % src)
     except Exception as e:
         traffic = {}
-        traffic_note = "no committed PMC file readable (%r)" % (e,)
+        traffic_note = "no static PMC figure applies (%s)" % (e,)
     roof_all = []
     comm_phases = {}
     overlapped = {}
@@ -639,6 +655,15 @@ def main():
                                "survey_8d_k3_bytes_plus_output": int(sv + 4.0 * a.batch * N0) if sv else None,
                                "note": "K3 (gather + first-order + FM) runs inside this GEMM; the fraction is on the bytes the kernel must move, "
                                        "the section-8(d) figure beside it still counts a concat write this kernel no longer does"}
+        if name == "emb_pool_bwd_fused_dgrad_L0":
+            # the first layer's dgrad with K4's unique-row pass as its epilogue: priced on the bytes it must move; its matrix side stated too
+            Fq, Dq, N0 = a.fields, a.dim, int(dnn_units[0]) if dnn_units else 1
+            fl = 2.0 * a.batch * Fq * Dq * N0
+            row["mfma_side"] = {"flops": fl, "TFLOPs": round(fl / sec / 1e12, 1), "frac_of_f16x2_ceiling": round(fl / sec / 1e12 / MFMA_F16X2_PEAK_TF, 4)}
+            row["note"] = ("dx = dy W^T for the 64 F embedding columns (f16x2 split) + K4's SGD update of every table row unique in the batch, applied from "
+                           "the accumulators: bytes = SURVEY 8(d)'s K4 figure 12FD + 16F minus the 4FD read of d_concat, which no longer exists, plus the "
+                           "read of dy; the rows several slots share go through emb_pool_bwd_dups.  DR_FUSE_K4=0 runs linear_bwd_dx_L0 + emb_pool_bwd instead "
+                           "(roofline_bwd_bare)")
         if k.get("note"):
             row["note"] = k["note"]
         if k.get("concurrent_with"):
@@ -702,6 +727,17 @@ def main():
                              "scope": "the bare gather + pool forward (dr_emb_pool_fwd: K3 + first-order + FM terms, concat stored; SURVEY 8(d) "
                                       "bytes 8FD + 12F + 8 per example) on the last batch, ALONE after the timed region -- in the timed step K3 runs "
                                       "inside emb_linear_fwd_L0 (see that row's hbm_side); DR_FUSE_K3=0 puts this kernel into the step"}
+    roofline_bwd_bare = None
+    if k4_alone_us is not None and getattr(eng, "fuse_k4", False):
+        bb = float(eng.alg_bytes_bwd())
+        ach = bb / (k4_alone_us * 1e-6) / 1e9
+        roofline_bwd_bare = {"kernel": "emb_pool_bwd", "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(ach / HBM_PEAK_GBS, 4), "avg_us": round(k4_alone_us, 2), "launches": 10, "alg_bytes": int(bb),
+                             "traffic": traffic.get("emb_pool_bwd"),
+                             "scope": "K4 as a kernel of its own (dr_emb_pool_bwd_sorted_ex, SURVEY 8(d) bytes 12FD + 16F per example: it reads the gradient "
+                                      "rows back from d_concat) on the last batch, ALONE after the timed region -- in the timed step its unique-row pass is "
+                                      "the epilogue of the first-layer dgrad (emb_pool_bwd_fused_dgrad_L0), which never writes those rows; DR_FUSE_K4=0 puts "
+                                      "this kernel into the step"}
     # measured copy ceiling next to the spec peak: the library's own streaming copy (dr_copy_nt: 16-byte
     # nontemporal loads / stores, the guide's "float4 copy") over 1 GiB, read + write bytes.  (Rounds 1-4 timed a torch copy here,
     # which K4 exceeded: not a ceiling.)
@@ -791,6 +827,10 @@ def main():
             if copy_gbs is not None:
                 roofline_fwd_bare["frac_of_measured_copy_ceiling"] = round(roofline_fwd_bare["achieved"] / copy_gbs, 4)
             out["roofline_fwd_bare"] = roofline_fwd_bare
+        if roofline_bwd_bare is not None:
+            if copy_gbs is not None:
+                roofline_bwd_bare["frac_of_measured_copy_ceiling"] = round(roofline_bwd_bare["achieved"] / copy_gbs, 4)
+            out["roofline_bwd_bare"] = roofline_bwd_bare
         if roof_pairs:
             out["roofline_pairs"] = roof_pairs
         out.update(extra)
@@ -802,6 +842,36 @@ def main():
             out["NOT_A_MEASUREMENT"] = "--share-device: all ranks on cuda:0, collectives staged through the host over gloo (data-path check only)"
         if overlapped:
             out["overlapped_side_stream"] = overlapped
+        # The same job with every product formed from EXACT operand splits (six bf16 MFMA products: 24-bit operands, i.e. fp32 operand
+        # arithmetic) beside the headline, whose first-layer GEMMs carry 22-bit operands (f16x2 split): a second engine, same seed, same
+        # batches, as many steps as the headline engine had run when its loss was read; the last 20 of them timed.
+        if (world == 1 and not force_sharded and a.model == "deepfm" and a.gemm == "bf16x3" and getattr(eng, "h2", False)
+                and a.optimizer == "sgd" and os.environ.get("DR_BENCH_STRICT", "1") == "1"):
+            prev_split = dr_ops.set_gemm_split("bf16x3")
+            try:
+                from deep_recommenders_amd.engine import DeepFMEngine
+                eng2 = DeepFMEngine(a.fields, a.vocab, a.dim, dnn_units, a.batch, num_dense=a.dense, lr=a.lr, device=device, optimizer=a.optimizer)
+                step2 = lambda i: eng2.train_step(*batches[i % nb], next_keys=batches[(i + 1) % nb][0], next_dense=batches[(i + 1) % nb][1])
+                total, n_t = a.warmup + settle_steps + a.steps, min(20, a.steps)
+                for i in range(total - n_t):
+                    step2(i)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(total - n_t, total):
+                    step2(i)
+                torch.cuda.synchronize()
+                ms2 = (time.perf_counter() - t1) / n_t * 1e3
+                loss2 = float(eng2.loss.item())
+                out["strict_fp32"] = {"gemm_split": "bf16x3", "ms_per_step": round(ms2, 4), "steps_timed": n_t, "steps_run": total,
+                                      "final_loss": round(loss2, 6), "headline_final_loss": round(loss, 6),
+                                      "rel_diff_of_final_loss": float("%.3g" % (abs(loss2 - loss) / max(abs(loss2), 1e-30))),
+                                      "note": "same seed, batches and step count as the headline engine; every GEMM product from exact three-way bf16 splits "
+                                              "(fp32 operand arithmetic, fp32 accumulate) -- the headline's first-layer GEMMs use the f16x2 split (22-bit operands)"}
+                del eng2, step2
+            except Exception as e:
+                out["strict_fp32"] = {"failed": repr(e)}
+            finally:
+                dr_ops.set_gemm_split(prev_split)
         if world == 1 and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(a, dnn_units)

@@ -13,6 +13,17 @@ import os as _os
 # micro-batches' forwards, RCCL's own) and two streams that share a queue run in line: 1.97 instead of 1.67 ms per step at world 1
 # (profiles/r05_sharded_step_boundary.log).  Read when the HIP runtime initialises, so it has to be in the environment before the first
 # device call; a value the user set wins.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# NOTE -- an import side effect on the whole process (every HIP user in it gets 8 queues), and a no-op when HIP is already up:
+if "GPU_MAX_HW_QUEUES" not in _os.environ:
+    _os.environ["GPU_MAX_HW_QUEUES"] = "8"
+    try:
+        import sys as _sys
+        _t = _sys.modules.get("torch")
+        if _t is not None and _t.cuda.is_initialized():
+            import warnings as _w
+            _w.warn("deep_recommenders_amd: the HIP runtime was initialised before this import, so GPU_MAX_HW_QUEUES=8 cannot take effect; "
+                    "export it before the first device call (the sharded engines' streams otherwise share 4 hardware queues)")
+    except Exception:
+        pass
 
 __version__ = "0.1.0"

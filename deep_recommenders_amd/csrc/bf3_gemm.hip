@@ -2459,6 +2459,9 @@ int rs_launch(const RsArgs& g, hipStream_t stream) {
     // buys nothing -- so it is opt-in (DR_BF3_STAGGER=1)
     static const bool stg = [] { const char* e = getenv("DR_BF3_STAGGER"); return e != nullptr && e[0] == '1'; }();
     if (g.mask != nullptr && g.accumulate) return DR_EINVAL;            // (no caller needs both)
+    // the kernels address B's planes through ONE buffer resource with 32-bit offsets: planes further apart than that would be clamped
+    // away and read as zeros without any error -- refuse instead
+    if ((int64_t)(g.a_amax != nullptr ? 2 : 3) * g.b_ps * 2 > (int64_t)0x7fffffff) return DR_EINVAL;
     if (g.a_amax != nullptr) {                                          // f16x2 operand mode
         if (g.b_amax == nullptr) return DR_EINVAL;
         if (g.c_amax != nullptr && hipMemsetAsync(g.c_amax, 0, sizeof(uint32_t), stream) != hipSuccess) return DR_ELAUNCH;

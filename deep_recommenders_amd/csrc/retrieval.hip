@@ -384,12 +384,17 @@ static int topk_mips_impl(const float* q, int64_t Bq, const float* cand, const v
     const bool h2 = rs_scan && dr_get_gemm_split() == DR_GEMM_SPLIT_F16X2;      // read at every call (dr_set_gemm_split)
     uint32_t* rec_q = reinterpret_cast<uint32_t*>(wsb + Bq * 8);
     const uint32_t* rec_c = rec_q + 1;
-    const bool pre = h2 && index != nullptr;                                    // the corpus' planes and record come with the index
+    // the corpus' planes and record come with the index -- unless its plane stride no longer fits the GEMM kernel's 32-bit buffer
+    // offsets (2 planes x rows x ld x 2 bytes > 2^31: ~8.3 M items at D = 128): plane 1 would fall behind the resource's clamped
+    // range and read as zeros, i.e. the scan would silently run on the h terms alone.  Such a corpus is split per chunk
+    // into the workspace like an un-indexed one; only the index' record is used.
+    const int64_t idx_ps = topk_index_rows(N) * (((int64_t)D + 31) / 32 * 32);
+    const bool pre = h2 && index != nullptr && 2 * idx_ps * 2 <= (int64_t)0x7fffffff;
     if (h2) {
         int rc = dr_h2_amax(q, D, Bq, D, rec_q, 1, stream);
-        if (rc == DR_OK && !pre) rc = dr_h2_amax(cand, D, N, D, rec_q + 1, 1, stream);
+        if (rc == DR_OK && index == nullptr) rc = dr_h2_amax(cand, D, N, D, rec_q + 1, 1, stream);
         if (rc != DR_OK) return rc;
-        if (pre) rec_c = const_cast<uint32_t*>(static_cast<const uint32_t*>(index));
+        if (index != nullptr) rec_c = const_cast<uint32_t*>(static_cast<const uint32_t*>(index));
     }
     const int64_t p_rows = pre ? topk_index_rows(N) : (scan + 31) / 32 * 32, p_ld = ((int64_t)D + 31) / 32 * 32, p_ps = p_rows * p_ld;
     if (rs_scan && !pre && (D % 32) != 0)      // the reduction padding of the planes must be zero (the kernel multiplies it)

@@ -766,17 +766,35 @@ class TopKIndex:
     Corpora the planes do not cover (D not a multiple of 4, D > 512, empty) keep `buf` None and take the plain path."""
 
     def __init__(self, cand):
+        # `cand` must be the caller's own fp32 tensor: staleness is detected through ITS version counter (a copy made here would
+        # never see the caller's later writes; writes through raw pointers -- another library -- are not seen either: call rebuild())
         self.cand = _c(cand, torch.float32)
+        self.follows_caller = self.cand is cand
         N, D = self.cand.shape
         self.buf = None
-        if N > 0 and D % 4 == 0 and 4 <= D <= 512 and self.cand.is_cuda:
-            self.buf = torch.empty(lib().dr_topk_index_bytes(N, D) // 4, dtype=torch.float32, device=self.cand.device)
-            assert self.buf.data_ptr() % 256 == 0
+        self._able = N > 0 and D % 4 == 0 and 4 <= D <= 512 and self.cand.is_cuda
         self._ver = None
         self.ensure_fresh()
 
+    def _wanted(self):
+        # the planes are only read by the f16x2 scan on the matrix-pipe GEMM mode (dr_topk_mips_indexed ignores them otherwise): a second
+        # copy of the corpus is not allocated for a split that will not use it (ADVICE r5) -- it is built on the first use that does
+        return self._able and get_gemm_split() == "f16x2" and get_gemm_mode() == "bf16x3"
+
     def ensure_fresh(self):
-        if self.buf is not None and self._ver != self.cand._version:
+        if not self._wanted():
+            return
+        if self.buf is None:
+            N, D = self.cand.shape
+            self.buf = torch.empty(lib().dr_topk_index_bytes(N, D) // 4, dtype=torch.float32, device=self.cand.device)
+            assert self.buf.data_ptr() % 256 == 0
+            self._ver = None
+        if self._ver != self.cand._version:
+            self.rebuild()
+
+    def rebuild(self):
+        """Recompute the record and the planes from the corpus as it stands (also after writes torch's version counter cannot see)."""
+        if self.buf is not None:
             N, D = self.cand.shape
             check(lib().dr_topk_index_build(ptr(self.cand), N, D, ptr(self.buf), self.buf.numel() * 4, stream_ptr()), "dr_topk_index_build")
             self._ver = self.cand._version
@@ -797,8 +815,9 @@ def topk_mips(q, cand, k, index_base=0, init=True, state=None, workspace=None):
         state = topk_state(Bq, k, q.device)
     if workspace is None:
         workspace = torch.empty(max(1, lib().dr_topk_workspace_bytes(Bq, N, int(k)) // 4), dtype=torch.float32, device=q.device)
-    if index is not None and index.buf is not None:
+    if index is not None:
         index.ensure_fresh()
+    if index is not None and index.buf is not None and index._wanted():
         rc = lib().dr_topk_mips_indexed(ptr(q), Bq, ptr(cand), ptr(index.buf), N, D, int(k), int(index_base), int(bool(init)),
                                         ptr(state[0]), ptr(state[1]), ptr(workspace), workspace.numel() * 4, stream_ptr())
     else:

@@ -479,7 +479,11 @@ class _NullCtx:
         return False
 
 
-_FUSE_PACK_DEFAULT = "1"      # DR_FUSE_PACK's default: on since round 5 (f16x2 epilogue through the LDS: world-1 step 1.62 -> 1.55 ms, profiles/r05_sharded_fuse_pack.log)
+# DR_FUSE_PACK's default: on since round 5 IN THE f16x2 SPLIT (its epilogue turns the accumulators through the LDS: world-1 step 1.62 ->
+# 1.55 ms, profiles/r05_sharded_fuse_pack.log); in the bf16x3 split the fused form is the old 4-bytes-per-lane epilogue, measured 27 %
+# slower than dgrad + pack (400 us against 173 + 143): off there unless DR_FUSE_PACK=1 asks for it
+def _fuse_pack_default(h2):
+    return "1" if h2 else "0"
 
 
 class ShardedDeepFMEngine:
@@ -627,8 +631,9 @@ class ShardedDeepFMEngine:
         # fields (one slot per (example, field)).  Round 4's epilogue (bf16x3: 4-byte scattered stores, a lane owning one column of
         # 16 rows) lost to dgrad + pack (400 us against 173 + 143 per half batch); round 5's, in the f16x2 split, turns each
         # accumulator block through the LDS and moves float4s with 8 lanes on a row.  DR_FUSE_PACK=0 / 1 (default: see _fuse_pack_default).
-        self.fuse_pack = (use_planes and _os.environ.get("DR_FUSE_PACK", _FUSE_PACK_DEFAULT) == "1" and D == 64 and num_fields <= 64
-                          and not self.ex.dedup)
+        _will_h2 = (self.fuse_k3 and ops.get_gemm_split() == "f16x2" and not (self.fuse_head and len(self.Ws) - 2 == 0))     # (= self.h2 below)
+        self.fuse_pack = (use_planes and _os.environ.get("DR_FUSE_PACK", _fuse_pack_default(_will_h2)) == "1" and D == 64
+                          and num_fields <= 64 and not self.ex.dedup)
         # streams for the later micro-batches' fused first layers (see train_step); DR_FWD_STREAMS=0: all on the training stream
         self.fwd_streams = ([torch.cuda.Stream(device=device) for _ in range(max(0, min(mb - 1, 3)))]
                             if (self.fuse_k3 and _os.environ.get("DR_FWD_STREAMS", "1") == "1") else [])

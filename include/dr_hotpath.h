@@ -501,6 +501,10 @@ int dr_inbatch_softmax_grad_scores_ws(const float* q, const float* c, int64_t B,
  * index_base, -1 = empty slot).  init = 1 starts a new search, init = 0 continues one (Streaming's
  * per-batch map + reduce, :201-233).  Returns DR_ESHAPE if init && k > N (the reference's
  * "input must have at least k columns", :13-23).
+ * A CONTINUED search (init = 0) must be handed its batches with non-decreasing index_base, as Streaming does (its counter-based row
+ * ids, :244-254): the chunk GEMM's filter epilogue keeps a candidate only if its score is strictly above the row's current k-th
+ * best, so a candidate that TIES that score wins its lower-index tie only against entries of LATER batches -- with index_base going
+ * backwards an equal-score, lower-index candidate could be dropped or kept depending on where a chunk boundary falls.
  * dr_topk_merge: merge two sorted lists per row, list a wins ties (Streaming's reduce; cross-rank merge).
  * ---------------------------------------------------------------------------------------- */
 int dr_scores_nt(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t M, int32_t N, int32_t D,

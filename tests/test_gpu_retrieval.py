@@ -178,6 +178,34 @@ def test_topk_index_gives_the_same_bits_and_follows_the_corpus(Bq, N, D, k):
     assert int((i1 == 5).sum()) > 0
 
 
+def test_topk_index_whose_planes_are_further_apart_than_2gb_still_scans_both_terms():
+    """the GEMM kernels reach the second fp16 plane of the corpus through a 32-bit buffer offset; an index of N = 600 000
+    items x D = 512 puts it 2.3 GB behind the first -- past the resource's range, where loads return zeros and the scan would run on
+    the h terms alone, silently (1e-3 score errors, ties lost).  dr_topk_mips_indexed must then split per chunk like the un-indexed scan:
+    same bits as dr_topk_mips, and both against an fp64 brute force."""
+    from deep_recommenders_amd import ops
+    g = torch.Generator(device="cuda")
+    g.manual_seed(9)
+    Bq, N, D, k = 64, 600_000, 512, 20
+    q = torch.randn((Bq, D), device="cuda", generator=g) / D ** 0.5
+    corpus = torch.randn((N, D), device="cuda", generator=g) / D ** 0.5
+    corpus[N - 7] = corpus[123]                                      # an exact tie across the whole corpus
+    index = ops.TopKIndex(corpus)
+    s0, i0 = ops.topk_mips(q, corpus, k)
+    s1, i1 = ops.topk_mips(q, index, k)
+    assert torch.equal(s0, s1) and torch.equal(i0, i1)
+    ref = torch.empty((Bq, N), dtype=torch.float64, device="cuda")
+    for c0 in range(0, N, 100_000):
+        ref[:, c0:c0 + 100_000] = q.double() @ corpus[c0:c0 + 100_000].double().t()
+    rs, ri = torch.sort(ref, dim=1, descending=True, stable=True)
+    want = rs[:, :k]
+    assert float((s1.double() - want).abs().max()) <= 3e-6 * float(want.abs().max())       # fp32-grade scores: BOTH terms were multiplied
+    # index sets agree wherever the fp64 scores are further apart than that
+    gap_ok = (rs[:, k - 1] - rs[:, k]) > 1e-5
+    same = torch.sort(i1, dim=1).values == torch.sort(ri[:, :k], dim=1).values
+    assert bool(same[gap_ok].all())
+
+
 @pytest.mark.parametrize("N,nlist", [(100_003, 1024), (5000, 1), (70_000, 8192), (300, 7)])
 def test_ivf_build_lists_is_a_stable_counting_sort(N, nlist):
     """dr_ivf_build_lists == np.argsort(assign, kind="stable") + the list boundaries (bit-exact); assignments outside [0, nlist) drop

@@ -60,12 +60,18 @@ def main():
     event_names = {"emb_linear_fwd_L0": pick("bf3_emb_linear_kernel<1>", "bf3_emb_linear_kernel<0>", "bf3_emb_linear_kernel"),
                    "emb_pool_fwd": "emb_pool_fwd_sv_kernel<16,8>",
                    "emb_pool_bwd": "emb_bwd_sorted_kernel<16,4,false>", "hash_bucket_i64": "hash_bucket_i64_kernel",
+                   "emb_pool_bwd_fused_dgrad_L0": "h2_occ_nt_kernel<8,0>",
                    "linear_fwd_L0": pick("bf3_gemm_rs_kernel<0,0,1,1,1>", "bf3_gemm_rs_kernel<0,0,1,1,0>", "bf3_gemm_rs_kernel<0,0,1,1>"),
                    "linear_bwd_dx_L0": pick("bf3_gemm_rs_kernel<0,0,1,1,1>", "bf3_gemm_rs_kernel<0,0,1,1,0>", "bf3_gemm_rs_kernel<0,0,1,1>"),
                    "tower_tail_fused": pick("tower_tail_fused_kernel<8>", "tower_tail_fused_kernel<4>"),
                    "linear_bwd_dw_L0": pick("bf3_gemm_tn_rs_kernel<1,1>", "bf3_gemm_tn_rs_kernel<1,0>", "bf3_gemm_tn_rs_kernel<1>")}
     h2 = any(n.endswith(",1,1,1>") or n in ("bf3_emb_linear_kernel<1>", "bf3_gemm_tn_rs_kernel<1,1>") for n in event_names.values() if n in kernels)
-    json.dump({"_note": note, "kernels": kernels, "event_names": event_names, "gemm_split": "f16x2" if h2 else "bf16x3"},
+    import hashlib
+    import os
+    lib = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "deep_recommenders_amd", "lib", "libdr_hotpath.so")
+    lib_sha = hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None
+    json.dump({"_note": note, "kernels": kernels, "event_names": event_names, "gemm_split": "f16x2" if h2 else "bf16x3",
+               "lib_sha256": lib_sha},
               open(out_path, "w"), indent=1, sort_keys=True)
     for k, v in kernels.items():
         print("%-60s %10.1f MB" % (k, v["hbm_bytes_corrected"] / 1e6))
