@@ -212,6 +212,9 @@ class DeepFMEngine:
             self._tab_ver = (self.table.data_ptr(), self.table._version)
             self.dense_amax = ops.h2_record(device) if self.dense_pad is not None else None
             self.dh0_amax = ops.h2_record(device)
+            self._amax_scratch = ops.h2_record(device)
+        self._tighten_every = int(_os.environ.get("DR_AMAX_TIGHTEN_STEPS", "2048"))
+        self._steps_since_tighten = 0
         # (timing experiment only -- the record goes stale: K4 without the running maximum, to price the tracking)
         self._exp_no_k4_amax = _os.environ.get("DR_EXP_K4_NO_AMAX", "0") == "1"
         # The slot sort of batch s + 1 next to K4 of batch s (DR_PREFETCH_PLAN=0: every step hashes and sorts its own batch).  K4 is
@@ -872,7 +875,23 @@ class DeepFMEngine:
         finally:
             self._in_train_step = False
         self._next_keys = self._next_dense = None
+        if self.h2 and self._tighten_every > 0:
+            self._steps_since_tighten += 1
+            if self._steps_since_tighten >= self._tighten_every:
+                self.tighten_amax()
         return self.loss
+
+    def tighten_amax(self):
+        """Recompute the table's amax record exactly (f16x2 mode).  K4 keeps it as a RUNNING maximum -- an upper bound that never comes
+        down: after one outlier row, or when training shrinks the embeddings, every other value would carry fewer than its 22 bits for
+        ever.  One pass over the slab on the training stream, BETWEEN two steps (nothing raises or reads the record
+        meanwhile): 66.6 GB at ~5 TB/s = 13 ms at config 3, every DR_AMAX_TIGHTEN_STEPS steps (default 2048: 6 us per step; 0 = never).
+        The new value goes into a scratch record first and replaces the old one with a 4-byte copy."""
+        if not self.h2:
+            return
+        ops.h2_amax(self.table, self._amax_scratch)
+        self.tab_amax.copy_(self._amax_scratch)
+        self._steps_since_tighten = 0
 
     # algorithmic bytes of the two embedding kernels per step (SURVEY.md §8d)
     def alg_bytes_fwd(self):
