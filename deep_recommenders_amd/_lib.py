@@ -88,6 +88,7 @@ SIGNATURES = {
     "dr_ivf_scan": [_p, _i64, _i32, _p, _i32, _p, _p, _p, _i32, _p, _p, _p],
     "dr_topk_merge": [_p, _p, _i32, _p, _p, _i32, _i64, _i32, _p, _p, _p],
     "dr_rowdot": [_p, _p, _i64, _i32, _p, _p],
+    "dr_rows_scale": [_p, _p, _i32, _p, _i64, _i32, _p, _p],
     "dr_gather_i64": [_p, _i64, _p, _i64, _p, _p],
     "dr_take_along_rows_f32": [_p, _i64, _i64, _i32, _p, _i32, _p, _p],
     "dr_take_along_rows_i64": [_p, _i64, _i64, _i32, _p, _i32, _p, _p],

@@ -505,6 +505,35 @@ extern "C" int dr_rowdot(const float* a, const float* b, int64_t B, int32_t D, f
     return DR_OK;
 }
 
+namespace {
+// out[r, :] = x[r, :] * f(s[r]).  mode 0: f = s;  mode 1: f = 1 / sqrt(s) for s > 0, 1 for s == 0 (faiss.normalize_L2 on squared
+// norms: zero rows stay);  mode 2: f = 1 / s for s > 0 and the row is taken from `fallback` for s == 0 (a k-means centroid = sum of its
+// members / their count; an empty cluster keeps its centroid).
+__global__ __launch_bounds__(256) void rows_scale_kernel(const float* __restrict__ x, const float* __restrict__ s, int mode,
+                                                         const float* __restrict__ fallback, int64_t M, int32_t D, float* __restrict__ out) {
+    const int64_t total = M * D, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t r = i / D;
+        const float sv = s[r], xv = x[i];
+        float o;
+        if (mode == 0) o = xv * sv;
+        else if (mode == 1) o = sv > 0.f ? xv / sqrtf(sv) : xv;
+        else o = sv > 0.f ? xv / sv : fallback[i];
+        out[i] = o;
+    }
+}
+}  // namespace
+
+extern "C" int dr_rows_scale(const float* x, const float* s, int32_t mode, const float* fallback, int64_t M, int32_t D, float* out,
+                             dr_stream_t stream) {
+    if (M < 0 || D <= 0 || mode < 0 || mode > 2) return DR_EINVAL;
+    if (M == 0) return DR_OK;
+    if (!x || !s || !out || (mode == 2 && !fallback)) return DR_EINVAL;
+    hipLaunchKernelGGL(rows_scale_kernel, dim3(dr_grid_for(M * D, 256)), dim3(256), 0, dr_s(stream), x, s, mode, fallback, M, D, out);
+    DR_CHECK_LAUNCH();
+    return DR_OK;
+}
+
 extern "C" int dr_gather_i64(const int64_t* src, int64_t nsrc, const int64_t* idx, int64_t n, int64_t* out, dr_stream_t stream) {
     if (n < 0 || nsrc < 0) return DR_EINVAL;
     if (n == 0) return DR_OK;

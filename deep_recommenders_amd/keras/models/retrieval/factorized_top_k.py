@@ -187,8 +187,8 @@ class Faiss(TopK):
 
     @staticmethod
     def _normalize_L2(x):
-        n = torch.linalg.vector_norm(x, dim=1, keepdim=True)
-        return x / torch.where(n > 0, n, torch.ones_like(n))                      # faiss.normalize_L2 leaves zero rows alone
+        x = x.contiguous()
+        return ops.rows_scale(x, ops.rowdot(x, x), mode=1)                        # x / |x|; faiss.normalize_L2 leaves zero rows alone
 
     def _assign(self, x, centroids):
         _, best = ops.topk_mips(x, centroids, 1)                                  # coarse quantizer = exact inner product
@@ -203,19 +203,17 @@ class Faiss(TopK):
         g = torch.Generator(device=cand.device)
         g.manual_seed(self._seed)
         centroids = cand[torch.randperm(N, device=cand.device, generator=g)[:self._nlist]].clone()
-        if self._nlist == 1:
-            return cand.mean(0, keepdim=True)
         # the cluster sizes ride along with the sums in the scatter-add's first-order channel (a ones vector as the per-row scalar):
         # one launch per iteration; the list build -- hist + scan + scatter -- is only needed once, by index() (fp32 counts are exact
         # to 2^24 members per cluster)
         ones = torch.ones(N, dtype=torch.float32, device=cand.device)
-        for _ in range(self._niter):
-            a = self._assign(cand, centroids)
+        for _ in range(1 if self._nlist == 1 else self._niter):
+            # (one list: every vector belongs to it -- its centroid is the mean, through the same two launches)
+            a = self._assign(cand, centroids) if self._nlist > 1 else torch.zeros(N, dtype=torch.int64, device=cand.device)
             sums = torch.zeros((self._nlist, D), dtype=torch.float32, device=cand.device)
             counts = torch.zeros(self._nlist, dtype=torch.float32, device=cand.device)
             ops.rows_scatter_add(a, cand, ones, 1.0, sums, counts)
-            counts = counts.reshape(-1, 1)
-            centroids = torch.where(counts > 0, sums / counts.clamp(min=1.0), centroids)     # an empty cluster keeps its centroid
+            centroids = ops.rows_scale(sums, counts, mode=2, fallback=centroids.contiguous())   # an empty cluster keeps its centroid
         return centroids
 
     def index(self, candidates, identifiers=None) -> "Faiss":

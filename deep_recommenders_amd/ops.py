@@ -892,6 +892,19 @@ def topk_merge(sa, ia, sb, ib, k):
     return out
 
 
+def rows_scale(x, s, mode=0, fallback=None, out=None):
+    """out[r, :] = x[r, :] * f(s[r]) (dr_rows_scale): mode 0 f = s; 1 f = 1 / sqrt(s), rows with s == 0 unchanged; 2 f = 1 / s, rows with
+    s == 0 taken from `fallback`."""
+    x = _c(x, torch.float32)
+    s = _c(s, torch.float32).reshape(-1)
+    M, D = x.shape
+    assert s.numel() == M and (fallback is None or (fallback.shape == x.shape and fallback.is_contiguous()))
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().dr_rows_scale(ptr(x), ptr(s), int(mode), ptr(fallback), M, D, ptr(out), stream_ptr()), "dr_rows_scale")
+    return out
+
+
 def rowdot(a, b):
     a = _c(a, torch.float32)
     b = _c(b, torch.float32)

@@ -560,6 +560,12 @@ int dr_topk_merge(const float* sa, const int64_t* ia, int32_t ka, const float* s
  * (:57-62); FactorizedTopK's in_top_k counting (:499-512, [TF] B14); and the sbcnm helper layers on explicit
  * logits: out = logits - log(p_j) (:86) + (dup_ij - labels_ij) * MIN_FLOAT (:66-75) + labels_ij * scale (:44) */
 int dr_rowdot(const float* a, const float* b, int64_t B, int32_t D, float* out, dr_stream_t stream);
+/* out[r, :] = x[r, :] * f(s[r]) for contiguous [M, D] matrices -- the row scalings of the `Faiss` index (factorized_top_k.py:370-371,
+ * 450-451: faiss.normalize_L2; :372: index.train's centroid update).  mode 0: f = s.  mode 1: f = 1 / sqrt(s), rows with s == 0 unchanged
+ * (s = dr_rowdot(x, x): L2 normalisation that leaves zero rows alone).  mode 2: f = 1 / s, rows with s == 0 taken from `fallback`
+ * [M, D] (centroid = member sum / member count; an empty cluster keeps its previous centroid).  out may alias x. */
+int dr_rows_scale(const float* x, const float* s, int32_t mode, const float* fallback, int64_t M, int32_t D, float* out,
+                  dr_stream_t stream);
 int dr_gather_i64(const int64_t* src, int64_t nsrc, const int64_t* idx, int64_t n, int64_t* out,
                   dr_stream_t stream);
 int dr_take_along_rows_f32(const float* arr, int64_t ld, int64_t B, int32_t C, const int64_t* idx, int32_t K,

@@ -178,6 +178,26 @@ def test_topk_index_gives_the_same_bits_and_follows_the_corpus(Bq, N, D, k):
     assert int((i1 == 5).sum()) > 0
 
 
+def test_rows_scale_modes():
+    """dr_rows_scale: the `Faiss` index' row scalings (faiss.normalize_L2 with zero rows left alone, factorized_top_k.py:370-371 of the
+    reference; the k-means centroid = member sum / count with empty clusters kept, :372) -- bit-exact against the same fp32 expressions."""
+    from deep_recommenders_amd import ops
+    g = torch.Generator(device="cuda")
+    g.manual_seed(2)
+    x = torch.randn((1000, 20), device="cuda", generator=g)
+    x[7] = 0
+    s = ops.rowdot(x, x).reshape(-1)
+    n = ops.rows_scale(x, s, mode=1)
+    want = torch.where(s[:, None] > 0, x / torch.sqrt(s)[:, None], x)
+    assert torch.equal(n, want) and bool((n[7] == 0).all())
+    assert float((n.norm(dim=1)[torch.arange(1000, device="cuda") != 7] - 1).abs().max()) < 1e-6
+    cnt = torch.randint(0, 4, (1000,), device="cuda", generator=g).float()
+    fb = torch.randn((1000, 20), device="cuda", generator=g)
+    m = ops.rows_scale(x, cnt, mode=2, fallback=fb)
+    assert torch.equal(m, torch.where(cnt[:, None] > 0, x / cnt[:, None].clamp(min=1.0), fb))
+    assert torch.equal(ops.rows_scale(x, cnt, mode=0), x * cnt[:, None])
+
+
 def test_topk_index_whose_planes_are_further_apart_than_2gb_still_scans_both_terms():
     """the GEMM kernels reach the second fp16 plane of the corpus through a 32-bit buffer offset; an index of N = 600 000
     items x D = 512 puts it 2.3 GB behind the first -- past the resource's range, where loads return zeros and the scan would run on
