@@ -414,20 +414,24 @@ def main():
         step(i)
     torch.cuda.synchronize()
     # Settling (single process only; untimed, like the warm-up): further blocks of 20 steps until two consecutive blocks agree within 2 %
-    # (or 3 s have passed).  The W warm-up steps cover the chip's ramp; this covers the HOST: the step needs 0.33 ms of launch work per
+    # (or 5 s have passed).  The W warm-up steps cover the chip's ramp; this covers the HOST: the step needs 0.33 ms of launch work per
     # 1.14 ms of GPU work, and on a box that is still busy with its own start-up (seen twice as the first command of a call: 1.52 and
     # 2.69 ms lines whose per-kernel times were normal) the launches fall behind for a few seconds.  Normally 2 blocks = 46 ms.
     settle_steps = 0
     if dist is None and a.warmup > 0 and os.environ.get("DR_BENCH_SETTLE", "1") == "1":
-        prev_t, t_begin = None, time.perf_counter()
-        while settle_steps < 4000 and time.perf_counter() - t_begin < 3.0:
+        prev_t, best_t, t_begin = None, None, time.perf_counter()
+        while settle_steps < 6000 and time.perf_counter() - t_begin < 5.0:
             t1 = time.perf_counter()
             for i in range(20):
                 step(a.warmup + settle_steps + i)
             torch.cuda.synchronize()
             cur_t = time.perf_counter() - t1
             settle_steps += 20
-            if prev_t is not None and abs(cur_t - prev_t) <= 0.02 * prev_t:
+            best_t = cur_t if best_t is None else min(best_t, cur_t)
+            # (round 6: two blocks that agree are not enough -- on a host busy with its neighbours' start-up the launches fall behind at
+            # a STABLE slow rate for a second or two, seen as a 1.31 ms line between 1.03 ms ones; the block must also be within 5 % of
+            # the fastest block seen so far)
+            if prev_t is not None and abs(cur_t - prev_t) <= 0.02 * prev_t and cur_t <= 1.05 * best_t:
                 break
             prev_t = cur_t
     if dist is not None:

@@ -68,7 +68,8 @@ struct K4Args {
 // (its loads re-read k-tile 0), 64 = no split / no A image writes
 template <int EPI, int DBG = 0>
 __global__ __launch_bounds__(1024) void h2_occ_nt_kernel(RsArgs g, K4Args e) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+    // (EPI 8: + 8 KB behind the ring for the epilogue's per-row scalars -- ONE __shared__ object on purpose)
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE + (EPI == 8 ? 10240 : 0)];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -316,18 +317,117 @@ __global__ __launch_bounds__(1024) void h2_occ_nt_kernel(RsArgs g, K4Args e) {
                 k4_id = mk(e.ids_t + (int64_t)fc * g.M + tm0, (int64_t)k4_rows * 4);
                 k4_fl = mk(e.flags + tm0 * e.F, (int64_t)k4_rows * e.F);
             }
+            if constexpr (EPI == 8) {
+                // ---- K4's unique-row pass on the tile's 256 x 4 slots.  What bounds it is HBM LATENCY (a table row can only be asked for once
+                // its id is known, and written once it has arrived): the fewer dependent round trips per tile and the more rows in flight per
+                // round trip, the better.  So everything a slot needs BESIDES its table row is made LDS-resident first -- the tile's 256 rows
+                // of sum_x (64 KB, by LDS-DMA), d_fm_logit and the saved first-order weights -- the accumulators are staged 16 rows at a time
+                // (4 KB per wave), and a pass keeps its EIGHT row groups' table rows in flight together (32 registers, nothing else waits in
+                // registers): two HBM round trips per tile.  Everything is addressed through buffer resources with 32-bit offsets relative
+                // to the tile, and every store is UNCONDITIONAL: a lane that must not write is given an offset past the end of its resource
+                // (and far from 2^32, where offset + size would wrap), which the memory unit drops -- the updated table row for a unique
+                // slot, the gradient row into d_concat for the others.
+                constexpr unsigned SXP = 65536, DLP = 2 * STAGE, LOP = 2 * STAGE + 1024, UIP = 2 * STAGE + 1024 + 4096;   // sum_x panel / d_fm_logit [256] / lin_old [16][64] / row ids [16][64]
+                const unsigned stq = lds0 + wave * 4096;                                     // this wave's 16-row staging area
+                const unsigned stq_wr = stq + (4 * (lane_e >> 5)) * 256 + (lane_e & 31) * 4; // + ((reg & 3) + 8 ((reg >> 2) & 1)) * 256 + b * 128
+                const unsigned stq_rd = stq + prow * 256 + pc4 * 4;                          // + 4 i * 256
+                {
+                    // sum_x rows 16 wave .. + 15 of the tile (4 pieces of 4 rows: lane -> row lane / 16, 16-byte chunk lane % 16: lane-linear)
+#pragma unroll
+                    for (int p4 = 0; p4 < 4; ++p4)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(k4_sx, (lds_ptr_t)(smem + SXP + (16 * wave + 4 * p4) * 256), 16,
+                                                                 (16 * wave + 4 * p4 + (lane_e >> 4)) * 256 + (lane_e & 15) * 16, 0, 0, 0);
+                    // per-row scalars of slot (row 64 wr + lane, this wave's field): d_fm_logit, the saved first-order weight, and the slot's
+                    // row id -- or -1 when the slot is not for this pass to update (row shared with another slot, id missing, row past M)
+                    unsigned dlv = __builtin_amdgcn_raw_buffer_load_b32(k4_dl, (64 * wr + lane_e) * 4, 0, 0);
+                    unsigned lov = __builtin_amdgcn_raw_buffer_load_b32(k4_lo, (64 * wr + lane_e) * 4, 0, 0);
+                    int idl = (int)__builtin_amdgcn_raw_buffer_load_b32(k4_id, (64 * wr + lane_e) * 4, 0, 0);
+                    int fll = (int)__builtin_amdgcn_raw_buffer_load_b8(k4_fl, (64 * wr + lane_e) * e.F + k4_f, 0, 0);
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(dlv), "+v"(lov), "+v"(idl), "+v"(fll) :: "memory");
+                    const int uid = (k4_on && 64 * wr + lane_e < k4_rows && idl >= 0 && fll != 0) ? idl : -1;
+                    OCC_DS_WRITE_B32(lds0 + DLP + (64 * wr + lane_e) * 4, dlv, 0);
+                    OCC_DS_WRITE_B32(lds0 + LOP + wave * 256 + lane_e * 4, lov, 0);
+                    OCC_DS_WRITE_B32(lds0 + UIP + wave * 256 + lane_e * 4, uid, 0);
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // panel, scalars: visible to every wave
+                }
+                if (k4_on) {                                            // (uniform) this wave's field exists
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        const int ml0 = 64 * wr + 32 * a + prow;        // row within the tile of this lane's group 0 (+ 4 it)
+                        unsigned voff[8];
+                        unsigned uqm = 0;
+                        u32x4 t[8];
+#pragma unroll
+                        for (int it = 0; it < 8; ++it) {
+                            const int uidv = *reinterpret_cast<const int*>(smem + UIP + wave * 256 + (32 * a + 4 * it + prow) * 4);
+                            if (uidv >= 0) uqm |= 1u << it;
+                            voff[it] = (unsigned)max(uidv, 0) * 256u + (unsigned)pc4 * 4u;
+                            t[it] = __builtin_amdgcn_raw_buffer_load_b128(k4_t, (int)voff[it], 0, 2);       // (aux 2 = nt)
+                        }
+                        // (an EXPLICIT wait for the rows.  hipcc counts vmcnt as if loads and stores retired in issue order; they do not -- a
+                        // register spill to scratch or a store the memory unit drops is acknowledged at once -- and with one of those between
+                        // a load and its use the counted wait the compiler inserts is satisfied early: measured, an FM term computed from a
+                        // sum_x that had not arrived.  This wait also covers the previous pass's stores.)
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {                   // 16 rows at a time through the wave's 4 KB
+#pragma unroll
+                            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                                for (int r8 = 0; r8 < 8; ++r8) {
+                                    const int reg = 8 * q + r8;
+                                    const float v = acc[a][b][reg] * h2_out;
+                                    acc[a][b][reg] = 0.f;
+                                    switch (b * 8 + r8) {                // (immediates must be literal)
+#define OCC_W(I) case I: OCC_DS_WRITE_B32(stq_wr, v, ((I & 3) + 8 * ((I & 7) >> 2)) * 256 + (I >> 3) * 128); break;
+                                        OCC_W(0) OCC_W(1) OCC_W(2) OCC_W(3) OCC_W(4) OCC_W(5) OCC_W(6) OCC_W(7) OCC_W(8) OCC_W(9) OCC_W(10) OCC_W(11)
+                                        OCC_W(12) OCC_W(13) OCC_W(14) OCC_W(15)
+#undef OCC_W
+                                    }
+                                }
+                            f32x4 v[4];
+                            // the quarter's four staged rows: writes retired, reads AND their wait in one asm statement (with the wait apart
+                            // the compiler, short of registers here, copied / spilled the destinations before the data had arrived)
+                            asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %4 offset:0\n\tds_read_b128 %1, %4 offset:1024\n\t"
+                                         "ds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+                                         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(stq_rd) : "memory");
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int it = 4 * q + i;
+                                const int ml = ml0 + 4 * it;
+                                const bool uq = (uqm >> it) & 1u;
+                                const f32x4 tv = __builtin_bit_cast(f32x4, t[it]);
+                                const f32x4 sv = *reinterpret_cast<const f32x4*>(smem + SXP + ml * 256 + pc4 * 4);
+                                const float dl = *reinterpret_cast<const float*>(smem + DLP + ml * 4);
+                                const float lo = *reinterpret_cast<const float*>(smem + LOP + wave * 256 + (32 * a + 4 * it + prow) * 4);
+                                // emb_bwd_unique_body's arithmetic (g += dl (sx - x) ; x = fma(scale, g, x))
+                                float4 gq = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+                                gq.x += dl * (sv[0] - tv[0]); gq.y += dl * (sv[1] - tv[1]);
+                                gq.z += dl * (sv[2] - tv[2]); gq.w += dl * (sv[3] - tv[3]);
+                                f32x4 r;
+                                r[0] = fmaf(e.scale, gq.x, tv[0]); r[1] = fmaf(e.scale, gq.y, tv[1]);
+                                r[2] = fmaf(e.scale, gq.z, tv[2]); r[3] = fmaf(e.scale, gq.w, tv[3]);
+                                if (uq) cmax = fmaxf(cmax, fmaxf(fmaxf(fabsf(r[0]), fabsf(r[1])), fmaxf(fabsf(r[2]), fabsf(r[3]))));
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r), k4_t, uq ? (int)voff[it] : (int)0xffffff00u, 0, 2);
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[i]), k4_dc,
+                                                                       (uq || ml >= k4_rows) ? (int)0x80000000u : ml * k4_ldc4 + pc4 * 4, 0, 2);
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaf(e.scale, dl, lo)), k4_lw,
+                                                                      (uq && pc4 == 0) ? (int)(voff[it] >> 6) : (int)0x80000000u, 0, 0);
+                            }
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the quarter's reads retired before the next one's writes
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+#pragma unroll
+                            for (int reg = 0; reg < 16; ++reg) acc[a][b][reg] = 0.f;
+                }
+            } else
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
-                // EPI 8: the pass's ids and flags, requested before the staging writes so that they are back when the rows are wanted
-                int idv[8], flv[8];
-                if constexpr (EPI == 8) {
-#pragma unroll
-                    for (int it = 0; it < 8; ++it) {
-                        const int ml = 64 * wr + 32 * a + prow + 4 * it;
-                        idv[it] = (int)__builtin_amdgcn_raw_buffer_load_b32(k4_id, ml * 4, 0, 0);
-                        flv[it] = (int)__builtin_amdgcn_raw_buffer_load_b8(k4_fl, ml * e.F + k4_f, 0, 0);
-                    }
-                }
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -344,77 +444,6 @@ __global__ __launch_bounds__(1024) void h2_occ_nt_kernel(RsArgs g, K4Args e) {
                     }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (one wave, in-order LDS: written before it is read)
                 const int64_t rbase = tm0 + 64 * wr + 32 * a + prow;
-                if constexpr (EPI == 8) {
-                    if (k4_on) {                                        // (uniform) this wave's field exists
-                        // Everything below is addressed through buffer resources built once per tile with 32-bit offsets relative to the
-                        // tile's first row (no 64-bit address arithmetic per lane, no address registers across the loads), and every
-                        // store is UNCONDITIONAL: a lane that must not write is given an offset past the end of its resource (and far from
-                        // 2^32, where offset + size would wrap), which the memory unit drops -- the updated table row for a unique slot, the
-                        // gradient row into d_concat for the others.
-                        const int ml0 = 64 * wr + 32 * a + prow;       // row within the tile of this lane's group 0 (+ 4 it)
-                        unsigned voff[4];
-                        bool uq[4];
-                        u32x4 t[4];
-                        // (EXPLICIT waits for everything loaded here.  hipcc counts vmcnt as if loads and stores retired in issue order; they do
-                        // not -- a register spill to scratch or a store the memory unit drops is acknowledged at once -- and with one of
-                        // those between a load and its use the counted wait the compiler inserts is satisfied early: measured, the FM term
-                        // computed from a sum_x that had not arrived)
-                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(idv[0]), "+v"(idv[1]), "+v"(idv[2]), "+v"(idv[3]), "+v"(idv[4]), "+v"(idv[5]), "+v"(idv[6]),
-                                     "+v"(idv[7]), "+v"(flv[0]), "+v"(flv[1]), "+v"(flv[2]), "+v"(flv[3]), "+v"(flv[4]), "+v"(flv[5]), "+v"(flv[6]), "+v"(flv[7]));
-#pragma unroll
-                        for (int half = 0; half < 2; ++half) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const int it = 4 * half + i;
-                                uq[i] = ml0 + 4 * it < k4_rows && idv[it] >= 0 && flv[it] != 0;
-                                voff[i] = (unsigned)max(idv[it], 0) * 256u + (unsigned)pc4 * 4u;
-                                t[i] = __builtin_amdgcn_raw_buffer_load_b128(k4_t, (int)voff[i], 0, 2);      // (aux 2 = nt)
-                            }
-                            f32x4 v[4];
-                            u32x4 sx[4];
-                            float dl[4], lo[4];
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const int ml = ml0 + 4 * (4 * half + i);
-                                dl[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(k4_dl, ml * 4, 0, 0));
-                                lo[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(k4_lo, ml * 4, 0, 0));
-                                sx[i] = __builtin_amdgcn_raw_buffer_load_b128(k4_sx, ml * 256 + pc4 * 4, 0, 0);
-                            }
-                            // the group's four staged rows: reads AND their wait in one asm statement -- with the wait apart the compiler,
-                            // short of registers here, copied / spilled the destinations before the data had arrived
-                            if (half == 0)
-                                asm volatile("ds_read_b128 %0, %4 offset:0\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\t"
-                                             "ds_read_b128 %3, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
-                                             : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(st_rd) : "memory");
-                            else
-                                asm volatile("ds_read_b128 %0, %4 offset:4096\n\tds_read_b128 %1, %4 offset:5120\n\tds_read_b128 %2, %4 offset:6144\n\t"
-                                             "ds_read_b128 %3, %4 offset:7168\n\ts_waitcnt lgkmcnt(0)"
-                                             : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(st_rd) : "memory");
-                            asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(sx[0]), "+v"(sx[1]), "+v"(sx[2]), "+v"(sx[3]),
-                                         "+v"(dl[0]), "+v"(dl[1]), "+v"(dl[2]), "+v"(dl[3]), "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]));
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const int ml = ml0 + 4 * (4 * half + i);
-                                const f32x4 tv = __builtin_bit_cast(f32x4, t[i]), sv = __builtin_bit_cast(f32x4, sx[i]);
-                                // emb_bwd_unique_body's arithmetic (g += dl (sx - x) ; x = fma(scale, g, x))
-                                float4 gq = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
-                                gq.x += dl[i] * (sv[0] - tv[0]); gq.y += dl[i] * (sv[1] - tv[1]);
-                                gq.z += dl[i] * (sv[2] - tv[2]); gq.w += dl[i] * (sv[3] - tv[3]);
-                                f32x4 r;
-                                r[0] = fmaf(e.scale, gq.x, tv[0]); r[1] = fmaf(e.scale, gq.y, tv[1]);
-                                r[2] = fmaf(e.scale, gq.z, tv[2]); r[3] = fmaf(e.scale, gq.w, tv[3]);
-                                if (uq[i]) cmax = fmaxf(cmax, fmaxf(fmaxf(fabsf(r[0]), fabsf(r[1])), fmaxf(fabsf(r[2]), fabsf(r[3]))));
-                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r), k4_t, uq[i] ? (int)voff[i] : (int)0xffffff00u, 0, 2);
-                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[i]), k4_dc,
-                                                                       (uq[i] || ml >= k4_rows) ? (int)0x80000000u : ml * k4_ldc4 + pc4 * 4, 0, 2);
-                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaf(e.scale, dl[i], lo[i])), k4_lw,
-                                                                      (uq[i] && pc4 == 0) ? (int)(voff[i] >> 6) : (int)0x80000000u, 0, 0);
-                            }
-                        }
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    continue;
-                }
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {                  // 4 row groups at a time: short-lived temporaries
                     f32x4 v[4];
@@ -487,6 +516,10 @@ int occ_nt_launch(const RsArgs& g, hipStream_t stream) {
     // domain: the f16x2 mode's plain epilogues; 16-byte rows of C (and of the mask) so that the epilogue's float4 moves are aligned
     if (g.a_amax == nullptr || g.b_amax == nullptr) return 1;
     if (g.x0 != nullptr || g.tau != nullptr || g.pack_pos != nullptr || g.sm_part_m != nullptr || g.sm_lse != nullptr) return 1;
+    // short reductions with the plain store epilogue (the first-layer dgrad shape, K = 256: eight k-tiles per output tile) stay on the
+    // 8-wave kernel, whose pipeline runs on across tile boundaries: 266 - 279 us against 291 here; everything else measured equal or
+    // faster on this kernel (forward shape 206 vs 231, dgrad + mask 406 vs 428, 1677^2 accumulate 1264 vs 1329; tools/exp/occ_bench.py)
+    if (g.mask == nullptr && !g.accumulate && g.K < 512) return 1;
     if ((g.ldc & 3) != 0 || (reinterpret_cast<uintptr_t>(g.C) & 15) != 0) return 1;
     if (g.mask != nullptr && ((g.ld_mask & 3) != 0 || (reinterpret_cast<uintptr_t>(g.mask) & 15) != 0)) return 1;
     if (g.bias != nullptr && (reinterpret_cast<uintptr_t>(g.bias) & 15) != 0) return 1;
