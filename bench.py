@@ -495,6 +495,42 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    # N > 1, weak line: the SAME job at SURVEY 8(e)'s split as well -- a global batch of `--batch` examples divided over the ranks (strong
+    # scaling) -- so that one driver command yields both scaling curves.  A second engine on every rank (per-rank
+    # batch = batch / N), 5 warm-up + 20 timed steps bracketed like the main region; failures are reported, never fatal.
+    strong = None
+    if (world > 1 and not a.global_batch and a.model == "deepfm" and sharded and os.environ.get("DR_BENCH_STRONG", "1") == "1"
+            and a.batch % world == 0):
+        try:
+            from deep_recommenders_amd.sharded import ShardedDeepFMEngine
+            pb = a.batch // world
+            eng_s = ShardedDeepFMEngine(a.fields, a.vocab, a.dim, dnn_units, pb, num_dense=a.dense, lr=a.lr, device=device, world=world,
+                                        rank=rank, micro_batches=a.micro_batches, transport=transport,
+                                        **({"optimizer": a.optimizer} if a.optimizer != "sgd" else {}))
+            sb = [(k[:pb].contiguous(), d[:pb].contiguous() if d is not None else None, l[:pb].contiguous()) for k, d, l in batches]
+            step_s = lambda i: eng_s.train_step(*sb[i % nb], next_keys=sb[(i + 1) % nb][0])
+            n_w, n_t = 5, min(20, a.steps)
+            for i in range(n_w):
+                step_s(i)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t1 = time.perf_counter()
+            for i in range(n_t):
+                step_s(n_w + i)
+            torch.cuda.synchronize()
+            dist.barrier()
+            dts = time.perf_counter() - t1
+            tt = torch.tensor([dts], device="cpu" if a.share_device else device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dts = tt.item()
+            strong = {"scaling": "strong", "global_batch": a.batch, "per_gpu_batch": pb, "steps": n_t, "warmup": n_w,
+                      "ms_per_step": round(dts / n_t * 1e3, 4), "value": round(a.batch * n_t / dts, 1), "unit": "examples/sec",
+                      "final_loss": round(float(eng_s.loss.item()), 6),
+                      "note": "SURVEY 8(e)'s partitioning (global batch divided over the ranks), measured after the weak timed region in the same process group"}
+            del eng_s, step_s, sb
+        except Exception as e_s:
+            strong = {"failed": repr(e_s)}
+
     # the slot plan K4 needs, ALONE on the idle chip (after the timed region): what it would add to K4 if it did not run beside the
     # previous step's K4 -- the overlapped event time in `overlapped_side_stream` is stretched by that sharing
     plan_alone_us = None
@@ -842,6 +878,8 @@ def main():
             out["exchange_phases"] = comm_phases
         if exchange is not None:
             out["exchange"] = exchange
+        if strong is not None:
+            out["strong"] = strong
         if a.share_device:
             out["NOT_A_MEASUREMENT"] = "--share-device: all ranks on cuda:0, collectives staged through the host over gloo (data-path check only)"
         if overlapped:

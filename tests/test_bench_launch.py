@@ -115,3 +115,7 @@ def test_share_device_two_ranks_on_one_gpu():
         c = ex["collectives"][tag]
         assert c["bytes_sent_per_rank"] > 0 and c["avg_us"] > 0 and c["GBps_per_link"] > 0
     assert ex["exposed_us_per_step"] is not None and ex["exposed_us_per_step"] >= 0
+    # the weak line carries SURVEY 8(e)'s split too: the same global batch divided over the two ranks
+    st = d["strong"]
+    assert "failed" not in st, st
+    assert st["global_batch"] == 4096 and st["per_gpu_batch"] == 2048 and st["ms_per_step"] > 0 and 0.0 < st["final_loss"] < 5.0

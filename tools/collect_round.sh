@@ -24,12 +24,19 @@ DR_NO_CONCAT=0 timeout -s KILL 200 python bench.py --no-cpu-baseline > gpurun_ou
 DR_FORCE_SHARDED=1 timeout -s KILL 200 python bench.py --no-cpu-baseline > gpurun_out/line_sharded_world1.log 2>&1
 DR_FORCE_SHARDED=1 timeout -s KILL 300 python bench.py --model dcn --no-cpu-baseline > gpurun_out/line_dcn_sharded_world1.log 2>&1
 DR_PREFETCH_EARLY=0 timeout -s KILL 200 python bench.py --no-cpu-baseline > gpurun_out/line_plan_beside_k4.log 2>&1
+# round 6: the three-kernel backward of round 5 (dgrad, wgrad, K4) beside the fused default; the 8-wave GEMM kernel everywhere
+DR_FUSE_K4=0 DR_BENCH_STRICT=0 timeout -s KILL 200 python bench.py --no-cpu-baseline > gpurun_out/line_k4_unfused.log 2>&1
+DR_H2_OCC=0 DR_BENCH_STRICT=0 timeout -s KILL 300 python bench.py --model dcn --no-cpu-baseline > gpurun_out/line_dcn_8wave.log 2>&1
+# round 6 experiment drivers: the 16-wave kernel against the 8-wave one (bit-identity + times), the fused dgrad + K4 against dgrad + K4
+timeout -s KILL 300 python tools/exp/occ_bench.py 2>&1 | grep "OCC=" > gpurun_out/occ_bench.log
+timeout -s KILL 300 python tools/exp/fused_k4_bench.py 2>&1 | grep FUSEDK4 > gpurun_out/fused_k4_bench.log
+timeout -s KILL 300 python tools/exp/fused_k4_bench.py 2000000 zipf 2>&1 | grep FUSEDK4 >> gpurun_out/fused_k4_bench.log
 # the six-product mode of rounds 2-3 beside the default (f16x2) lines: default, DCN, sharded
 DR_GEMM_SPLIT=bf16x3 timeout -s KILL 200 python bench.py --no-cpu-baseline > gpurun_out/line_bf16x3.log 2>&1
 DR_GEMM_SPLIT=bf16x3 timeout -s KILL 300 python bench.py --model dcn --no-cpu-baseline > gpurun_out/line_dcn_bf16x3.log 2>&1
 DR_GEMM_SPLIT=bf16x3 DR_FORCE_SHARDED=1 timeout -s KILL 200 python bench.py --no-cpu-baseline > gpurun_out/line_sharded_world1_bf16x3.log 2>&1
 timeout -s KILL 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-for f in default adam zipf c2 dcn dssm unfused concat sharded_world1 dcn_sharded_world1 plan_beside_k4 bf16x3 dcn_bf16x3 sharded_world1_bf16x3; do
+for f in default adam zipf c2 dcn dssm unfused concat sharded_world1 dcn_sharded_world1 plan_beside_k4 k4_unfused dcn_8wave bf16x3 dcn_bf16x3 sharded_world1_bf16x3; do
   python - $f <<'PY'
 import json, sys
 try:
