@@ -630,9 +630,11 @@ def main():
         # the static figures describe the LIBRARY they were collected on (tools/collect_profiles.sh records its sha256): a kernel change
         # that doubled the traffic must not keep printing the old number -- a different library gets no figure
         lib_sha = _lib_sha256()
-        if pmc.get("lib_sha256") and lib_sha and pmc["lib_sha256"] != lib_sha:
-            raise RuntimeError("collected on libdr_hotpath.so %s..., this run loads %s...: re-collect with tools/collect_profiles.sh"
-                               % (pmc["lib_sha256"][:12], lib_sha[:12]))
+        if not pmc.get("lib_sha256"):
+            raise RuntimeError("%s records no library hash (collected before round 6): re-collect with tools/collect_profiles.sh" % src)
+        if not lib_sha or pmc["lib_sha256"] != lib_sha:
+            raise RuntimeError("%s was collected on libdr_hotpath.so %s..., this run loads %s...: re-collect with tools/collect_profiles.sh"
+                               % (src, pmc["lib_sha256"][:12], (lib_sha or "?")[:12]))
         default_cfg = (a.model, a.batch, a.fields, a.vocab, a.dim, a.dense, a.dnn, a.optimizer, a.gemm) == \
             ("deepfm", 65536, 26, 10_000_000, 64, 13, "256,32", "sgd", "bf16x3")
         if default_cfg and world == 1 and not force_sharded:

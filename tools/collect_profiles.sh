@@ -8,6 +8,7 @@
 # rocprofv3 only, the profiled python keeps a pipe open and the call runs into gpurun's own limit.  Give the gpurun call a --timeout
 # that matches the work (the budget left is the default ceiling).
 set -u
+export DR_BENCH_STRICT=0      # (the profiled passes time the shipped step only; the strict-fp32 sub-record is in the bench lines)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $R/gpurun_out

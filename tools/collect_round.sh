@@ -47,3 +47,6 @@ except Exception as e:
     print(sys.argv[1], "FAILED", e)
 PY
 done
+# the raw per-dispatch traces are tens of MB (gpurun merges at most 64 MiB back): the summaries above are what profiles/ keeps
+rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc_sq gpurun_out/prof_stats
+du -sh gpurun_out

@@ -3,6 +3,7 @@
 # besides the kernel trace).  Output: gpurun_out/pmc_sq/*counter_collection.csv -> tools/sq_pmc_summary.py
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
+export DR_BENCH_STRICT=0
 rm -rf $R/gpurun_out/pmc_sq
 timeout -s KILL 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES \
   --kernel-trace --output-format csv -d $R/gpurun_out/pmc_sq -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $R/gpurun_out/pmc_sq.log 2>&1
