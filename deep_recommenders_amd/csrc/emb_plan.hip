@@ -17,11 +17,17 @@
 //                        so nothing depends on arrival order -> bit-reproducible plan), writes it at its offset (partitions are
 //                        row ranges: bucket order is row order) and emits the duplicate pass's work list (segment heads).  The
 //                        "sorted" arrays then hold ONLY the m shared-row slots; dup_count[1] = m tells K4 how long they are.
-//   LARGE  m beyond that or a partition beyond its LDS table (skewed / Zipf keys, where most slots share rows), or geometry the
-//          composite key cannot hold (n > 2^24 slots, >= 2^31 - 1 rows): a plain LSD radix sort of ALL n slots by row (8-bit
-//          digits; per pass per-block histograms -> one scan block per digit -> stable scatter), then the same head / flag
-//          marking over the full list.  Every kernel of this path is always launched and returns at once unless the device-side
-//          switch says LARGE (the verdict lives on the device; the host never waits for it).
+//   LARGE  m beyond that or a partition beyond its LDS table (skewed / Zipf keys, where most slots share rows): ONE more launch
+//          (plan_large_kernel, round 6), always made, that returns at once unless the device-side switch says LARGE (the verdict
+//          lives on the device; the host never waits for it): block b sorts partition b -- the partitions are row ranges, so the
+//          concatenation of the sorted partitions is the list sorted by row -- with a block-local LSD radix sort over the bits in
+//          which the partition's rows differ, then marks flags and segment heads over the full list.  Rounds 3-5 ran a chip-wide
+//          LSD radix sort of all n slots here: 14 more launches that were always made and gated on the device; on uniform ids each
+//          of them was an empty kernel -- and an empty kernel on the side stream still costs the training stream ~2.7 us (the
+//          dispatcher has to find it a CU between the GEMMs' blocks): 38 us of a 1.06 ms step (tools/exp/exp_plan.sh).
+//          Geometry the composite key cannot hold (n > 2^24 slots, >= 2^31 - 1 rows; known on the host): the chip-wide radix sort
+//          of ALL n slots by row (8-bit digits; per pass per-block histograms -> one scan block per digit -> stable scatter), then
+//          the same head / flag marking over the full list.
 //
 // Replaces the ordering half of the autodiff of [TF] safe_embedding_lookup_sparse (IndexedSlices -> unsorted_segment_sum into the
 // variable) reached from optimizer.minimize (examples/train_fm_on_movielens_estimator.py:51-52, reference root); K4 itself is
@@ -58,6 +64,8 @@ unsigned bits_for(uint64_t v) {
     while (b < 64 && (v >> b) != 0) ++b;
     return b;
 }
+
+__device__ __forceinline__ unsigned bits_for_dev(uint32_t v) { return v == 0 ? 1u : 32u - (unsigned)__clz((int)v); }
 
 int radix_blocks(int64_t n) {
     int64_t nb = (n + RADIX_CHUNK - 1) / RADIX_CHUNK;
@@ -116,6 +124,29 @@ __global__ __launch_bounds__(256) void radix_make_keys_kernel(const int64_t* __r
     }
 }
 
+// SMALL 1a (round 6: one launch instead of make_keys + hist): block b builds the composite keys of its contiguous chunk -- the chunk
+// radix_scatter_kernel<1> re-reads -- and counts their partition digits on the way.
+__global__ __launch_bounds__(256) void plan_keys_hist_kernel(const int64_t* __restrict__ ids, int32_t n, int32_t F,
+                                                             const int64_t* __restrict__ row_base, uint64_t sentinel, uint32_t mul,
+                                                             uint64_t* __restrict__ keys, uint32_t* __restrict__ ghist) {
+    __shared__ uint32_t h[RADIX];
+    const int nb = gridDim.x, t = threadIdx.x;
+    const int32_t chunk = (n + nb - 1) / nb;
+    const int32_t beg = (int32_t)blockIdx.x * chunk, end = beg + chunk < n ? beg + chunk : n;
+    h[t] = 0;
+    __syncthreads();
+    for (int32_t p = beg + t; p < end; p += 256) {
+        const int64_t id = ids[p];
+        const uint64_t r0 = id >= 0 ? (uint64_t)(row_base[p % F] + id) : sentinel;      // (see radix_make_keys_kernel)
+        const uint64_t row = r0 < sentinel ? r0 : sentinel;
+        const uint64_t ck = (row << 24) | (uint32_t)p;
+        keys[p] = ck;
+        atomicAdd(&h[digit_of<1>(ck, mul)], 1u);
+    }
+    __syncthreads();
+    ghist[t * nb + blockIdx.x] = h[t];
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void radix_hist_kernel(const uint64_t* __restrict__ keys, int32_t n, uint32_t shift_or_mul,
                                                          uint32_t* __restrict__ ghist, const Ctrl* __restrict__ ctrl) {
@@ -134,10 +165,17 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const uint64_t* __restr
 // One block per digit d: ghist[d][0 .. nb) -> exclusive scan over the blocks (position inside the digit's range); the digit's
 // total goes to tot[d] -- the scatter blocks turn the 256 totals into range starts themselves (an LDS scan), so no block here
 // needs another digit's column and nothing is combined with atomics.
+// GATED = 0 (the SMALL path's partition pass) also zeroes the plan's device-side state, which nothing before the claim kernel
+// touches (round 6: two hipMemsetAsync launches less on the side stream).
 template <int GATED>
 __global__ __launch_bounds__(256) void radix_scan_kernel(uint32_t* __restrict__ ghist, int32_t nb, uint32_t* __restrict__ tot,
-                                                         const Ctrl* __restrict__ ctrl) {
+                                                         Ctrl* __restrict__ ctrl, int32_t* __restrict__ dup_count) {
     if (GATED && ctrl->large == 0) return;
+    if (!GATED && blockIdx.x == 0) {
+        int32_t* c = reinterpret_cast<int32_t*>(ctrl);
+        for (int i = threadIdx.x; i < (int)(sizeof(Ctrl) / 4); i += 256) c[i] = 0;
+        if (threadIdx.x < 2) dup_count[threadIdx.x] = 0;
+    }
     __shared__ uint32_t part[256];
     const int t = threadIdx.x, d = blockIdx.x;
     const int32_t per = (nb + 255) / 256;
@@ -403,6 +441,141 @@ __global__ __launch_bounds__(256) void radix_mark_kernel(const uint64_t* __restr
     for (int j = t; j < nh; j += 256) dup_heads[gbase + j] = hl[j];
 }
 
+// ---- LARGE in one launch (claimable geometry): block b sorts partition b by (row, slot), then marks it -------------------------
+// The partition pass left partition b -- the slots whose row falls into the b-th of 256 row ranges -- as composite keys
+// (row << 24 | slot) at [beg, beg + cnt) of `ka`, in slot order.  A block-local LSD radix sort (8-bit digits of row - min row, as
+// many passes as that difference has digits; stable, so equal rows stay in slot order) ping-pongs between `ka` and the same range
+// of `rows` (both n x 8 bytes) and ends in `ka`; then rows / slots / flags / heads are written exactly as radix_mark_kernel
+// writes them over the chip-wide sort's output: the list K4's duplicate pass walks is the same list (the order of dup_heads is
+// arrival order in both).  Any partition size is taken (one block walks it 1024 keys at a time: a field whose every example
+// carries the same id is 65 536 keys = 64 steps per pass); Zipf batches at config 3 have 4 - 15 K keys per partition.
+constexpr int LG_T = 1024, LG_W = LG_T / 64;
+__global__ __launch_bounds__(LG_T) void plan_large_kernel(uint64_t* __restrict__ ka, const uint32_t* __restrict__ tot,
+                                                          uint64_t num_rows, int32_t n, uint64_t* __restrict__ rows,
+                                                          int32_t* __restrict__ slots, uint8_t* __restrict__ flags,
+                                                          int32_t* __restrict__ dup_heads, int32_t* __restrict__ dup_count,
+                                                          const Ctrl* __restrict__ ctrl) {
+    if (ctrl->large == 0) return;
+    __shared__ uint32_t running[RADIX];
+    __shared__ uint32_t wcnt[LG_W][RADIX];
+    __shared__ uint32_t starts[RADIX];
+    __shared__ uint32_t rmin, rmax;
+    __shared__ int32_t nh, gbase;
+    const int t = threadIdx.x, b = blockIdx.x, w = t >> 6, lane = t & 63;
+    if (t < RADIX) starts[t] = tot[t];
+    if (t == 0) { rmin = 0xFFFFFFFFu; rmax = 0u; }
+    if (b == 0 && t == 0) dup_count[1] = n;
+    __syncthreads();
+    uint32_t beg = 0;
+    for (int i = 0; i < b; ++i) beg += starts[i];
+    const int32_t cnt = (int32_t)starts[b];
+    uint64_t* src = ka + beg;
+    uint64_t* dst = rows + beg;
+    // the bits in which this partition's rows differ (rows < 2^31 here: 32-bit LDS atomics)
+    {
+        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+        for (int32_t i = t; i < cnt; i += LG_T) {
+            const uint32_t r = (uint32_t)(src[i] >> 24);
+            lo = r < lo ? r : lo;
+            hi = r > hi ? r : hi;
+        }
+        if (lo <= hi) { atomicMin(&rmin, lo); atomicMax(&rmax, hi); }
+    }
+    __syncthreads();
+    const uint32_t base_row = rmin;
+    int passes = 0;
+    if (cnt > 1 && rmax > rmin) passes = (int)((bits_for_dev(rmax - rmin) + RADIX_BITS - 1) / RADIX_BITS);
+    if (passes & 1) {                                                 // an odd number of passes must START in `rows` to end in `ka`
+        for (int32_t i = t; i < cnt; i += LG_T) dst[i] = src[i];
+        uint64_t* x = src; src = dst; dst = x;
+        __syncthreads();
+    }
+    for (int p = 0; p < passes; ++p) {
+        const uint32_t shift = (uint32_t)(p * RADIX_BITS);
+        if (t < RADIX) running[t] = 0;
+        __syncthreads();
+        for (int32_t i = t; i < cnt; i += LG_T)
+            atomicAdd(&running[(((uint32_t)(src[i] >> 24) - base_row) >> shift) & (RADIX - 1)], 1u);
+        __syncthreads();
+        {   // exclusive scan of the 256 digit counts (every thread passes every barrier)
+            const uint32_t mine = t < RADIX ? running[t] : 0u;
+            for (int o = 1; o < RADIX; o <<= 1) {
+                const uint32_t x = (t < RADIX && t >= o) ? running[t - o] : 0u;
+                __syncthreads();
+                if (t < RADIX) running[t] += x;
+                __syncthreads();
+            }
+            if (t < RADIX) running[t] -= mine;
+        }
+        __syncthreads();
+        for (int32_t base = 0; base < cnt; base += LG_T) {            // block-uniform trip count
+            const int32_t i = base + t;
+            const bool live = i < cnt;
+            const uint64_t k = live ? src[i] : 0ull;
+            const uint32_t d = (((uint32_t)(k >> 24) - base_row) >> shift) & (RADIX - 1);
+#pragma unroll
+            for (int q = 0; q < LG_W * RADIX / LG_T; ++q) (&wcnt[0][0])[q * LG_T + t] = 0;
+            __syncthreads();
+            uint64_t mask = __ballot(live);
+#pragma unroll
+            for (int bb = 0; bb < RADIX_BITS; ++bb) {
+                const bool bit = (d >> bb) & 1u;
+                const uint64_t vote = __ballot(bit);
+                mask &= bit ? vote : ~vote;
+            }
+            const uint32_t rank_in_wave = __popcll(mask & ((1ull << lane) - 1ull));
+            if (live && rank_in_wave == 0) wcnt[w][d] = __popcll(mask);
+            __syncthreads();
+            uint32_t pos = 0;
+            if (live) {
+                pos = running[d] + rank_in_wave;
+                for (int ww = 0; ww < w; ++ww) pos += wcnt[ww][d];
+            }
+            __syncthreads();                                          // every read of running[] precedes its update
+            if (t < RADIX) {
+                uint32_t add = 0;
+#pragma unroll
+                for (int ww = 0; ww < LG_W; ++ww) add += wcnt[ww][t];
+                running[t] += add;
+            }
+            if (live) dst[pos] = k;
+            __syncthreads();
+        }
+        uint64_t* x = src; src = dst; dst = x;
+    }
+    // `src` == ka + beg holds the partition sorted by (row, slot): decode + mark (cf. radix_mark_kernel; positions are global)
+    for (int32_t base = 0; base < cnt; base += LG_T) {
+        const int32_t i = base + t;
+        const bool in = i < cnt;
+        const uint64_t ck = in ? src[i] : ~0ull;
+        const uint64_t k = ck >> 24;
+        const int32_t gi = (int32_t)beg + i;
+        const bool valid = in && k < num_rows;
+        const bool seg_start = in && (i == 0 || (src[i - 1] >> 24) != k);          // a row never straddles partitions
+        const bool has_next = in && (i + 1 < cnt) && (src[i + 1] >> 24) == k;
+        if (in) {
+            const int32_t slot = (int32_t)(ck & 0xFFFFFFu);
+            rows[gi] = k;
+            slots[gi] = slot;
+            flags[slot] = (valid && seg_start && !has_next) ? 1 : 0;
+        }
+        const bool head = valid && ((seg_start && has_next) || (!seg_start && (gi % CH) == 0 && i >= CH && (src[i - CH] >> 24) == k));
+        if (t == 0) nh = 0;
+        __syncthreads();
+        const uint64_t bal = __ballot(head);
+        int wbase = 0;
+        const int leader = bal != 0 ? __ffsll((unsigned long long)bal) - 1 : 0;
+        if (bal != 0 && lane == leader) wbase = atomicAdd(&nh, __popcll(bal));
+        __syncthreads();
+        if (t == 0) gbase = nh > 0 ? atomicAdd(dup_count, nh) : 0;                 // one global atomic per 1024 keys
+        __syncthreads();
+        if (bal != 0) {
+            wbase = __shfl(wbase, leader, 64);
+            if (head) dup_heads[gbase + wbase + __popcll(bal & ((1ull << lane) - 1ull))] = gi;
+        }
+    }
+}
+
 }  // namespace
 
 // Test / tuning hook: the largest shared-row list the SMALL path takes (default and maximum 16384); 0 sends every batch that has
@@ -443,8 +616,6 @@ extern "C" int dr_emb_sort_slots(const int64_t* ids, int64_t B, int32_t F, const
     const int grid = dr_grid_for(n, 256);
     const int nb = radix_blocks(n);
 
-    if (hipMemsetAsync(ctrl, 0, sizeof(Ctrl), s) != hipSuccess) return DR_ELAUNCH;
-    if (hipMemsetAsync(dup_count, 0, 2 * sizeof(int32_t), s) != hipSuccess) return DR_ELAUNCH;
     // the composite key holds 24 bits of slot and the LDS table 31 bits of row; anything larger sorts all slots
     const bool claimable = n64 <= (1 << 24) && num_rows < 0x7fffffffLL;
     if (claimable) {
@@ -452,10 +623,9 @@ extern "C" int dr_emb_sort_slots(const int64_t* ids, int64_t B, int32_t F, const
         const uint32_t mul = (uint32_t)((((uint64_t)RADIX) << 32) / (uint64_t)num_rows);
         // one block per CU: the 256 x 256 write frontiers of the partitions stay resident in the L2s
         const int nbs = nb < 256 ? nb : 256;
-        hipLaunchKernelGGL((radix_make_keys_kernel<0>), dim3(grid), dim3(256), 0, s, ids, n, F, row_base, (uint64_t)num_rows, rows_y,
-                           slots_y, ctrl);
-        hipLaunchKernelGGL((radix_hist_kernel<1>), dim3(nbs), dim3(256), 0, s, rows_y, n, mul, ghist, ctrl);
-        hipLaunchKernelGGL((radix_scan_kernel<0>), dim3(RADIX), dim3(256), 0, s, ghist, (int32_t)nbs, tot, ctrl);
+        hipLaunchKernelGGL(plan_keys_hist_kernel, dim3(nbs), dim3(256), 0, s, ids, n, F, row_base, (uint64_t)num_rows, mul, rows_y,
+                           ghist);
+        hipLaunchKernelGGL((radix_scan_kernel<0>), dim3(RADIX), dim3(256), 0, s, ghist, (int32_t)nbs, tot, ctrl, dup_count);
         hipLaunchKernelGGL((radix_scatter_kernel<1>), dim3(nbs), dim3(256), 0, s, rows_y, slots_y, keys_x, vals_x, n, mul, ghist, tot,
                            ctrl);
         // (dynamic LDS beyond 64 KB needs the opt-in)
@@ -468,10 +638,16 @@ extern "C" int dr_emb_sort_slots(const int64_t* ids, int64_t B, int32_t F, const
                            (int32_t)log_tab, unique_flags, blist, ctrl);
         hipLaunchKernelGGL(plan_bucket_sort_kernel, dim3(NBK), dim3(256), 0, s, blist, ctrl, (int32_t)g_small_limit.load(), rows_y,
                            sorted_slots, dup_heads, dup_count);
-    } else {
-        if (hipMemsetAsync(&ctrl->large, 1, sizeof(int32_t), s) != hipSuccess) return DR_ELAUNCH;
+        // LARGE, gated on the device: the partitions (still in keys_x) sorted one per block
+        hipLaunchKernelGGL(plan_large_kernel, dim3(NBK), dim3(LG_T), 0, s, keys_x, tot, (uint64_t)num_rows, n, rows_y, sorted_slots,
+                           unique_flags, dup_heads, dup_count, ctrl);
+        DR_CHECK_LAUNCH();
+        return DR_OK;
     }
-    // LARGE path (each kernel returns at once unless ctrl->large): the final pass must land in the output arrays
+    // geometry beyond the composite key: the chip-wide LSD radix sort of all n slots; the final pass must land in the output arrays
+    if (hipMemsetAsync(ctrl, 0, sizeof(Ctrl), s) != hipSuccess) return DR_ELAUNCH;
+    if (hipMemsetAsync(dup_count, 0, 2 * sizeof(int32_t), s) != hipSuccess) return DR_ELAUNCH;
+    if (hipMemsetAsync(&ctrl->large, 1, sizeof(int32_t), s) != hipSuccess) return DR_ELAUNCH;
     const unsigned bits = bits_for((uint64_t)num_rows);            // the sentinel == num_rows needs these bits too
     const int passes = (int)((bits + RADIX_BITS - 1) / RADIX_BITS);
     uint64_t* kbuf[2] = {keys_x, rows_y};
@@ -482,7 +658,7 @@ extern "C" int dr_emb_sort_slots(const int64_t* ids, int64_t B, int32_t F, const
     for (int p = 0; p < passes; ++p) {
         const uint32_t shift = (uint32_t)(p * RADIX_BITS);
         hipLaunchKernelGGL((radix_hist_kernel<0>), dim3(nb), dim3(256), 0, s, kbuf[cur], n, shift, ghist, ctrl);
-        hipLaunchKernelGGL((radix_scan_kernel<1>), dim3(RADIX), dim3(256), 0, s, ghist, (int32_t)nb, tot, ctrl);
+        hipLaunchKernelGGL((radix_scan_kernel<1>), dim3(RADIX), dim3(256), 0, s, ghist, (int32_t)nb, tot, ctrl, dup_count);
         hipLaunchKernelGGL((radix_scatter_kernel<0>), dim3(nb), dim3(256), 0, s, kbuf[cur], vbuf[cur], kbuf[cur ^ 1], vbuf[cur ^ 1], n,
                            shift, ghist, tot, ctrl);
         cur ^= 1;

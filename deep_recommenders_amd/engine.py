@@ -230,9 +230,14 @@ class DeepFMEngine:
         # forward no longer shares the machine with the tail of the previous step's plan (251 -> 237 us), K4 runs 260 - 265 us instead of
         # 267 - 301 (0.63 - 0.645 of the roofline instead of 0.555 - 0.627: the kernel the metric names keeps its margin over 0.60
         # whatever the box), the wgrad and the narrow backward pay 3 us each.  DR_PREFETCH_EARLY=0: beside K4 as in rounds 2 - 4.
-        _pe = _os.environ.get("DR_PREFETCH_EARLY", "1")
+        # Round 6: "2" is the default -- the chain starts BEHIND the fused first layer, beside the tower tail (the one kernel of the step
+        # that leaves registers and LDS free on every CU), and runs on beside the wgrad.  Since the plan went from ~25 launches to 8
+        # (csrc/emb_plan.hip: the gated radix passes became one launch) the chain is short enough to profit: 0.975 - 0.978 ms against
+        # 0.984 - 0.989 at the start of the step and 1.026 - 1.032 beside K4 (same call, alternating; before the slimmer plan the same
+        # three read 1.056 - 1.061 / -- / 1.09).  Without the fused first layer "2" means "1".
+        _pe = _os.environ.get("DR_PREFETCH_EARLY", "2")
         self.prefetch_early = _pe in ("1", "2")
-        self.prefetch_after_fwd = _pe == "2"      # "2": behind the first GEMM, beside the tower tail
+        self.prefetch_after_fwd = _pe == "2" and self.fuse_k3      # "2": behind the first GEMM, beside the tower tail
         # Fewer cross-stream packets in front of K4 (rocprofv3 showed a 31 us gap there against 11 - 13 us between the other
         # dependent kernels): the side chain is ordered behind the plane refresh instead of an event of its own, and the wait for
         # a PREFETCHED plan -- long complete by then -- sits in front of the first-layer wgrad.  DR_LEAN_EVENTS=0: as before.
@@ -391,6 +396,14 @@ class DeepFMEngine:
         nxt = self.cur ^ 1
         self.ev_fwd0.record()                   # behind the previous step's K4 (the last user of buffer `nxt`)
         nk.record_stream(self.side)
+        self._exp_n = getattr(self, "_exp_n", 0) + 1
+        if _os_env("DR_EXP_SKIP_PLAN", "") and self._exp_n > 8:      # EXPERIMENT (tools/exp/exp_plan.sh, timing only): buffers keep an older batch's ids + plan
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(self.ev_fwd0)
+                self._ev_hashed[nxt].record(self.side)
+                self._ev_sorted[nxt].record(self.side)
+            self._early_issued = True
+            return
         with torch.cuda.stream(self.side):
             self.side.wait_event(self.ev_fwd0)
             self._k("next_batch: hash_bucket_i64(side stream, overlapped)", "overlap", self.B * self.F * 16,

@@ -720,6 +720,77 @@ def _emb_bwd_sorted_case(ops, D, F, V, hot, path):
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("case", ["one_partition_two_passes", "one_partition_one_pass", "one_row", "spread", "three_passes"])
+def test_slot_plan_large_path_sorts_any_partition(ops, case):
+    """The LARGE path in one launch (plan_large_kernel, round 6): block b sorts partition b with as many 8-bit passes as its rows
+    differ in.  Cases: a partition of 50 000 keys (49 steps of 1024) whose rows differ in 12 bits (two passes: ends where it
+    started), in 8 bits (one pass: starts with a copy), not at all (no pass); keys spread over all partitions; 20-bit differences."""
+    rng = np.random.default_rng(5)
+    if case == "one_partition_two_passes":
+        B, F, V = 50000, 2, 1_000_000
+        ids = np.stack([rng.integers(0, 3000, B), rng.integers(0, V, B)], 1)
+    elif case == "one_partition_one_pass":
+        B, F, V = 50000, 2, 1_000_000
+        ids = np.stack([rng.integers(0, 200, B), rng.integers(0, 200, B)], 1)
+    elif case == "one_row":
+        B, F, V = 3000, 1, 100_000
+        ids = np.full((B, F), 777)
+    elif case == "spread":
+        B, F, V = 20000, 5, 300
+        ids = rng.integers(0, V, (B, F))
+    else:
+        B, F, V = 30000, 1, 200_000_000                 # one field of 2e8 rows: a partition spans 781 K rows = 20 bits
+        ids = rng.integers(0, 4000, (B, F)) * 50_000 + rng.integers(0, 3, (B, F))
+    ids[rng.random((B, F)) < 0.03] = -1
+    row_base = (np.arange(F) * V).astype(np.int64)
+    R = F * V
+    keys = np.where(ids.reshape(-1) >= 0, (ids + row_base[None, :]).reshape(-1), R)
+    prev = ops.emb_plan_set_small_limit(0)
+    try:
+        plan = ops.emb_sort_slots(_dev(ids), _dev(row_base), R)
+        plan2 = ops.emb_sort_slots(_dev(ids), _dev(row_base), R)
+    finally:
+        ops.emb_plan_set_small_limit(prev)
+    n = B * F
+    assert plan.sorted_len() == n
+    order = np.argsort(keys, kind="stable")
+    np.testing.assert_array_equal(plan.slots.cpu().numpy()[:n], order.astype(np.int32))
+    np.testing.assert_array_equal(plan.rows.cpu().numpy()[:n], keys[order])
+    assert torch.equal(plan.rows[:n], plan2.rows[:n]) and torch.equal(plan.slots[:n], plan2.slots[:n]) and torch.equal(plan.flags, plan2.flags)
+    sr = keys[order]
+    uniq, cnt = np.unique(keys, return_counts=True)
+    c_of = cnt[np.searchsorted(uniq, keys)]
+    np.testing.assert_array_equal(plan.flags.cpu().numpy()[:n], ((c_of == 1) & (keys < R)).astype(np.uint8))
+    i = np.arange(n)
+    seg_start = np.ones(n, dtype=bool); seg_start[1:] = sr[1:] != sr[:-1]
+    has_next = np.zeros(n, dtype=bool); has_next[:-1] = sr[1:] == sr[:-1]
+    back = np.zeros(n, dtype=bool); back[32:] = sr[32:] == sr[:-32]
+    want_heads = np.nonzero((sr < R) & ((seg_start & has_next) | (~seg_start & (i % 32 == 0) & (i >= 32) & back)))[0]
+    nh = int(plan.dup_count[0].item())
+    np.testing.assert_array_equal(np.sort(plan.dup_heads.cpu().numpy()[:nh]), want_heads)
+
+
+def test_slot_plan_geometry_beyond_the_composite_key(ops):
+    """num_rows >= 2^31 - 1 cannot go through the 31-bit claim tables / the composite key: the host sends such a call to the
+    chip-wide radix sort of all slots (the only path that still takes more than one launch per phase)."""
+    rng = np.random.default_rng(6)
+    B, F = 6000, 1
+    R = (1 << 31) + 1000
+    ids = R - 1 - rng.integers(0, 3000, (B, F)) * 7
+    ids[rng.random((B, F)) < 0.05] = -1
+    row_base = np.zeros(F, dtype=np.int64)
+    keys = np.where(ids.reshape(-1) >= 0, ids.reshape(-1), R)
+    plan = ops.emb_sort_slots(_dev(ids), _dev(row_base), R)
+    n = B * F
+    assert plan.sorted_len() == n
+    order = np.argsort(keys, kind="stable")
+    np.testing.assert_array_equal(plan.slots.cpu().numpy()[:n], order.astype(np.int32))
+    np.testing.assert_array_equal(plan.rows.cpu().numpy()[:n], keys[order])
+    uniq, cnt = np.unique(keys, return_counts=True)
+    c_of = cnt[np.searchsorted(uniq, keys)]
+    np.testing.assert_array_equal(plan.flags.cpu().numpy()[:n], ((c_of == 1) & (keys < R)).astype(np.uint8))
+
+
 @pytest.mark.parametrize("D,F,V,hot", [(64, 26, 5000, False), (16, 7, 50, True), (12, 5, 1000, False)])
 def test_emb_bwd_sorted_adam_matches_oracle_over_steps(ops, D, F, V, hot):
     """Fused row-wise Adam K4 over 3 steps == oracle (pre-summed duplicate gradients, [TF] B15 update on touched rows);

@@ -340,11 +340,12 @@ def test_engine_next_batch_prefetch_is_bit_identical(optimizer, D, V):
     assert engs[0].loss.item() == engs[1].loss.item()
 
 
-@pytest.mark.parametrize("switch,value", [("DR_REDUCE_SIDE", "1"), ("DR_REDUCE_SIDE", "2"), ("DR_PREFETCH_EARLY", "0"), ("DR_PREFETCH_EARLY", "2")])
+@pytest.mark.parametrize("switch,value", [("DR_REDUCE_SIDE", "1"), ("DR_REDUCE_SIDE", "2"), ("DR_PREFETCH_EARLY", "0"), ("DR_PREFETCH_EARLY", "1")])
 def test_engine_schedule_switches_are_bit_identical(switch, value, monkeypatch):
     """Round 4's measured-and-rejected schedules stay correct: the step's small reduce kernels on the side stream
     (dr_tower_head_fwd_bwd_parts / dr_linear_bwd_narrow_parts / dr_bf3_wgrad_emb_parts: the two halves of each call on two streams),
-    and the next batch's hash + plan issued at the start of the step.  Same kernels, same arithmetic order: parameters and losses
+    and the next batch's hash + plan issued at the start of the step (round 5's default) or beside K4 (rounds 2-4) instead of behind the
+    fused first layer (round 6).  Same kernels, same arithmetic order: parameters and losses
     must be bit-identical to the default schedule over prefetched steps (D = 64: fused first layer, gathering wgrad, planes)."""
     from deep_recommenders_amd.engine import DeepFMEngine
     F, B, Nd, D, V = 4, 2304, 3, 64, 3000
@@ -370,7 +371,7 @@ def test_engine_schedule_switches_are_bit_identical(switch, value, monkeypatch):
         # table's amax record while K4 raises it on the other stream -- engine.py)
         assert alt.reduce_side and alt.reduce_side_wgrad == (value == "1" and not alt.h2)
     else:
-        assert base.prefetch_early and not base.prefetch_after_fwd          # the default since round 5: issued at the start of the step
+        assert base.prefetch_early and base.prefetch_after_fwd              # the default since round 6: issued behind the fused first layer
         assert alt.prefetch_early == (value != "0") and alt.prefetch_after_fwd == (value == "2")
     assert l0 == l1
     assert torch.equal(base.table, alt.table) and torch.equal(base.lin_w, alt.lin_w) and torch.equal(base.flat_params, alt.flat_params)
