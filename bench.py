@@ -410,9 +410,49 @@ def main():
         else:
             step = lambda i: eng.train_step(*batches[i % nb], next_keys=batches[(i + 1) % nb][0])
 
+    # per-kernel HIP events: decided here, because the untimed steps below must run the code path of the timed region
+    prof = getattr(eng, "enable_kernel_events", None)
+    first_gemm_flops = 2.0 * a.batch * (a.fields * a.dim + a.dense) * (dnn_units[0] if dnn_units else 1)
+    events_on = a.events == "on" or (a.events == "auto" and (a.model != "deepfm" or first_gemm_flops >= 4e9))
+    if os.environ.get("DR_BENCH_EVENTS", "1") == "0" or not events_on:
+        prof = None
+    ev_every = 1
+    # The sharded step drives four streams; a step with event records on them takes anywhere from 1.1 x to 5 x as long as one without
+    # (round 4, same box, same flags: 1.96 and 3.85 ms per step with every 4th step bracketed, 1.68 - 1.71 ms with none).  So with
+    # --events auto the timed region of a sharded DeepFM run carries NO events; the per-phase durations, the exchange report and the
+    # exposed waits are taken from EV_EXTRA bracketed steps run after the timed region and its loss read-out (same batches, same
+    # prefetch), and the line says so.  --events on: every 4th step of the timed region, as before.
+    EV_EXTRA = 8
+    # (round 5: the two-tower step too -- ~120 small launches, bound by the host: bracketing every kernel of the timed region took the
+    # line from 1.07-1.09 to 2.75-4.0 ms on this round's boxes, profiles/r05_bench_line_dssm*.json; its per-kernel rows come from
+    # bracketed steps after the timed region as well)
+    events_after = (prof is not None and a.events == "auto" and
+                    ((a.model == "deepfm" and hasattr(eng, "exchange_report")) or a.model == "dssm"))
+    ev_steps = a.steps
+    if events_after:
+        prof_after, prof = prof, None
+
+    def events_begin():
+        # the DeepFM engines bracket every 4th step of the timed region (steps 0, 4, 8, ...): two event records per kernel
+        # on EVERY step cost ~5 % of a 1.5 ms step (round 3: 1.56 vs 1.48 ms; sharded engine, round 4: 2.05 vs 1.94 ms); the per-kernel
+        # averages are over those launches
+        try:
+            every = 4 if (a.model == "deepfm" and a.steps >= 8) else 1
+            eng.enable_kernel_events(True, every=every)
+        except TypeError:
+            every = 1
+            eng.enable_kernel_events(True)
+        return every
+
+    if prof is not None and hasattr(eng, "reserve_kernel_events"):
+        # every event pair the timed region will record exists before the first step (round 6: creating them inside the timed region cost
+        # the FIRST process of a fresh box 0.3 - 0.45 ms per step -- lines of 1.32 / 1.44 ms whose kernel rows were normal)
+        eng.reserve_kernel_events(((a.steps + 3) // 4 + 8) * 32)
     for i in range(a.warmup):
         step(i)
     torch.cuda.synchronize()
+    if prof is not None:
+        ev_every = events_begin()        # (the settling blocks run what the timed region runs; their samples are dropped below)
     # Settling (single process only; untimed, like the warm-up): further blocks of 20 steps until two consecutive blocks agree within 2 %
     # (or 5 s have passed).  The W warm-up steps cover the chip's ramp; this covers the HOST: the step needs 0.33 ms of launch work per
     # 1.14 ms of GPU work, and on a box that is still busy with its own start-up (seen twice as the first command of a call: 1.52 and
@@ -437,36 +477,8 @@ def main():
     if dist is not None:
         dist.barrier()
     # ---- timed region: exactly K steps; per-kernel HIP events ride along on the launch stream -------
-    prof = getattr(eng, "enable_kernel_events", None)
-    first_gemm_flops = 2.0 * a.batch * (a.fields * a.dim + a.dense) * (dnn_units[0] if dnn_units else 1)
-    events_on = a.events == "on" or (a.events == "auto" and (a.model != "deepfm" or first_gemm_flops >= 4e9))
-    if os.environ.get("DR_BENCH_EVENTS", "1") == "0" or not events_on:
-        prof = None
-    ev_every = 1
-    # The sharded step drives four streams; a step with event records on them takes anywhere from 1.1 x to 5 x as long as one without
-    # (round 4, same box, same flags: 1.96 and 3.85 ms per step with every 4th step bracketed, 1.68 - 1.71 ms with none).  So with
-    # --events auto the timed region of a sharded DeepFM run carries NO events; the per-phase durations, the exchange report and the
-    # exposed waits are taken from EV_EXTRA bracketed steps run after the timed region and its loss read-out (same batches, same
-    # prefetch), and the line says so.  --events on: every 4th step of the timed region, as before.
-    EV_EXTRA = 8
-    # (round 5: the two-tower step too -- ~120 small launches, bound by the host: bracketing every kernel of the timed region took the
-    # line from 1.07-1.09 to 2.75-4.0 ms on this round's boxes, profiles/r05_bench_line_dssm*.json; its per-kernel rows come from
-    # bracketed steps after the timed region as well)
-    events_after = (prof is not None and a.events == "auto" and
-                    ((a.model == "deepfm" and hasattr(eng, "exchange_report")) or a.model == "dssm"))
-    ev_steps = a.steps
-    if events_after:
-        prof_after, prof = prof, None
     if prof is not None:
-        # the DeepFM engines bracket every 4th step of the timed region (steps 0, 4, 8, ...): two event records per kernel
-        # on EVERY step cost ~5 % of a 1.5 ms step (round 3: 1.56 vs 1.48 ms; sharded engine, round 4: 2.05 vs 1.94 ms); the per-kernel
-        # averages are over those launches
-        try:
-            ev_every = 4 if (a.model == "deepfm" and a.steps >= 8) else 1
-            eng.enable_kernel_events(True, every=ev_every)
-        except TypeError:
-            ev_every = 1
-            eng.enable_kernel_events(True)
+        ev_every = events_begin()        # (drops the samples of the settling blocks; their event pairs are reused)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(a.steps):

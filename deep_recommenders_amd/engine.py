@@ -163,6 +163,7 @@ class DeepFMEngine:
         self.ws = torch.empty(1024, **f32)
         self._events = None      # name -> [bound, work, [(start, end), ...]]
         self._ev_every, self._ev_step, self._ev_live = 1, 0, False
+        self._ev_pool = []
         # ---- deterministic backward: slots sorted by table row on a side stream (depends only on ids) ----
         # Schedule experiments and their outcomes are recorded in DESIGN.md section 3 (sort started with K3 / in the backward /
         # on a high-priority stream, K4 overlapped with the first-layer wgrad, FM gradient folded into the dgrad epilogue):
@@ -421,15 +422,24 @@ class DeepFMEngine:
         """Per-kernel HIP events on the launch stream.  every = n: only every n-th train_step is bracketed -- two event records per
         kernel are two extra packets per kernel boundary, and at 12 kernels per 1.5 ms step that is no longer free (round 3: 1.56
         ms with events on every step, 1.48 ms without, same box); bench.py samples every 4th step of the timed region."""
+        for rec in (getattr(self, "_events", None) or {}).values():       # the pairs of the previous collection go back to the pool
+            self._ev_pool.extend(rec[2])
         self._events = {} if on else None
         self._ev_every = max(1, int(every))
         self._ev_step = 0
         self._ev_live = bool(on)
 
+    def reserve_kernel_events(self, n_pairs: int):
+        """Create n_pairs timing-event pairs NOW, so that a bracketed region creates none: on a box's first process hipEventCreate costs
+        tens of microseconds a piece (round 6: the first bench.py of a fresh box read 1.32 - 1.44 ms per step with 25 bracketed steps
+        in its timed region, the same command a second time 1.00 ms; with events off both read 0.98)."""
+        while len(self._ev_pool) < n_pairs:
+            self._ev_pool.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+
     def _k(self, name, bound, work, fn):
         if self._events is None or not self._ev_live:
             return fn()
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s, e = self._ev_pool.pop() if self._ev_pool else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         s.record()
         r = fn()
         e.record()
