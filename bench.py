@@ -757,7 +757,7 @@ def main():
                                      "longest MFMA-bound kernel is in roofline_mfma, every kernel in roofline_all")
             # its ordering step (the slot plan) runs on a side stream beside the PREVIOUS step's K4: this row's event time already
             # contains what that sharing costs K4; charged a second way below -- plan event time added to the kernel's own
-            plan = [v for k, v in overlapped.items() if "emb_sort_slots" in k]
+            plan = [v for k, v in overlapped.items() if "sort_slots" in k]        # (round 6: the event spans K1 + the plan, one chain)
             if plan:
                 pu = plan[0]["event_us_while_overlapped"]
                 roofline["plan_event_us_while_overlapped"] = pu

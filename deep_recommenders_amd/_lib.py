@@ -61,6 +61,7 @@ SIGNATURES = {
     "dr_emb_pack_grads_dedup": [_p, _p, _i64, _i32, _i32, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p],
     "dr_emb_sort_workspace_bytes": [_i64],
     "dr_emb_sort_slots": [_p, _i64, _i32, _p, _i64, _p, _p, _p, _p, _p, _p, _i64, _p],
+    "dr_hash_sort_slots": [_p, _i64, _i32, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _i64, _p],
     "dr_emb_plan_set_small_limit": [_i32],
     "dr_adam_catchup_rows": [_p, _i64, _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _f32, _f32, _f32, _f32, _p],
     "dr_emb_pool_bwd_sorted": [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _i64, _p, _i64, _p, _p, _p, _f32, _p, _p,

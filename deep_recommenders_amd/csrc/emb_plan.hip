@@ -33,6 +33,7 @@
 // variable) reached from optimizer.minimize (examples/train_fm_on_movielens_estimator.py:51-52, reference root); K4 itself is
 // csrc/emb_sorted.hip.
 #include "dr_common.h"
+#include "hash_i64.h"
 #include <atomic>
 
 namespace {
@@ -124,24 +125,63 @@ __global__ __launch_bounds__(256) void radix_make_keys_kernel(const int64_t* __r
     }
 }
 
-// SMALL 1a (round 6: one launch instead of make_keys + hist): block b builds the composite keys of its contiguous chunk -- the chunk
-// radix_scatter_kernel<1> re-reads -- and counts their partition digits on the way.
-__global__ __launch_bounds__(256) void plan_keys_hist_kernel(const int64_t* __restrict__ ids, int32_t n, int32_t F,
-                                                             const int64_t* __restrict__ row_base, uint64_t sentinel, uint32_t mul,
-                                                             uint64_t* __restrict__ keys, uint32_t* __restrict__ ghist) {
+// SMALL 1a (round 6: ONE launch for what were up to four -- K1, the field-major ids, make_keys, hist).  Block b owns `sub` consecutive
+// examples (64 at config 3: 1024 blocks), walks them 64 at a time and leaves, per slot: the bucket id (HASH: Fingerprint64(text(key)) mod
+// buckets, exactly dr_hash_bucket_i64; else the ids are an input), the field-major int32 id (TRANS: through a 64 x (F + 1) LDS tile so that
+// both sides are coalesced, exactly dr_ids_transpose_i32), the composite key row << 24 | slot, and the block's partition-digit counts.
+// Four consecutive blocks are one chunk of plan_scatter_kernel (their counts are adjacent in the scan).
+constexpr int FRONT_GROUP = 4;
+template <bool HASH, bool TRANS>
+__global__ __launch_bounds__(256) void plan_front_kernel(const int64_t* __restrict__ src, int64_t B, int32_t F,
+                                                         const uint64_t* __restrict__ col_buckets, int64_t* __restrict__ ids_out,
+                                                         int32_t* __restrict__ ids_t, const int64_t* __restrict__ row_base,
+                                                         uint64_t sentinel, uint32_t mul, int32_t sub, uint64_t* __restrict__ keys,
+                                                         uint32_t* __restrict__ ghist) {
+    extern __shared__ uint64_t fsm[];                      // [F] row_base, (HASH) [F] buckets + [F] floor((2^64 - 1) / buckets), (TRANS) tile
     __shared__ uint32_t h[RADIX];
+    int64_t* rb = reinterpret_cast<int64_t*>(fsm);
+    uint64_t* cb = fsm + F;
+    int32_t* tile = reinterpret_cast<int32_t*>(fsm + (HASH ? 3 : 1) * F);
     const int nb = gridDim.x, t = threadIdx.x;
-    const int32_t chunk = (n + nb - 1) / nb;
-    const int32_t beg = (int32_t)blockIdx.x * chunk, end = beg + chunk < n ? beg + chunk : n;
+    for (int c = t; c < F; c += 256) {
+        rb[c] = row_base[c];
+        if (HASH) {
+            const uint64_t nbk = col_buckets[c];
+            cb[c] = nbk;
+            cb[F + c] = nbk != 0 ? ~0ull / nbk : 0;
+        }
+    }
     h[t] = 0;
     __syncthreads();
-    for (int32_t p = beg + t; p < end; p += 256) {
-        const int64_t id = ids[p];
-        const uint64_t r0 = id >= 0 ? (uint64_t)(row_base[p % F] + id) : sentinel;      // (see radix_make_keys_kernel)
-        const uint64_t row = r0 < sentinel ? r0 : sentinel;
-        const uint64_t ck = (row << 24) | (uint32_t)p;
-        keys[p] = ck;
-        atomicAdd(&h[digit_of<1>(ck, mul)], 1u);
+    const int64_t e0 = (int64_t)blockIdx.x * sub;
+    const int64_t e1 = e0 + sub < B ? e0 + sub : B;
+    for (int64_t g0 = e0; g0 < e1; g0 += 64) {             // block-uniform trip count
+        const int ge = (int)(e1 - g0 < 64 ? e1 - g0 : 64);
+        const int ns = ge * F;
+        const int64_t p0 = g0 * F;
+        for (int q = t; q < ns; q += 256) {
+            const int r = q / F, f = q - r * F;
+            const int64_t p = p0 + q;
+            int64_t id = src[p];
+            if (HASH) {
+                id = drhash::bucket_of_key(id, cb[f], cb[F + f]);
+                ids_out[p] = id;
+            }
+            if (TRANS) tile[r * (F + 1) + f] = (int32_t)id;
+            const uint64_t r0 = id >= 0 ? (uint64_t)(rb[f] + id) : sentinel;           // (see radix_make_keys_kernel)
+            const uint64_t row = r0 < sentinel ? r0 : sentinel;
+            const uint64_t ck = (row << 24) | (uint32_t)p;
+            keys[p] = ck;
+            atomicAdd(&h[digit_of<1>(ck, mul)], 1u);
+        }
+        if (TRANS) {
+            __syncthreads();
+            for (int q = t; q < F * 64; q += 256) {
+                const int f = q >> 6, r = q & 63;
+                if (r < ge) ids_t[(int64_t)f * B + g0 + r] = tile[r * (F + 1) + f];
+            }
+            __syncthreads();
+        }
     }
     __syncthreads();
     ghist[t * nb + blockIdx.x] = h[t];
@@ -262,8 +302,77 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* __re
     }
 }
 
+// ---- the stable scatter step of a 1024-thread block: key k with digit d goes to running[d] + (earlier keys of this step with the same
+// digit): wave-level match by eight ballots, earlier waves' counts through LDS; running[] advances by the step's counts.  Every thread of
+// the block calls it (barriers inside).
+constexpr int LG_T = 1024, LG_W = LG_T / 64;
+__device__ __forceinline__ void scatter_step_1024(bool live, uint64_t k, uint32_t d, uint32_t* __restrict__ running,
+                                                  uint32_t (*__restrict__ wcnt)[RADIX], uint64_t* __restrict__ dst) {
+    const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+#pragma unroll
+    for (int q = 0; q < LG_W * RADIX / LG_T; ++q) (&wcnt[0][0])[q * LG_T + t] = 0;
+    __syncthreads();
+    uint64_t mask = __ballot(live);                                   // lanes with my digit (dead lanes never match)
+#pragma unroll
+    for (int bb = 0; bb < RADIX_BITS; ++bb) {
+        const bool bit = (d >> bb) & 1u;
+        const uint64_t vote = __ballot(bit);
+        mask &= bit ? vote : ~vote;
+    }
+    const uint32_t rank_in_wave = __popcll(mask & ((1ull << lane) - 1ull));
+    if (live && rank_in_wave == 0) wcnt[w][d] = __popcll(mask);
+    __syncthreads();
+    uint32_t pos = 0;
+    if (live) {
+        pos = running[d] + rank_in_wave;
+        for (int ww = 0; ww < w; ++ww) pos += wcnt[ww][d];
+    }
+    __syncthreads();                                                  // every read of running[] precedes its update
+    if (t < RADIX) {
+        uint32_t add = 0;
+#pragma unroll
+        for (int ww = 0; ww < LG_W; ++ww) add += wcnt[ww][t];
+        running[t] += add;
+    }
+    if (live) dst[pos] = k;
+    __syncthreads();
+}
+
+// SMALL 1b: the partition pass's stable scatter (round 6: 1024 threads per block -- 7 steps per chunk at config 3 instead of 26; one
+// block per CU keeps the 256 x 256 write frontiers of the partitions resident in the L2s).  Block b re-reads chunk b = FRONT_GROUP front
+// blocks' slots in order; its range starts = scanned counts of its first front block.
+__global__ __launch_bounds__(LG_T) void plan_scatter_kernel(const uint64_t* __restrict__ kin, uint64_t* __restrict__ kout, int32_t n,
+                                                            uint32_t mul, int32_t chunk, const uint32_t* __restrict__ ghist,
+                                                            int32_t gstride, const uint32_t* __restrict__ tot) {
+    __shared__ uint32_t running[RADIX];
+    __shared__ uint32_t wcnt[LG_W][RADIX];
+    const int t = threadIdx.x;
+    const int64_t beg64 = (int64_t)blockIdx.x * chunk;
+    const int32_t beg = (int32_t)(beg64 < n ? beg64 : n), end = (int32_t)(beg64 + chunk < n ? beg64 + chunk : n);
+    {   // range starts = exclusive scan of the 256 digit totals
+        const uint32_t mine = t < RADIX ? tot[t] : 0u;
+        if (t < RADIX) running[t] = mine;
+        __syncthreads();
+        for (int o = 1; o < RADIX; o <<= 1) {
+            const uint32_t x = (t < RADIX && t >= o) ? running[t - o] : 0u;
+            __syncthreads();
+            if (t < RADIX) running[t] += x;
+            __syncthreads();
+        }
+        if (t < RADIX) running[t] = running[t] - mine + ghist[t * gstride + blockIdx.x * FRONT_GROUP];
+    }
+    __syncthreads();
+    for (int32_t base = beg; base < end; base += LG_T) {              // block-uniform trip count
+        const int32_t i = base + t;
+        const bool live = i < end;
+        const uint64_t k = live ? kin[i] : 0ull;
+        scatter_step_1024(live, k, digit_of<1>(k, mul), running, wcnt, kout);
+    }
+}
+
 // ---- SMALL 2: one block per partition claims its rows in an LDS table, flags the slots, collects the shared-row slots -------------
-__global__ __launch_bounds__(512) void plan_lds_claim_kernel(const uint64_t* __restrict__ keys,
+constexpr int CLAIM_T = 1024;          // (round 6: 512 -> 1024 threads, 7 keys per thread and sweep at config 3)
+__global__ __launch_bounds__(CLAIM_T) void plan_lds_claim_kernel(const uint64_t* __restrict__ keys,
                                                              const uint32_t* __restrict__ tot, uint64_t num_rows, int32_t log_tab,
                                                              uint8_t* __restrict__ flags, uint64_t* __restrict__ blist,
                                                              Ctrl* __restrict__ ctrl) {
@@ -276,7 +385,7 @@ __global__ __launch_bounds__(512) void plan_lds_claim_kernel(const uint64_t* __r
     // this partition's range = [sum of the totals below b, + tot[b])
     if (t < RADIX) starts[t] = tot[t];
     if (t == 0) ndup = 0;
-    for (int i = t; i < LDS_TAB; i += 512) tab[i] = EMPTY;
+    for (int i = t; i < LDS_TAB; i += CLAIM_T) tab[i] = EMPTY;
     __syncthreads();
     uint32_t beg = 0;
     for (int i = 0; i < b; ++i) beg += starts[i];                     // (LDS broadcasts; b <= 255)
@@ -286,7 +395,7 @@ __global__ __launch_bounds__(512) void plan_lds_claim_kernel(const uint64_t* __r
         return;
     }
     // sweep 1: insert
-    for (uint32_t i = t; i < cnt; i += 512) {
+    for (uint32_t i = t; i < cnt; i += CLAIM_T) {
         const uint64_t k = keys[beg + i] >> 24;
         if (k >= num_rows) continue;                                  // missing id
         const uint32_t r = (uint32_t)k;
@@ -303,7 +412,7 @@ __global__ __launch_bounds__(512) void plan_lds_claim_kernel(const uint64_t* __r
     }
     __syncthreads();
     // sweep 2: flags + the shared-row slots (composite key row << 24 | slot) into this partition's bucket
-    for (uint32_t i = t; i < cnt; i += 512) {
+    for (uint32_t i = t; i < cnt; i += CLAIM_T) {
         const uint64_t ck = keys[beg + i];
         const uint64_t k = ck >> 24;
         const uint32_t slot = (uint32_t)(ck & 0xFFFFFFu);
@@ -449,7 +558,6 @@ __global__ __launch_bounds__(256) void radix_mark_kernel(const uint64_t* __restr
 // writes them over the chip-wide sort's output: the list K4's duplicate pass walks is the same list (the order of dup_heads is
 // arrival order in both).  Any partition size is taken (one block walks it 1024 keys at a time: a field whose every example
 // carries the same id is 65 536 keys = 64 steps per pass); Zipf batches at config 3 have 4 - 15 K keys per partition.
-constexpr int LG_T = 1024, LG_W = LG_T / 64;
 __global__ __launch_bounds__(LG_T) void plan_large_kernel(uint64_t* __restrict__ ka, const uint32_t* __restrict__ tot,
                                                           uint64_t num_rows, int32_t n, uint64_t* __restrict__ rows,
                                                           int32_t* __restrict__ slots, uint8_t* __restrict__ flags,
@@ -461,7 +569,7 @@ __global__ __launch_bounds__(LG_T) void plan_large_kernel(uint64_t* __restrict__
     __shared__ uint32_t starts[RADIX];
     __shared__ uint32_t rmin, rmax;
     __shared__ int32_t nh, gbase;
-    const int t = threadIdx.x, b = blockIdx.x, w = t >> 6, lane = t & 63;
+    const int t = threadIdx.x, b = blockIdx.x, lane = t & 63;
     if (t < RADIX) starts[t] = tot[t];
     if (t == 0) { rmin = 0xFFFFFFFFu; rmax = 0u; }
     if (b == 0 && t == 0) dup_count[1] = n;
@@ -512,34 +620,7 @@ __global__ __launch_bounds__(LG_T) void plan_large_kernel(uint64_t* __restrict__
             const int32_t i = base + t;
             const bool live = i < cnt;
             const uint64_t k = live ? src[i] : 0ull;
-            const uint32_t d = (((uint32_t)(k >> 24) - base_row) >> shift) & (RADIX - 1);
-#pragma unroll
-            for (int q = 0; q < LG_W * RADIX / LG_T; ++q) (&wcnt[0][0])[q * LG_T + t] = 0;
-            __syncthreads();
-            uint64_t mask = __ballot(live);
-#pragma unroll
-            for (int bb = 0; bb < RADIX_BITS; ++bb) {
-                const bool bit = (d >> bb) & 1u;
-                const uint64_t vote = __ballot(bit);
-                mask &= bit ? vote : ~vote;
-            }
-            const uint32_t rank_in_wave = __popcll(mask & ((1ull << lane) - 1ull));
-            if (live && rank_in_wave == 0) wcnt[w][d] = __popcll(mask);
-            __syncthreads();
-            uint32_t pos = 0;
-            if (live) {
-                pos = running[d] + rank_in_wave;
-                for (int ww = 0; ww < w; ++ww) pos += wcnt[ww][d];
-            }
-            __syncthreads();                                          // every read of running[] precedes its update
-            if (t < RADIX) {
-                uint32_t add = 0;
-#pragma unroll
-                for (int ww = 0; ww < LG_W; ++ww) add += wcnt[ww][t];
-                running[t] += add;
-            }
-            if (live) dst[pos] = k;
-            __syncthreads();
+            scatter_step_1024(live, k, (((uint32_t)(k >> 24) - base_row) >> shift) & (RADIX - 1), running, wcnt, dst);
         }
         uint64_t* x = src; src = dst; dst = x;
     }
@@ -591,9 +672,44 @@ extern "C" int64_t dr_emb_sort_workspace_bytes(int64_t n) {
     return (int64_t)layout_for(n).total;
 }
 
-extern "C" int dr_emb_sort_slots(const int64_t* ids, int64_t B, int32_t F, const int64_t* row_base, int64_t num_rows,
-                                 int64_t* sorted_rows, int32_t* sorted_slots, uint8_t* unique_flags, int32_t* dup_heads,
-                                 int32_t* dup_count, void* workspace, int64_t workspace_bytes, dr_stream_t stream) {
+namespace {
+// ids != nullptr: the plan of these bucket ids.  raw != nullptr: K1 in front -- ids_out (and ids_t, may be null) are OUTPUTS of the front
+// kernel.  Returns DR_OK + *done = false when the geometry is not the fused front's (the caller then runs the plain entry points).
+int plan_small_front(const int64_t* raw, const uint64_t* col_buckets, int64_t* ids_out, int32_t* ids_t, const int64_t* ids, int64_t B,
+                     int32_t F, const int64_t* row_base, int64_t num_rows, uint64_t* rows_y, uint64_t* keys_x, uint32_t* ghist,
+                     uint32_t* tot, Ctrl* ctrl, int32_t* dup_count, hipStream_t s) {
+    const int64_t n64 = B * F;
+    const int32_t n = (int32_t)n64;
+    // row * 256 / num_rows as a multiply-shift; floor, so that row * mul >> 32 <= 255 for every row < num_rows
+    const uint32_t mul = (uint32_t)((((uint64_t)RADIX) << 32) / (uint64_t)num_rows);
+    // front blocks of `sub` examples (a multiple of 64), at most RADIX_MAX_BLOCKS of them; FRONT_GROUP of them = one scatter chunk
+    int64_t sub = 64;
+    while ((B + sub - 1) / sub > RADIX_MAX_BLOCKS) sub += 64;
+    const int nbf = (int)((B + sub - 1) / sub);
+    const int nbs = (nbf + FRONT_GROUP - 1) / FRONT_GROUP;
+    const int64_t chunk = sub * FRONT_GROUP * F;
+    if (chunk > 0x7fffffff) return DR_EINVAL;
+    const bool trans = ids_t != nullptr;
+    const size_t lds = (size_t)8 * (raw ? 3 : 1) * F + (trans ? (size_t)4 * 64 * (F + 1) : 0);
+    if (raw) {
+        if (trans)
+            hipLaunchKernelGGL((plan_front_kernel<true, true>), dim3(nbf), dim3(256), lds, s, raw, B, F, col_buckets, ids_out, ids_t, row_base,
+                               (uint64_t)num_rows, mul, (int32_t)sub, rows_y, ghist);
+        else
+            hipLaunchKernelGGL((plan_front_kernel<true, false>), dim3(nbf), dim3(256), lds, s, raw, B, F, col_buckets, ids_out, ids_t,
+                               row_base, (uint64_t)num_rows, mul, (int32_t)sub, rows_y, ghist);
+    } else {
+        hipLaunchKernelGGL((plan_front_kernel<false, false>), dim3(nbf), dim3(256), lds, s, ids, B, F, col_buckets, ids_out, ids_t, row_base,
+                           (uint64_t)num_rows, mul, (int32_t)sub, rows_y, ghist);
+    }
+    hipLaunchKernelGGL((radix_scan_kernel<0>), dim3(RADIX), dim3(256), 0, s, ghist, (int32_t)nbf, tot, ctrl, dup_count);
+    hipLaunchKernelGGL(plan_scatter_kernel, dim3(nbs), dim3(LG_T), 0, s, rows_y, keys_x, n, mul, (int32_t)chunk, ghist, (int32_t)nbf, tot);
+    return DR_OK;
+}
+
+int sort_slots_impl(const int64_t* raw, const uint64_t* col_buckets, int32_t* ids_t, const int64_t* ids, int64_t B, int32_t F,
+                    const int64_t* row_base, int64_t num_rows, int64_t* sorted_rows, int32_t* sorted_slots, uint8_t* unique_flags,
+                    int32_t* dup_heads, int32_t* dup_count, void* workspace, int64_t workspace_bytes, dr_stream_t stream) {
     if (B < 0 || F <= 0 || num_rows <= 0) return DR_EINVAL;
     const int64_t n64 = B * F;
     if (n64 == 0) return DR_OK;
@@ -618,23 +734,24 @@ extern "C" int dr_emb_sort_slots(const int64_t* ids, int64_t B, int32_t F, const
 
     // the composite key holds 24 bits of slot and the LDS table 31 bits of row; anything larger sorts all slots
     const bool claimable = n64 <= (1 << 24) && num_rows < 0x7fffffffLL;
+    // K1 inside the front kernel: its LDS holds the per-field constants and (for the field-major ids) a 64 x (F + 1) tile
+    const bool fused_front = raw != nullptr && claimable && F <= 64;
+    if (raw && !fused_front) {
+        int rc = dr_hash_bucket_i64(raw, B, F, col_buckets, const_cast<int64_t*>(ids), stream);
+        if (rc == DR_OK && ids_t) rc = dr_ids_transpose_i32(ids, B, F, ids_t, stream);
+        if (rc != DR_OK) return rc;
+    }
     if (claimable) {
-        // row * 256 / num_rows as a multiply-shift; floor, so that row * mul >> 32 <= 255 for every row < num_rows
-        const uint32_t mul = (uint32_t)((((uint64_t)RADIX) << 32) / (uint64_t)num_rows);
-        // one block per CU: the 256 x 256 write frontiers of the partitions stay resident in the L2s
-        const int nbs = nb < 256 ? nb : 256;
-        hipLaunchKernelGGL(plan_keys_hist_kernel, dim3(nbs), dim3(256), 0, s, ids, n, F, row_base, (uint64_t)num_rows, mul, rows_y,
-                           ghist);
-        hipLaunchKernelGGL((radix_scan_kernel<0>), dim3(RADIX), dim3(256), 0, s, ghist, (int32_t)nbs, tot, ctrl, dup_count);
-        hipLaunchKernelGGL((radix_scatter_kernel<1>), dim3(nbs), dim3(256), 0, s, rows_y, slots_y, keys_x, vals_x, n, mul, ghist, tot,
-                           ctrl);
+        int rc = plan_small_front(fused_front ? raw : nullptr, col_buckets, const_cast<int64_t*>(ids), fused_front ? ids_t : nullptr, ids, B,
+                                  F, row_base, num_rows, rows_y, keys_x, ghist, tot, ctrl, dup_count, s);
+        if (rc != DR_OK) return rc;
         // (dynamic LDS beyond 64 KB needs the opt-in)
         static const hipError_t lds_optin = hipFuncSetAttribute(reinterpret_cast<const void*>(plan_lds_claim_kernel),
                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 4 << LDS_TAB_MAX_LOG);
         if (lds_optin != hipSuccess) return DR_ELAUNCH;
         int log_tab = 12;
         while (log_tab < LDS_TAB_MAX_LOG && (1 << log_tab) < 2 * ((n + NBK - 1) / NBK)) ++log_tab;
-        hipLaunchKernelGGL(plan_lds_claim_kernel, dim3(NBK), dim3(512), (size_t)4 << log_tab, s, keys_x, tot, (uint64_t)num_rows,
+        hipLaunchKernelGGL(plan_lds_claim_kernel, dim3(NBK), dim3(CLAIM_T), (size_t)4 << log_tab, s, keys_x, tot, (uint64_t)num_rows,
                            (int32_t)log_tab, unique_flags, blist, ctrl);
         hipLaunchKernelGGL(plan_bucket_sort_kernel, dim3(NBK), dim3(256), 0, s, blist, ctrl, (int32_t)g_small_limit.load(), rows_y,
                            sorted_slots, dup_heads, dup_count);
@@ -669,4 +786,24 @@ extern "C" int dr_emb_sort_slots(const int64_t* ids, int64_t B, int32_t F, const
                        unique_flags, dup_heads, dup_count, ctrl);
     DR_CHECK_LAUNCH();
     return DR_OK;
+}
+}  // namespace
+
+extern "C" int dr_emb_sort_slots(const int64_t* ids, int64_t B, int32_t F, const int64_t* row_base, int64_t num_rows,
+                                 int64_t* sorted_rows, int32_t* sorted_slots, uint8_t* unique_flags, int32_t* dup_heads,
+                                 int32_t* dup_count, void* workspace, int64_t workspace_bytes, dr_stream_t stream) {
+    return sort_slots_impl(nullptr, nullptr, nullptr, ids, B, F, row_base, num_rows, sorted_rows, sorted_slots, unique_flags, dup_heads,
+                           dup_count, workspace, workspace_bytes, stream);
+}
+
+// K1 + the field-major ids + the slot plan of the same batch: dr_hash_bucket_i64(keys -> ids_out), dr_ids_transpose_i32(ids_out -> ids_t_out;
+// ids_t_out may be NULL) and dr_emb_sort_slots(ids_out) with the first three kernels of the chain as ONE (the engines' next-batch prefetch:
+// every launch on the side stream costs the training stream 3 - 5 us beside the GEMMs).  Same outputs, bit for bit.
+extern "C" int dr_hash_sort_slots(const int64_t* keys, int64_t B, int32_t F, const uint64_t* col_buckets, int64_t* ids_out,
+                                  int32_t* ids_t_out, const int64_t* row_base, int64_t num_rows, int64_t* sorted_rows,
+                                  int32_t* sorted_slots, uint8_t* unique_flags, int32_t* dup_heads, int32_t* dup_count, void* workspace,
+                                  int64_t workspace_bytes, dr_stream_t stream) {
+    if (!keys || !col_buckets || !ids_out) return DR_EINVAL;
+    return sort_slots_impl(keys, col_buckets, ids_t_out, ids_out, B, F, row_base, num_rows, sorted_rows, sorted_slots, unique_flags,
+                           dup_heads, dup_count, workspace, workspace_bytes, stream);
 }

@@ -179,7 +179,11 @@ class DeepFMEngine:
         # the tables and produces concat / sum_x / fm_logit on the way).  Needs D == 64 and the planes path; DR_FUSE_K3=0: K3 as
         # its own kernel.
         self.fuse_k3 = _os.environ.get("DR_FUSE_K3", "1") == "1" and D == 64 and self.Nd <= 32 and V <= (1 << 24)
-        self.dense_pad = torch.zeros((B, 32), dtype=torch.float32, device=device) if (self.fuse_k3 and self.Nd) else None
+        # (two buffers, indexed like the ids / plan buffers -- round 6: the next batch's dense features are placed with the early chain,
+        # while this step's forward and wgrad still read the current buffer; see _prefetch_early)
+        self._dense_pads = ([torch.zeros((B, 32), dtype=torch.float32, device=device) for _ in range(2)]
+                            if (self.fuse_k3 and self.Nd) else None)
+        self._dense_amaxs = None
         # `concat` is never built (round 3): the fused first layer stops storing the gathered embeddings (0.44 GB written per step,
         # ~70 us of the kernel) because nothing reads them any more -- the first layer's wgrad gathers its operand from the tables
         # itself (dr_bf3_wgrad_emb, from field-major int32 ids), and K4's duplicate pass takes x of the few slots that share rows
@@ -211,7 +215,7 @@ class DeepFMEngine:
             self.wplanes[0] = ops.H2WeightPlanes(self.Ws[0], double_buffer=True)
             self.tab_amax = ops.h2_amax(self.table)
             self._tab_ver = (self.table.data_ptr(), self.table._version)
-            self.dense_amax = ops.h2_record(device) if self.dense_pad is not None else None
+            self._dense_amaxs = [ops.h2_record(device) for _ in range(2)] if self._dense_pads is not None else None
             self.dh0_amax = ops.h2_record(device)
             self._amax_scratch = ops.h2_record(device)
         self._tighten_every = int(_os.environ.get("DR_AMAX_TIGHTEN_STEPS", "2048"))
@@ -243,6 +247,9 @@ class DeepFMEngine:
         # dependent kernels): the side chain is ordered behind the plane refresh instead of an event of its own, and the wait for
         # a PREFETCHED plan -- long complete by then -- sits in front of the first-layer wgrad.  DR_LEAN_EVENTS=0: as before.
         self.lean_events = _os.environ.get("DR_LEAN_EVENTS", "1") == "1"
+        # the early prefetch as ONE C call whose first kernel is K1 + field-major ids + composite keys + histogram (dr_hash_sort_slots);
+        # DR_FUSE_PLAN_FRONT=0: dr_hash_bucket_i64, dr_ids_transpose_i32, dr_emb_sort_slots one after the other (8 launches instead of 6)
+        self.fuse_plan_front = _os.environ.get("DR_FUSE_PLAN_FRONT", "1") == "1"
         self._plan_prefetched = False
         if sorted_bwd:
             self._plans = [ops.SortPlan(B * F, device) for _ in range(2)]
@@ -250,6 +257,13 @@ class DeepFMEngine:
             # every 8th CU -- so that its ~25 small launches would not spread over the machine beside K4: the step went from 1.19 to
             # 1.75 - 1.85 ms, K4 itself unchanged; profiles/r05_ab_side_stream.log)
             self.side = torch.cuda.Stream(device=device)
+            # Round 6: a stream of its own for what must be in place before the NEXT forward (the first layer's plane refresh behind its
+            # wgrad, the next batch's dense features).  On `side` these five small launches queued behind the plan chain, whose kernels
+            # only get CUs when a GEMM drains (a side kernel's blocks wait for the training stream's kernel to run out of blocks: the
+            # chain advances about one kernel per kernel boundary of the step) -- rocprofv3 showed the refresh starting 17 us after the
+            # fused dgrad + K4 had ENDED and the next forward waiting 39 us for the dense features' record.  DR_SIDE_R=0: as before.
+            self.side_r = torch.cuda.Stream(device=device) if _os.environ.get("DR_SIDE_R", "1") == "1" else self.side
+            self._refresh_stream = self.side
             self.ev_ids = torch.cuda.Event()
             self._ev_sorted = [torch.cuda.Event(), torch.cuda.Event()]
             self._ev_hashed = [torch.cuda.Event(), torch.cuda.Event()]
@@ -314,6 +328,14 @@ class DeepFMEngine:
             self.ev_dw = torch.cuda.Event()
 
     @property
+    def dense_pad(self):
+        return self._dense_pads[self.cur] if self._dense_pads is not None else None
+
+    @property
+    def dense_amax(self):
+        return self._dense_amaxs[self.cur] if self._dense_amaxs is not None else None
+
+    @property
     def ids(self):
         return self._ids[self.cur]
 
@@ -353,12 +375,14 @@ class DeepFMEngine:
         (ordered,) = mark
         nk = self._next_keys
         nxt = self.cur ^ 1
-        nk.record_stream(self.side)
         early_done = self._early_issued
         self._early_issued = False
-        with torch.cuda.stream(self.side):
+        # (only the dense features are left to place when the chain went out early: on the stream the plane refresh was queued on)
+        st = self._refresh_stream if (early_done and ordered) else self.side
+        nk.record_stream(st)
+        with torch.cuda.stream(st):
             if not ordered:
-                self.side.wait_event(self.ev_k4)
+                st.wait_event(self.ev_k4)
             if not early_done:
                 self._k("next_batch: hash_bucket_i64(side stream, overlapped)", "overlap", self.B * self.F * 16,
                         lambda: ops.hash_bucket_i64(nk, self.col_buckets, out=self._ids[nxt]))
@@ -366,26 +390,30 @@ class DeepFMEngine:
                     ops.ids_transpose_i32(self._ids[nxt], out=self._ids_t[nxt])
             nd = self._next_dense
             self._pref_dense = None
-            if nd is not None and self.Nd and not self.overlap_dw:
+            if early_done and getattr(self, "_dense_early", False):
+                self._pref_dense = self._token(nd)             # placed at the start of the step (_prefetch_early)
+            elif nd is not None and self.Nd and not self.overlap_dw:
                 # the dense features of that batch too: this step's wgrad (the last reader of concat's dense columns) and forward
                 # (dense_pad) are behind us on the training stream, which the side stream has waited for
-                nd.record_stream(self.side)
+                nd.record_stream(st)
                 if not self.no_concat:
                     self.concat[:, self.F * self.D:self.F * self.D + self.Nd].copy_(nd)
-                if self.dense_pad is not None:
-                    self.dense_pad[:, :self.Nd].copy_(nd)
+                if self._dense_pads is not None:               # (the buffer the next forward switches to)
+                    self._dense_pads[nxt][:, :self.Nd].copy_(nd)
                     if self.h2:
-                        ops.h2_amax(self.dense_pad, self.dense_amax)
+                        ops.h2_amax(self._dense_pads[nxt], self._dense_amaxs[nxt])
                 self._pref_dense = self._token(nd)
-            if early_done:
-                self._ev_dense[nxt].record(self.side)       # ids and plan were issued at the start of the step: only the dense features here
+            if early_done and getattr(self, "_dense_early", False):
+                self._dense_by_event = True                    # (_ev_dense[nxt] was recorded behind the early copy)
+            elif early_done:
+                self._ev_dense[nxt].record(st)       # ids and plan were issued at the start of the step: only the dense features here
                 self._dense_by_event = True
             else:
                 self._dense_by_event = False
-                self._ev_hashed[nxt].record(self.side)          # what the next forward waits for: ids (+ dense features) in place
+                self._ev_hashed[nxt].record(st)          # what the next forward waits for: ids (+ dense features) in place
                 self._k("next_batch: emb_sort_slots(side stream, overlapped)", "overlap", self.B * self.F * 36,
                         lambda: ops.emb_sort_slots(self._ids[nxt], self.row_base, self.R, self._plans[nxt]))
-                self._ev_sorted[nxt].record(self.side)
+                self._ev_sorted[nxt].record(st)
         self._pref = self._token(nk)
 
     def _prefetch_early(self):
@@ -405,15 +433,36 @@ class DeepFMEngine:
                 self._ev_sorted[nxt].record(self.side)
             self._early_issued = True
             return
+        nd = self._next_dense
+        self._dense_early = (nd is not None and self.Nd and self.no_concat and self._dense_pads is not None and not self.overlap_dw)
+        if self._dense_early:
+            # the next batch's dense features into the OTHER buffer (its last reader was the previous step's wgrad), on the second side
+            # stream, beside the plan's front kernel: in rounds 3 - 5 this copy, a fill and the amax pass waited for THIS step's wgrad --
+            # three more small launches between the wgrad and the next forward, which rocprofv3 showed ending 10 - 20 us after the
+            # step's last kernel.  (In FRONT of the plan chain on `side` they cost it the tower tail's window: 0.990 -> 0.994 ms.)
+            nd.record_stream(self.side_r)
+            with torch.cuda.stream(self.side_r):
+                self.side_r.wait_event(self.ev_fwd0)
+                self._dense_pads[nxt][:, :self.Nd].copy_(nd)
+                if self.h2:
+                    ops.h2_amax(self._dense_pads[nxt], self._dense_amaxs[nxt])
+                self._ev_dense[nxt].record(self.side_r)
         with torch.cuda.stream(self.side):
             self.side.wait_event(self.ev_fwd0)
-            self._k("next_batch: hash_bucket_i64(side stream, overlapped)", "overlap", self.B * self.F * 16,
-                    lambda: ops.hash_bucket_i64(nk, self.col_buckets, out=self._ids[nxt]))
-            if self.no_concat:
-                ops.ids_transpose_i32(self._ids[nxt], out=self._ids_t[nxt])
-            self._ev_hashed[nxt].record(self.side)
-            self._k("next_batch: emb_sort_slots(side stream, overlapped)", "overlap", self.B * self.F * 36,
-                    lambda: ops.emb_sort_slots(self._ids[nxt], self.row_base, self.R, self._plans[nxt]))
+            if self.fuse_plan_front:
+                # K1, the field-major ids and the plan as one chain of 6 launches (round 6: dr_hash_sort_slots; rounds 3 - 5: 27)
+                self._k("next_batch: hash_sort_slots(side stream, overlapped)", "overlap", self.B * self.F * 52,
+                        lambda: ops.hash_sort_slots(nk, self.col_buckets, self.row_base, self.R, self._ids[nxt],
+                                                    self._ids_t[nxt] if self.no_concat else None, self._plans[nxt]))
+                self._ev_hashed[nxt].record(self.side)
+            else:
+                self._k("next_batch: hash_bucket_i64(side stream, overlapped)", "overlap", self.B * self.F * 16,
+                        lambda: ops.hash_bucket_i64(nk, self.col_buckets, out=self._ids[nxt]))
+                if self.no_concat:
+                    ops.ids_transpose_i32(self._ids[nxt], out=self._ids_t[nxt])
+                self._ev_hashed[nxt].record(self.side)
+                self._k("next_batch: emb_sort_slots(side stream, overlapped)", "overlap", self.B * self.F * 36,
+                        lambda: ops.emb_sort_slots(self._ids[nxt], self.row_base, self.R, self._plans[nxt]))
             self._ev_sorted[nxt].record(self.side)
         self._early_issued = True
 
@@ -731,6 +780,7 @@ class DeepFMEngine:
                     # the weight just moved: its planes follow -- on the side stream, beside whatever comes next on this one (the
                     # two split launches are needed only by the next step's forward / dgrad, which wait for ev_planes)
                     self.ev_dw_done.record()
+                    self._refresh_stream = self.side
                     with torch.cuda.stream(self.side):
                         self.side.wait_event(self.ev_dw_done)
                         if self._wgrad_reduce_deferred(i) and self.h2:
@@ -795,16 +845,18 @@ class DeepFMEngine:
         # The weight just moved: its planes follow on the side stream, BESIDE the dgrad, which keeps reading the previous W image and
         # record (H2WeightPlanes(double_buffer=True): the refresh writes the other pair) -- the next forward waits for nothing.
         w_old = self.wplanes[0].w
+        early = self._early_issued
+        rs = self.side_r if early else self.side           # (without the early chain the hash + plan follow on `side`, behind the refresh)
+        self._refresh_stream = rs
         self.ev_dw_done.record()
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(self.ev_dw_done)
+        with torch.cuda.stream(rs):
+            rs.wait_event(self.ev_dw_done)
             self.wplanes[0].refresh()
-            self.ev_planes.record(self.side)
+            self.ev_planes.record(rs)
         self._planes_pending = True
         self._planes_pending_l0 = True
         # the next batch's dense features (and, unless they went out at the start of the step, its hash + plan) behind the refresh: the
         # wgrad was the last reader of dense_pad
-        early = self._early_issued
         mark = self._prefetch_mark()
         if early:
             self._prefetch_issue(mark)

@@ -539,6 +539,22 @@ def emb_sort_slots(ids, row_base, num_rows, plan=None):
     return plan
 
 
+def hash_sort_slots(keys, col_buckets, row_base, num_rows, ids_out, ids_t_out=None, plan=None):
+    """hash_bucket_i64(keys -> ids_out) + ids_transpose_i32(ids_out -> ids_t_out, optional) + emb_sort_slots(ids_out) as one chain whose
+    first kernel does the work of the first four (dr_hash_sort_slots): same outputs, bit for bit."""
+    keys = _c(keys, torch.int64)
+    B, F = keys.shape
+    assert ids_out.shape == (B, F) and ids_out.dtype == torch.int64 and ids_out.is_contiguous()
+    if ids_t_out is not None:
+        assert ids_t_out.shape == (F, B) and ids_t_out.dtype == torch.int32 and ids_t_out.is_contiguous()
+    if plan is None or plan.n < B * F:
+        plan = SortPlan(B * F, keys.device)
+    check(lib().dr_hash_sort_slots(ptr(keys), B, F, ptr(col_buckets), ptr(ids_out), ptr(ids_t_out), ptr(row_base), int(num_rows),
+                                   ptr(plan.rows), ptr(plan.slots), ptr(plan.flags), ptr(plan.dup_heads), ptr(plan.dup_count),
+                                   ptr(plan.workspace), plan.workspace.numel(), stream_ptr()), "dr_hash_sort_slots")
+    return plan
+
+
 def emb_plan_set_small_limit(limit):
     """largest shared-row list the plan's one-block LDS sort takes (0: radix path whenever a row is shared); returns the previous"""
     return int(lib().dr_emb_plan_set_small_limit(int(limit)))

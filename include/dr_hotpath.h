@@ -192,6 +192,16 @@ int dr_emb_sort_slots(const int64_t* ids, int64_t B, int32_t F, const int64_t* r
                       int64_t* sorted_rows, int32_t* sorted_slots, uint8_t* unique_flags,
                       int32_t* dup_heads, int32_t* dup_count, void* workspace, int64_t workspace_bytes,
                       dr_stream_t stream);
+/* Round 6 -- K1, the field-major ids and the slot plan of one batch in ONE chain (the engines' next-batch prefetch):
+ * dr_hash_bucket_i64(keys [B, F], col_buckets -> ids_out [B, F]), dr_ids_transpose_i32(ids_out -> ids_t_out [F, B] int32; ids_t_out may be
+ * NULL) and dr_emb_sort_slots(ids_out, ...), bit for bit, with hash, transpose, composite keys and partition histogram as one kernel when
+ * F <= 64 and the geometry fits the composite key (otherwise the three entry points are called one after the other).  Replaces the same
+ * reference lines as K1 ([TF] categorical_column_with_hash_bucket, examples/train_fm_on_movielens_estimator.py:12-13,20-21) and the
+ * plan (the grouping half of unsorted_segment_sum in the autodiff of keras/models/ranking/fm.py:57-61). */
+int dr_hash_sort_slots(const int64_t* keys, int64_t B, int32_t F, const uint64_t* col_buckets, int64_t* ids_out,
+                       int32_t* ids_t_out, const int64_t* row_base, int64_t num_rows, int64_t* sorted_rows,
+                       int32_t* sorted_slots, uint8_t* unique_flags, int32_t* dup_heads, int32_t* dup_count, void* workspace,
+                       int64_t workspace_bytes, dr_stream_t stream);
 int dr_emb_pool_bwd_sorted(const int64_t* ids, const int64_t* row_base, const int64_t* sorted_rows,
                            const int32_t* sorted_slots, const uint8_t* unique_flags,
                            const int32_t* dup_heads, const int32_t* dup_count, int64_t B, int32_t F,

@@ -770,6 +770,41 @@ def test_slot_plan_large_path_sorts_any_partition(ops, case):
     np.testing.assert_array_equal(np.sort(plan.dup_heads.cpu().numpy()[:nh]), want_heads)
 
 
+@pytest.mark.parametrize("B,F,V,trans", [(65536, 26, 10_000_000, True), (1000, 7, 5000, True), (77, 1, 50, False), (4096, 64, 3000, True),
+                                          (300, 65, 100, True), (130, 3, 1 << 40, True)])
+def test_hash_sort_slots_equals_the_three_calls(ops, B, F, V, trans):
+    """dr_hash_sort_slots (round 6: K1 + field-major ids + composite keys + partition histogram in ONE kernel, then the plan) against
+    dr_hash_bucket_i64 -> dr_ids_transpose_i32 -> dr_emb_sort_slots: ids, ids_t and every plan array bit for bit.  Shapes: the bench's;
+    ragged example groups; one field; the widest fused geometry (F = 64); F = 65 and 2^40 rows (the entry point falls back to the three
+    calls: no fused front / no composite key).  Keys include negatives, -1 (dropped) and a pass-through column."""
+    g = torch.Generator(device="cuda").manual_seed(B + F)
+    keys = torch.randint(-(10**6), 10**15, (B, F), device="cuda", generator=g)
+    keys[torch.rand((B, F), device="cuda", generator=g) < 0.05] = -1
+    buckets = torch.full((F,), V, dtype=torch.int64, device="cuda")
+    if F > 2:
+        buckets[2] = 0                                        # pass-through column: the key is the id
+        keys[:, 2] = torch.randint(0, min(V, 10**6), (B,), device="cuda", generator=g)
+    row_base = (torch.arange(F, dtype=torch.int64, device="cuda") * V)
+    R = F * V
+    ids0 = ops.hash_bucket_i64(keys, buckets)
+    idt0 = ops.ids_transpose_i32(ids0) if trans else None
+    plan0 = ops.emb_sort_slots(ids0, row_base, R)
+    ids1 = torch.full_like(ids0, -7)
+    idt1 = torch.full((F, B), -7, dtype=torch.int32, device="cuda") if trans else None
+    plan1 = ops.hash_sort_slots(keys, buckets, row_base, R, ids1, idt1)
+    torch.cuda.synchronize()
+    assert torch.equal(ids1, ids0)
+    if trans:
+        assert torch.equal(idt1, idt0)
+    L = plan0.sorted_len()
+    assert plan1.sorted_len() == L
+    assert torch.equal(plan1.flags, plan0.flags)
+    assert torch.equal(plan1.rows[:L], plan0.rows[:L]) and torch.equal(plan1.slots[:L], plan0.slots[:L])
+    nh = int(plan0.dup_count[0].item())
+    assert int(plan1.dup_count[0].item()) == nh
+    assert torch.equal(torch.sort(plan1.dup_heads[:nh]).values, torch.sort(plan0.dup_heads[:nh]).values)
+
+
 def test_slot_plan_geometry_beyond_the_composite_key(ops):
     """num_rows >= 2^31 - 1 cannot go through the 31-bit claim tables / the composite key: the host sends such a call to the
     chip-wide radix sort of all slots (the only path that still takes more than one launch per phase)."""
