@@ -1132,7 +1132,14 @@ class ShardedDeepFMEngine:
             if i == 0 and h2:
                 # records of the whole rank batch: x = [received rows, dense features], d h0 = the micro-batches' pieces
                 self._x_record()
-                torch.amax(torch.cat(self.dh0_amax), 0, keepdim=True, out=self.dh0_amax_all)
+                # (float bits of non-negative values order like integers: the batch's record is the integer maximum of the micro-batches';
+                # round 6: M - 1 one-element launches instead of cat + a reduce kernel)
+                if len(self.dh0_amax) == 1:
+                    self.dh0_amax_all.copy_(self.dh0_amax[0])
+                else:
+                    torch.maximum(self.dh0_amax[0], self.dh0_amax[1], out=self.dh0_amax_all)
+                    for r in self.dh0_amax[2:]:
+                        torch.maximum(self.dh0_amax_all, r, out=self.dh0_amax_all)
                 self._k("linear_bwd_dw_L%d" % i, "mfma", 2.0 * B * self.Ws[i].shape[0] * self.Ws[i].shape[1],
                         lambda xin=xin, dyi=dyi, i=i: ops.h2_wgrad(xin, self.x_amax_all, dyi, self.dh0_amax_all, 1.0, self.gWs[i], self.gbs[i],
                                                                    workspace=self.wg_ws[i]))
