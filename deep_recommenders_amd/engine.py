@@ -16,6 +16,19 @@ import torch
 from . import ops
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_streams(device):
+    """The engines' two side streams, ONE pair per device and process: HIP maps streams onto a few hardware queues, and a second engine's
+    streams of its own ended up sharing a queue with the training stream (bench.py's strict-fp32 leg, a second engine in the process:
+    1.63 - 1.67 ms per step against 1.37 with shared streams -- every refresh launch serialised the training stream behind it)."""
+    key = str(torch.device(device))
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+    return _SIDE_STREAMS[key]
+
+
 def _pad4(n):
     return (n + 3) // 4 * 4
 
@@ -256,13 +269,13 @@ class DeepFMEngine:
             # (round 5, measured and rejected: this stream restricted to a subset of the CUs -- hipExtStreamCreateWithCUMask, every 4th /
             # every 8th CU -- so that its ~25 small launches would not spread over the machine beside K4: the step went from 1.19 to
             # 1.75 - 1.85 ms, K4 itself unchanged; profiles/r05_ab_side_stream.log)
-            self.side = torch.cuda.Stream(device=device)
+            self.side, _side_r = _side_streams(device)
             # Round 6: a stream of its own for what must be in place before the NEXT forward (the first layer's plane refresh behind its
             # wgrad, the next batch's dense features).  On `side` these five small launches queued behind the plan chain, whose kernels
             # only get CUs when a GEMM drains (a side kernel's blocks wait for the training stream's kernel to run out of blocks: the
             # chain advances about one kernel per kernel boundary of the step) -- rocprofv3 showed the refresh starting 17 us after the
             # fused dgrad + K4 had ENDED and the next forward waiting 39 us for the dense features' record.  DR_SIDE_R=0: as before.
-            self.side_r = torch.cuda.Stream(device=device) if _os.environ.get("DR_SIDE_R", "1") == "1" else self.side
+            self.side_r = _side_r if _os.environ.get("DR_SIDE_R", "1") == "1" else self.side
             self._refresh_stream = self.side
             self.ev_ids = torch.cuda.Event()
             self._ev_sorted = [torch.cuda.Event(), torch.cuda.Event()]

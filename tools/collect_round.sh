@@ -24,6 +24,13 @@ DR_NO_CONCAT=0 timeout -s KILL 200 python bench.py --no-cpu-baseline > gpurun_ou
 DR_FORCE_SHARDED=1 timeout -s KILL 200 python bench.py --no-cpu-baseline > gpurun_out/line_sharded_world1.log 2>&1
 DR_FORCE_SHARDED=1 timeout -s KILL 300 python bench.py --model dcn --no-cpu-baseline > gpurun_out/line_dcn_sharded_world1.log 2>&1
 DR_PREFETCH_EARLY=0 timeout -s KILL 200 python bench.py --no-cpu-baseline > gpurun_out/line_plan_beside_k4.log 2>&1
+# round 6 (second half): the prefetch chain as rounds 3 - 5 scheduled it (start of the step, K1 / transpose / plan as three calls, one side stream)
+DR_PREFETCH_EARLY=1 DR_FUSE_PLAN_FRONT=0 DR_SIDE_R=0 DR_BENCH_STRICT=0 timeout -s KILL 200 python bench.py --no-cpu-baseline > gpurun_out/line_chain_r5_schedule.log 2>&1
+# what the chain costs the step (tools/exp/exp_plan.sh: the chain not launched at all, timing only), and one step as a timeline
+bash tools/exp/exp_plan.sh > gpurun_out/plan_cost.log 2>&1
+bash tools/exp/timeline_call.sh default bf3_emb_linear_kernel -- > /dev/null 2>&1
+bash tools/exp/timeline_call.sh sharded bf3_gemm_tn_rs_kernel DR_FORCE_SHARDED=1 -- > /dev/null 2>&1
+cd $R
 # round 6: the three-kernel backward of round 5 (dgrad, wgrad, K4) beside the fused default; the 8-wave GEMM kernel everywhere
 DR_FUSE_K4=0 DR_BENCH_STRICT=0 timeout -s KILL 200 python bench.py --no-cpu-baseline > gpurun_out/line_k4_unfused.log 2>&1
 DR_H2_OCC=0 DR_BENCH_STRICT=0 timeout -s KILL 300 python bench.py --model dcn --no-cpu-baseline > gpurun_out/line_dcn_8wave.log 2>&1
@@ -36,7 +43,7 @@ DR_GEMM_SPLIT=bf16x3 timeout -s KILL 200 python bench.py --no-cpu-baseline > gpu
 DR_GEMM_SPLIT=bf16x3 timeout -s KILL 300 python bench.py --model dcn --no-cpu-baseline > gpurun_out/line_dcn_bf16x3.log 2>&1
 DR_GEMM_SPLIT=bf16x3 DR_FORCE_SHARDED=1 timeout -s KILL 200 python bench.py --no-cpu-baseline > gpurun_out/line_sharded_world1_bf16x3.log 2>&1
 timeout -s KILL 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-for f in default adam zipf c2 dcn dssm unfused concat sharded_world1 dcn_sharded_world1 plan_beside_k4 k4_unfused dcn_8wave bf16x3 dcn_bf16x3 sharded_world1_bf16x3; do
+for f in default adam zipf c2 dcn dssm unfused concat sharded_world1 dcn_sharded_world1 plan_beside_k4 chain_r5_schedule k4_unfused dcn_8wave bf16x3 dcn_bf16x3 sharded_world1_bf16x3; do
   python - $f <<'PY'
 import json, sys
 try:
@@ -48,5 +55,5 @@ except Exception as e:
 PY
 done
 # the raw per-dispatch traces are tens of MB (gpurun merges at most 64 MiB back): the summaries above are what profiles/ keeps
-rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc_sq gpurun_out/prof_stats
+rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc_sq gpurun_out/prof_stats gpurun_out/tl_default gpurun_out/tl_sharded
 du -sh gpurun_out
