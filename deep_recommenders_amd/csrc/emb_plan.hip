@@ -98,30 +98,21 @@ __device__ __forceinline__ uint32_t digit_of(uint64_t k, uint32_t shift_or_mul) 
     return d < RADIX - 1 ? d : RADIX - 1;
 }
 
-// ---- the counting-sort pass: keys, per-block histograms, per-digit scan, stable scatter ---------------------------------------------
-// GATED = 0: always runs (the SMALL path's partition pass); 1: only when ctrl->large (the LARGE path)
-// (the SMALL path moves ONE 8-byte word per slot, the composite key row << 24 | slot: n <= 2^24 slots, rows < 2^31.  A scattered
-// store is a partial-line read-modify-write in HBM once the partitions' write frontiers fall out of the L2 -- the first version
-// moved 12 bytes in two stores from 1024 blocks and cost the K4 it runs beside 77 us)
-template <int GATED>
+// ---- the chip-wide LSD radix sort (geometry beyond the composite key): keys, per-block histograms, per-digit scan, stable scatter ----
+// (rounds 3 - 5 also ran these kernels, gated on a device-side switch, behind every SMALL plan: round 6 replaced that use by
+// plan_large_kernel; radix_scan_kernel is shared with the SMALL path's partition pass)
+// keys of the chip-wide sort (geometry beyond the composite key): row per slot, slot number as the payload
 __global__ __launch_bounds__(256) void radix_make_keys_kernel(const int64_t* __restrict__ ids, int32_t n, int32_t F,
                                                               const int64_t* __restrict__ row_base, uint64_t sentinel,
-                                                              uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                              const Ctrl* __restrict__ ctrl) {
-    if (GATED && ctrl->large == 0) return;
+                                                              uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
     const int32_t stride = gridDim.x * blockDim.x;
     for (int32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
         const int64_t id = ids[p];
-        // missing ids sort to the end -- and so does an id beyond the slab (sentinel == num_rows): shifted into the composite key it
-        // would wrap and alias a valid row, which K4 would then update
+        // missing ids sort to the end -- and so does an id beyond the slab (sentinel == num_rows): it would alias a valid row, which
+        // K4 would then update
         const uint64_t r0 = id >= 0 ? (uint64_t)(row_base[p % F] + id) : sentinel;
-        const uint64_t row = r0 < sentinel ? r0 : sentinel;
-        if (GATED) {
-            keys[p] = row;
-            vals[p] = (uint32_t)p;
-        } else {
-            keys[p] = (row << 24) | (uint32_t)p;
-        }
+        keys[p] = r0 < sentinel ? r0 : sentinel;
+        vals[p] = (uint32_t)p;
     }
 }
 
@@ -187,17 +178,15 @@ __global__ __launch_bounds__(256) void plan_front_kernel(const int64_t* __restri
     ghist[t * nb + blockIdx.x] = h[t];
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void radix_hist_kernel(const uint64_t* __restrict__ keys, int32_t n, uint32_t shift_or_mul,
-                                                         uint32_t* __restrict__ ghist, const Ctrl* __restrict__ ctrl) {
-    if (MODE == 0 && ctrl->large == 0) return;
+__global__ __launch_bounds__(256) void radix_hist_kernel(const uint64_t* __restrict__ keys, int32_t n, uint32_t shift,
+                                                         uint32_t* __restrict__ ghist) {
     __shared__ uint32_t h[RADIX];
     const int nb = gridDim.x, t = threadIdx.x;
     const int32_t chunk = (n + nb - 1) / nb;
     const int32_t beg = (int32_t)blockIdx.x * chunk, end = beg + chunk < n ? beg + chunk : n;
     h[t] = 0;
     __syncthreads();
-    for (int32_t i = beg + t; i < end; i += 256) atomicAdd(&h[digit_of<MODE>(keys[i], shift_or_mul)], 1u);
+    for (int32_t i = beg + t; i < end; i += 256) atomicAdd(&h[digit_of<0>(keys[i], shift)], 1u);
     __syncthreads();
     ghist[t * nb + blockIdx.x] = h[t];
 }
@@ -205,13 +194,12 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const uint64_t* __restr
 // One block per digit d: ghist[d][0 .. nb) -> exclusive scan over the blocks (position inside the digit's range); the digit's
 // total goes to tot[d] -- the scatter blocks turn the 256 totals into range starts themselves (an LDS scan), so no block here
 // needs another digit's column and nothing is combined with atomics.
-// GATED = 0 (the SMALL path's partition pass) also zeroes the plan's device-side state, which nothing before the claim kernel
+// ZERO (the SMALL path's partition pass): block 0 also zeroes the plan's device-side state, which nothing before the claim kernel
 // touches (round 6: two hipMemsetAsync launches less on the side stream).
-template <int GATED>
+template <bool ZERO>
 __global__ __launch_bounds__(256) void radix_scan_kernel(uint32_t* __restrict__ ghist, int32_t nb, uint32_t* __restrict__ tot,
                                                          Ctrl* __restrict__ ctrl, int32_t* __restrict__ dup_count) {
-    if (GATED && ctrl->large == 0) return;
-    if (!GATED && blockIdx.x == 0) {
+    if (ZERO && blockIdx.x == 0) {
         int32_t* c = reinterpret_cast<int32_t*>(ctrl);
         for (int i = threadIdx.x; i < (int)(sizeof(Ctrl) / 4); i += 256) c[i] = 0;
         if (threadIdx.x < 2) dup_count[threadIdx.x] = 0;
@@ -243,12 +231,10 @@ __global__ __launch_bounds__(256) void radix_scan_kernel(uint32_t* __restrict__ 
 // stable scatter: block b re-reads its chunk in order, 256 keys at a time; a key's destination = start of its digit's range
 // + the scanned histogram entry of its digit for this block, advanced by the tiles already written + the number of EARLIER keys
 // of the tile with the same digit (wave-level match by eight ballots, earlier waves' counts through LDS).
-template <int MODE>
 __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin,
                                                             uint64_t* __restrict__ kout, uint32_t* __restrict__ vout, int32_t n,
-                                                            uint32_t shift_or_mul, const uint32_t* __restrict__ ghist,
-                                                            const uint32_t* __restrict__ tot, const Ctrl* __restrict__ ctrl) {
-    if (MODE == 0 && ctrl->large == 0) return;
+                                                            uint32_t shift, const uint32_t* __restrict__ ghist,
+                                                            const uint32_t* __restrict__ tot) {
     __shared__ uint32_t running[RADIX];
     __shared__ uint32_t wcnt[4][RADIX];
     const int nb = gridDim.x, t = threadIdx.x, w = t >> 6, lane = t & 63;
@@ -273,8 +259,8 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* __re
         const int32_t i = base + t;
         const bool live = i < end;
         const uint64_t k = live ? kin[i] : 0ull;
-        const uint32_t v = (MODE == 0 && live) ? vin[i] : 0u;
-        const uint32_t d = digit_of<MODE>(k, shift_or_mul);
+        const uint32_t v = live ? vin[i] : 0u;
+        const uint32_t d = digit_of<0>(k, shift);
         wcnt[0][t] = 0; wcnt[1][t] = 0; wcnt[2][t] = 0; wcnt[3][t] = 0;
         __syncthreads();
         uint64_t mask = __ballot(live);                               // lanes with my digit (dead lanes never match)
@@ -296,7 +282,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* __re
         running[t] += wcnt[0][t] + wcnt[1][t] + wcnt[2][t] + wcnt[3][t];
         if (live) {
             kout[pos] = k;
-            if (MODE == 0) vout[pos] = v;
+            vout[pos] = v;
         }
         __syncthreads();
     }
@@ -515,9 +501,7 @@ __global__ __launch_bounds__(256) void plan_bucket_sort_kernel(const uint64_t* _
 // same-address atomic per wave cost 300 us, they retire at ~88 per microsecond).
 __global__ __launch_bounds__(256) void radix_mark_kernel(const uint64_t* __restrict__ rows, const int32_t* __restrict__ slots,
                                                          int32_t n, uint64_t num_rows, uint8_t* __restrict__ flags,
-                                                         int32_t* __restrict__ dup_heads, int32_t* __restrict__ dup_count,
-                                                         const Ctrl* __restrict__ ctrl) {
-    if (ctrl->large == 0) return;
+                                                         int32_t* __restrict__ dup_heads, int32_t* __restrict__ dup_count) {
     __shared__ int32_t hl[MARK_MAX_CHUNK];
     __shared__ int32_t nh, gbase;
     const int t = threadIdx.x, lane = t & 63;
@@ -702,7 +686,7 @@ int plan_small_front(const int64_t* raw, const uint64_t* col_buckets, int64_t* i
         hipLaunchKernelGGL((plan_front_kernel<false, false>), dim3(nbf), dim3(256), lds, s, ids, B, F, col_buckets, ids_out, ids_t, row_base,
                            (uint64_t)num_rows, mul, (int32_t)sub, rows_y, ghist);
     }
-    hipLaunchKernelGGL((radix_scan_kernel<0>), dim3(RADIX), dim3(256), 0, s, ghist, (int32_t)nbf, tot, ctrl, dup_count);
+    hipLaunchKernelGGL((radix_scan_kernel<true>), dim3(RADIX), dim3(256), 0, s, ghist, (int32_t)nbf, tot, ctrl, dup_count);
     hipLaunchKernelGGL(plan_scatter_kernel, dim3(nbs), dim3(LG_T), 0, s, rows_y, keys_x, n, mul, (int32_t)chunk, ghist, (int32_t)nbf, tot);
     return DR_OK;
 }
@@ -762,28 +746,25 @@ int sort_slots_impl(const int64_t* raw, const uint64_t* col_buckets, int32_t* id
         return DR_OK;
     }
     // geometry beyond the composite key: the chip-wide LSD radix sort of all n slots; the final pass must land in the output arrays
-    if (hipMemsetAsync(ctrl, 0, sizeof(Ctrl), s) != hipSuccess) return DR_ELAUNCH;
     if (hipMemsetAsync(dup_count, 0, 2 * sizeof(int32_t), s) != hipSuccess) return DR_ELAUNCH;
-    if (hipMemsetAsync(&ctrl->large, 1, sizeof(int32_t), s) != hipSuccess) return DR_ELAUNCH;
     const unsigned bits = bits_for((uint64_t)num_rows);            // the sentinel == num_rows needs these bits too
     const int passes = (int)((bits + RADIX_BITS - 1) / RADIX_BITS);
     uint64_t* kbuf[2] = {keys_x, rows_y};
     uint32_t* vbuf[2] = {vals_x, slots_y};
     int cur = (passes & 1) ? 0 : 1;                                // passes odd: start in the workspace, end in the outputs
-    hipLaunchKernelGGL((radix_make_keys_kernel<1>), dim3(grid), dim3(256), 0, s, ids, n, F, row_base, (uint64_t)num_rows, kbuf[cur],
-                       vbuf[cur], ctrl);
+    hipLaunchKernelGGL(radix_make_keys_kernel, dim3(grid), dim3(256), 0, s, ids, n, F, row_base, (uint64_t)num_rows, kbuf[cur], vbuf[cur]);
     for (int p = 0; p < passes; ++p) {
         const uint32_t shift = (uint32_t)(p * RADIX_BITS);
-        hipLaunchKernelGGL((radix_hist_kernel<0>), dim3(nb), dim3(256), 0, s, kbuf[cur], n, shift, ghist, ctrl);
-        hipLaunchKernelGGL((radix_scan_kernel<1>), dim3(RADIX), dim3(256), 0, s, ghist, (int32_t)nb, tot, ctrl, dup_count);
-        hipLaunchKernelGGL((radix_scatter_kernel<0>), dim3(nb), dim3(256), 0, s, kbuf[cur], vbuf[cur], kbuf[cur ^ 1], vbuf[cur ^ 1], n,
-                           shift, ghist, tot, ctrl);
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(256), 0, s, kbuf[cur], n, shift, ghist);
+        hipLaunchKernelGGL((radix_scan_kernel<false>), dim3(RADIX), dim3(256), 0, s, ghist, (int32_t)nb, tot, ctrl, dup_count);
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(256), 0, s, kbuf[cur], vbuf[cur], kbuf[cur ^ 1], vbuf[cur ^ 1], n, shift, ghist,
+                           tot);
         cur ^= 1;
     }
     int mark_blocks = MARK_BLOCKS;
     while ((n + mark_blocks - 1) / mark_blocks > MARK_MAX_CHUNK) mark_blocks *= 2;
-    hipLaunchKernelGGL(radix_mark_kernel, dim3(mark_blocks), dim3(256), 0, s, rows_y, sorted_slots, n, (uint64_t)num_rows,
-                       unique_flags, dup_heads, dup_count, ctrl);
+    hipLaunchKernelGGL(radix_mark_kernel, dim3(mark_blocks), dim3(256), 0, s, rows_y, sorted_slots, n, (uint64_t)num_rows, unique_flags, dup_heads,
+                       dup_count);
     DR_CHECK_LAUNCH();
     return DR_OK;
 }
