@@ -177,6 +177,7 @@ class DeepFMEngine:
         self._events = None      # name -> [bound, work, [(start, end), ...]]
         self._ev_every, self._ev_step, self._ev_live = 1, 0, False
         self._ev_pool = []
+        self._ev_only = None
         # ---- deterministic backward: slots sorted by table row on a side stream (depends only on ids) ----
         # Schedule experiments and their outcomes are recorded in DESIGN.md section 3 (sort started with K3 / in the backward /
         # on a high-priority stream, K4 overlapped with the first-layer wgrad, FM gradient folded into the dgrad epilogue):
@@ -480,10 +481,13 @@ class DeepFMEngine:
         self._early_issued = True
 
     # ---- per-kernel HIP events on the launch stream (bench.py's roofline numbers) ----------------------
-    def enable_kernel_events(self, on: bool, every: int = 1):
+    def enable_kernel_events(self, on: bool, every: int = 1, only=None):
         """Per-kernel HIP events on the launch stream.  every = n: only every n-th train_step is bracketed -- two event records per
         kernel are two extra packets per kernel boundary, and at 12 kernels per 1.5 ms step that is no longer free (round 3: 1.56
-        ms with events on every step, 1.48 ms without, same box); bench.py samples every 4th step of the timed region."""
+        ms with events on every step, 1.48 ms without, same box); bench.py samples every 4th step of the timed region.
+        only: names of the kernels to bracket (None = all).  Round 6: with all 9 kernels of the step bracketed, every 4th step, the
+        0.97 ms step read 0.979 - 0.985 (off: 0.967 - 0.968): bench.py brackets only the headline kernel inside its timed region."""
+        self._ev_only = set(only) if only is not None else None
         for rec in (getattr(self, "_events", None) or {}).values():       # the pairs of the previous collection go back to the pool
             self._ev_pool.extend(rec[2])
         self._events = {} if on else None
@@ -499,7 +503,7 @@ class DeepFMEngine:
             self._ev_pool.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
 
     def _k(self, name, bound, work, fn):
-        if self._events is None or not self._ev_live:
+        if self._events is None or not self._ev_live or (self._ev_only is not None and name not in self._ev_only):
             return fn()
         s, e = self._ev_pool.pop() if self._ev_pool else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         s.record()
