@@ -4,8 +4,10 @@
 //
 // Criteo-shaped batches are almost duplicate-free (uniform hashed ids: 99.3 % of the B*F slots are the only slot of their row),
 // so sorting all 1.7 M (row, slot) pairs four digits deep to find 11 K duplicates is the wrong algorithm.  Instead:
-//   SMALL  1. PARTITION  one counting-sort pass (per-block histogram -> scan -> stable scatter, the radix machinery below with the
-//                        digit "row * 256 / num_rows") splits the slots into 256 row-range partitions of ~6.6 K slots.
+//   SMALL  1. PARTITION  one counting-sort pass with the digit "row * 256 / num_rows" splits the slots into 256 row-range partitions
+//                        of ~6.6 K slots: plan_front_kernel (composite keys + per-block digit counts -- and, through
+//                        dr_hash_sort_slots, K1's hash and the field-major int32 ids of the same batch in the same kernel) ->
+//                        radix_scan_kernel -> plan_scatter_kernel (stable, 1024-thread blocks).
 //          2. CLAIM      one block per partition inserts its rows into an open-addressed table IN LDS (32 K entries, ds_cmpst):
 //                        a slot that finds its row already there sets the entry's DUP bit.  A second sweep over the partition
 //                        writes flag[slot] = "DUP bit clear" and collects the shared-row slots (composite key row << 24 | slot)
